@@ -1,0 +1,470 @@
+/*
+ * lash_oracle.c — CPU ORACLE (scalar restatement) of lash's sketching hot path.
+ * TEST INFRASTRUCTURE ONLY: see lash_oracle.h for who may use it and for the pinning status
+ * ("parity unpinned" for the crate-internal rules; XXH3 layer pinned by tests/golden/).
+ *
+ * Reference map (all paths under /root/reference/src):
+ *   filter_out_n ............ utils.rs:33-41
+ *   mask_bits ............... utils.rs:57-64
+ *   per-record k-mer loop ... utils.rs:457-505   (three k regimes: <=14, ==16, 15 & 17..=32)
+ *   add_kmer (HMH/HLL/ULL) .. utils.rs:395-398, 411-413, 427-429
+ *   new / save .............. utils.rs:391-393,400-402 / 407-409,415-417 / 422-425,431-433
+ *   one sketch per file ..... utils.rs:450-509
+ *
+ * The oracle deliberately keeps the reference's *structure* (copy-filter the record, 2-bit pack it
+ * into a second buffer, slide a window, recompute the reverse complement from scratch per k-mer,
+ * apply the sequential register rule), so that it is an independent statement of the result and
+ * not a CPU twin of the GPU kernels (which use funnel-shift windows and OR/max-merge algebra).
+ */
+#include "lash_oracle.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * XXH3, inputs of 4..8 bytes (XXH 0.8 spec; xxhash-rust 0.8.15 implements the same function).
+ * Closed forms per SURVEY.md Appendix C; pinned by tests/golden/xxh3_vectors.json.
+ * ---------------------------------------------------------------------------------------- */
+#define XXH_PRIME64_1 0x9E3779B185EBCA87ULL
+#define XXH_PRIME_MX1 0x165667919E3779F9ULL
+#define XXH_PRIME_MX2 0x9FB21C651E98DF25ULL
+/* little-endian u64 words of the default kSecret at byte offsets 8, 16, 24 */
+#define XXH_SEC8  0x1cad21f72c81017cULL
+#define XXH_SEC16 0xdb979083e96dd4deULL
+#define XXH_SEC24 0x1f67b3b7a4a44072ULL
+
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+static inline uint64_t xxh3_short_seed(uint64_t seed)
+{
+    /* seed ^= (u64)swap32((u32)seed) << 32  (XXH3_len_4to8_64b / _128b) */
+    return seed ^ ((uint64_t)bswap32((uint32_t)seed) << 32);
+}
+
+uint64_t lash_or_xxh3_64_8b(uint64_t v, uint64_t seed)
+{
+    /* XXH3_len_4to8_64b with len == 8: input1 = first 4 bytes, input2 = last 4 bytes */
+    uint64_t s = xxh3_short_seed(seed);
+    uint32_t in1 = (uint32_t)v, in2 = (uint32_t)(v >> 32);
+    uint64_t bitflip = (XXH_SEC8 ^ XXH_SEC16) - s;
+    uint64_t in64 = (uint64_t)in2 + ((uint64_t)in1 << 32);
+    uint64_t h = in64 ^ bitflip;
+    /* XXH3_rrmxmx(h, len = 8) */
+    h ^= rotl64(h, 49) ^ rotl64(h, 24);
+    h *= XXH_PRIME_MX2;
+    h ^= (h >> 35) + 8;
+    h *= XXH_PRIME_MX2;
+    return h ^ (h >> 28);
+}
+
+void lash_or_xxh3_128_4b(uint32_t w, uint64_t seed, uint64_t *lo, uint64_t *hi)
+{
+    /* XXH3_len_4to8_128b with len == 4: input_lo == input_hi == w */
+    uint64_t s = xxh3_short_seed(seed);
+    uint64_t in64 = (uint64_t)w + ((uint64_t)w << 32);
+    uint64_t bitflip = (XXH_SEC16 ^ XXH_SEC24) + s;
+    uint64_t keyed = in64 ^ bitflip;
+    unsigned __int128 m = (unsigned __int128)keyed * (XXH_PRIME64_1 + (4u << 2));
+    uint64_t l = (uint64_t)m, h = (uint64_t)(m >> 64);
+    h += l << 1;
+    l ^= h >> 3;
+    l ^= l >> 35;            /* XXH_xorshift64(l, 35) */
+    l *= XXH_PRIME_MX2;
+    l ^= l >> 28;            /* XXH_xorshift64(l, 28) */
+    h ^= h >> 37;            /* XXH3_avalanche(h) */
+    h *= XXH_PRIME_MX1;
+    h ^= h >> 32;
+    *lo = l;
+    *hi = h;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * utils.rs:33-41 / 57-64
+ * ---------------------------------------------------------------------------------------- */
+size_t lash_or_filter_out_n(const uint8_t *seq, size_t n, uint8_t *out)
+{
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t c = seq[i];
+        if (c == 'A' || c == 'C' || c == 'T' || c == 'G') out[m++] = c;   /* upper-case only */
+    }
+    return m;
+}
+
+uint64_t lash_or_mask_bits(uint64_t v, int k)
+{
+    unsigned b = 2u * (unsigned)k;
+    if (b == 64) return v;
+    return v & ((1ULL << b) - 1);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * kmerutils 0.0.14 restated [UNPINNED, switch U5]: Alphabet2b A=0 C=1 G=2 T=3; Sequence::new(.,2)
+ * packs 4 bases per byte; k-mers are built by shift-left-and-OR (first base most significant);
+ * reverse_complement = reverse the 2-bit groups, complement (3-b), right-align to 2k bits;
+ * Ord compares the packed value.  All of U5 lives in base_code(), kseq_*() and revcomp().
+ * ---------------------------------------------------------------------------------------- */
+static inline unsigned base_code(uint8_t c)
+{
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; default: return 3; /* 'T' */ }
+}
+
+typedef struct { uint8_t *bytes; size_t n_bases; } kseq_t;   /* KSeq::new(&seq, 2) */
+
+static void kseq_pack(kseq_t *ks, const uint8_t *filtered, size_t n)
+{
+    ks->n_bases = n;
+    ks->bytes = (uint8_t *)calloc((n + 3) / 4 + 1, 1);
+    for (size_t i = 0; i < n; i++)
+        ks->bytes[i >> 2] |= (uint8_t)(base_code(filtered[i]) << (6 - 2 * (i & 3)));
+}
+static inline unsigned kseq_get(const kseq_t *ks, size_t i)
+{
+    return (ks->bytes[i >> 2] >> (6 - 2 * (i & 3))) & 3u;
+}
+
+static inline uint64_t revcomp(uint64_t v, int k)
+{
+    /* complement every 2-bit group, reverse group order inside the 64-bit word, right-align */
+    uint64_t x = ~v;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    return x >> (64 - 2 * k);
+}
+
+typedef void (*kmer_sink)(void *ctx, uint64_t masked);
+
+/* The `while let Some(km) = it.next()` loops, utils.rs:469-476 / 481-488 / 493-498.
+ * The three container types differ only in width; min() and mask_bits() see the same numbers
+ * (Kmer32bit's 4-bit length tag is equal on both sides of min() and removed by mask_bits). */
+static uint64_t iterate_kmers(const kseq_t *ks, int k, kmer_sink sink, void *ctx, uint64_t *out)
+{
+    size_t L = ks->n_bases;
+    if (L < (size_t)k) return 0;
+    uint64_t kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    uint64_t fwd = 0, count = 0;
+    for (size_t i = 0; i < L; i++) {
+        fwd = ((fwd << 2) | kseq_get(ks, i)) & kmask;           /* iterator advance */
+        if (i + 1 < (size_t)k) continue;
+        uint64_t rc = revcomp(fwd, k);                           /* km.reverse_complement() */
+        uint64_t canon = fwd < rc ? fwd : rc;                    /* km.min(rc) */
+        uint64_t masked;
+        if (k <= 14 || k == 16)                                  /* u32 containers (utils.rs:471-474,483-486) */
+            masked = lash_or_mask_bits((uint64_t)(uint32_t)canon, k);
+        else                                                     /* Kmer64bit (utils.rs:495-496) */
+            masked = lash_or_mask_bits(canon, k);
+        if (sink) sink(ctx, masked);
+        if (out) out[count] = masked;
+        count++;
+    }
+    return count;
+}
+
+uint64_t lash_or_record_kmers(const uint8_t *seq, size_t n, int k, uint64_t *out)
+{
+    if (k < 1 || k > 32) return 0;
+    uint8_t *filt = (uint8_t *)malloc(n + 1);
+    size_t m = lash_or_filter_out_n(seq, n, filt);                /* utils.rs:459 */
+    uint64_t cnt = 0;
+    if (m >= (size_t)k) {                                        /* utils.rs:460-462 */
+        kseq_t ks;
+        kseq_pack(&ks, filt, m);                                 /* utils.rs:464 */
+        cnt = iterate_kmers(&ks, k, NULL, NULL, out);
+        free(ks.bytes);
+    }
+    free(filt);
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Sketch states and the three add_kmer rules.
+ * ---------------------------------------------------------------------------------------- */
+#define HMH_P 14
+#define HMH_M (1u << HMH_P)
+#define HMH_R 10
+
+typedef struct {
+    int algo, p;
+    uint64_t seed;
+    int hmh_x_is_low;
+    uint16_t *hmh;     /* hyperminhash::Sketch: 16384 x u16            [UNPINNED, A.2] */
+    uint8_t *reg;      /* HLL m[] / ULL state[]: 2^p x u8              [UNPINNED, A.3/A.4] */
+    uint64_t hll_zero; /* streaming_algorithms HyperLogLog.zero        */
+    double hll_sum;    /* streaming_algorithms HyperLogLog.sum         */
+} sketch_t;
+
+/* hyperminhash add_hash(x, y)  [UNPINNED, A.2; axiomhq/hyperminhash AddHash] */
+static inline void hmh_add_hash(uint16_t *regs, uint64_t x, uint64_t y)
+{
+    uint32_t bucket = (uint32_t)(x >> (64 - HMH_P));
+    uint32_t lz = (uint32_t)__builtin_clzll((x << HMH_P) ^ 0x3FFFULL) + 1;   /* 1..=51 */
+    uint16_t sig = (uint16_t)(y & ((1u << HMH_R) - 1));
+    uint16_t reg = (uint16_t)((lz << HMH_R) | sig);
+    if (regs[bucket] < reg) regs[bucket] = reg;
+}
+
+/* utils.rs:395-398 -> Sketch::add_bytes_with_seed(&(masked as u32).to_le_bytes(), seed) */
+static void hmh_add_kmer(void *ctx, uint64_t masked)
+{
+    sketch_t *s = (sketch_t *)ctx;
+    uint64_t lo, hi;
+    lash_or_xxh3_128_4b((uint32_t)masked, s->seed, &lo, &hi);
+    if (s->hmh_x_is_low) hmh_add_hash(s->hmh, lo, hi);           /* switch U1 */
+    else                 hmh_add_hash(s->hmh, hi, lo);
+}
+
+static inline double pow2_neg(unsigned e)
+{
+    /* 2^-e exactly (the crate's f64 bit-hack produces the same value) */
+    uint64_t bits = (uint64_t)(1023 - e) << 52;
+    double d;
+    memcpy(&d, &bits, 8);
+    return d;
+}
+
+/* utils.rs:411-413 -> push_hash64(xxh3_64_with_seed(&masked.to_le_bytes(), seed))
+ * [UNPINNED, A.3: bucket = LOW p bits, rho from the remaining 64-p bits; zero/sum kept incrementally] */
+static void hll_add_kmer(void *ctx, uint64_t masked)
+{
+    sketch_t *s = (sketch_t *)ctx;
+    uint64_t x = lash_or_xxh3_64_8b(masked, s->seed);
+    uint64_t j = x & ((1ULL << s->p) - 1);
+    uint64_t w = x >> s->p;
+    unsigned bitlen = w ? 64u - (unsigned)__builtin_clzll(w) : 0u;
+    uint8_t rho = (uint8_t)((64 - s->p) - bitlen + 1);           /* 1..=65-p */
+    uint8_t old = s->reg[j];
+    uint8_t neu = old > rho ? old : rho;
+    s->hll_zero -= (old == 0);
+    s->hll_sum -= pow2_neg(old);
+    s->hll_sum += pow2_neg(neu);
+    s->reg[j] = neu;
+}
+
+/* hash4j UltraLogLog pack/unpack, as ported by crate ultraloglog [UNPINNED, A.4] */
+static inline uint64_t ull_unpack(uint8_t r)
+{
+    if (r < 8) return 0;   /* only r == 0 occurs below 4(p-1) >= 8; Java's mod-64 shift gives 0 for r == 0 */
+    return (4ULL | (r & 3u)) << ((r >> 2) - 2);
+}
+static inline uint8_t ull_pack(uint64_t x)
+{
+    unsigned nlz1 = (unsigned)__builtin_clzll(x) + 1;            /* x != 0 */
+    uint64_t below = (nlz1 >= 64) ? 0 : (x << nlz1) >> 62;
+    return (uint8_t)((((64u - nlz1) & 63u) << 2) | (unsigned)below);
+}
+
+/* utils.rs:427-429 -> UltraLogLog::add(xxh3_64_with_seed(&masked.to_le_bytes(), seed)) */
+static void ull_add_kmer(void *ctx, uint64_t masked)
+{
+    sketch_t *s = (sketch_t *)ctx;
+    uint64_t h = lash_or_xxh3_64_8b(masked, s->seed);
+    int p = s->p, q = 64 - p;
+    uint64_t idx = h >> q;
+    uint64_t t = ~(~h << p);                                      /* low p bits all ones => nlz <= q */
+    unsigned nlz = (unsigned)__builtin_clzll(t);
+    uint64_t prefix = ull_unpack(s->reg[idx]);
+    prefix |= 1ULL << (nlz + (unsigned)p - 1);
+    s->reg[idx] = ull_pack(prefix);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * new() and save()  (byte images).  Each layout is isolated in one function (switches U2-U4).
+ * ---------------------------------------------------------------------------------------- */
+static int check_params(int algo, int k, int p)
+{
+    if (k < 1 || k > 32) return -1;                              /* utils.rs:500-502 */
+    if (algo == LASH_OR_HMH) return 0;                           /* precision ignored, main.rs:212-213 */
+    if (algo == LASH_OR_HLL) return (p >= 4 && p <= 16) ? 0 : -1;  /* get_alpha assert [UNPINNED] */
+    if (algo == LASH_OR_ULL) return (p >= 3 && p <= 26) ? 0 : -1;  /* UltraLogLog::new range [UNPINNED] */
+    return -1;                                                   /* main.rs:245 */
+}
+
+size_t lash_or_image_bytes(int algo, int p)
+{
+    switch (algo) {
+    case LASH_OR_HMH: return (size_t)HMH_M * 2;                   /* U2: 16384 x u16 LE, no header */
+    case LASH_OR_HLL: return 33 + ((size_t)1 << p);               /* U3: bincode(alpha,zero,sum,p,len,m) */
+    case LASH_OR_ULL: return 8 + ((size_t)1 << p);                /* U4: bincode(Vec<u8>) = u64 len + bytes */
+    default: return 0;
+    }
+}
+
+static void put_u64(uint8_t *dst, uint64_t v) { for (int i = 0; i < 8; i++) dst[i] = (uint8_t)(v >> (8 * i)); }
+static void put_f64(uint8_t *dst, double d) { uint64_t b; memcpy(&b, &d, 8); put_u64(dst, b); }
+static uint64_t get_u64(const uint8_t *src) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)src[i] << (8 * i); return v; }
+
+static double hll_alpha(int p)
+{
+    switch (p) { case 4: return 0.673; case 5: return 0.697; case 6: return 0.709;
+    default: return 0.7213 / (1.0 + 1.079 / (double)(1u << p)); }
+}
+
+static void hmh_save(const uint16_t *regs, uint8_t *image)       /* U2 */
+{
+    for (uint32_t i = 0; i < HMH_M; i++) { image[2 * i] = (uint8_t)regs[i]; image[2 * i + 1] = (uint8_t)(regs[i] >> 8); }
+}
+static void hll_save(int p, const uint8_t *m, uint64_t zero, double sum, uint8_t *image)   /* U3 */
+{
+    size_t n = (size_t)1 << p;
+    put_f64(image + 0, hll_alpha(p));
+    put_u64(image + 8, zero);
+    put_f64(image + 16, sum);
+    image[24] = (uint8_t)p;
+    put_u64(image + 25, (uint64_t)n);
+    memcpy(image + 33, m, n);
+}
+static void ull_save(int p, const uint8_t *state, uint8_t *image)   /* U4 */
+{
+    size_t n = (size_t)1 << p;
+    put_u64(image, (uint64_t)n);
+    memcpy(image + 8, state, n);
+}
+
+static int sketch_new(sketch_t *s, const lash_or_params *prm)
+{
+    memset(s, 0, sizeof *s);
+    s->algo = prm->algo; s->p = prm->p; s->seed = prm->seed; s->hmh_x_is_low = prm->hmh_x_is_low;
+    if (prm->algo == LASH_OR_HMH) {
+        s->hmh = (uint16_t *)calloc(HMH_M, 2);                    /* Sketch::default() */
+    } else {
+        size_t n = (size_t)1 << prm->p;
+        s->reg = (uint8_t *)calloc(n, 1);
+        s->hll_zero = n;                                          /* with_p: zero = m, sum = m */
+        s->hll_sum = (double)n;
+    }
+    return 0;
+}
+static void sketch_free(sketch_t *s) { free(s->hmh); free(s->reg); }
+
+int lash_or_sketch_genome(const lash_or_params *prm, const uint8_t *seq,
+                          const uint64_t *rec_off, uint64_t n_rec, uint8_t *image)
+{
+    if (check_params(prm->algo, prm->k, prm->p)) return -1;
+    sketch_t s;
+    sketch_new(&s, prm);                                         /* utils.rs:454 */
+    kmer_sink sink = prm->algo == LASH_OR_HMH ? hmh_add_kmer : prm->algo == LASH_OR_HLL ? hll_add_kmer : ull_add_kmer;
+    for (uint64_t r = 0; r < n_rec; r++) {                       /* utils.rs:457 */
+        const uint8_t *rec = seq + rec_off[r];
+        size_t n = (size_t)(rec_off[r + 1] - rec_off[r]);
+        uint8_t *filt = (uint8_t *)malloc(n + 1);
+        size_t m = lash_or_filter_out_n(rec, n, filt);            /* utils.rs:459 */
+        if (m >= (size_t)prm->k) {                               /* utils.rs:460-462 */
+            kseq_t ks;
+            kseq_pack(&ks, filt, m);                             /* utils.rs:464 */
+            iterate_kmers(&ks, prm->k, sink, &s, NULL);
+            free(ks.bytes);
+        }
+        free(filt);
+    }
+    if (prm->algo == LASH_OR_HMH) hmh_save(s.hmh, image);
+    else if (prm->algo == LASH_OR_HLL) hll_save(s.p, s.reg, s.hll_zero, s.hll_sum, image);
+    else ull_save(s.p, s.reg, image);
+    sketch_free(&s);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * files.par_iter() — one task per genome, dynamic scheduling (utils.rs:450-452)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const lash_or_params *prm; const uint8_t *seq; const uint64_t *rec_off, *genome_rec_off;
+    uint32_t n_genomes; uint8_t *images; size_t image_bytes; volatile uint32_t *next; int err;
+} mt_job;
+
+static void *mt_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    for (;;) {
+        uint32_t g = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (g >= j->n_genomes) break;
+        uint64_t r0 = j->genome_rec_off[g], r1 = j->genome_rec_off[g + 1];
+        if (lash_or_sketch_genome(j->prm, j->seq, j->rec_off + r0, r1 - r0, j->images + (size_t)g * j->image_bytes))
+            j->err = -1;
+    }
+    return NULL;
+}
+
+int lash_or_sketch_genomes(const lash_or_params *prm, const uint8_t *seq, const uint64_t *rec_off,
+                           const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *images, int threads)
+{
+    if (check_params(prm->algo, prm->k, prm->p)) return -1;
+    if (threads < 1) threads = 1;
+    volatile uint32_t next = 0;
+    mt_job job = { prm, seq, rec_off, genome_rec_off, n_genomes, images, lash_or_image_bytes(prm->algo, prm->p), &next, 0 };
+    if (threads == 1) { mt_worker(&job); return job.err; }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)threads);
+    for (int t = 0; t < threads; t++) { jobs[t] = job; pthread_create(&th[t], NULL, mt_worker, &jobs[t]); }
+    int err = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); err |= jobs[t].err; }
+    free(th); free(jobs);
+    return err;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Union of serialized sketches (dist side: utils.rs:171 Sketch::union, :261 UltraLogLog::merge,
+ * :357 HyperLogLog::union) — used by tests of the on-device merge.
+ * ---------------------------------------------------------------------------------------- */
+int lash_or_merge_images(int algo, int p, const uint8_t *a, const uint8_t *b, uint8_t *out)
+{
+    if (algo == LASH_OR_HMH) {
+        for (uint32_t i = 0; i < HMH_M; i++) {
+            uint16_t x = (uint16_t)(a[2 * i] | (a[2 * i + 1] << 8)), y = (uint16_t)(b[2 * i] | (b[2 * i + 1] << 8));
+            uint16_t m = x > y ? x : y;
+            out[2 * i] = (uint8_t)m; out[2 * i + 1] = (uint8_t)(m >> 8);
+        }
+        return 0;
+    }
+    size_t n = (size_t)1 << p;
+    if (algo == LASH_OR_HLL) {
+        if (a[24] != p || b[24] != p || get_u64(a + 25) != n || get_u64(b + 25) != n) return -1;
+        uint8_t *m = (uint8_t *)malloc(n);
+        uint64_t zero = 0; double sum = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            m[i] = a[33 + i] > b[33 + i] ? a[33 + i] : b[33 + i];
+            zero += (m[i] == 0);
+            sum += pow2_neg(m[i]);
+        }
+        hll_save(p, m, zero, sum, out);
+        free(m);
+        return 0;
+    }
+    if (algo == LASH_OR_ULL) {
+        if (get_u64(a) != n || get_u64(b) != n) return -1;
+        put_u64(out, (uint64_t)n);
+        for (size_t i = 0; i < n; i++) {
+            uint8_t x = a[8 + i], y = b[8 + i];
+            if (x == 0) out[8 + i] = y;
+            else if (y == 0) out[8 + i] = x;
+            else out[8 + i] = ull_pack(ull_unpack(x) | ull_unpack(y));
+        }
+        return 0;
+    }
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic genomes: base i of genome g = 2 bits of a splitmix64 stream.
+ * ---------------------------------------------------------------------------------------- */
+#define SYNTH_SEED 20260128ULL
+#define GOLDEN 0x9E3779B97F4A7C15ULL
+static inline uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + GOLDEN;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+void lash_or_synth_genome(uint64_t genome, uint64_t n_bases, uint8_t *out_ascii)
+{
+    static const char acgt[4] = { 'A', 'C', 'G', 'T' };
+    uint64_t base = SYNTH_SEED ^ (genome * GOLDEN);
+    for (uint64_t i = 0; i < n_bases; i += 32) {
+        uint64_t w = splitmix64(base + (i >> 5));
+        uint64_t lim = n_bases - i < 32 ? n_bases - i : 32;
+        for (uint64_t j = 0; j < lim; j++) out_ascii[i + j] = (uint8_t)acgt[(w >> (2 * j)) & 3];
+    }
+}

@@ -1,0 +1,78 @@
+/*
+ * lash_oracle.h — CPU ORACLE for the lash sketching hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a scalar C restatement of the reference algorithm
+ * (/root/reference/src/utils.rs:33-41, 57-64, 377-434, 439-510, 567-574) and of the
+ * crate-internal rules it calls into.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load it; the product library (liblash_gfx950.so)
+ * never links, dlopens or calls anything in this directory.
+ *
+ * PINNING STATUS (see DESIGN.md "Oracle"):
+ *   - XXH3 layer (xxh3_64 of 8 bytes, xxh3_128 of 4 bytes, seeded): PINNED against
+ *     libxxhash 0.8.2 via python-xxhash golden vectors committed in tests/golden/.
+ *   - kmerutils / hyperminhash / streaming_algorithms / ultraloglog crate rules and
+ *     the three `save` byte layouts: PARITY UNPINNED.  The crates are un-vendored
+ *     third-party dependencies (Cargo.lock:713,917,1834,2012), no Rust toolchain exists
+ *     in this image, and the reference ships no tests or golden vectors.  They are
+ *     restated from the published algorithms (axiomhq/hyperminhash, HLL of Flajolet
+ *     et al. as in alecmocatta/streaming_algorithms, hash4j UltraLogLog) and every
+ *     unverified choice sits behind exactly one function or switch in lash_oracle.c.
+ */
+#ifndef LASH_ORACLE_H
+#define LASH_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { LASH_OR_HMH = 0, LASH_OR_HLL = 1, LASH_OR_ULL = 2 };
+
+typedef struct {
+    int algo;            /* LASH_OR_HMH / HLL / ULL   (main.rs:210-246)              */
+    int k;               /* 1..=32                    (utils.rs:466-502)             */
+    int p;               /* HLL 4..=16, ULL 3..=26; ignored for HMH (main.rs:212-213) */
+    uint64_t seed;       /* -s, default 42            (main.rs:88-95)                */
+    int hmh_x_is_low;    /* switch U1: 0 => x = high64(xxh3_128), y = low64 */
+} lash_or_params;
+
+/* XXH3 short-input closed forms (utils.rs:412,428 and inside hyperminhash for :397). */
+uint64_t lash_or_xxh3_64_8b(uint64_t v, uint64_t seed);
+void     lash_or_xxh3_128_4b(uint32_t w, uint64_t seed, uint64_t *lo, uint64_t *hi);
+
+/* utils.rs:33-41 — returns number of bytes kept. `out` must hold n bytes. */
+size_t   lash_or_filter_out_n(const uint8_t *seq, size_t n, uint8_t *out);
+/* utils.rs:57-64 */
+uint64_t lash_or_mask_bits(uint64_t v, int k);
+
+/* Masked canonical k-mers of ONE record, in iterator order (utils.rs:459-499).
+ * Returns the count (0 if fewer than k bases survive the filter). `out` may be NULL. */
+uint64_t lash_or_record_kmers(const uint8_t *seq, size_t n, int k, uint64_t *out);
+
+/* Size in bytes of one serialized sketch (what S::save writes, utils.rs:400-402,415-417,431-433). */
+size_t   lash_or_image_bytes(int algo, int p);
+
+/* One file == one sketch (utils.rs:452-508): all records of one genome -> one image.
+ * rec_off has n_rec+1 byte offsets into seq.  Returns 0 or a negative error. */
+int      lash_or_sketch_genome(const lash_or_params *prm, const uint8_t *seq,
+                               const uint64_t *rec_off, uint64_t n_rec, uint8_t *image);
+
+/* files.par_iter().map(...).collect() (utils.rs:450-452,507-509): one task per genome,
+ * dynamic scheduling over `threads` OS threads; images written in genome order. */
+int      lash_or_sketch_genomes(const lash_or_params *prm, const uint8_t *seq,
+                                const uint64_t *rec_off, const uint64_t *genome_rec_off,
+                                uint32_t n_genomes, uint8_t *images, int threads);
+
+/* Union of two serialized sketches of the same algo/p, as the dist side would form it
+ * (hyperminhash union = max, HLL union = max + recomputed zero/sum,
+ * UltraLogLog::merge = pack(unpack|unpack)).  utils.rs:171,261,357. */
+int      lash_or_merge_images(int algo, int p, const uint8_t *a, const uint8_t *b, uint8_t *out);
+
+/* Synthetic genome generator of SURVEY.md §8(d): base i of genome g. */
+void     lash_or_synth_genome(uint64_t genome, uint64_t n_bases, uint8_t *out_ascii);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

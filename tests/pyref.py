@@ -1,0 +1,136 @@
+"""Naive pure-Python restatement of the reference hot path, for SMALL cases only.
+
+Independent of oracle/lash_oracle.c in style: every k-mer is packed from scratch from the filtered
+string, the reverse complement is built by string reversal, registers are updated one k-mer at a
+time.  Reference lines: utils.rs:33-41 (filter), 57-64 (mask), 457-505 (loops), 395-429 (add_kmer).
+"""
+import struct
+
+M64 = (1 << 64) - 1
+CODE = {"A": 0, "C": 1, "G": 2, "T": 3}
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+P64_1 = 0x9E3779B185EBCA87
+MX1 = 0x165667919E3779F9
+MX2 = 0x9FB21C651E98DF25
+SEC8, SEC16, SEC24 = 0x1CAD21F72C81017C, 0xDB979083E96DD4DE, 0x1F67B3B7A4A44072
+
+
+def _rotl(x, r):
+    return ((x << r) | (x >> (64 - r))) & M64
+
+
+def _short_seed(seed):
+    lo = seed & 0xFFFFFFFF
+    return seed ^ (int.from_bytes(lo.to_bytes(4, "little"), "big") << 32)
+
+
+def xxh3_64_8b(v, seed):
+    s = _short_seed(seed)
+    bitflip = ((SEC8 ^ SEC16) - s) & M64
+    keyed = (((v >> 32) | ((v & 0xFFFFFFFF) << 32)) ^ bitflip) & M64
+    h = keyed
+    h ^= _rotl(h, 49) ^ _rotl(h, 24)
+    h = (h * MX2) & M64
+    h ^= ((h >> 35) + 8)
+    h = (h * MX2) & M64
+    return h ^ (h >> 28)
+
+
+def xxh3_128_4b(w, seed):
+    s = _short_seed(seed)
+    bitflip = ((SEC16 ^ SEC24) + s) & M64
+    keyed = ((w | (w << 32)) ^ bitflip) & M64
+    m = keyed * ((P64_1 + 16) & M64)
+    lo, hi = m & M64, (m >> 64) & M64
+    hi = (hi + ((lo << 1) & M64)) & M64
+    lo ^= hi >> 3
+    lo ^= lo >> 35
+    lo = (lo * MX2) & M64
+    lo ^= lo >> 28
+    hi ^= hi >> 37
+    hi = (hi * MX1) & M64
+    hi ^= hi >> 32
+    return lo, hi
+
+
+def filter_out_n(seq: str) -> str:
+    return "".join(c for c in seq if c in "ACGT")
+
+
+def pack(kmer: str) -> int:
+    v = 0
+    for c in kmer:
+        v = (v << 2) | CODE[c]
+    return v
+
+
+def canonical_kmers(record: str, k: int):
+    s = filter_out_n(record)
+    if len(s) < k:
+        return []
+    out = []
+    for i in range(len(s) - k + 1):
+        km = s[i:i + k]
+        rc = "".join(COMP[c] for c in reversed(km))
+        canon = min(pack(km), pack(rc))
+        if k <= 14 or k == 16:
+            canon &= 0xFFFFFFFF
+        if 2 * k < 64:
+            canon &= (1 << (2 * k)) - 1
+        out.append(canon)
+    return out
+
+
+def clz64(x):
+    return 64 - x.bit_length()
+
+
+def hmh_sketch(records, k, seed, x_is_low=False):
+    regs = [0] * 16384
+    for rec in records:
+        for km in canonical_kmers(rec, k):
+            lo, hi = xxh3_128_4b(km & 0xFFFFFFFF, seed)
+            x, y = (lo, hi) if x_is_low else (hi, lo)
+            bucket = x >> 50
+            lz = clz64(((x << 14) & M64) ^ 0x3FFF) + 1
+            reg = (lz << 10) | (y & 0x3FF)
+            if regs[bucket] < reg:
+                regs[bucket] = reg
+    return b"".join(struct.pack("<H", r) for r in regs)
+
+
+def hll_sketch(records, k, p, seed):
+    m = [0] * (1 << p)
+    for rec in records:
+        for km in canonical_kmers(rec, k):
+            x = xxh3_64_8b(km, seed)
+            j = x & ((1 << p) - 1)
+            w = x >> p
+            rho = (64 - p) - w.bit_length() + 1
+            m[j] = max(m[j], rho)
+    zero = sum(1 for r in m if r == 0)
+    tot = sum(2.0 ** (-r) for r in m)
+    alpha = {4: 0.673, 5: 0.697, 6: 0.709}.get(p, 0.7213 / (1.0 + 1.079 / (1 << p)))
+    return struct.pack("<dQdBQ", alpha, zero, tot, p, 1 << p) + bytes(m)
+
+
+def ull_unpack(r):
+    return 0 if r == 0 else (4 | (r & 3)) << ((r >> 2) - 2)
+
+
+def ull_pack(x):
+    top = x.bit_length() - 1
+    return (top << 2) | ((x >> (top - 2)) & 3 if top >= 2 else (x << (2 - top)) & 3)
+
+
+def ull_sketch(records, k, p, seed):
+    st = [0] * (1 << p)
+    for rec in records:
+        for km in canonical_kmers(rec, k):
+            h = xxh3_64_8b(km, seed)
+            idx = h >> (64 - p)
+            t = (~((~h & M64) << p)) & M64
+            nlz = clz64(t)
+            st[idx] = ull_pack(ull_unpack(st[idx]) | (1 << (nlz + p - 1)))
+    return struct.pack("<Q", 1 << p) + bytes(st)
