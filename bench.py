@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — k-mers/s sketched on MI355X, BASELINE.json's metric on its configs[1] workload.
+
+One step = one pass of the hot path (pack -> sketch -> finalize, i.e. the body of the reference's
+files.par_iter().map(...) at utils.rs:450-509) over one batch of synthetic genomes whose ASCII records are already
+resident in HBM; the images `S::save` would write stay in HBM.  Default workload: 1 000 synthetic 5 Mbp genomes per
+GPU, -a hmh -k 16, seed 42 (SURVEY.md §8(d) generator).  Genomes shard across ranks with no data-path collective
+(weak scaling: every rank sketches its own 1 000 genomes).
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement" for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_genome(L, image_bytes):
+    """packed 2-bit input + the sketch image, per genome of L surviving bases."""
+    return (L + 3) // 4 + image_bytes
+
+
+def cpu_baseline(algo, k, p, seed, L, target_s):
+    """Times the CPU oracle (a port: the Rust reference cannot be built here) with the reference's parallel
+    structure — one task per genome over all host cores (utils.rs:450-452) — on a bounded sample of the same
+    synthetic workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    n = cores * 2
+    gen0 = 10_000_000                     # genome ids disjoint from the GPU workload
+    seqs = np.concatenate([O.synth_genome(gen0 + g, L) for g in range(n)])
+    rec_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
+    goff = np.arange(n + 1, dtype=np.uint64)
+    algo_id = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}[algo]
+    done, elapsed = 0, 0.0
+    while elapsed < target_s:
+        t0 = time.perf_counter()
+        O.sketch_genomes(algo_id, k, p, seed, seqs, rec_off, goff, threads=cores)
+        elapsed += time.perf_counter() - t0
+        done += n
+    kmers = done * (L - k + 1)
+    return {"value": kmers / elapsed, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": "%d synthetic %d-bp genomes, %s k=%d, in-memory sequences (no FASTA parse), %.1f s of CPU work; "
+                      "oracle/lash_oracle.c compiled -O3 for baseline x86-64, one task per genome over %d threads"
+                      % (done, L, algo, k, elapsed, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU (weak scaling)")
+    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--algo", default="hmh")
+    ap.add_argument("-k", type=int, default=16)
+    ap.add_argument("-p", type=int, default=14)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import lash_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+    dev = torch.device("cuda", local_rank)
+
+    algo, k, p, seed, L, G = args.algo, args.k, args.p if args.algo != "hmh" else 0, args.seed, args.length, args.genomes
+    ib = lash_amd.image_bytes(algo, p)
+    stream = torch.cuda.current_stream()
+    ctx = lash_amd.Context(local_rank, stream=stream)     # raises without GPU / library: no fallback
+
+    # ---- synthetic input, generated in HBM (the same generator as oracle/lash_oracle.c) ----
+    d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
+    first = rank * G
+    ctx.synth_genomes_device(first, G, L, d_seq)
+    rec_off = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)        # one record per genome
+    goff = np.arange(G + 1, dtype=np.uint64)
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+    d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ctx.enable_timing(True)                   # HIP events on the stream the kernels run on
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kmers_per_genome = L - k + 1
+    kmers_step_rank = G * kmers_per_genome
+    assert tm["kmers"] == kmers_step_rank * args.steps, "device k-mer census disagrees with the workload"
+    total_kmers = kmers_step_rank * world * args.steps
+    value = total_kmers / elapsed
+
+    out = None
+    if rank == 0:
+        sketch_ms = tm["sketch_ms"] / max(tm["calls"], 1)
+        alg_bytes = G * algorithmic_bytes_per_genome(L, ib)
+        achieved = alg_bytes / (sketch_ms * 1e-3) / 1e9 if sketch_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per sketch launch, if collected
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "%s_k%d_p%d_g%d_l%d" % (algo, k, p, G, L)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "k-mers/s sketched (%s, k=%d)" % (algo, k), "value": value, "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if algo != "hmh" else "u32/u64",
+            "data": "synthetic",
+            "config": {"workload": "%d synthetic %d-bp genomes per GPU, -a %s -k %d%s, seed %d, ASCII records resident in HBM "
+                                   "-> sketch images in HBM (pack + sketch + finalize)"
+                                   % (G, L, algo, k, "" if algo == "hmh" else " -p %d" % p, seed),
+                       "genomes_per_gpu": G, "genome_length": L, "algo": algo, "k": k, "p": p, "sharding": "genomes across ranks"},
+            "roofline": {"bound": "hbm", "kernel": "sketch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sketch_ms,
+                         "note": "integer-ALU/LDS-atomic bound kernel: see DESIGN.md 'Roofline'"},
+            "stage_ms_per_step": {"pack": tm["pack_ms"] / max(tm["calls"], 1), "sketch": sketch_ms,
+                                  "finalize": tm["finalize_ms"] / max(tm["calls"], 1)},
+        }
+
+    # ---- parity spot check against the CPU oracle (outside the timed region) ----
+    if rank == 0 and not args.no_parity_check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        img = d_img.view(G, ib)
+        ok = True
+        for g in sorted({0, G // 2, G - 1}):
+            host = O.synth_genome(first + g, L)
+            want = O.sketch_genomes(lash_amd.ALGOS[algo], k, p, seed, host, np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
+            ok = ok and bool(np.array_equal(img[g].cpu().numpy(), want))
+        out["parity_vs_oracle"] = "bit-identical (3 genomes spot-checked)" if ok else "MISMATCH"
+        if not ok:
+            print(json.dumps(out))
+            raise SystemExit("parity check failed")
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(algo, k, p, seed, L, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,128 @@
+/*
+ * lash_gfx950.h — C ABI of liblash_gfx950.so: the MI355X (gfx950) drop-in for lash's sketching hot path.
+ *
+ * What it replaces.  In the reference the per-k-mer plug-in boundary is
+ *     trait KmerSketch { fn new(Option<u32>); fn add_kmer(&mut self, masked: u64, seed: u64); fn save(&self, w) }
+ * (/root/reference/src/utils.rs:377-386) with a single caller, the per-file closure of `sketch_files`
+ * (utils.rs:452-508).  A per-k-mer FFI call is meaningless for a GPU, so the boundary is that closure widened
+ * to a batch:  records of many files in  ->  the byte images `S::save` would have written out
+ * (utils.rs:400-402, 415-417, 431-433), in file order (utils.rs:509, 571-573).  A Rust host `write_all`s the
+ * images into its zstd encoder unchanged; INTEGRATION.md shows the `extern "C"` block.
+ *
+ * Rules of the ABI: plain pointers and sizes only; the caller allocates and frees every buffer; the library owns
+ * only what hangs off a lash_ctx / lash_packed; no exceptions or aborts cross the boundary (0 = OK, <0 = error);
+ * a lash_ctx is used by one host thread at a time; there is NO CPU fallback — without a HIP device every compute
+ * entry returns LASH_ENODEV.
+ */
+#ifndef LASH_GFX950_H
+#define LASH_GFX950_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LASH_ABI_VERSION 1
+
+/* error codes */
+#define LASH_OK       0
+#define LASH_EINVAL  (-1)   /* bad algo / k / p / arguments: mirrors the panics at utils.rs:500-502, main.rs:245 and
+                               the expect()s at utils.rs:408,423 */
+#define LASH_ENODEV  (-2)   /* no usable HIP device */
+#define LASH_EHIP    (-3)   /* HIP runtime error; text via lash_ctx_last_error() */
+#define LASH_ENOMEM  (-4)
+#define LASH_ELIMIT  (-5)   /* a genome has more than 2^32-64 bases in one call (split it and merge images) */
+
+/* -a {hmh,hll,ull}  (main.rs:69-76, 210-246) */
+#define LASH_HMH 0
+#define LASH_HLL 1
+#define LASH_ULL 2
+
+/* flags */
+#define LASH_F_HMH_X_LOW   1u  /* SURVEY App. D switch U1: take x (bucket, lz) from the LOW 64 bits of xxh3_128 */
+#define LASH_F_ACCUMULATE  2u  /* out_images already hold sketches of the same algo/p: union the new ones in */
+
+typedef struct lash_ctx lash_ctx;        /* one per (host thread, GPU): stream, workspace, scratch */
+typedef struct lash_packed lash_packed;  /* device-resident 2-bit genomes produced by lash_pack_* */
+
+typedef struct {
+    int32_t  algo;    /* LASH_HMH / LASH_HLL / LASH_ULL                                        */
+    int32_t  k;       /* 1..=32 (utils.rs:466-502)                                             */
+    int32_t  p;       /* HLL 4..=16, ULL 3..=26, ignored for HMH (main.rs:212-213)             */
+    uint32_t flags;   /* LASH_F_*                                                              */
+    uint64_t seed;    /* -s (main.rs:88-95); handed to xxh3 exactly as utils.rs:397,412,428 do  */
+} lash_params;
+
+/* Sums over every sketch call since lash_ctx_enable_timing(ctx, 1) (HIP events on the ctx stream). */
+typedef struct {
+    float    pack_ms;           /* ASCII -> 2-bit + record-break bitmap (incl. the small table uploads)   */
+    float    sketch_ms;         /* k-mer / xxh3 / register-update kernel (the dominant kernel)             */
+    float    finalize_ms;       /* partial-sketch reduction + byte images                                  */
+    uint32_t calls;             /* sketch calls summed                                                     */
+    uint32_t sketch_launches;   /* launches of the sketch kernel summed                                    */
+    uint32_t sketch_workgroups; /* workgroups of the last sketch launch                                    */
+    uint32_t reserved;
+    uint64_t kmers;             /* valid k-mers hashed, device-counted, summed                             */
+    uint64_t bases_last;        /* bases that survived filter_out_n in the last call                       */
+    uint64_t packed_bytes;      /* 2-bit words + break bitmap read by the sketch kernel, summed            */
+} lash_timing;
+
+/* ---- library / context ---------------------------------------------------------------------------------- */
+int         lash_abi_version(void);
+int         lash_device_count(void);                       /* 0 when no GPU is visible */
+const char *lash_strerror(int code);
+int         lash_ctx_create(lash_ctx **out, int device);   /* device >= 0 */
+void        lash_ctx_destroy(lash_ctx *ctx);
+int         lash_ctx_set_stream(lash_ctx *ctx, void *hip_stream);   /* run on the caller's hipStream_t (NULL = own) */
+int         lash_ctx_synchronize(lash_ctx *ctx);
+const char *lash_ctx_last_error(lash_ctx *ctx);
+int         lash_ctx_enable_timing(lash_ctx *ctx, int on); /* (re)starts the sums; HIP events around each stage */
+int         lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out);   /* synchronizes the stream */
+
+/* ---- parameters / sizes (host only, no GPU needed) -------------------------------------------------------- */
+int         lash_params_check(const lash_params *prm);     /* LASH_OK or LASH_EINVAL */
+size_t      lash_sketch_image_bytes(int algo, int p);      /* bytes S::save writes per sketch; 0 if invalid */
+
+/* ---- the hot path --------------------------------------------------------------------------------------- */
+/* Replaces the body of files.par_iter().map(...) (utils.rs:450-509) for a batch of files ("genomes").
+ *   seq            concatenated record sequences exactly as needletail's seqrec.seq() yields them (utils.rs:459):
+ *                  no headers, no line ends; any byte other than upper-case A C G T is deleted (utils.rs:33-41)
+ *   rec_off        n_rec+1 byte offsets into seq (record r = [rec_off[r], rec_off[r+1]))
+ *   genome_rec_off n_genomes+1 record indices (genome g owns records [genome_rec_off[g], genome_rec_off[g+1]))
+ *   out_images     n_genomes * lash_sketch_image_bytes() bytes, genome order
+ * Host-resident buffers; copies in, runs, copies out, synchronizes. */
+int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm,
+                      const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                      const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images);
+
+/* Same with seq / rec_off / out_images already in device memory (asynchronous on the ctx stream).
+ * The two small per-genome tables stay on the host: genome_byte_off[g] == rec_off[genome_rec_off[g]]. */
+int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm,
+                             const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
+                             const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
+                             uint32_t n_genomes, uint8_t *d_out_images);
+
+/* Two-stage form for callers that keep genomes resident in HBM as 2-bit (0.28 B/base incl. break bitmap):
+ * pack once, sketch many times (other k / algo / seed).  The pack stage performs filter_out_n + KSeq::new
+ * (utils.rs:459,464) and records where records begin so that no k-mer spans two records (utils.rs:457-464). */
+int  lash_pack_device(lash_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
+                      const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes,
+                      lash_packed **out);
+int  lash_sketch_packed_device(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images);
+void lash_packed_free(lash_ctx *ctx, lash_packed *pk);
+uint64_t lash_packed_bytes(const lash_packed *pk);          /* device bytes held */
+
+/* Union of serialized sketches, image-wise: dst[i] = dst[i] U src[i]
+ * (hyperminhash union / HyperLogLog::union / UltraLogLog::merge, utils.rs:171,261,357). */
+int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, const uint8_t *d_src, uint64_t n_images);
+int lash_merge_images(lash_ctx *ctx, int algo, int p, uint8_t *dst, const uint8_t *src, uint64_t n_images);
+
+/* Synthetic genomes of SURVEY.md §8(d) generated in HBM (bench / tests): genome ids first..first+n-1,
+ * n_bases ASCII bytes each, written back to back at d_out. */
+int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

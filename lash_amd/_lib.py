@@ -1,0 +1,76 @@
+"""ctypes binding of liblash_gfx950.so — every symbol of include/lash_gfx950.h.
+
+The library is the product; this module only declares prototypes.  It fails loudly when the shared object is
+missing: there is no Python or CPU fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "liblash_gfx950.so")
+
+OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT = 0, -1, -2, -3, -4, -5
+HMH, HLL, ULL = 0, 1, 2
+F_HMH_X_LOW, F_ACCUMULATE = 1, 2
+ABI_VERSION = 1
+
+
+class Params(C.Structure):
+    _fields_ = [("algo", C.c_int32), ("k", C.c_int32), ("p", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("pack_ms", C.c_float), ("sketch_ms", C.c_float), ("finalize_ms", C.c_float), ("calls", C.c_uint32),
+                ("sketch_launches", C.c_uint32), ("sketch_workgroups", C.c_uint32), ("reserved", C.c_uint32),
+                ("kmers", C.c_uint64), ("bases_last", C.c_uint64), ("packed_bytes", C.c_uint64)]
+
+
+_vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+_PP = C.POINTER(Params)
+
+# name -> (restype, argtypes); must list every function include/lash_gfx950.h declares (tests check this)
+PROTOTYPES = {
+    "lash_abi_version": (_int, []),
+    "lash_device_count": (_int, []),
+    "lash_strerror": (C.c_char_p, [_int]),
+    "lash_ctx_create": (_int, [C.POINTER(_vp), _int]),
+    "lash_ctx_destroy": (None, [_vp]),
+    "lash_ctx_set_stream": (_int, [_vp, _vp]),
+    "lash_ctx_synchronize": (_int, [_vp]),
+    "lash_ctx_last_error": (C.c_char_p, [_vp]),
+    "lash_ctx_enable_timing": (_int, [_vp, _int]),
+    "lash_ctx_get_timing": (_int, [_vp, C.POINTER(Timing)]),
+    "lash_params_check": (_int, [_PP]),
+    "lash_sketch_image_bytes": (C.c_size_t, [_int, _int]),
+    "lash_sketch_batch": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),
+    "lash_sketch_batch_device": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
+    "lash_pack_device": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
+    "lash_sketch_packed_device": (_int, [_vp, _PP, _vp, _vp]),
+    "lash_packed_free": (None, [_vp, _vp]),
+    "lash_packed_bytes": (_u64, [_vp]),
+    "lash_merge_images_device": (_int, [_vp, _int, _int, _vp, _vp, _u64]),
+    "lash_merge_images": (_int, [_vp, _int, _int, _vp, _vp, _u64]),
+    "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library (cached).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s is missing: build it with `python -m lash_amd.build` (needs hipcc). "
+            "lash_amd has no CPU fallback for the sketching hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lash_abi_version() != ABI_VERSION:
+        raise RuntimeError("liblash_gfx950.so ABI version %d != binding %d" % (lib.lash_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib

@@ -1,0 +1,618 @@
+// lash_api.hip — the extern "C" boundary of liblash_gfx950.so (include/lash_gfx950.h): contexts, HBM workspace,
+// work-item planning and the three stages pack -> sketch -> finalize on one HIP stream.
+//
+// Reference side of the boundary: the per-file closure of sketch_files
+// (/root/reference/src/utils.rs:452-508) and KmerSketch::{new,add_kmer,save} (utils.rs:377-434).
+// There is no CPU fallback here: every compute entry needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/lash_gfx950.h"
+#include "lash_kernels.h"
+
+using namespace lash;
+
+namespace {
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct EvSet {
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};   // call start, pack done, sketch done, finalize done
+    bool pack = false, done = false;
+};
+
+struct HostStage {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+}  // namespace
+
+struct lash_packed {
+    uint32_t n_genomes = 0;
+    DevBuf words, brk, nvalid, descs;
+    uint64_t total_words = 0, total_brk = 0;
+    std::vector<uint64_t> byte_len;      // per genome, host copy (upper bound of surviving bases)
+    bool owned_by_ctx = false;           // the scratch instance reused by lash_sketch_batch_device
+};
+
+struct lash_ctx {
+    int device = 0;
+    int cu_count = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool timing = false;
+    std::vector<EvSet> ev_pool;          // one set of 4 events per timed call since lash_ctx_enable_timing(ctx, 1)
+    size_t ev_used = 0;
+    EvSet *cur_ev = nullptr;
+    lash_timing last{};
+    HostStage ring[8];                   // pinned staging for the small per-call tables
+    unsigned ring_next = 0;
+    const lash_packed *last_packed = nullptr;
+    DevBuf items, item_begin, partials, gregs, counter;
+    bool counter_zeroed = false;
+    DevBuf st_seq, st_rec, st_img;       // staging for the host-buffer entry
+    lash_packed scratch;
+};
+
+namespace {
+
+int fail(lash_ctx *ctx, int code, const char *what, hipError_t e)
+{
+    if (ctx) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                              \
+    do {                                                               \
+        hipError_t e__ = (expr);                                       \
+        if (e__ != hipSuccess) return fail((ctx), e__ == hipErrorOutOfMemory ? LASH_ENOMEM : LASH_EHIP, #expr, e__); \
+    } while (0)
+
+// grow-only device buffer; growing synchronizes the stream first because queued kernels may still use the old one
+int reserve(lash_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return LASH_OK;
+    if (b.ptr) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&b.ptr, want));
+    b.cap = want;
+    return LASH_OK;
+}
+
+void release(DevBuf &b)
+{
+    if (b.ptr) (void)hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.cap = 0;
+}
+
+// Small host tables go through a ring of pinned buffers, so the async copy never reads a dead std::vector and a
+// call never has to drain the stream.
+int upload(lash_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (bytes == 0) return LASH_OK;
+    HostStage &hs = ctx->ring[ctx->ring_next++ % 8];
+    if (hs.pending) { HIPCHK(ctx, hipEventSynchronize(hs.done)); hs.pending = false; }
+    if (!hs.done) HIPCHK(ctx, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+    if (hs.cap < bytes) {
+        if (hs.ptr) HIPCHK(ctx, hipHostFree(hs.ptr));
+        hs.ptr = nullptr;
+        hs.cap = 0;
+        HIPCHK(ctx, hipHostMalloc(&hs.ptr, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        hs.cap = bytes + bytes / 4 + 4096;
+    }
+    memcpy(hs.ptr, h_src, bytes);
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, hs.ptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(hs.done, ctx->stream));
+    hs.pending = true;
+    return LASH_OK;
+}
+
+int timing_begin(lash_ctx *ctx)
+{
+    ctx->cur_ev = nullptr;
+    if (!ctx->timing) return LASH_OK;
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        if (ctx->ev_pool.size() >= 4096) return LASH_OK;       // stop recording, keep running
+        EvSet s;
+        for (auto &e : s.e) HIPCHK(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(s);
+    }
+    EvSet *s = &ctx->ev_pool[ctx->ev_used++];
+    s->pack = false;
+    s->done = false;
+    ctx->cur_ev = s;
+    HIPCHK(ctx, hipEventRecord(s->e[0], ctx->stream));
+    return LASH_OK;
+}
+
+double hll_alpha(int p)
+{
+    switch (p) {
+    case 4: return 0.673;
+    case 5: return 0.697;
+    case 6: return 0.709;
+    default: return 0.7213 / (1.0 + 1.079 / (double)(1u << p));
+    }
+}
+
+uint64_t header_bytes(int algo) { return algo == LASH_HMH ? 0 : algo == LASH_HLL ? 33 : 8; }
+
+int pack_into(lash_ctx *ctx, lash_packed *pk, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
+              const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes)
+{
+    if (n_genomes && (!genome_rec_off || !genome_byte_off)) return LASH_EINVAL;
+    std::vector<GenomeDesc> descs(n_genomes);
+    pk->byte_len.assign(n_genomes, 0);
+    uint64_t wo = 0, bo = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        if (genome_rec_off[g + 1] < genome_rec_off[g] || genome_byte_off[g + 1] < genome_byte_off[g] ||
+            genome_rec_off[g + 1] > n_rec)
+            return LASH_EINVAL;
+        GenomeDesc &d = descs[g];
+        d.byte_off = genome_byte_off[g];
+        d.byte_len = genome_byte_off[g + 1] - genome_byte_off[g];
+        if (d.byte_len > 0xFFFFFFFFull - 64) return LASH_ELIMIT;
+        d.rec_begin = genome_rec_off[g];
+        d.rec_end = genome_rec_off[g + 1];
+        d.word_off = wo;
+        d.brk_off = bo;
+        pk->byte_len[g] = d.byte_len;
+        uint64_t nw = (d.byte_len + 15) / 16 + 2 * PAD_WORDS;
+        wo += (nw + 3) & ~3ull;                                   // keep every genome 16-byte aligned
+        bo += (d.byte_len + 1 + 31) / 32 + 4;                     // +3 words of look-ahead in kmer_valid_mask
+    }
+    pk->n_genomes = n_genomes;
+    pk->total_words = wo + 2 * PAD_WORDS;
+    pk->total_brk = bo + 4;
+    int rc;
+    if ((rc = reserve(ctx, pk->words, pk->total_words * 4))) return rc;
+    if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
+    if ((rc = reserve(ctx, pk->nvalid, (size_t)(n_genomes + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, pk->descs, (size_t)(n_genomes + 1) * sizeof(GenomeDesc)))) return rc;
+    if (n_genomes == 0) return LASH_OK;
+    if ((rc = upload(ctx, pk->descs.ptr, descs.data(), descs.size() * sizeof(GenomeDesc)))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, ctx->stream));
+    PackArgs pa{};
+    pa.seq = d_seq;
+    pa.seq_end = d_seq + genome_byte_off[n_genomes];
+    pa.rec_off = d_rec_off;
+    pa.genomes = static_cast<const GenomeDesc *>(pk->descs.ptr);
+    pa.words = static_cast<uint32_t *>(pk->words.ptr);
+    pa.brk = static_cast<uint32_t *>(pk->brk.ptr);
+    pa.nvalid = static_cast<uint64_t *>(pk->nvalid.ptr);
+    HIPCHK(ctx, launch_pack(pa, n_genomes, ctx->stream));
+    return LASH_OK;
+}
+
+int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, bool timed_pack)
+{
+    const uint32_t n_genomes = pk->n_genomes;
+    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, (prm->flags & LASH_F_HMH_X_LOW) != 0);
+    const uint64_t image_bytes = lash_sketch_image_bytes(prm->algo, prm->p);
+
+    // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
+    const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(plan.lds_bytes, 1u)) : 4u;
+    const uint64_t slots = (uint64_t)ctx->cu_count * std::min(wg_per_cu, 2048u / plan.threads);
+    uint64_t total_words = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) total_words += (pk->byte_len[g] + 15) / 16;
+    const uint64_t step = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
+    const uint64_t min_slice = step * 8;                           // amortise the LDS clear + flush
+    uint64_t target = total_words / (slots * 8) + 1;
+    target = std::max(target, min_slice);
+    std::vector<WorkItem> items;
+    std::vector<uint32_t> item_begin(n_genomes + 1, 0);
+    items.reserve(n_genomes * 2);
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        item_begin[g] = (uint32_t)items.size();
+        const uint64_t nw = ((pk->byte_len[g] + 15) / 16 + 3) & ~3ull;
+        if (nw == 0) continue;
+        const uint64_t ns = (nw + target - 1) / target;
+        const uint64_t per = (((nw + ns - 1) / ns) + 3) & ~3ull;
+        uint32_t s = 0;
+        for (uint64_t b = 0; b < nw; b += per, ++s)
+            items.push_back(WorkItem{g, (uint32_t)b, (uint32_t)std::min(nw, b + per), s});
+    }
+    item_begin[n_genomes] = (uint32_t)items.size();
+    const uint32_t n_items = (uint32_t)items.size();
+
+    int rc;
+    if ((rc = reserve(ctx, ctx->items, (size_t)(n_items + 1) * sizeof(WorkItem)))) return rc;
+    if ((rc = reserve(ctx, ctx->item_begin, (size_t)(n_genomes + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + 1) * plan.partial_stride))) return rc;
+    if ((rc = reserve(ctx, ctx->counter, 64))) return rc;
+    if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
+    if ((rc = upload(ctx, ctx->items.ptr, items.data(), (size_t)n_items * sizeof(WorkItem)))) return rc;
+    if ((rc = upload(ctx, ctx->item_begin.ptr, item_begin.data(), (size_t)(n_genomes + 1) * 4))) return rc;
+    if (!ctx->counter_zeroed) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 8, ctx->stream));
+        ctx->counter_zeroed = true;
+    }
+    if (!plan.use_lds && n_items)
+        HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n_items * plan.nreg32 * 4, ctx->stream));
+
+    EvSet *ev = ctx->cur_ev;
+    if (ev) { ev->pack = timed_pack; HIPCHK(ctx, hipEventRecord(ev->e[1], ctx->stream)); }
+
+    SketchArgs sa{};
+    sa.words = static_cast<const uint32_t *>(pk->words.ptr);
+    sa.brk = static_cast<const uint32_t *>(pk->brk.ptr);
+    sa.genomes = static_cast<const GenomeDesc *>(pk->descs.ptr);
+    sa.nvalid = static_cast<const uint64_t *>(pk->nvalid.ptr);
+    sa.items = static_cast<const WorkItem *>(ctx->items.ptr);
+    sa.partials = static_cast<uint8_t *>(ctx->partials.ptr);
+    sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
+    sa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
+    sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
+    sa.partial_stride = plan.partial_stride;
+    sa.nreg32 = plan.nreg32;
+    sa.k = prm->k;
+    sa.p = prm->p;
+    HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream));
+    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
+
+    FinalizeArgs fa{};
+    fa.partials = static_cast<const uint8_t *>(ctx->partials.ptr);
+    fa.items = static_cast<const WorkItem *>(ctx->items.ptr);
+    fa.genome_item_begin = static_cast<const uint32_t *>(ctx->item_begin.ptr);
+    fa.nvalid = static_cast<const uint64_t *>(pk->nvalid.ptr);
+    fa.images = d_out_images;
+    fa.partial_stride = plan.partial_stride;
+    fa.partial_base_off = 0;
+    fa.image_bytes = image_bytes;
+    const double alpha = hll_alpha(prm->p);
+    memcpy(&fa.alpha_bits, &alpha, 8);
+    fa.algo = prm->algo;
+    fa.p = prm->p;
+    fa.k = prm->k;
+    fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
+    HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
+    if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream)); ev->done = true; }
+    ctx->cur_ev = nullptr;
+    ctx->last_packed = pk;
+    ctx->last.calls += 1;
+    ctx->last.sketch_launches += n_items ? 1 : 0;
+    ctx->last.sketch_workgroups = n_items;
+    for (uint32_t g = 0; g < n_genomes; ++g)
+        ctx->last.packed_bytes += (pk->byte_len[g] + 15) / 16 * 4 + (pk->byte_len[g] + 31) / 32 * 4;
+    return LASH_OK;
+}
+
+}  // namespace
+
+// ===============================================================================================================
+extern "C" {
+
+int lash_abi_version(void) { return LASH_ABI_VERSION; }
+
+int lash_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *lash_strerror(int code)
+{
+    switch (code) {
+    case LASH_OK: return "ok";
+    case LASH_EINVAL: return "invalid argument (algorithm must be hmh/hll/ull, k 1..=32, hll p 4..=16, ull p 3..=26)";
+    case LASH_ENODEV: return "no usable HIP device (liblash_gfx950 has no CPU fallback)";
+    case LASH_EHIP: return "HIP runtime error";
+    case LASH_ENOMEM: return "out of device memory";
+    case LASH_ELIMIT: return "a genome exceeds 2^32-64 bytes in one call; split it and merge the images";
+    default: return "unknown error";
+    }
+}
+
+int lash_params_check(const lash_params *prm)
+{
+    if (!prm) return LASH_EINVAL;
+    if (prm->k < 1 || prm->k > 32) return LASH_EINVAL;                    // utils.rs:500-502
+    switch (prm->algo) {
+    case LASH_HMH: return LASH_OK;                                        // precision ignored, main.rs:212-213
+    case LASH_HLL: return (prm->p >= 4 && prm->p <= 16) ? LASH_OK : LASH_EINVAL;
+    case LASH_ULL: return (prm->p >= 3 && prm->p <= 26) ? LASH_OK : LASH_EINVAL;
+    default: return LASH_EINVAL;                                          // main.rs:245
+    }
+}
+
+size_t lash_sketch_image_bytes(int algo, int p)
+{
+    switch (algo) {
+    case LASH_HMH: return (size_t)HMH_M * 2;                               // 16384 x u16 LE
+    case LASH_HLL: return (p >= 4 && p <= 16) ? 33 + ((size_t)1 << p) : 0;   // bincode(alpha, zero, sum, p, len) + m
+    case LASH_ULL: return (p >= 3 && p <= 26) ? 8 + ((size_t)1 << p) : 0;    // bincode(Vec<u8>)
+    default: return 0;
+    }
+}
+
+int lash_ctx_create(lash_ctx **out, int device)
+{
+    if (!out) return LASH_EINVAL;
+    *out = nullptr;
+    int n = lash_device_count();
+    if (n <= 0) return LASH_ENODEV;
+    if (device < 0 || device >= n) return LASH_EINVAL;
+    lash_ctx *ctx = new (std::nothrow) lash_ctx();
+    if (!ctx) return LASH_ENOMEM;
+    ctx->device = device;
+    ctx->scratch.owned_by_ctx = true;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return LASH_EHIP;
+    }
+    ctx->own_stream = true;
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = ctx;
+    return LASH_OK;
+}
+
+void lash_ctx_destroy(lash_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
+                      &ctx->st_img, &ctx->scratch.words, &ctx->scratch.brk, &ctx->scratch.nvalid, &ctx->scratch.descs})
+        release(*b);
+    for (auto &s : ctx->ev_pool)
+        for (auto &e : s.e)
+            if (e) (void)hipEventDestroy(e);
+    for (auto &hs : ctx->ring) {
+        if (hs.done) (void)hipEventDestroy(hs.done);
+        if (hs.ptr) (void)hipHostFree(hs.ptr);
+    }
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int lash_ctx_set_stream(lash_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    if (!hip_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return LASH_OK;
+}
+
+int lash_ctx_synchronize(lash_ctx *ctx)
+{
+    if (!ctx) return LASH_EINVAL;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
+const char *lash_ctx_last_error(lash_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int lash_ctx_enable_timing(lash_ctx *ctx, int on)
+{
+    if (!ctx) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timing = on != 0;
+    ctx->ev_used = 0;
+    ctx->cur_ev = nullptr;
+    ctx->last = lash_timing{};
+    ctx->counter_zeroed = false;                                  // the k-mer census restarts as well
+    return LASH_OK;
+}
+
+int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
+{
+    if (!ctx || !out) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    lash_timing t = ctx->last;
+    t.pack_ms = t.sketch_ms = t.finalize_ms = 0.f;
+    for (size_t i = 0; i < ctx->ev_used; ++i) {
+        const EvSet &s = ctx->ev_pool[i];
+        if (!s.done) continue;
+        float ms = 0.f;
+        if (s.pack) { HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[0], s.e[1])); t.pack_ms += ms; }
+        HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[1], s.e[2])); t.sketch_ms += ms;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[2], s.e[3])); t.finalize_ms += ms;
+    }
+    t.kmers = 0;
+    t.bases_last = 0;
+    if (ctx->counter.ptr && ctx->counter_zeroed) {
+        unsigned long long c = 0;
+        HIPCHK(ctx, hipMemcpy(&c, ctx->counter.ptr, 8, hipMemcpyDeviceToHost));
+        t.kmers = c;
+    }
+    if (ctx->last_packed && ctx->last_packed->n_genomes) {
+        std::vector<uint64_t> nv(ctx->last_packed->n_genomes);
+        HIPCHK(ctx, hipMemcpy(nv.data(), ctx->last_packed->nvalid.ptr, nv.size() * 8, hipMemcpyDeviceToHost));
+        for (uint64_t v : nv) t.bases_last += v;
+    }
+    *out = t;
+    return LASH_OK;
+}
+
+int lash_pack_device(lash_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
+                     const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes,
+                     lash_packed **out)
+{
+    if (!ctx || !out) return LASH_EINVAL;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    lash_packed *pk = new (std::nothrow) lash_packed();
+    if (!pk) return LASH_ENOMEM;
+    int rc = pack_into(ctx, pk, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, n_genomes);
+    if (rc) { lash_packed_free(ctx, pk); return rc; }
+    *out = pk;
+    return LASH_OK;
+}
+
+void lash_packed_free(lash_ctx *ctx, lash_packed *pk)
+{
+    if (!pk || pk->owned_by_ctx) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->last_packed == pk) ctx->last_packed = nullptr;
+    }
+    release(pk->words);
+    release(pk->brk);
+    release(pk->nvalid);
+    release(pk->descs);
+    delete pk;
+}
+
+uint64_t lash_packed_bytes(const lash_packed *pk)
+{
+    return pk ? pk->words.cap + pk->brk.cap + pk->nvalid.cap + pk->descs.cap : 0;
+}
+
+int lash_sketch_packed_device(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images)
+{
+    if (!ctx || !pk || (pk->n_genomes && !d_out_images)) return LASH_EINVAL;
+    int rc = lash_params_check(prm);
+    if (rc) return rc;
+    (void)hipSetDevice(ctx->device);
+    if ((rc = timing_begin(ctx))) return rc;
+    return sketch_from(ctx, prm, pk, d_out_images, false);
+}
+
+int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off,
+                             uint64_t n_rec, const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
+                             uint32_t n_genomes, uint8_t *d_out_images)
+{
+    if (!ctx || (n_genomes && !d_out_images)) return LASH_EINVAL;
+    int rc = lash_params_check(prm);
+    if (rc) return rc;
+    (void)hipSetDevice(ctx->device);
+    if ((rc = timing_begin(ctx))) return rc;
+    rc = pack_into(ctx, &ctx->scratch, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, n_genomes);
+    if (rc) return rc;
+    return sketch_from(ctx, prm, &ctx->scratch, d_out_images, true);
+}
+
+int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                      const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images)
+{
+    if (!ctx || !rec_off || !genome_rec_off || (n_genomes && !out_images)) return LASH_EINVAL;
+    int rc = lash_params_check(prm);
+    if (rc) return rc;
+    (void)hipSetDevice(ctx->device);
+    for (uint64_t r = 0; r < n_rec; ++r)
+        if (rec_off[r + 1] < rec_off[r]) return LASH_EINVAL;
+    const uint64_t seq_bytes = rec_off[n_rec];
+    if (seq_bytes && !seq) return LASH_EINVAL;
+    std::vector<uint64_t> gbo(n_genomes + 1);
+    for (uint32_t g = 0; g <= n_genomes; ++g) {
+        if (genome_rec_off[g] > n_rec) return LASH_EINVAL;
+        gbo[g] = rec_off[genome_rec_off[g]];
+    }
+    const size_t img_bytes = (size_t)n_genomes * lash_sketch_image_bytes(prm->algo, prm->p);
+    if ((rc = reserve(ctx, ctx->st_seq, seq_bytes + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->st_rec, (size_t)(n_rec + 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->st_img, img_bytes + 64))) return rc;
+    if (seq_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->st_seq.ptr, seq, seq_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_rec.ptr, rec_off, (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if ((prm->flags & LASH_F_ACCUMULATE) && img_bytes)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->st_img.ptr, out_images, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = lash_sketch_batch_device(ctx, prm, static_cast<const uint8_t *>(ctx->st_seq.ptr),
+                                  static_cast<const uint64_t *>(ctx->st_rec.ptr), n_rec, genome_rec_off, gbo.data(),
+                                  n_genomes, static_cast<uint8_t *>(ctx->st_img.ptr));
+    if (rc) return rc;
+    if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
+int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, const uint8_t *d_src, uint64_t n_images)
+{
+    if (!ctx || (n_images && (!d_dst || !d_src)) || n_images > 0x7FFFFFFFull) return LASH_EINVAL;
+    lash_params prm{algo, 16, p, 0, 0};
+    int rc = lash_params_check(&prm);
+    if (rc) return rc;
+    if (n_images == 0) return LASH_OK;
+    (void)hipSetDevice(ctx->device);
+    // one pseudo work item per image: "partials" are the source images themselves (registers after the header)
+    std::vector<WorkItem> items((size_t)n_images);
+    std::vector<uint32_t> begin((size_t)n_images + 1);
+    for (uint64_t i = 0; i < n_images; ++i) { items[i] = WorkItem{(uint32_t)i, 0, 0, 0}; begin[i] = (uint32_t)i; }
+    begin[n_images] = (uint32_t)n_images;
+    if ((rc = reserve(ctx, ctx->items, (size_t)(n_images + 1) * sizeof(WorkItem)))) return rc;
+    if ((rc = reserve(ctx, ctx->item_begin, (size_t)(n_images + 1) * 4))) return rc;
+    if ((rc = upload(ctx, ctx->items.ptr, items.data(), items.size() * sizeof(WorkItem)))) return rc;
+    if ((rc = upload(ctx, ctx->item_begin.ptr, begin.data(), begin.size() * 4))) return rc;
+    FinalizeArgs fa{};
+    fa.partials = d_src;
+    fa.items = static_cast<const WorkItem *>(ctx->items.ptr);
+    fa.genome_item_begin = static_cast<const uint32_t *>(ctx->item_begin.ptr);
+    fa.nvalid = nullptr;
+    fa.images = d_dst;
+    fa.image_bytes = lash_sketch_image_bytes(algo, p);
+    fa.partial_stride = fa.image_bytes;
+    fa.partial_base_off = header_bytes(algo);
+    const double alpha = hll_alpha(p);
+    memcpy(&fa.alpha_bits, &alpha, 8);
+    fa.algo = algo;
+    fa.p = p;
+    fa.k = 16;
+    fa.accumulate = 1;
+    HIPCHK(ctx, launch_finalize(fa, (uint32_t)n_images, ctx->stream));
+    return LASH_OK;
+}
+
+int lash_merge_images(lash_ctx *ctx, int algo, int p, uint8_t *dst, const uint8_t *src, uint64_t n_images)
+{
+    if (!ctx || (n_images && (!dst || !src))) return LASH_EINVAL;
+    const size_t ib = lash_sketch_image_bytes(algo, p);
+    if (!ib) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    const size_t bytes = ib * (size_t)n_images;
+    int rc;
+    if ((rc = reserve(ctx, ctx->st_img, bytes + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->st_seq, bytes + 64))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_img.ptr, dst, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->st_seq.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = lash_merge_images_device(ctx, algo, p, static_cast<uint8_t *>(ctx->st_img.ptr),
+                                  static_cast<const uint8_t *>(ctx->st_seq.ptr), n_images);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(dst, ctx->st_img.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
+int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out)
+{
+    if (!ctx || (n_genomes && n_bases && !d_out)) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, launch_synth(first_genome, n_genomes, n_bases, d_out, ctx->stream));
+    return LASH_OK;
+}
+
+}  // extern "C"

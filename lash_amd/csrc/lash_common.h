@@ -1,0 +1,54 @@
+// lash_common.h — structures shared by the host side of liblash_gfx950 and its gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace lash {
+
+// ---- HBM layout of a packed batch (DESIGN.md "Data layout") ----------------------------------------------
+// words : 2-bit bases, 16 per u32, FIRST base in bits 31:30 (so a k-mer is a funnel-shift window and its
+//         numeric value follows kmerutils' "first base most significant" rule).  Each genome starts on a
+//         16-byte boundary (word_off % 4 == 0) and is followed by >= PAD_WORDS readable words.
+// brk   : 1 bit per packed base position, LSB-first inside a u32; bit i is set when position i is the first
+//         surviving base of a record (k-mers never span records: utils.rs:457-464).
+// nvalid: per genome, the number of bases that survived filter_out_n (utils.rs:33-41), device-written.
+struct GenomeDesc {
+    uint64_t byte_off;    // first byte of the genome's records in seq
+    uint64_t byte_len;    // bytes of all its records
+    uint64_t word_off;    // into words[]
+    uint64_t brk_off;     // into brk[] (u32 units)
+    uint64_t rec_begin;   // records [rec_begin, rec_end) of rec_off[]
+    uint64_t rec_end;
+};
+
+// One workgroup of the sketch kernel = one slice of one genome.
+struct WorkItem {
+    uint32_t genome;
+    uint32_t word_begin;  // slice = packed words [word_begin, word_end) of the genome, multiples of 4
+    uint32_t word_end;
+    uint32_t slice;       // slice index inside the genome
+};
+
+constexpr int      PAD_WORDS        = 8;       // readable slack after every genome (look-ahead words)
+constexpr int      SKETCH_WORDS_PER_THREAD = 4;   // one global_load_dwordx4 per lane per step
+constexpr int      HMH_P            = 14;
+constexpr uint32_t HMH_M            = 1u << HMH_P;
+
+// XXH3 constants (XXH 0.8 spec; closed forms in SURVEY.md Appendix C, pinned by tests/golden/xxh3_vectors.json)
+constexpr uint64_t XXH_PRIME64_1 = 0x9E3779B185EBCA87ULL;
+constexpr uint64_t XXH_PRIME_MX1 = 0x165667919E3779F9ULL;
+constexpr uint64_t XXH_PRIME_MX2 = 0x9FB21C651E98DF25ULL;
+constexpr uint64_t XXH_SEC8  = 0x1cad21f72c81017cULL;
+constexpr uint64_t XXH_SEC16 = 0xdb979083e96dd4deULL;
+constexpr uint64_t XXH_SEC24 = 0x1f67b3b7a4a44072ULL;
+
+inline uint64_t xxh3_short_seed(uint64_t seed)
+{
+    uint32_t lo = (uint32_t)seed;
+    uint32_t sw = (lo >> 24) | ((lo >> 8) & 0xFF00u) | ((lo << 8) & 0xFF0000u) | (lo << 24);
+    return seed ^ ((uint64_t)sw << 32);
+}
+// seed-dependent constants folded on the host and passed as kernel arguments
+inline uint64_t xxh3_bitflip64(uint64_t seed)  { return (XXH_SEC8 ^ XXH_SEC16) - xxh3_short_seed(seed); }   // 8-byte input, 64-bit hash
+inline uint64_t xxh3_bitflip128(uint64_t seed) { return (XXH_SEC16 ^ XXH_SEC24) + xxh3_short_seed(seed); }  // 4-byte input, 128-bit hash
+
+}  // namespace lash

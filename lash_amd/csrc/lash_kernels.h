@@ -1,0 +1,71 @@
+// lash_kernels.h — host-callable launchers of the gfx950 kernels (implemented in *.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lash_common.h"
+
+namespace lash {
+
+// ---- sketch stage ----------------------------------------------------------------------------------------
+struct SketchArgs {
+    const uint32_t   *words;      // packed 2-bit bases
+    const uint32_t   *brk;        // record-break bitmap
+    const GenomeDesc *genomes;
+    const uint64_t   *nvalid;     // surviving bases per genome
+    const WorkItem   *items;
+    uint8_t          *partials;   // [n_items][partial_stride] partial sketches in image register format
+    uint32_t         *gregs;      // [n_items][nreg32] zeroed u32 words, only for the global-register variant
+    unsigned long long *kmer_counter;   // += valid k-mers
+    uint64_t          bitflip;    // xxh3 seed-folded constant (64- or 128-bit variant by algo)
+    uint32_t          partial_stride;
+    uint32_t          nreg32;     // u32 words of register state (HMH 16384, HLL 2^p, ULL 2*2^p)
+    int               k;
+    int               p;
+};
+
+struct SketchPlan {
+    int      algo, k, p;
+    bool     x_low;
+    bool     use_lds;
+    uint32_t threads;             // 512 (<= 64 KiB of LDS, two workgroups per CU) or 1024
+    uint32_t lds_bytes;
+    uint32_t nreg32;
+    uint32_t partial_bytes;       // bytes of one partial sketch (register array only)
+    uint32_t partial_stride;      // rounded up to 16
+};
+
+SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low);
+hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream);
+
+struct FinalizeArgs {
+    const uint8_t  *partials;
+    const WorkItem *items;
+    const uint32_t *genome_item_begin;   // n_genomes + 1
+    const uint64_t *nvalid;              // NULL => every item is live (merge of images)
+    uint8_t        *images;
+    uint64_t        partial_stride;
+    uint64_t        partial_base_off;    // offset of the register array inside each partial (merge: header size)
+    uint64_t        image_bytes;
+    uint64_t        alpha_bits;          // HLL alpha as f64 bits
+    int             algo, p, k;
+    int             accumulate;          // union into the registers already in images[]
+};
+hipError_t launch_finalize(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream);
+
+// ---- pack stage -------------------------------------------------------------------------------------------
+struct PackArgs {
+    const uint8_t    *seq;
+    const uint8_t    *seq_end;    // one past the caller's buffer (edge loads are bounds-checked)
+    const uint64_t   *rec_off;
+    const GenomeDesc *genomes;
+    uint32_t         *words;
+    uint32_t         *brk;        // zeroed before the launch
+    uint64_t         *nvalid;
+};
+hipError_t launch_pack(const PackArgs &args, uint32_t n_genomes, hipStream_t stream);
+
+// ---- synthetic genomes --------------------------------------------------------------------
+hipError_t launch_synth(uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out, hipStream_t stream);
+
+}  // namespace lash

@@ -1,0 +1,197 @@
+"""Python face of the C ABI (include/lash_gfx950.h).  Mirrors the reference's sketch interface for the hot path:
+`sketch_files::<S>(precision, files, k, out, threads, seed, aa)` (utils.rs:439-447) becomes
+`Context.sketch_batch(algo, k, p, seed, records...)` returning the bytes `S::save` would write (utils.rs:571-573).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, Timing
+
+ALGOS = {"hmh": _lib.HMH, "hll": _lib.HLL, "ull": _lib.ULL}
+
+
+class LashError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lash error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _algo(a):
+    if isinstance(a, str):
+        if a not in ALGOS:
+            # main.rs:245 panics with this text
+            raise LashError(_lib.EINVAL, "Algorithm must be either hmh, ull, or hll")
+        return ALGOS[a]
+    return int(a)
+
+
+def image_bytes(algo, p=0):
+    return int(_lib.load().lash_sketch_image_bytes(_algo(algo), int(p)))
+
+
+def params_check(algo, k, p=0):
+    prm = Params(_algo(algo), int(k), int(p), 0, 0)
+    return int(_lib.load().lash_params_check(C.byref(prm)))
+
+
+def records_to_arrays(genomes):
+    """genomes: list of lists of record byte strings -> (seq u8, rec_off u64, genome_rec_off u64)."""
+    recs = [r for g in genomes for r in g]
+    seq = np.frombuffer(b"".join(recs), dtype=np.uint8).copy() if recs else np.zeros(0, np.uint8)
+    rec_off = np.zeros(len(recs) + 1, dtype=np.uint64)
+    if recs:
+        rec_off[1:] = np.cumsum([len(r) for r in recs], dtype=np.uint64)
+    goff = np.zeros(len(genomes) + 1, dtype=np.uint64)
+    if genomes:
+        goff[1:] = np.cumsum([len(g) for g in genomes], dtype=np.uint64)
+    return seq, rec_off, goff
+
+
+def _ptr(x):
+    """device pointer of a torch tensor / raw int, or host pointer of a numpy array"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()
+
+
+class Packed:
+    """Device-resident 2-bit genomes (lash_packed*)."""
+
+    def __init__(self, ctx, handle, n_genomes):
+        self._ctx, self._h, self.n_genomes = ctx, handle, n_genomes
+
+    @property
+    def device_bytes(self):
+        return int(_lib.load().lash_packed_bytes(self._h))
+
+    def free(self):
+        if self._h:
+            _lib.load().lash_packed_free(self._ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One lash_ctx: a GPU, a stream and the HBM workspace.  Not thread-safe (like the C object)."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        rc = self._lib.lash_ctx_create(C.byref(h), int(device))
+        if rc != _lib.OK:
+            raise LashError(rc, self._lib.lash_strerror(rc).decode())
+        self._h = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- plumbing ---------------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != _lib.OK:
+            detail = self._lib.lash_ctx_last_error(self._h).decode() if rc in (_lib.EHIP, _lib.ENOMEM) else ""
+            raise LashError(rc, self._lib.lash_strerror(rc).decode() + (": " + detail if detail else ""))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lash_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream):
+        """stream: a raw hipStream_t as int, or an object with .cuda_stream (torch.cuda.Stream); None = own stream"""
+        ptr = None if stream is None else int(getattr(stream, "cuda_stream", stream))
+        self._check(self._lib.lash_ctx_set_stream(self._h, ptr))
+
+    def synchronize(self):
+        self._check(self._lib.lash_ctx_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        self._check(self._lib.lash_ctx_enable_timing(self._h, 1 if on else 0))
+
+    def timing(self):
+        t = Timing()
+        self._check(self._lib.lash_ctx_get_timing(self._h, C.byref(t)))
+        return {f[0]: getattr(t, f[0]) for f in Timing._fields_ if f[0] != "reserved"}
+
+    @staticmethod
+    def _params(algo, k, p, seed, flags):
+        return Params(_algo(algo), int(k), int(p or 0), int(flags), int(seed) & (2**64 - 1))
+
+    # -- hot path ---------------------------------------------------------------------------------------------
+    def sketch_batch(self, algo, k, p, seed, seq, rec_off, genome_rec_off, flags=0, out=None):
+        """Host buffers in, images[n_genomes, image_bytes] (numpy uint8) out."""
+        prm = self._params(algo, k, p, seed, flags)
+        self._check(self._lib.lash_params_check(C.byref(prm)))
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        goff = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
+        n_g, n_rec = len(goff) - 1, len(rec_off) - 1
+        ib = image_bytes(prm.algo, prm.p)
+        if out is None:
+            out = np.zeros((n_g, ib), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size == n_g * ib and out.flags.c_contiguous
+        seq_p = seq.ctypes.data if seq.size else None
+        self._check(self._lib.lash_sketch_batch(self._h, C.byref(prm), seq_p, rec_off.ctypes.data, n_rec,
+                                                goff.ctypes.data, n_g, out.ctypes.data if out.size else None))
+        return out
+
+    def sketch_batch_device(self, algo, k, p, seed, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, d_out,
+                            flags=0):
+        """Device-resident records in, device images out; asynchronous on the context's stream."""
+        prm = self._params(algo, k, p, seed, flags)
+        goff = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
+        gbo = np.ascontiguousarray(genome_byte_off, dtype=np.uint64)
+        assert len(goff) == len(gbo)
+        self._keep = (goff, gbo)
+        self._check(self._lib.lash_sketch_batch_device(self._h, C.byref(prm), _ptr(d_seq), _ptr(d_rec_off), int(n_rec),
+                                                       goff.ctypes.data, gbo.ctypes.data, len(goff) - 1, _ptr(d_out)))
+
+    def pack_device(self, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off):
+        goff = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
+        gbo = np.ascontiguousarray(genome_byte_off, dtype=np.uint64)
+        h = C.c_void_p()
+        self._check(self._lib.lash_pack_device(self._h, _ptr(d_seq), _ptr(d_rec_off), int(n_rec), goff.ctypes.data,
+                                               gbo.ctypes.data, len(goff) - 1, C.byref(h)))
+        return Packed(self, h, len(goff) - 1)
+
+    def sketch_packed_device(self, algo, k, p, seed, packed, d_out, flags=0):
+        prm = self._params(algo, k, p, seed, flags)
+        self._check(self._lib.lash_sketch_packed_device(self._h, C.byref(prm), packed._h, _ptr(d_out)))
+
+    def merge_images_device(self, algo, p, d_dst, d_src, n_images):
+        self._check(self._lib.lash_merge_images_device(self._h, _algo(algo), int(p or 0), _ptr(d_dst), _ptr(d_src),
+                                                       int(n_images)))
+
+    def merge_images(self, algo, p, dst, src):
+        """dst[i] = dst[i] U src[i] on the GPU; numpy uint8 arrays [n, image_bytes]; returns dst."""
+        assert dst.dtype == np.uint8 and src.dtype == np.uint8 and dst.shape == src.shape
+        assert dst.flags.c_contiguous and src.flags.c_contiguous
+        n = dst.shape[0] if dst.ndim == 2 else 1
+        self._check(self._lib.lash_merge_images(self._h, _algo(algo), int(p or 0), dst.ctypes.data, src.ctypes.data, n))
+        return dst
+
+    def synth_genomes_device(self, first_genome, n_genomes, n_bases, d_out):
+        self._check(self._lib.lash_synth_genomes_device(self._h, int(first_genome), int(n_genomes), int(n_bases),
+                                                        _ptr(d_out)))

@@ -1,0 +1,263 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): liblash_gfx950.so, called through its C ABI, must give
+bit-identical sketch images to the CPU oracle on the same inputs."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fastx import read_fastx
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALGO = {"hmh": 0, "hll": 1, "ull": 2}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lash_amd
+    c = lash_amd.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_images(algo, k, p, seed, seq, rec_off, goff, x_low=0):
+    return O.sketch_genomes(algo, k, p, seed, seq, rec_off, goff, threads=8, hmh_x_is_low=x_low)
+
+
+def assert_same(got, want, what=""):
+    assert got.shape == want.shape, what
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("%s: %d bytes differ, first at %s (got %d want %d)" % (
+            what, len(bad), bad[0], got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+def messy_genomes(rng, n_genomes, max_rec=6, max_len=3000):
+    alphabet = "ACGT" * 12 + "NnacgtRYKM-"
+    gs = []
+    for _ in range(n_genomes):
+        recs = []
+        for _ in range(rng.randint(0, max_rec)):
+            mode = rng.random()
+            n = rng.randint(0, max_len)
+            if mode < 0.5:
+                s = "".join(rng.choice("ACGT") for _ in range(n))
+            elif mode < 0.8:
+                s = "".join(rng.choice(alphabet) for _ in range(n))
+            elif mode < 0.9:
+                s = "N" * n
+            else:
+                s = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, 40)))
+            recs.append(s.encode())
+        gs.append(recs)
+    return gs
+
+
+def test_fixture_files_match_oracle_and_digests(ctx):
+    import lash_amd
+    want_dig = json.load(open(os.path.join(GOLD, "fixture_digests.json")))
+    for key, dig in sorted(want_dig.items()):
+        name, an, k, p, _ = key.split("|")
+        k, p = int(k[1:]), int(p[1:])
+        recs = read_fastx(os.path.join(GOLD, name))
+        seq, off, goff = lash_amd.records_to_arrays([recs])
+        img = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+        assert hashlib.sha256(img[0].tobytes()).hexdigest() == dig, key
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 8, 0), ("hmh", 15, 0), ("hmh", 17, 0), ("hmh", 32, 0),
+                                    ("hll", 21, 14), ("hll", 16, 10), ("hll", 5, 4), ("hll", 31, 15), ("hll", 32, 12),
+                                    ("ull", 16, 12), ("ull", 1, 3), ("ull", 19, 14), ("ull", 27, 8), ("ull", 32, 10)])
+def test_messy_batches_match_oracle(ctx, an, k, p):
+    import lash_amd
+    rng = random.Random(hash((an, k, p)) & 0xFFFF)
+    gs = messy_genomes(rng, 23)
+    gs[5] = []                              # genome without records
+    gs[7] = [b"", b"", b"ACGT"]             # empty records
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
+    assert_same(got, want, "%s k=%d p=%d" % (an, k, p))
+
+
+@pytest.mark.parametrize("k", list(range(1, 33)))
+def test_every_k_hmh_and_ull(ctx, k):
+    import lash_amd
+    rng = random.Random(77 + k)
+    gs = messy_genomes(rng, 6, max_rec=4, max_len=1500)
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    for an, p in (("hmh", 0), ("ull", 9), ("hll", 8)):
+        got = ctx.sketch_batch(an, k, p, 1234567, seq, off, goff)
+        want = oracle_images(ALGO[an], k, p, 1234567, seq, off, goff)
+        assert_same(got, want, "%s k=%d" % (an, k))
+
+
+@pytest.mark.parametrize("seed", [0, 42, 93, 2**63 + 5, 2**64 - 1])
+def test_seeds(ctx, seed):
+    import lash_amd
+    gs = [[O.synth_genome(g, 30000).tobytes()] for g in range(3)]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    for an, k, p in (("hmh", 16, 0), ("hll", 21, 12), ("ull", 16, 12)):
+        assert_same(ctx.sketch_batch(an, k, p, seed, seq, off, goff),
+                    oracle_images(ALGO[an], k, p, seed, seq, off, goff), "%s seed=%d" % (an, seed))
+
+
+def test_hmh_x_low_switch(ctx):
+    import lash_amd
+    gs = [[O.synth_genome(9, 50000).tobytes()]]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    got = ctx.sketch_batch("hmh", 16, 0, 42, seq, off, goff, flags=lash_amd.F_HMH_X_LOW)
+    assert_same(got, oracle_images(0, 16, 0, 42, seq, off, goff, x_low=1), "x_low")
+    assert not np.array_equal(got, ctx.sketch_batch("hmh", 16, 0, 42, seq, off, goff))
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hll", 21, 14), ("ull", 16, 12), ("hmh", 31, 0), ("ull", 11, 14)])
+def test_multi_slice_genomes(ctx, an, k, p):
+    """Genomes long enough to be cut into several workgroup slices and many lane tiles; N runs and record
+    boundaries placed near slice/tile/word boundaries."""
+    import lash_amd
+    rng = np.random.default_rng(11)
+    g0 = O.synth_genome(100, 3_000_000)
+    g1 = O.synth_genome(101, 1_234_567).copy()
+    g1[500_000:500_777] = ord("N")
+    g1[1_000_001] = ord("n")
+    cuts = [0, 15, 16, 17, 31, 32, 33, 4095, 4096, 4097, 32768, 32769, 262144 - 1, 262144, 262144 + 1, 700_000, 1_234_567]
+    recs1 = [g1[a:b].tobytes() for a, b in zip(cuts[:-1], cuts[1:])]
+    g2 = O.synth_genome(102, 70_001)
+    seq, off, goff = lash_amd.records_to_arrays([[g0.tobytes()], recs1, [g2.tobytes()]])
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
+    assert_same(got, want, "%s k=%d p=%d" % (an, k, p))
+
+
+def test_short_reads_fastq_like(ctx):
+    """cfg5 shape: thousands of 150-bp reads, some with N, into one sketch."""
+    import lash_amd
+    rng = random.Random(5)
+    reads = []
+    for i in range(4000):
+        r = [rng.choice("ACGT") for _ in range(150)]
+        if i % 17 == 0:
+            r[rng.randrange(150)] = "N"
+        if i % 501 == 0:
+            r = r[:12]
+        reads.append("".join(r).encode())
+    seq, off, goff = lash_amd.records_to_arrays([reads])
+    for an, k, p in (("ull", 16, 12), ("hmh", 16, 0), ("hll", 21, 10), ("ull", 31, 12)):
+        assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), oracle_images(ALGO[an], k, p, 42, seq, off, goff), an)
+
+
+@pytest.mark.parametrize("an,k,p", [("hll", 16, 16), ("ull", 16, 15), ("ull", 21, 18), ("ull", 9, 20)])
+def test_global_register_variant(ctx, an, k, p):
+    """2^p registers that do not fit in LDS live in HBM/L2 and are updated with global atomics."""
+    import lash_amd
+    gs = [[O.synth_genome(7, 200_000).tobytes()], [b"ACGTNACGT" * 50], []]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), oracle_images(ALGO[an], k, p, 42, seq, off, goff), an)
+
+
+def test_parameter_errors_mirror_reference_panics(ctx):
+    import lash_amd
+    seq, off, goff = lash_amd.records_to_arrays([[b"ACGT" * 10]])
+    for an, k, p in (("hmh", 0, 0), ("hmh", 33, 0), ("hll", 16, 3), ("hll", 16, 17), ("ull", 16, 2), ("ull", 16, 27)):
+        with pytest.raises(lash_amd.LashError) as e:
+            ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+        assert e.value.code == lash_amd.EINVAL
+    with pytest.raises(lash_amd.LashError):
+        ctx.sketch_batch("minhash", 16, 0, 42, seq, off, goff)
+
+
+def test_empty_batch_and_empty_genomes(ctx):
+    import lash_amd
+    seq, off, goff = lash_amd.records_to_arrays([])
+    assert ctx.sketch_batch("hmh", 16, 0, 42, seq, off, goff).shape == (0, 32768)
+    seq, off, goff = lash_amd.records_to_arrays([[], [b""], [b"NNNN"], [b"ACG"]])
+    for an, k, p in (("hmh", 16, 0), ("hll", 16, 10), ("ull", 16, 10)):
+        assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), oracle_images(ALGO[an], k, p, 42, seq, off, goff), an)
+
+
+def test_merge_and_accumulate(ctx):
+    import lash_amd
+    a = [[O.synth_genome(g, 40000).tobytes()] for g in range(4)]
+    b = [[O.synth_genome(50 + g, 25000).tobytes()] for g in range(4)]
+    sa, oa, ga = lash_amd.records_to_arrays(a)
+    sb, ob, gb = lash_amd.records_to_arrays(b)
+    both = [x + y for x, y in zip(a, b)]
+    sc, oc, gc = lash_amd.records_to_arrays(both)
+    for an, k, p in (("hmh", 16, 0), ("hll", 21, 14), ("ull", 16, 12), ("ull", 16, 16)):
+        ia = ctx.sketch_batch(an, k, p, 42, sa, oa, ga)
+        ib = ctx.sketch_batch(an, k, p, 42, sb, ob, gb)
+        whole = oracle_images(ALGO[an], k, p, 42, sc, oc, gc)
+        merged = ctx.merge_images(an, p, ia.copy(), ib)
+        assert_same(merged, whole, "merge " + an)
+        for i in range(4):
+            assert np.array_equal(O.merge_images(ALGO[an], p, ia[i], ib[i]), whole[i])
+        acc = ctx.sketch_batch(an, k, p, 42, sb, ob, gb, flags=lash_amd.F_ACCUMULATE, out=ia.copy())
+        assert_same(acc, whole, "accumulate " + an)
+        again = ctx.sketch_batch(an, k, p, 42, sb, ob, gb, flags=lash_amd.F_ACCUMULATE, out=acc.copy())
+        assert_same(again, whole, "idempotent " + an)
+
+
+def test_device_entries_and_synth_generator(ctx):
+    import torch
+    import lash_amd
+    n_g, L = 6, 100_003
+    d_seq = torch.empty(n_g * L, dtype=torch.uint8, device="cuda:0")
+    ctx.synth_genomes_device(1000, n_g, L, d_seq)
+    ctx.synchronize()
+    host = d_seq.cpu().numpy()
+    for g in range(n_g):
+        assert np.array_equal(host[g * L:(g + 1) * L], O.synth_genome(1000 + g, L)), g
+    rec_off = (np.arange(n_g + 1, dtype=np.uint64) * L)
+    goff = np.arange(n_g + 1, dtype=np.uint64)
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to("cuda:0")
+    ib = lash_amd.image_bytes("hmh")
+    d_out = torch.zeros(n_g * ib, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()                 # torch's fill runs on its own stream
+    ctx.enable_timing(True)
+    ctx.sketch_batch_device("hmh", 16, 0, 42, d_seq, d_rec, n_g, goff, rec_off, d_out)
+    t = ctx.timing()
+    want = oracle_images(0, 16, 0, 42, host, rec_off, goff)
+    assert_same(d_out.cpu().numpy().reshape(n_g, ib), want, "device entry")
+    assert t["kmers"] == n_g * (L - 15) and t["bases_last"] == n_g * L and t["calls"] == 1
+    assert t["sketch_ms"] > 0 and t["pack_ms"] > 0
+    # two-stage form: pack once, sketch with several parameter sets
+    pk = ctx.pack_device(d_seq, d_rec, n_g, goff, rec_off)
+    for an, k, p in (("hll", 21, 14), ("ull", 16, 12), ("hmh", 24, 0)):
+        ibx = lash_amd.image_bytes(an, p)
+        d_o = torch.zeros(n_g * ibx, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.sketch_packed_device(an, k, p, 42, pk, d_o)
+        ctx.synchronize()
+        assert_same(d_o.cpu().numpy().reshape(n_g, ibx), oracle_images(ALGO[an], k, p, 42, host, rec_off, goff), an)
+    pk.free()
+    ctx.enable_timing(False)
+
+
+def test_runs_on_callers_stream(ctx):
+    import torch
+    import lash_amd
+    s = torch.cuda.Stream()
+    ctx.set_stream(s)
+    gs = [[O.synth_genome(3, 50000).tobytes()]]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    got = ctx.sketch_batch("ull", 16, 12, 42, seq, off, goff)
+    ctx.set_stream(None)
+    assert_same(got, oracle_images(2, 16, 12, 42, seq, off, goff), "stream")
+
+
+def test_kmer_census_with_messy_records(ctx):
+    import lash_amd
+    rng = random.Random(3)
+    gs = messy_genomes(rng, 9)
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    for k in (1, 7, 16, 21, 32):
+        want = sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+        ctx.enable_timing(True)
+        ctx.sketch_batch("hmh", k, 0, 42, seq, off, goff)
+        assert ctx.timing()["kmers"] == want, k
+    ctx.enable_timing(False)

@@ -1,0 +1,187 @@
+// ubench.hip — instruction-rate microbenchmarks that price the sketch kernel's inner loop on gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip ; run on the GPU box.
+// Prints cycles per wave-instruction per SIMD (s_memtime ticks) for 1 and 4 waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+enum Op { OP_XOR, OP_ALIGNBIT, OP_MUL_LO, OP_MUL_HI, OP_MAD_U64, OP_MUL_U24, OP_MAD_U24, OP_LSHR64, OP_ADD64, OP_FFBH, OP_BFE,
+          OP_DS_MAX_RAND, OP_DS_MAX_SAME, OP_DS_OR_RAND, OP_DS_ADD_SEQ, OP_XOR3LIKE, OP_PERM, OP_COUNT };
+static const char *names[] = {"v_xor_b32", "v_alignbit_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mul_u32_u24",
+                              "v_mad_u32_u24", "v_lshrrev_b64", "v_lshl_add_u64", "v_ffbh_u32", "v_bfe_u32",
+                              "ds_max_u32 random", "ds_max_u32 same-addr", "ds_or_b32 random", "ds_add_u32 lane-seq",
+                              "v_bitop3/xor3", "v_perm_b32"};
+
+template <int OP>
+__global__ void __launch_bounds__(1024) bench(unsigned long long *cycles, uint32_t *sink, int iters)
+{
+    __shared__ uint32_t lds[16384];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    uint32_t a0 = threadIdx.x * 2654435761u + 1, a1 = a0 ^ 0x9E3779B9u, a2 = a0 * 3 + 7, a3 = a1 * 5 + 11;
+    uint32_t a4 = a0 + 0x1234567, a5 = a1 + 0x7654321, a6 = a2 ^ 0xdeadbeef, a7 = a3 ^ 0xcafebabe;
+    uint64_t b0 = a0, b1 = a1, b2 = a2, b3 = a3, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
+    const uint32_t c = 0x85EBCA97u + blockIdx.x;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#define R8(STMT) STMT(a0, b0) STMT(a1, b1) STMT(a2, b2) STMT(a3, b3) STMT(a4, b4) STMT(a5, b5) STMT(a6, b6) STMT(a7, b7)
+        if constexpr (OP == OP_XOR) {
+#define S(a, b) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_ALIGNBIT) {
+#define S(a, b) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_MUL_LO) {
+#define S(a, b) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_MUL_HI) {
+#define S(a, b) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_MAD_U64) {
+#define S(a, b) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(b) : "v"(a), "v"(c) : "vcc");
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_MUL_U24) {
+#define S(a, b) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_MAD_U24) {
+#define S(a, b) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_LSHR64) {
+#define S(a, b) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(b)); asm volatile("v_or_b32 %0, %1, %0" : "+v"(a) : "v"(c));
+            R8(S)
+#undef S
+#define S(a, b) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(b));
+            R8(S)
+#undef S
+        } else if constexpr (OP == OP_ADD64) {
+#define S(a, b) asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(b));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_FFBH) {
+#define S(a, b) asm volatile("v_ffbh_u32 %0, %0" : "+v"(a));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_BFE) {
+#define S(a, b) asm volatile("v_bfe_u32 %0, %0, 3, 20" : "+v"(a));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_XOR3LIKE) {
+#define S(a, b) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a) : "v"(c), "v"(a7));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_PERM) {
+#define S(a, b) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a) : "v"(c), "v"(a7));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_DS_MAX_RAND || OP == OP_DS_OR_RAND) {
+            // 16 LDS atomics per iteration on pseudo-random dword addresses (xorshift per lane), no return value
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                a0 ^= a0 << 13; a0 ^= a0 >> 17; a0 ^= a0 << 5;
+                uint32_t addr = (a0 >> 8) & (16383u << 2);
+                if constexpr (OP == OP_DS_MAX_RAND) asm volatile("ds_max_u32 %0, %1" :: "v"(addr), "v"(a0) : "memory");
+                else asm volatile("ds_or_b32 %0, %1" :: "v"(addr), "v"(a0) : "memory");
+            }
+        } else if constexpr (OP == OP_DS_MAX_SAME) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                a0 ^= a0 << 13; a0 ^= a0 >> 17; a0 ^= a0 << 5;
+                uint32_t addr = (uint32_t)j * 4;
+                asm volatile("ds_max_u32 %0, %1" :: "v"(addr), "v"(a0) : "memory");
+            }
+        } else if constexpr (OP == OP_DS_ADD_SEQ) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                a0 ^= a0 << 13; a0 ^= a0 >> 17; a0 ^= a0 << 5;
+                uint32_t addr = ((threadIdx.x & 63) * 4 + j * 256) & 65535u;
+                asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(a0) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    uint32_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7) ^ (uint32_t)((b0 ^ b7) >> 32);
+    if (r == 0x12345) sink[0] = r + lds[threadIdx.x];
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template <int OP>
+void run(int threads, int iters, unsigned long long *d_cyc, uint32_t *d_sink)
+{
+    const int blocks = 256;    // one workgroup per CU
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(threads), 0, 0, d_cyc, d_sink, iters / 4);   // warm-up
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(threads), 0, 0, d_cyc, d_sink, iters);
+    CHK(hipEventRecord(e1));
+    CHK(hipDeviceSynchronize());
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    int nw = blocks * threads / 64;
+    std::vector<unsigned long long> h(nw);
+    CHK(hipMemcpy(h.data(), d_cyc, nw * 8, hipMemcpyDeviceToHost));
+    double avg = 0; for (auto v : h) avg += (double)v; avg /= nw;
+    const double per_wave_instr = avg / ((double)iters * 16.0);            // memtime ticks (100 MHz const clock? see below)
+    const int waves_per_simd = threads / 256;
+    // s_memtime on gfx9 counts at a constant 100 MHz; convert with the wall time of the same launch
+    const double instr_total = (double)iters * 16.0 * nw;                   // wave-instructions
+    const double ns_per_instr_per_simd = (double)ms * 1e6 / (instr_total / (256.0 * 4.0));
+    printf("%-24s waves/SIMD=%d  %8.3f ns per wave-instr per SIMD  (= %6.2f cycles @2.4GHz)   memtime ticks/instr/wave=%.3f\n",
+           names[OP], waves_per_simd, ns_per_instr_per_simd, ns_per_instr_per_simd * 2.4, per_wave_instr);
+}
+
+template <int OP> void both(unsigned long long *c, uint32_t *s) { run<OP>(256, 4000, c, s); run<OP>(1024, 4000, c, s); }
+
+__global__ void copy_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = in[i];
+}
+__global__ void read_kernel(const uint4 *__restrict__ in, uint32_t *out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i < n; i += stride) { uint4 v = in[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x1234567) out[0] = acc;
+}
+
+int main()
+{
+    unsigned long long *d_cyc; uint32_t *d_sink;
+    CHK(hipMalloc(&d_cyc, 256 * 16 * 8)); CHK(hipMalloc(&d_sink, 4096));
+    hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
+    printf("device: %s  CUs=%d  clock=%d kHz  LDS/block=%zu\n", p.name, p.multiProcessorCount, p.clockRate, p.sharedMemPerBlock);
+    both<OP_XOR>(d_cyc, d_sink); both<OP_ALIGNBIT>(d_cyc, d_sink); both<OP_MUL_LO>(d_cyc, d_sink); both<OP_MUL_HI>(d_cyc, d_sink);
+    both<OP_MAD_U64>(d_cyc, d_sink); both<OP_MUL_U24>(d_cyc, d_sink); both<OP_MAD_U24>(d_cyc, d_sink); both<OP_LSHR64>(d_cyc, d_sink);
+    both<OP_ADD64>(d_cyc, d_sink); both<OP_FFBH>(d_cyc, d_sink); both<OP_BFE>(d_cyc, d_sink); both<OP_XOR3LIKE>(d_cyc, d_sink);
+    both<OP_PERM>(d_cyc, d_sink);
+    both<OP_DS_MAX_RAND>(d_cyc, d_sink); both<OP_DS_MAX_SAME>(d_cyc, d_sink); both<OP_DS_OR_RAND>(d_cyc, d_sink); both<OP_DS_ADD_SEQ>(d_cyc, d_sink);
+    // HBM copy / read bandwidth (2 GiB buffers, beyond the 256 MiB Infinity Cache)
+    size_t bytes = (size_t)2 << 30;
+    uint4 *a, *b; CHK(hipMalloc(&a, bytes)); CHK(hipMalloc(&b, bytes));
+    CHK(hipMemset(a, 1, bytes)); CHK(hipMemset(b, 2, bytes));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CHK(hipEventRecord(e0));
+        hipLaunchKernelGGL(copy_kernel, dim3(256 * 8), dim3(256), 0, 0, a, b, bytes / 16);
+        CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
+        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("copy  2 GiB: %.3f ms  %.2f TB/s (read+write)\n", ms, 2.0 * bytes / ms / 1e9);
+        CHK(hipEventRecord(e0));
+        hipLaunchKernelGGL(read_kernel, dim3(256 * 8), dim3(256), 0, 0, a, d_sink, bytes / 16);
+        CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("read  2 GiB: %.3f ms  %.2f TB/s\n", ms, (double)bytes / ms / 1e9);
+    }
+    return 0;
+}
