@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "liblash_gfx950.so")
+LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx950.so")   # override: A/B builds
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT = 0, -1, -2, -3, -4, -5
 HMH, HLL, ULL = 0, 1, 2

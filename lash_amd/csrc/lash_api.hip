@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -42,8 +43,10 @@ struct HostStage {
 struct lash_packed {
     uint32_t n_genomes = 0;
     DevBuf words, brk, nvalid, descs;
+    DevBuf tile_begin, tiles, lookback;   // pack scratch (lookback: descriptors + flag + ticket counters)
     uint64_t total_words = 0, total_brk = 0;
     std::vector<uint64_t> byte_len;      // per genome, host copy (upper bound of surviving bases)
+    uint32_t *error_flag = nullptr;      // device word set by the pack kernel if a look-back spin hit its bound
     bool owned_by_ctx = false;           // the scratch instance reused by lash_sketch_batch_device
 };
 
@@ -187,14 +190,33 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, const uint8_t *d_seq, const uint64
     pk->n_genomes = n_genomes;
     pk->total_words = wo + 2 * PAD_WORDS;
     pk->total_brk = bo + 4;
+    // tiles of the single-pass pack: genomes are cut at 16-byte-aligned addresses, tiles never straddle genomes
+    const uint64_t tile_bytes = pack_v2_tile_bytes();
+    std::vector<uint32_t> tile_begin(n_genomes + 1, 0);
+    uint64_t n_tiles = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        tile_begin[g] = (uint32_t)n_tiles;
+        if (descs[g].byte_len) {
+            const uint64_t lead = (reinterpret_cast<uintptr_t>(d_seq) + descs[g].byte_off) & 15u;
+            n_tiles += (lead + descs[g].byte_len + tile_bytes - 1) / tile_bytes;
+        }
+        if (n_tiles > 0x7FFFFFFFull) return LASH_ELIMIT;
+    }
+    tile_begin[n_genomes] = (uint32_t)n_tiles;
     int rc;
     if ((rc = reserve(ctx, pk->words, pk->total_words * 4))) return rc;
     if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
     if ((rc = reserve(ctx, pk->nvalid, (size_t)(n_genomes + 1) * 8))) return rc;
     if ((rc = reserve(ctx, pk->descs, (size_t)(n_genomes + 1) * sizeof(GenomeDesc)))) return rc;
+    if ((rc = reserve(ctx, pk->tile_begin, (size_t)(n_genomes + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
+    if ((rc = reserve(ctx, pk->lookback, (size_t)(n_tiles + 2) * 8 + PACK_TICKET_SHARDS * 128 + 256))) return rc;
     if (n_genomes == 0) return LASH_OK;
     if ((rc = upload(ctx, pk->descs.ptr, descs.data(), descs.size() * sizeof(GenomeDesc)))) return rc;
+    if ((rc = upload(ctx, pk->tile_begin.ptr, tile_begin.data(), tile_begin.size() * 4))) return rc;
     HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(pk->nvalid.ptr, 0, (size_t)(n_genomes + 1) * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, (size_t)(n_tiles + 2) * 8 + PACK_TICKET_SHARDS * 128 + 256, ctx->stream));
     PackArgs pa{};
     pa.seq = d_seq;
     pa.seq_end = d_seq + genome_byte_off[n_genomes];
@@ -203,7 +225,23 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, const uint8_t *d_seq, const uint64
     pa.words = static_cast<uint32_t *>(pk->words.ptr);
     pa.brk = static_cast<uint32_t *>(pk->brk.ptr);
     pa.nvalid = static_cast<uint64_t *>(pk->nvalid.ptr);
-    HIPCHK(ctx, launch_pack(pa, n_genomes, ctx->stream));
+    uint64_t *lb = static_cast<uint64_t *>(pk->lookback.ptr);
+    PackV2Args v2{};
+    v2.tiles = static_cast<const TileInfo *>(pk->tiles.ptr);
+    v2.desc = lb;
+    v2.error_flag = reinterpret_cast<uint32_t *>(lb + n_tiles);
+    v2.ticket = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(lb + n_tiles + 1) + 127) & ~(uintptr_t)127);
+    v2.n_tiles = (uint32_t)n_tiles;
+    PackMapArgs pm{};
+    pm.seq = d_seq;
+    pm.rec_off = d_rec_off;
+    pm.genomes = pa.genomes;
+    pm.tile_begin = static_cast<const uint32_t *>(pk->tile_begin.ptr);
+    pm.tiles = static_cast<TileInfo *>(pk->tiles.ptr);
+    pm.n_tiles = (uint32_t)n_tiles;
+    pm.n_genomes = n_genomes;
+    HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, ctx->stream));
+    pk->error_flag = v2.error_flag;
     return LASH_OK;
 }
 
@@ -214,7 +252,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     const uint64_t image_bytes = lash_sketch_image_bytes(prm->algo, prm->p);
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
-    const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(plan.lds_bytes, 1u)) : 4u;
+    const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(plan.lds_bytes, 1u)) : 4u;   // 64 KiB + census -> 2
     const uint64_t slots = (uint64_t)ctx->cu_count * std::min(wg_per_cu, 2048u / plan.threads);
     uint64_t total_words = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) total_words += (pk->byte_len[g] + 15) / 16;
@@ -378,7 +416,8 @@ void lash_ctx_destroy(lash_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
-                      &ctx->st_img, &ctx->scratch.words, &ctx->scratch.brk, &ctx->scratch.nvalid, &ctx->scratch.descs})
+                      &ctx->st_img, &ctx->scratch.words, &ctx->scratch.brk, &ctx->scratch.nvalid, &ctx->scratch.descs,
+                      &ctx->scratch.tile_begin, &ctx->scratch.tiles, &ctx->scratch.lookback})
         release(*b);
     for (auto &s : ctx->ev_pool)
         for (auto &e : s.e)
@@ -406,11 +445,21 @@ int lash_ctx_set_stream(lash_ctx *ctx, void *hip_stream)
     return LASH_OK;
 }
 
+static int check_pack_flag(lash_ctx *ctx, const lash_packed *pk)
+{
+    if (!pk || !pk->error_flag) return LASH_OK;
+    uint32_t f = 0;
+    HIPCHK(ctx, hipMemcpy(&f, pk->error_flag, 4, hipMemcpyDeviceToHost));
+    if (f) { ctx->err = "pack kernel: look-back spin bound exceeded (results invalid)"; return LASH_EHIP; }
+    return LASH_OK;
+}
+
 int lash_ctx_synchronize(lash_ctx *ctx)
 {
     if (!ctx) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return LASH_OK;
+    return check_pack_flag(ctx, ctx->last_packed);
 }
 
 const char *lash_ctx_last_error(lash_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
@@ -482,10 +531,8 @@ void lash_packed_free(lash_ctx *ctx, lash_packed *pk)
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         if (ctx->last_packed == pk) ctx->last_packed = nullptr;
     }
-    release(pk->words);
-    release(pk->brk);
-    release(pk->nvalid);
-    release(pk->descs);
+    for (DevBuf *b : {&pk->words, &pk->brk, &pk->nvalid, &pk->descs, &pk->tile_begin, &pk->tiles, &pk->lookback})
+        release(*b);
     delete pk;
 }
 
@@ -548,7 +595,7 @@ int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq,
     if (rc) return rc;
     if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return LASH_OK;
+    return check_pack_flag(ctx, &ctx->scratch);
 }
 
 int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, const uint8_t *d_src, uint64_t n_images)

@@ -63,7 +63,40 @@ struct PackArgs {
     uint32_t         *brk;        // zeroed before the launch
     uint64_t         *nvalid;
 };
-hipError_t launch_pack(const PackArgs &args, uint32_t n_genomes, hipStream_t stream);
+// one 16 KiB tile of one genome (filled by pack_map_kernel)
+struct TileInfo {
+    int64_t  toff;      // first byte of the tile, relative to seq (16-byte aligned address; may be < byte_off)
+    uint64_t r0;        // first record starting at or after toff
+    uint32_t nrec;      // records starting inside the tile
+    uint32_t g;         // genome
+    uint32_t tb;        // first tile of that genome (look-back stops there)
+    int32_t  rel_lo;    // genome bytes occupy [rel_lo, rel_hi) of the tile
+    int32_t  rel_hi;
+    uint32_t flags;     // TF_FIRST | TF_LAST | TF_FULL
+    uint32_t pad;
+    uint64_t word_off;  // the genome's offsets into words[] / brk[] (copied from GenomeDesc: saves a dependent load)
+    uint64_t brk_off;
+};
+static_assert(sizeof(TileInfo) == 64, "TileInfo is one 64-byte line");
+struct PackV2Args {
+    const TileInfo *tiles;           // n_tiles
+    uint64_t       *desc;            // n_tiles look-back descriptors, zeroed before the launch
+    uint32_t       *ticket;          // PACK_TICKET_SHARDS counters at a 128-byte stride, zeroed before the launch
+    uint32_t       *error_flag;      // zeroed; != 0 after the launch means a look-back spin hit its bound
+    uint32_t        n_tiles;
+    uint32_t        n_shards;        // set by launch_pack_v2
+};
+constexpr uint32_t PACK_TICKET_SHARDS = 16;
+struct PackMapArgs {
+    const uint8_t    *seq;
+    const uint64_t   *rec_off;
+    const GenomeDesc *genomes;
+    const uint32_t   *tile_begin;    // n_genomes + 1: first tile of each genome
+    TileInfo         *tiles;
+    uint32_t          n_tiles, n_genomes;
+};
+uint32_t   pack_v2_tile_bytes();
+hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, hipStream_t stream);
 
 // ---- synthetic genomes --------------------------------------------------------------------
 hipError_t launch_synth(uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out, hipStream_t stream);

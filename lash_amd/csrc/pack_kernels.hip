@@ -7,17 +7,21 @@
 // and remembers where each record's surviving bases begin, because k-mers never span records
 // (a fresh KSeq per record, utils.rs:457-464) but DO span deleted characters.
 //
-// v1 structure: one 256-thread workgroup walks one genome front to back in 4 KiB tiles, carrying the running
-// count of surviving bases and the not-yet-complete output word from tile to tile, so no inter-workgroup
-// communication is needed.  Parallelism = number of genomes (>= ~1000 at the BASELINE configs).
+// One pass over the batch: 1 B/base read, 0.25 B/base written.  Stream compaction needs, for every tile, the number
+// of bases that survived before it in the same genome; that prefix comes from a decoupled look-back scan
+// (Merrill & Garland) whose per-tile state is ONE naturally aligned 8-byte word
+//      bits 63:32  count   surviving bases (AGGREGATE: of this tile; INCLUSIVE: of the genome up to and incl. it)
+//      bits 31:2   tail    the last min(count,15) of those bases, last base in bits 3:2
+//      bits  1:0   status  0 = not ready, 1 = AGGREGATE, 2 = INCLUSIVE
+// written with a single agent-scope relaxed atomic store and polled with agent-scope relaxed loads (nothing else is
+// handed off, so no fence is needed).  Carrying the tail means the output word shared by two tiles is written by
+// exactly one of them (the later one): no zero-fill of the 2-bit stream, no atomics on it; only the sparse
+// record-break bits use atomicOr on a zeroed bitmap.
 #include <hip/hip_runtime.h>
 
 #include "lash_kernels.h"
 
 namespace lash {
-
-constexpr int PACK_THREADS = 256;
-constexpr int PACK_TILE = PACK_THREADS * 16;             // bytes per tile: one 16-byte load per lane
 
 // Four ASCII bytes -> four 2-bit codes (byte 0 first, in bits 7:6 of the result) and a 4-bit validity mask.
 // code = (c >> 1) & 3 maps A C T G -> 0 1 2 3; x ^ (x >> 1) swaps 2 and 3 to get kmerutils' A C G T = 0 1 2 3.
@@ -66,125 +70,419 @@ __device__ __forceinline__ Lane16 classify16(const uint4 q, uint32_t keep)
     return o;
 }
 
-__device__ __forceinline__ uint4 load16_guarded(const uint8_t *seq_lo, const uint8_t *seq_hi, const uint8_t *p)
+
+constexpr int P2_THREADS = 256;
+constexpr int P2_CHUNKS = 4;
+constexpr int P2_TILE = P2_THREADS * P2_CHUNKS * 16;       // 16 KiB of one genome: 4 coalesced 16-byte chunks per lane
+constexpr uint32_t P2_SPIN_LIMIT = 1u << 24;
+constexpr uint32_t TF_FIRST = 1u, TF_LAST = 2u, TF_FULL = 4u;
+
+__device__ __forceinline__ uint64_t desc_make(uint32_t count, uint32_t tail30, uint32_t status)
 {
-    // p is 16-byte aligned; [seq_lo, seq_hi) is the caller's buffer.  Interior chunks use one dwordx4 load.
-    if (p >= seq_lo && p + 16 <= seq_hi) return *reinterpret_cast<const uint4 *>(p);
+    return ((uint64_t)count << 32) | ((uint64_t)(tail30 & 0x3FFFFFFFu) << 2) | status;
+}
+__device__ __forceinline__ uint32_t desc_count(uint64_t d) { return (uint32_t)(d >> 32); }
+__device__ __forceinline__ uint32_t desc_tail(uint64_t d) { return ((uint32_t)d >> 2) & 0x3FFFFFFFu; }
+// A (earlier) ++ B (later): on entry (cnt, tail) is B, on exit it is the concatenation
+__device__ __forceinline__ void agg_combine(uint32_t &cnt, uint32_t &tail, uint32_t a_cnt, uint32_t a_tail)
+{
+    const uint32_t nb = cnt < 15u ? cnt : 15u;
+    tail = (uint32_t)((((uint64_t)a_tail << (2 * nb)) | tail) & 0x3FFFFFFFu);
+    cnt += a_cnt;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// map kernel: one thread per tile -> TileInfo (which genome, where in seq, which records start inside)
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_map_kernel(PackMapArgs m)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m.n_tiles) return;
+    uint32_t lo = 0, hi = m.n_genomes;                       // last g with tile_begin[g] <= t (genomes without
+    while (hi - lo > 1) {                                    // tiles share tile_begin with their successor)
+        const uint32_t mid = (lo + hi) >> 1;
+        if (m.tile_begin[mid] <= t) lo = mid; else hi = mid;
+    }
+    const uint32_t g = lo;
+    const GenomeDesc gd = m.genomes[g];
+    const uint32_t tb = m.tile_begin[g], te = m.tile_begin[g + 1];
+    const int64_t g0 = (int64_t)gd.byte_off, g1 = g0 + (int64_t)gd.byte_len;
+    const int64_t lead = (int64_t)((reinterpret_cast<uintptr_t>(m.seq) + gd.byte_off) & 15u);   // 16-B aligned loads
+    const int64_t toff = g0 - lead + (int64_t)(t - tb) * P2_TILE;                                // relative to seq
+    auto lower_bound = [&](int64_t x) {                      // first r in [rec_begin, rec_end] with rec_off[r] >= x
+        uint64_t a = gd.rec_begin, b = gd.rec_end;
+        while (a < b) {
+            const uint64_t mid = (a + b) >> 1;
+            if ((int64_t)m.rec_off[mid] < x) a = mid + 1; else b = mid;
+        }
+        return a;
+    };
+    TileInfo ti;
+    ti.toff = toff;
+    ti.r0 = lower_bound(toff);
+    const uint64_t r1 = (t + 1 < te) ? lower_bound(toff + P2_TILE) : gd.rec_end;
+    ti.nrec = (uint32_t)(r1 - ti.r0 > 0xFFFFFFFFull ? 0xFFFFFFFFull : r1 - ti.r0);
+    ti.g = g;
+    ti.tb = tb;
+    ti.rel_lo = (int32_t)(g0 > toff ? g0 - toff : 0);
+    ti.rel_hi = (int32_t)(g1 - toff < P2_TILE ? g1 - toff : P2_TILE);
+    ti.flags = (t == tb ? TF_FIRST : 0u) | (t + 1 == te ? TF_LAST : 0u) |
+               ((toff >= g0 && toff + P2_TILE <= g1) ? TF_FULL : 0u);
+    ti.pad = 0;
+    ti.word_off = gd.word_off;
+    ti.brk_off = gd.brk_off;
+    m.tiles[t] = ti;
+}
+
+// TileInfo through the vector path, then pinned into SGPRs (the index is wave-uniform): keeps two tiles' worth of
+// descriptors out of the VGPR budget
+__device__ __forceinline__ TileInfo load_tile_uniform(const TileInfo *p)
+{
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 x = q[i];
+        w[4 * i + 0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.x);
+        w[4 * i + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.y);
+        w[4 * i + 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.z);
+        w[4 * i + 3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)x.w);
+    }
+    TileInfo t;
+    t.toff = (int64_t)(((uint64_t)w[1] << 32) | w[0]);
+    t.r0 = ((uint64_t)w[3] << 32) | w[2];
+    t.nrec = w[4];
+    t.g = w[5];
+    t.tb = w[6];
+    t.rel_lo = (int32_t)w[7];
+    t.rel_hi = (int32_t)w[8];
+    t.flags = w[9];
+    t.pad = 0;
+    t.word_off = ((uint64_t)w[13] << 32) | w[12];
+    t.brk_off = ((uint64_t)w[15] << 32) | w[14];
+    return t;
+}
+
+__device__ __forceinline__ uint4 load16_clipped(const uint8_t *seq, int64_t off, int64_t seq_bytes)
+{
+    // 16 bytes at seq[off .. off+16), bytes outside [0, seq_bytes) read as 0 (only the batch's first / last chunk)
+    if (off >= 0 && off + 16 <= seq_bytes) return *reinterpret_cast<const uint4 *>(seq + off);
     uint32_t w[4] = {0, 0, 0, 0};
     for (int j = 0; j < 16; ++j) {
-        const uint8_t *b = p + j;
-        if (b >= seq_lo && b < seq_hi) w[j >> 2] |= (uint32_t)(*b) << (8 * (j & 3));
+        const int64_t o = off + j;
+        if (o >= 0 && o < seq_bytes) w[j >> 2] |= (uint32_t)seq[o] << (8 * (j & 3));
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-__global__ void __launch_bounds__(PACK_THREADS) pack_genome_kernel(PackArgs a)
+// ------------------------------------------------------------------------------------------------------------
+// the pack kernel: persistent workgroups, software-pipelined over tiles
+//
+//   iteration i:  classify(T_i) -> loads(T_i+1) go out -> stage(T_i), publish AGGREGATE(T_i)
+//                 -> look-back + publish INCLUSIVE(T_i-1) -> store(T_i-1)
+//
+// * a tile's AGGREGATE is published as soon as its bytes are classified, and its own look-back runs one iteration
+//   later, when its predecessors' aggregates are (almost always) already there: little spinning, and a drawn tile
+//   is never left idle where successors would wait on it;
+// * the next tile's 16 KiB of loads are in flight during the whole second half of the iteration.  Workgroup barriers
+//   are raw s_barrier + s_waitcnt lgkmcnt(0) (LDS only): __syncthreads() would also drain vmcnt, i.e. the prefetch.
+//
+// Tickets are sharded: workgroup b serves shard b % S, and shard s hands out tiles s, s+S, s+2S, ... in order from
+// its own counter (one L2 atomic word saturates near 88 draws/us; 16 KiB tiles need ~300/us at HBM speed).
+// Deadlock-free for ANY residency: let m be the smallest tile whose AGGREGATE is not published.  Tiles < m all have
+// aggregates, so every look-back below m terminates; m's holder therefore finishes what it does before reaching
+// m (only tiles < m), and if m is not drawn yet its shard's workgroups hold only smaller tiles.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier()
 {
-    __shared__ uint32_t stage[PACK_TILE / 16 + 4];          // tile output, assembled by LDS ORs
-    __shared__ uint32_t recbits[PACK_TILE / 32];            // which bytes of the tile start a record
-    __shared__ uint32_t wave_tot[PACK_THREADS / 64];
-
-    const GenomeDesc gd = a.genomes[blockIdx.x];
-    const uint8_t *gbeg = a.seq + gd.byte_off, *gend = gbeg + gd.byte_len;
-    const uint8_t *abeg = reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(gbeg) & ~(uintptr_t)15);
-    uint32_t *__restrict__ dstw = a.words + gd.word_off;
-    uint32_t *__restrict__ dbrk = a.brk + gd.brk_off;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-    uint64_t prefix = 0;          // surviving bases before this tile (uniform)
-    uint32_t carry_bits = 0;      // the (prefix & 15) bases not yet written, first in bits 31:30 (uniform)
-    uint64_t cursor = gd.rec_begin;
-
-    for (const uint8_t *tb = abeg; tb < gend; tb += PACK_TILE) {
-        // ---- 0. reset staging ----
-        for (uint32_t i = tid; i < PACK_TILE / 16 + 4; i += PACK_THREADS) stage[i] = 0;
-        if (tid < PACK_TILE / 32) recbits[tid] = 0;
-        __syncthreads();
-
-        // ---- 1. mark record starts that fall into this tile ----
-        const uint64_t tile_lo = (uint64_t)(tb - a.seq), tile_hi = tile_lo + PACK_TILE;   // may wrap below 0 only for tb < seq: guarded by rec_off >= byte_off
-        for (;;) {
-            const uint64_t r = cursor + tid;
-            bool in = false;
-            if (r < gd.rec_end) {
-                const uint64_t ro = a.rec_off[r];
-                if ((int64_t)(ro - tile_lo) < (int64_t)PACK_TILE) {
-                    in = true;
-                    const uint32_t off = (uint32_t)(ro - tile_lo);
-                    atomicOr(&recbits[off >> 5], 1u << (off & 31));
-                }
-            }
-            const int n_in = __syncthreads_count(in);
-            cursor += (uint64_t)n_in;
-            if (n_in < PACK_THREADS) break;
-        }
-        (void)tile_hi;
-
-        // ---- 2. classify this lane's 16 bytes ----
-        const uint8_t *p = tb + 16 * tid;
-        uint32_t keep = 0xFFFFu;
-        if (p < gbeg) { const long d = gbeg - p; keep = d >= 16 ? 0u : (0xFFFFu << d) & 0xFFFFu; }
-        if (p + 16 > gend) { const long d = gend - p; keep &= d <= 0 ? 0u : (d >= 16 ? 0xFFFFu : ((1u << d) - 1u)); }
-        Lane16 l16{0, 0, 0};
-        if (keep) l16 = classify16(load16_guarded(a.seq, a.seq_end, p), keep);
-
-        // ---- 3. exclusive scan of the survivor counts over the workgroup ----
-        uint32_t inc = l16.cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t n = __shfl_up(inc, d, 64);
-            if (lane >= (uint32_t)d) inc += n;
-        }
-        if (lane == 63) wave_tot[wid] = inc;
-        __syncthreads();
-        uint32_t wave_base = 0, tile_cnt = 0;
-#pragma unroll
-        for (int i = 0; i < PACK_THREADS / 64; ++i) {
-            const uint32_t t = wave_tot[i];
-            if (i < (int)wid) wave_base += t;
-            tile_cnt += t;
-        }
-        const uint32_t excl = wave_base + inc - l16.cnt;    // survivors of this tile before this lane
-
-        // ---- 4. record-break bits (global, sparse): position of the first survivor at/after each record start ----
-        const uint32_t rb = (recbits[tid >> 1] >> ((tid & 1) * 16)) & 0xFFFFu;
-        uint32_t m = rb;
-        while (m) {
-            const uint32_t j = (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            const uint64_t pos = prefix + excl + (uint32_t)__builtin_popcount(l16.vmask & ((1u << j) - 1u));
-            atomicOr(dbrk + (pos >> 5), 1u << (pos & 31));
-        }
-
-        // ---- 5. assemble the tile's output words in LDS ----
-        const uint32_t carry = (uint32_t)(prefix & 15);
-        if (tid == 0 && carry) atomicOr(&stage[0], carry_bits);
-        if (l16.cnt) {
-            const uint32_t q = carry + excl, wi = q >> 4, sh = (q & 15) * 2;
-            atomicOr(&stage[wi], l16.bits >> sh);
-            if (sh) atomicOr(&stage[wi + 1], l16.bits << (32 - sh));
-        }
-        __syncthreads();
-
-        // ---- 6. store the complete words, carry the rest ----
-        const uint32_t total = carry + tile_cnt, nfull = total >> 4;       // nfull <= 256
-        if (tid < nfull) dstw[(prefix >> 4) + tid] = stage[tid];
-        carry_bits = stage[nfull];
-        prefix += tile_cnt;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        if (prefix & 15) dstw[prefix >> 4] = carry_bits;     // last, partial word (zero-padded)
-        a.nvalid[blockIdx.x] = prefix;
-    }
-    // a few defined words after the end keep look-ahead reads of the sketch kernel deterministic
-    if (tid < PAD_WORDS) dstw[((prefix + 15) >> 4) + tid] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 }
 
-hipError_t launch_pack(const PackArgs &args, uint32_t n_genomes, hipStream_t stream)
+struct CarriedTile {          // what iteration i+1 needs to finish tile T_i (all wave-uniform)
+    uint64_t word_off, brk_off;
+    uint32_t t, tb, g, flags, tile_cnt, own_tail, has_rec, valid;
+};
+
+__global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, PackV2Args v)
 {
-    if (n_genomes == 0) return hipSuccess;
-    hipLaunchKernelGGL(pack_genome_kernel, dim3(n_genomes), dim3(PACK_THREADS), 0, stream, args);
+    constexpr int STAGE_WORDS = P2_TILE / 16 + 8;
+    __shared__ uint32_t stage[2][STAGE_WORDS];              // surviving bases of tile i (buffer i & 1), from bit 31 of word 0
+    __shared__ uint32_t recbits[P2_TILE / 32];              // which bytes of the current tile start a record
+    __shared__ uint32_t brkloc[2][P2_TILE / 32];            // the same in tile-local compacted positions
+    __shared__ uint32_t row_tot[P2_CHUNKS][P2_THREADS / 64];
+    __shared__ uint32_t wave_flag[P2_THREADS / 64];
+    __shared__ uint32_t s_next, s_prev_cnt, s_prev_tail, s_fail, s_own_tail;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t seq_bytes = a.seq_end - a.seq;
+    const uint32_t shard = blockIdx.x % v.n_shards;
+    uint32_t *const my_ticket = v.ticket + shard * 32u;     // 128-byte stride
+
+    auto issue_loads = [&](const TileInfo &ti, uint4 (&q)[P2_CHUNKS]) {
+        if (ti.flags & TF_FULL) {
+#pragma unroll
+            for (int c = 0; c < P2_CHUNKS; ++c)
+                q[c] = *reinterpret_cast<const uint4 *>(a.seq + ti.toff + (int64_t)((c * P2_THREADS + (int)tid) * 16));
+        } else {
+#pragma unroll
+            for (int c = 0; c < P2_CHUNKS; ++c) {
+                const int32_t cs = (c * P2_THREADS + (int)tid) * 16;
+                q[c] = (cs + 16 > ti.rel_lo && cs < ti.rel_hi) ? load16_clipped(a.seq, ti.toff + cs, seq_bytes)
+                                                                : make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: first tile, its loads, and the ticket after it ----
+    if (tid == 0) s_next = shard + v.n_shards * atomicAdd(my_ticket, 1u);
+    lds_barrier();
+    uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
+    if (t >= v.n_tiles) return;
+    TileInfo ti = load_tile_uniform(v.tiles + t);
+    uint4 q[P2_CHUNKS];
+    issue_loads(ti, q);
+    lds_barrier();                                          // everyone has read s_next
+    if (tid == 0) s_next = shard + v.n_shards * atomicAdd(my_ticket, 1u);
+
+    CarriedTile ct{};
+    bool have_cur = true;
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t buf = it & 1u;
+        uint32_t excl[P2_CHUNKS], tile_cnt = 0;
+        Lane16 l16[P2_CHUNKS];
+        const bool has_rec = have_cur && ti.nrec != 0;      // uniform
+        bool have_next = false;
+        uint32_t t_next = 0xFFFFFFFFu;
+        TileInfo ti_next = ti;
+
+        if (have_cur) {
+            // ---- 1. record starts inside this tile (sparse; most tiles have none) ----
+            if (has_rec) {
+                for (uint32_t i = tid; i < P2_TILE / 32; i += P2_THREADS) { recbits[i] = 0; brkloc[buf][i] = 0; }
+                lds_barrier();
+                for (uint64_t r = ti.r0 + tid; r < ti.r0 + ti.nrec; r += P2_THREADS) {
+                    const int64_t off = (int64_t)a.rec_off[r] - ti.toff;
+                    if (off >= 0 && off < P2_TILE) atomicOr(&recbits[off >> 5], 1u << (off & 31));
+                }
+            }
+            // ---- 2. classify (waits for this tile's loads) ----
+            bool allv = true;
+#pragma unroll
+            for (int c = 0; c < P2_CHUNKS; ++c) {
+                uint32_t keep = 0xFFFFu;
+                if (!(ti.flags & TF_FULL)) {
+                    const int32_t cs = (c * P2_THREADS + (int)tid) * 16;
+                    int32_t lo = ti.rel_lo - cs, hi = ti.rel_hi - cs;
+                    lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+                    hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+                    keep = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                }
+                l16[c] = keep ? classify16(q[c], keep) : Lane16{0, 0, 0};
+                allv = allv && l16[c].vmask == 0xFFFFu;
+            }
+            const bool wave_all = __builtin_amdgcn_ballot_w64(!allv) == 0ull;
+            if (lane == 0) wave_flag[wid] = wave_all ? 1u : 0u;
+        }
+        lds_barrier();                                      // B2: wave_flag, s_next, recbits visible
+        bool clean = false;
+        if (have_cur) {
+            clean = (wave_flag[0] & wave_flag[1] & wave_flag[2] & wave_flag[3]) != 0;
+            // ---- 3. next tile: its descriptor and its loads go out now and stay in flight ----
+            t_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
+            have_next = t_next < v.n_tiles;
+            if (have_next) {
+                ti_next = load_tile_uniform(v.tiles + t_next);
+                issue_loads(ti_next, q);
+            }
+            // ---- 4. positions inside the tile + staging of the surviving bases into stage[buf] ----
+            if (clean) {
+                // nothing was deleted: lane's chunk c is exactly word (c*256 + tid) of the tile-local stream
+                tile_cnt = P2_TILE;
+#pragma unroll
+                for (int c = 0; c < P2_CHUNKS; ++c) {
+                    const uint32_t ci = (uint32_t)(c * P2_THREADS) + tid;
+                    excl[c] = ci * 16u;
+                    stage[buf][ci] = l16[c].bits;
+                }
+                if (tid < 8) stage[buf][P2_TILE / 16 + tid] = 0;
+            } else {
+                uint32_t inc[P2_CHUNKS];
+#pragma unroll
+                for (int c = 0; c < P2_CHUNKS; ++c) inc[c] = l16[c].cnt;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                    for (int c = 0; c < P2_CHUNKS; ++c) {
+                        const uint32_t n = __shfl_up(inc[c], d, 64);
+                        if (lane >= (uint32_t)d) inc[c] += n;
+                    }
+                }
+                if (lane == 63) {
+#pragma unroll
+                    for (int c = 0; c < P2_CHUNKS; ++c) row_tot[c][wid] = inc[c];
+                }
+                for (uint32_t i = tid; i < (uint32_t)STAGE_WORDS; i += P2_THREADS) stage[buf][i] = 0;
+                lds_barrier();
+                tile_cnt = 0;
+#pragma unroll
+                for (int c = 0; c < P2_CHUNKS; ++c) {
+                    uint32_t base = tile_cnt;
+#pragma unroll
+                    for (int w = 0; w < P2_THREADS / 64; ++w) {
+                        const uint32_t x = row_tot[c][w];
+                        if (w < (int)wid) base += x;
+                        tile_cnt += x;
+                    }
+                    excl[c] = base + inc[c] - l16[c].cnt;
+                }
+#pragma unroll
+                for (int c = 0; c < P2_CHUNKS; ++c) {
+                    if (l16[c].cnt) {
+                        const uint32_t wi = excl[c] >> 4, sh = (excl[c] & 15u) * 2u;
+                        atomicOr(&stage[buf][wi], l16[c].bits >> sh);
+                        if (sh) atomicOr(&stage[buf][wi + 1], l16[c].bits << (32 - sh));
+                    }
+                }
+            }
+            // record starts -> tile-local compacted positions (the global offset is known one iteration later)
+            if (has_rec) {
+#pragma unroll
+                for (int c = 0; c < P2_CHUNKS; ++c) {
+                    const uint32_t ci = (uint32_t)(c * P2_THREADS) + tid;
+                    uint32_t m = (recbits[ci >> 1] >> ((ci & 1u) * 16u)) & 0xFFFFu;
+                    while (m) {
+                        const uint32_t jb = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        const uint32_t pos = excl[c] + (uint32_t)__builtin_popcount(l16[c].vmask & ((1u << jb) - 1u));
+                        atomicOr(&brkloc[buf][pos >> 5], 1u << (pos & 31));      // pos <= byte offset < P2_TILE
+                    }
+                }
+            }
+        }
+        lds_barrier();                                      // B3: stage[buf] complete
+
+        // ---- 5. wave 0: publish AGGREGATE(cur); draw a ticket; look back for the carried tile; publish its INCLUSIVE ----
+        if (wid == 0) {
+            uint32_t nn = 0xFFFFFFFFu;
+            uint32_t own_tail = 0;
+            if (have_cur) {
+                if (lane == 0 && have_next) nn = shard + v.n_shards * atomicAdd(my_ticket, 1u);
+                const uint32_t nb = tile_cnt < 15u ? tile_cnt : 15u;    // last min(cnt,15) staged bases, right-aligned
+                if (nb) {
+                    const uint32_t wi = (tile_cnt - 1) >> 4;
+                    const uint64_t win = ((uint64_t)(wi ? stage[buf][wi - 1] : 0u) << 32) | stage[buf][wi];
+                    const uint32_t used = ((tile_cnt - 1) & 15u) + 1u;   // bases of word wi in use
+                    own_tail = (uint32_t)((win >> (32 - 2 * used)) & ((1ull << (2 * nb)) - 1ull));
+                }
+                if (lane == 0)
+                    __hip_atomic_store(v.desc + t, desc_make(tile_cnt, own_tail, (ti.flags & TF_FIRST) ? 2u : 1u),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            uint32_t p_cnt = 0, p_tail = 0, fail = 0;
+            if (ct.valid && !(ct.flags & TF_FIRST)) {
+                int64_t j = (int64_t)ct.t - 1;              // window of 64 predecessors: lane i looks at tile j - i
+                uint32_t spins = 0;
+                for (;;) {
+                    const int64_t idx = j - (int64_t)lane;
+                    uint64_t d = desc_make(0, 0, 2u);       // before the genome's first tile: the empty prefix
+                    if (idx >= (int64_t)ct.tb) d = __hip_atomic_load(v.desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t st = (uint32_t)d & 3u;
+                    const uint64_t m_incl = __builtin_amdgcn_ballot_w64(st == 2u);
+                    const uint64_t m_none = __builtin_amdgcn_ballot_w64(st == 0u);
+                    const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
+                    const uint64_t need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+                    if (m_none & need) {                    // a needed predecessor has not published yet
+                        if (++spins > P2_SPIN_LIMIT) { fail = 1; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                        continue;
+                    }
+                    // ordered product D[first_incl] ++ ... ++ D[0] by a 6-step shuffle tree: lane i ends with
+                    // D[i+2^k-1] ++ ... ++ D[i]; lanes past the first INCLUSIVE one are the identity (0, 0)
+                    uint32_t w_cnt = (int)lane <= first_incl ? desc_count(d) : 0u;
+                    uint32_t w_tail = (int)lane <= first_incl ? desc_tail(d) : 0u;
+#pragma unroll
+                    for (int sft = 1; sft < 64; sft <<= 1) {
+                        uint32_t e_cnt = __shfl_down(w_cnt, sft, 64), e_tail = __shfl_down(w_tail, sft, 64);
+                        if (lane + (uint32_t)sft >= 64u) { e_cnt = 0; e_tail = 0; }
+                        agg_combine(w_cnt, w_tail, e_cnt, e_tail);           // lanes i+sft.. are EARLIER than lane i
+                    }
+                    w_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_cnt);
+                    w_tail = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_tail);
+                    agg_combine(p_cnt, p_tail, w_cnt, w_tail);               // the window is earlier than p
+                    if (first_incl < 64) break;
+                    j -= 64;
+                }
+                uint32_t i_cnt = ct.tile_cnt, i_tail = ct.own_tail;
+                agg_combine(i_cnt, i_tail, p_cnt, p_tail);
+                if (lane == 0 && !fail)
+                    __hip_atomic_store(v.desc + ct.t, desc_make(i_cnt, i_tail, 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (lane == 0) { s_prev_cnt = p_cnt; s_prev_tail = p_tail; s_fail = fail; s_next = nn; s_own_tail = own_tail; }
+        }
+        lds_barrier();                                      // B4
+        if (s_fail) { if (tid == 0) atomicOr(v.error_flag, 1u); return; }
+
+        // ---- 6. finish the carried tile: break bits and output words (its bases are in stage[buf ^ 1]) ----
+        if (ct.valid) {
+            const uint32_t pb = buf ^ 1u;
+            const uint32_t prev = s_prev_cnt;
+            if (ct.has_rec) {
+                for (uint32_t i = tid; i < P2_TILE / 32; i += P2_THREADS) {
+                    uint32_t m = brkloc[pb][i];
+                    while (m) {
+                        const uint32_t jb = (uint32_t)__builtin_ctz(m);
+                        m &= m - 1;
+                        const uint64_t pos = (uint64_t)prev + i * 32u + jb;
+                        atomicOr(a.brk + ct.brk_off + (pos >> 5), 1u << (pos & 31));
+                    }
+                }
+            }
+            const uint32_t carry = prev & 15u;
+            const uint32_t cw = s_prev_tail & (carry ? ((1u << (2 * carry)) - 1u) : 0u);     // right-aligned carried bases
+            const uint32_t total = carry + ct.tile_cnt;
+            const bool last_tile = (ct.flags & TF_LAST) != 0;
+            const uint32_t nout = last_tile ? (total + 15u) >> 4 : total >> 4;
+            uint32_t *dst = a.words + ct.word_off + (prev >> 4);
+            for (uint32_t jw = tid; jw < nout; jw += P2_THREADS) {
+                const uint32_t hiw = jw ? stage[pb][jw - 1] : cw;
+                const uint32_t low = stage[pb][jw];
+                dst[jw] = carry ? __builtin_amdgcn_alignbit(hiw, low, 2 * carry) : low;
+            }
+            if (last_tile) {
+                if (tid == 0) a.nvalid[ct.g] = (uint64_t)prev + ct.tile_cnt;
+                if (tid < PAD_WORDS) dst[nout + tid] = 0;      // defined look-ahead words for the sketch kernel
+            }
+        }
+        if (!have_cur) return;                              // that was the drain iteration
+
+        // ---- 7. rotate: cur becomes the carried tile ----
+        ct.word_off = ti.word_off; ct.brk_off = ti.brk_off; ct.t = t; ct.tb = ti.tb; ct.g = ti.g; ct.flags = ti.flags;
+        ct.tile_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_cnt);
+        ct.own_tail = s_own_tail;
+        ct.has_rec = has_rec ? 1u : 0u;
+        ct.valid = 1u;
+        have_cur = have_next;
+        t = t_next;
+        ti = ti_next;
+        lds_barrier();                                      // B5: s_* / recbits are rewritten by the next iteration
+    }
+}
+
+uint32_t pack_v2_tile_bytes() { return P2_TILE; }
+
+hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, hipStream_t stream)
+{
+    if (v.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_map_kernel, dim3((v.n_tiles + 255) / 256), dim3(256), 0, stream, m);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    uint32_t grid = cu_count * 8u;                             // persistent workgroups, up to 8 per CU
+    if (grid > v.n_tiles) grid = v.n_tiles;
+    PackV2Args vv = v;
+    vv.n_shards = grid < PACK_TICKET_SHARDS ? grid : PACK_TICKET_SHARDS;
+    hipLaunchKernelGGL(pack_lookback_kernel, dim3(grid), dim3(P2_THREADS), 0, stream, args, vv);
     return hipGetLastError();
 }
 

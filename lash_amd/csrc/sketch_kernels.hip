@@ -19,8 +19,10 @@
 //     value with a 0/~0 mask taken from the record-break bitmap: max(x,0) and OR 0 are no-ops (no divergence).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
+#include "lash_device.h"
 #include "lash_kernels.h"
 
 namespace lash {
@@ -28,73 +30,19 @@ namespace lash {
 enum { KM_16 = 0, KM_LT16 = 1, KM_GT16 = 2 };
 
 // ------------------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s)
-{
-    return __builtin_amdgcn_alignbit(hi, lo, s);        // ({hi,lo} >> (s & 31))[31:0]
-}
-
-// reverse complement of the 16 bases of one packed word (first base in bits 31:30 on both sides)
-__device__ __forceinline__ uint32_t rcword(uint32_t x)
-{
-    uint32_t y = __builtin_bitreverse32(~x);            // groups reversed, bits inside each group swapped
-    return ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
-}
-
-__device__ __forceinline__ uint32_t clz64_nz(uint32_t hi, uint32_t lo)
-{
-    // count leading zeros of {hi,lo}; v_ffbh_u32 returns 0xFFFFFFFF for 0, which min() discards
-    uint32_t ch = hi ? (uint32_t)__builtin_clz(hi) : 0xFFFFFFFFu;
-    uint32_t cl = lo ? (uint32_t)__builtin_clz(lo) + 32u : 64u;
-    return ch < cl ? ch : cl;
-}
-
-// XXH3-128 of the 4 little-endian bytes of w (XXH3_len_4to8_128b, len = 4), seed folded into `bitflip`.
-__device__ __forceinline__ void xxh3_128_4b(uint32_t w, uint64_t bitflip, uint64_t &lo, uint64_t &hi)
-{
-    const uint32_t a0 = w ^ (uint32_t)bitflip, a1 = w ^ (uint32_t)(bitflip >> 32);
-    constexpr uint64_t C = XXH_PRIME64_1 + 16;           // PRIME64_1 + (len << 2)
-    constexpr uint32_t c0 = (uint32_t)C, c1 = (uint32_t)(C >> 32);
-    // 64 x 64 -> 128 as four v_mad_u64_u32
-    uint64_t t = (uint64_t)a0 * c0;
-    uint64_t u = (uint64_t)a1 * c0 + (t >> 32);
-    uint64_t v = (uint64_t)a0 * c1 + (uint32_t)u;
-    uint64_t h = (uint64_t)a1 * c1 + ((u >> 32) + (v >> 32));
-    uint64_t l = (uint64_t)(uint32_t)t | (v << 32);
-    h += l << 1;
-    l ^= h >> 3;
-    l ^= l >> 35;
-    l *= XXH_PRIME_MX2;
-    l ^= l >> 28;
-    h ^= h >> 37;
-    h *= XXH_PRIME_MX1;
-    h ^= h >> 32;
-    lo = l;
-    hi = h;
-}
-
-// XXH3-64 of the 8 little-endian bytes of {v_hi,v_lo} (XXH3_len_4to8_64b, len = 8 -> XXH3_rrmxmx)
-__device__ __forceinline__ uint64_t xxh3_64_8b(uint32_t v_lo, uint32_t v_hi, uint64_t bitflip)
-{
-    // input64 = input2 + (input1 << 32): the two halves trade places
-    uint64_t h = (((uint64_t)v_lo << 32) | v_hi) ^ bitflip;
-    h ^= ((h << 49) | (h >> 15)) ^ ((h << 24) | (h >> 40));
-    h *= XXH_PRIME_MX2;
-    h ^= (h >> 35) + 8;
-    h *= XXH_PRIME_MX2;
-    return h ^ (h >> 28);
-}
-
-// ------------------------------------------------------------------------------------------------------------
 // register spaces: LDS (the normal case) or global memory (2^p too large for 160 KiB of LDS)
 // ------------------------------------------------------------------------------------------------------------
 struct LdsRegs {
     uint32_t *base;
+#ifdef LASH_ABL_NO_ATOMIC   // timing-only diagnostic build (tools/variants.sh): results are wrong by construction
+    __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const { asm volatile("" ::"v"(i), "v"(v)); }
+    __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const { asm volatile("" ::"v"(i), "v"(v)); }
+#else
     __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const
     { (void)__hip_atomic_fetch_max(base + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const
     { (void)__hip_atomic_fetch_or(base + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i]; }
 };
 struct GlobalRegs {
@@ -109,10 +57,15 @@ struct GlobalRegs {
 
 // ------------------------------------------------------------------------------------------------------------
 // the three add_kmer rules.  `vm` is 0 or ~0: invalid k-mers degrade to max(x,0) / OR 0.
+//
+// FAST: every rule needs a 64-bit count-leading-zeros whose answer is < 32 unless the top word `t` of the
+// counted value is 0 (probability 2^-32 per k-mer).  The fast form counts in the top word only
+// (one v_ffbh_u32) and returns `t`; when t == 0 it has pushed a harmless under-estimate (max) or nothing (OR),
+// and the caller re-runs the word with FAST = false — legal because max/OR are idempotent.
 // ------------------------------------------------------------------------------------------------------------
-template <int ALGO, bool XLOW, class Regs>
-__device__ __forceinline__ void add_kmer(const Regs &regs, uint32_t c_lo, uint32_t c_hi, uint32_t vm,
-                                         uint64_t bitflip, int p)
+template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs>
+__device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, uint32_t c_hi, uint32_t vm,
+                                             uint64_t bitflip, int p)
 {
     if constexpr (ALGO == 0) {
         // utils.rs:395-398: Sketch::add_bytes_with_seed(&(masked as u32).to_le_bytes(), seed)
@@ -122,30 +75,52 @@ __device__ __forceinline__ void add_kmer(const Regs &regs, uint32_t c_lo, uint32
         const uint64_t x = XLOW ? lo : hi, y = XLOW ? hi : lo;
         const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x;
         const uint32_t bucket = xh >> 18;                                    // x >> 50
-        const uint32_t th = alignbit(xh, xl, 18);                            // ((x << 14) ^ 0x3FFF) high word
-        const uint32_t tl = (xl << 14) | 0x3FFFu;                            // ... low word, never 0
-        const uint32_t lz = clz64_nz(th, tl) + 1;                            // 1..=51
-        const uint32_t reg = ((lz << 10) | ((uint32_t)y & 0x3FFu)) & vm;
+        const uint32_t th = alignbit(xh, xl, 18);                            // high word of (x << 14) ^ 0x3FFF
+        uint32_t lzm1;                                                        // lz - 1; FAST with th == 0: 0xFFFFFFFF, so
+                                                                              // reg wraps to sig alone (an under-estimate)
+        if constexpr (FAST) {
+            lzm1 = ffbh_u32(th);
+        } else {
+            const uint32_t tl = (xl << 14) | 0x3FFFu;                        // low word, never 0
+            lzm1 = clz64_nz(th, tl);
+        }
+        uint32_t reg = ((lzm1 << 10) | ((uint32_t)y & 0x3FFu)) + 0x400u;              // (lz << 10) | sig, lz = 1..=51
+        if constexpr (MASKED) reg &= vm;
         regs.umax(bucket, reg);
+        return th;
     } else if constexpr (ALGO == 1) {
         // utils.rs:411-413: push_hash64(xxh3_64(masked.to_le_bytes(), seed)): bucket = low p bits,
         // rho = 1 + leading zeros of the remaining 64-p bits = clz64(h | (2^p - 1)) + 1
         const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
+        const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
         const uint32_t pm = (1u << p) - 1u;
-        const uint32_t j = (uint32_t)h & pm;
-        const uint32_t rho = clz64_nz((uint32_t)(h >> 32), (uint32_t)h | pm) + 1;
-        regs.umax(j, rho & vm);
+        const uint32_t j = hl & pm;
+        uint32_t rho;
+        if constexpr (FAST) rho = ffbh_u32(hh) + 1u;                         // hh == 0 -> 0 (an under-estimate)
+        else rho = clz64_nz(hh, hl | pm) + 1u;
+        if constexpr (MASKED) rho &= vm;
+        regs.umax(j, rho);
+        return hh;
     } else {
         // utils.rs:427-429: UltraLogLog::add(h): idx = top p bits, bit (nlz + p - 1) of the register's prefix
         // bitmap; sequential pack(unpack(old) | bit) == pack(OR of all bits), so OR now, pack later
         const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
         const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
-        const uint32_t idx = hh >> (32 - p) >> 0;                            // p <= 26 < 32
-        const uint64_t t = (h << p) | ((1ull << p) - 1ull);                  // ~(~h << p)
-        const uint32_t nlz = clz64_nz((uint32_t)(t >> 32), (uint32_t)t);    // 0..=64-p
-        const uint32_t bit = nlz + (uint32_t)p - 1u;                         // p-1..=63
-        (void)hl;
-        regs.bor(idx * 2u + (bit >> 5), (1u << (bit & 31u)) & vm);
+        const uint32_t idx = hh >> (32 - p);                                 // p <= 26 < 32
+        const uint32_t th = alignbit(hh, hl, 32 - p);                        // high word of ~(~h << p), p >= 3
+        uint32_t bit, one;
+        if constexpr (FAST) {
+            bit = ffbh_u32(th) + (uint32_t)p - 1u;                           // valid when th != 0
+            one = th < 1u ? th : 1u;                                          // th == 0 -> push nothing
+        } else {
+            const uint32_t tl = (hl << p) | pm_of(p);
+            bit = clz64_nz(th, tl) + (uint32_t)p - 1u;                       // nlz 0..=64-p -> bit p-1..=63
+            one = 1u;
+        }
+        uint32_t val = one << (bit & 31u);
+        if constexpr (MASKED) val &= vm;
+        regs.bor(idx * 2u + ((bit >> 5) & 1u), val);
+        return th;
     }
 }
 
@@ -153,12 +128,11 @@ __device__ __forceinline__ void add_kmer(const Regs &regs, uint32_t c_lo, uint32
 // which k-mer start positions of a lane's 64 are real k-mers of the reference's iterator?
 // position i is valid iff i + k <= L (genome end) and no record begins in (i, i+k-1].
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t kmer_valid_mask(const uint32_t *bk, uint64_t pos0, uint64_t nk, int k)
+__device__ __forceinline__ uint64_t kmer_valid_mask(uint32_t b0, uint32_t b1, uint32_t b2, uint64_t pos0, uint64_t nk, int k)
 {
+    // b0..b2: break bits of positions pos0 .. pos0+95
     const uint64_t lim = nk - pos0;                       // caller guarantees pos0 < nk
     const uint64_t kvm = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
-    const uint64_t wi = pos0 >> 5;                        // pos0 is a multiple of 64
-    const uint32_t b0 = bk[wi], b1 = bk[wi + 1], b2 = bk[wi + 2];
     if ((b0 | b1 | b2) == 0u || k == 1) return kvm;
     // S(i) = OR_{d=1..k-1} B(i+d) by doubling on the 96-bit window
     uint64_t lo = (uint64_t)b0 | ((uint64_t)b1 << 32), hi = b2;
@@ -179,13 +153,63 @@ __device__ __forceinline__ uint64_t kmer_valid_mask(const uint32_t *bk, uint64_t
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// one packed word = 16 k-mer start positions, fully unrolled: 16 independent instruction streams per lane
+// ------------------------------------------------------------------------------------------------------------
+struct KParams {
+    uint64_t bitflip;
+    uint64_t mask_gt;      // KM_GT16: low 2k bits
+    uint32_t sh_lt;        // KM_LT16: 32 - 2k
+    uint32_t mask_lt;      // KM_LT16: low 2k bits
+    uint32_t sh_gt;        // KM_GT16: 64 - 2k
+    int p;
+};
+
+template <int ALGO, int KMODE, bool XLOW, bool MASKED, bool FAST, class Regs>
+__device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1,
+                                                 uint32_t c2, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw)
+{
+    uint32_t zacc = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const uint32_t vm = MASKED ? (uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1) : 0xFFFFFFFFu;   // 0 or ~0
+        uint32_t can_lo, can_hi = 0;
+        if constexpr (KMODE == KM_GT16) {
+            const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
+            const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
+            const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
+            const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
+            const uint32_t rh = r ? alignbit(r2, r1, 2 * r) : r1;
+            const uint64_t rc = (((uint64_t)rh << 32) | rl) & kp.mask_gt;
+            const uint64_t can = fwd < rc ? fwd : rc;                            // km.min(rc), utils.rs:494
+            can_lo = (uint32_t)can;
+            can_hi = (uint32_t)(can >> 32);
+        } else {
+            uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
+            uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
+            if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
+            can_lo = fwd < rc ? fwd : rc;                                        // utils.rs:470,482
+        }
+        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p);
+        zacc = zacc < t ? zacc : t;
+    }
+    return zacc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------------------
+#ifndef LASH_SKETCH_WAVES_PER_EU
+#define LASH_SKETCH_WAVES_PER_EU_ATTR
+#else
+#define LASH_SKETCH_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(LASH_SKETCH_WAVES_PER_EU, LASH_SKETCH_WAVES_PER_EU)))
+#endif
+
 template <int ALGO, int KMODE, bool XLOW, bool USE_LDS>
-__global__ void __launch_bounds__(1024) sketch_kernel(SketchArgs a)
+__global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
+    // dynamic LDS: [nreg32 register words][16 words of per-wave census]; registers start at LDS offset 0 so the
+    // bucket offset goes straight into the ds_max / ds_or address
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
-    __shared__ unsigned long long kmer_count_wg;          // NB: static LDS object after the dynamic array is fine here (no LDS-DMA)
 
     const WorkItem it = a.items[blockIdx.x];
     const GenomeDesc gd = a.genomes[it.genome];
@@ -196,63 +220,76 @@ __global__ void __launch_bounds__(1024) sketch_kernel(SketchArgs a)
 
     using Regs = typename std::conditional<USE_LDS, LdsRegs, GlobalRegs>::type;
     Regs regs;
+    uint32_t *census;
     if constexpr (USE_LDS) {
         regs.base = lds_regs;
+        census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
     } else {
         regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;           // zeroed by the host (hipMemsetAsync)
+        census = lds_regs;
     }
-    if (threadIdx.x == 0) kmer_count_wg = 0;
     __syncthreads();
 
     const uint32_t *__restrict__ w = a.words + gd.word_off;
     const uint32_t *__restrict__ bk = a.brk + gd.brk_off;
-    const uint64_t bitflip = a.bitflip;
-    const uint32_t sh_lt = 32u - 2u * (uint32_t)k;                        // KM_LT16: fwd >>= sh_lt
-    const uint32_t mask_lt = (KMODE == KM_LT16) ? ((1u << (2 * k)) - 1u) : 0xFFFFFFFFu;
-    const uint32_t sh_gt = 64u - 2u * (uint32_t)k;                        // KM_GT16: fwd64 >>= sh_gt
-    const uint64_t mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    KParams kp;
+    kp.bitflip = a.bitflip;
+    kp.p = p;
+    kp.sh_lt = 32u - 2u * (uint32_t)k;
+    kp.mask_lt = (KMODE == KM_LT16) ? ((1u << (2 * k)) - 1u) : 0xFFFFFFFFu;
+    kp.sh_gt = 64u - 2u * (uint32_t)k;
+    kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
     uint32_t my_kmers = 0;
 
+    // One tile = blockDim.x * 4 words.  The next tile's words and break bits are loaded into registers before the
+    // current tile is hashed (about 10k cycles of VALU work per tile cover the HBM latency).
+    struct TileRegs { uint4 q; uint32_t c4, c5, b0, b1, b2; };
     const uint32_t step = blockDim.x * SKETCH_WORDS_PER_THREAD;
+    auto tile_active = [&](uint32_t tile) {
+        const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
+        return tile < it.word_end && w0 < it.word_end && (uint64_t)w0 * 16 < nk;
+    };
+    // Loads are unconditional (inactive lanes and the prefetch past the last tile read a clamped, in-bounds
+    // address): a predicated load sits in an exec-masked block and hipcc then waits for it at the block's end,
+    // which would expose the HBM latency once per tile.
+    const uint32_t w_last = it.word_end - SKETCH_WORDS_PER_THREAD;        // slices are >= 4 words, multiples of 4
+    auto tile_load = [&](uint32_t tile, TileRegs &t) {
+        uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
+        w0 = w0 < w_last ? w0 : w_last;
+        t.q = *reinterpret_cast<const uint4 *>(w + w0);                   // 64 bases, 16 B per lane, coalesced
+        t.c4 = w[w0 + 4];                                                 // look-ahead (same or next cache line)
+        t.c5 = (KMODE == KM_GT16) ? w[w0 + 5] : 0u;
+        const uint32_t bi = w0 >> 1;                                      // (w0 * 16) / 32
+        t.b0 = bk[bi]; t.b1 = bk[bi + 1]; t.b2 = bk[bi + 2];
+    };
+    TileRegs nxt;
+    tile_load(it.word_begin, nxt);
     for (uint32_t tile = it.word_begin; tile < it.word_end; tile += step) {
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
         const uint64_t pos0 = (uint64_t)w0 * 16;
-        if (w0 >= it.word_end || pos0 >= nk) continue;
+        const bool active = tile_active(tile);
+        const TileRegs cur = nxt;
+        tile_load(tile + step, nxt);
 
-        const uint4 q = *reinterpret_cast<const uint4 *>(w + w0);         // 64 bases, 16 B, coalesced
-        uint32_t c0 = q.x, c1 = q.y, c2 = q.z, c3 = q.w;
-        uint32_t c4 = w[w0 + 4];                                          // look-ahead (same or next cache line)
-        uint32_t c5 = (KMODE == KM_GT16) ? w[w0 + 5] : 0u;
-        uint64_t kv = kmer_valid_mask(bk, pos0, nk, k);
+        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+        uint64_t kv = 0;
+        if (active) {
+            c0 = cur.q.x; c1 = cur.q.y; c2 = cur.q.z; c3 = cur.q.w; c4 = cur.c4; c5 = cur.c5;
+            kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
+        }
         my_kmers += (uint32_t)__builtin_popcountll(kv);
+        // wave-uniform: every lane of this wave has 64 real k-mers -> no per-k-mer masking at all
+        const bool all_valid = __builtin_amdgcn_ballot_w64(kv != ~0ull) == 0ull;
 
         uint32_t r0 = rcword(c0), r1 = rcword(c1), r2 = (KMODE == KM_GT16) ? rcword(c2) : 0u;
 #pragma unroll 1
         for (int wi = 0; wi < SKETCH_WORDS_PER_THREAD; ++wi) {
-            const uint32_t kvw = (uint32_t)kv;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t vm = (uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1);    // 0 or ~0
-                uint32_t can_lo, can_hi = 0;
-                if constexpr (KMODE == KM_GT16) {
-                    const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
-                    const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
-                    const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> sh_gt;
-                    const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
-                    const uint32_t rh = r ? alignbit(r2, r1, 2 * r) : r1;
-                    const uint64_t rc = (((uint64_t)rh << 32) | rl) & mask_gt;
-                    const uint64_t can = fwd < rc ? fwd : rc;                            // km.min(rc), utils.rs:494
-                    can_lo = (uint32_t)can;
-                    can_hi = (uint32_t)(can >> 32);
-                } else {
-                    uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
-                    uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
-                    if constexpr (KMODE == KM_LT16) { fwd >>= sh_lt; rc &= mask_lt; }
-                    can_lo = fwd < rc ? fwd : rc;                                        // utils.rs:470,482
-                }
-                add_kmer<ALGO, XLOW>(regs, can_lo, can_hi, vm, bitflip, p);
-            }
+            uint32_t z;
+            if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
+            else           z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
+            if (z == 0u)   // a hash whose rank field starts with >= 32 zero bits (2^-32 per k-mer): exact re-run
+                (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
             // rotate the window by one word
             c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = 0;
             r0 = r1;
@@ -261,12 +298,16 @@ __global__ void __launch_bounds__(1024) sketch_kernel(SketchArgs a)
         }
     }
 
-    // valid k-mer census (tests compare it with the oracle's iterator count)
+    // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one atomic
     for (int off = 32; off > 0; off >>= 1) my_kmers += __shfl_down(my_kmers, off, 64);
-    if ((threadIdx.x & 63) == 0 && my_kmers) atomicAdd(&kmer_count_wg, (unsigned long long)my_kmers);
+    if ((threadIdx.x & 63) == 0) census[threadIdx.x >> 6] = my_kmers;
     if constexpr (!USE_LDS) __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0 && kmer_count_wg) atomicAdd(a.kmer_counter, kmer_count_wg);
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) tot += census[i];
+        if (tot) atomicAdd(a.kmer_counter, tot);
+    }
 
     // flush the partial sketch in image register format (u16 LE for HMH, u8 for HLL / ULL)
     uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)blockIdx.x * a.partial_stride);
@@ -424,7 +465,12 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     s.lds_bytes = s.nreg32 * 4u;
     s.use_lds = s.lds_bytes <= 128u * 1024u;
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU
+    if (const char *e = getenv("LASH_SKETCH_THREADS")) {                    // tuning knob (tools/)
+        const int t = atoi(e);
+        if (t == 256 || t == 512 || t == 1024) s.threads = (uint32_t)t;
+    }
     if (!s.use_lds) s.lds_bytes = 0;
+    s.lds_bytes += 64u;                                                    // per-wave census words after the registers
     return s;
 }
 

@@ -1,6 +1,6 @@
 // ubench.hip — instruction-rate microbenchmarks that price the sketch kernel's inner loop on gfx950.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip ; run on the GPU box.
-// Prints cycles per wave-instruction per SIMD (s_memtime ticks) for 1 and 4 waves per SIMD.
+// Prints steady-state ns (and cycles) per wave-instruction per SIMD at 4 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -18,13 +18,16 @@ static const char *names[] = {"v_xor_b32", "v_alignbit_b32", "v_mul_lo_u32", "v_
 template <int OP>
 __global__ void __launch_bounds__(1024) bench(unsigned long long *cycles, uint32_t *sink, int iters)
 {
-    __shared__ uint32_t lds[16384];
-    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
+    extern __shared__ uint32_t lds[];            // 40 KiB: caps residency at 4 workgroups per CU
+    if (OP >= OP_DS_MAX_RAND && OP <= OP_DS_ADD_SEQ) {
+        for (int i = threadIdx.x; i < 10240; i += blockDim.x) lds[i] = 0;
+        __syncthreads();
+    }
     uint32_t a0 = threadIdx.x * 2654435761u + 1, a1 = a0 ^ 0x9E3779B9u, a2 = a0 * 3 + 7, a3 = a1 * 5 + 11;
     uint32_t a4 = a0 + 0x1234567, a5 = a1 + 0x7654321, a6 = a2 ^ 0xdeadbeef, a7 = a3 ^ 0xcafebabe;
     uint64_t b0 = a0, b1 = a1, b2 = a2, b3 = a3, b4 = a4, b5 = a5, b6 = a6, b7 = a7;
     const uint32_t c = 0x85EBCA97u + blockIdx.x;
+    unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
 #define R8(STMT) STMT(a0, b0) STMT(a1, b1) STMT(a2, b2) STMT(a3, b3) STMT(a4, b4) STMT(a5, b5) STMT(a6, b6) STMT(a7, b7)
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long *cycles, uint32
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 a0 ^= a0 << 13; a0 ^= a0 >> 17; a0 ^= a0 << 5;
-                uint32_t addr = (a0 >> 8) & (16383u << 2);
+                uint32_t addr = (a0 >> 8) & (8191u << 2);
                 if constexpr (OP == OP_DS_MAX_RAND) asm volatile("ds_max_u32 %0, %1" :: "v"(addr), "v"(a0) : "memory");
                 else asm volatile("ds_or_b32 %0, %1" :: "v"(addr), "v"(a0) : "memory");
             }
@@ -110,37 +113,44 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long *cycles, uint32
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
     uint32_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7) ^ (uint32_t)((b0 ^ b7) >> 32);
     if (r == 0x12345) sink[0] = r + lds[threadIdx.x];
-    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned slot = (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) & 4095u;
+        cycles[slot] = t1 - t0;
+        cycles[4096 + slot] = rt1 - rt0;     // 100 MHz ticks
+    }
 }
 
+// Steady-state pricing: 16 rounds of workgroups per CU slot (so start/finish skew averages out), 4 waves per SIMD
+// (4 x 256-thread workgroups per CU, enforced with 40 KiB of dynamic LDS each), wall time from HIP events over a
+// launch of several ms, clock from s_memtime / s_memrealtime inside the kernel.
 template <int OP>
-void run(int threads, int iters, unsigned long long *d_cyc, uint32_t *d_sink)
+void run(int, int iters, unsigned long long *d_cyc, uint32_t *d_sink)
 {
-    const int blocks = 256;    // one workgroup per CU
+    const int threads = 256, blocks = 256 * 4 * 16;
+    auto kern = bench<OP>;
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(threads), 0, 0, d_cyc, d_sink, iters / 4);   // warm-up
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 40960, 0, d_cyc, d_sink, iters / 4);   // warm-up
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(bench<OP>, dim3(blocks), dim3(threads), 0, 0, d_cyc, d_sink, iters);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 40960, 0, d_cyc, d_sink, iters);
     CHK(hipEventRecord(e1));
     CHK(hipDeviceSynchronize());
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-    int nw = blocks * threads / 64;
-    std::vector<unsigned long long> h(nw);
+    const int nw = 4096;
+    std::vector<unsigned long long> h(nw), hr(nw);
     CHK(hipMemcpy(h.data(), d_cyc, nw * 8, hipMemcpyDeviceToHost));
-    double avg = 0; for (auto v : h) avg += (double)v; avg /= nw;
-    const double per_wave_instr = avg / ((double)iters * 16.0);            // memtime ticks (100 MHz const clock? see below)
-    const int waves_per_simd = threads / 256;
-    // s_memtime on gfx9 counts at a constant 100 MHz; convert with the wall time of the same launch
-    const double instr_total = (double)iters * 16.0 * nw;                   // wave-instructions
-    const double ns_per_instr_per_simd = (double)ms * 1e6 / (instr_total / (256.0 * 4.0));
-    printf("%-24s waves/SIMD=%d  %8.3f ns per wave-instr per SIMD  (= %6.2f cycles @2.4GHz)   memtime ticks/instr/wave=%.3f\n",
-           names[OP], waves_per_simd, ns_per_instr_per_simd, ns_per_instr_per_simd * 2.4, per_wave_instr);
+    CHK(hipMemcpy(hr.data(), d_cyc + 4096, nw * 8, hipMemcpyDeviceToHost));
+    double avg = 0, avgr = 0; for (auto v : h) avg += (double)v; for (auto v : hr) avgr += (double)v;
+    const double ghz = avg / (avgr * 10.0);                                   // shader cycles per ns
+    const double instr_per_simd = (double)iters * 16.0 * ((double)blocks * threads / 64.0) / 1024.0;
+    const double ns = (double)ms * 1e6 / instr_per_simd;
+    printf("%-24s %7.3f ms  %6.3f ns per wave-instr per SIMD   clock %.2f GHz -> %5.2f cycles\n", names[OP], ms, ns, ghz, ns * ghz);
 }
 
-template <int OP> void both(unsigned long long *c, uint32_t *s) { run<OP>(256, 4000, c, s); run<OP>(1024, 4000, c, s); }
+template <int OP> void both(unsigned long long *c, uint32_t *s) { run<OP>(0, OP >= OP_DS_MAX_RAND && OP <= OP_DS_ADD_SEQ ? 100 : 400, c, s); }
 
 __global__ void copy_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n)
 {
@@ -158,7 +168,7 @@ __global__ void read_kernel(const uint4 *__restrict__ in, uint32_t *out, size_t 
 int main()
 {
     unsigned long long *d_cyc; uint32_t *d_sink;
-    CHK(hipMalloc(&d_cyc, 256 * 16 * 8)); CHK(hipMalloc(&d_sink, 4096));
+    CHK(hipMalloc(&d_cyc, 2 * 4096 * 8)); CHK(hipMalloc(&d_sink, 4096));
     hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
     printf("device: %s  CUs=%d  clock=%d kHz  LDS/block=%zu\n", p.name, p.multiProcessorCount, p.clockRate, p.sharedMemPerBlock);
     both<OP_XOR>(d_cyc, d_sink); both<OP_ALIGNBIT>(d_cyc, d_sink); both<OP_MUL_LO>(d_cyc, d_sink); both<OP_MUL_HI>(d_cyc, d_sink);
