@@ -339,8 +339,33 @@ static int sketch_new(sketch_t *s, const lash_or_params *prm)
 }
 static void sketch_free(sketch_t *s) { free(s->hmh); free(s->reg); }
 
+/* Per-thread buffers for the two per-record copies (utils.rs:459 Vec, :464 KSeq).  The reference allocates them
+ * per record; the oracle keeps one growing pair per worker thread so that the CPU baseline measures the algorithm
+ * and not mmap/page-fault contention of the allocator on many-core hosts. */
+typedef struct { uint8_t *filt; size_t filt_cap; uint8_t *packed; size_t packed_cap; } scratch_t;
+
+static void scratch_reserve(scratch_t *sc, size_t n)
+{
+    if (sc->filt_cap < n + 1) { free(sc->filt); sc->filt_cap = n + n / 4 + 64; sc->filt = (uint8_t *)malloc(sc->filt_cap); }
+    size_t pb = (n + 3) / 4 + 1;
+    if (sc->packed_cap < pb) { free(sc->packed); sc->packed_cap = pb + pb / 4 + 64; sc->packed = (uint8_t *)malloc(sc->packed_cap); }
+}
+static void scratch_free(scratch_t *sc) { free(sc->filt); free(sc->packed); memset(sc, 0, sizeof *sc); }
+
+static int sketch_genome_with(const lash_or_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                              uint8_t *image, scratch_t *sc);
+
 int lash_or_sketch_genome(const lash_or_params *prm, const uint8_t *seq,
                           const uint64_t *rec_off, uint64_t n_rec, uint8_t *image)
+{
+    scratch_t sc = {0};
+    int rc = sketch_genome_with(prm, seq, rec_off, n_rec, image, &sc);
+    scratch_free(&sc);
+    return rc;
+}
+
+static int sketch_genome_with(const lash_or_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                              uint8_t *image, scratch_t *sc)
 {
     if (check_params(prm->algo, prm->k, prm->p)) return -1;
     sketch_t s;
@@ -349,15 +374,17 @@ int lash_or_sketch_genome(const lash_or_params *prm, const uint8_t *seq,
     for (uint64_t r = 0; r < n_rec; r++) {                       /* utils.rs:457 */
         const uint8_t *rec = seq + rec_off[r];
         size_t n = (size_t)(rec_off[r + 1] - rec_off[r]);
-        uint8_t *filt = (uint8_t *)malloc(n + 1);
-        size_t m = lash_or_filter_out_n(rec, n, filt);            /* utils.rs:459 */
+        scratch_reserve(sc, n);
+        size_t m = lash_or_filter_out_n(rec, n, sc->filt);        /* utils.rs:459 */
         if (m >= (size_t)prm->k) {                               /* utils.rs:460-462 */
             kseq_t ks;
-            kseq_pack(&ks, filt, m);                             /* utils.rs:464 */
+            ks.n_bases = m;                                      /* utils.rs:464 */
+            ks.bytes = sc->packed;
+            memset(ks.bytes, 0, (m + 3) / 4 + 1);
+            for (size_t i = 0; i < m; i++)
+                ks.bytes[i >> 2] |= (uint8_t)(base_code(sc->filt[i]) << (6 - 2 * (i & 3)));
             iterate_kmers(&ks, prm->k, sink, &s, NULL);
-            free(ks.bytes);
         }
-        free(filt);
     }
     if (prm->algo == LASH_OR_HMH) hmh_save(s.hmh, image);
     else if (prm->algo == LASH_OR_HLL) hll_save(s.p, s.reg, s.hll_zero, s.hll_sum, image);
@@ -377,13 +404,15 @@ typedef struct {
 static void *mt_worker(void *arg)
 {
     mt_job *j = (mt_job *)arg;
+    scratch_t sc = {0};
     for (;;) {
         uint32_t g = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
         if (g >= j->n_genomes) break;
         uint64_t r0 = j->genome_rec_off[g], r1 = j->genome_rec_off[g + 1];
-        if (lash_or_sketch_genome(j->prm, j->seq, j->rec_off + r0, r1 - r0, j->images + (size_t)g * j->image_bytes))
+        if (sketch_genome_with(j->prm, j->seq, j->rec_off + r0, r1 - r0, j->images + (size_t)g * j->image_bytes, &sc))
             j->err = -1;
     }
+    scratch_free(&sc);
     return NULL;
 }
 
