@@ -61,6 +61,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: when PyTorch is around (tests, bench.py) its bundled libamdhip64 must be the copy
+    # that gets loaded, so import torch BEFORE dlopen()ing our library (same SONAME: the loader then shares it).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "%s is missing: build it with `python -m lash_amd.build` (needs hipcc). "

@@ -38,5 +38,41 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+HOST_DIR = os.path.join(CSRC, "host")
+HOST_SOURCES = ["main.cpp", "sketch_files.cpp", "fastx.cpp", "zstd_dl.cpp", "json_out.cpp", "dist.cpp"]
+CLI = os.path.join(PKG, "bin", "lash")
+HOSTLIB = os.path.join(PKG, "liblash_host.so")
+
+
+def _host_stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    deps = [os.path.join(HOST_DIR, f) for f in os.listdir(HOST_DIR)] + [os.path.join(ROOT, "include", "lash_gfx950.h")]
+    return any(os.path.getmtime(d) > t for d in deps) or os.path.getmtime(LIB) > t
+
+
+def build_host(force=False, verbose=False):
+    """The C++ host side above the C ABI: the `lash` command line (lash_amd/bin/lash) and liblash_host.so, the same
+    objects without main() behind a few extern "C" hooks so that tests can drive the FASTX / JSON / zstd code."""
+    build_library(force=False, verbose=verbose)
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    common = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread"]
+    link = ["-L" + PKG, "-llash_gfx950", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,$ORIGIN", "-lz", "-ldl", "-lpthread"]
+    if force or _host_stale(CLI, HOST_SOURCES):
+        cmd = common + ["-o", CLI] + [os.path.join(HOST_DIR, s) for s in HOST_SOURCES] + link
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if force or _host_stale(HOSTLIB, HOST_SOURCES):
+        srcs = [s for s in HOST_SOURCES if s != "main.cpp"] + ["host_hooks.cpp"]
+        cmd = common + ["-shared", "-o", HOSTLIB] + [os.path.join(HOST_DIR, s) for s in srcs] + link
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return CLI
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))

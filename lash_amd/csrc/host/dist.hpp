@@ -1,0 +1,18 @@
+// dist.hpp — `lash dist` (/root/reference/src/main.rs:280-617, utils.rs:84-373): the consumer of the sketch files.
+// SURVEY.md §8(f) row f2 ("next"): not part of the round-1 hot path.
+#pragma once
+#include <string>
+
+namespace lashhost {
+
+struct DistOptions {
+    std::string query_prefix, ref_prefix, output_file = "dist", estimator = "fgra";
+    int model = 1;          // 1 = Poisson: min(-ln(f)/k, 1); 0 = binomial: 1 - f^(1/k)   (main.rs:415-423)
+    int threads = 1;
+    bool fp32 = false, matrix = false;
+    int device = 0;
+};
+
+std::string run_dist(const DistOptions &opt);
+
+}  // namespace lashhost

@@ -1,0 +1,107 @@
+#include "fastx.hpp"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "zstd_dl.hpp"
+
+namespace lashhost {
+
+std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t> &out)
+{
+    out.clear();
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return "Invalid input file: cannot open " + path;
+    unsigned char magic[6] = {0, 0, 0, 0, 0, 0};
+    size_t got = fread(magic, 1, 6, f);
+    if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        fclose(f);
+        gzFile g = gzopen(path.c_str(), "rb");
+        if (!g) return "Invalid input file: gzopen failed for " + path;
+        gzbuffer(g, 1 << 20);
+        std::vector<uint8_t> buf(1 << 22);
+        for (;;) {
+            int n = gzread(g, buf.data(), (unsigned)buf.size());
+            if (n < 0) { gzclose(g); return "Invalid input file: corrupt gzip stream in " + path; }
+            if (n == 0) break;
+            out.insert(out.end(), buf.begin(), buf.begin() + n);
+        }
+        gzclose(g);
+        return "";
+    }
+    // rest of the file
+    std::vector<uint8_t> raw(magic, magic + got);
+    {
+        std::vector<uint8_t> buf(1 << 22);
+        size_t n;
+        while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) raw.insert(raw.end(), buf.begin(), buf.begin() + n);
+        fclose(f);
+    }
+    if (got >= 4 && magic[0] == 0x28 && magic[1] == 0xb5 && magic[2] == 0x2f && magic[3] == 0xfd) {
+        std::string err = zstd_decompress_all(raw.data(), raw.size(), out);
+        return err.empty() ? "" : "Invalid input file: " + err + " (" + path + ")";
+    }
+    if (got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')
+        return "Invalid input file: bzip2 input is not supported by this build (" + path + ")";
+    if (got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z' && magic[5] == 0)
+        return "Invalid input file: xz input is not supported by this build (" + path + ")";
+    out.swap(raw);
+    return "";
+}
+
+std::string parse_fastx_buffer(const uint8_t *d, size_t n, RecordBatch &out)
+{
+    size_t i = 0;
+    while (i < n && (d[i] == '\n' || d[i] == '\r')) ++i;            // leading blank lines
+    if (i >= n) return "";                                          // empty file: no records
+    auto line_end = [&](size_t p) { const void *q = memchr(d + p, '\n', n - p); return q ? (size_t)((const uint8_t *)q - d) : n; };
+    if (d[i] == '>') {
+        while (i < n) {
+            if (d[i] != '>') return "Invalid input file: expected '>' at record start";
+            i = line_end(i);                                        // skip the header line
+            if (i < n) ++i;
+            while (i < n && d[i] != '>') {                          // sequence lines
+                size_t e = line_end(i), stop = e;
+                while (stop > i && d[stop - 1] == '\r') --stop;
+                out.seq.insert(out.seq.end(), d + i, d + stop);
+                i = e < n ? e + 1 : n;
+            }
+            out.rec_off.push_back(out.seq.size());
+        }
+        return "";
+    }
+    if (d[i] == '@') {
+        while (i < n) {
+            while (i < n && (d[i] == '\n' || d[i] == '\r')) ++i;
+            if (i >= n) break;
+            if (d[i] != '@') return "";                             // malformed tail: records so far stand (utils.rs:458)
+            size_t e = line_end(i);                                 // header
+            if (e >= n) break;
+            size_t s = e + 1, se = line_end(s), stop = se;          // sequence line
+            while (stop > s && d[stop - 1] == '\r') --stop;
+            if (se >= n) break;                                     // truncated record: skipped
+            size_t p = se + 1;
+            if (p >= n || d[p] != '+') return "";
+            size_t pe = line_end(p);                                // '+' line
+            if (pe >= n) break;
+            size_t qs = pe + 1, qe = line_end(qs);                  // quality line
+            out.seq.insert(out.seq.end(), d + s, d + stop);
+            out.rec_off.push_back(out.seq.size());
+            i = qe < n ? qe + 1 : n;
+        }
+        return "";
+    }
+    return "Invalid input file: neither FASTA ('>') nor FASTQ ('@')";
+}
+
+std::string read_fastx_file(const std::string &path, RecordBatch &out)
+{
+    std::vector<uint8_t> data;
+    std::string err = slurp_maybe_compressed(path, data);
+    if (!err.empty()) return err;
+    return parse_fastx_buffer(data.data(), data.size(), out);
+}
+
+}  // namespace lashhost

@@ -1,0 +1,32 @@
+// fastx.hpp — FASTA/FASTQ record reader for the host side of lash-gfx950 (replaces needletail::parse_fastx_file,
+// /root/reference/src/utils.rs:453-459; semantics per SURVEY.md App. A.5).
+//   * compression is sniffed from magic bytes: gzip (zlib), zstd (dlopen'd libzstd), plain; bzip2 / xz are reported
+//     as unsupported (the image has no headers for them);
+//   * '>' => FASTA: header line, then sequence lines up to the next '>' with '\n' and '\r' stripped;
+//     '@' => FASTQ: 4-line records, the sequence is line 2;
+//   * seq() bytes are appended UNFILTERED: deleting non-ACGT bytes is the pack kernel's job (utils.rs:459 -> 33-41).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace lashhost {
+
+struct RecordBatch {
+    std::vector<uint8_t> seq;          // concatenated record sequences
+    std::vector<uint64_t> rec_off;     // n_rec + 1 offsets into seq (rec_off[0] == 0 for a fresh batch)
+    RecordBatch() { rec_off.push_back(0); }
+    uint64_t n_rec() const { return rec_off.size() - 1; }
+};
+
+// Appends every record of `path` to `out`.  Returns "" on success, else an error message
+// (the reference panics with "Invalid input file", utils.rs:453).
+std::string read_fastx_file(const std::string &path, RecordBatch &out);
+
+// Parses an in-memory (already decompressed) FASTA/FASTQ buffer.
+std::string parse_fastx_buffer(const uint8_t *data, size_t n, RecordBatch &out);
+
+// Whole file into memory, transparently inflating gzip / zstd.
+std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t> &out);
+
+}  // namespace lashhost

@@ -1,0 +1,96 @@
+// host_hooks.cpp — extern "C" test hooks over the host-side C++ (FASTX reader, JSON writers, zstd, list files) so
+// that tests/ can drive them through ctypes.  Not part of the product ABI (that is include/lash_gfx950.h).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fastx.hpp"
+#include "json_out.hpp"
+#include "sketch_files.hpp"
+#include "zstd_dl.hpp"
+
+using namespace lashhost;
+
+namespace {
+char *dup_str(const std::string &s)
+{
+    char *p = (char *)malloc(s.size() + 1);
+    memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+}  // namespace
+
+extern "C" {
+
+void lash_host_free(void *p) { free(p); }
+
+// Parses a FASTA/FASTQ(.gz/.zst) file.  On success returns NULL and fills seq/rec_off (malloc'd, caller frees with
+// lash_host_free); otherwise returns the error text (malloc'd).
+char *lash_host_read_fastx(const char *path, uint8_t **seq, uint64_t *seq_bytes, uint64_t **rec_off, uint64_t *n_rec)
+{
+    RecordBatch rb;
+    std::string err = read_fastx_file(path, rb);
+    if (!err.empty()) return dup_str(err);
+    *seq_bytes = rb.seq.size();
+    *n_rec = rb.n_rec();
+    *seq = (uint8_t *)malloc(rb.seq.size() + 1);
+    memcpy(*seq, rb.seq.data(), rb.seq.size());
+    *rec_off = (uint64_t *)malloc(rb.rec_off.size() * 8);
+    memcpy(*rec_off, rb.rec_off.data(), rb.rec_off.size() * 8);
+    return nullptr;
+}
+
+// '\n'-separated items in, pretty JSON array out (malloc'd)
+char *lash_host_json_array(const char *items_nl, uint64_t n_items)
+{
+    std::vector<std::string> v;
+    const char *p = items_nl;
+    for (uint64_t i = 0; i < n_items; ++i) {
+        const char *e = strchr(p, '\n');
+        v.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+        p = e ? e + 1 : p + strlen(p);
+    }
+    return dup_str(json_pretty_string_array(v));
+}
+
+char *lash_host_write_parameters(const char *output_name, const char *algorithm, int k, int precision, uint64_t seed)
+{
+    std::string err = write_parameters_json(output_name, algorithm, k, precision, seed);
+    return err.empty() ? nullptr : dup_str(err);
+}
+
+// list file -> '\n'-joined kept lines (malloc'd), count in *n
+char *lash_host_read_list(const char *path, uint64_t *n)
+{
+    std::vector<std::string> files;
+    std::string err = read_list_file(path, files);
+    if (!err.empty()) { *n = (uint64_t)-1; return dup_str(err); }
+    std::string j;
+    for (auto &f : files) { j += f; j += '\n'; }
+    *n = files.size();
+    return dup_str(j);
+}
+
+char *lash_host_zstd_write(const char *path, const uint8_t *data, uint64_t n, int level, int workers)
+{
+    ZstdWriter zw;
+    std::string err = zw.open(path, level, workers);
+    if (err.empty()) err = zw.write(data, (size_t)(n / 2));
+    if (err.empty()) err = zw.write(data + n / 2, (size_t)(n - n / 2));
+    if (err.empty()) err = zw.finish();
+    return err.empty() ? nullptr : dup_str(err);
+}
+
+char *lash_host_zstd_read(const char *path, uint8_t **out, uint64_t *n)
+{
+    std::vector<uint8_t> v;
+    std::string err = zstd_decompress_file(path, v);
+    if (!err.empty()) return dup_str(err);
+    *n = v.size();
+    *out = (uint8_t *)malloc(v.size() + 1);
+    memcpy(*out, v.data(), v.size());
+    return nullptr;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// sketch_files.hpp — host driver that mirrors the reference's
+//     sketch_files::<S>(precision, files, kmer_length, output_name, threads, seed, aa)
+// (/root/reference/src/utils.rs:439-583) on top of the C ABI: files are parsed by a pool of reader threads,
+// grouped into batches in file order, sketched on one or more GPUs (one lash_ctx per device, one host thread each,
+// contiguous batches => output order == file order, utils.rs:509), and the images are streamed through zstd
+// level 3 into {output_name}_sketches.bin (utils.rs:567-574); {output_name}_files.json follows (utils.rs:577-580).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace lashhost {
+
+struct SketchOptions {
+    int algo = 0;                    // LASH_HMH / LASH_HLL / LASH_ULL
+    int precision = 10;              // -p, ignored for hmh (main.rs:212-213)
+    int k = 16;
+    uint64_t seed = 42;
+    int threads = 1;                 // -t: reader threads and zstd workers (main.rs:184-192)
+    std::vector<int> devices;        // GPUs to use; empty = device 0
+    uint64_t batch_bytes = 1ull << 30;   // sequence bytes per GPU batch
+    uint32_t flags = 0;              // LASH_F_HMH_X_LOW
+};
+
+struct SketchStats {
+    uint64_t files = 0, records = 0, bytes = 0, batches = 0;
+    double seconds = 0;
+};
+
+// Returns "" on success, otherwise the error text (the reference panics / returns Err).
+std::string sketch_files(const SketchOptions &opt, const std::vector<std::string> &files,
+                         const std::string &output_name, SketchStats *stats = nullptr);
+
+// main.rs:200-207: one path per line, lines that are blank after trim() are dropped, others kept verbatim
+std::string read_list_file(const std::string &path, std::vector<std::string> &files);
+
+// main.rs:248-276
+std::string write_parameters_json(const std::string &output_name, const std::string &algorithm, int k, int precision,
+                                  uint64_t seed);
+
+}  // namespace lashhost

@@ -1,0 +1,165 @@
+#include "zstd_dl.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+
+namespace lashhost {
+namespace {
+
+struct InBuf { const void *src; size_t size; size_t pos; };
+struct OutBuf { void *dst; size_t size; size_t pos; };
+
+struct Api {
+    void *h = nullptr;
+    void *(*createCStream)() = nullptr;
+    size_t (*freeCStream)(void *) = nullptr;
+    size_t (*initCStream)(void *, int) = nullptr;
+    size_t (*compressStream)(void *, OutBuf *, InBuf *) = nullptr;
+    size_t (*endStream)(void *, OutBuf *) = nullptr;
+    size_t (*CCtx_setParameter)(void *, int, int) = nullptr;
+    void *(*createDStream)() = nullptr;
+    size_t (*freeDStream)(void *) = nullptr;
+    size_t (*initDStream)(void *) = nullptr;
+    size_t (*decompressStream)(void *, OutBuf *, InBuf *) = nullptr;
+    unsigned (*isError)(size_t) = nullptr;
+    const char *(*getErrorName)(size_t) = nullptr;
+    std::string why;
+};
+
+Api &api()
+{
+    static Api a;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"libzstd.so.1", "libzstd.so", "/usr/lib/x86_64-linux-gnu/libzstd.so.1", "/opt/conda/lib/libzstd.so.1"};
+        for (const char *n : names) {
+            a.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (a.h) break;
+        }
+        if (!a.h) { a.why = "libzstd.so.1 not found"; return; }
+        auto sym = [&](const char *s) { return dlsym(a.h, s); };
+        a.createCStream = (void *(*)())sym("ZSTD_createCStream");
+        a.freeCStream = (size_t(*)(void *))sym("ZSTD_freeCStream");
+        a.initCStream = (size_t(*)(void *, int))sym("ZSTD_initCStream");
+        a.compressStream = (size_t(*)(void *, OutBuf *, InBuf *))sym("ZSTD_compressStream");
+        a.endStream = (size_t(*)(void *, OutBuf *))sym("ZSTD_endStream");
+        a.CCtx_setParameter = (size_t(*)(void *, int, int))sym("ZSTD_CCtx_setParameter");
+        a.createDStream = (void *(*)())sym("ZSTD_createDStream");
+        a.freeDStream = (size_t(*)(void *))sym("ZSTD_freeDStream");
+        a.initDStream = (size_t(*)(void *))sym("ZSTD_initDStream");
+        a.decompressStream = (size_t(*)(void *, OutBuf *, InBuf *))sym("ZSTD_decompressStream");
+        a.isError = (unsigned (*)(size_t))sym("ZSTD_isError");
+        a.getErrorName = (const char *(*)(size_t))sym("ZSTD_getErrorName");
+        if (!a.createCStream || !a.initCStream || !a.compressStream || !a.endStream || !a.createDStream ||
+            !a.decompressStream || !a.isError || !a.freeCStream || !a.freeDStream || !a.initDStream) {
+            a.why = "libzstd lacks the streaming API";
+            a.h = nullptr;
+        }
+    });
+    return a;
+}
+
+std::string zerr(size_t code)
+{
+    Api &a = api();
+    return std::string("zstd: ") + (a.getErrorName ? a.getErrorName(code) : "error");
+}
+
+}  // namespace
+
+bool zstd_available(std::string *why)
+{
+    Api &a = api();
+    if (!a.h && why) *why = a.why;
+    return a.h != nullptr;
+}
+
+ZstdWriter::ZstdWriter() {}
+ZstdWriter::~ZstdWriter()
+{
+    if (cstream_) api().freeCStream(cstream_);
+    if (f_) fclose(f_);
+}
+
+std::string ZstdWriter::open(const std::string &path, int level, int workers)
+{
+    Api &a = api();
+    if (!a.h) return "zstd unavailable: " + a.why;
+    f_ = fopen(path.c_str(), "wb");
+    if (!f_) return "cannot create " + path;
+    cstream_ = a.createCStream();
+    if (!cstream_) return "ZSTD_createCStream failed";
+    size_t rc = a.initCStream(cstream_, level);
+    if (a.isError(rc)) return zerr(rc);
+    // ZSTD_c_nbWorkers = 400; fails harmlessly when the library was built without multithreading
+    if (workers > 1 && a.CCtx_setParameter) (void)a.CCtx_setParameter(cstream_, 400, workers);
+    out_.resize(1 << 20);
+    return "";
+}
+
+std::string ZstdWriter::write(const void *data, size_t n)
+{
+    Api &a = api();
+    InBuf in{data, n, 0};
+    while (in.pos < in.size) {
+        OutBuf ob{out_.data(), out_.size(), 0};
+        size_t rc = a.compressStream(cstream_, &ob, &in);
+        if (a.isError(rc)) return zerr(rc);
+        if (ob.pos && fwrite(out_.data(), 1, ob.pos, f_) != ob.pos) return "short write";
+    }
+    return "";
+}
+
+std::string ZstdWriter::finish()
+{
+    Api &a = api();
+    for (;;) {
+        OutBuf ob{out_.data(), out_.size(), 0};
+        size_t rc = a.endStream(cstream_, &ob);
+        if (a.isError(rc)) return zerr(rc);
+        if (ob.pos && fwrite(out_.data(), 1, ob.pos, f_) != ob.pos) return "short write";
+        if (rc == 0) break;
+    }
+    a.freeCStream(cstream_);
+    cstream_ = nullptr;
+    int e = fclose(f_);
+    f_ = nullptr;
+    return e ? "close failed" : "";
+}
+
+std::string zstd_decompress_all(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
+{
+    Api &a = api();
+    if (!a.h) return "zstd unavailable: " + a.why;
+    void *ds = a.createDStream();
+    if (!ds) return "ZSTD_createDStream failed";
+    a.initDStream(ds);
+    out.clear();
+    std::vector<uint8_t> buf(1 << 22);
+    InBuf in{src, n, 0};
+    size_t rc = 1;
+    while (in.pos < in.size) {
+        OutBuf ob{buf.data(), buf.size(), 0};
+        rc = a.decompressStream(ds, &ob, &in);
+        if (a.isError(rc)) { a.freeDStream(ds); return zerr(rc); }
+        out.insert(out.end(), buf.begin(), buf.begin() + ob.pos);
+        if (rc == 0 && in.pos < in.size) a.initDStream(ds);        // concatenated frames
+    }
+    a.freeDStream(ds);
+    return "";
+}
+
+std::string zstd_decompress_file(const std::string &path, std::vector<uint8_t> &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return "Error opening " + path;
+    std::vector<uint8_t> raw, buf(1 << 22);
+    size_t n;
+    while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) raw.insert(raw.end(), buf.begin(), buf.begin() + n);
+    fclose(f);
+    return zstd_decompress_all(raw.data(), raw.size(), out);
+}
+
+}  // namespace lashhost

@@ -1,0 +1,97 @@
+"""CPU tests of the C++ host side (lash_amd/csrc/host): FASTX reader, list-file rules, JSON writers, zstd stream,
+and the `lash` command line's behaviour without a GPU."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_lib as H
+from fastx import read_fastx as py_read_fastx
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = ["fixture_A.fasta", "fixture_B.fasta", "fixture_C.fasta", "fixture_B40.fastq"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_fastx_reader_matches_needletail_semantics(name, tmp_path):
+    path = os.path.join(GOLD, name)
+    want = py_read_fastx(path)
+    assert H.read_fastx(path) == want
+    gz = tmp_path / (name + ".gz")                       # needletail sniffs the gzip magic
+    with open(path, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    assert H.read_fastx(str(gz)) == want
+    zs = tmp_path / (name + ".zst")
+    H.zstd_write(str(zs), open(path, "rb").read())
+    assert H.read_fastx(str(zs)) == want
+
+
+def test_fastx_reader_edge_cases(tmp_path):
+    p = tmp_path / "e.fa"
+    p.write_bytes(b">only header\n")
+    assert H.read_fastx(str(p)) == [b""]
+    p.write_bytes(b">a\nACGT\n\nTT\n>b\n>c\nGG")
+    assert H.read_fastx(str(p)) == [b"ACGTTT", b"", b"GG"]
+    p.write_bytes(b"")
+    assert H.read_fastx(str(p)) == []
+    p.write_bytes(b"@r1\nACGTN\n+\nIIIII\n@r2\nGGCC\n+r2\nIIII\n")
+    assert H.read_fastx(str(p)) == [b"ACGTN", b"GGCC"]
+    p.write_bytes(b"not a sequence file\n")
+    with pytest.raises(ValueError, match="Invalid input file"):
+        H.read_fastx(str(p))
+    with pytest.raises(ValueError, match="Invalid input file"):
+        H.read_fastx(str(tmp_path / "missing.fa"))
+
+
+def test_list_file_rules(tmp_path):
+    # main.rs:200-207: lines().filter(|l| !l.trim().is_empty()) — kept lines are NOT trimmed
+    p = tmp_path / "list.txt"
+    p.write_bytes(b"a.fa\n\n  \n b.fa \r\nc.fa")
+    assert H.read_list(str(p)) == ["a.fa", " b.fa ", "c.fa"]
+
+
+def test_json_documents_match_serde_pretty(tmp_path):
+    assert H.json_array([]) == "[]"
+    assert H.json_array(["a.fa", 'we"ird\\name\t.fa']) == '[\n  "a.fa",\n  "we\\"ird\\\\name\\t.fa"\n]'
+    assert json.loads(H.json_array(["x", "y/z.fasta"])) == ["x", "y/z.fasta"]
+    pre = str(tmp_path / "out")
+    H.write_parameters(pre, "hmh", 16, 10, 42)
+    assert open(pre + "_parameters.json").read() == \
+        '{\n  "algorithm": "hmh",\n  "k": "16",\n  "molecule": "nucleotide",\n  "seed": "42"\n}'
+    H.write_parameters(pre, "ull", 21, 12, 7)
+    assert open(pre + "_parameters.json").read() == \
+        '{\n  "algorithm": "ull",\n  "k": "21",\n  "molecule": "nucleotide",\n  "precision": "12",\n  "seed": "7"\n}'
+
+
+def test_zstd_stream_roundtrip_and_interop(tmp_path):
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 4, size=3_000_000, dtype=np.uint8).tobytes() + b"\x00" * 100_000
+    p = str(tmp_path / "x.bin")
+    H.zstd_write(p, data, level=3, workers=4)
+    assert os.path.getsize(p) < len(data)
+    assert H.zstd_read(p) == data
+    try:
+        import pyarrow as pa
+    except Exception:
+        return
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"\x28\xb5\x2f\xfd"               # one standard zstd frame: any decoder (incl. the zstd crate) reads it
+    assert pa.decompress(raw, decompressed_size=len(data), codec="zstd").to_pybytes() == data
+
+
+def test_cli_without_gpu_fails_loudly(tmp_path):
+    import lash_amd
+    if lash_amd.load().lash_device_count() > 0:
+        pytest.skip("a GPU is present")
+    lst = tmp_path / "l.txt"
+    lst.write_text(os.path.join(GOLD, "fixture_A.fasta") + "\n")
+    r = subprocess.run([H.CLI, "sketch", "-f", str(lst), "-o", str(tmp_path / "o")], capture_output=True, text=True)
+    assert r.returncode != 0 and "no usable HIP device" in r.stderr
+    assert "initializing logger" in r.stdout            # main.rs:23 banner
+    r = subprocess.run([H.CLI, "sketch", "-f", str(lst), "-a", "minhash"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Algorithm must be either hmh, ull, or hll" in r.stderr
+    r = subprocess.run([H.CLI, "sketch"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--file" in r.stderr
