@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -27,8 +28,8 @@ struct DevBuf {
 };
 
 struct EvSet {
-    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};   // call start, pack done, sketch done, finalize done
-    bool pack = false, done = false;
+    hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pack start/end (pack stream); sketch start,
+    bool pack = false, done = false;                                   // sketch end, finalize end (main stream)
 };
 
 struct HostStage {
@@ -57,17 +58,17 @@ struct lash_ctx {
     bool own_stream = false;
     std::string err;
     bool timing = false;
-    std::vector<EvSet> ev_pool;          // one set of 4 events per timed call since lash_ctx_enable_timing(ctx, 1)
+    std::deque<EvSet> ev_pool;           // one event set per timed (chunk of a) call; deque: stable addresses on growth
     size_t ev_used = 0;
     EvSet *cur_ev = nullptr;
     lash_timing last{};
-    HostStage ring[8];                   // pinned staging for the small per-call tables
+    HostStage ring[32];                  // pinned staging for the small per-call tables
     unsigned ring_next = 0;
-    const lash_packed *last_packed = nullptr;
+    std::vector<const lash_packed *> last_packed;   // what the last sketch call consumed (for bases_last / error flags)
     DevBuf items, item_begin, partials, gregs, counter;
     bool counter_zeroed = false;
     DevBuf st_seq, st_rec, st_img;       // staging for the host-buffer entry
-    lash_packed scratch;
+    lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
 };
 
 namespace {
@@ -113,10 +114,11 @@ void release(DevBuf &b)
 
 // Small host tables go through a ring of pinned buffers, so the async copy never reads a dead std::vector and a
 // call never has to drain the stream.
-int upload(lash_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+int upload(lash_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStream_t stream = nullptr)
 {
     if (bytes == 0) return LASH_OK;
-    HostStage &hs = ctx->ring[ctx->ring_next++ % 8];
+    if (!stream) stream = ctx->stream;
+    HostStage &hs = ctx->ring[ctx->ring_next++ % 32];
     if (hs.pending) { HIPCHK(ctx, hipEventSynchronize(hs.done)); hs.pending = false; }
     if (!hs.done) HIPCHK(ctx, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
     if (hs.cap < bytes) {
@@ -127,18 +129,18 @@ int upload(lash_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
         hs.cap = bytes + bytes / 4 + 4096;
     }
     memcpy(hs.ptr, h_src, bytes);
-    HIPCHK(ctx, hipMemcpyAsync(d_dst, hs.ptr, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(hs.done, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, hs.ptr, bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, hipEventRecord(hs.done, stream));
     hs.pending = true;
     return LASH_OK;
 }
 
-int timing_begin(lash_ctx *ctx)
+int timing_begin(lash_ctx *ctx)      // sets ctx->cur_ev to a fresh event set (or nullptr when timing is off / exhausted)
 {
     ctx->cur_ev = nullptr;
     if (!ctx->timing) return LASH_OK;
     if (ctx->ev_used == ctx->ev_pool.size()) {
-        if (ctx->ev_pool.size() >= 4096) return LASH_OK;       // stop recording, keep running
+        if (ctx->ev_pool.size() >= 16384) return LASH_OK;      // stop recording, keep running
         EvSet s;
         for (auto &e : s.e) HIPCHK(ctx, hipEventCreate(&e));
         ctx->ev_pool.push_back(s);
@@ -147,7 +149,6 @@ int timing_begin(lash_ctx *ctx)
     s->pack = false;
     s->done = false;
     ctx->cur_ev = s;
-    HIPCHK(ctx, hipEventRecord(s->e[0], ctx->stream));
     return LASH_OK;
 }
 
@@ -163,10 +164,14 @@ double hll_alpha(int p)
 
 uint64_t header_bytes(int algo) { return algo == LASH_HMH ? 0 : algo == LASH_HLL ? 33 : 8; }
 
-int pack_into(lash_ctx *ctx, lash_packed *pk, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
-              const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes)
+// Packs genomes [0, n_genomes) described by genome_rec_off / genome_byte_off (absolute record indices / byte offsets
+// into d_seq) on `stream`.  `ev`, when set, gets its pack-start / pack-end events recorded on that stream.
+int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, const uint8_t *d_seq, const uint8_t *d_seq_end,
+              const uint64_t *d_rec_off, uint64_t n_rec, const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
+              uint32_t n_genomes)
 {
     if (n_genomes && (!genome_rec_off || !genome_byte_off)) return LASH_EINVAL;
+    pk->error_flag = nullptr;
     std::vector<GenomeDesc> descs(n_genomes);
     pk->byte_len.assign(n_genomes, 0);
     uint64_t wo = 0, bo = 0;
@@ -212,14 +217,17 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, const uint8_t *d_seq, const uint64
     if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
     if ((rc = reserve(ctx, pk->lookback, (size_t)(n_tiles + 2) * 8 + PACK_TICKET_SHARDS * 128 + 256))) return rc;
     if (n_genomes == 0) return LASH_OK;
-    if ((rc = upload(ctx, pk->descs.ptr, descs.data(), descs.size() * sizeof(GenomeDesc)))) return rc;
-    if ((rc = upload(ctx, pk->tile_begin.ptr, tile_begin.data(), tile_begin.size() * 4))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(pk->nvalid.ptr, 0, (size_t)(n_genomes + 1) * 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, (size_t)(n_tiles + 2) * 8 + PACK_TICKET_SHARDS * 128 + 256, ctx->stream));
+    if (ev) { ev->pack = true; HIPCHK(ctx, hipEventRecord(ev->e[0], stream)); }
+    if ((rc = upload(ctx, pk->descs.ptr, descs.data(), descs.size() * sizeof(GenomeDesc), stream))) return rc;
+    if ((rc = upload(ctx, pk->tile_begin.ptr, tile_begin.data(), tile_begin.size() * 4, stream))) return rc;
+    bool any_multi = false;                                   // single-record genomes never consult the bitmap
+    for (uint32_t g = 0; g < n_genomes && !any_multi; ++g) any_multi = descs[g].rec_end - descs[g].rec_begin > 1;
+    if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
+    HIPCHK(ctx, hipMemsetAsync(pk->nvalid.ptr, 0, (size_t)(n_genomes + 1) * 8, stream));
+    HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, (size_t)(n_tiles + 2) * 8 + PACK_TICKET_SHARDS * 128 + 256, stream));
     PackArgs pa{};
     pa.seq = d_seq;
-    pa.seq_end = d_seq + genome_byte_off[n_genomes];
+    pa.seq_end = d_seq_end;
     pa.rec_off = d_rec_off;
     pa.genomes = static_cast<const GenomeDesc *>(pk->descs.ptr);
     pa.words = static_cast<uint32_t *>(pk->words.ptr);
@@ -240,12 +248,13 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, const uint8_t *d_seq, const uint64
     pm.tiles = static_cast<TileInfo *>(pk->tiles.ptr);
     pm.n_tiles = (uint32_t)n_tiles;
     pm.n_genomes = n_genomes;
-    HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, ctx->stream));
+    HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, stream));
+    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[1], stream));
     pk->error_flag = v2.error_flag;
     return LASH_OK;
 }
 
-int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, bool timed_pack)
+int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, EvSet *ev)
 {
     const uint32_t n_genomes = pk->n_genomes;
     const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, (prm->flags & LASH_F_HMH_X_LOW) != 0);
@@ -285,18 +294,18 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     if ((rc = upload(ctx, ctx->items.ptr, items.data(), (size_t)n_items * sizeof(WorkItem)))) return rc;
     if ((rc = upload(ctx, ctx->item_begin.ptr, item_begin.data(), (size_t)(n_genomes + 1) * 4))) return rc;
     if (!ctx->counter_zeroed) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 64, ctx->stream));      // [0,8) k-mer census, [16,64) zero words
         ctx->counter_zeroed = true;
     }
     if (!plan.use_lds && n_items)
         HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n_items * plan.nreg32 * 4, ctx->stream));
 
-    EvSet *ev = ctx->cur_ev;
-    if (ev) { ev->pack = timed_pack; HIPCHK(ctx, hipEventRecord(ev->e[1], ctx->stream)); }
+    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
 
     SketchArgs sa{};
     sa.words = static_cast<const uint32_t *>(pk->words.ptr);
     sa.brk = static_cast<const uint32_t *>(pk->brk.ptr);
+    sa.zero_words = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(ctx->counter.ptr) + 16);   // zeroed once, never written
     sa.genomes = static_cast<const GenomeDesc *>(pk->descs.ptr);
     sa.nvalid = static_cast<const uint64_t *>(pk->nvalid.ptr);
     sa.items = static_cast<const WorkItem *>(ctx->items.ptr);
@@ -309,7 +318,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     sa.k = prm->k;
     sa.p = prm->p;
     HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream));
-    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
+    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
 
     FinalizeArgs fa{};
     fa.partials = static_cast<const uint8_t *>(ctx->partials.ptr);
@@ -327,10 +336,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.k = prm->k;
     fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
     HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
-    if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream)); ev->done = true; }
-    ctx->cur_ev = nullptr;
-    ctx->last_packed = pk;
-    ctx->last.calls += 1;
+    if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
+    ctx->last_packed.push_back(pk);
     ctx->last.sketch_launches += n_items ? 1 : 0;
     ctx->last.sketch_workgroups = n_items;
     for (uint32_t g = 0; g < n_genomes; ++g)
@@ -399,9 +406,10 @@ int lash_ctx_create(lash_ctx **out, int device)
     ctx->device = device;
     ctx->scratch.owned_by_ctx = true;
     hipDeviceProp_t prop;
-    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete ctx;
+    const bool ok = hipSetDevice(device) == hipSuccess && hipGetDeviceProperties(&prop, device) == hipSuccess &&
+                    hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) {
+        lash_ctx_destroy(ctx);
         return LASH_EHIP;
     }
     ctx->own_stream = true;
@@ -416,9 +424,12 @@ void lash_ctx_destroy(lash_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
-                      &ctx->st_img, &ctx->scratch.words, &ctx->scratch.brk, &ctx->scratch.nvalid, &ctx->scratch.descs,
-                      &ctx->scratch.tile_begin, &ctx->scratch.tiles, &ctx->scratch.lookback})
+                      &ctx->st_img})
         release(*b);
+    {
+        lash_packed &sc = ctx->scratch;
+        for (DevBuf *b : {&sc.words, &sc.brk, &sc.nvalid, &sc.descs, &sc.tile_begin, &sc.tiles, &sc.lookback}) release(*b);
+    }
     for (auto &s : ctx->ev_pool)
         for (auto &e : s.e)
             if (e) (void)hipEventDestroy(e);
@@ -459,7 +470,11 @@ int lash_ctx_synchronize(lash_ctx *ctx)
     if (!ctx) return LASH_EINVAL;
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return check_pack_flag(ctx, ctx->last_packed);
+    for (const lash_packed *pk : ctx->last_packed) {
+        const int rc = check_pack_flag(ctx, pk);
+        if (rc) return rc;
+    }
+    return LASH_OK;
 }
 
 const char *lash_ctx_last_error(lash_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
@@ -489,8 +504,8 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
         if (!s.done) continue;
         float ms = 0.f;
         if (s.pack) { HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[0], s.e[1])); t.pack_ms += ms; }
-        HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[1], s.e[2])); t.sketch_ms += ms;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[2], s.e[3])); t.finalize_ms += ms;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[2], s.e[3])); t.sketch_ms += ms;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[3], s.e[4])); t.finalize_ms += ms;
     }
     t.kmers = 0;
     t.bases_last = 0;
@@ -499,9 +514,10 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
         HIPCHK(ctx, hipMemcpy(&c, ctx->counter.ptr, 8, hipMemcpyDeviceToHost));
         t.kmers = c;
     }
-    if (ctx->last_packed && ctx->last_packed->n_genomes) {
-        std::vector<uint64_t> nv(ctx->last_packed->n_genomes);
-        HIPCHK(ctx, hipMemcpy(nv.data(), ctx->last_packed->nvalid.ptr, nv.size() * 8, hipMemcpyDeviceToHost));
+    for (const lash_packed *pk : ctx->last_packed) {
+        if (!pk->n_genomes) continue;
+        std::vector<uint64_t> nv(pk->n_genomes);
+        HIPCHK(ctx, hipMemcpy(nv.data(), pk->nvalid.ptr, nv.size() * 8, hipMemcpyDeviceToHost));
         for (uint64_t v : nv) t.bases_last += v;
     }
     *out = t;
@@ -517,7 +533,10 @@ int lash_pack_device(lash_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_rec_
     (void)hipSetDevice(ctx->device);
     lash_packed *pk = new (std::nothrow) lash_packed();
     if (!pk) return LASH_ENOMEM;
-    int rc = pack_into(ctx, pk, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, n_genomes);
+    int rc = n_genomes && (!genome_rec_off || !genome_byte_off) ? LASH_EINVAL : LASH_OK;
+    if (rc == LASH_OK)
+        rc = pack_into(ctx, pk, ctx->stream, nullptr, d_seq, n_genomes ? d_seq + genome_byte_off[n_genomes] : d_seq, d_rec_off, n_rec,
+                       genome_rec_off, genome_byte_off, n_genomes);
     if (rc) { lash_packed_free(ctx, pk); return rc; }
     *out = pk;
     return LASH_OK;
@@ -529,7 +548,8 @@ void lash_packed_free(lash_ctx *ctx, lash_packed *pk)
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-        if (ctx->last_packed == pk) ctx->last_packed = nullptr;
+        for (auto it = ctx->last_packed.begin(); it != ctx->last_packed.end();)
+            it = (*it == pk) ? ctx->last_packed.erase(it) : it + 1;
     }
     for (DevBuf *b : {&pk->words, &pk->brk, &pk->nvalid, &pk->descs, &pk->tile_begin, &pk->tiles, &pk->lookback})
         release(*b);
@@ -548,21 +568,34 @@ int lash_sketch_packed_device(lash_ctx *ctx, const lash_params *prm, const lash_
     if (rc) return rc;
     (void)hipSetDevice(ctx->device);
     if ((rc = timing_begin(ctx))) return rc;
-    return sketch_from(ctx, prm, pk, d_out_images, false);
+    ctx->last_packed.clear();
+    ctx->last.calls += 1;
+    return sketch_from(ctx, prm, pk, d_out_images, ctx->cur_ev);
 }
 
 int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off,
                              uint64_t n_rec, const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
                              uint32_t n_genomes, uint8_t *d_out_images)
 {
-    if (!ctx || (n_genomes && !d_out_images)) return LASH_EINVAL;
+    if (!ctx || (n_genomes && (!d_out_images || !genome_rec_off || !genome_byte_off))) return LASH_EINVAL;
     int rc = lash_params_check(prm);
     if (rc) return rc;
     (void)hipSetDevice(ctx->device);
+    ctx->last_packed.clear();
+    ctx->last.calls += 1;
+    if (n_genomes == 0) return LASH_OK;
+
+    // One packed batch, one stream.  Packing chunk c+1 on a second stream while chunk c is sketched was measured and
+    // rejected (DESIGN.md "Rejected"): the pack workgroups' LDS fragments the CU's 160 KiB so that only one 64 KiB
+    // sketch workgroup fits, and the step got 20-40 % slower.
     if ((rc = timing_begin(ctx))) return rc;
-    rc = pack_into(ctx, &ctx->scratch, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, n_genomes);
+    EvSet *ev = ctx->cur_ev;
+    rc = pack_into(ctx, &ctx->scratch, ctx->stream, ev, d_seq, d_seq + genome_byte_off[n_genomes], d_rec_off, n_rec,
+                   genome_rec_off, genome_byte_off, n_genomes);
     if (rc) return rc;
-    return sketch_from(ctx, prm, &ctx->scratch, d_out_images, true);
+    rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
+    ctx->cur_ev = nullptr;
+    return rc;
 }
 
 int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
@@ -595,7 +628,9 @@ int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq,
     if (rc) return rc;
     if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return check_pack_flag(ctx, &ctx->scratch);
+    for (const lash_packed *pk : ctx->last_packed)
+        if ((rc = check_pack_flag(ctx, pk))) return rc;
+    return LASH_OK;
 }
 
 int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, const uint8_t *d_src, uint64_t n_images)

@@ -11,6 +11,7 @@ namespace lash {
 struct SketchArgs {
     const uint32_t   *words;      // packed 2-bit bases
     const uint32_t   *brk;        // record-break bitmap
+    const uint32_t   *zero_words; // >= 4 zero words (stand-in bitmap for single-record genomes)
     const GenomeDesc *genomes;
     const uint64_t   *nvalid;     // surviving bases per genome
     const WorkItem   *items;

@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) pack_map_kernel(PackMapArgs m)
     ti.r0 = lower_bound(toff);
     const uint64_t r1 = (t + 1 < te) ? lower_bound(toff + P2_TILE) : gd.rec_end;
     ti.nrec = (uint32_t)(r1 - ti.r0 > 0xFFFFFFFFull ? 0xFFFFFFFFull : r1 - ti.r0);
+    if (gd.rec_end - gd.rec_begin <= 1) ti.nrec = 0;         // a single record has no interior boundary to mark
     ti.g = g;
     ti.tb = tb;
     ti.rel_lo = (int32_t)(g0 > toff ? g0 - toff : 0);

@@ -232,7 +232,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     __syncthreads();
 
     const uint32_t *__restrict__ w = a.words + gd.word_off;
-    const uint32_t *__restrict__ bk = a.brk + gd.brk_off;
+    // A genome with a single record has no interior record boundary: its lanes read three always-zero words (one
+    // L1-resident line) instead of streaming 1/8 B per base of break bitmap from HBM.  No branch, no second loop.
+    const bool multi_rec = gd.rec_end - gd.rec_begin > 1;
+    const uint32_t *__restrict__ bk = multi_rec ? a.brk + gd.brk_off : a.zero_words;
     KParams kp;
     kp.bitflip = a.bitflip;
     kp.p = p;
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         t.q = *reinterpret_cast<const uint4 *>(w + w0);                   // 64 bases, 16 B per lane, coalesced
         t.c4 = w[w0 + 4];                                                 // look-ahead (same or next cache line)
         t.c5 = (KMODE == KM_GT16) ? w[w0 + 5] : 0u;
-        const uint32_t bi = w0 >> 1;                                      // (w0 * 16) / 32
+        const uint32_t bi = multi_rec ? w0 >> 1 : 0u;                     // (w0 * 16) / 32
         t.b0 = bk[bi]; t.b1 = bk[bi + 1]; t.b2 = bk[bi + 2];
     };
     TileRegs nxt;
