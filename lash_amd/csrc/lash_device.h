@@ -40,18 +40,31 @@ __device__ __forceinline__ uint32_t clz64_nz(uint32_t hi, uint32_t lo)
     return ch < cl ? ch : cl;
 }
 
+// 64 x 64 -> 128 multiply of {a1,a0} by the XXH3 constant PRIME64_1 + (len << 2), len = 4.
+// Four v_mad_u64_u32; the third one adds the full 64-bit partial sum and its carry-out (VCC) is folded into the
+// fourth's addend, which saves three register-pair moves and a 64-bit add over the textbook chain:
+//   t = a0*c0;  u = a1*c0 + hi32(t);  {carry, v} = a0*c1 + u;  hi = a1*c1 + {carry, hi32(v)};  lo = {lo32(v), lo32(t)}
+__device__ __forceinline__ void xxh3_mul128(uint32_t a0, uint32_t a1, uint64_t &lo, uint64_t &hi)
+{
+    constexpr uint64_t C = XXH_PRIME64_1 + 16;
+    constexpr uint32_t c0 = (uint32_t)C, c1 = (uint32_t)(C >> 32);
+    const uint64_t t = (uint64_t)a0 * c0;
+    const uint64_t u = (uint64_t)a1 * c0 + (t >> 32);
+    uint64_t v;
+    uint32_t carry;
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc"
+        : "=v"(v), "=v"(carry)
+        : "v"(a0), "s"(c1), "v"(u)
+        : "vcc");
+    hi = (uint64_t)a1 * c1 + (((uint64_t)carry << 32) | (v >> 32));
+    lo = (uint64_t)(uint32_t)t | (v << 32);
+}
+
 // XXH3-128 of the 4 little-endian bytes of w (XXH3_len_4to8_128b, len = 4), seed folded into `bitflip`.
 __device__ __forceinline__ void xxh3_128_4b(uint32_t w, uint64_t bitflip, uint64_t &lo, uint64_t &hi)
 {
-    const uint32_t a0 = w ^ (uint32_t)bitflip, a1 = w ^ (uint32_t)(bitflip >> 32);
-    constexpr uint64_t C = XXH_PRIME64_1 + 16;           // PRIME64_1 + (len << 2)
-    constexpr uint32_t c0 = (uint32_t)C, c1 = (uint32_t)(C >> 32);
-    // 64 x 64 -> 128 as four v_mad_u64_u32
-    uint64_t t = (uint64_t)a0 * c0;
-    uint64_t u = (uint64_t)a1 * c0 + (t >> 32);
-    uint64_t v = (uint64_t)a0 * c1 + (uint32_t)u;
-    uint64_t h = (uint64_t)a1 * c1 + ((u >> 32) + (v >> 32));
-    uint64_t l = (uint64_t)(uint32_t)t | (v << 32);
+    uint64_t l, h;
+    xxh3_mul128(w ^ (uint32_t)bitflip, w ^ (uint32_t)(bitflip >> 32), l, h);
     h += l << 1;
     l ^= h >> 3;
     l ^= l >> 35;
@@ -62,6 +75,25 @@ __device__ __forceinline__ void xxh3_128_4b(uint32_t w, uint64_t bitflip, uint64
     h ^= h >> 32;
     lo = l;
     hi = h;
+}
+
+// The part of the same hash that a HyperMinHash update with x = high64 needs when the rank fits in 18 bits:
+//   xh    = bits 63:32 of the high half (bucket = xh >> 18, rank field = xh & 0x3FFFF)
+//   sig10 = bits 9:0 of the low half
+// Skips the low word of the last multiply and the final xorshift of the high half (they only feed bits 31:0 of x).
+__device__ __forceinline__ void xxh3_128_4b_hmh_fast(uint32_t w, uint64_t bitflip, uint32_t &xh, uint32_t &sig10)
+{
+    uint64_t l, h;
+    xxh3_mul128(w ^ (uint32_t)bitflip, w ^ (uint32_t)(bitflip >> 32), l, h);
+    h += l << 1;
+    l ^= h >> 3;
+    l ^= l >> 35;
+    l *= XXH_PRIME_MX2;
+    sig10 = ((uint32_t)l ^ (uint32_t)(l >> 28)) & 0x3FFu;
+    h ^= h >> 37;
+    constexpr uint32_t m0 = (uint32_t)XXH_PRIME_MX1, m1 = (uint32_t)(XXH_PRIME_MX1 >> 32);
+    const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+    xh = __umulhi(h0, m0) + h0 * m1 + h1 * m0;
 }
 
 // XXH3-64 of the 8 little-endian bytes of {v_hi,v_lo} (XXH3_len_4to8_64b, len = 8 -> XXH3_rrmxmx)

@@ -70,24 +70,35 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
     if constexpr (ALGO == 0) {
         // utils.rs:395-398: Sketch::add_bytes_with_seed(&(masked as u32).to_le_bytes(), seed)
         (void)c_hi;                                      // k > 16: only the low 32 bits are hashed
-        uint64_t lo, hi;
-        xxh3_128_4b(c_lo, bitflip, lo, hi);
-        const uint64_t x = XLOW ? lo : hi, y = XLOW ? hi : lo;
-        const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x;
-        const uint32_t bucket = xh >> 18;                                    // x >> 50
-        const uint32_t th = alignbit(xh, xl, 18);                            // high word of (x << 14) ^ 0x3FFF
-        uint32_t lzm1;                                                        // lz - 1; FAST with th == 0: 0xFFFFFFFF, so
-                                                                              // reg wraps to sig alone (an under-estimate)
-        if constexpr (FAST) {
-            lzm1 = ffbh_u32(th);
+        if constexpr (FAST && !XLOW) {
+            // rank from the 18 bits of x that share a word with the bucket: t18 = those bits, left-aligned, padded
+            // with ones -> clz(t18) = lz - 1 when any of them is set, else 18 (an under-estimate; re-run by caller)
+            uint32_t xh, sig;
+            xxh3_128_4b_hmh_fast(c_lo, bitflip, xh, sig);
+            const uint32_t t18 = (xh << 14) | 0x3FFFu;
+            uint32_t reg = ((ffbh_u32(t18) << 10) | sig) + 0x400u;
+            if constexpr (MASKED) reg &= vm;
+            regs.umax(xh >> 18, reg);
+            return t18;                                  // < 0x4000 <=> all 18 rank bits were zero
         } else {
-            const uint32_t tl = (xl << 14) | 0x3FFFu;                        // low word, never 0
-            lzm1 = clz64_nz(th, tl);
+            uint64_t lo, hi;
+            xxh3_128_4b(c_lo, bitflip, lo, hi);
+            const uint64_t x = XLOW ? lo : hi, y = XLOW ? hi : lo;
+            const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x;
+            const uint32_t bucket = xh >> 18;                                // x >> 50
+            const uint32_t th = alignbit(xh, xl, 18);                        // high word of (x << 14) ^ 0x3FFF
+            uint32_t lzm1;                                                   // lz - 1; FAST with th == 0: 0xFFFFFFFF, so
+            if constexpr (FAST) {                                            // reg wraps to sig alone (an under-estimate)
+                lzm1 = ffbh_u32(th);
+            } else {
+                const uint32_t tl = (xl << 14) | 0x3FFFu;                    // low word, never 0
+                lzm1 = clz64_nz(th, tl);
+            }
+            uint32_t reg = ((lzm1 << 10) | ((uint32_t)y & 0x3FFu)) + 0x400u; // (lz << 10) | sig, lz = 1..=51
+            if constexpr (MASKED) reg &= vm;
+            regs.umax(bucket, reg);
+            return th;
         }
-        uint32_t reg = ((lzm1 << 10) | ((uint32_t)y & 0x3FFu)) + 0x400u;              // (lz << 10) | sig, lz = 1..=51
-        if constexpr (MASKED) reg &= vm;
-        regs.umax(bucket, reg);
-        return th;
     } else if constexpr (ALGO == 1) {
         // utils.rs:411-413: push_hash64(xxh3_64(masked.to_le_bytes(), seed)): bucket = low p bits,
         // rho = 1 + leading zeros of the remaining 64-p bits = clz64(h | (2^p - 1)) + 1
@@ -291,7 +302,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             uint32_t z;
             if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
             else           z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
-            if (z == 0u)   // a hash whose rank field starts with >= 32 zero bits (2^-32 per k-mer): exact re-run
+            // FAST forms return a word whose smallness flags "rank not decided by the bits looked at": exact re-run
+            // (HMH/x-high looks at 18 bits -> 2^-18 per k-mer; the others at 32 bits -> 2^-32)
+            constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+            if (z <= Z_REDO)
                 (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
             // rotate the window by one word
             c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = 0;

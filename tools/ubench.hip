@@ -9,11 +9,12 @@
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 enum Op { OP_XOR, OP_ALIGNBIT, OP_MUL_LO, OP_MUL_HI, OP_MAD_U64, OP_MUL_U24, OP_MAD_U24, OP_LSHR64, OP_ADD64, OP_FFBH, OP_BFE,
-          OP_DS_MAX_RAND, OP_DS_MAX_SAME, OP_DS_OR_RAND, OP_DS_ADD_SEQ, OP_XOR3LIKE, OP_PERM, OP_COUNT };
+          OP_DS_MAX_RAND, OP_DS_MAX_SAME, OP_DS_OR_RAND, OP_DS_ADD_SEQ, OP_XOR3LIKE, OP_PERM, OP_MIX_XOR_MUL, OP_MIX_XOR_MAD64, OP_MIX_3XOR_MUL, OP_MOV, OP_ADD3, OP_LSHL_OR, OP_ADD_U32, OP_COUNT };
 static const char *names[] = {"v_xor_b32", "v_alignbit_b32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_mul_u32_u24",
                               "v_mad_u32_u24", "v_lshrrev_b64", "v_lshl_add_u64", "v_ffbh_u32", "v_bfe_u32",
                               "ds_max_u32 random", "ds_max_u32 same-addr", "ds_or_b32 random", "ds_add_u32 lane-seq",
-                              "v_bitop3/xor3", "v_perm_b32"};
+                              "v_bitop3/xor3", "v_perm_b32", "mix 8 xor + 8 mul_lo", "mix 8 xor + 8 mad_u64",
+                              "mix 12 xor + 4 mul_lo", "v_mov_b32", "v_add3_u32", "v_lshl_or_b32", "v_add_u32"};
 
 template <int OP>
 __global__ void __launch_bounds__(1024) bench(unsigned long long *cycles, uint32_t *sink, int iters)
@@ -80,6 +81,46 @@ __global__ void __launch_bounds__(1024) bench(unsigned long long *cycles, uint32
 #undef S
         } else if constexpr (OP == OP_XOR3LIKE) {
 #define S(a, b) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(a) : "v"(c), "v"(a7));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_MIX_XOR_MUL) {
+#define S(a, b) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "v"(c));
+            R8(S)
+#undef S
+#define S(a, b) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(b) : "v"(c));
+            { uint32_t m0 = (uint32_t)b0, m1 = (uint32_t)b1, m2 = (uint32_t)b2, m3 = (uint32_t)b3, m4 = (uint32_t)b4, m5 = (uint32_t)b5, m6 = (uint32_t)b6, m7 = (uint32_t)b7;
+              S(a0, m0) S(a1, m1) S(a2, m2) S(a3, m3) S(a4, m4) S(a5, m5) S(a6, m6) S(a7, m7)
+              b0 = m0; b1 = m1; b2 = m2; b3 = m3; b4 = m4; b5 = m5; b6 = m6; b7 = m7; }
+#undef S
+        } else if constexpr (OP == OP_MIX_XOR_MAD64) {
+#define S(a, b) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "v"(c));
+            R8(S)
+#undef S
+#define S(a, b) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(b) : "v"(a7), "v"(c) : "vcc");
+            R8(S)
+#undef S
+        } else if constexpr (OP == OP_MIX_3XOR_MUL) {
+#define S(a, b) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "v"(c));
+            R8(S) S(a0, b0) S(a1, b1) S(a2, b2) S(a3, b3)
+#undef S
+            { uint32_t m0 = (uint32_t)b0, m1 = (uint32_t)b1, m2 = (uint32_t)b2, m3 = (uint32_t)b3;
+              asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(m0) : "v"(c)); asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(m1) : "v"(c));
+              asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(m2) : "v"(c)); asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(m3) : "v"(c));
+              b0 = m0; b1 = m1; b2 = m2; b3 = m3; }
+        } else if constexpr (OP == OP_MOV) {
+#define S(a, b) asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_ADD3) {
+#define S(a, b) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(c), "v"(a7));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_LSHL_OR) {
+#define S(a, b) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a) : "v"(c));
+            R8(S) R8(S)
+#undef S
+        } else if constexpr (OP == OP_ADD_U32) {
+#define S(a, b) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(c));
             R8(S) R8(S)
 #undef S
         } else if constexpr (OP == OP_PERM) {
@@ -150,7 +191,7 @@ void run(int, int iters, unsigned long long *d_cyc, uint32_t *d_sink)
     printf("%-24s %7.3f ms  %6.3f ns per wave-instr per SIMD   clock %.2f GHz -> %5.2f cycles\n", names[OP], ms, ns, ghz, ns * ghz);
 }
 
-template <int OP> void both(unsigned long long *c, uint32_t *s) { run<OP>(0, OP >= OP_DS_MAX_RAND && OP <= OP_DS_ADD_SEQ ? 100 : 400, c, s); }
+template <int OP> void both(unsigned long long *c, uint32_t *s) { run<OP>(0, OP >= OP_DS_MAX_RAND && OP <= OP_DS_ADD_SEQ ? 100 : 1600, c, s); }
 
 __global__ void copy_kernel(const uint4 *__restrict__ in, uint4 *__restrict__ out, size_t n)
 {
@@ -175,6 +216,8 @@ int main()
     both<OP_MAD_U64>(d_cyc, d_sink); both<OP_MUL_U24>(d_cyc, d_sink); both<OP_MAD_U24>(d_cyc, d_sink); both<OP_LSHR64>(d_cyc, d_sink);
     both<OP_ADD64>(d_cyc, d_sink); both<OP_FFBH>(d_cyc, d_sink); both<OP_BFE>(d_cyc, d_sink); both<OP_XOR3LIKE>(d_cyc, d_sink);
     both<OP_PERM>(d_cyc, d_sink);
+    both<OP_MOV>(d_cyc, d_sink); both<OP_ADD_U32>(d_cyc, d_sink); both<OP_ADD3>(d_cyc, d_sink); both<OP_LSHL_OR>(d_cyc, d_sink);
+    both<OP_MIX_XOR_MUL>(d_cyc, d_sink); both<OP_MIX_XOR_MAD64>(d_cyc, d_sink); both<OP_MIX_3XOR_MUL>(d_cyc, d_sink);
     both<OP_DS_MAX_RAND>(d_cyc, d_sink); both<OP_DS_MAX_SAME>(d_cyc, d_sink); both<OP_DS_OR_RAND>(d_cyc, d_sink); both<OP_DS_ADD_SEQ>(d_cyc, d_sink);
     // HBM copy / read bandwidth (2 GiB buffers, beyond the 256 MiB Infinity Cache)
     size_t bytes = (size_t)2 << 30;
