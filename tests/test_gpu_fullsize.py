@@ -1,0 +1,153 @@
+"""Full-size GPU checks at BASELINE.json's configurations (inputs generated in HBM; the oracle cannot finish these in
+seconds, so parity rests on size-independent properties of the path plus oracle spot checks on a few genomes):
+  * the device k-mer census equals the reference iterator's count (L - k + 1 per genome);
+  * spot-checked genomes are bit-identical to the CPU oracle;
+  * idempotence: unioning a batch into its own sketches changes nothing (max / OR are idempotent);
+  * permutation: sketching the genomes in another order permutes the images and nothing else;
+  * splitting: a genome sketched in two halves (overlapping by k-1 bases) and merged equals the genome sketched whole;
+  * streaming: cfg5's chunked accumulate path equals the one-shot sketch of the same reads.
+Set LASH_FULLSIZE=0 to shrink the workloads 10x (CI boxes with little HBM)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+FULL = os.environ.get("LASH_FULLSIZE", "1") != "0"
+L = 5_000_000
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    yield ctx, torch, lash_amd
+    ctx.close()
+
+
+def _sketch_synth(ctx, torch, lash_amd, first, G, algo, k, p, flags=0, d_img=None, d_seq=None):
+    dev = torch.device("cuda", 0)
+    if d_seq is None:
+        d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
+        ctx.synth_genomes_device(first, G, L, d_seq)
+    rec_off = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)
+    goff = np.arange(G + 1, dtype=np.uint64)
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+    ib = lash_amd.image_bytes(algo, p)
+    if d_img is None:
+        d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.enable_timing(True)
+    ctx.sketch_batch_device(algo, k, p, 42, d_seq, d_rec, G, goff, rec_off, d_img, flags=flags)
+    t = ctx.timing()
+    ctx.enable_timing(False)
+    return d_seq, d_img.view(G, ib), t
+
+
+@pytest.mark.parametrize("algo,k,p,G", [("hmh", 16, 0, 1000), ("hll", 21, 14, 10000)])
+def test_baseline_config_properties(env, algo, k, p, G):
+    """configs[1]: 1 000 x 5 Mbp hmh k=16;  configs[2]: 10 000 x 5 Mbp hll p=14 k=21 (50 GB of ASCII in HBM)."""
+    ctx, torch, lash_amd = env
+    if not FULL:
+        G //= 10
+    algo_id = lash_amd.ALGOS[algo]
+    d_seq, img, t = _sketch_synth(ctx, torch, lash_amd, 0, G, algo, k, p)
+    assert t["kmers"] == G * (L - k + 1) and t["bases_last"] == G * L
+    # oracle spot checks
+    for g in (0, G // 3, G - 1):
+        want = O.sketch_genomes(algo_id, k, p, 42, O.synth_genome(g, L), np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
+        assert np.array_equal(img[g].cpu().numpy(), want), g
+    # distinct genomes give distinct sketches (no slot is written twice / skipped)
+    assert torch.unique(img[: min(G, 512)], dim=0).shape[0] == min(G, 512)
+    # idempotence
+    before = img.clone()
+    _, img2, _ = _sketch_synth(ctx, torch, lash_amd, 0, G, algo, k, p, flags=lash_amd.F_ACCUMULATE, d_img=img.reshape(-1), d_seq=d_seq)
+    assert torch.equal(img2, before)
+    del d_seq, img2
+    # permutation: genomes G-1 .. 0 generated in reverse order
+    n = min(G, 64)
+    d_rev = torch.empty(n * L, dtype=torch.uint8, device="cuda:0")
+    for i in range(n):
+        ctx.synth_genomes_device(n - 1 - i, 1, L, d_rev[i * L:(i + 1) * L])
+    ctx.synchronize()
+    _, img_rev, _ = _sketch_synth(ctx, torch, lash_amd, 0, n, algo, k, p, d_seq=d_rev)
+    assert torch.equal(img_rev.flip(0), before[:n])
+
+
+@pytest.mark.parametrize("algo,k,p", [("hmh", 16, 0), ("hll", 21, 14), ("ull", 16, 12)])
+def test_split_and_merge_equals_whole(env, algo, k, p):
+    ctx, torch, lash_amd = env
+    dev = torch.device("cuda", 0)
+    G = 8
+    d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
+    ctx.synth_genomes_device(500, G, L, d_seq)
+    _, whole, _ = _sketch_synth(ctx, torch, lash_amd, 500, G, algo, k, p, d_seq=d_seq)
+    # two "genomes" per genome: [0, cut + k - 1) and [cut, L): together they contain every k-mer exactly as the whole does
+    cut = 2_345_679
+    halves = torch.cat([torch.cat([d_seq[g * L:g * L + cut + k - 1], d_seq[g * L + cut:(g + 1) * L]]) for g in range(G)])
+    lens = []
+    for g in range(G):
+        lens += [cut + k - 1, L - cut]
+    rec_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    goff = np.arange(2 * G + 1, dtype=np.uint64)
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+    ib = lash_amd.image_bytes(algo, p)
+    d_img = torch.zeros(2 * G * ib, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.sketch_batch_device(algo, k, p, 42, halves, d_rec, 2 * G, goff, rec_off, d_img)
+    ctx.synchronize()
+    parts = d_img.view(G, 2, ib)
+    a = parts[:, 0].contiguous()
+    b = parts[:, 1].contiguous()
+    ctx.merge_images_device(algo, p, a, b, G)
+    ctx.synchronize()
+    assert torch.equal(a, whole)
+
+
+def test_streamed_metagenome_chunks(env):
+    """configs[4] shape: 150-bp reads streamed in chunks into ONE ull p=12 sketch with on-device accumulation.
+    Full size would be 100 Gbp; the property (chunked == one-shot) is checked at 3 Gbp (0.3 Gbp when shrunk)."""
+    ctx, torch, lash_amd = env
+    dev = torch.device("cuda", 0)
+    total = 3_000_000_000 if FULL else 300_000_000
+    total -= total % 150
+    n_reads = total // 150
+    d_seq = torch.empty(total, dtype=torch.uint8, device=dev)
+    ctx.synth_genomes_device(900_000, 1, total, d_seq)          # one long random sequence cut into 150-bp reads
+    ctx.synchronize()
+    ib = lash_amd.image_bytes("ull", 12)
+
+    def run(chunks):
+        d_img = torch.zeros(ib, dtype=torch.uint8, device=dev)
+        per = (n_reads + chunks - 1) // chunks
+        kmers = 0
+        for c in range(chunks):
+            r0, r1 = c * per, min(n_reads, (c + 1) * per)
+            if r1 <= r0:
+                break
+            d_rec = (torch.arange(r0, r1 + 1, dtype=torch.int64, device=dev) * 150)
+            goff = np.array([0, r1 - r0], dtype=np.uint64)
+            gbo = np.array([r0 * 150, r1 * 150], dtype=np.uint64)
+            torch.cuda.synchronize()
+            ctx.enable_timing(True)
+            # record offsets are absolute into d_seq; genome_rec_off indexes d_rec
+            ctx.sketch_batch_device("ull", 16, 12, 42, d_seq, d_rec, r1 - r0, goff, gbo, d_img,
+                                    flags=lash_amd.F_ACCUMULATE if c else 0)
+            kmers += ctx.timing()["kmers"]
+            ctx.enable_timing(False)
+        return d_img, kmers
+
+    one, k1 = run(1)
+    many, k2 = run(7)
+    assert k1 == k2 == n_reads * (150 - 16 + 1)
+    assert torch.equal(one, many)
+    # oracle on a prefix of the reads, merged with itself, is a sub-sketch: every register it sets is <= in the full sketch's union
+    head = 200_000
+    host = d_seq[: head * 150].cpu().numpy()
+    off = (np.arange(head + 1, dtype=np.uint64) * 150)
+    sub = O.sketch_genomes(O.ULL, 16, 12, 42, host, off, np.array([0, head], np.uint64), threads=8)[0]
+    merged = O.merge_images(O.ULL, 12, one.cpu().numpy(), sub)
+    assert np.array_equal(merged, one.cpu().numpy())
