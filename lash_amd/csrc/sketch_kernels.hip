@@ -300,13 +300,23 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 #pragma unroll 1
         for (int wi = 0; wi < SKETCH_WORDS_PER_THREAD; ++wi) {
             uint32_t z;
-            if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
-            else           z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
+            if (all_valid) {
+                z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
+            } else {
+                // the masks are taken from an opaque copy so that hipcc cannot hoist the 16 v_bfe_i32 above the
+                // branch, where the (usual) all-valid path would pay for them too
+                uint32_t kvw = (uint32_t)kv;
+                asm volatile("" : "+v"(kvw));
+                z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+            }
             // FAST forms return a word whose smallness flags "rank not decided by the bits looked at": exact re-run
             // (HMH/x-high looks at 18 bits -> 2^-18 per k-mer; the others at 32 bits -> 2^-32)
             constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
-            if (z <= Z_REDO)
-                (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, (uint32_t)kv);
+            if (z <= Z_REDO) {
+                uint32_t kvw = (uint32_t)kv;
+                asm volatile("" : "+v"(kvw));
+                (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+            }
             // rotate the window by one word
             c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = 0;
             r0 = r1;
