@@ -118,6 +118,14 @@ uint64_t lash_packed_bytes(const lash_packed *pk);          /* device bytes held
 int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, const uint8_t *d_src, uint64_t n_images);
 int lash_merge_images(lash_ctx *ctx, int algo, int p, uint8_t *dst, const uint8_t *src, uint64_t n_images);
 
+/* dist side, HyperMinHash: the register scan of hyperminhash's Sketch::similarity for every (reference, query) pair
+ * (/root/reference/src/utils.rs:150-167):  out_c[r * n_qry + q] = #{i : a_i != 0 and a_i == b_i},
+ * out_n[r * n_qry + q] = #{i : a_i != 0 or b_i != 0}.  Images are 32 768-byte HMH sketches as written by `save`. */
+int lash_hmh_pair_counts_device(lash_ctx *ctx, const uint8_t *d_ref_images, uint32_t n_ref, const uint8_t *d_qry_images,
+                                uint32_t n_qry, uint32_t *d_out_c, uint32_t *d_out_n);
+int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
+                         uint32_t n_qry, uint32_t *out_c, uint32_t *out_n);
+
 /* Synthetic genomes of SURVEY.md §8(d) generated in HBM (bench / tests): genome ids first..first+n-1,
  * n_bases ASCII bytes each, written back to back at d_out. */
 int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out);

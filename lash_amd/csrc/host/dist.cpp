@@ -1,11 +1,221 @@
+// dist.cpp — `lash dist` for the gfx950 build.
+//
+// Mirrors /root/reference/src/main.rs:280-617 (file discovery, parameter checks, output formats, distance formula)
+// and utils.rs:84-184 (hmh_distance).  The O(N_ref * N_qry * 16384) register scan runs on the GPU
+// (lash_hmh_pair_counts); cardinalities (LogLog-beta) and the expected-collision correction are restated from
+// axiomhq/hyperminhash, which the crate hyperminhash 0.1.4 ports [PARITY UNPINNED, like every crate-internal rule].
+// Row order: the reference iterates hashbrown maps under rayon (nondeterministic); here rows come in
+// file order, so parity with the reference is on the SET of rows.
+// HyperLogLog / UltraLogLog distances need the crates' estimator tables (HLL++ bias data, FGRA constants) and are
+// not built yet.
 #include "dist.hpp"
 
-namespace lashhost {
+#include <dirent.h>
+#include <sys/stat.h>
 
-std::string run_dist(const DistOptions &)
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <vector>
+
+#include "../../../include/lash_gfx950.h"
+#include "json_out.hpp"
+#include "zstd_dl.hpp"
+
+namespace lashhost {
+namespace {
+
+constexpr int HP = 14, HQ = 6, HR = 10;
+constexpr uint32_t HM = 1u << HP;
+
+// main.rs:284-337
+std::string find_files(const std::string &prefix, std::map<std::string, std::string> &out)
 {
-    return "lash dist is not built yet in the gfx950 port (SURVEY.md section 8(f), row f2); "
-           "the sketch files written by `lash sketch` are the reference's format and can be read by upstream `lash dist`";
+    std::string norm = prefix;
+    size_t slash = norm.find_last_of('/');
+    if (slash != std::string::npos) norm = norm.substr(slash + 1);
+    if (norm.rfind("./", 0) == 0) norm = norm.substr(2);
+    DIR *d = opendir("./");
+    if (!d) return "cannot read the current directory";
+    out.clear();
+    while (dirent *e = readdir(d)) {
+        std::string name = e->d_name;
+        struct stat st;
+        if (stat(name.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
+        if (name.rfind(norm, 0) != 0) continue;
+        auto ends = [&](const char *suf) { size_t n = strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
+        if (ends("parameters.json")) out["params"] = name;
+        else if (ends("files.json")) out["files"] = name;
+        else if (ends(".bin")) out["sketches"] = name;
+    }
+    closedir(d);
+    if (out.size() != 3) {
+        std::ostringstream m;
+        m << "There should be 3 files starting with " << norm << " but " << out.size() << " were found instead";
+        return m.str();
+    }
+    return "";
+}
+
+std::string slurp(const std::string &path, std::string &out)
+{
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return "cannot open " + path;
+    std::ostringstream ss;
+    ss << in.rdbuf();
+    out = ss.str();
+    return "";
+}
+
+// hyperminhash (axiomhq) restated: LogLog-beta cardinality of one sketch
+double hmh_beta(double ez)
+{
+    const double zl = std::log(ez + 1.0);
+    return -0.370393911 * ez + 0.070471823 * zl + 0.17393686 * std::pow(zl, 2) + 0.16339839 * std::pow(zl, 3) +
+           -0.09237745 * std::pow(zl, 4) + 0.03738027 * std::pow(zl, 5) + -0.005384159 * std::pow(zl, 6) +
+           0.00042419 * std::pow(zl, 7);
+}
+
+double hmh_cardinality(const uint8_t *img)
+{
+    double sum = 0.0, ez = 0.0;
+    for (uint32_t i = 0; i < HM; ++i) {
+        const uint32_t reg = img[2 * i] | (img[2 * i + 1] << 8);
+        const uint32_t lz = reg >> (16 - HQ);
+        if (lz == 0) ez += 1.0;
+        sum += 1.0 / std::pow(2.0, (double)lz);
+    }
+    const double m = (double)HM;
+    const double alpha = 0.7213 / (1.0 + 1.079 / m);
+    return alpha * m * (m - ez) / (hmh_beta(ez) + sum);
+}
+
+double hmh_expected_collision(double n, double m)
+{
+    const double two_q = 64.0, two_r = 1024.0;
+    double x = 0.0;
+    for (double i = 1.0; i <= two_q; i += 1.0) {
+        for (double j = 1.0; j <= two_r; j += 1.0) {
+            double b1, b2;
+            if (i != two_q) {
+                const double den = std::pow(2.0, HP + HR + i);
+                b1 = (two_r + j) / den;
+                b2 = (two_r + j + 1.0) / den;
+            } else {
+                const double den = std::pow(2.0, HP + HR + i - 1.0);
+                b1 = j / den;
+                b2 = (j + 1.0) / den;
+            }
+            const double prx = std::pow(1.0 - b2, n) - std::pow(1.0 - b1, n);
+            const double pry = std::pow(1.0 - b2, m) - std::pow(1.0 - b1, m);
+            x += prx * pry;
+        }
+    }
+    return x * (double)HP + 0.5;
+}
+
+double hmh_approx_expected_collisions(double n, double m)
+{
+    if (n < m) std::swap(n, m);
+    if (n > std::pow(2.0, std::pow(2.0, (double)HQ) + (double)HR)) return 1.8446744073709552e19;   // u64::MAX
+    if (n > std::pow(2.0, (double)(HP + 5))) {
+        const double d = (4.0 * n / m) / std::pow((1.0 + n) / m, 2.0);
+        return 0.169919487159739093975315012348 * std::pow(2.0, (double)(HP - HR)) * d + 0.5;
+    }
+    return hmh_expected_collision(n, m) / (double)HP;
+}
+
+template <class T>
+T compute_distance(T frac, int k, int model)
+{
+    const T kk = (T)k;
+    if (model == 1) { const T d = -std::log(frac) / kk; return d < (T)1 ? d : (T)1; }      // (-frac.ln() / k).min(1)
+    return (T)1 - std::pow(frac, (T)1 / kk);
+}
+
+}  // namespace
+
+std::string run_dist(const DistOptions &opt)
+{
+    std::map<std::string, std::string> rf, qf;
+    std::string err = find_files(opt.ref_prefix, rf);
+    if (err.empty()) err = find_files(opt.query_prefix, qf);
+    if (!err.empty()) return err;
+    std::string txt;
+    std::map<std::string, std::string> rp, qp;
+    if (!(err = slurp(rf["params"], txt)).empty() || !json_parse_string_object(txt, rp)) return err.empty() ? "bad parameters JSON " + rf["params"] : err;
+    if (!(err = slurp(qf["params"], txt)).empty() || !json_parse_string_object(txt, qp)) return err.empty() ? "bad parameters JSON " + qf["params"] : err;
+    if (rp["k"] != qp["k"]) return "Genomes were not sketched with the same k";                       // main.rs:368-370
+    if (rp["algorithm"] != qp["algorithm"]) return "Algorithms do not match in query and sketch genomes";
+    const std::string algo = rp["algorithm"];
+    if ((algo == "ull" || algo == "hll") && rp["precision"] != qp["precision"])
+        return algo + " was not sketched with same precision btwn genomes";
+    const int k = atoi(rp["k"].c_str());
+    if (opt.model != 0 && opt.model != 1) return "model needs to be 0 or 1";
+    std::vector<std::string> rnames, qnames;
+    if (!(err = slurp(rf["files"], txt)).empty() || !json_parse_string_array(txt, rnames)) return err.empty() ? "bad names JSON " + rf["files"] : err;
+    if (!(err = slurp(qf["files"], txt)).empty() || !json_parse_string_array(txt, qnames)) return err.empty() ? "bad names JSON " + qf["files"] : err;
+    if (algo != "hmh")
+        return "lash dist for -a " + algo + " is not built in the gfx950 port yet (it needs the " +
+               (algo == "hll" ? "streaming_algorithms HLL++ bias tables" : "ultraloglog FGRA/ML estimator constants") + ")";
+    const bool same_files = qf["files"] == rf["files"];                                               // main.rs:404
+
+    std::vector<uint8_t> rimg, qimg;
+    if (!(err = zstd_decompress_file(rf["sketches"], rimg)).empty()) return err;
+    if (!(err = zstd_decompress_file(qf["sketches"], qimg)).empty()) return err;
+    const size_t ib = (size_t)HM * 2;
+    if (rimg.size() < rnames.size() * ib) return "Error with reading from " + rf["sketches"];
+    if (qimg.size() < qnames.size() * ib) return "Error with reading from " + qf["sketches"];
+    const uint32_t nr = (uint32_t)rnames.size(), nq = (uint32_t)qnames.size();
+
+    // ---- GPU: C and N of every pair ----
+    std::vector<uint32_t> C((size_t)nr * nq), N((size_t)nr * nq);
+    {
+        lash_ctx *ctx = nullptr;
+        int rc = lash_ctx_create(&ctx, opt.device);
+        if (rc != LASH_OK) return lash_strerror(rc);
+        rc = lash_hmh_pair_counts(ctx, rimg.data(), nr, qimg.data(), nq, C.data(), N.data());
+        std::string e2 = rc == LASH_OK ? "" : std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
+        lash_ctx_destroy(ctx);
+        if (!e2.empty()) return e2;
+    }
+    std::vector<double> rcard(nr), qcard(nq);
+    for (uint32_t i = 0; i < nr; ++i) rcard[i] = hmh_cardinality(rimg.data() + i * ib);
+    for (uint32_t j = 0; j < nq; ++j) qcard[j] = hmh_cardinality(qimg.data() + j * ib);
+
+    FILE *out = fopen(opt.output_file.c_str(), "w");
+    if (!out) return "cannot create " + opt.output_file;
+    if (!opt.matrix) fprintf(out, "Reference\tQuery\tDistance\n");                                   // main.rs:409-412
+    else for (uint32_t j = 0; j < nq; ++j) fprintf(out, "\t%s", qnames[j].c_str());                   // main.rs:439-441
+    for (uint32_t i = 0; i < nr; ++i) {
+        bool first = true;
+        for (uint32_t j = 0; j < nq; ++j) {
+            if (same_files && j > i) continue;                                                        // utils.rs:158-160
+            const double c = (double)C[(size_t)i * nq + j], n = (double)N[(size_t)i * nq + j];
+            double sim = 0.0;
+            if (c != 0.0) {                                                                           // Sketch::similarity
+                const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
+                sim = c < ec ? 0.0 : (c - ec) / n;
+            }
+            if (sim < 0.0) sim = 0.0;                                                                 // .max(0.0), utils.rs:164
+            const double frac = 2.0 * sim / (1.0 + sim);                                              // utils.rs:165-167
+            double d;
+            if (qnames[j] == rnames[i]) d = 0.0;                                                      // main.rs:452-453
+            else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
+            else d = compute_distance<double>(frac, k, opt.model);
+            if (!opt.matrix) fprintf(out, "%s\t%s\t%.6f\n", rnames[i].c_str(), qnames[j].c_str(), d);
+            else {
+                if (first) fprintf(out, "\n%s", rnames[i].c_str());
+                fprintf(out, "\t%.6f", d);
+            }
+            first = false;
+        }
+    }
+    fclose(out);
+    return "";
 }
 
 }  // namespace lashhost

@@ -689,6 +689,36 @@ int lash_merge_images(lash_ctx *ctx, int algo, int p, uint8_t *dst, const uint8_
     return LASH_OK;
 }
 
+int lash_hmh_pair_counts_device(lash_ctx *ctx, const uint8_t *d_ref_images, uint32_t n_ref, const uint8_t *d_qry_images,
+                                uint32_t n_qry, uint32_t *d_out_c, uint32_t *d_out_n)
+{
+    if (!ctx || ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_c || !d_out_n))) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, launch_hmh_pairs(d_ref_images, n_ref, d_qry_images, n_qry, d_out_c, d_out_n, ctx->stream));
+    return LASH_OK;
+}
+
+int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
+                         uint32_t n_qry, uint32_t *out_c, uint32_t *out_n)
+{
+    if (!ctx || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_c || !out_n))) return LASH_EINVAL;
+    if (n_ref == 0 || n_qry == 0) return LASH_OK;
+    (void)hipSetDevice(ctx->device);
+    const size_t ib = (size_t)HMH_M * 2, rb = ib * n_ref, qb = ib * n_qry, pb = (size_t)n_ref * n_qry * 4;
+    int rc;
+    if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->st_img, 2 * pb + 64))) return rc;
+    uint8_t *d_r = static_cast<uint8_t *>(ctx->st_seq.ptr), *d_q = d_r + rb;
+    uint32_t *d_c = static_cast<uint32_t *>(ctx->st_img.ptr), *d_n = d_c + (size_t)n_ref * n_qry;
+    HIPCHK(ctx, hipMemcpyAsync(d_r, ref_images, rb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_q, qry_images, qb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = lash_hmh_pair_counts_device(ctx, d_r, n_ref, d_q, n_qry, d_c, d_n))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_c, d_c, pb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out_n, d_n, pb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
 int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out)
 {
     if (!ctx || (n_genomes && n_bases && !d_out)) return LASH_EINVAL;

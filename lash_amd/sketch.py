@@ -192,6 +192,18 @@ class Context:
         self._check(self._lib.lash_merge_images(self._h, _algo(algo), int(p or 0), dst.ctypes.data, src.ctypes.data, n))
         return dst
 
+    def hmh_pair_counts(self, ref_images, qry_images):
+        """HyperMinHash pair statistics (C, N) of serialized sketches: numpy uint8 [n, 32768] in, two uint32
+        [n_ref, n_qry] arrays out (hyperminhash Sketch::similarity's register scan, utils.rs:164)."""
+        ref = np.ascontiguousarray(ref_images, dtype=np.uint8)
+        qry = np.ascontiguousarray(qry_images, dtype=np.uint8)
+        assert ref.ndim == 2 and qry.ndim == 2 and ref.shape[1] == 32768 and qry.shape[1] == 32768
+        c = np.zeros((ref.shape[0], qry.shape[0]), dtype=np.uint32)
+        n = np.zeros_like(c)
+        self._check(self._lib.lash_hmh_pair_counts(self._h, ref.ctypes.data, ref.shape[0], qry.ctypes.data, qry.shape[0],
+                                                   c.ctypes.data, n.ctypes.data))
+        return c, n
+
     def synth_genomes_device(self, first_genome, n_genomes, n_bases, d_out):
         self._check(self._lib.lash_synth_genomes_device(self._h, int(first_genome), int(n_genomes), int(n_bases),
                                                         _ptr(d_out)))

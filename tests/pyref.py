@@ -134,3 +134,69 @@ def ull_sketch(records, k, p, seed):
             nlz = clz64(t)
             st[idx] = ull_pack(ull_unpack(st[idx]) | (1 << (nlz + p - 1)))
     return struct.pack("<Q", 1 << p) + bytes(st)
+
+
+# ---- dist side: hyperminhash similarity as published by axiomhq/hyperminhash (the crate hyperminhash 0.1.4 ports it)
+# and the Mash-style distance of main.rs:415-423.  [PARITY UNPINNED like every crate-internal rule.]
+import math
+
+
+def hmh_regs(image: bytes):
+    return struct.unpack("<16384H", image)
+
+
+def hmh_cardinality(image: bytes) -> float:
+    s, ez = 0.0, 0.0
+    for r in hmh_regs(image):
+        lz = r >> 10
+        if lz == 0:
+            ez += 1.0
+        s += 1.0 / math.pow(2.0, lz)
+    m = 16384.0
+    alpha = 0.7213 / (1.0 + 1.079 / m)
+    zl = math.log(ez + 1.0)
+    beta = (-0.370393911 * ez + 0.070471823 * zl + 0.17393686 * zl ** 2 + 0.16339839 * zl ** 3 - 0.09237745 * zl ** 4
+            + 0.03738027 * zl ** 5 - 0.005384159 * zl ** 6 + 0.00042419 * zl ** 7)
+    return alpha * m * (m - ez) / (beta + s)
+
+
+def hmh_expected_collisions(n: float, m: float) -> float:
+    p, q, r = 14, 6, 10
+    if n < m:
+        n, m = m, n
+    if n > 2.0 ** (2 ** q + r):
+        return 1.8446744073709552e19
+    if n > 2.0 ** (p + 5):
+        d = (4.0 * n / m) / ((1.0 + n) / m) ** 2
+        return 0.169919487159739093975315012348 * 2.0 ** (p - r) * d + 0.5
+    x = 0.0
+    for i in range(1, 65):
+        for j in range(1, 1025):
+            if i != 64:
+                den = 2.0 ** (p + r + i)
+                b1, b2 = (1024 + j) / den, (1024 + j + 1) / den
+            else:
+                den = 2.0 ** (p + r + i - 1)
+                b1, b2 = j / den, (j + 1) / den
+            x += (math.pow(1 - b2, n) - math.pow(1 - b1, n)) * (math.pow(1 - b2, m) - math.pow(1 - b1, m))
+    return (x * p + 0.5) / p
+
+
+def hmh_similarity(a: bytes, b: bytes) -> float:
+    ra, rb = hmh_regs(a), hmh_regs(b)
+    c = sum(1 for x, y in zip(ra, rb) if x != 0 and x == y)
+    n = sum(1 for x, y in zip(ra, rb) if x != 0 or y != 0)
+    if c == 0:
+        return 0.0
+    ec = hmh_expected_collisions(hmh_cardinality(a), hmh_cardinality(b))
+    return 0.0 if c < ec else (c - ec) / n
+
+
+def mash_distance(sim: float, k: int, model: int, same_name: bool) -> float:
+    sim = max(sim, 0.0)
+    frac = 2.0 * sim / (1.0 + sim)
+    if same_name:
+        return 0.0
+    if model == 1:
+        return 1.0 if frac == 0.0 else min(-math.log(frac) / k, 1.0)
+    return 1.0 - frac ** (1.0 / k)

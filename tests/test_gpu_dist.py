@@ -1,0 +1,106 @@
+"""GPU tests of the dist side: the HyperMinHash pair-statistics kernel against numpy, and the
+`lash dist` command line against a pure-Python restatement of hyperminhash's similarity + the Mash distance
+(main.rs:415-423).  Row order is nondeterministic in the reference, so rows are compared as a set."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_lib as H
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_hmh_pair_counts_match_numpy():
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    rng = np.random.default_rng(9)
+    nr, nq = 37, 21
+    ref = rng.integers(0, 5, size=(nr, 16384), dtype=np.uint16)        # small alphabet -> many equal / zero registers
+    qry = rng.integers(0, 5, size=(nq, 16384), dtype=np.uint16)
+    qry[3] = ref[5]
+    qry[4] = 0
+    c, n = ctx.hmh_pair_counts(ref.view(np.uint8).reshape(nr, -1), qry.view(np.uint8).reshape(nq, -1))
+    want_c = ((ref[:, None, :] == qry[None, :, :]) & (ref[:, None, :] != 0)).sum(axis=2)
+    want_n = ((ref[:, None, :] != 0) | (qry[None, :, :] != 0)).sum(axis=2)
+    assert np.array_equal(c, want_c) and np.array_equal(n, want_n)
+    ctx.close()
+
+
+def _mutated(seq: np.ndarray, rate: float, seed: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    out = seq.copy()
+    idx = rng.random(len(seq)) < rate
+    out[idx] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(idx.sum()))
+    return out
+
+
+@pytest.mark.parametrize("matrix,model,fp32", [(False, 1, False), (True, 1, False), (False, 0, True)])
+def test_lash_dist_cli_hmh(tmp_path, matrix, model, fp32):
+    # five related genomes (mutation rates 0 .. 10 %) so that distances span the interesting range
+    base = O.synth_genome(77, 400_000)
+    genomes = [base, _mutated(base, 0.001, 1), _mutated(base, 0.01, 2), _mutated(base, 0.1, 3), O.synth_genome(78, 400_000)]
+    paths = []
+    for i, g in enumerate(genomes):
+        p = tmp_path / ("g%d.fa" % i)
+        p.write_bytes(b">g\n" + g.tobytes() + b"\n")
+        paths.append(str(p))
+    (tmp_path / "all.txt").write_text("\n".join(paths) + "\n")
+    (tmp_path / "two.txt").write_text("\n".join(paths[:2]) + "\n")
+    env = dict(os.environ)
+    for pre, lst in (("refs", "all.txt"), ("qry", "two.txt")):
+        r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / lst), "-o", pre, "-k", "16"], cwd=tmp_path, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+    imgs = [O.sketch_genomes(O.HMH, 16, 0, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0].tobytes() for g in genomes]
+
+    def expected(ri, qi):
+        return R.mash_distance(R.hmh_similarity(imgs[qi], imgs[ri]), 16, model, paths[ri] == paths[qi])
+
+    flags = (["--dm"] if matrix else []) + (["--fp32"] if fp32 else []) + ["-m", str(model)]
+    # all-vs-all on the same files: lower triangle incl. the diagonal, every unordered pair exactly once
+    r = subprocess.run([H.CLI, "dist", "-q", "refs", "-r", "refs", "-o", "d_self.txt"] + flags, cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "Distances computed." in r.stdout
+    text = (tmp_path / "d_self.txt").read_text()
+    tol = 2e-6 if fp32 else 1.1e-6
+    if not matrix:
+        lines = text.strip().split("\n")
+        assert lines[0] == "Reference\tQuery\tDistance"
+        rows = {}
+        for ln in lines[1:]:
+            a, b, d = ln.split("\t")
+            rows[frozenset((a, b))] = float(d)
+        assert len(rows) == 5 * 6 // 2 and len(lines) - 1 == 15
+        for i in range(5):
+            for j in range(i + 1):
+                assert abs(rows[frozenset((paths[i], paths[j]))] - expected(i, j)) <= tol, (i, j)
+        d01 = rows[frozenset((paths[0], paths[1]))]
+        d03 = rows[frozenset((paths[0], paths[3]))]
+        d04 = rows[frozenset((paths[0], paths[4]))]
+        assert 0 < d01 < rows[frozenset((paths[0], paths[2]))] < d03 <= d04 <= 1.0
+    else:
+        lines = text.split("\n")
+        assert lines[0] == "".join("\t" + p for p in paths)
+        assert len(lines) == 6 and not text.endswith("\n")
+        for i, ln in enumerate(lines[1:]):
+            cells = ln.split("\t")
+            assert cells[0] == paths[i] and len(cells) == i + 2
+            for j, d in enumerate(cells[1:]):
+                assert abs(float(d) - expected(i, j)) <= tol
+    # query set vs reference set (different files): full rectangle
+    r = subprocess.run([H.CLI, "dist", "-q", "qry", "-r", "refs", "-o", "d_qr.txt", "-m", str(model)], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = (tmp_path / "d_qr.txt").read_text().strip().split("\n")
+    assert len(lines) == 1 + 5 * 2
+    for ln in lines[1:]:
+        a, b, d = ln.split("\t")
+        assert abs(float(d) - R.mash_distance(R.hmh_similarity(imgs[paths.index(b)], imgs[paths.index(a)]), 16, model, a == b)) <= 1.1e-6
+    # mismatched k is refused like the reference's panic (main.rs:368-370)
+    r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "two.txt"), "-o", "k21", "-k", "21"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0
+    r = subprocess.run([H.CLI, "dist", "-q", "k21", "-r", "refs"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "same k" in r.stderr
