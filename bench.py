@@ -168,7 +168,7 @@ def main():
         out = {
             "metric": "k-mers/s sketched (%s, k=%d)" % (algo, k), "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64" if algo != "hmh" else "u32/u64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "%d synthetic %d-bp genomes per GPU, -a %s -k %d%s, seed %d, ASCII records resident in HBM "
                                    "-> sketch images in HBM (pack + sketch + finalize)"

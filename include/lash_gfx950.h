@@ -80,6 +80,11 @@ const char *lash_ctx_last_error(lash_ctx *ctx);
 int         lash_ctx_enable_timing(lash_ctx *ctx, int on); /* (re)starts the sums; HIP events around each stage */
 int         lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out);   /* synchronizes the stream */
 
+/* Page-locked host memory for the buffers handed to lash_sketch_batch (optional: pageable memory works, pinned memory
+ * lets the H2D copy run at PCIe speed).  Free with lash_host_free_pinned. */
+void       *lash_host_alloc_pinned(size_t bytes);
+void        lash_host_free_pinned(void *p);
+
 /* ---- parameters / sizes (host only, no GPU needed) -------------------------------------------------------- */
 int         lash_params_check(const lash_params *prm);     /* LASH_OK or LASH_EINVAL */
 size_t      lash_sketch_image_bytes(int algo, int p);      /* bytes S::save writes per sketch; 0 if invalid */

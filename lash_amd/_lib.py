@@ -40,6 +40,8 @@ PROTOTYPES = {
     "lash_ctx_last_error": (C.c_char_p, [_vp]),
     "lash_ctx_enable_timing": (_int, [_vp, _int]),
     "lash_ctx_get_timing": (_int, [_vp, C.POINTER(Timing)]),
+    "lash_host_alloc_pinned": (_vp, [C.c_size_t]),
+    "lash_host_free_pinned": (None, [_vp]),
     "lash_params_check": (_int, [_PP]),
     "lash_sketch_image_bytes": (C.c_size_t, [_int, _int]),
     "lash_sketch_batch": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),

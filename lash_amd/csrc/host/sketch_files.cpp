@@ -1,5 +1,6 @@
 #include "sketch_files.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -58,9 +59,31 @@ struct ParsedFile {
     bool done = false;
 };
 
+// sequence bytes of one batch in page-locked memory (H2D at PCIe speed); buffers are recycled between batches
+struct PinnedBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0, size = 0;
+    bool append(const uint8_t *src, size_t n)
+    {
+        if (size + n > cap) {
+            size_t want = std::max(size + n, cap + cap / 2 + (64u << 20));
+            uint8_t *q = static_cast<uint8_t *>(lash_host_alloc_pinned(want));
+            if (!q) return false;
+            if (size) memcpy(q, p, size);
+            lash_host_free_pinned(p);
+            p = q;
+            cap = want;
+        }
+        if (n) memcpy(p + size, src, n);
+        size += n;
+        return true;
+    }
+    ~PinnedBuf() { lash_host_free_pinned(p); }
+};
+
 struct Batch {
     uint64_t index = 0;
-    std::vector<uint8_t> seq;
+    std::unique_ptr<PinnedBuf> seq;
     std::vector<uint64_t> rec_off{0};
     std::vector<uint64_t> genome_rec_off{0};
     std::vector<uint8_t> images;
@@ -115,6 +138,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     for (int r = 0; r < n_readers; ++r) readers.emplace_back(reader);
 
     // ---- stage 3: GPU workers ----
+    std::vector<std::unique_ptr<PinnedBuf>> pool;            // recycled pinned buffers (guarded by qmu)
     std::deque<std::shared_ptr<Batch>> todo;
     std::map<uint64_t, std::shared_ptr<Batch>> finished;
     std::mutex qmu;
@@ -136,12 +160,13 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             else {
                 const uint32_t ng = (uint32_t)(b->genome_rec_off.size() - 1);
                 b->images.assign((size_t)ng * ib, 0);
-                int r2 = lash_sketch_batch(ctx, &prm, b->seq.data(), b->rec_off.data(), b->rec_off.size() - 1,
+                int r2 = lash_sketch_batch(ctx, &prm, b->seq->p, b->rec_off.data(), b->rec_off.size() - 1,
                                            b->genome_rec_off.data(), ng, b->images.data());
                 if (r2 != LASH_OK) b->err = std::string(lash_strerror(r2)) + " " + lash_ctx_last_error(ctx);
             }
-            std::vector<uint8_t>().swap(b->seq);
             std::lock_guard<std::mutex> lk(qmu);
+            b->seq->size = 0;
+            pool.push_back(std::move(b->seq));
             finished[b->index] = b;
             cv_done.notify_all();
         }
@@ -177,7 +202,14 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     // ---- stage 2 (this thread): merge parsed files into batches in file order ----
     std::string err;
     uint64_t n_records = 0, n_bytes = 0, batch_index = 0;
-    auto cur = std::make_shared<Batch>();
+    auto new_batch = [&]() {
+        auto b = std::make_shared<Batch>();
+        std::lock_guard<std::mutex> lk(qmu);
+        if (!pool.empty()) { b->seq = std::move(pool.back()); pool.pop_back(); }
+        else b->seq.reset(new PinnedBuf());
+        return b;
+    };
+    auto cur = new_batch();
     auto submit = [&]() {
         cur->index = batch_index++;
         {
@@ -185,10 +217,11 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             todo.push_back(cur);
             cv_todo.notify_one();
         }
-        cur = std::make_shared<Batch>();
-        // keep at most 2 batches per device queued or running
-        std::unique_lock<std::mutex> lk(qmu);
-        cv_done.wait(lk, [&] { return todo.size() < 2 * devices.size(); });
+        {   // keep at most 2 batches per device queued or running
+            std::unique_lock<std::mutex> lk(qmu);
+            cv_done.wait(lk, [&] { return todo.size() < 2 * devices.size(); });
+        }
+        cur = new_batch();
     };
     for (size_t i = 0; i < n_files && err.empty(); ++i) {
         ParsedFile *pf = parsed[i].get();
@@ -197,8 +230,8 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             cv_parsed.wait(lk, [&] { return pf->done; });
         }
         if (!pf->err.empty()) { err = pf->err; break; }
-        const uint64_t base = cur->seq.size();
-        cur->seq.insert(cur->seq.end(), pf->rb.seq.begin(), pf->rb.seq.end());
+        const uint64_t base = cur->seq->size;
+        if (!cur->seq->append(pf->rb.seq.data(), pf->rb.seq.size())) { err = "out of pinned host memory"; break; }
         for (size_t r = 1; r < pf->rb.rec_off.size(); ++r) cur->rec_off.push_back(base + pf->rb.rec_off[r]);
         cur->genome_rec_off.push_back(cur->rec_off.size() - 1);
         n_records += pf->rb.n_rec();
@@ -210,7 +243,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             cv_window.notify_all();
         }
         parsed[i].reset();
-        if (cur->seq.size() >= opt.batch_bytes) submit();
+        if (cur->seq->size >= opt.batch_bytes) submit();
     }
     if (err.empty() && cur->genome_rec_off.size() > 1) submit();
     {

@@ -372,6 +372,18 @@ const char *lash_strerror(int code)
     }
 }
 
+void *lash_host_alloc_pinned(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void lash_host_free_pinned(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int lash_params_check(const lash_params *prm)
 {
     if (!prm) return LASH_EINVAL;

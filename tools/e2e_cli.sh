@@ -1,0 +1,27 @@
+#!/bin/bash
+# tools/e2e_cli.sh [n_genomes] — end-to-end `lash sketch` from FASTA files on tmpfs (host parse + PCIe + GPU + zstd),
+# the number DESIGN.md quotes beside the HBM-resident rate.  Run on the GPU box.
+N=${1:-200}
+REPO=$(pwd)
+D=/dev/shm/lash_e2e_$$
+mkdir -p $D && cd $D
+python3 - <<PY
+import sys
+sys.path.insert(0, "$REPO/tests")
+import oracle_lib as O
+names = []
+for g in range($N):
+    s = O.synth_genome(g, 5_000_000).tobytes()
+    with open("g%d.fa" % g, "wb") as f:
+        f.write(b">g%d\n" % g)
+        f.write(b"\n".join(s[i:i + 80] for i in range(0, len(s), 80)))
+        f.write(b"\n")
+    names.append("$D/g%d.fa" % g)
+open("list.txt", "w").write("\n".join(names) + "\n")
+PY
+for T in 8 32 64; do
+  S=$(date +%s.%N); $REPO/lash_amd/bin/lash sketch -f list.txt -o out_$T -k 16 -t $T 2>&1 | tail -1; E=$(date +%s.%N)
+  python3 -c "print(\"threads=$T wall=%.2f s\" % ($E - $S))"
+done
+ls -la out_32_sketches.bin | awk '{print "sketches.bin bytes:", $5}'
+cd / && rm -rf $D
