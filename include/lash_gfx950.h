@@ -108,6 +108,17 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm,
                              const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
                              uint32_t n_genomes, uint8_t *d_out_images);
 
+/* File bytes in: the FASTA / FASTQ parse itself runs on the device, so the host only reads (or
+ * inflates) files into one buffer.  file_fmt[g] is LASH_FMT_FASTA ('>' files) or LASH_FMT_FASTQ ('@' files, 4-line
+ * records); file g is bytes [file_off[g], file_off[g+1]) of raw, uncompressed.  Semantics are needletail's
+ * (utils.rs:453-459) followed by the same path as lash_sketch_batch: one sketch per file. */
+#define LASH_FMT_FASTA 1
+#define LASH_FMT_FASTQ 2
+int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *raw, const uint64_t *file_off,
+                          const uint8_t *file_fmt, uint32_t n_files, uint8_t *out_images);
+int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_raw, const uint64_t *file_off,
+                                 const uint8_t *file_fmt, uint32_t n_files, uint8_t *d_out_images);
+
 /* Two-stage form for callers that keep genomes resident in HBM as 2-bit (0.28 B/base incl. break bitmap):
  * pack once, sketch many times (other k / algo / seed).  The pack stage performs filter_out_n + KSeq::new
  * (utils.rs:459,464) and records where records begin so that no k-mer spans two records (utils.rs:457-464). */

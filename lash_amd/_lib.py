@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx95
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT = 0, -1, -2, -3, -4, -5
 HMH, HLL, ULL = 0, 1, 2
 F_HMH_X_LOW, F_ACCUMULATE = 1, 2
+FMT_FASTA, FMT_FASTQ = 1, 2
 ABI_VERSION = 1
 
 
@@ -46,6 +47,8 @@ PROTOTYPES = {
     "lash_sketch_image_bytes": (C.c_size_t, [_int, _int]),
     "lash_sketch_batch": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),
     "lash_sketch_batch_device": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
+    "lash_sketch_files_raw": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
+    "lash_sketch_files_raw_device": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
     "lash_pack_device": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
     "lash_sketch_packed_device": (_int, [_vp, _PP, _vp, _vp]),
     "lash_packed_free": (None, [_vp, _vp]),

@@ -168,23 +168,26 @@ uint64_t header_bytes(int algo) { return algo == LASH_HMH ? 0 : algo == LASH_HLL
 // into d_seq) on `stream`.  `ev`, when set, gets its pack-start / pack-end events recorded on that stream.
 int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, const uint8_t *d_seq, const uint8_t *d_seq_end,
               const uint64_t *d_rec_off, uint64_t n_rec, const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
-              uint32_t n_genomes)
+              uint32_t n_genomes, const uint8_t *formats = nullptr)
 {
-    if (n_genomes && (!genome_rec_off || !genome_byte_off)) return LASH_EINVAL;
+    // formats == nullptr: record sequences + rec_off table; else per genome LASH_FMT_FASTA / LASH_FMT_FASTQ raw file bytes
+    if (n_genomes && (!genome_byte_off || (!formats && !genome_rec_off))) return LASH_EINVAL;
     pk->error_flag = nullptr;
     std::vector<GenomeDesc> descs(n_genomes);
     pk->byte_len.assign(n_genomes, 0);
     uint64_t wo = 0, bo = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) {
-        if (genome_rec_off[g + 1] < genome_rec_off[g] || genome_byte_off[g + 1] < genome_byte_off[g] ||
-            genome_rec_off[g + 1] > n_rec)
-            return LASH_EINVAL;
+        if (genome_byte_off[g + 1] < genome_byte_off[g]) return LASH_EINVAL;
+        if (!formats && (genome_rec_off[g + 1] < genome_rec_off[g] || genome_rec_off[g + 1] > n_rec)) return LASH_EINVAL;
+        if (formats && formats[g] != LASH_FMT_FASTA && formats[g] != LASH_FMT_FASTQ) return LASH_EINVAL;
         GenomeDesc &d = descs[g];
         d.byte_off = genome_byte_off[g];
         d.byte_len = genome_byte_off[g + 1] - genome_byte_off[g];
         if (d.byte_len > 0xFFFFFFFFull - 64) return LASH_ELIMIT;
-        d.rec_begin = genome_rec_off[g];
-        d.rec_end = genome_rec_off[g + 1];
+        d.rec_begin = formats ? 0 : genome_rec_off[g];
+        d.rec_end = formats ? 0 : genome_rec_off[g + 1];
+        d.format = formats ? formats[g] : 0u;
+        d.pad = 0;
         d.word_off = wo;
         d.brk_off = bo;
         pk->byte_len[g] = d.byte_len;
@@ -215,16 +218,17 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     if ((rc = reserve(ctx, pk->descs, (size_t)(n_genomes + 1) * sizeof(GenomeDesc)))) return rc;
     if ((rc = reserve(ctx, pk->tile_begin, (size_t)(n_genomes + 1) * 4))) return rc;
     if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
-    if ((rc = reserve(ctx, pk->lookback, (size_t)(n_tiles + 2) * 8 + PACK_TICKET_SHARDS * 128 + 256))) return rc;
+    if ((rc = reserve(ctx, pk->lookback, (size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512))) return rc;
     if (n_genomes == 0) return LASH_OK;
     if (ev) { ev->pack = true; HIPCHK(ctx, hipEventRecord(ev->e[0], stream)); }
     if ((rc = upload(ctx, pk->descs.ptr, descs.data(), descs.size() * sizeof(GenomeDesc), stream))) return rc;
     if ((rc = upload(ctx, pk->tile_begin.ptr, tile_begin.data(), tile_begin.size() * 4, stream))) return rc;
     bool any_multi = false;                                   // single-record genomes never consult the bitmap
-    for (uint32_t g = 0; g < n_genomes && !any_multi; ++g) any_multi = descs[g].rec_end - descs[g].rec_begin > 1;
+    for (uint32_t g = 0; g < n_genomes && !any_multi; ++g)
+        any_multi = descs[g].format != 0u || descs[g].rec_end - descs[g].rec_begin > 1;
     if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
     HIPCHK(ctx, hipMemsetAsync(pk->nvalid.ptr, 0, (size_t)(n_genomes + 1) * 8, stream));
-    HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, (size_t)(n_tiles + 2) * 8 + PACK_TICKET_SHARDS * 128 + 256, stream));
+    HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, (size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512, stream));
     PackArgs pa{};
     pa.seq = d_seq;
     pa.seq_end = d_seq_end;
@@ -238,7 +242,8 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     v2.tiles = static_cast<const TileInfo *>(pk->tiles.ptr);
     v2.desc = lb;
     v2.error_flag = reinterpret_cast<uint32_t *>(lb + n_tiles);
-    v2.ticket = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(lb + n_tiles + 1) + 127) & ~(uintptr_t)127);
+    v2.desc2 = reinterpret_cast<uint32_t *>(lb + n_tiles + 1);
+    v2.ticket = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(v2.desc2 + n_tiles + 1) + 127) & ~(uintptr_t)127);
     v2.n_tiles = (uint32_t)n_tiles;
     PackMapArgs pm{};
     pm.seq = d_seq;
@@ -248,7 +253,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pm.tiles = static_cast<TileInfo *>(pk->tiles.ptr);
     pm.n_tiles = (uint32_t)n_tiles;
     pm.n_genomes = n_genomes;
-    HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, stream));
+    HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, formats != nullptr, stream));
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[1], stream));
     pk->error_flag = v2.error_flag;
     return LASH_OK;
@@ -637,6 +642,51 @@ int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq,
     rc = lash_sketch_batch_device(ctx, prm, static_cast<const uint8_t *>(ctx->st_seq.ptr),
                                   static_cast<const uint64_t *>(ctx->st_rec.ptr), n_rec, genome_rec_off, gbo.data(),
                                   n_genomes, static_cast<uint8_t *>(ctx->st_img.ptr));
+    if (rc) return rc;
+    if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (const lash_packed *pk : ctx->last_packed)
+        if ((rc = check_pack_flag(ctx, pk))) return rc;
+    return LASH_OK;
+}
+
+int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_raw, const uint64_t *file_off,
+                                 const uint8_t *file_fmt, uint32_t n_files, uint8_t *d_out_images)
+{
+    if (!ctx || (n_files && (!d_out_images || !file_off || !file_fmt))) return LASH_EINVAL;
+    int rc = lash_params_check(prm);
+    if (rc) return rc;
+    (void)hipSetDevice(ctx->device);
+    ctx->last_packed.clear();
+    ctx->last.calls += 1;
+    if (n_files == 0) return LASH_OK;
+    if ((rc = timing_begin(ctx))) return rc;
+    EvSet *ev = ctx->cur_ev;
+    rc = pack_into(ctx, &ctx->scratch, ctx->stream, ev, d_raw, d_raw + file_off[n_files], nullptr, 0, nullptr, file_off, n_files,
+                   file_fmt);
+    if (rc) return rc;
+    rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
+    ctx->cur_ev = nullptr;
+    return rc;
+}
+
+int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *raw, const uint64_t *file_off,
+                          const uint8_t *file_fmt, uint32_t n_files, uint8_t *out_images)
+{
+    if (!ctx || !file_off || (n_files && (!out_images || !file_fmt))) return LASH_EINVAL;
+    int rc = lash_params_check(prm);
+    if (rc) return rc;
+    (void)hipSetDevice(ctx->device);
+    const uint64_t bytes = file_off[n_files];
+    if (bytes && !raw) return LASH_EINVAL;
+    const size_t img_bytes = (size_t)n_files * lash_sketch_image_bytes(prm->algo, prm->p);
+    if ((rc = reserve(ctx, ctx->st_seq, bytes + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->st_img, img_bytes + 64))) return rc;
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->st_seq.ptr, raw, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((prm->flags & LASH_F_ACCUMULATE) && img_bytes)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->st_img.ptr, out_images, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = lash_sketch_files_raw_device(ctx, prm, static_cast<const uint8_t *>(ctx->st_seq.ptr), file_off, file_fmt, n_files,
+                                      static_cast<uint8_t *>(ctx->st_img.ptr));
     if (rc) return rc;
     if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

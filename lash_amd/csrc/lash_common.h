@@ -16,8 +16,10 @@ struct GenomeDesc {
     uint64_t byte_len;    // bytes of all its records
     uint64_t word_off;    // into words[]
     uint64_t brk_off;     // into brk[] (u32 units)
-    uint64_t rec_begin;   // records [rec_begin, rec_end) of rec_off[]
+    uint64_t rec_begin;   // records [rec_begin, rec_end) of rec_off[]  (format 0 only)
     uint64_t rec_end;
+    uint32_t format;      // 0 = record sequences + rec_off table; 1 = raw FASTA file bytes; 2 = raw FASTQ file bytes
+    uint32_t pad;
 };
 
 // One workgroup of the sketch kernel = one slice of one genome.

@@ -82,6 +82,7 @@ static_assert(sizeof(TileInfo) == 64, "TileInfo is one 64-byte line");
 struct PackV2Args {
     const TileInfo *tiles;           // n_tiles
     uint64_t       *desc;            // n_tiles look-back descriptors, zeroed before the launch
+    uint32_t       *desc2;           // n_tiles line-state descriptors (raw FASTA/FASTQ genomes), zeroed
     uint32_t       *ticket;          // PACK_TICKET_SHARDS counters at a 128-byte stride, zeroed before the launch
     uint32_t       *error_flag;      // zeroed; != 0 after the launch means a look-back spin hit its bound
     uint32_t        n_tiles;
@@ -97,7 +98,8 @@ struct PackMapArgs {
     uint32_t          n_tiles, n_genomes;
 };
 uint32_t   pack_v2_tile_bytes();
-hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, hipStream_t stream);
+hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, bool any_raw,
+                          hipStream_t stream);
 
 // ---- dist side (HyperMinHash pair statistics) ------------------------------------------------------------------
 hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t *d_c,

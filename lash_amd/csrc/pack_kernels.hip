@@ -75,7 +75,7 @@ constexpr int P2_THREADS = 256;
 constexpr int P2_CHUNKS = 4;
 constexpr int P2_TILE = P2_THREADS * P2_CHUNKS * 16;       // 16 KiB of one genome: 4 coalesced 16-byte chunks per lane
 constexpr uint32_t P2_SPIN_LIMIT = 1u << 24;
-constexpr uint32_t TF_FIRST = 1u, TF_LAST = 2u, TF_FULL = 4u;
+constexpr uint32_t TF_FIRST = 1u, TF_LAST = 2u, TF_FULL = 4u, TF_FASTA = 8u, TF_FASTQ = 16u;
 
 __device__ __forceinline__ uint64_t desc_make(uint32_t count, uint32_t tail30, uint32_t status)
 {
@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) pack_map_kernel(PackMapArgs m)
     const int64_t lead = (int64_t)((reinterpret_cast<uintptr_t>(m.seq) + gd.byte_off) & 15u);   // 16-B aligned loads
     const int64_t toff = g0 - lead + (int64_t)(t - tb) * P2_TILE;                                // relative to seq
     auto lower_bound = [&](int64_t x) {                      // first r in [rec_begin, rec_end] with rec_off[r] >= x
+        if (gd.format != 0u) return (uint64_t)0;
         uint64_t a = gd.rec_begin, b = gd.rec_end;
         while (a < b) {
             const uint64_t mid = (a + b) >> 1;
@@ -122,13 +123,15 @@ __global__ void __launch_bounds__(256) pack_map_kernel(PackMapArgs m)
     ti.r0 = lower_bound(toff);
     const uint64_t r1 = (t + 1 < te) ? lower_bound(toff + P2_TILE) : gd.rec_end;
     ti.nrec = (uint32_t)(r1 - ti.r0 > 0xFFFFFFFFull ? 0xFFFFFFFFull : r1 - ti.r0);
-    if (gd.rec_end - gd.rec_begin <= 1) ti.nrec = 0;         // a single record has no interior boundary to mark
+    if (gd.format != 0u) { ti.r0 = 0; ti.nrec = 0; }        // raw file bytes: records are found on the device
+    else if (gd.rec_end - gd.rec_begin <= 1) ti.nrec = 0;    // a single record has no interior boundary to mark
     ti.g = g;
     ti.tb = tb;
     ti.rel_lo = (int32_t)(g0 > toff ? g0 - toff : 0);
     ti.rel_hi = (int32_t)(g1 - toff < P2_TILE ? g1 - toff : P2_TILE);
     ti.flags = (t == tb ? TF_FIRST : 0u) | (t + 1 == te ? TF_LAST : 0u) |
-               ((toff >= g0 && toff + P2_TILE <= g1) ? TF_FULL : 0u);
+               ((toff >= g0 && toff + P2_TILE <= g1) ? TF_FULL : 0u) |
+               (gd.format == 1u ? TF_FASTA : gd.format == 2u ? TF_FASTQ : 0u);
     ti.pad = 0;
     ti.word_off = gd.word_off;
     ti.brk_off = gd.brk_off;
@@ -194,6 +197,61 @@ __device__ __forceinline__ uint4 load16_clipped(const uint8_t *seq, int64_t off,
 // aggregates, so every look-back below m terminates; m's holder therefore finishes what it does before reaching
 // m (only tiles < m), and if m is not drawn yet its shard's workgroups hold only smaller tiles.
 // ------------------------------------------------------------------------------------------------------------
+// ---- raw FASTA / FASTQ bytes (the parse moves onto the device) -------------------------------
+// needletail semantics: FASTA = '>' header line, then sequence lines up to the next '>';
+// FASTQ = 4-line records, line 2 is the sequence.  Newlines, '\r' and everything else that is not ACGT are dropped by
+// the same filter that implements filter_out_n; what is added here is (a) header / '+' / quality lines are dropped
+// even where they contain ACGT, (b) a record starts at every '>' (FASTA) or header-ending newline (FASTQ).
+// Line state is a prefix property of the file: "last of {'>' -> header, '\n' -> sequence}" for FASTA, "newlines so far
+// mod 4" for FASTQ.  Inside a tile it is resolved with ballots / shuffles, across tiles with a second, 4-byte
+// look-back descriptor (bits 1:0 status, FASTA: bit 2 = tile has a setter, bit 3 = state after it; FASTQ: bits 3:2 =
+// newline count mod 4 / phase at the tile's end).
+__device__ __forceinline__ uint32_t eqmask16(const uint4 q, uint32_t pat4)
+{
+    auto m4 = [&](uint32_t w) {
+        const uint32_t z = w ^ pat4;
+        const uint32_t nz = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;
+        const uint32_t v = (~nz & 0x80808080u) >> 7;
+        return ((v * 0x01020408u) >> 24) & 0xFu;
+    };
+    return m4(q.x) | (m4(q.y) << 4) | (m4(q.z) << 8) | (m4(q.w) << 12);
+}
+
+// one lane's 16 bytes of FASTA: which are inside a header line, which '>' start a record
+__device__ __forceinline__ void fasta_chunk(uint32_t gt, uint32_t nl, uint32_t in_hdr, uint32_t &hdrmask, uint32_t &recstart)
+{
+    uint32_t S = gt | nl, state = in_hdr, prev = 0;
+    hdrmask = 0;
+    recstart = 0;
+    while (S) {
+        const uint32_t p = (uint32_t)__builtin_ctz(S);
+        S &= S - 1;
+        if (state) hdrmask |= ((1u << p) - 1u) & ~((1u << prev) - 1u);
+        const uint32_t is_gt = (gt >> p) & 1u;
+        if (is_gt && !state) recstart |= 1u << p;
+        state = is_gt;
+        prev = p;
+    }
+    if (state) hdrmask |= 0xFFFFu & ~((1u << prev) - 1u);
+}
+
+// one lane's 16 bytes of FASTQ: which belong to a sequence line, which newlines end a header line
+__device__ __forceinline__ void fastq_chunk(uint32_t nl, uint32_t in_phase, uint32_t &seqmask, uint32_t &recstart)
+{
+    uint32_t S = nl, ph = in_phase, prev = 0;
+    seqmask = 0;
+    recstart = 0;
+    while (S) {
+        const uint32_t p = (uint32_t)__builtin_ctz(S);
+        S &= S - 1;
+        if (ph == 1u) seqmask |= ((1u << p) - 1u) & ~((1u << prev) - 1u);
+        if (ph == 0u) recstart |= 1u << p;
+        ph = (ph + 1u) & 3u;
+        prev = p + 1u;
+    }
+    if (ph == 1u) seqmask |= 0xFFFFu & ~((1u << prev) - 1u);
+}
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -206,6 +264,8 @@ struct CarriedTile {          // what iteration i+1 needs to finish tile T_i (al
     uint32_t t, tb, g, flags, tile_cnt, own_tail, has_rec, valid;
 };
 
+// RAW = false: every genome comes as record sequences + rec_off (lean kernel); RAW = true: some genomes are raw file bytes
+template <bool RAW>
 __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, PackV2Args v)
 {
     constexpr int STAGE_WORDS = P2_TILE / 16 + 8;
@@ -214,7 +274,8 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
     __shared__ uint32_t brkloc[2][P2_TILE / 32];            // the same in tile-local compacted positions
     __shared__ uint32_t row_tot[P2_CHUNKS][P2_THREADS / 64];
     __shared__ uint32_t wave_flag[P2_THREADS / 64];
-    __shared__ uint32_t s_next, s_prev_cnt, s_prev_tail, s_fail, s_own_tail;
+    __shared__ uint32_t grp[P2_CHUNKS * (P2_THREADS / 64)];  // raw mode: per (chunk row, wave) line-state summary
+    __shared__ uint32_t s_next, s_prev_cnt, s_prev_tail, s_fail, s_own_tail, s_line_in, s_rawfail;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t seq_bytes = a.seq_end - a.seq;
@@ -237,7 +298,7 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
     };
 
     // ---- prologue: first tile, its loads, and the ticket after it ----
-    if (tid == 0) s_next = shard + v.n_shards * atomicAdd(my_ticket, 1u);
+    if (tid == 0) { s_next = shard + v.n_shards * atomicAdd(my_ticket, 1u); s_rawfail = 0; }
     lds_barrier();
     uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
     if (t >= v.n_tiles) return;
@@ -253,13 +314,14 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
         const uint32_t buf = it & 1u;
         uint32_t excl[P2_CHUNKS], tile_cnt = 0;
         Lane16 l16[P2_CHUNKS];
-        const bool has_rec = have_cur && ti.nrec != 0;      // uniform
+        const bool raw = RAW && have_cur && (ti.flags & (TF_FASTA | TF_FASTQ)) != 0;          // uniform
+        const bool has_rec = have_cur && (ti.nrec != 0 || raw);                                // uniform
         bool have_next = false;
         uint32_t t_next = 0xFFFFFFFFu;
         TileInfo ti_next = ti;
 
         if (have_cur) {
-            // ---- 1. record starts inside this tile (sparse; most tiles have none) ----
+            // ---- 1. record starts inside this tile (records mode: from rec_off, sparse; raw mode: found below) ----
             if (has_rec) {
                 for (uint32_t i = tid; i < P2_TILE / 32; i += P2_THREADS) { recbits[i] = 0; brkloc[buf][i] = 0; }
                 lds_barrier();
@@ -268,19 +330,154 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
                     if (off >= 0 && off < P2_TILE) atomicOr(&recbits[off >> 5], 1u << (off & 31));
                 }
             }
-            // ---- 2. classify (waits for this tile's loads) ----
-            bool allv = true;
+            // ---- 2. which bytes belong to the genome; raw mode: which of those are sequence ----
+            uint32_t keep[P2_CHUNKS];
 #pragma unroll
             for (int c = 0; c < P2_CHUNKS; ++c) {
-                uint32_t keep = 0xFFFFu;
+                keep[c] = 0xFFFFu;
                 if (!(ti.flags & TF_FULL)) {
                     const int32_t cs = (c * P2_THREADS + (int)tid) * 16;
                     int32_t lo = ti.rel_lo - cs, hi = ti.rel_hi - cs;
                     lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
                     hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
-                    keep = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+                    keep[c] = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
                 }
-                l16[c] = keep ? classify16(q[c], keep) : Lane16{0, 0, 0};
+            }
+            if constexpr (RAW) if (raw) {
+                const bool fasta = (ti.flags & TF_FASTA) != 0;                                 // uniform
+                uint32_t nl[P2_CHUNKS], gt[P2_CHUNKS], lane_in[P2_CHUNKS];
+                uint32_t unresolved = 0;                       // bit c: lane_in[c] still needs the group / tile state
+#pragma unroll
+                for (int c = 0; c < P2_CHUNKS; ++c) {
+                    nl[c] = eqmask16(q[c], 0x0A0A0A0Au) & keep[c];
+                    gt[c] = fasta ? (eqmask16(q[c], 0x3E3E3E3Eu) & keep[c]) : 0u;
+                }
+                if (fasta) {
+#pragma unroll
+                    for (int c = 0; c < P2_CHUNKS; ++c) {
+                        const uint32_t S = gt[c] | nl[c];
+                        const bool has = S != 0u;
+                        const bool end_hdr = has && ((gt[c] >> (31 - __builtin_clz(S | 1u))) & 1u);
+                        const uint64_t m_has = __builtin_amdgcn_ballot_w64(has), m_hdr = __builtin_amdgcn_ballot_w64(end_hdr);
+                        const uint64_t prior = m_has & ((1ull << lane) - 1ull);
+                        if (prior) lane_in[c] = (uint32_t)(m_hdr >> (63 - __builtin_clzll(prior))) & 1u;
+                        else { lane_in[c] = 0; unresolved |= 1u << c; }
+                        if (lane == 0)
+                            grp[c * (P2_THREADS / 64) + wid] = m_has ? (1u | ((uint32_t)((m_hdr >> (63 - __builtin_clzll(m_has))) & 1u) << 1)) : 0u;
+                    }
+                } else {
+                    uint32_t inc[P2_CHUNKS];
+#pragma unroll
+                    for (int c = 0; c < P2_CHUNKS; ++c) inc[c] = (uint32_t)__builtin_popcount(nl[c]);
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                        for (int c = 0; c < P2_CHUNKS; ++c) {
+                            const uint32_t n = __shfl_up(inc[c], d, 64);
+                            if (lane >= (uint32_t)d) inc[c] += n;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < P2_CHUNKS; ++c) {
+                        lane_in[c] = inc[c] - (uint32_t)__builtin_popcount(nl[c]);            // newlines before, in this wave row
+                        if (lane == 63) grp[c * (P2_THREADS / 64) + wid] = inc[c];
+                    }
+                    unresolved = 0xFu;
+                }
+                lds_barrier();
+                // groups in tile order g = c * 4 + w; wave 0 also resolves the tile's incoming state by look-back
+                constexpr int NG = P2_CHUNKS * (P2_THREADS / 64);
+                if (wid == 0) {
+                    uint32_t agg, fail = 0, in_state = 0;
+                    if (fasta) {
+                        agg = 0;
+                        for (int g = NG - 1; g >= 0; --g) { const uint32_t x = grp[g]; if (x & 1u) { agg = 1u | (x & 2u); break; } }
+                    } else {
+                        uint32_t tot = 0;
+                        for (int g = 0; g < NG; ++g) tot += grp[g];
+                        agg = tot & 3u;
+                    }
+                    // desc2 word: status | payload << 2   (FASTA payload: has | state << 1; FASTQ: count / phase)
+                    if (!(ti.flags & TF_FIRST)) {
+                        if (lane == 0) __hip_atomic_store(v.desc2 + t, 1u | (agg << 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        int64_t j = (int64_t)t - 1;
+                        uint32_t spins = 0, acc = 0;
+                        for (;;) {
+                            const int64_t idx = j - (int64_t)lane;
+                            uint32_t d = 2u;                                   // before the file's first tile: state 0
+                            if (idx >= (int64_t)ti.tb) d = __hip_atomic_load(v.desc2 + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint32_t st = d & 3u, pay = d >> 2;
+                            const bool decisive = st == 2u || (fasta && st == 1u && (pay & 1u));
+                            const uint64_t m_dec = __builtin_amdgcn_ballot_w64(decisive);
+                            const uint64_t m_none = __builtin_amdgcn_ballot_w64(st == 0u);
+                            const int first = m_dec ? __builtin_ctzll(m_dec) : 64;
+                            const uint64_t need = first >= 63 ? ~0ull : ((2ull << first) - 1ull);
+                            if (m_none & need) {
+                                if (++spins > P2_SPIN_LIMIT) { fail = 1; break; }
+                                __builtin_amdgcn_s_sleep(2);
+                                continue;
+                            }
+                            if (fasta) {
+                                if (first < 64) { in_state = (uint32_t)__builtin_amdgcn_readlane((int)(pay >> 1), first) & 1u; break; }
+                            } else {
+                                // phase = inclusive phase of lane `first` + newline counts of the nearer aggregates
+                                const uint64_t below = first < 64 ? need : ~0ull;
+                                const uint64_t b0 = __builtin_amdgcn_ballot_w64((pay & 1u) != 0) & below;
+                                const uint64_t b1 = __builtin_amdgcn_ballot_w64((pay & 2u) != 0) & below;
+                                acc += (uint32_t)__builtin_popcountll(b0) + 2u * (uint32_t)__builtin_popcountll(b1);
+                                if (first < 64) { in_state = acc & 3u; break; }
+                            }
+                            j -= 64;
+                        }
+                    }
+                    const uint32_t end_state = fasta ? ((agg & 1u) ? (agg >> 1) & 1u : in_state) : (in_state + agg) & 3u;
+                    if (lane == 0) {
+                        if (!fail) __hip_atomic_store(v.desc2 + t, 2u | ((fasta ? (1u | (end_state << 1)) : end_state) << 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_line_in = in_state;
+                        if (fail) s_rawfail = 1;
+                    }
+                }
+                lds_barrier();
+                if (s_rawfail) { if (tid == 0) atomicOr(v.error_flag, 1u); return; }
+                const uint32_t tile_in = s_line_in;
+                bool rs_any = false;
+#pragma unroll
+                for (int c = 0; c < P2_CHUNKS; ++c) {
+                    const int g = c * (P2_THREADS / 64) + (int)wid;
+                    uint32_t in = lane_in[c];
+                    if (fasta) {
+                        if (unresolved & (1u << c)) {
+                            in = tile_in;
+                            for (int k = g - 1; k >= 0; --k) { const uint32_t x = grp[k]; if (x & 1u) { in = (x >> 1) & 1u; break; } }
+                        }
+                        uint32_t hdrmask, rs;
+                        fasta_chunk(gt[c], nl[c], in, hdrmask, rs);
+                        keep[c] &= ~hdrmask;
+                        lane_in[c] = rs;
+                    } else {
+                        uint32_t before = tile_in;
+                        for (int k = 0; k < g; ++k) before += grp[k];
+                        uint32_t seqmask, rs;
+                        fastq_chunk(nl[c], (in + before) & 3u, seqmask, rs);
+                        keep[c] &= seqmask;
+                        lane_in[c] = rs;
+                    }
+                    rs_any = rs_any || lane_in[c] != 0u;
+                }
+                // record-start marks into the tile bitmap (two lanes share a word)
+                if (rs_any) {
+#pragma unroll
+                    for (int c = 0; c < P2_CHUNKS; ++c) {
+                        const uint32_t ci = (uint32_t)(c * P2_THREADS) + tid;
+                        if (lane_in[c]) atomicOr(&recbits[ci >> 1], lane_in[c] << ((ci & 1u) * 16u));
+                    }
+                }
+            }
+            // ---- 2b. classify (records mode: waits for this tile's loads here) ----
+            bool allv = true;
+#pragma unroll
+            for (int c = 0; c < P2_CHUNKS; ++c) {
+                l16[c] = keep[c] ? classify16(q[c], keep[c]) : Lane16{0, 0, 0};
                 allv = allv && l16[c].vmask == 0xFFFFu;
             }
             const bool wave_all = __builtin_amdgcn_ballot_w64(!allv) == 0ull;
@@ -473,7 +670,8 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
 
 uint32_t pack_v2_tile_bytes() { return P2_TILE; }
 
-hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, hipStream_t stream)
+hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, bool any_raw,
+                          hipStream_t stream)
 {
     if (v.n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_map_kernel, dim3((v.n_tiles + 255) / 256), dim3(256), 0, stream, m);
@@ -483,7 +681,8 @@ hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackM
     if (grid > v.n_tiles) grid = v.n_tiles;
     PackV2Args vv = v;
     vv.n_shards = grid < PACK_TICKET_SHARDS ? grid : PACK_TICKET_SHARDS;
-    hipLaunchKernelGGL(pack_lookback_kernel, dim3(grid), dim3(P2_THREADS), 0, stream, args, vv);
+    if (any_raw) hipLaunchKernelGGL(pack_lookback_kernel<true>, dim3(grid), dim3(P2_THREADS), 0, stream, args, vv);
+    else hipLaunchKernelGGL(pack_lookback_kernel<false>, dim3(grid), dim3(P2_THREADS), 0, stream, args, vv);
     return hipGetLastError();
 }
 

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint32_t *__restrict__ w = a.words + gd.word_off;
     // A genome with a single record has no interior record boundary: its lanes read three always-zero words (one
     // L1-resident line) instead of streaming 1/8 B per base of break bitmap from HBM.  No branch, no second loop.
-    const bool multi_rec = gd.rec_end - gd.rec_begin > 1;
+    const bool multi_rec = gd.format != 0u || gd.rec_end - gd.rec_begin > 1;
     const uint32_t *__restrict__ bk = multi_rec ? a.brk + gd.brk_off : a.zero_words;
     KParams kp;
     kp.bitflip = a.bitflip;

@@ -157,6 +157,23 @@ class Context:
                                                 goff.ctypes.data, n_g, out.ctypes.data if out.size else None))
         return out
 
+    def sketch_files_raw(self, algo, k, p, seed, files_bytes, flags=0):
+        """files_bytes: list of uncompressed FASTA / FASTQ file contents (bytes).  The parse runs on the GPU.
+        Returns images[n_files, image_bytes]."""
+        prm = self._params(algo, k, p, seed, flags)
+        self._check(self._lib.lash_params_check(C.byref(prm)))
+        raw = np.frombuffer(b"".join(files_bytes), dtype=np.uint8) if files_bytes else np.zeros(0, np.uint8)
+        off = np.zeros(len(files_bytes) + 1, dtype=np.uint64)
+        if files_bytes:
+            off[1:] = np.cumsum([len(f) for f in files_bytes], dtype=np.uint64)
+        fmt = np.array([_lib.FMT_FASTQ if f.lstrip(b"\r\n")[:1] == b"@" else _lib.FMT_FASTA for f in files_bytes], dtype=np.uint8)
+        ib = image_bytes(prm.algo, prm.p)
+        out = np.zeros((len(files_bytes), ib), dtype=np.uint8)
+        self._check(self._lib.lash_sketch_files_raw(self._h, C.byref(prm), raw.ctypes.data if raw.size else None,
+                                                    off.ctypes.data, fmt.ctypes.data if fmt.size else None,
+                                                    len(files_bytes), out.ctypes.data if out.size else None))
+        return out
+
     def sketch_batch_device(self, algo, k, p, seed, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, d_out,
                             flags=0):
         """Device-resident records in, device images out; asynchronous on the context's stream."""

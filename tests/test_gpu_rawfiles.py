@@ -1,0 +1,88 @@
+"""GPU tests of the device-side FASTA/FASTQ scan: lash_sketch_files_raw takes uncompressed file
+bytes and must produce the same images as parsing the file on the host (needletail semantics, tests/fastx.py) and
+sketching the records with the oracle."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from fastx import read_fastx
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ALGO = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lash_amd
+    c = lash_amd.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_for_files(tmp_path, files_bytes, algo, k, p):
+    out = []
+    for i, fb in enumerate(files_bytes):
+        path = tmp_path / ("f%d" % i)
+        path.write_bytes(fb)
+        recs = read_fastx(str(path))
+        seq = np.frombuffer(b"".join(recs), np.uint8)
+        off = np.cumsum([0] + [len(r) for r in recs]).astype(np.uint64)
+        out.append(O.sketch_genomes(ALGO[algo], k, p, 42, seq, off, np.array([0, len(recs)], np.uint64))[0])
+    return np.stack(out)
+
+
+def wrap(s, w, eol=b"\n"):
+    return eol.join(s[i:i + w] for i in range(0, len(s), w)) + eol
+
+
+def make_files():
+    rng = random.Random(11)
+
+    def rseq(n, alphabet="ACGT"):
+        return "".join(rng.choice(alphabet) for _ in range(n)).encode()
+
+    files = []
+    for name in ("fixture_A.fasta", "fixture_B.fasta", "fixture_C.fasta", "fixture_B40.fastq"):
+        files.append(open(os.path.join(GOLD, name), "rb").read())
+    # multi-tile FASTA, 60-column lines, ACGT in the headers, N runs, lower case
+    body = bytearray(rseq(700_000, "ACGT" * 20 + "Nacgt"))
+    files.append(b">chr1 ACGTACGTACGT description with bases GATTACA\n" + wrap(bytes(body), 60) +
+                 b">chr2 TTTT\n" + wrap(rseq(123_457), 70) + b">empty\n>tiny ACGT\nACGTAC\n")
+    # single-line records: no newline inside 300 kb of sequence; a header longer than one 16 KiB tile
+    files.append(b">" + b"ACGT" * 6000 + b" long header\n" + rseq(300_000) + b"\n>second\n" + rseq(50_000))
+    # CRLF line ends, no trailing newline
+    files.append(b">crlf\r\n" + wrap(rseq(40_000), 80, b"\r\n") + b">last\r\n" + rseq(33))
+    # FASTQ: 150-bp reads with ACGT-looking quality strings and '@' / '>' inside qualities
+    reads = []
+    for i in range(3000):
+        r = rseq(rng.choice([150, 150, 150, 76, 12]), "ACGT" * 30 + "N")
+        qual = bytes(rng.choice(b"ACGT@>+IIIIFFFF#") for _ in range(len(r)))
+        reads.append(b"@read%d ACGT\n" % i + r + b"\n+\n" + qual + b"\n")
+    files.append(b"".join(reads))
+    files.append(b"@only\nACGTACGTACGTACGTACGTA\n+\nIIIIIIIIIIIIIIIIIIIII")        # no trailing newline
+    files.append(b">no sequence at all\n")
+    return files
+
+
+@pytest.mark.parametrize("algo,k,p", [("hmh", 16, 0), ("hll", 21, 12), ("ull", 16, 12), ("hmh", 7, 0)])
+def test_raw_files_match_host_parse_plus_oracle(ctx, tmp_path, algo, k, p):
+    files = make_files()
+    got = ctx.sketch_files_raw(algo, k, p, 42, files)
+    want = oracle_for_files(tmp_path, files, algo, k, p)
+    for i in range(len(files)):
+        assert np.array_equal(got[i], want[i]), "file %d (%d bytes) differs for %s" % (i, len(files[i]), algo)
+
+
+def test_raw_large_wrapped_fasta(ctx, tmp_path):
+    """A 20 Mbp genome as 80-column FASTA: ~1 250 tiles, every tile starts mid-line; plus many files in one call."""
+    g = O.synth_genome(4242, 20_000_000).tobytes()
+    files = [b">big\n" + wrap(g, 80)] + [b">g%d\n" % i + wrap(O.synth_genome(5000 + i, 300_000 + 17 * i).tobytes(), 61) for i in range(40)]
+    got = ctx.sketch_files_raw("hmh", 16, 0, 42, files)
+    want0 = O.sketch_genomes(O.HMH, 16, 0, 42, np.frombuffer(g, np.uint8), np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0]
+    assert np.array_equal(got[0], want0)
+    want = oracle_for_files(tmp_path, files[1:], "hmh", 16, 0)
+    assert np.array_equal(got[1:], want)
