@@ -125,9 +125,8 @@ int cmd_sketch(int argc, char **argv)
     if (!err.empty()) { fprintf(stderr, "Error: %s\n", err.c_str()); return 1; }
     err = write_parameters_json(output, alg, opt.k, opt.precision, opt.seed);
     if (!err.empty()) { fprintf(stderr, "Error: %s\n", err.c_str()); return 1; }
-    fprintf(stderr, "sketched %llu files (%llu records, %.3f Gbases) in %.2f s on %zu GPU(s), %llu batches\n",
-            (unsigned long long)st.files, (unsigned long long)st.records, st.bytes / 1e9, st.seconds, opt.devices.size(),
-            (unsigned long long)st.batches);
+    fprintf(stderr, "sketched %llu files (%.3f GB of FASTA/FASTQ text) in %.2f s on %zu GPU(s), %llu batches\n",
+            (unsigned long long)st.files, st.bytes / 1e9, st.seconds, opt.devices.size(), (unsigned long long)st.batches);
     return 0;
 }
 

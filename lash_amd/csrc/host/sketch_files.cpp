@@ -1,5 +1,9 @@
 #include "sketch_files.hpp"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -8,6 +12,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -53,42 +58,121 @@ std::string write_parameters_json(const std::string &output_name, const std::str
 
 namespace {
 
-struct ParsedFile {
-    RecordBatch rb;
-    std::string err;
-    bool done = false;
-};
-
-// sequence bytes of one batch in page-locked memory (H2D at PCIe speed); buffers are recycled between batches
+// page-locked host memory (H2D at PCIe speed); recycled between batches
 struct PinnedBuf {
     uint8_t *p = nullptr;
-    size_t cap = 0, size = 0;
-    bool append(const uint8_t *src, size_t n)
+    size_t cap = 0;
+    bool reserve(size_t n)
     {
-        if (size + n > cap) {
-            size_t want = std::max(size + n, cap + cap / 2 + (64u << 20));
-            uint8_t *q = static_cast<uint8_t *>(lash_host_alloc_pinned(want));
-            if (!q) return false;
-            if (size) memcpy(q, p, size);
-            lash_host_free_pinned(p);
-            p = q;
-            cap = want;
-        }
-        if (n) memcpy(p + size, src, n);
-        size += n;
-        return true;
+        if (n <= cap) return true;
+        lash_host_free_pinned(p);
+        cap = n + n / 8 + (1u << 20);
+        p = static_cast<uint8_t *>(lash_host_alloc_pinned(cap));
+        if (!p) cap = 0;
+        return p != nullptr;
     }
     ~PinnedBuf() { lash_host_free_pinned(p); }
 };
 
-struct Batch {
-    uint64_t index = 0;
-    std::unique_ptr<PinnedBuf> seq;
-    std::vector<uint64_t> rec_off{0};
-    std::vector<uint64_t> genome_rec_off{0};
-    std::vector<uint8_t> images;
+struct FileSlot {
+    bool compressed = false, sized = false;
+    uint64_t size = 0;
+    std::vector<uint8_t> inflated;        // compressed inputs only, until placed
     std::string err;
 };
+
+struct Batch {
+    uint64_t index = 0;
+    size_t f0 = 0, f1 = 0;                // files [f0, f1)
+    std::unique_ptr<PinnedBuf> buf;
+    std::vector<uint64_t> file_off{0};
+    std::vector<uint8_t> fmt;
+    std::atomic<size_t> remaining{0};
+    std::vector<uint8_t> images;
+    std::string err;
+    std::mutex emu;
+};
+
+// simple worker pool
+class Pool {
+public:
+    explicit Pool(int n)
+    {
+        for (int i = 0; i < n; ++i)
+            th_.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu_);
+                        cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                        if (q_.empty()) return;
+                        f = std::move(q_.front());
+                        q_.pop_front();
+                    }
+                    f();
+                }
+            });
+    }
+    void submit(std::function<void()> f)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        q_.push_back(std::move(f));
+        cv_.notify_one();
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+private:
+    std::vector<std::thread> th_;
+    std::deque<std::function<void()>> q_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+bool peek_compressed(const std::string &path, uint64_t &size, std::string &err)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) { err = "Invalid input file: cannot open " + path; return false; }
+    size = (uint64_t)st.st_size;
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "Invalid input file: cannot open " + path; return false; }
+    unsigned char m[6] = {0, 0, 0, 0, 0, 0};
+    size_t got = fread(m, 1, 6, f);
+    fclose(f);
+    if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) return true;
+    if (got >= 4 && m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) return true;
+    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') return true;               // reported as unsupported by slurp
+    if (got >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) return true;
+    return false;
+}
+
+std::string read_exact(const std::string &path, uint8_t *dst, uint64_t size)
+{
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return "Invalid input file: cannot open " + path;
+    uint64_t done = 0;
+    while (done < size) {
+        ssize_t n = pread(fd, dst + done, (size_t)std::min<uint64_t>(size - done, 1u << 30), (off_t)done);
+        if (n <= 0) { close(fd); return "Invalid input file: short read on " + path; }
+        done += (uint64_t)n;
+    }
+    close(fd);
+    return "";
+}
+
+// needletail sniffs '>' / '@' (SURVEY App. A.5); anything else is "Invalid input file" (utils.rs:453)
+int sniff_format(const uint8_t *p, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        if (p[i] == '\n' || p[i] == '\r' || p[i] == ' ' || p[i] == '\t') continue;
+        return p[i] == '>' ? LASH_FMT_FASTA : p[i] == '@' ? LASH_FMT_FASTQ : 0;
+    }
+    return 0;
+}
 
 }  // namespace
 
@@ -104,46 +188,16 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     if (n_dev_avail <= 0) return lash_strerror(LASH_ENODEV);
     for (int d : devices)
         if (d < 0 || d >= n_dev_avail) return "device index out of range";
-    const int n_readers = std::max(1, opt.threads);
     const size_t n_files = files.size();
 
-    // ---- stage 1: reader pool, files claimed in order, results delivered in order ----
-    std::vector<std::unique_ptr<ParsedFile>> parsed(n_files);
-    for (auto &p : parsed) p.reset(new ParsedFile());
-    std::mutex mu;
-    std::condition_variable cv_parsed, cv_window;
-    std::atomic<size_t> next_file{0};
-    size_t consumed = 0;                                   // files already merged into batches (guarded by mu)
-    uint64_t inflight_bytes = 0;                           // parsed but not yet consumed
-    const uint64_t window_bytes = std::max<uint64_t>(opt.batch_bytes * 2, 1ull << 28);
-    bool abort_all = false;
-    auto reader = [&]() {
-        for (;;) {
-            size_t i = next_file.fetch_add(1);
-            if (i >= n_files) return;
-            {   // bounded look-ahead so that host memory stays ~2 batches
-                std::unique_lock<std::mutex> lk(mu);
-                cv_window.wait(lk, [&] { return abort_all || inflight_bytes < window_bytes || i == consumed; });
-                if (abort_all) return;
-            }
-            ParsedFile *pf = parsed[i].get();
-            pf->err = read_fastx_file(files[i], pf->rb);
-            std::lock_guard<std::mutex> lk(mu);
-            inflight_bytes += pf->rb.seq.size();
-            pf->done = true;
-            cv_parsed.notify_all();
-        }
-    };
-    std::vector<std::thread> readers;
-    for (int r = 0; r < n_readers; ++r) readers.emplace_back(reader);
-
-    // ---- stage 3: GPU workers ----
-    std::vector<std::unique_ptr<PinnedBuf>> pool;            // recycled pinned buffers (guarded by qmu)
+    // ---- GPU workers: one context per device; the FASTA/FASTQ parse runs on the GPU (lash_sketch_files_raw) ----
     std::deque<std::shared_ptr<Batch>> todo;
     std::map<uint64_t, std::shared_ptr<Batch>> finished;
+    std::vector<std::unique_ptr<PinnedBuf>> pool_bufs;      // recycled pinned buffers (guarded by qmu)
     std::mutex qmu;
     std::condition_variable cv_todo, cv_done;
     bool no_more = false;
+    size_t in_flight = 0;                                  // batches planned but not yet written (guarded by qmu)
     auto gpu_worker = [&](int device) {
         lash_ctx *ctx = nullptr;
         int rc = lash_ctx_create(&ctx, device);
@@ -156,17 +210,17 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                 b = todo.front();
                 todo.pop_front();
             }
-            if (rc != LASH_OK) b->err = lash_strerror(rc);
-            else {
-                const uint32_t ng = (uint32_t)(b->genome_rec_off.size() - 1);
-                b->images.assign((size_t)ng * ib, 0);
-                int r2 = lash_sketch_batch(ctx, &prm, b->seq->p, b->rec_off.data(), b->rec_off.size() - 1,
-                                           b->genome_rec_off.data(), ng, b->images.data());
-                if (r2 != LASH_OK) b->err = std::string(lash_strerror(r2)) + " " + lash_ctx_last_error(ctx);
+            if (b->err.empty()) {
+                if (rc != LASH_OK) b->err = lash_strerror(rc);
+                else {
+                    const uint32_t ng = (uint32_t)(b->f1 - b->f0);
+                    b->images.assign((size_t)ng * ib, 0);
+                    int r2 = lash_sketch_files_raw(ctx, &prm, b->buf->p, b->file_off.data(), b->fmt.data(), ng, b->images.data());
+                    if (r2 != LASH_OK) b->err = std::string(lash_strerror(r2)) + " " + lash_ctx_last_error(ctx);
+                }
             }
             std::lock_guard<std::mutex> lk(qmu);
-            b->seq->size = 0;
-            pool.push_back(std::move(b->seq));
+            pool_bufs.push_back(std::move(b->buf));
             finished[b->index] = b;
             cv_done.notify_all();
         }
@@ -175,9 +229,9 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     std::vector<std::thread> workers;
     for (int d : devices) workers.emplace_back(gpu_worker, d);
 
-    // ---- stage 4: writer (in order) ----
+    // ---- writer: images in batch (== file) order into one zstd frame (utils.rs:567-574) ----
     std::string werr;
-    uint64_t n_batches_total = 0;                          // set when known (guarded by qmu)
+    uint64_t n_batches_total = 0;
     bool batches_known = false;
     std::thread writer([&]() {
         ZstdWriter zw;
@@ -188,9 +242,11 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             {
                 std::unique_lock<std::mutex> lk(qmu);
                 cv_done.wait(lk, [&] { return finished.count(want) || (batches_known && want >= n_batches_total); });
-                if (batches_known && want >= n_batches_total && !finished.count(want)) break;
+                if (!finished.count(want)) break;
                 b = finished[want];
                 finished.erase(want);
+                --in_flight;
+                cv_done.notify_all();
             }
             if (werr.empty() && !b->err.empty()) werr = b->err;
             if (werr.empty()) werr = zw.write(b->images.data(), b->images.size());
@@ -199,58 +255,108 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
         if (werr.empty()) werr = zw.finish();
     });
 
-    // ---- stage 2 (this thread): merge parsed files into batches in file order ----
+    // ---- readers: inflate compressed inputs ahead of the planner; place every file's bytes into its batch ----
+    std::vector<FileSlot> slots(n_files);
+    std::mutex smu;
+    std::condition_variable cv_sized, cv_window;
+    uint64_t inflated_held = 0;                            // bytes of inflated-but-unplaced data (guarded by smu)
+    const uint64_t inflate_window = std::max<uint64_t>(2 * opt.batch_bytes, 1ull << 28);
     std::string err;
-    uint64_t n_records = 0, n_bytes = 0, batch_index = 0;
-    auto new_batch = [&]() {
-        auto b = std::make_shared<Batch>();
-        std::lock_guard<std::mutex> lk(qmu);
-        if (!pool.empty()) { b->seq = std::move(pool.back()); pool.pop_back(); }
-        else b->seq.reset(new PinnedBuf());
-        return b;
-    };
-    auto cur = new_batch();
-    auto submit = [&]() {
-        cur->index = batch_index++;
-        {
-            std::lock_guard<std::mutex> lk(qmu);
-            todo.push_back(cur);
-            cv_todo.notify_one();
-        }
-        {   // keep at most 2 batches per device queued or running
-            std::unique_lock<std::mutex> lk(qmu);
-            cv_done.wait(lk, [&] { return todo.size() < 2 * devices.size(); });
-        }
-        cur = new_batch();
-    };
-    for (size_t i = 0; i < n_files && err.empty(); ++i) {
-        ParsedFile *pf = parsed[i].get();
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_parsed.wait(lk, [&] { return pf->done; });
-        }
-        if (!pf->err.empty()) { err = pf->err; break; }
-        const uint64_t base = cur->seq->size;
-        if (!cur->seq->append(pf->rb.seq.data(), pf->rb.seq.size())) { err = "out of pinned host memory"; break; }
-        for (size_t r = 1; r < pf->rb.rec_off.size(); ++r) cur->rec_off.push_back(base + pf->rb.rec_off[r]);
-        cur->genome_rec_off.push_back(cur->rec_off.size() - 1);
-        n_records += pf->rb.n_rec();
-        n_bytes += pf->rb.seq.size();
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            inflight_bytes -= pf->rb.seq.size();
-            consumed = i + 1;
-            cv_window.notify_all();
-        }
-        parsed[i].reset();
-        if (cur->seq->size >= opt.batch_bytes) submit();
-    }
-    if (err.empty() && cur->genome_rec_off.size() > 1) submit();
+    uint64_t n_bytes = 0, batch_index = 0;
     {
-        std::lock_guard<std::mutex> lk(mu);
-        abort_all = !err.empty();
-        cv_window.notify_all();
-    }
+        Pool pool(std::max(1, opt.threads));
+        size_t next_inflate = 0;
+        auto pump_inflates = [&]() {                       // called with smu held
+            while (next_inflate < n_files) {
+                FileSlot &s = slots[next_inflate];
+                if (!s.compressed) { ++next_inflate; continue; }
+                if (inflated_held >= inflate_window) break;
+                const size_t i = next_inflate++;
+                inflated_held += 1;                        // placeholder so that at least progress is bounded per file
+                pool.submit([&, i]() {
+                    std::vector<uint8_t> data;
+                    std::string e = slurp_maybe_compressed(files[i], data);
+                    std::lock_guard<std::mutex> lk(smu);
+                    slots[i].err = e;
+                    slots[i].size = data.size();
+                    inflated_held += data.size();
+                    slots[i].inflated.swap(data);
+                    slots[i].sized = true;
+                    cv_sized.notify_all();
+                });
+            }
+        };
+        for (size_t i = 0; i < n_files && err.empty(); ++i) {
+            std::string e;
+            uint64_t sz = 0;
+            const bool comp = peek_compressed(files[i], sz, e);
+            if (!e.empty()) { err = e; break; }
+            slots[i].compressed = comp;
+            if (!comp) { slots[i].size = sz; slots[i].sized = true; }
+        }
+        std::shared_ptr<Batch> cur;
+        auto finalize = [&]() {
+            if (!cur || cur->f1 == cur->f0) return;
+            {   // at most 2 batches per device planned / queued / running / unwritten
+                std::unique_lock<std::mutex> lk(qmu);
+                cv_done.wait(lk, [&] { return in_flight < 2 * devices.size() + 1; });
+                ++in_flight;
+                if (!pool_bufs.empty()) { cur->buf = std::move(pool_bufs.back()); pool_bufs.pop_back(); }
+            }
+            if (!cur->buf) cur->buf.reset(new PinnedBuf());
+            if (!cur->buf->reserve(cur->file_off.back() + 64)) { cur->err = "out of pinned host memory"; }
+            cur->index = batch_index++;
+            cur->fmt.assign(cur->f1 - cur->f0, 0);
+            cur->remaining = cur->f1 - cur->f0;
+            std::shared_ptr<Batch> b = cur;
+            for (size_t i = b->f0; i < b->f1; ++i) {
+                pool.submit([&, b, i]() {
+                    FileSlot &s = slots[i];
+                    uint8_t *dst = b->buf->p ? b->buf->p + b->file_off[i - b->f0] : nullptr;
+                    std::string e = s.err;
+                    if (e.empty() && dst) {
+                        if (s.compressed) {
+                            if (s.size) memcpy(dst, s.inflated.data(), s.size);
+                            std::vector<uint8_t>().swap(s.inflated);
+                            std::lock_guard<std::mutex> lk(smu);
+                            inflated_held -= std::min<uint64_t>(inflated_held, s.size + 1);
+                            cv_window.notify_all();
+                        } else {
+                            e = read_exact(files[i], dst, s.size);
+                        }
+                        if (e.empty()) {
+                            const int f = sniff_format(dst, s.size);
+                            if (!f) e = "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + files[i];
+                            b->fmt[i - b->f0] = (uint8_t)(f ? f : LASH_FMT_FASTA);
+                        }
+                    }
+                    if (!e.empty()) { std::lock_guard<std::mutex> lk(b->emu); if (b->err.empty()) b->err = e; }
+                    if (b->remaining.fetch_sub(1) == 1) {
+                        std::lock_guard<std::mutex> lk(qmu);
+                        todo.push_back(b);
+                        cv_todo.notify_one();
+                    }
+                });
+            }
+            cur.reset();
+        };
+        for (size_t i = 0; i < n_files && err.empty(); ++i) {
+            {
+                std::unique_lock<std::mutex> lk(smu);
+                pump_inflates();
+                while (!slots[i].sized) {
+                    cv_sized.wait_for(lk, std::chrono::milliseconds(50));
+                    pump_inflates();
+                }
+            }
+            if (!cur) { cur = std::make_shared<Batch>(); cur->f0 = cur->f1 = i; }
+            cur->file_off.push_back(cur->file_off.back() + slots[i].size);
+            cur->f1 = i + 1;
+            n_bytes += slots[i].size;
+            if (cur->file_off.back() >= opt.batch_bytes) finalize();
+        }
+        if (err.empty()) finalize();
+    }   // Pool joins here: every placement task has run
     {
         std::lock_guard<std::mutex> lk(qmu);
         no_more = true;
@@ -259,7 +365,6 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
         cv_todo.notify_all();
         cv_done.notify_all();
     }
-    for (auto &t : readers) t.join();
     for (auto &t : workers) t.join();
     {
         std::lock_guard<std::mutex> lk(qmu);
@@ -278,7 +383,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     }
     if (stats) {
         stats->files = n_files;
-        stats->records = n_records;
+        stats->records = 0;
         stats->bytes = n_bytes;
         stats->batches = batch_index;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
