@@ -2,12 +2,67 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
 #include "zstd_dl.hpp"
 
 namespace lashhost {
+
+struct ByteStream::Impl {
+    int kind = 0;               // 0 plain, 1 gzip, 2 zstd
+    FILE *f = nullptr;
+    gzFile g = nullptr;
+    ZstdReader z;
+};
+
+ByteStream::ByteStream() : impl_(new Impl()) {}
+ByteStream::~ByteStream()
+{
+    if (impl_->f) fclose(impl_->f);
+    if (impl_->g) gzclose(impl_->g);
+    delete impl_;
+}
+
+std::string ByteStream::open(const std::string &path)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return "Invalid input file: cannot open " + path;
+    unsigned char m[6] = {0, 0, 0, 0, 0, 0};
+    const size_t got = fread(m, 1, 6, f);
+    if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) {
+        fclose(f);
+        impl_->g = gzopen(path.c_str(), "rb");
+        if (!impl_->g) return "Invalid input file: gzopen failed for " + path;
+        gzbuffer(impl_->g, 1 << 20);
+        impl_->kind = 1;
+        return "";
+    }
+    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') { fclose(f); return "Invalid input file: bzip2 input is not supported by this build (" + path + ")"; }
+    if (got >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) { fclose(f); return "Invalid input file: xz input is not supported by this build (" + path + ")"; }
+    rewind(f);
+    if (got >= 4 && m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) {
+        impl_->kind = 2;
+        return impl_->z.open(f);
+    }
+    impl_->f = f;
+    return "";
+}
+
+long ByteStream::read(uint8_t *dst, size_t n, std::string &err)
+{
+    if (impl_->kind == 0) return (long)fread(dst, 1, n, impl_->f);
+    if (impl_->kind == 2) return impl_->z.read(dst, n, err);
+    size_t done = 0;
+    while (done < n) {
+        const int r = gzread(impl_->g, dst + done, (unsigned)std::min<size_t>(n - done, 1u << 30));
+        if (r < 0) { err = "Invalid input file: corrupt gzip stream"; return -1; }
+        if (r == 0) break;
+        done += (size_t)r;
+    }
+    return (long)done;
+}
 
 std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t> &out)
 {

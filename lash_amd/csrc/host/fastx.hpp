@@ -26,6 +26,20 @@ std::string read_fastx_file(const std::string &path, RecordBatch &out);
 // Parses an in-memory (already decompressed) FASTA/FASTQ buffer.
 std::string parse_fastx_buffer(const uint8_t *data, size_t n, RecordBatch &out);
 
+// Sequential reader of a file's uncompressed bytes (plain, gzip via zlib, zstd via the dlopen'd streaming API): the
+// large-file path streams chunks through it instead of holding a whole metagenome in memory.
+class ByteStream {
+public:
+    ByteStream();
+    ~ByteStream();
+    std::string open(const std::string &path);
+    // reads up to n bytes; returns the count (0 = end of data) or -1 with err set
+    long read(uint8_t *dst, size_t n, std::string &err);
+private:
+    struct Impl;
+    Impl *impl_;
+};
+
 // Whole file into memory, transparently inflating gzip / zstd.
 std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t> &out);
 

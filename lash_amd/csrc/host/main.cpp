@@ -2,7 +2,8 @@
 // (/root/reference/src/main.rs:26-177) on top of liblash_gfx950.so.
 //   lash sketch -f LIST [-o sketch] [-k 16] [-t N] [-a hmh|hll|ull] [-p 10] [-s 42]        (main.rs:30-96, 180-279)
 //   lash dist   -q PREFIX -r PREFIX [-o dist] [-t N] [-e fgra|ml] [-m 1|0] [--fp32] [--dm]   (main.rs:107-176, 280-617)
-// Extras that do not exist upstream: --gpus N / --device D (which GPUs to use), --batch-mb M, --hmh-x-low.
+// Extras that do not exist upstream: --gpus N / --device D (which GPUs to use), --batch-mb M, --stream-mb M (files
+// larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,7 +96,8 @@ int cmd_sketch(int argc, char **argv)
     SketchOptions opt;
     const std::string output = a.kv.count("output") ? a.kv["output"] : "sketch";
     const std::string alg = a.kv.count("algorithm") ? a.kv["algorithm"] : "hmh";
-    uint64_t k = 16, p = 10, seed = 42, threads = std::thread::hardware_concurrency(), gpus = 0, dev = 0, batch_mb = 1024;
+    uint64_t k = 16, p = 10, seed = 42, threads = std::thread::hardware_concurrency(), gpus = 0, dev = 0, batch_mb = 1024,
+             stream_mb = 1024;
     if (a.kv.count("kmer") && !to_u64(a.kv["kmer"], k)) { fprintf(stderr, "error: invalid value for --kmer\n"); return 2; }
     if (a.kv.count("precision") && !to_u64(a.kv["precision"], p)) { fprintf(stderr, "error: invalid value for --precision\n"); return 2; }
     if (a.kv.count("seed") && !to_u64(a.kv["seed"], seed)) { fprintf(stderr, "error: invalid value for --seed\n"); return 2; }
@@ -103,6 +105,7 @@ int cmd_sketch(int argc, char **argv)
     if (a.kv.count("gpus") && !to_u64(a.kv["gpus"], gpus)) { fprintf(stderr, "error: invalid value for --gpus\n"); return 2; }
     if (a.kv.count("device") && !to_u64(a.kv["device"], dev)) { fprintf(stderr, "error: invalid value for --device\n"); return 2; }
     if (a.kv.count("batch-mb") && !to_u64(a.kv["batch-mb"], batch_mb)) { fprintf(stderr, "error: invalid value for --batch-mb\n"); return 2; }
+    if (a.kv.count("stream-mb") && !to_u64(a.kv["stream-mb"], stream_mb)) { fprintf(stderr, "error: invalid value for --stream-mb\n"); return 2; }
     if (alg == "hmh") opt.algo = LASH_HMH;
     else if (alg == "hll") opt.algo = LASH_HLL;
     else if (alg == "ull") opt.algo = LASH_ULL;
@@ -113,6 +116,7 @@ int cmd_sketch(int argc, char **argv)
     opt.seed = seed;
     opt.threads = (int)std::max<uint64_t>(1, threads);
     opt.batch_bytes = std::max<uint64_t>(1, batch_mb) << 20;
+    opt.stream_bytes = std::max<uint64_t>(1, stream_mb) << 20;
     opt.flags = a.flags.count("hmh-x-low") ? LASH_F_HMH_X_LOW : 0;
     if (gpus > 0) for (uint64_t d = 0; d < gpus; ++d) opt.devices.push_back((int)d);
     else opt.devices.push_back((int)dev);

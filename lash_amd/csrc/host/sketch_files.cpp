@@ -75,7 +75,7 @@ struct PinnedBuf {
 };
 
 struct FileSlot {
-    bool compressed = false, sized = false;
+    bool compressed = false, sized = false, big = false;
     uint64_t size = 0;
     std::vector<uint8_t> inflated;        // compressed inputs only, until placed
     std::string err;
@@ -174,6 +174,84 @@ int sniff_format(const uint8_t *p, uint64_t n)
     return 0;
 }
 
+// Where to cut a chunk of a large file so that the next chunk starts at a record boundary.
+//   FASTA: before the last "\n>" in the second half; a record longer than the chunk is cut at a line boundary and
+//          `overlap` bytes (whole lines, >= 4 KiB, header-free by construction) are repeated at the start of the next
+//          chunk so that no k-mer across the cut is lost (repeated k-mers are harmless: max / OR are idempotent).
+//   FASTQ: before the last line that starts with '@' and whose line-after-next starts with '+' (a quality line that
+//          happens to start with '@' fails that test).
+size_t find_cut(const uint8_t *b, size_t n, int fmt, size_t &overlap)
+{
+    overlap = 0;
+    if (fmt == LASH_FMT_FASTA) {
+        for (size_t q = n - 1; q > n / 2; --q)
+            if (b[q] == '>' && b[q - 1] == '\n') return q;
+        size_t cut = n;
+        while (cut > n / 2 && b[cut - 1] != '\n') --cut;
+        if (cut <= n / 2) {                               // one enormous line: cut anywhere inside it
+            overlap = n > 8192 ? 4096 : 0;
+            return n;
+        }
+        size_t o = cut > 4096 ? cut - 4096 : 0;
+        while (o > 0 && b[o - 1] != '\n') --o;
+        overlap = cut - o;
+        return cut;
+    }
+    auto line_end = [&](size_t p) { const void *e = memchr(b + p, '\n', n - p); return e ? (size_t)((const uint8_t *)e - b) : n; };
+    for (size_t q = n - 1; q > n / 2; --q) {
+        if (b[q] != '@' || b[q - 1] != '\n') continue;
+        const size_t e1 = line_end(q);
+        if (e1 >= n) continue;
+        const size_t e2 = line_end(e1 + 1);
+        if (e2 >= n || e2 + 1 >= n) continue;
+        if (b[e2 + 1] == '+') return q;
+    }
+    return 0;                                             // no FASTQ record boundary in the second half
+}
+
+// One file too large for a batch: chunks of it are sketched into the same image with LASH_F_ACCUMULATE.
+std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::string &path, uint64_t chunk_bytes,
+                            PinnedBuf &buf, uint8_t *image, uint64_t &bytes_seen)
+{
+    ByteStream bs;
+    std::string err = bs.open(path);
+    if (!err.empty()) return err;
+    if (!buf.reserve(chunk_bytes + 64)) return "out of pinned host memory";
+    size_t have = 0;                                      // bytes at the front of buf carried from the previous chunk
+    bool first = true, eof = false;
+    int fmt = 0;
+    while (!eof) {
+        while (have < chunk_bytes) {
+            const long r = bs.read(buf.p + have, chunk_bytes - have, err);
+            if (r < 0) return err + " (" + path + ")";
+            if (r == 0) { eof = true; break; }
+            have += (size_t)r;
+            bytes_seen += (uint64_t)r;
+        }
+        if (first) {
+            fmt = sniff_format(buf.p, have);
+            if (!fmt) return "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + path;
+        }
+        size_t overlap = 0;
+        const size_t cut = eof ? have : find_cut(buf.p, have, fmt, overlap);
+        if (!eof && cut == 0) return "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path;
+        lash_params prm = prm0;
+        if (!first) prm.flags |= LASH_F_ACCUMULATE;
+        const uint64_t off[2] = {0, (uint64_t)cut};
+        const uint8_t f = (uint8_t)fmt;
+        if (cut) {
+            const int rc = lash_sketch_files_raw(ctx, &prm, buf.p, off, &f, 1, image);
+            if (rc != LASH_OK) return std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
+            first = false;
+        }
+        const size_t keep_from = cut - overlap;
+        have -= keep_from;
+        if (have) memmove(buf.p, buf.p + keep_from, have);
+    }
+    if (first) return "Invalid input file: empty (" + path + ")";
+    return "";
+}
+
 }  // namespace
 
 std::string sketch_files(const SketchOptions &opt, const std::vector<std::string> &files, const std::string &output_name,
@@ -220,7 +298,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                 }
             }
             std::lock_guard<std::mutex> lk(qmu);
-            pool_bufs.push_back(std::move(b->buf));
+            if (b->buf) pool_bufs.push_back(std::move(b->buf));
             finished[b->index] = b;
             cv_done.notify_all();
         }
@@ -286,14 +364,19 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                 });
             }
         };
+        const uint64_t stream_bytes = std::min<uint64_t>(std::max<uint64_t>(opt.stream_bytes, 1u << 16), 0xF0000000ull);
         for (size_t i = 0; i < n_files && err.empty(); ++i) {
             std::string e;
             uint64_t sz = 0;
             const bool comp = peek_compressed(files[i], sz, e);
             if (!e.empty()) { err = e; break; }
             slots[i].compressed = comp;
-            if (!comp) { slots[i].size = sz; slots[i].sized = true; }
+            slots[i].big = comp ? sz > stream_bytes / 3 : sz > stream_bytes;
+            if (slots[i].big) { slots[i].compressed = false; slots[i].size = 0; slots[i].sized = true; }   // handled by the planner itself
+            else if (!comp) { slots[i].size = sz; slots[i].sized = true; }
         }
+        lash_ctx *stream_ctx = nullptr;
+        PinnedBuf stream_buf;
         std::shared_ptr<Batch> cur;
         auto finalize = [&]() {
             if (!cur || cur->f1 == cur->f0) return;
@@ -349,6 +432,27 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                     pump_inflates();
                 }
             }
+            if (slots[i].big) {
+                // a large file is its own "batch": streamed here, in file order, into one accumulated image
+                finalize();
+                auto b = std::make_shared<Batch>();
+                b->f0 = i;
+                b->f1 = i + 1;
+                b->images.assign(ib, 0);
+                if (!stream_ctx) {
+                    const int rc = lash_ctx_create(&stream_ctx, devices[0]);
+                    if (rc != LASH_OK) { err = lash_strerror(rc); break; }
+                }
+                uint64_t seen = 0;
+                b->err = stream_big_file(stream_ctx, prm, files[i], stream_bytes, stream_buf, b->images.data(), seen);
+                n_bytes += seen;
+                std::lock_guard<std::mutex> lk(qmu);
+                b->index = batch_index++;
+                ++in_flight;
+                finished[b->index] = b;
+                cv_done.notify_all();
+                continue;
+            }
             if (!cur) { cur = std::make_shared<Batch>(); cur->f0 = cur->f1 = i; }
             cur->file_off.push_back(cur->file_off.back() + slots[i].size);
             cur->f1 = i + 1;
@@ -356,6 +460,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             if (cur->file_off.back() >= opt.batch_bytes) finalize();
         }
         if (err.empty()) finalize();
+        if (stream_ctx) lash_ctx_destroy(stream_ctx);
     }   // Pool joins here: every placement task has run
     {
         std::lock_guard<std::mutex> lk(qmu);

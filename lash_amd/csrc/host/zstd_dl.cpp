@@ -129,6 +129,45 @@ std::string ZstdWriter::finish()
     return e ? "close failed" : "";
 }
 
+ZstdReader::ZstdReader() {}
+ZstdReader::~ZstdReader()
+{
+    if (ds_) api().freeDStream(ds_);
+    if (f_) fclose(f_);
+}
+
+std::string ZstdReader::open(FILE *f)
+{
+    f_ = f;
+    Api &a = api();
+    if (!a.h) return "zstd unavailable: " + a.why;
+    ds_ = a.createDStream();
+    if (!ds_) return "ZSTD_createDStream failed";
+    a.initDStream(ds_);
+    in_.resize(1 << 20);
+    return "";
+}
+
+long ZstdReader::read(uint8_t *dst, size_t n, std::string &err)
+{
+    Api &a = api();
+    OutBuf ob{dst, n, 0};
+    while (ob.pos < ob.size) {
+        if (in_pos_ == in_size_ && !eof_) {
+            in_size_ = fread(in_.data(), 1, in_.size(), f_);
+            in_pos_ = 0;
+            if (in_size_ == 0) eof_ = true;
+        }
+        if (in_pos_ == in_size_ && eof_) break;
+        InBuf ib{in_.data(), in_size_, in_pos_};
+        size_t rc = a.decompressStream(ds_, &ob, &ib);
+        in_pos_ = ib.pos;
+        if (a.isError(rc)) { err = zerr(rc); return -1; }
+        if (rc == 0 && (in_pos_ < in_size_ || !eof_)) a.initDStream(ds_);      // next frame, if any
+    }
+    return (long)ob.pos;
+}
+
 std::string zstd_decompress_all(const uint8_t *src, size_t n, std::vector<uint8_t> &out)
 {
     Api &a = api();

@@ -25,6 +25,21 @@ private:
     std::vector<uint8_t> out_;
 };
 
+// incremental decoder over a FILE* (for ByteStream)
+class ZstdReader {
+public:
+    ZstdReader();
+    ~ZstdReader();
+    std::string open(FILE *f);                 // takes ownership of f
+    long read(uint8_t *dst, size_t n, std::string &err);
+private:
+    void *ds_ = nullptr;
+    FILE *f_ = nullptr;
+    std::vector<uint8_t> in_;
+    size_t in_pos_ = 0, in_size_ = 0;
+    bool eof_ = false;
+};
+
 std::string zstd_decompress_all(const uint8_t *src, size_t n, std::vector<uint8_t> &out);
 std::string zstd_decompress_file(const std::string &path, std::vector<uint8_t> &out);
 

@@ -44,3 +44,52 @@ def test_lash_sketch_cli_outputs(tmp_path, algo, k, p, extra):
         off = np.cumsum([0] + [len(x) for x in recs]).astype(np.uint64)
         want = O.sketch_genomes(ALGO[algo], k, p, 42, seq, off, np.array([0, len(recs)], np.uint64))[0].tobytes()
         assert blob[i * ib:(i + 1) * ib] == want, (algo, names[i])
+
+
+def test_large_files_are_streamed_in_chunks(tmp_path):
+    """BASELINE configs[4] shape through the CLI: files larger than --stream-mb are cut at record boundaries and
+    accumulated on the device into one sketch; small neighbours keep their batch path and the file order."""
+    import gzip
+    import random
+    rng = random.Random(2)
+    big = O.synth_genome(31, 9_000_000).tobytes()
+    # FASTA with one record longer than the 2 MiB chunk (line-boundary cut + overlap) and several shorter ones
+    fa = b">r0\n" + b"\n".join(big[i:i + 70] for i in range(0, 5_000_000, 70)) + b"\n"
+    pos = 5_000_000
+    for j in range(1, 12):
+        n = rng.randint(200_000, 500_000)
+        fa += b">r%d some ACGT text\n" % j + b"\n".join(big[i:i + 80] for i in range(pos, pos + n, 80)) + b"\n"
+        pos += n
+    # one enormous single-line record
+    fa1 = b">oneline\n" + big[:6_000_000] + b"\n>tail\nACGTACGTACGTACGTACGTACGTACGTACGT\n"
+    reads = []
+    for i in range(40_000):
+        s = rng.randrange(0, 8_000_000)
+        reads.append(b"@r%d\n" % i + big[s:s + 150] + b"\n+\n" + bytes(rng.choice(b"@+IIIIFF>") for _ in range(150)) + b"\n")
+    fq = b"".join(reads)
+    small = b">s\n" + big[100:50_100] + b"\n"
+    contents = {"big.fa": fa, "small1.fa": small, "oneline.fa": fa1, "reads.fq": fq, "small2.fa": small[:20_000] + b"\n"}
+    paths = []
+    for name, data in contents.items():
+        (tmp_path / name).write_bytes(data)
+        paths.append(str(tmp_path / name))
+    with gzip.open(tmp_path / "reads.fq.gz", "wb", compresslevel=1) as g:
+        g.write(fq)
+    paths.append(str(tmp_path / "reads.fq.gz"))
+    lst = tmp_path / "l.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    for algo, k, p in (("hmh", 16, 10), ("ull", 21, 12)):
+        out = str(tmp_path / ("big_" + algo))
+        r = subprocess.run([H.CLI, "sketch", "-f", str(lst), "-o", out, "-a", algo, "-k", str(k), "-p", str(p),
+                            "--stream-mb", "2", "--batch-mb", "1", "-t", "4"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        blob = H.zstd_read(out + "_sketches.bin")
+        ib = O.image_bytes(ALGO[algo], p)
+        assert len(blob) == ib * len(paths)
+        for i, path in enumerate(paths):
+            src = path[:-3] if path.endswith(".gz") else path
+            recs = read_fastx(src)
+            seq = np.frombuffer(b"".join(recs), np.uint8)
+            off = np.cumsum([0] + [len(x) for x in recs]).astype(np.uint64)
+            want = O.sketch_genomes(ALGO[algo], k, p, 42, seq, off, np.array([0, len(recs)], np.uint64), threads=8)[0].tobytes()
+            assert blob[i * ib:(i + 1) * ib] == want, (algo, os.path.basename(path))
