@@ -42,6 +42,11 @@ extern "C" {
 /* flags */
 #define LASH_F_HMH_X_LOW   1u  /* SURVEY App. D switch U1: take x (bucket, lz) from the LOW 64 bits of xxh3_128 */
 #define LASH_F_ACCUMULATE  2u  /* out_images already hold sketches of the same algo/p: union the new ones in */
+#define LASH_F_NO_DIRECT   4u  /* lash_sketch_batch[_device]: always pack first.  By default the sketch kernel first reads
+                                  the record bytes itself, which is exact while a genome holds only upper-case ACGT
+                                  (filter_out_n, utils.rs:33-41, deletes nothing); genomes where it meets anything else
+                                  are re-done through the pack stage in the same call.  Same images either way: set this
+                                  for batches known to be full of N / lower case, to skip the attempt */
 
 typedef struct lash_ctx lash_ctx;        /* one per (host thread, GPU): stream, workspace, scratch */
 typedef struct lash_packed lash_packed;  /* device-resident 2-bit genomes produced by lash_pack_* */
@@ -62,7 +67,7 @@ typedef struct {
     uint32_t calls;             /* sketch calls summed                                                     */
     uint32_t sketch_launches;   /* launches of the sketch kernel summed                                    */
     uint32_t sketch_workgroups; /* workgroups of the last sketch launch                                    */
-    uint32_t reserved;
+    uint32_t direct_launches;   /* launches of the direct (ASCII-reading) sketch kernel summed              */
     uint64_t kmers;             /* valid k-mers hashed, device-counted, summed                             */
     uint64_t bases_last;        /* bases that survived filter_out_n in the last call                       */
     uint64_t packed_bytes;      /* 2-bit words + break bitmap read by the sketch kernel, summed            */

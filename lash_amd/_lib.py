@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx95
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT = 0, -1, -2, -3, -4, -5
 HMH, HLL, ULL = 0, 1, 2
-F_HMH_X_LOW, F_ACCUMULATE = 1, 2
+F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT = 1, 2, 4
 FMT_FASTA, FMT_FASTQ = 1, 2
 ABI_VERSION = 1
 
@@ -22,7 +22,7 @@ class Params(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("pack_ms", C.c_float), ("sketch_ms", C.c_float), ("finalize_ms", C.c_float), ("calls", C.c_uint32),
-                ("sketch_launches", C.c_uint32), ("sketch_workgroups", C.c_uint32), ("reserved", C.c_uint32),
+                ("sketch_launches", C.c_uint32), ("sketch_workgroups", C.c_uint32), ("direct_launches", C.c_uint32),
                 ("kmers", C.c_uint64), ("bases_last", C.c_uint64), ("packed_bytes", C.c_uint64)]
 
 

@@ -48,6 +48,14 @@ struct lash_packed {
     uint64_t total_words = 0, total_brk = 0;
     std::vector<uint64_t> byte_len;      // per genome, host copy (upper bound of surviving bases)
     uint32_t *error_flag = nullptr;      // device word set by the pack kernel if a look-back spin hit its bound
+    // direct mode (lash_sketch_batch[_device] without LASH_F_NO_DIRECT): the pack launch is deferred and restricted,
+    // on the device, to the genomes the direct sketch pass flagged dirty
+    bool direct = false, any_multi = false;
+    const uint8_t *d_seq = nullptr;
+    DevBuf dirty, tile_begin_c, brk_bytes;
+    PackArgs pa{};
+    PackV2Args v2{};
+    PackMapArgs pm{};
     bool owned_by_ctx = false;           // the scratch instance reused by lash_sketch_batch_device
 };
 
@@ -65,7 +73,7 @@ struct lash_ctx {
     HostStage ring[32];                  // pinned staging for the small per-call tables
     unsigned ring_next = 0;
     std::vector<const lash_packed *> last_packed;   // what the last sketch call consumed (for bases_last / error flags)
-    DevBuf items, item_begin, partials, gregs, counter;
+    DevBuf items, item_begin, item_kmers, partials, gregs, counter;
     bool counter_zeroed = false;
     DevBuf st_seq, st_rec, st_img;       // staging for the host-buffer entry
     lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
@@ -168,11 +176,14 @@ uint64_t header_bytes(int algo) { return algo == LASH_HMH ? 0 : algo == LASH_HLL
 // into d_seq) on `stream`.  `ev`, when set, gets its pack-start / pack-end events recorded on that stream.
 int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, const uint8_t *d_seq, const uint8_t *d_seq_end,
               const uint64_t *d_rec_off, uint64_t n_rec, const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
-              uint32_t n_genomes, const uint8_t *formats = nullptr)
+              uint32_t n_genomes, const uint8_t *formats = nullptr, bool direct = false)
 {
     // formats == nullptr: record sequences + rec_off table; else per genome LASH_FMT_FASTA / LASH_FMT_FASTQ raw file bytes
     if (n_genomes && (!genome_byte_off || (!formats && !genome_rec_off))) return LASH_EINVAL;
     pk->error_flag = nullptr;
+    pk->direct = direct && !formats && n_genomes;
+    direct = pk->direct;
+    pk->d_seq = d_seq;
     std::vector<GenomeDesc> descs(n_genomes);
     pk->byte_len.assign(n_genomes, 0);
     uint64_t wo = 0, bo = 0;
@@ -219,6 +230,10 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     if ((rc = reserve(ctx, pk->tile_begin, (size_t)(n_genomes + 1) * 4))) return rc;
     if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
     if ((rc = reserve(ctx, pk->lookback, (size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512))) return rc;
+    if (direct) {
+        if ((rc = reserve(ctx, pk->dirty, (size_t)(n_genomes + 1) * 4))) return rc;
+        if ((rc = reserve(ctx, pk->tile_begin_c, (size_t)(n_genomes + 2) * 4))) return rc;
+    }
     if (n_genomes == 0) return LASH_OK;
     if (ev) { ev->pack = true; HIPCHK(ctx, hipEventRecord(ev->e[0], stream)); }
     if ((rc = upload(ctx, pk->descs.ptr, descs.data(), descs.size() * sizeof(GenomeDesc), stream))) return rc;
@@ -226,8 +241,23 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     bool any_multi = false;                                   // single-record genomes never consult the bitmap
     for (uint32_t g = 0; g < n_genomes && !any_multi; ++g)
         any_multi = descs[g].format != 0u || descs[g].rec_end - descs[g].rec_begin > 1;
+    pk->any_multi = any_multi;
     if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
-    HIPCHK(ctx, hipMemsetAsync(pk->nvalid.ptr, 0, (size_t)(n_genomes + 1) * 8, stream));
+    if (direct) {
+        // nothing deleted unless proven otherwise: surviving bases = bytes; the deferred pack overwrites dirty genomes
+        std::vector<uint64_t> nv(pk->byte_len.begin(), pk->byte_len.end());
+        nv.push_back(0);
+        if ((rc = upload(ctx, pk->nvalid.ptr, nv.data(), nv.size() * 8, stream))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(pk->dirty.ptr, 0, (size_t)(n_genomes + 1) * 4, stream));
+        if (any_multi) {
+            if ((rc = reserve(ctx, pk->brk_bytes, pk->total_brk * 4))) return rc;
+            HIPCHK(ctx, hipMemsetAsync(pk->brk_bytes.ptr, 0, pk->total_brk * 4, stream));
+            HIPCHK(ctx, launch_brk_bytes(static_cast<const GenomeDesc *>(pk->descs.ptr), d_rec_off, n_genomes,
+                                         static_cast<uint32_t *>(pk->brk_bytes.ptr), stream));
+        }
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(pk->nvalid.ptr, 0, (size_t)(n_genomes + 1) * 8, stream));
+    }
     HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, (size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512, stream));
     PackArgs pa{};
     pa.seq = d_seq;
@@ -253,9 +283,28 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pm.tiles = static_cast<TileInfo *>(pk->tiles.ptr);
     pm.n_tiles = (uint32_t)n_tiles;
     pm.n_genomes = n_genomes;
-    HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, formats != nullptr, stream));
-    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[1], stream));
     pk->error_flag = v2.error_flag;
+    if (direct) {                                             // launched by pack_dirty() after the direct sketch pass
+        pk->pa = pa; pk->v2 = v2; pk->pm = pm;
+    } else {
+        HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, formats != nullptr, stream));
+    }
+    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[1], stream));
+    return LASH_OK;
+}
+
+// direct mode, second half: pack exactly the genomes whose dirty flag the direct sketch pass set.  Which ones is
+// decided on the device (scan of the flagged genomes' tile counts), so the host queues this without waiting.
+int pack_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
+{
+    uint32_t *tbc = static_cast<uint32_t *>(pk->tile_begin_c.ptr);
+    const uint32_t *dirty = static_cast<const uint32_t *>(pk->dirty.ptr);
+    HIPCHK(ctx, launch_dirty_tile_scan(pk->pm.tile_begin, dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
+    PackV2Args v2 = pk->v2;
+    PackMapArgs pm = pk->pm;
+    pm.tile_begin = tbc;
+    pm.n_tiles_dev = v2.n_tiles_dev = tbc + pk->n_genomes + 1;
+    HIPCHK(ctx, launch_pack_v2(pk->pa, v2, pm, (uint32_t)ctx->cu_count, false, stream));
     return LASH_OK;
 }
 
@@ -294,12 +343,14 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     if ((rc = reserve(ctx, ctx->items, (size_t)(n_items + 1) * sizeof(WorkItem)))) return rc;
     if ((rc = reserve(ctx, ctx->item_begin, (size_t)(n_genomes + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + 1) * plan.partial_stride))) return rc;
-    if ((rc = reserve(ctx, ctx->counter, 64))) return rc;
+    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
     if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
     if ((rc = upload(ctx, ctx->items.ptr, items.data(), (size_t)n_items * sizeof(WorkItem)))) return rc;
     if ((rc = upload(ctx, ctx->item_begin.ptr, item_begin.data(), (size_t)(n_genomes + 1) * 4))) return rc;
     if (!ctx->counter_zeroed) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 64, ctx->stream));      // [0,8) k-mer census, [16,64) zero words
+        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));     // [0,8) k-mer census, [16,64) zero words,
+                                                                                 // [128,256) direct mode's safe load target
         ctx->counter_zeroed = true;
     }
     if (!plan.use_lds && n_items)
@@ -316,13 +367,24 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     sa.items = static_cast<const WorkItem *>(ctx->items.ptr);
     sa.partials = static_cast<uint8_t *>(ctx->partials.ptr);
     sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
-    sa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
+    sa.item_kmers = static_cast<uint32_t *>(ctx->item_kmers.ptr);
+    sa.safe = static_cast<const uint8_t *>(ctx->counter.ptr) + 128;
     sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
     sa.partial_stride = plan.partial_stride;
     sa.nreg32 = plan.nreg32;
     sa.k = prm->k;
     sa.p = prm->p;
-    HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream));
+    if (pk->direct) {
+        sa.seq = pk->d_seq;
+        sa.brk_bytes = static_cast<const uint32_t *>(pk->brk_bytes.ptr);
+        sa.dirty = static_cast<uint32_t *>(pk->dirty.ptr);
+        HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true));     // ASCII in, exact while nothing is deleted
+        if ((rc = pack_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
+        HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, false));    // the flagged genomes, from their 2-bit form
+        ctx->last.direct_launches += n_items ? 1 : 0;
+    } else {
+        HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream));
+    }
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
 
     FinalizeArgs fa{};
@@ -330,6 +392,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.items = static_cast<const WorkItem *>(ctx->items.ptr);
     fa.genome_item_begin = static_cast<const uint32_t *>(ctx->item_begin.ptr);
     fa.nvalid = static_cast<const uint64_t *>(pk->nvalid.ptr);
+    fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
+    fa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
     fa.images = d_out_images;
     fa.partial_stride = plan.partial_stride;
     fa.partial_base_off = 0;
@@ -440,12 +504,14 @@ void lash_ctx_destroy(lash_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
+    for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->item_kmers, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
                       &ctx->st_img})
         release(*b);
     {
         lash_packed &sc = ctx->scratch;
-        for (DevBuf *b : {&sc.words, &sc.brk, &sc.nvalid, &sc.descs, &sc.tile_begin, &sc.tiles, &sc.lookback}) release(*b);
+        for (DevBuf *b : {&sc.words, &sc.brk, &sc.nvalid, &sc.descs, &sc.tile_begin, &sc.tiles, &sc.lookback, &sc.dirty,
+                          &sc.tile_begin_c, &sc.brk_bytes})
+            release(*b);
     }
     for (auto &s : ctx->ev_pool)
         for (auto &e : s.e)
@@ -607,8 +673,10 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     // sketch workgroup fits, and the step got 20-40 % slower.
     if ((rc = timing_begin(ctx))) return rc;
     EvSet *ev = ctx->cur_ev;
+    static const bool env_no_direct = getenv("LASH_NO_DIRECT") != nullptr;          // A/B knob for tools/
+    const bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct;
     rc = pack_into(ctx, &ctx->scratch, ctx->stream, ev, d_seq, d_seq + genome_byte_off[n_genomes], d_rec_off, n_rec,
-                   genome_rec_off, genome_byte_off, n_genomes);
+                   genome_rec_off, genome_byte_off, n_genomes, nullptr, direct);
     if (rc) return rc;
     rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
     ctx->cur_ev = nullptr;

@@ -17,7 +17,13 @@ struct SketchArgs {
     const WorkItem   *items;
     uint8_t          *partials;   // [n_items][partial_stride] partial sketches in image register format
     uint32_t         *gregs;      // [n_items][nreg32] zeroed u32 words, only for the global-register variant
-    unsigned long long *kmer_counter;   // += valid k-mers
+    uint32_t         *item_kmers; // [n_items] valid k-mers of each work item (summed per genome by finalize_kernel)
+    // direct mode (sketch_kernel<..., DIRECT>): format-0 genomes are read as ASCII straight from the caller's buffer
+    const uint8_t    *seq;        // the caller's record bytes
+    const uint32_t   *brk_bytes;  // record-break bitmap in BYTE positions (== base positions while nothing is deleted)
+    const uint8_t    *safe;       // >= 128 readable bytes: load target of lanes that are not on the fast path
+    uint32_t         *dirty;      // [n_genomes + 1] per genome: a byte outside {A,C,G,T} was met; [n_genomes] = how many.
+                                  // non-direct launches with dirty != NULL run only the genomes flagged here
     uint64_t          bitflip;    // xxh3 seed-folded constant (64- or 128-bit variant by algo)
     uint32_t          partial_stride;
     uint32_t          nreg32;     // u32 words of register state (HMH 16384, HLL 2^p, ULL 2*2^p)
@@ -37,13 +43,19 @@ struct SketchPlan {
 };
 
 SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low);
-hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream);
+hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
+                         bool direct = false);
+// record starts of multi-record format-0 genomes -> args.brk_bytes (zeroed before the launch)
+hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint32_t *brk_bytes,
+                            hipStream_t stream);
 
 struct FinalizeArgs {
     const uint8_t  *partials;
     const WorkItem *items;
     const uint32_t *genome_item_begin;   // n_genomes + 1
     const uint64_t *nvalid;              // NULL => every item is live (merge of images)
+    const uint32_t *item_kmers;          // NULL or per-item valid k-mer counts ...
+    unsigned long long *kmer_counter;    // ... whose per-genome sums are added here
     uint8_t        *images;
     uint64_t        partial_stride;
     uint64_t        partial_base_off;    // offset of the register array inside each partial (merge: header size)
@@ -85,8 +97,9 @@ struct PackV2Args {
     uint32_t       *desc2;           // n_tiles line-state descriptors (raw FASTA/FASTQ genomes), zeroed
     uint32_t       *ticket;          // PACK_TICKET_SHARDS counters at a 128-byte stride, zeroed before the launch
     uint32_t       *error_flag;      // zeroed; != 0 after the launch means a look-back spin hit its bound
-    uint32_t        n_tiles;
+    uint32_t        n_tiles;         // upper bound when n_tiles_dev is set
     uint32_t        n_shards;        // set by launch_pack_v2
+    const uint32_t *n_tiles_dev;     // NULL, or the device-side tile count (pack only the genomes flagged dirty)
 };
 constexpr uint32_t PACK_TICKET_SHARDS = 16;
 struct PackMapArgs {
@@ -96,7 +109,12 @@ struct PackMapArgs {
     const uint32_t   *tile_begin;    // n_genomes + 1: first tile of each genome
     TileInfo         *tiles;
     uint32_t          n_tiles, n_genomes;
+    const uint32_t   *n_tiles_dev;   // see PackV2Args
 };
+// tile_begin_c[g] = tiles of the dirty genomes before g; n_tiles_c = their total (one workgroup, device-side, so the
+// host never waits to learn which genomes the direct sketch pass gave up on)
+hipError_t launch_dirty_tile_scan(const uint32_t *tile_begin, const uint32_t *dirty, uint32_t n_genomes,
+                                  uint32_t *tile_begin_c, uint32_t *n_tiles_c, hipStream_t stream);
 uint32_t   pack_v2_tile_bytes();
 hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, bool any_raw,
                           hipStream_t stream);

@@ -97,7 +97,8 @@ __device__ __forceinline__ void agg_combine(uint32_t &cnt, uint32_t &tail, uint3
 __global__ void __launch_bounds__(256) pack_map_kernel(PackMapArgs m)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= m.n_tiles) return;
+    const uint32_t n_tiles = m.n_tiles_dev ? *m.n_tiles_dev : m.n_tiles;
+    if (t >= n_tiles) return;
     uint32_t lo = 0, hi = m.n_genomes;                       // last g with tile_begin[g] <= t (genomes without
     while (hi - lo > 1) {                                    // tiles share tile_begin with their successor)
         const uint32_t mid = (lo + hi) >> 1;
@@ -281,6 +282,7 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
     const int64_t seq_bytes = a.seq_end - a.seq;
     const uint32_t shard = blockIdx.x % v.n_shards;
     uint32_t *const my_ticket = v.ticket + shard * 32u;     // 128-byte stride
+    const uint32_t n_tiles = v.n_tiles_dev ? *v.n_tiles_dev : v.n_tiles;
 
     auto issue_loads = [&](const TileInfo &ti, uint4 (&q)[P2_CHUNKS]) {
         if (ti.flags & TF_FULL) {
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
     if (tid == 0) { s_next = shard + v.n_shards * atomicAdd(my_ticket, 1u); s_rawfail = 0; }
     lds_barrier();
     uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
-    if (t >= v.n_tiles) return;
+    if (t >= n_tiles) return;
     TileInfo ti = load_tile_uniform(v.tiles + t);
     uint4 q[P2_CHUNKS];
     issue_loads(ti, q);
@@ -489,7 +491,7 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
             clean = (wave_flag[0] & wave_flag[1] & wave_flag[2] & wave_flag[3]) != 0;
             // ---- 3. next tile: its descriptor and its loads go out now and stay in flight ----
             t_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_next);
-            have_next = t_next < v.n_tiles;
+            have_next = t_next < n_tiles;
             if (have_next) {
                 ti_next = load_tile_uniform(v.tiles + t_next);
                 issue_loads(ti_next, q);
@@ -669,6 +671,43 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
 }
 
 uint32_t pack_v2_tile_bytes() { return P2_TILE; }
+
+// exclusive scan of the dirty genomes' tile counts (see launch_dirty_tile_scan in lash_kernels.h)
+__global__ void __launch_bounds__(1024) dirty_tile_scan_kernel(const uint32_t *tile_begin, const uint32_t *dirty,
+                                                               uint32_t n_genomes, uint32_t *tile_begin_c, uint32_t *n_tiles_c)
+{
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_genomes; base += 1024) {
+        const uint32_t g = base + tid;
+        const uint32_t x = (g < n_genomes && dirty[g]) ? tile_begin[g + 1] - tile_begin[g] : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t n = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t)d) inc += n;
+        }
+        if (lane == 63) wave_tot[wid] = inc;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wid; ++w) before += wave_tot[w];
+        if (g < n_genomes) tile_begin_c[g] = before + inc - x;
+        __syncthreads();
+        if (tid == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) { tile_begin_c[n_genomes] = carry; *n_tiles_c = carry; }
+}
+
+hipError_t launch_dirty_tile_scan(const uint32_t *tile_begin, const uint32_t *dirty, uint32_t n_genomes,
+                                  uint32_t *tile_begin_c, uint32_t *n_tiles_c, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dirty_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, tile_begin, dirty, n_genomes, tile_begin_c, n_tiles_c);
+    return hipGetLastError();
+}
 
 hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackMapArgs &m, uint32_t cu_count, bool any_raw,
                           hipStream_t stream)

@@ -215,7 +215,43 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
 #define LASH_SKETCH_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(LASH_SKETCH_WAVES_PER_EU, LASH_SKETCH_WAVES_PER_EU)))
 #endif
 
-template <int ALGO, int KMODE, bool XLOW, bool USE_LDS>
+// ---- direct mode: 2-bit words straight from ASCII ------------------------------------------------------------
+// While a genome holds nothing but upper-case ACGT, filter_out_n (utils.rs:33-41) deletes nothing, base i IS byte i,
+// and the pack stage's scan has nothing to compute: the sketch kernel can read the caller's bytes itself and save
+// the 2-bit round trip through HBM.  Per 4 bytes: code = ((x>>1)^(x>>2))&3 maps A,C,G,T -> 0,1,2,3 (SURVEY App. A:
+// kmerutils' 2-bit alphabet); one v_perm rebuilds the letters those codes stand for, and any difference from x is a
+// byte outside the alphabet -> the genome is flagged dirty and re-done by the pack + sketch path (lash_api.hip).
+__device__ __forceinline__ uint4 load16_any(const uint8_t *p)    // any alignment (gfx950 global loads take it)
+{
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ uint32_t ascii4_to_2bit(uint32_t x, uint32_t &bad)
+{
+    const uint32_t code = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    bad |= x ^ __builtin_amdgcn_perm(0x54474341u, 0x54474341u, code);      // "ACGT"[code] per byte
+    return (code * 0x40100401u) >> 24;                                       // b0<<6 | b1<<4 | b2<<2 | b3 (no carries)
+}
+__device__ __forceinline__ uint32_t ascii16_to_word(const uint4 q, uint32_t &bad)
+{
+    return (ascii4_to_2bit(q.x, bad) << 24) | (ascii4_to_2bit(q.y, bad) << 16) | (ascii4_to_2bit(q.z, bad) << 8) |
+           ascii4_to_2bit(q.w, bad);
+}
+// tail lanes: 16 bytes at genome offset o, byte by byte; bytes at or past L read as 'A' (their k-mers are masked)
+__device__ __noinline__ uint32_t ascii16_slow(const uint8_t *gseq, uint64_t o, uint64_t L, uint32_t &bad)
+{
+    uint32_t w = 0;
+    for (uint32_t b = 0; b < 16; ++b) {
+        const uint32_t c = (o + b < L) ? gseq[o + b] : 0x41u;
+        const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
+        bad |= c ^ ((0x54474341u >> (8 * code)) & 0xFFu);
+        w = (w << 2) | code;
+    }
+    return w;
+}
+
+template <int ALGO, int KMODE, bool XLOW, bool USE_LDS, bool DIRECT>
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
     // dynamic LDS: [nreg32 register words][16 words of per-wave census]; registers start at LDS offset 0 so the
@@ -224,7 +260,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     const WorkItem it = a.items[blockIdx.x];
     const GenomeDesc gd = a.genomes[it.genome];
-    const uint64_t L = a.nvalid[it.genome];
+    if constexpr (!DIRECT) { if (a.dirty && a.dirty[it.genome] == 0u) return; }   // fallback launch: dirty genomes only
+    const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
     const int k = a.k, p = a.p;
     const uint64_t nk = L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0;     // k-mer start positions of the genome
     if ((uint64_t)it.word_begin * 16 >= nk) return;                       // slice beyond the surviving bases
@@ -246,7 +283,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     // A genome with a single record has no interior record boundary: its lanes read three always-zero words (one
     // L1-resident line) instead of streaming 1/8 B per base of break bitmap from HBM.  No branch, no second loop.
     const bool multi_rec = gd.format != 0u || gd.rec_end - gd.rec_begin > 1;
-    const uint32_t *__restrict__ bk = multi_rec ? a.brk + gd.brk_off : a.zero_words;
+    const uint32_t *__restrict__ bk = multi_rec ? (DIRECT ? a.brk_bytes : a.brk) + gd.brk_off : a.zero_words;
+    const uint8_t *__restrict__ gseq = DIRECT ? a.seq + gd.byte_off : nullptr;
+    uint32_t *const dirty = DIRECT ? a.dirty + it.genome : nullptr;
     KParams kp;
     kp.bitflip = a.bitflip;
     kp.p = p;
@@ -258,7 +297,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     // One tile = blockDim.x * 4 words.  The next tile's words and break bits are loaded into registers before the
     // current tile is hashed (about 10k cycles of VALU work per tile cover the HBM latency).
-    struct TileRegs { uint4 q; uint32_t c4, c5, b0, b1, b2; };
+    // direct mode keeps the raw bytes in registers until they are hashed: 4 x 16 own bytes + 1 (2) look-ahead chunks
+    struct TileRegs { uint4 q; uint4 a1, a2, a3, la, lb; uint32_t c4, c5, b0, b1, b2, dflag; };
     const uint32_t step = blockDim.x * SKETCH_WORDS_PER_THREAD;
     auto tile_active = [&](uint32_t tile) {
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
@@ -268,12 +308,21 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     // address): a predicated load sits in an exec-masked block and hipcc then waits for it at the block's end,
     // which would expose the HBM latency once per tile.
     const uint32_t w_last = it.word_end - SKETCH_WORDS_PER_THREAD;        // slices are >= 4 words, multiples of 4
+    auto direct_fast = [&](uint32_t w0) { return (uint64_t)w0 * 16 + 96 <= L; };   // all 96 bytes inside the genome
     auto tile_load = [&](uint32_t tile, TileRegs &t) {
         uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
         w0 = w0 < w_last ? w0 : w_last;
-        t.q = *reinterpret_cast<const uint4 *>(w + w0);                   // 64 bases, 16 B per lane, coalesced
-        t.c4 = w[w0 + 4];                                                 // look-ahead (same or next cache line)
-        t.c5 = (KMODE == KM_GT16) ? w[w0 + 5] : 0u;
+        if constexpr (DIRECT) {
+            const uint8_t *src = direct_fast(w0) ? gseq + (uint64_t)w0 * 16 : a.safe;   // any alignment: byte_off is arbitrary
+            t.q = load16_any(src); t.a1 = load16_any(src + 16); t.a2 = load16_any(src + 32); t.a3 = load16_any(src + 48);
+            t.la = load16_any(src + 64);
+            if constexpr (KMODE == KM_GT16) t.lb = load16_any(src + 80);
+            t.dflag = __hip_atomic_load(dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            t.q = *reinterpret_cast<const uint4 *>(w + w0);               // 64 bases, 16 B per lane, coalesced
+            t.c4 = w[w0 + 4];                                             // look-ahead (same or next cache line)
+            t.c5 = (KMODE == KM_GT16) ? w[w0 + 5] : 0u;
+        }
         const uint32_t bi = multi_rec ? w0 >> 1 : 0u;                     // (w0 * 16) / 32
         t.b0 = bk[bi]; t.b1 = bk[bi + 1]; t.b2 = bk[bi + 2];
     };
@@ -288,7 +337,29 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
         uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
         uint64_t kv = 0;
-        if (active) {
+        if constexpr (DIRECT) {
+            // another workgroup (or an earlier tile) met a byte outside ACGT: this genome goes to the fallback path
+            if (__builtin_amdgcn_readfirstlane((int)cur.dflag) != 0) break;
+            uint32_t bad = 0;
+            if (active) {
+                if (direct_fast(w0)) {
+                    c0 = ascii16_to_word(cur.q, bad); c1 = ascii16_to_word(cur.a1, bad); c2 = ascii16_to_word(cur.a2, bad);
+                    c3 = ascii16_to_word(cur.a3, bad); c4 = ascii16_to_word(cur.la, bad);
+                    if constexpr (KMODE == KM_GT16) c5 = ascii16_to_word(cur.lb, bad);
+                } else {
+                    const uint64_t o = (uint64_t)w0 * 16;
+                    c0 = ascii16_slow(gseq, o, L, bad); c1 = ascii16_slow(gseq, o + 16, L, bad);
+                    c2 = ascii16_slow(gseq, o + 32, L, bad); c3 = ascii16_slow(gseq, o + 48, L, bad);
+                    c4 = ascii16_slow(gseq, o + 64, L, bad);
+                    if constexpr (KMODE == KM_GT16) c5 = ascii16_slow(gseq, o + 80, L, bad);
+                }
+                kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
+            }
+            if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull) {
+                if ((threadIdx.x & 63) == 0) atomicOr(dirty, 1u);
+                break;
+            }
+        } else if (active) {
             c0 = cur.q.x; c1 = cur.q.y; c2 = cur.q.z; c3 = cur.q.w; c4 = cur.c4; c5 = cur.c5;
             kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
         }
@@ -325,7 +396,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         }
     }
 
-    // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one atomic
+    // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one store per item
     for (int off = 32; off > 0; off >>= 1) my_kmers += __shfl_down(my_kmers, off, 64);
     if ((threadIdx.x & 63) == 0) census[threadIdx.x >> 6] = my_kmers;
     if constexpr (!USE_LDS) __threadfence();
@@ -333,7 +404,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     if (threadIdx.x == 0) {
         unsigned long long tot = 0;
         for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) tot += census[i];
-        if (tot) atomicAdd(a.kmer_counter, tot);
+        a.item_kmers[blockIdx.x] = (uint32_t)tot;          // a slice holds < 2^32 positions; summed by finalize_kernel
     }
 
     // flush the partial sketch in image register format (u16 LE for HMH, u8 for HLL / ULL)
@@ -433,6 +504,12 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a)
     uint8_t *img = a.images + (uint64_t)g * a.image_bytes;
     if (threadIdx.x < 72) hist[threadIdx.x] = 0;
     __syncthreads();
+    if (a.item_kmers && threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (uint32_t it = i0; it < i1; ++it)
+            if ((uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];
+        if (tot) atomicAdd(a.kmer_counter, tot);
+    }
 
     for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
         uint32_t acc = a.accumulate ? load_u32_any(img + hdr + 4ull * wi) : 0u;
@@ -501,10 +578,10 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     return s;
 }
 
-template <int ALGO, int KMODE, bool XLOW, bool USE_LDS>
+template <int ALGO, int KMODE, bool XLOW, bool USE_LDS, bool DIRECT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
-    auto kern = sketch_kernel<ALGO, KMODE, XLOW, USE_LDS>;
+    auto kern = sketch_kernel<ALGO, KMODE, XLOW, USE_LDS, DIRECT>;
     if (plan.lds_bytes > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
@@ -514,30 +591,60 @@ static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uin
     return hipGetLastError();
 }
 
-template <int ALGO, bool XLOW>
+template <int ALGO, bool XLOW, bool DIRECT>
 static hipError_t launch_kmode(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
     if (plan.use_lds) {
-        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, true>(plan, args, n, s);
-        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, true>(plan, args, n, s);
-        return launch_one<ALGO, KM_GT16, XLOW, true>(plan, args, n, s);
+        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, true, DIRECT>(plan, args, n, s);
+        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, true, DIRECT>(plan, args, n, s);
+        return launch_one<ALGO, KM_GT16, XLOW, true, DIRECT>(plan, args, n, s);
     }
-    if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, false>(plan, args, n, s);
-    if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, false>(plan, args, n, s);
-    return launch_one<ALGO, KM_GT16, XLOW, false>(plan, args, n, s);
+    if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, false, DIRECT>(plan, args, n, s);
+    if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, false, DIRECT>(plan, args, n, s);
+    return launch_one<ALGO, KM_GT16, XLOW, false, DIRECT>(plan, args, n, s);
 }
 
-hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
+template <bool DIRECT>
+static hipError_t launch_algo(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
-    if (n_items == 0) return hipSuccess;
     switch (plan.algo) {
-    case 0: return plan.x_low ? launch_kmode<0, true>(plan, args, n_items, stream)
-                              : launch_kmode<0, false>(plan, args, n_items, stream);
-    case 1: return launch_kmode<1, false>(plan, args, n_items, stream);
-    case 2: return launch_kmode<2, false>(plan, args, n_items, stream);
+    case 0: return plan.x_low ? launch_kmode<0, true, DIRECT>(plan, args, n_items, stream)
+                              : launch_kmode<0, false, DIRECT>(plan, args, n_items, stream);
+    case 1: return launch_kmode<1, false, DIRECT>(plan, args, n_items, stream);
+    case 2: return launch_kmode<2, false, DIRECT>(plan, args, n_items, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream, bool direct)
+{
+    if (n_items == 0) return hipSuccess;
+    return direct ? launch_algo<true>(plan, args, n_items, stream) : launch_algo<false>(plan, args, n_items, stream);
+}
+
+// one thread per record: the first byte of every record but a genome's first is a k-mer barrier (utils.rs:457-464)
+__global__ void __launch_bounds__(256) brk_bytes_kernel(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes,
+                                                        uint32_t *brk_bytes)
+{
+    for (uint32_t g = blockIdx.y; g < n_genomes; g += gridDim.y) {
+        const GenomeDesc gd = genomes[g];
+        if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
+        for (uint64_t r = gd.rec_begin + 1 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < gd.rec_end;
+             r += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t pos = rec_off[r] - gd.byte_off;
+            if (pos < gd.byte_len) atomicOr(brk_bytes + gd.brk_off + (pos >> 5), 1u << (pos & 31));
+        }
+    }
+}
+
+hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint32_t *brk_bytes,
+                            hipStream_t stream)
+{
+    if (n_genomes == 0) return hipSuccess;
+    hipLaunchKernelGGL(brk_bytes_kernel, dim3(8, n_genomes < 65535u ? n_genomes : 65535u), dim3(256), 0, stream, genomes,
+                       rec_off, n_genomes, brk_bytes);
+    return hipGetLastError();
 }
 
 hipError_t launch_finalize(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream)

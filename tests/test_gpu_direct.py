@@ -1,0 +1,111 @@
+"""GPU parity tests of the direct (ASCII-reading) sketch pass and its dirty-genome fallback (DESIGN.md "Direct mode").
+
+lash_sketch_batch[_device] first lets the sketch kernel read the record bytes itself — exact while a genome holds only
+upper-case ACGT, because filter_out_n (utils.rs:33-41) then deletes nothing — and re-does, in the same call, every genome
+in which it met another byte through the pack stage.  Both routes must give the oracle's images, whatever the mix."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ALGO = {"hmh": 0, "hll": 1, "ull": 2}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lash_amd
+    c = lash_amd.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_images(an, k, p, seed, seq, off, goff):
+    return O.sketch_genomes(ALGO[an], k, p, seed, seq, off, goff, threads=8)
+
+
+def same(got, want, what):
+    if not np.array_equal(got, want):
+        rows = sorted({int(r) for r in np.argwhere(got != want)[:, 0]})
+        raise AssertionError("%s: genomes %s differ" % (what, rows[:10]))
+
+
+def clean_records(rng, n_rec, lo, hi):
+    return ["".join(rng.choice("ACGT") for _ in range(rng.randint(lo, hi))).encode() for _ in range(n_rec)]
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 9, 0), ("hmh", 23, 0), ("hll", 21, 14), ("hll", 16, 8),
+                                    ("ull", 16, 12), ("ull", 31, 10), ("ull", 4, 6)])
+def test_clean_genomes_any_alignment(ctx, an, k, p):
+    """Only ACGT: everything stays on the direct pass.  Odd lengths put every genome at a different byte alignment;
+    multi-record genomes exercise the byte-position break bitmap; tiny genomes the byte-wise tail."""
+    import lash_amd
+    rng = random.Random(hash((an, k, p)) & 0xFFFF)
+    gs = [clean_records(rng, 1, 1, 300) for _ in range(6)]
+    gs += [clean_records(rng, rng.randint(2, 9), 0, 5000) for _ in range(8)]
+    gs += [[O.synth_genome(700 + i, 100_000 + 37 * i + 1).tobytes()] for i in range(3)]
+    gs += [[], [b""], [b"A"], [b"ACGT" * 24], [b"ACGT" * 23 + b"ACG"], [b"C" * 95, b"G" * 97]]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    assert tm["direct_launches"] == 1
+    assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+    same(got, oracle_images(an, k, p, 42, seq, off, goff), "%s k=%d p=%d" % (an, k, p))
+    same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), got, "NO_DIRECT")
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hll", 21, 12), ("ull", 19, 11)])
+def test_mixed_clean_and_dirty_genomes(ctx, an, k, p):
+    """A batch where some genomes are clean, some are dirty from the first byte, and some only near their end (so that
+    most of their direct pass has already run when the flag goes up)."""
+    import lash_amd
+    rng = random.Random(5)
+    L = 600_000
+    gs = []
+    for i in range(12):
+        g = O.synth_genome(900 + i, L + i).copy()
+        kind = i % 4
+        if kind == 1:
+            g[0] = ord("N")
+        elif kind == 2:
+            g[L - 5] = ord("a")                       # lower case is deleted too (utils.rs:36)
+        elif kind == 3:
+            g[L // 2: L // 2 + 1000] = ord("N")
+        cuts = sorted({0, len(g)} | ({rng.randint(0, len(g)) for _ in range(3)} if i % 3 == 0 else set()))
+        gs.append([g[a:b].tobytes() for a, b in zip(cuts[:-1], cuts[1:])])
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+    same(got, oracle_images(an, k, p, 42, seq, off, goff), "mixed")
+    same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), got, "NO_DIRECT")
+
+
+def test_every_byte_value_is_classified_like_filter_out_n(ctx):
+    """One genome per byte value: ACGT flanks around a single foreign byte.  Only A, C, G, T may stay on the direct pass;
+    the images must match the oracle for all 256."""
+    import lash_amd
+    flank = O.synth_genome(5, 500).tobytes()
+    gs = [[flank + bytes([b]) + flank] for b in range(256)]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    got = ctx.sketch_batch("hmh", 11, 0, 42, seq, off, goff)
+    same(got, oracle_images("hmh", 11, 0, 42, seq, off, goff), "byte values")
+
+
+def test_accumulate_through_direct_pass(ctx):
+    import lash_amd
+    a = [[O.synth_genome(1, 40_000).tobytes()], [O.synth_genome(2, 50_001).tobytes()]]
+    b = [[O.synth_genome(3, 30_003).tobytes()], [b"ACGTN" * 3000]]
+    sa, oa, ga = lash_amd.records_to_arrays(a)
+    sb, ob, gb = lash_amd.records_to_arrays(b)
+    img = ctx.sketch_batch("ull", 16, 10, 42, sa, oa, ga)
+    img = ctx.sketch_batch("ull", 16, 10, 42, sb, ob, gb, flags=lash_amd.F_ACCUMULATE, out=img)
+    both = [[a[0][0], b[0][0]], [a[1][0], b[1][0]]]
+    s2, o2, g2 = lash_amd.records_to_arrays(both)
+    same(img, oracle_images("ull", 16, 10, 42, s2, o2, g2), "accumulate")
