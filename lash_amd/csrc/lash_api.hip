@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,8 +44,12 @@ struct HostStage {
 
 struct lash_packed {
     uint32_t n_genomes = 0;
-    DevBuf words, brk, nvalid, descs;
-    DevBuf tile_begin, tiles, lookback;   // pack scratch (lookback: descriptors + flag + ticket counters)
+    DevBuf words, brk;
+    DevBuf tables;                        // one upload: [descs | tile_begin | nvalid] (+ the work items in direct mode)
+    GenomeDesc *d_descs = nullptr;        // sections of `tables`
+    uint32_t *d_tile_begin = nullptr;
+    uint64_t *d_nvalid = nullptr;
+    DevBuf tiles, lookback;               // pack scratch (lookback: descriptors + flag + ticket counters + dirty flags)
     uint64_t total_words = 0, total_brk = 0;
     std::vector<uint64_t> byte_len;      // per genome, host copy (upper bound of surviving bases)
     uint32_t *error_flag = nullptr;      // device word set by the pack kernel if a look-back spin hit its bound
@@ -52,7 +57,12 @@ struct lash_packed {
     // on the device, to the genomes the direct sketch pass flagged dirty
     bool direct = false, any_multi = false;
     const uint8_t *d_seq = nullptr;
-    DevBuf dirty, tile_begin_c, brk_bytes;
+    uint32_t *d_dirty = nullptr;         // inside `lookback` (zeroed by the same memset)
+    DevBuf tile_begin_c, brk_bytes;
+    std::vector<GenomeDesc> h_descs;     // host copies, uploaded together with the work items
+    std::vector<uint32_t> h_tile_begin;
+    std::vector<uint64_t> h_nvalid;
+    const uint64_t *d_rec_off = nullptr;
     PackArgs pa{};
     PackV2Args v2{};
     PackMapArgs pm{};
@@ -73,7 +83,7 @@ struct lash_ctx {
     HostStage ring[32];                  // pinned staging for the small per-call tables
     unsigned ring_next = 0;
     std::vector<const lash_packed *> last_packed;   // what the last sketch call consumed (for bases_last / error flags)
-    DevBuf items, item_begin, item_kmers, partials, gregs, counter;
+    DevBuf items, item_begin, item_kmers, partials, gregs, counter;   // items: [work items | item_begin] of a sketch call
     bool counter_zeroed = false;
     DevBuf st_seq, st_rec, st_img;       // staging for the host-buffer entry
     lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
@@ -143,6 +153,35 @@ int upload(lash_ctx *ctx, void *d_dst, const void *h_src, size_t bytes, hipStrea
     return LASH_OK;
 }
 
+// several small tables, one pinned staging buffer, one copy: sec[i] lands at d_base + off[i] (offsets 256-B aligned)
+struct Section { const void *src; size_t bytes; size_t off; };
+size_t layout_sections(std::vector<Section> &sec)
+{
+    size_t at = 0;
+    for (Section &x : sec) { x.off = at; at += (x.bytes + 255) & ~(size_t)255; }
+    return at;
+}
+int upload_sections(lash_ctx *ctx, void *d_base, const std::vector<Section> &sec, size_t total, hipStream_t stream)
+{
+    if (total == 0) return LASH_OK;
+    HostStage &hs = ctx->ring[ctx->ring_next++ % 32];
+    if (hs.pending) { HIPCHK(ctx, hipEventSynchronize(hs.done)); hs.pending = false; }
+    if (!hs.done) HIPCHK(ctx, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+    if (hs.cap < total) {
+        if (hs.ptr) HIPCHK(ctx, hipHostFree(hs.ptr));
+        hs.ptr = nullptr;
+        hs.cap = 0;
+        HIPCHK(ctx, hipHostMalloc(&hs.ptr, total + total / 4 + 4096, hipHostMallocDefault));
+        hs.cap = total + total / 4 + 4096;
+    }
+    for (const Section &x : sec)
+        if (x.bytes) memcpy(static_cast<uint8_t *>(hs.ptr) + x.off, x.src, x.bytes);
+    HIPCHK(ctx, hipMemcpyAsync(d_base, hs.ptr, total, hipMemcpyHostToDevice, stream));
+    HIPCHK(ctx, hipEventRecord(hs.done, stream));
+    hs.pending = true;
+    return LASH_OK;
+}
+
 int timing_begin(lash_ctx *ctx)      // sets ctx->cur_ev to a fresh event set (or nullptr when timing is off / exhausted)
 {
     ctx->cur_ev = nullptr;
@@ -159,6 +198,21 @@ int timing_begin(lash_ctx *ctx)      // sets ctx->cur_ev to a fresh event set (o
     ctx->cur_ev = s;
     return LASH_OK;
 }
+
+// LASH_TRACE_HOST=1: host-side microsecond marks of one call on stderr (tools/, DESIGN.md "Host cost of a call")
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    HostTrace() : on(getenv("LASH_TRACE_HOST") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[lash host] %8.1f us  %s\n", us, what);
+    }
+};
+HostTrace *g_trace = nullptr;
+#define TRACE(what) do { if (g_trace) g_trace->mark(what); } while (0)
 
 double hll_alpha(int p)
 {
@@ -184,7 +238,8 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pk->direct = direct && !formats && n_genomes;
     direct = pk->direct;
     pk->d_seq = d_seq;
-    std::vector<GenomeDesc> descs(n_genomes);
+    std::vector<GenomeDesc> &descs = pk->h_descs;
+    descs.assign(n_genomes, GenomeDesc{});
     pk->byte_len.assign(n_genomes, 0);
     uint64_t wo = 0, bo = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) {
@@ -211,7 +266,8 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pk->total_brk = bo + 4;
     // tiles of the single-pass pack: genomes are cut at 16-byte-aligned addresses, tiles never straddle genomes
     const uint64_t tile_bytes = pack_v2_tile_bytes();
-    std::vector<uint32_t> tile_begin(n_genomes + 1, 0);
+    std::vector<uint32_t> &tile_begin = pk->h_tile_begin;
+    tile_begin.assign(n_genomes + 1, 0);
     uint64_t n_tiles = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) {
         tile_begin[g] = (uint32_t)n_tiles;
@@ -222,51 +278,55 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
         if (n_tiles > 0x7FFFFFFFull) return LASH_ELIMIT;
     }
     tile_begin[n_genomes] = (uint32_t)n_tiles;
+    TRACE("pack: tables built");
     int rc;
     if ((rc = reserve(ctx, pk->words, pk->total_words * 4))) return rc;
     if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
-    if ((rc = reserve(ctx, pk->nvalid, (size_t)(n_genomes + 1) * 8))) return rc;
-    if ((rc = reserve(ctx, pk->descs, (size_t)(n_genomes + 1) * sizeof(GenomeDesc)))) return rc;
-    if ((rc = reserve(ctx, pk->tile_begin, (size_t)(n_genomes + 1) * 4))) return rc;
     if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
-    if ((rc = reserve(ctx, pk->lookback, (size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512))) return rc;
-    if (direct) {
-        if ((rc = reserve(ctx, pk->dirty, (size_t)(n_genomes + 1) * 4))) return rc;
-        if ((rc = reserve(ctx, pk->tile_begin_c, (size_t)(n_genomes + 2) * 4))) return rc;
-    }
+    const size_t lb_bytes = (((size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512) + 15) & ~(size_t)15;
+    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(n_genomes + 1) * 4))) return rc;
+    pk->d_dirty = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(pk->lookback.ptr) + lb_bytes);
+    if (direct && (rc = reserve(ctx, pk->tile_begin_c, (size_t)(n_genomes + 2) * 4))) return rc;
     if (n_genomes == 0) return LASH_OK;
-    if (ev) { ev->pack = true; HIPCHK(ctx, hipEventRecord(ev->e[0], stream)); }
-    if ((rc = upload(ctx, pk->descs.ptr, descs.data(), descs.size() * sizeof(GenomeDesc), stream))) return rc;
-    if ((rc = upload(ctx, pk->tile_begin.ptr, tile_begin.data(), tile_begin.size() * 4, stream))) return rc;
+    TRACE("pack: reserved");
     bool any_multi = false;                                   // single-record genomes never consult the bitmap
     for (uint32_t g = 0; g < n_genomes && !any_multi; ++g)
         any_multi = descs[g].format != 0u || descs[g].rec_end - descs[g].rec_begin > 1;
     pk->any_multi = any_multi;
-    if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
-    if (direct) {
-        // nothing deleted unless proven otherwise: surviving bases = bytes; the deferred pack overwrites dirty genomes
-        std::vector<uint64_t> nv(pk->byte_len.begin(), pk->byte_len.end());
-        nv.push_back(0);
-        if ((rc = upload(ctx, pk->nvalid.ptr, nv.data(), nv.size() * 8, stream))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(pk->dirty.ptr, 0, (size_t)(n_genomes + 1) * 4, stream));
-        if (any_multi) {
-            if ((rc = reserve(ctx, pk->brk_bytes, pk->total_brk * 4))) return rc;
-            HIPCHK(ctx, hipMemsetAsync(pk->brk_bytes.ptr, 0, pk->total_brk * 4, stream));
-            HIPCHK(ctx, launch_brk_bytes(static_cast<const GenomeDesc *>(pk->descs.ptr), d_rec_off, n_genomes,
-                                         static_cast<uint32_t *>(pk->brk_bytes.ptr), stream));
-        }
+    pk->d_rec_off = d_rec_off;
+    // surviving bases per genome: written by the pack kernel; direct mode starts from "nothing deleted" (= bytes) and
+    // the deferred pack overwrites the genomes that turn out dirty
+    pk->h_nvalid.assign(n_genomes + 1, 0);
+    if (direct) std::copy(pk->byte_len.begin(), pk->byte_len.end(), pk->h_nvalid.begin());
+    if (ev) { ev->pack = true; HIPCHK(ctx, hipEventRecord(ev->e[0], stream)); }
+    if (!direct) {
+        std::vector<Section> sec = {{descs.data(), descs.size() * sizeof(GenomeDesc), 0},
+                                    {tile_begin.data(), tile_begin.size() * 4, 0},
+                                    {pk->h_nvalid.data(), pk->h_nvalid.size() * 8, 0}};
+        const size_t total = layout_sections(sec);
+        if ((rc = reserve(ctx, pk->tables, total))) return rc;
+        if ((rc = upload_sections(ctx, pk->tables.ptr, sec, total, stream))) return rc;
+        uint8_t *tb = static_cast<uint8_t *>(pk->tables.ptr);
+        pk->d_descs = reinterpret_cast<GenomeDesc *>(tb + sec[0].off);
+        pk->d_tile_begin = reinterpret_cast<uint32_t *>(tb + sec[1].off);
+        pk->d_nvalid = reinterpret_cast<uint64_t *>(tb + sec[2].off);
+        TRACE("pack: tables uploaded");
+        if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
+        HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes, stream));
+        TRACE("pack: memsets queued");
     } else {
-        HIPCHK(ctx, hipMemsetAsync(pk->nvalid.ptr, 0, (size_t)(n_genomes + 1) * 8, stream));
+        // direct mode: tables go up together with the work items (sketch_from), the pack launch follows the direct pass
+        pk->d_descs = nullptr; pk->d_tile_begin = nullptr; pk->d_nvalid = nullptr;
+        if (any_multi && (rc = reserve(ctx, pk->brk_bytes, pk->total_brk * 4))) return rc;
     }
-    HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, (size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512, stream));
     PackArgs pa{};
     pa.seq = d_seq;
     pa.seq_end = d_seq_end;
     pa.rec_off = d_rec_off;
-    pa.genomes = static_cast<const GenomeDesc *>(pk->descs.ptr);
+    pa.genomes = pk->d_descs;                                 // direct mode: filled in by direct_begin()
     pa.words = static_cast<uint32_t *>(pk->words.ptr);
     pa.brk = static_cast<uint32_t *>(pk->brk.ptr);
-    pa.nvalid = static_cast<uint64_t *>(pk->nvalid.ptr);
+    pa.nvalid = pk->d_nvalid;
     uint64_t *lb = static_cast<uint64_t *>(pk->lookback.ptr);
     PackV2Args v2{};
     v2.tiles = static_cast<const TileInfo *>(pk->tiles.ptr);
@@ -279,7 +339,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pm.seq = d_seq;
     pm.rec_off = d_rec_off;
     pm.genomes = pa.genomes;
-    pm.tile_begin = static_cast<const uint32_t *>(pk->tile_begin.ptr);
+    pm.tile_begin = pk->d_tile_begin;
     pm.tiles = static_cast<TileInfo *>(pk->tiles.ptr);
     pm.n_tiles = (uint32_t)n_tiles;
     pm.n_genomes = n_genomes;
@@ -290,6 +350,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
         HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, formats != nullptr, stream));
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[1], stream));
+    TRACE("pack: done");
     return LASH_OK;
 }
 
@@ -298,8 +359,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
 int pack_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 {
     uint32_t *tbc = static_cast<uint32_t *>(pk->tile_begin_c.ptr);
-    const uint32_t *dirty = static_cast<const uint32_t *>(pk->dirty.ptr);
-    HIPCHK(ctx, launch_dirty_tile_scan(pk->pm.tile_begin, dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
+    HIPCHK(ctx, launch_dirty_tile_scan(pk->pm.tile_begin, pk->d_dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
     PackV2Args v2 = pk->v2;
     PackMapArgs pm = pk->pm;
     pm.tile_begin = tbc;
@@ -338,16 +398,48 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     }
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
+    TRACE("sketch: planned");
 
     int rc;
-    if ((rc = reserve(ctx, ctx->items, (size_t)(n_items + 1) * sizeof(WorkItem)))) return rc;
-    if ((rc = reserve(ctx, ctx->item_begin, (size_t)(n_genomes + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + 1) * plan.partial_stride))) return rc;
     if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
     if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
-    if ((rc = upload(ctx, ctx->items.ptr, items.data(), (size_t)n_items * sizeof(WorkItem)))) return rc;
-    if ((rc = upload(ctx, ctx->item_begin.ptr, item_begin.data(), (size_t)(n_genomes + 1) * 4))) return rc;
+    const WorkItem *d_items;
+    const uint32_t *d_item_begin;
+    {
+        std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0},
+                                    {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0}};
+        lash_packed *mpk = const_cast<lash_packed *>(pk);
+        if (pk->direct) {                                          // everything this call needs in ONE copy
+            sec.push_back({pk->h_descs.data(), pk->h_descs.size() * sizeof(GenomeDesc), 0});
+            sec.push_back({pk->h_tile_begin.data(), pk->h_tile_begin.size() * 4, 0});
+            sec.push_back({pk->h_nvalid.data(), pk->h_nvalid.size() * 8, 0});
+        }
+        const size_t total = layout_sections(sec);
+        DevBuf &dst = pk->direct ? mpk->tables : ctx->items;
+        if ((rc = reserve(ctx, dst, total + 256))) return rc;
+        if ((rc = upload_sections(ctx, dst.ptr, sec, total, ctx->stream))) return rc;
+        uint8_t *tb = static_cast<uint8_t *>(dst.ptr);
+        d_items = reinterpret_cast<const WorkItem *>(tb + sec[0].off);
+        d_item_begin = reinterpret_cast<const uint32_t *>(tb + sec[1].off);
+        if (pk->direct) {
+            mpk->d_descs = reinterpret_cast<GenomeDesc *>(tb + sec[2].off);
+            mpk->d_tile_begin = reinterpret_cast<uint32_t *>(tb + sec[3].off);
+            mpk->d_nvalid = reinterpret_cast<uint64_t *>(tb + sec[4].off);
+            mpk->pa.genomes = mpk->pm.genomes = pk->d_descs;
+            mpk->pa.nvalid = pk->d_nvalid;
+            mpk->pm.tile_begin = pk->d_tile_begin;
+            const size_t lb_bytes = reinterpret_cast<uint8_t *>(pk->d_dirty) - static_cast<uint8_t *>(pk->lookback.ptr);
+            HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (size_t)(n_genomes + 1) * 4, ctx->stream));
+            if (pk->any_multi) {
+                HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, ctx->stream));
+                HIPCHK(ctx, hipMemsetAsync(pk->brk_bytes.ptr, 0, pk->total_brk * 4, ctx->stream));
+                HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, static_cast<uint32_t *>(pk->brk_bytes.ptr),
+                                             ctx->stream));
+            }
+        }
+    }
     if (!ctx->counter_zeroed) {
         HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));     // [0,8) k-mer census, [16,64) zero words,
                                                                                  // [128,256) direct mode's safe load target
@@ -357,14 +449,15 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n_items * plan.nreg32 * 4, ctx->stream));
 
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
+    TRACE("sketch: items uploaded");
 
     SketchArgs sa{};
     sa.words = static_cast<const uint32_t *>(pk->words.ptr);
     sa.brk = static_cast<const uint32_t *>(pk->brk.ptr);
     sa.zero_words = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(ctx->counter.ptr) + 16);   // zeroed once, never written
-    sa.genomes = static_cast<const GenomeDesc *>(pk->descs.ptr);
-    sa.nvalid = static_cast<const uint64_t *>(pk->nvalid.ptr);
-    sa.items = static_cast<const WorkItem *>(ctx->items.ptr);
+    sa.genomes = pk->d_descs;
+    sa.nvalid = pk->d_nvalid;
+    sa.items = d_items;
     sa.partials = static_cast<uint8_t *>(ctx->partials.ptr);
     sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
     sa.item_kmers = static_cast<uint32_t *>(ctx->item_kmers.ptr);
@@ -377,7 +470,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     if (pk->direct) {
         sa.seq = pk->d_seq;
         sa.brk_bytes = static_cast<const uint32_t *>(pk->brk_bytes.ptr);
-        sa.dirty = static_cast<uint32_t *>(pk->dirty.ptr);
+        sa.dirty = pk->d_dirty;
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true));     // ASCII in, exact while nothing is deleted
         if ((rc = pack_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, false));    // the flagged genomes, from their 2-bit form
@@ -386,12 +479,13 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream));
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
+    TRACE("sketch: launched");
 
     FinalizeArgs fa{};
     fa.partials = static_cast<const uint8_t *>(ctx->partials.ptr);
-    fa.items = static_cast<const WorkItem *>(ctx->items.ptr);
-    fa.genome_item_begin = static_cast<const uint32_t *>(ctx->item_begin.ptr);
-    fa.nvalid = static_cast<const uint64_t *>(pk->nvalid.ptr);
+    fa.items = d_items;
+    fa.genome_item_begin = d_item_begin;
+    fa.nvalid = pk->d_nvalid;
     fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
     fa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
     fa.images = d_out_images;
@@ -406,6 +500,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
     HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
     if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
+    TRACE("finalize: launched");
     ctx->last_packed.push_back(pk);
     ctx->last.sketch_launches += n_items ? 1 : 0;
     ctx->last.sketch_workgroups = n_items;
@@ -509,8 +604,7 @@ void lash_ctx_destroy(lash_ctx *ctx)
         release(*b);
     {
         lash_packed &sc = ctx->scratch;
-        for (DevBuf *b : {&sc.words, &sc.brk, &sc.nvalid, &sc.descs, &sc.tile_begin, &sc.tiles, &sc.lookback, &sc.dirty,
-                          &sc.tile_begin_c, &sc.brk_bytes})
+        for (DevBuf *b : {&sc.words, &sc.brk, &sc.tables, &sc.tiles, &sc.lookback, &sc.tile_begin_c, &sc.brk_bytes})
             release(*b);
     }
     for (auto &s : ctx->ev_pool)
@@ -600,7 +694,7 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
     for (const lash_packed *pk : ctx->last_packed) {
         if (!pk->n_genomes) continue;
         std::vector<uint64_t> nv(pk->n_genomes);
-        HIPCHK(ctx, hipMemcpy(nv.data(), pk->nvalid.ptr, nv.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(nv.data(), pk->d_nvalid, nv.size() * 8, hipMemcpyDeviceToHost));
         for (uint64_t v : nv) t.bases_last += v;
     }
     *out = t;
@@ -634,14 +728,14 @@ void lash_packed_free(lash_ctx *ctx, lash_packed *pk)
         for (auto it = ctx->last_packed.begin(); it != ctx->last_packed.end();)
             it = (*it == pk) ? ctx->last_packed.erase(it) : it + 1;
     }
-    for (DevBuf *b : {&pk->words, &pk->brk, &pk->nvalid, &pk->descs, &pk->tile_begin, &pk->tiles, &pk->lookback})
+    for (DevBuf *b : {&pk->words, &pk->brk, &pk->tables, &pk->tiles, &pk->lookback, &pk->tile_begin_c, &pk->brk_bytes})
         release(*b);
     delete pk;
 }
 
 uint64_t lash_packed_bytes(const lash_packed *pk)
 {
-    return pk ? pk->words.cap + pk->brk.cap + pk->nvalid.cap + pk->descs.cap : 0;
+    return pk ? pk->words.cap + pk->brk.cap + pk->tables.cap : 0;
 }
 
 int lash_sketch_packed_device(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images)
@@ -673,6 +767,9 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     // sketch workgroup fits, and the step got 20-40 % slower.
     if ((rc = timing_begin(ctx))) return rc;
     EvSet *ev = ctx->cur_ev;
+    HostTrace trace;
+    g_trace = trace.on ? &trace : nullptr;
+    TRACE("call");
     static const bool env_no_direct = getenv("LASH_NO_DIRECT") != nullptr;          // A/B knob for tools/
     const bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct;
     rc = pack_into(ctx, &ctx->scratch, ctx->stream, ev, d_seq, d_seq + genome_byte_off[n_genomes], d_rec_off, n_rec,
@@ -680,6 +777,7 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     if (rc) return rc;
     rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
     ctx->cur_ev = nullptr;
+    g_trace = nullptr;
     return rc;
 }
 
@@ -735,6 +833,7 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
     if (rc) return rc;
     rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
     ctx->cur_ev = nullptr;
+    g_trace = nullptr;
     return rc;
 }
 
