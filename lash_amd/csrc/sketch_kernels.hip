@@ -218,9 +218,8 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
 // ---- direct mode: 2-bit words straight from ASCII ------------------------------------------------------------
 // While a genome holds nothing but upper-case ACGT, filter_out_n (utils.rs:33-41) deletes nothing, base i IS byte i,
 // and the pack stage's scan has nothing to compute: the sketch kernel can read the caller's bytes itself and save
-// the 2-bit round trip through HBM.  Per 4 bytes: code = ((x>>1)^(x>>2))&3 maps A,C,G,T -> 0,1,2,3 (SURVEY App. A:
-// kmerutils' 2-bit alphabet); one v_perm rebuilds the letters those codes stand for, and any difference from x is a
-// byte outside the alphabet -> the genome is flagged dirty and re-done by the pack + sketch path (lash_api.hip).
+// the 2-bit round trip through HBM.  Codes are kmerutils' 2-bit alphabet A,C,G,T -> 0,1,2,3; a byte
+// outside the alphabet flags the genome dirty and it is re-done by the pack + sketch path (lash_api.hip).
 __device__ __forceinline__ uint4 load16_any(const uint8_t *p)    // any alignment (gfx950 global loads take it)
 {
     uint4 v;
@@ -229,8 +228,12 @@ __device__ __forceinline__ uint4 load16_any(const uint8_t *p)    // any alignmen
 }
 __device__ __forceinline__ uint32_t ascii4_to_2bit(uint32_t x, uint32_t &bad)
 {
-    const uint32_t code = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
-    bad |= x ^ __builtin_amdgcn_perm(0x54474341u, 0x54474341u, code);      // "ACGT"[code] per byte
+    // The low 3 bits tell the four letters apart (A 1, C 3, T 4, G 7), so they index two 8-entry byte tables held in
+    // v_perm operands: the letter that key stands for (0xFF for the keys no letter has: never equal to x, whose low
+    // bits ARE the key) and its 2-bit code.
+    const uint32_t key = x & 0x07070707u;
+    bad |= x ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, key);        // entries 7..4 | 3..0
+    const uint32_t code = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, key);
     return (code * 0x40100401u) >> 24;                                       // b0<<6 | b1<<4 | b2<<2 | b3 (no carries)
 }
 __device__ __forceinline__ uint32_t ascii16_to_word(const uint4 q, uint32_t &bad)
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
 // ------------------------------------------------------------------------------------------------------------
 // finalize: reduce a genome's partial sketches (max / ULL merge), add the image header, optionally union into
-// what is already in the image (LASH_F_ACCUMULATE, lash_merge_images).  One 256-thread workgroup per genome.
+// what is already in the image (LASH_F_ACCUMULATE, lash_merge_images).  One workgroup per genome.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t ull_unpack32pair(uint32_t r, uint32_t &hi)
 {
@@ -491,7 +494,7 @@ __device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
 }
 
 template <int ALGO>
-__global__ void __launch_bounds__(256) finalize_kernel(FinalizeArgs a)
+__global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
 {
     __shared__ uint32_t hist[72];
     const uint32_t g = blockIdx.x;
@@ -650,10 +653,13 @@ hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, 
 hipError_t launch_finalize(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream)
 {
     if (n_genomes == 0) return hipSuccess;
+    // 4 image bytes per thread and pass; many genomes in a batch -> latency-bound unless the workgroups are wide
+    const uint32_t nwords = (args.algo == 0 ? HMH_M * 2 : (1u << args.p)) >> 2;
+    const uint32_t threads = nwords >= 4096 ? 1024u : nwords >= 1024 ? 512u : 256u;
     switch (args.algo) {
-    case 0: hipLaunchKernelGGL(finalize_kernel<0>, dim3(n_genomes), dim3(256), 0, stream, args); break;
-    case 1: hipLaunchKernelGGL(finalize_kernel<1>, dim3(n_genomes), dim3(256), 0, stream, args); break;
-    case 2: hipLaunchKernelGGL(finalize_kernel<2>, dim3(n_genomes), dim3(256), 0, stream, args); break;
+    case 0: hipLaunchKernelGGL(finalize_kernel<0>, dim3(n_genomes), dim3(threads), 0, stream, args); break;
+    case 1: hipLaunchKernelGGL(finalize_kernel<1>, dim3(n_genomes), dim3(threads), 0, stream, args); break;
+    case 2: hipLaunchKernelGGL(finalize_kernel<2>, dim3(n_genomes), dim3(threads), 0, stream, args); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
