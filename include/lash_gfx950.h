@@ -62,7 +62,7 @@ typedef struct {
 /* Sums over every sketch call since lash_ctx_enable_timing(ctx, 1) (HIP events on the ctx stream). */
 typedef struct {
     float    pack_ms;           /* ASCII -> 2-bit + record-break bitmap (incl. the small table uploads)   */
-    float    sketch_ms;         /* k-mer / xxh3 / register-update kernel (the dominant kernel)             */
+    float    sketch_ms;         /* k-mer / xxh3 / register-update kernels (direct pass + dirty-genome fallback) */
     float    finalize_ms;       /* partial-sketch reduction + byte images                                  */
     uint32_t calls;             /* sketch calls summed                                                     */
     uint32_t sketch_launches;   /* launches of the sketch kernel summed                                    */
@@ -71,6 +71,8 @@ typedef struct {
     uint64_t kmers;             /* valid k-mers hashed, device-counted, summed                             */
     uint64_t bases_last;        /* bases that survived filter_out_n in the last call                       */
     uint64_t packed_bytes;      /* 2-bit words + break bitmap read by the sketch kernel, summed            */
+    float    direct_ms;         /* the part of sketch_ms spent in the direct (ASCII-reading) sketch kernel */
+    float    reserved;
 } lash_timing;
 
 /* ---- library / context ---------------------------------------------------------------------------------- */

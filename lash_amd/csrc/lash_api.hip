@@ -29,8 +29,8 @@ struct DevBuf {
 };
 
 struct EvSet {
-    hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // pack start/end (pack stream); sketch start,
-    bool pack = false, done = false;                                   // sketch end, finalize end (main stream)
+    hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pack start/end; sketch start/end;
+    bool pack = false, done = false, direct = false;                            // finalize end; end of the direct pass
 };
 
 struct HostStage {
@@ -195,6 +195,7 @@ int timing_begin(lash_ctx *ctx)      // sets ctx->cur_ev to a fresh event set (o
     EvSet *s = &ctx->ev_pool[ctx->ev_used++];
     s->pack = false;
     s->done = false;
+    s->direct = false;
     ctx->cur_ev = s;
     return LASH_OK;
 }
@@ -472,6 +473,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.brk_bytes = static_cast<const uint32_t *>(pk->brk_bytes.ptr);
         sa.dirty = pk->d_dirty;
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true));     // ASCII in, exact while nothing is deleted
+        if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
         if ((rc = pack_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, false));    // the flagged genomes, from their 2-bit form
         ctx->last.direct_launches += n_items ? 1 : 0;
@@ -675,7 +677,7 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     lash_timing t = ctx->last;
-    t.pack_ms = t.sketch_ms = t.finalize_ms = 0.f;
+    t.pack_ms = t.sketch_ms = t.finalize_ms = t.direct_ms = 0.f;
     for (size_t i = 0; i < ctx->ev_used; ++i) {
         const EvSet &s = ctx->ev_pool[i];
         if (!s.done) continue;
@@ -683,6 +685,7 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
         if (s.pack) { HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[0], s.e[1])); t.pack_ms += ms; }
         HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[2], s.e[3])); t.sketch_ms += ms;
         HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[3], s.e[4])); t.finalize_ms += ms;
+        if (s.direct) { HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[2], s.e[5])); t.direct_ms += ms; }
     }
     t.kmers = 0;
     t.bases_last = 0;

@@ -242,16 +242,22 @@ __device__ __forceinline__ uint32_t ascii16_to_word(const uint4 q, uint32_t &bad
            ascii4_to_2bit(q.w, bad);
 }
 // tail lanes: 16 bytes at genome offset o, byte by byte; bytes at or past L read as 'A' (their k-mers are masked)
-__device__ __noinline__ uint32_t ascii16_slow(const uint8_t *gseq, uint64_t o, uint64_t L, uint32_t &bad)
+__device__ __noinline__ uint64_t ascii16_slow_raw(const uint8_t *gseq, uint64_t o, uint64_t L)
 {
-    uint32_t w = 0;
+    uint32_t w = 0, bad = 0;
     for (uint32_t b = 0; b < 16; ++b) {
         const uint32_t c = (o + b < L) ? gseq[o + b] : 0x41u;
         const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
         bad |= c ^ ((0x54474341u >> (8 * code)) & 0xFFu);
         w = (w << 2) | code;
     }
-    return w;
+    return ((uint64_t)bad << 32) | w;                   // by value: a reference argument would live in scratch memory
+}
+__device__ __forceinline__ uint32_t ascii16_slow(const uint8_t *gseq, uint64_t o, uint64_t L, uint32_t &bad)
+{
+    const uint64_t r = ascii16_slow_raw(gseq, o, L);
+    bad |= (uint32_t)(r >> 32);
+    return (uint32_t)r;
 }
 
 template <int ALGO, int KMODE, bool XLOW, bool USE_LDS, bool DIRECT>

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench tools/ubench.hip ; run on the GPU box.
 // Prints steady-state ns (and cycles) per wave-instruction per SIMD at 4 waves per SIMD.
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -206,12 +207,28 @@ __global__ void read_kernel(const uint4 *__restrict__ in, uint32_t *out, size_t 
     if (acc == 0x1234567) out[0] = acc;
 }
 
-int main()
+// the direct sketch kernel's access pattern: a lane owns 64 contiguous bytes (4 x dwordx4 at a 64-B lane stride) and
+// also reads the 16 bytes after them; calibrates FETCH_SIZE for profiles/traffic.json
+__global__ void read64_kernel(const uint4 *__restrict__ in, uint32_t *out, size_t n64)
 {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i + 1 < n64; i += stride) {
+        const uint4 *p = in + 4 * i;
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w ^ e.x;
+    }
+    if (acc == 0x1234567) out[0] = acc;
+}
+
+int main(int argc, char **argv)
+{
+    const bool hbm_only = argc > 1 && !strcmp(argv[1], "hbm");
     unsigned long long *d_cyc; uint32_t *d_sink;
     CHK(hipMalloc(&d_cyc, 2 * 4096 * 8)); CHK(hipMalloc(&d_sink, 4096));
     hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
     printf("device: %s  CUs=%d  clock=%d kHz  LDS/block=%zu\n", p.name, p.multiProcessorCount, p.clockRate, p.sharedMemPerBlock);
+    if (!hbm_only) {
     both<OP_XOR>(d_cyc, d_sink); both<OP_ALIGNBIT>(d_cyc, d_sink); both<OP_MUL_LO>(d_cyc, d_sink); both<OP_MUL_HI>(d_cyc, d_sink);
     both<OP_MAD_U64>(d_cyc, d_sink); both<OP_MUL_U24>(d_cyc, d_sink); both<OP_MAD_U24>(d_cyc, d_sink); both<OP_LSHR64>(d_cyc, d_sink);
     both<OP_ADD64>(d_cyc, d_sink); both<OP_FFBH>(d_cyc, d_sink); both<OP_BFE>(d_cyc, d_sink); both<OP_XOR3LIKE>(d_cyc, d_sink);
@@ -219,6 +236,7 @@ int main()
     both<OP_MOV>(d_cyc, d_sink); both<OP_ADD_U32>(d_cyc, d_sink); both<OP_ADD3>(d_cyc, d_sink); both<OP_LSHL_OR>(d_cyc, d_sink);
     both<OP_MIX_XOR_MUL>(d_cyc, d_sink); both<OP_MIX_XOR_MAD64>(d_cyc, d_sink); both<OP_MIX_3XOR_MUL>(d_cyc, d_sink);
     both<OP_DS_MAX_RAND>(d_cyc, d_sink); both<OP_DS_MAX_SAME>(d_cyc, d_sink); both<OP_DS_OR_RAND>(d_cyc, d_sink); both<OP_DS_ADD_SEQ>(d_cyc, d_sink);
+    }
     // HBM copy / read bandwidth (2 GiB buffers, beyond the 256 MiB Infinity Cache)
     size_t bytes = (size_t)2 << 30;
     uint4 *a, *b; CHK(hipMalloc(&a, bytes)); CHK(hipMalloc(&b, bytes));
@@ -235,6 +253,11 @@ int main()
         CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
         CHK(hipEventElapsedTime(&ms, e0, e1));
         if (rep) printf("read  2 GiB: %.3f ms  %.2f TB/s\n", ms, (double)bytes / ms / 1e9);
+        CHK(hipEventRecord(e0));
+        hipLaunchKernelGGL(read64_kernel, dim3(256 * 8), dim3(256), 0, 0, a, d_sink, bytes / 64);
+        CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("read64 2 GiB (64 B + 16 B look-ahead per lane): %.3f ms  %.2f TB/s\n", ms, (double)bytes / ms / 1e9);
     }
     return 0;
 }
