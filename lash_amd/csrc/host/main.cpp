@@ -4,6 +4,7 @@
 //   lash dist   -q PREFIX -r PREFIX [-o dist] [-t N] [-e fgra|ml] [-m 1|0] [--fp32] [--dm]   (main.rs:107-176, 280-617)
 // Extras that do not exist upstream: --gpus N / --device D (which GPUs to use), --batch-mb M, --stream-mb M (files
 // larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,7 +97,7 @@ int cmd_sketch(int argc, char **argv)
     SketchOptions opt;
     const std::string output = a.kv.count("output") ? a.kv["output"] : "sketch";
     const std::string alg = a.kv.count("algorithm") ? a.kv["algorithm"] : "hmh";
-    uint64_t k = 16, p = 10, seed = 42, threads = std::thread::hardware_concurrency(), gpus = 0, dev = 0, batch_mb = 1024,
+    uint64_t k = 16, p = 10, seed = 42, threads = std::thread::hardware_concurrency(), gpus = 0, dev = 0, batch_mb = 64,
              stream_mb = 1024;
     if (a.kv.count("kmer") && !to_u64(a.kv["kmer"], k)) { fprintf(stderr, "error: invalid value for --kmer\n"); return 2; }
     if (a.kv.count("precision") && !to_u64(a.kv["precision"], p)) { fprintf(stderr, "error: invalid value for --precision\n"); return 2; }
@@ -167,13 +168,21 @@ int cmd_dist(int argc, char **argv)
 
 }  // namespace
 
+static void epoch_mark(const char *what)
+{
+    if (!getenv("LASH_CLI_TIMING")) return;
+    const double t = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "[lash cli] epoch %.3f  %s\n", t, what);
+}
+
 int main(int argc, char **argv)
 {
+    epoch_mark("main entered");
     printf("\n ************** initializing logger *****************\n\n");                   // main.rs:23
     fflush(stdout);
     if (argc < 2) { usage(); return 2; }
     const std::string cmd = argv[1];
-    if (cmd == "sketch") return cmd_sketch(argc, argv);
+    if (cmd == "sketch") { const int rc = cmd_sketch(argc, argv); epoch_mark("main returning"); return rc; }
     if (cmd == "dist") return cmd_dist(argc, argv);
     if (cmd == "--version" || cmd == "-V") { printf("Genome Sketching via HyperLogLog, HyperMinhash and UltraLogLog %s\n", VERSION); return 0; }
     usage();

@@ -258,6 +258,16 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                          SketchStats *stats)
 {
     const auto t_start = std::chrono::steady_clock::now();
+    // LASH_CLI_TIMING=1: pipeline marks on stderr (seconds since sketch_files() started)
+    const bool timing = getenv("LASH_CLI_TIMING") != nullptr;
+    std::mutex tmu;
+    auto mark = [&](const char *what, uint64_t a = 0, double dur = -1.0) {
+        if (!timing) return;
+        const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        std::lock_guard<std::mutex> lk(tmu);
+        if (dur >= 0) fprintf(stderr, "[lash cli] %7.3f s  %s %llu (%.3f s)\n", t, what, (unsigned long long)a, dur);
+        else fprintf(stderr, "[lash cli] %7.3f s  %s %llu\n", t, what, (unsigned long long)a);
+    };
     lash_params prm{opt.algo, opt.k, opt.precision, opt.flags, opt.seed};
     if (lash_params_check(&prm) != LASH_OK) return lash_strerror(LASH_EINVAL);
     const size_t ib = lash_sketch_image_bytes(opt.algo, opt.precision);
@@ -276,9 +286,14 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     std::condition_variable cv_todo, cv_done;
     bool no_more = false;
     size_t in_flight = 0;                                  // batches planned but not yet written (guarded by qmu)
+    // Enough batches to keep every device fed and to read ahead while the HIP contexts come up (~0.3 s), but not more
+    // page-locked memory than ~512 MiB: pinning costs ~0.18 s per GB and is the slowest thing the host does here.
+    const size_t in_flight_cap = std::max<size_t>(2 * devices.size() + 1,
+                                                  (size_t)((512ull << 20) / std::max<uint64_t>(opt.batch_bytes, 1)));
     auto gpu_worker = [&](int device) {
         lash_ctx *ctx = nullptr;
         int rc = lash_ctx_create(&ctx, device);
+        mark("context ready on device", (uint64_t)device);
         for (;;) {
             std::shared_ptr<Batch> b;
             {
@@ -293,7 +308,9 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                 else {
                     const uint32_t ng = (uint32_t)(b->f1 - b->f0);
                     b->images.assign((size_t)ng * ib, 0);
+                    const auto g0 = std::chrono::steady_clock::now();
                     int r2 = lash_sketch_files_raw(ctx, &prm, b->buf->p, b->file_off.data(), b->fmt.data(), ng, b->images.data());
+                    mark("GPU done, batch", b->index, std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count());
                     if (r2 != LASH_OK) b->err = std::string(lash_strerror(r2)) + " " + lash_ctx_last_error(ctx);
                 }
             }
@@ -380,15 +397,17 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
         std::shared_ptr<Batch> cur;
         auto finalize = [&]() {
             if (!cur || cur->f1 == cur->f0) return;
-            {   // at most 2 batches per device planned / queued / running / unwritten
+            {   // bounded number of batches planned / queued / running / unwritten
                 std::unique_lock<std::mutex> lk(qmu);
-                cv_done.wait(lk, [&] { return in_flight < 2 * devices.size() + 1; });
+                cv_done.wait(lk, [&] { return in_flight < in_flight_cap; });
                 ++in_flight;
                 if (!pool_bufs.empty()) { cur->buf = std::move(pool_bufs.back()); pool_bufs.pop_back(); }
             }
             if (!cur->buf) cur->buf.reset(new PinnedBuf());
+            const auto p0 = std::chrono::steady_clock::now();
             if (!cur->buf->reserve(cur->file_off.back() + 64)) { cur->err = "out of pinned host memory"; }
             cur->index = batch_index++;
+            mark("batch planned (pinned buffer ready)", cur->index, std::chrono::duration<double>(std::chrono::steady_clock::now() - p0).count());
             cur->fmt.assign(cur->f1 - cur->f0, 0);
             cur->remaining = cur->f1 - cur->f0;
             std::shared_ptr<Batch> b = cur;
@@ -415,6 +434,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                     }
                     if (!e.empty()) { std::lock_guard<std::mutex> lk(b->emu); if (b->err.empty()) b->err = e; }
                     if (b->remaining.fetch_sub(1) == 1) {
+                        mark("batch read into memory", b->index);
                         std::lock_guard<std::mutex> lk(qmu);
                         todo.push_back(b);
                         cv_todo.notify_one();
@@ -476,6 +496,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
         cv_done.notify_all();
     }
     writer.join();
+    mark("writer done", 0);
     if (err.empty()) err = werr;
     if (!err.empty()) return err;
 

@@ -18,7 +18,7 @@ struct SketchOptions {
     uint64_t seed = 42;
     int threads = 1;                 // -t: reader threads and zstd workers (main.rs:184-192)
     std::vector<int> devices;        // GPUs to use; empty = device 0
-    uint64_t batch_bytes = 1ull << 30;   // file bytes per GPU batch
+    uint64_t batch_bytes = 1ull << 26;   // file bytes per GPU batch (page-locking a buffer costs ~0.18 s per GB)
     uint64_t stream_bytes = 1ull << 30;  // files larger than this (compressed: > 1/3 of it on disk) are streamed in chunks
                                          // of this size with on-device accumulation (BASELINE configs[4]); < 4 GiB
     uint32_t flags = 0;              // LASH_F_HMH_X_LOW

@@ -19,9 +19,9 @@ for g in range($N):
     names.append("$D/g%d.fa" % g)
 open("list.txt", "w").write("\n".join(names) + "\n")
 PY
-for T in 8 32 64; do
-  S=$(date +%s.%N); $REPO/lash_amd/bin/lash sketch -f list.txt -o out_$T -k 16 -t $T 2>&1 | tail -1; E=$(date +%s.%N)
-  python3 -c "print(\"threads=$T wall=%.2f s\" % ($E - $S))"
+for T in ${THREADS:-8 32 64}; do
+  S=$(date +%s.%N); $REPO/lash_amd/bin/lash sketch -f list.txt -o out_$T -k 16 -t $T ${EXTRA:-} 2>&1 | tail -${TAILN:-1}; E=$(date +%s.%N)
+  python3 -c "print(\"threads=$T wall=%.2f s  (start %.3f end %.3f)\" % ($E - $S, $S, $E))"
 done
 ls -la out_32_sketches.bin | awk '{print "sketches.bin bytes:", $5}'
 cd / && rm -rf $D
