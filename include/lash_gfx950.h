@@ -149,6 +149,15 @@ int lash_hmh_pair_counts_device(lash_ctx *ctx, const uint8_t *d_ref_images, uint
 int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
                          uint32_t n_qry, uint32_t *out_c, uint32_t *out_n);
 
+/* dist side, HyperLogLog: for every (reference, query) pair the two numbers `len()` needs from the union sketch
+ * (/root/reference/src/utils.rs:355-363: ref_hll.union(q_hll); ref_hll.len()):
+ * out_zero[r * n_qry + q] = #{i : max(a_i, b_i) == 0},  out_sum[r * n_qry + q] = sum_i 2^-max(a_i, b_i).
+ * Images are HLL sketches of precision p as written by `save` (33-byte header + 2^p registers). */
+int lash_hll_pair_union_stats_device(lash_ctx *ctx, int p, const uint8_t *d_ref_images, uint32_t n_ref,
+                                     const uint8_t *d_qry_images, uint32_t n_qry, uint32_t *d_out_zero, double *d_out_sum);
+int lash_hll_pair_union_stats(lash_ctx *ctx, int p, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
+                              uint32_t n_qry, uint32_t *out_zero, double *out_sum);
+
 /* Synthetic genomes of SURVEY.md §8(d) generated in HBM (bench / tests): genome ids first..first+n-1,
  * n_bases ASCII bytes each, written back to back at d_out. */
 int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out);

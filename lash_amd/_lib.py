@@ -58,6 +58,8 @@ PROTOTYPES = {
     "lash_merge_images": (_int, [_vp, _int, _int, _vp, _vp, _u64]),
     "lash_hmh_pair_counts_device": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp]),
     "lash_hmh_pair_counts": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp]),
+    "lash_hll_pair_union_stats_device": (_int, [_vp, _int, _vp, _u32, _vp, _u32, _vp, _vp]),
+    "lash_hll_pair_union_stats": (_int, [_vp, _int, _vp, _u32, _vp, _u32, _vp, _vp]),
     "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),
 }
 

@@ -6,8 +6,12 @@
 // axiomhq/hyperminhash, which the crate hyperminhash 0.1.4 ports [PARITY UNPINNED, like every crate-internal rule].
 // Row order: the reference iterates hashbrown maps under rayon (nondeterministic); here rows come in
 // file order, so parity with the reference is on the SET of rows.
-// HyperLogLog / UltraLogLog distances need the crates' estimator tables (HLL++ bias data, FGRA constants) and are
-// not built yet.
+// HyperLogLog (utils.rs:290-373): per pair union -> len -> inclusion-exclusion Jaccard.  The union's zero / sum come
+// from the GPU (lash_hll_pair_union_stats); `len()` is streaming_algorithms' HLL++ estimator restated [PARITY
+// UNPINNED]: linear counting below the published per-precision threshold, else alpha*m^2/sum.  Its third regime
+// (estimate <= 5m: subtract a k-nearest-neighbour bias read from the HLL++ empirical tables) needs data that is not
+// in this image; a sketch or union that falls there is refused with a message instead of being estimated differently.
+// UltraLogLog distances need the FGRA / ML estimator constants of ultraloglog 0.1.6 and are not built.
 #include "dist.hpp"
 
 #include <dirent.h>
@@ -128,6 +132,26 @@ double hmh_approx_expected_collisions(double n, double m)
     return hmh_expected_collision(n, m) / (double)HP;
 }
 
+// ---- HyperLogLog len() (streaming_algorithms 0.3.3, HLL++ as published by Heule et al.) ----
+constexpr double HLL_THRESHOLD[15] = {10, 20, 40, 80, 220, 400, 900, 1800, 3100, 6500, 11500, 20000, 50000, 120000, 350000};  // p = 4..18
+
+// returns false when the estimate falls in the bias-corrected regime (no tables here)
+bool hll_len(int p, double alpha, uint64_t zero, double sum, double &out)
+{
+    const double m = (double)(1u << p);
+    if (zero > 0) {
+        const double h = m * std::log(m / (double)zero);
+        if (h <= HLL_THRESHOLD[p - 4]) { out = h; return true; }
+    }
+    const double e = alpha * m * m / sum;
+    if (e <= 5.0 * m) return false;
+    out = e;
+    return true;
+}
+
+uint64_t rd_u64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+double rd_f64(const uint8_t *p) { double v; memcpy(&v, p, 8); return v; }
+
 template <class T>
 T compute_distance(T frac, int k, int model)
 {
@@ -158,33 +182,48 @@ std::string run_dist(const DistOptions &opt)
     std::vector<std::string> rnames, qnames;
     if (!(err = slurp(rf["files"], txt)).empty() || !json_parse_string_array(txt, rnames)) return err.empty() ? "bad names JSON " + rf["files"] : err;
     if (!(err = slurp(qf["files"], txt)).empty() || !json_parse_string_array(txt, qnames)) return err.empty() ? "bad names JSON " + qf["files"] : err;
-    if (algo != "hmh")
-        return "lash dist for -a " + algo + " is not built in the gfx950 port yet (it needs the " +
-               (algo == "hll" ? "streaming_algorithms HLL++ bias tables" : "ultraloglog FGRA/ML estimator constants") + ")";
+    if (algo == "ull")
+        return "lash dist for -a ull is not built in the gfx950 port yet (it needs the ultraloglog FGRA/ML estimator constants)";
     const bool same_files = qf["files"] == rf["files"];                                               // main.rs:404
 
     std::vector<uint8_t> rimg, qimg;
     if (!(err = zstd_decompress_file(rf["sketches"], rimg)).empty()) return err;
     if (!(err = zstd_decompress_file(qf["sketches"], qimg)).empty()) return err;
-    const size_t ib = (size_t)HM * 2;
+    const bool hll = algo == "hll";
+    const int prec = hll ? atoi(rp["precision"].c_str()) : 0;
+    if (hll && (prec < 4 || prec > 16)) return "bad precision in " + rf["params"];
+    const size_t ib = hll ? lash_sketch_image_bytes(LASH_HLL, prec) : (size_t)HM * 2;
     if (rimg.size() < rnames.size() * ib) return "Error with reading from " + rf["sketches"];
     if (qimg.size() < qnames.size() * ib) return "Error with reading from " + qf["sketches"];
     const uint32_t nr = (uint32_t)rnames.size(), nq = (uint32_t)qnames.size();
 
-    // ---- GPU: C and N of every pair ----
-    std::vector<uint32_t> C((size_t)nr * nq), N((size_t)nr * nq);
+    // ---- GPU: the O(N_ref * N_qry * registers) scan of every pair ----
+    std::vector<uint32_t> C((size_t)nr * nq), N(hll ? 0 : (size_t)nr * nq);      // hll: C = zero registers of the union
+    std::vector<double> usum(hll ? (size_t)nr * nq : 0);
     {
         lash_ctx *ctx = nullptr;
         int rc = lash_ctx_create(&ctx, opt.device);
         if (rc != LASH_OK) return lash_strerror(rc);
-        rc = lash_hmh_pair_counts(ctx, rimg.data(), nr, qimg.data(), nq, C.data(), N.data());
+        rc = hll ? lash_hll_pair_union_stats(ctx, prec, rimg.data(), nr, qimg.data(), nq, C.data(), usum.data())
+                 : lash_hmh_pair_counts(ctx, rimg.data(), nr, qimg.data(), nq, C.data(), N.data());
         std::string e2 = rc == LASH_OK ? "" : std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
         lash_ctx_destroy(ctx);
         if (!e2.empty()) return e2;
     }
     std::vector<double> rcard(nr), qcard(nq);
-    for (uint32_t i = 0; i < nr; ++i) rcard[i] = hmh_cardinality(rimg.data() + i * ib);
-    for (uint32_t j = 0; j < nq; ++j) qcard[j] = hmh_cardinality(qimg.data() + j * ib);
+    const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which "
+                           "this build does not have (sketch with a smaller -p)";
+    for (uint32_t i = 0; i < nr; ++i) {
+        const uint8_t *im = rimg.data() + i * ib;
+        if (!hll) rcard[i] = hmh_cardinality(im);
+        else if (!hll_len(prec, rd_f64(im), rd_u64(im + 8), rd_f64(im + 16), rcard[i])) return rnames[i] + bias_msg;   // utils.rs:314-315
+    }
+    for (uint32_t j = 0; j < nq; ++j) {
+        const uint8_t *im = qimg.data() + j * ib;
+        if (!hll) qcard[j] = hmh_cardinality(im);
+        else if (!hll_len(prec, rd_f64(im), rd_u64(im + 8), rd_f64(im + 16), qcard[j])) return qnames[j] + bias_msg;
+    }
+    const double hll_alpha = hll && nr ? rd_f64(rimg.data()) : 0.0;
 
     FILE *out = fopen(opt.output_file.c_str(), "w");
     if (!out) return "cannot create " + opt.output_file;
@@ -194,13 +233,22 @@ std::string run_dist(const DistOptions &opt)
         bool first = true;
         for (uint32_t j = 0; j < nq; ++j) {
             if (same_files && j > i) continue;                                                        // utils.rs:158-160
-            const double c = (double)C[(size_t)i * nq + j], n = (double)N[(size_t)i * nq + j];
             double sim = 0.0;
-            if (c != 0.0) {                                                                           // Sketch::similarity
-                const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
-                sim = c < ec ? 0.0 : (c - ec) / n;
+            if (hll) {                                                                                // utils.rs:352-365
+                double u;
+                if (!hll_len(prec, hll_alpha, C[(size_t)i * nq + j], usum[(size_t)i * nq + j], u)) {
+                    fclose(out);
+                    return "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
+                }
+                sim = (rcard[i] + qcard[j] - u) / u;
+            } else {
+                const double c = (double)C[(size_t)i * nq + j], n = (double)N[(size_t)i * nq + j];
+                if (c != 0.0) {                                                                       // Sketch::similarity
+                    const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
+                    sim = c < ec ? 0.0 : (c - ec) / n;
+                }
             }
-            if (sim < 0.0) sim = 0.0;                                                                 // .max(0.0), utils.rs:164
+            if (sim < 0.0) sim = 0.0;                                                                 // .max(0.0), utils.rs:164,362
             const double frac = 2.0 * sim / (1.0 + sim);                                              // utils.rs:165-167
             double d;
             if (qnames[j] == rnames[i]) d = 0.0;                                                      // main.rs:452-453

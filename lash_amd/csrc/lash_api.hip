@@ -951,6 +951,38 @@ int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_re
     return LASH_OK;
 }
 
+int lash_hll_pair_union_stats_device(lash_ctx *ctx, int p, const uint8_t *d_ref_images, uint32_t n_ref,
+                                     const uint8_t *d_qry_images, uint32_t n_qry, uint32_t *d_out_zero, double *d_out_sum)
+{
+    if (!ctx || p < 4 || p > 16 || ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_zero || !d_out_sum)))
+        return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, launch_hll_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, d_out_zero, d_out_sum, ctx->stream));
+    return LASH_OK;
+}
+
+int lash_hll_pair_union_stats(lash_ctx *ctx, int p, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
+                              uint32_t n_qry, uint32_t *out_zero, double *out_sum)
+{
+    if (!ctx || p < 4 || p > 16 || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_zero || !out_sum))) return LASH_EINVAL;
+    if (n_ref == 0 || n_qry == 0) return LASH_OK;
+    (void)hipSetDevice(ctx->device);
+    const size_t ib = lash_sketch_image_bytes(LASH_HLL, p), rb = ib * n_ref, qb = ib * n_qry, np = (size_t)n_ref * n_qry;
+    int rc;
+    if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->st_img, np * 12 + 64))) return rc;
+    uint8_t *d_r = static_cast<uint8_t *>(ctx->st_seq.ptr), *d_q = d_r + rb;
+    double *d_s = static_cast<double *>(ctx->st_img.ptr);
+    uint32_t *d_z = reinterpret_cast<uint32_t *>(d_s + np);
+    HIPCHK(ctx, hipMemcpyAsync(d_r, ref_images, rb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_q, qry_images, qb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = lash_hll_pair_union_stats_device(ctx, p, d_r, n_ref, d_q, n_qry, d_z, d_s))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_zero, d_z, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out_sum, d_s, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
 int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out)
 {
     if (!ctx || (n_genomes && n_bases && !d_out)) return LASH_EINVAL;

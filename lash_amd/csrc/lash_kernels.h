@@ -123,6 +123,9 @@ hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackM
 hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t *d_c,
                             uint32_t *d_n, hipStream_t stream);
 
+hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p,
+                            uint32_t *d_zero, double *d_sum, hipStream_t stream);
+
 // ---- synthetic genomes --------------------------------------------------------------------
 hipError_t launch_synth(uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out, hipStream_t stream);
 

@@ -221,6 +221,19 @@ class Context:
                                                    c.ctypes.data, n.ctypes.data))
         return c, n
 
+    def hll_pair_union_stats(self, p, ref_images, qry_images):
+        """HyperLogLog union statistics of serialized sketches: numpy uint8 [n, 33 + 2^p] in; (zero uint32, sum float64)
+        [n_ref, n_qry] out — what `len()` reads after `union` (utils.rs:355-363)."""
+        ref = np.ascontiguousarray(ref_images, dtype=np.uint8)
+        qry = np.ascontiguousarray(qry_images, dtype=np.uint8)
+        ib = 33 + (1 << int(p))
+        assert ref.ndim == 2 and qry.ndim == 2 and ref.shape[1] == ib and qry.shape[1] == ib
+        zero = np.zeros((ref.shape[0], qry.shape[0]), dtype=np.uint32)
+        usum = np.zeros((ref.shape[0], qry.shape[0]), dtype=np.float64)
+        self._check(self._lib.lash_hll_pair_union_stats(self._h, int(p), ref.ctypes.data, ref.shape[0], qry.ctypes.data,
+                                                        qry.shape[0], zero.ctypes.data, usum.ctypes.data))
+        return zero, usum
+
     def synth_genomes_device(self, first_genome, n_genomes, n_bases, d_out):
         self._check(self._lib.lash_synth_genomes_device(self._h, int(first_genome), int(n_genomes), int(n_bases),
                                                         _ptr(d_out)))

@@ -200,3 +200,30 @@ def mash_distance(sim: float, k: int, model: int, same_name: bool) -> float:
     if model == 1:
         return 1.0 if frac == 0.0 else min(-math.log(frac) / k, 1.0)
     return 1.0 - frac ** (1.0 / k)
+
+
+# ---- HyperLogLog dist side (utils.rs:290-373; streaming_algorithms' HLL++ len(), regimes without the bias tables) ----
+HLL_THRESHOLD = [10, 20, 40, 80, 220, 400, 900, 1800, 3100, 6500, 11500, 20000, 50000, 120000, 350000]   # p = 4..18
+
+
+def hll_alpha(p: int) -> float:
+    return {4: 0.673, 5: 0.697, 6: 0.709}.get(p, 0.7213 / (1.0 + 1.079 / (1 << p)))
+
+
+def hll_len_from_regs(p: int, regs) -> float:
+    """None when the estimate falls into the bias-corrected regime (tables not available)."""
+    m = float(1 << p)
+    zero = sum(1 for r in regs if r == 0)
+    if zero:
+        h = m * math.log(m / zero)
+        if h <= HLL_THRESHOLD[p - 4]:
+            return h
+    e = hll_alpha(p) * m * m / math.fsum(2.0 ** -int(r) for r in regs)
+    return None if e <= 5.0 * m else e
+
+
+def hll_similarity(p: int, a: bytes, b: bytes) -> float:
+    ra, rb = a[33:], b[33:]
+    la, lb = hll_len_from_regs(p, ra), hll_len_from_regs(p, rb)
+    u = hll_len_from_regs(p, [max(x, y) for x, y in zip(ra, rb)])
+    return max((la + lb - u) / u, 0.0)

@@ -104,3 +104,80 @@ def test_lash_dist_cli_hmh(tmp_path, matrix, model, fp32):
     assert r.returncode == 0
     r = subprocess.run([H.CLI, "dist", "-q", "k21", "-r", "refs"], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "same k" in r.stderr
+
+
+def test_hll_pair_union_stats_match_numpy():
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    rng = np.random.default_rng(4)
+    for p, nr, nq in ((4, 3, 2), (10, 19, 33), (14, 17, 5)):
+        m = 1 << p
+        ref = np.zeros((nr, 33 + m), np.uint8)
+        qry = np.zeros((nq, 33 + m), np.uint8)
+        ref[:, :33] = rng.integers(0, 256, size=(nr, 33))                   # headers must be ignored
+        ref[:, 33:] = rng.integers(0, 40, size=(nr, m)) * (rng.random((nr, m)) < 0.7)
+        qry[:, 33:] = rng.integers(0, 62 - p, size=(nq, m)) * (rng.random((nq, m)) < 0.5)
+        qry[0, 33:] = 0
+        zero, usum = ctx.hll_pair_union_stats(p, ref, qry)
+        u = np.maximum(ref[:, None, 33:], qry[None, :, 33:]).astype(np.int64)
+        assert np.array_equal(zero, (u == 0).sum(axis=2))
+        want = np.array([[float(np.sum(np.ldexp(1.0, -u[i, j]).astype(np.longdouble))) for j in range(nq)] for i in range(nr)])
+        assert np.array_equal(usum, want)                                    # exact sum, rounded once
+    ctx.close()
+
+
+@pytest.mark.parametrize("matrix,model,p", [(False, 1, 10), (True, 0, 12)])
+def test_lash_dist_cli_hll(tmp_path, matrix, model, p):
+    base = O.synth_genome(177, 300_000)
+    genomes = [base, _mutated(base, 0.002, 1), _mutated(base, 0.02, 2), O.synth_genome(178, 300_000)]
+    paths = []
+    for i, g in enumerate(genomes):
+        f = tmp_path / ("h%d.fa" % i)
+        f.write_bytes(b">g\n" + g.tobytes() + b"\n")
+        paths.append(str(f))
+    (tmp_path / "all.txt").write_text("\n".join(paths) + "\n")
+    env = dict(os.environ)
+    r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "all.txt"), "-o", "hl", "-k", "21", "-a", "hll", "-p", str(p)],
+                       cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    imgs = [O.sketch_genomes(O.HLL, 21, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0].tobytes() for g in genomes]
+    flags = (["--dm"] if matrix else []) + ["-m", str(model)]
+    r = subprocess.run([H.CLI, "dist", "-q", "hl", "-r", "hl", "-o", "d.txt"] + flags, cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    text = (tmp_path / "d.txt").read_text()
+
+    def expected(i, j):
+        return R.mash_distance(R.hll_similarity(p, imgs[i], imgs[j]), 21, model, i == j)
+
+    got = {}
+    if not matrix:
+        for ln in text.strip().split("\n")[1:]:
+            a, b, d = ln.split("\t")
+            got[frozenset((paths.index(a), paths.index(b)))] = float(d)
+    else:
+        for i, ln in enumerate(text.split("\n")[1:]):
+            cells = ln.split("\t")
+            assert cells[0] == paths[i] and len(cells) == i + 2
+            for j, d in enumerate(cells[1:]):
+                got[frozenset((i, j))] = float(d)
+    assert len(got) == 4 * 5 // 2
+    for i in range(4):
+        for j in range(i + 1):
+            assert abs(got[frozenset((i, j))] - expected(i, j)) <= 1.1e-6, (i, j)
+    assert 0 < got[frozenset((0, 1))] < got[frozenset((0, 2))] < got[frozenset((0, 3))] <= 1.0
+
+
+def test_lash_dist_hll_refuses_the_bias_table_regime_and_ull(tmp_path):
+    """A 20 kbp genome at p = 14: the raw estimate is below 5 * 2^14, where streaming_algorithms subtracts a bias read from
+    the HLL++ tables.  Those tables are not available here, so the command must fail loudly, never estimate differently."""
+    g = O.synth_genome(3, 20_000)
+    (tmp_path / "s.fa").write_bytes(b">s\n" + g.tobytes() + b"\n")
+    (tmp_path / "l.txt").write_text(str(tmp_path / "s.fa") + "\n")
+    env = dict(os.environ)
+    for algo, pre in (("hll", "sm"), ("ull", "ul")):
+        r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "l.txt"), "-o", pre, "-a", algo, "-p", "14"], cwd=tmp_path, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+    r = subprocess.run([H.CLI, "dist", "-q", "sm", "-r", "sm"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "bias tables" in r.stderr
+    r = subprocess.run([H.CLI, "dist", "-q", "ul", "-r", "ul"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "ull" in r.stderr
