@@ -87,6 +87,14 @@ struct lash_ctx {
     bool counter_zeroed = false;
     DevBuf st_seq, st_rec, st_img;       // staging for the host-buffer entry
     lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
+    // direct-mode feedback: the dirty-tile count of the last direct call comes back through a pinned word, is looked at
+    // (never waited for) by the next call, and switches the optimistic pass off while batches keep turning out dirty
+    uint32_t *probe_host = nullptr;      // pinned: [0] = dirty tiles of the last probed call
+    hipEvent_t probe_ev = nullptr;
+    bool probe_pending = false;
+    uint32_t probe_tiles = 0;            // all tiles of that call
+    float dirty_frac = 0.f;              // last observed fraction of tiles in dirty genomes
+    uint32_t direct_skipped = 0;         // calls since the optimistic pass was last tried
 };
 
 namespace {
@@ -361,6 +369,17 @@ int pack_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 {
     uint32_t *tbc = static_cast<uint32_t *>(pk->tile_begin_c.ptr);
     HIPCHK(ctx, launch_dirty_tile_scan(pk->pm.tile_begin, pk->d_dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
+    if (!ctx->probe_host) {
+        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->probe_host), 64, hipHostMallocDefault));
+        ctx->probe_host[0] = 0;
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->probe_ev, hipEventDisableTiming));
+    }
+    if (!ctx->probe_pending) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->probe_host, tbc + pk->n_genomes + 1, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(ctx, hipEventRecord(ctx->probe_ev, stream));
+        ctx->probe_pending = true;
+        ctx->probe_tiles = pk->pm.n_tiles;
+    }
     PackV2Args v2 = pk->v2;
     PackMapArgs pm = pk->pm;
     pm.tile_begin = tbc;
@@ -612,6 +631,8 @@ void lash_ctx_destroy(lash_ctx *ctx)
     for (auto &s : ctx->ev_pool)
         for (auto &e : s.e)
             if (e) (void)hipEventDestroy(e);
+    if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
+    if (ctx->probe_ev) (void)hipEventDestroy(ctx->probe_ev);
     for (auto &hs : ctx->ring) {
         if (hs.done) (void)hipEventDestroy(hs.done);
         if (hs.ptr) (void)hipHostFree(hs.ptr);
@@ -774,7 +795,17 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     g_trace = trace.on ? &trace : nullptr;
     TRACE("call");
     static const bool env_no_direct = getenv("LASH_NO_DIRECT") != nullptr;          // A/B knob for tools/
-    const bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct;
+    // A genome that turns out dirty late has cost a wasted direct pass, so the optimistic pass only pays while most of a
+    // batch is clean (break-even near 20 % dirty).  Feedback from the previous direct call, read without waiting:
+    if (ctx->probe_pending && hipEventQuery(ctx->probe_ev) == hipSuccess) {
+        ctx->dirty_frac = ctx->probe_tiles ? (float)ctx->probe_host[0] / (float)ctx->probe_tiles : 0.f;
+        ctx->probe_pending = false;
+    }
+    bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct;
+    if (direct && ctx->dirty_frac > 0.2f) {
+        if (++ctx->direct_skipped < 8) direct = false;          // pack first; try again every 8th call
+        else ctx->direct_skipped = 0;
+    }
     rc = pack_into(ctx, &ctx->scratch, ctx->stream, ev, d_seq, d_seq + genome_byte_off[n_genomes], d_rec_off, n_rec,
                    genome_rec_off, genome_byte_off, n_genomes, nullptr, direct);
     if (rc) return rc;

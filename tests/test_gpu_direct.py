@@ -38,10 +38,11 @@ def clean_records(rng, n_rec, lo, hi):
 
 @pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 9, 0), ("hmh", 23, 0), ("hll", 21, 14), ("hll", 16, 8),
                                     ("ull", 16, 12), ("ull", 31, 10), ("ull", 4, 6)])
-def test_clean_genomes_any_alignment(ctx, an, k, p):
+def test_clean_genomes_any_alignment(an, k, p):
     """Only ACGT: everything stays on the direct pass.  Odd lengths put every genome at a different byte alignment;
     multi-record genomes exercise the byte-position break bitmap; tiny genomes the byte-wise tail."""
     import lash_amd
+    ctx = lash_amd.Context(0)               # fresh: no dirty-batch history that would make it pack first
     rng = random.Random(hash((an, k, p)) & 0xFFFF)
     gs = [clean_records(rng, 1, 1, 300) for _ in range(6)]
     gs += [clean_records(rng, rng.randint(2, 9), 0, 5000) for _ in range(8)]
@@ -56,6 +57,7 @@ def test_clean_genomes_any_alignment(ctx, an, k, p):
     assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
     same(got, oracle_images(an, k, p, 42, seq, off, goff), "%s k=%d p=%d" % (an, k, p))
     same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), got, "NO_DIRECT")
+    ctx.close()
 
 
 @pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hll", 21, 12), ("ull", 19, 11)])
@@ -109,3 +111,25 @@ def test_accumulate_through_direct_pass(ctx):
     both = [[a[0][0], b[0][0]], [a[1][0], b[1][0]]]
     s2, o2, g2 = lash_amd.records_to_arrays(both)
     same(img, oracle_images("ull", 16, 10, 42, s2, o2, g2), "accumulate")
+
+
+def test_direct_pass_backs_off_while_batches_are_dirty():
+    """The context looks at the previous direct call's dirty-tile count (without waiting for it) and packs first while
+    batches keep turning out dirty, probing again every 8th call.  Results never change."""
+    import lash_amd
+    c = lash_amd.Context(0)
+    dirty = [[(O.synth_genome(40 + i, 200_000).tobytes()[:-1] + b"N")] for i in range(6)]
+    clean = [[O.synth_genome(50 + i, 200_000).tobytes()] for i in range(6)]
+    sd, od, gd = lash_amd.records_to_arrays(dirty)
+    sc, oc, gc = lash_amd.records_to_arrays(clean)
+    want_d = oracle_images("hmh", 16, 0, 42, sd, od, gd)
+    want_c = oracle_images("hmh", 16, 0, 42, sc, oc, gc)
+    c.enable_timing(True)
+    for _ in range(12):
+        same(c.sketch_batch("hmh", 16, 0, 42, sd, od, gd), want_d, "dirty batch")      # synchronous: feedback has landed
+    tried = c.timing()["direct_launches"]
+    assert 2 <= tried <= 4, tried                      # call 1, then every 8th: far fewer than 12
+    for _ in range(10):
+        same(c.sketch_batch("hmh", 16, 0, 42, sc, oc, gc), want_c, "clean batch")
+    assert c.timing()["direct_launches"] - tried >= 2  # back on once a probe saw a clean batch
+    c.close()
