@@ -34,16 +34,21 @@ enum { KM_16 = 0, KM_LT16 = 1, KM_GT16 = 2 };
 // ------------------------------------------------------------------------------------------------------------
 struct LdsRegs {
     uint32_t *base;
+    // The register table starts at LDS address 0 (the kernel has no static __shared__; checked at kernel entry), so the
+    // word index goes straight into the DS address.  Through a pointer hipcc adds the table's link-time base (0) with a
+    // v_add_u32 per k-mer; the update itself is fire-and-forget, nothing in the hashing loop reads the table back, and
+    // lds_wait() drains the counter before the flush reads it.
 #ifdef LASH_ABL_NO_ATOMIC   // timing-only diagnostic build (tools/variants.sh): results are wrong by construction
     __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const { asm volatile("" ::"v"(i), "v"(v)); }
     __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const { asm volatile("" ::"v"(i), "v"(v)); }
 #else
     __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const
-    { (void)__hip_atomic_fetch_max(base + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    { asm volatile("ds_max_u32 %0, %1" ::"v"(i << 2), "v"(v) : "memory"); }
     __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const
-    { (void)__hip_atomic_fetch_or(base + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    { asm volatile("ds_or_b32 %0, %1" ::"v"(i << 2), "v"(v) : "memory"); }
 #endif
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i]; }
+    static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
 struct GlobalRegs {
     uint32_t *base;
@@ -53,6 +58,7 @@ struct GlobalRegs {
     { if (v) (void)__hip_atomic_fetch_or(base + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ __forceinline__ uint32_t get(uint32_t i) const
     { return __hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ void lds_wait() {}
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -279,6 +285,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     Regs regs;
     uint32_t *census;
     if constexpr (USE_LDS) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
         census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
@@ -406,6 +413,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
 
     // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one store per item
+    Regs::lds_wait();
     for (int off = 32; off > 0; off >>= 1) my_kmers += __shfl_down(my_kmers, off, 64);
     if ((threadIdx.x & 63) == 0) census[threadIdx.x >> 6] = my_kmers;
     if constexpr (!USE_LDS) __threadfence();
