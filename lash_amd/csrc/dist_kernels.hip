@@ -4,53 +4,87 @@
 // /root/reference/src/utils.rs:164:   C = #{i : a_i != 0 and a_i == b_i},   N = #{i : a_i != 0 or b_i != 0}.
 // The O(N_ref * N_qry * 16384) part runs here; cardinalities and the collision correction are O(pairs) host work.
 //
-// One 256-thread workgroup owns a 16 x 16 tile of pairs and walks the 16 384 registers in chunks of 512 staged in
-// LDS (rows padded to 257 words so that the 16 query rows of a column land on different banks; the reference row is
-// a broadcast).  Two u16 registers per u32 are compared with SWAR zero-half tests.
+// Both kernels tile the pair matrix and walk the registers in chunks staged in LDS (details at each kernel).
 #include <hip/hip_runtime.h>
 
 #include "lash_kernels.h"
 
 namespace lash {
 
-constexpr int DT = 16;                 // tile edge (pairs)
-constexpr int DCHUNK_WORDS = 256;      // 512 registers per sketch per chunk
-constexpr int DROW = DCHUNK_WORDS + 1; // padded LDS row
+constexpr int DT = 16;                 // HLL kernel: tile edge (pairs), one pair per lane
 
-__device__ __forceinline__ uint32_t zero_halves(uint32_t x)
-{
-    // 0x8000 in every 16-bit half of x that is zero (exact, no carries across halves)
-    return ~(((x & 0x7FFF7FFFu) + 0x7FFF7FFFu) | x | 0x7FFF7FFFu);
-}
+// ---- HyperMinHash: two u16 registers per u32, compared with packed 16-bit VALU ops --------------------------------------
+// per half h of a word pair (a, b):   [a_h != 0 and a_h != b_h] = min(a_h ^ b_h, min(a_h, 1))
+//                                     [a_h != 0 or  b_h != 0]   = min(a_h, 1) | min(b_h, 1)
+// C = (non-zero registers of a) - sum of the first, N = sum of the second; the sums run in packed u16 counters (at most
+// 8 192 words per sketch, so a half never exceeds 8 192).  A 256-thread workgroup owns a 64 x 64 tile of pairs, a lane a
+// 4 x 4 block of it: the flags min(a,1) / min(b,1) are computed once per operand word and shared by 4 pairs, and one
+// ds_read_b128 per operand side fetches the lane's 4 rows (LDS chunks are stored word-major: T[word][row]).
+// Only the two min() need packed 16-bit ops (v_pk_min_u16, ~4.2 cycles); xor / or / add are plain 32-bit ops (~2.4).
+// hipcc turns min(x, 1) on u16 vectors into compare + select per half, hence the inline asm.
+constexpr int HT = 64;                 // tile edge (pairs)
+constexpr int HB = 4;                  // block edge per lane
+constexpr int HCW = 64;                // words (= 128 registers) per sketch per LDS chunk
+constexpr int HSTRIDE = HT + 4;        // LDS row (one word of 64 sketches), padded, 16-byte multiple
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 __global__ void __launch_bounds__(256) hmh_pairs_kernel(const uint32_t *__restrict__ ref, uint32_t n_ref,
                                                         const uint32_t *__restrict__ qry, uint32_t n_qry,
                                                         uint32_t *__restrict__ out_c, uint32_t *__restrict__ out_n)
 {
-    __shared__ uint32_t R[DT][DROW], Q[DT][DROW];
-    const uint32_t tid = threadIdx.x, tr = tid / DT, tq = tid % DT;
-    const uint32_t r0 = blockIdx.y * DT, q0 = blockIdx.x * DT;
-    constexpr uint32_t WORDS = HMH_M / 2;                       // 8192 u32 per sketch
-    uint32_t c = 0, n = 0;
-    for (uint32_t w0 = 0; w0 < WORDS; w0 += DCHUNK_WORDS) {
-        for (uint32_t i = tid; i < DT * DCHUNK_WORDS; i += 256) {
-            const uint32_t row = i / DCHUNK_WORDS, col = i % DCHUNK_WORDS;
-            R[row][col] = (r0 + row < n_ref) ? ref[(uint64_t)(r0 + row) * WORDS + w0 + col] : 0u;
-            Q[row][col] = (q0 + row < n_qry) ? qry[(uint64_t)(q0 + row) * WORDS + w0 + col] : 0u;
+    __shared__ __attribute__((aligned(16))) uint32_t R[HCW][HSTRIDE], Q[HCW][HSTRIDE];
+    const uint32_t tid = threadIdx.x, tr = tid / 16, tq = tid % 16;           // lane block: rows tr*4.., columns tq*4..
+    const uint32_t r0 = blockIdx.y * HT, q0 = blockIdx.x * HT;
+    constexpr uint32_t WORDS = HMH_M / 2;                                       // 8192 u32 per sketch
+    uint32_t one = 0x00010001u;
+    asm volatile("" : "+v"(one));                                              // keep it in a VGPR (VOP3P operand)
+    uint32_t acc_ne[HB][HB], acc_or[HB][HB], nz_a[HB];                          // packed u16 counters
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+        nz_a[i] = 0;
+#pragma unroll
+        for (int j = 0; j < HB; ++j) { acc_ne[i][j] = 0; acc_or[i][j] = 0; }
+    }
+    for (uint32_t w0 = 0; w0 < WORDS; w0 += HCW) {
+        // stage: global reads run along the words of a sketch (coalesced), LDS is written word-major
+        for (uint32_t i = tid; i < HT * HCW; i += 256) {
+            const uint32_t row = i / HCW, col = i % HCW;
+            R[col][row] = (r0 + row < n_ref) ? ref[(uint64_t)(r0 + row) * WORDS + w0 + col] : 0u;
+            Q[col][row] = (q0 + row < n_qry) ? qry[(uint64_t)(q0 + row) * WORDS + w0 + col] : 0u;
         }
         __syncthreads();
-#pragma unroll 8
-        for (uint32_t w = 0; w < DCHUNK_WORDS; ++w) {
-            const uint32_t a = R[tr][w], b = Q[tq][w];
-            const uint32_t za = zero_halves(a), zb = zero_halves(b);
-            c += (uint32_t)__builtin_popcount(zero_halves(a ^ b) & ~za);          // equal and non-zero
-            n += 2u - (uint32_t)__builtin_popcount(za & zb);                      // not both zero
+#pragma unroll 2
+        for (uint32_t w = 0; w < HCW; ++w) {
+            const uint4 av = *reinterpret_cast<const uint4 *>(&R[w][tr * HB]);
+            const uint4 bv = *reinterpret_cast<const uint4 *>(&Q[w][tq * HB]);
+            const uint32_t a[HB] = {av.x, av.y, av.z, av.w}, b[HB] = {bv.x, bv.y, bv.z, bv.w};
+            uint32_t fa[HB], fb[HB];
+#pragma unroll
+            for (int i = 0; i < HB; ++i) { fa[i] = pk_min_u16(a[i], one); fb[i] = pk_min_u16(b[i], one); nz_a[i] += fa[i]; }
+#pragma unroll
+            for (int i = 0; i < HB; ++i) {
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    acc_ne[i][j] += pk_min_u16(a[i] ^ b[j], fa[i]);       // plain adds: a half never exceeds 8 192
+                    acc_or[i][j] += fa[i] | fb[j];
+                }
+            }
         }
         __syncthreads();
     }
-    if (r0 + tr < n_ref && q0 + tq < n_qry) {
-        out_c[(uint64_t)(r0 + tr) * n_qry + q0 + tq] = c;
-        out_n[(uint64_t)(r0 + tr) * n_qry + q0 + tq] = n;
+#pragma unroll
+    for (int i = 0; i < HB; ++i) {
+        const uint32_t r = r0 + tr * HB + i;
+        const uint32_t nza = (nz_a[i] & 0xFFFFu) + (nz_a[i] >> 16);
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+            const uint32_t q = q0 + tq * HB + j;
+            if (r < n_ref && q < n_qry) {
+                out_c[(uint64_t)r * n_qry + q] = nza - ((acc_ne[i][j] & 0xFFFFu) + (acc_ne[i][j] >> 16));
+                out_n[(uint64_t)r * n_qry + q] = (acc_or[i][j] & 0xFFFFu) + (acc_or[i][j] >> 16);
+            }
+        }
     }
 }
 
@@ -123,7 +157,7 @@ hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t 
                             uint32_t *d_n, hipStream_t stream)
 {
     if (n_ref == 0 || n_qry == 0) return hipSuccess;
-    dim3 grid((n_qry + DT - 1) / DT, (n_ref + DT - 1) / DT);
+    dim3 grid((n_qry + HT - 1) / HT, (n_ref + HT - 1) / HT);
     hipLaunchKernelGGL(hmh_pairs_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(d_ref), n_ref,
                        reinterpret_cast<const uint32_t *>(d_qry), n_qry, d_c, d_n);
     return hipGetLastError();

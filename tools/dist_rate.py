@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""tools/dist_rate.py — pairs/s of the dist-side pair kernels on resident images (GPU box)."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import lash_amd
+from lash_amd._lib import load
+import ctypes as C
+
+n = int(os.environ.get("N", 2048))
+lib = load()
+ctx = lash_amd.Context(0, stream=torch.cuda.current_stream())
+g = torch.Generator(device="cuda").manual_seed(1)
+# HMH: random u16 registers from a small alphabet so that equal / zero cases occur
+img = torch.randint(0, 7, (n, 16384), dtype=torch.int16, device="cuda", generator=g).view(torch.uint8).reshape(n, 32768).contiguous()
+c = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+m = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+def run_hmh():
+    rc = lib.lash_hmh_pair_counts_device(ctx._h, img.data_ptr(), n, img.data_ptr(), n, c.data_ptr(), m.data_ptr())
+    assert rc == 0
+run_hmh(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3): run_hmh()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+print("hmh pairs: %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (n, n, dt * 1e3, n * n / dt, n * n * 16384 / dt))
+# check a few entries
+a = img.view(torch.int16).reshape(n, 16384)
+for (i, j) in ((0, 0), (3, 17), (n - 1, 5)):
+    wc = int(((a[i] == a[j]) & (a[i] != 0)).sum()); wn = int(((a[i] != 0) | (a[j] != 0)).sum())
+    assert int(c[i, j]) == wc and int(m[i, j]) == wn, (i, j)
+for p in (12, 14):
+    ib = 33 + (1 << p)
+    h = torch.randint(0, 30, (n, ib), dtype=torch.uint8, device="cuda", generator=g)
+    z = torch.zeros((n, n), dtype=torch.int32, device="cuda")
+    s = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    def run_hll():
+        rc = lib.lash_hll_pair_union_stats_device(ctx._h, p, h.data_ptr(), n, h.data_ptr(), n, z.data_ptr(), s.data_ptr())
+        assert rc == 0
+    run_hll(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): run_hll()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print("hll p=%d pairs: %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (p, n, n, dt * 1e3, n * n / dt, n * n * (1 << p) / dt))
+print("ok")
