@@ -17,6 +17,7 @@
 #include <dirent.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -197,19 +198,6 @@ std::string run_dist(const DistOptions &opt)
     if (qimg.size() < qnames.size() * ib) return "Error with reading from " + qf["sketches"];
     const uint32_t nr = (uint32_t)rnames.size(), nq = (uint32_t)qnames.size();
 
-    // ---- GPU: the O(N_ref * N_qry * registers) scan of every pair ----
-    std::vector<uint32_t> C((size_t)nr * nq), N(hll ? 0 : (size_t)nr * nq);      // hll: C = zero registers of the union
-    std::vector<double> usum(hll ? (size_t)nr * nq : 0);
-    {
-        lash_ctx *ctx = nullptr;
-        int rc = lash_ctx_create(&ctx, opt.device);
-        if (rc != LASH_OK) return lash_strerror(rc);
-        rc = hll ? lash_hll_pair_union_stats(ctx, prec, rimg.data(), nr, qimg.data(), nq, C.data(), usum.data())
-                 : lash_hmh_pair_counts(ctx, rimg.data(), nr, qimg.data(), nq, C.data(), N.data());
-        std::string e2 = rc == LASH_OK ? "" : std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
-        lash_ctx_destroy(ctx);
-        if (!e2.empty()) return e2;
-    }
     std::vector<double> rcard(nr), qcard(nq);
     const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which "
                            "this build does not have (sketch with a smaller -p)";
@@ -229,39 +217,60 @@ std::string run_dist(const DistOptions &opt)
     if (!out) return "cannot create " + opt.output_file;
     if (!opt.matrix) fprintf(out, "Reference\tQuery\tDistance\n");                                   // main.rs:409-412
     else for (uint32_t j = 0; j < nq; ++j) fprintf(out, "\t%s", qnames[j].c_str());                   // main.rs:439-441
-    for (uint32_t i = 0; i < nr; ++i) {
-        bool first = true;
-        for (uint32_t j = 0; j < nq; ++j) {
-            if (same_files && j > i) continue;                                                        // utils.rs:158-160
-            double sim = 0.0;
-            if (hll) {                                                                                // utils.rs:352-365
-                double u;
-                if (!hll_len(prec, hll_alpha, C[(size_t)i * nq + j], usum[(size_t)i * nq + j], u)) {
-                    fclose(out);
-                    return "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
+    // ---- GPU: the O(N_ref * N_qry * registers) scan, in blocks of reference rows so that the per-pair tables stay
+    //      bounded (all-vs-all on 10^5 sketches is 10^10 pairs) ----
+    lash_ctx *ctx = nullptr;
+    {
+        const int rc = lash_ctx_create(&ctx, opt.device);
+        if (rc != LASH_OK) { fclose(out); return lash_strerror(rc); }
+    }
+    const uint32_t rows_per_block = opt.block_rows ? std::min(opt.block_rows, std::max(nr, 1u))
+                                                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nr, (64ull << 20) / std::max<uint32_t>(nq, 1)));
+    std::vector<uint32_t> C((size_t)rows_per_block * nq), N(hll ? 0 : (size_t)rows_per_block * nq);   // hll: C = zero registers of the union
+    std::vector<double> usum(hll ? (size_t)rows_per_block * nq : 0);
+    std::string fail;
+    for (uint32_t i0 = 0; i0 < nr && fail.empty(); i0 += rows_per_block) {
+        const uint32_t i1 = std::min(nr, i0 + rows_per_block);
+        const int rc = hll ? lash_hll_pair_union_stats(ctx, prec, rimg.data() + (size_t)i0 * ib, i1 - i0, qimg.data(), nq, C.data(), usum.data())
+                           : lash_hmh_pair_counts(ctx, rimg.data() + (size_t)i0 * ib, i1 - i0, qimg.data(), nq, C.data(), N.data());
+        if (rc != LASH_OK) { fail = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx); break; }
+        for (uint32_t i = i0; i < i1 && fail.empty(); ++i) {
+            bool first = true;
+            const size_t row = (size_t)(i - i0) * nq;
+            for (uint32_t j = 0; j < nq; ++j) {
+                if (same_files && j > i) continue;                                                    // utils.rs:158-160
+                double sim = 0.0;
+                if (hll) {                                                                            // utils.rs:352-365
+                    double u;
+                    if (!hll_len(prec, hll_alpha, C[row + j], usum[row + j], u)) {
+                        fail = "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
+                        break;
+                    }
+                    sim = (rcard[i] + qcard[j] - u) / u;
+                } else {
+                    const double c = (double)C[row + j], n = (double)N[row + j];
+                    if (c != 0.0) {                                                                   // Sketch::similarity
+                        const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
+                        sim = c < ec ? 0.0 : (c - ec) / n;
+                    }
                 }
-                sim = (rcard[i] + qcard[j] - u) / u;
-            } else {
-                const double c = (double)C[(size_t)i * nq + j], n = (double)N[(size_t)i * nq + j];
-                if (c != 0.0) {                                                                       // Sketch::similarity
-                    const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
-                    sim = c < ec ? 0.0 : (c - ec) / n;
+                if (sim < 0.0) sim = 0.0;                                                             // .max(0.0), utils.rs:164,362
+                const double frac = 2.0 * sim / (1.0 + sim);                                          // utils.rs:165-167
+                double d;
+                if (qnames[j] == rnames[i]) d = 0.0;                                                  // main.rs:452-453
+                else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
+                else d = compute_distance<double>(frac, k, opt.model);
+                if (!opt.matrix) fprintf(out, "%s\t%s\t%.6f\n", rnames[i].c_str(), qnames[j].c_str(), d);
+                else {
+                    if (first) fprintf(out, "\n%s", rnames[i].c_str());
+                    fprintf(out, "\t%.6f", d);
                 }
+                first = false;
             }
-            if (sim < 0.0) sim = 0.0;                                                                 // .max(0.0), utils.rs:164,362
-            const double frac = 2.0 * sim / (1.0 + sim);                                              // utils.rs:165-167
-            double d;
-            if (qnames[j] == rnames[i]) d = 0.0;                                                      // main.rs:452-453
-            else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
-            else d = compute_distance<double>(frac, k, opt.model);
-            if (!opt.matrix) fprintf(out, "%s\t%s\t%.6f\n", rnames[i].c_str(), qnames[j].c_str(), d);
-            else {
-                if (first) fprintf(out, "\n%s", rnames[i].c_str());
-                fprintf(out, "\t%.6f", d);
-            }
-            first = false;
         }
     }
+    lash_ctx_destroy(ctx);
+    if (!fail.empty()) { fclose(out); return fail; }
     fclose(out);
     return "";
 }

@@ -11,6 +11,7 @@ struct DistOptions {
     int threads = 1;
     bool fp32 = false, matrix = false;
     int device = 0;
+    uint32_t block_rows = 0;   // reference rows per GPU call; 0 = as many as keep the pair tables under ~0.5 GB
 };
 
 std::string run_dist(const DistOptions &opt);

@@ -3,7 +3,8 @@
 //   lash sketch -f LIST [-o sketch] [-k 16] [-t N] [-a hmh|hll|ull] [-p 10] [-s 42]        (main.rs:30-96, 180-279)
 //   lash dist   -q PREFIX -r PREFIX [-o dist] [-t N] [-e fgra|ml] [-m 1|0] [--fp32] [--dm]   (main.rs:107-176, 280-617)
 // Extras that do not exist upstream: --gpus N / --device D (which GPUs to use), --batch-mb M, --stream-mb M (files
-// larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low.
+// larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low; dist: --device D, --block-rows N
+// (reference rows per GPU call).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -151,7 +152,9 @@ int cmd_dist(int argc, char **argv)
     opt.ref_prefix = a.kv["reference"];
     opt.output_file = a.kv.count("output_file") ? a.kv["output_file"] : "dist";
     opt.estimator = a.kv.count("estimator") ? a.kv["estimator"] : "fgra";
-    uint64_t model = 1, threads = std::thread::hardware_concurrency(), dev = 0;
+    uint64_t model = 1, threads = std::thread::hardware_concurrency(), dev = 0, block_rows = 0;
+    if (a.kv.count("block-rows") && !to_u64(a.kv["block-rows"], block_rows)) { fprintf(stderr, "error: invalid value for --block-rows\n"); return 2; }
+    opt.block_rows = (uint32_t)std::min<uint64_t>(block_rows, 0xFFFFFFFFull);
     if (a.kv.count("model") && !to_u64(a.kv["model"], model)) { fprintf(stderr, "error: invalid value for --model\n"); return 2; }
     if (a.kv.count("threads") && !to_u64(a.kv["threads"], threads)) { fprintf(stderr, "error: invalid value for --threads\n"); return 2; }
     if (a.kv.count("device") && !to_u64(a.kv["device"], dev)) { fprintf(stderr, "error: invalid value for --device\n"); return 2; }

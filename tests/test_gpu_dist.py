@@ -66,6 +66,10 @@ def test_lash_dist_cli_hmh(tmp_path, matrix, model, fp32):
     assert r.returncode == 0, r.stderr
     assert "Distances computed." in r.stdout
     text = (tmp_path / "d_self.txt").read_text()
+    # the same in blocks of 2 reference rows per GPU call (how 10^5 x 10^5 runs stay bounded): identical file
+    r = subprocess.run([H.CLI, "dist", "-q", "refs", "-r", "refs", "-o", "d_blk.txt", "--block-rows", "2"] + flags, cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "d_blk.txt").read_text() == text
     tol = 2e-6 if fp32 else 1.1e-6
     if not matrix:
         lines = text.strip().split("\n")
