@@ -31,11 +31,12 @@ def algorithmic_bytes_per_genome(L, image_bytes, ascii_input):
     return (L if ascii_input else (L + 3) // 4) + image_bytes
 
 
-def cpu_baseline(algo, k, p, seed, L, target_s):
-    """Times the CPU oracle (a port: the Rust reference cannot be built here) with the reference's parallel
+def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
+    """The only place bench.py touches oracle/.  Times the CPU oracle (a port: the Rust reference cannot be built here) with the reference's parallel
     structure — one task per genome, dynamic scheduling (utils.rs:450-452) — on a bounded sample of the same
     synthetic workload.  The thread count is the best of a short scan (on many-core hosts all logical cores is
-    not always the fastest); `cores` reports the threads actually used."""
+    not always the fastest); `cores` reports the threads actually used.  `check_images` {genome index: GPU image}: the
+    oracle also sketches those genomes of the GPU workload and the images must be identical (returned as the flag)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
@@ -64,12 +65,17 @@ def cpu_baseline(algo, k, p, seed, L, target_s):
         elapsed += time.perf_counter() - t0
         done += n
     kmers = done * (L - k + 1)
+    ok = True
+    for g, got in check_images.items():
+        host = O.synth_genome(first_genome + g, L)
+        want = O.sketch_genomes(algo_id, k, p, seed, host, np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
+        ok = ok and bool(np.array_equal(got, want))
     return {"value": kmers / elapsed, "unit": "k-mers/s", "cores": best, "kind": "port",
             "sample": "%d synthetic %d-bp genomes, %s k=%d, in-memory sequences (no FASTA parse), %.1f s of CPU work; "
                       "oracle/lash_oracle.c compiled -O3 for baseline x86-64, one task per genome over %d threads "
                       "(best of a scan over %s threads on %d logical cores)"
                       % (done, L, algo, k, elapsed, best, sorted(scan), ncpu),
-            "thread_scan": {str(T): v for T, v in sorted(scan.items())}}
+            "thread_scan": {str(T): v for T, v in sorted(scan.items())}}, ok
 
 
 def main():
@@ -157,6 +163,14 @@ def main():
     packed_elapsed = time.perf_counter() - tp0
     pk.free()
 
+    # oracle-free cross-check on every rank: the pack-first route (a different kernel chain) must give the same images
+    d_img2 = torch.zeros_like(d_img)
+    ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img2, flags=lash_amd.F_NO_DIRECT)
+    torch.cuda.synchronize()
+    routes_agree = bool(torch.equal(d_img, d_img2))
+    del d_img2
+    assert routes_agree, "direct and pack-first routes disagree"
+
     kmers_per_genome = L - k + 1
     kmers_step_rank = G * kmers_per_genome
     assert tm["kmers"] == kmers_step_rank * args.steps, "device k-mer census disagrees with the workload"
@@ -198,25 +212,21 @@ def main():
             "stage_ms_per_step": {"pack": tm["pack_ms"] / max(tm["calls"], 1), "sketch": stage_sketch_ms,
                                   "finalize": tm["finalize_ms"] / max(tm["calls"], 1)},
             "packed_resident_kmers_per_s_this_rank": kmers_step_rank * args.steps / packed_elapsed,   # 2-bit genomes kept in HBM
+            "routes_agree": "direct and pack-first images identical (all %d genomes of this rank)" % G,
         }
 
-    # ---- parity spot check against the CPU oracle (outside the timed region) ----
-    if rank == 0 and not args.no_parity_check:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        img = d_img.view(G, ib)
-        ok = True
-        for g in sorted({0, G // 2, G - 1}):
-            host = O.synth_genome(first + g, L)
-            want = O.sketch_genomes(lash_amd.ALGOS[algo], k, p, seed, host, np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
-            ok = ok and bool(np.array_equal(img[g].cpu().numpy(), want))
-        out["parity_vs_oracle"] = "bit-identical (3 genomes spot-checked)" if ok else "MISMATCH"
-        if not ok:
-            print(json.dumps(out))
-            raise SystemExit("parity check failed")
+    # ---- the CPU leg (rank 0, N = 1 only, outside the timed region): the oracle timed as the baseline and used as the
+    #      checker of three of the images this run produced ----
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(algo, k, p, seed, L, args.cpu_seconds)
+            img = d_img.view(G, ib)
+            check = {g: img[g].cpu().numpy() for g in sorted({0, G // 2, G - 1})} if not args.no_parity_check else {}
+            out["cpu_baseline"], ok = cpu_baseline(algo, k, p, seed, L, args.cpu_seconds, first, check)
+            if check:
+                out["parity_vs_oracle"] = "bit-identical (3 genomes spot-checked)" if ok else "MISMATCH"
+            if not ok:
+                print(json.dumps(out))
+                raise SystemExit("parity check failed")
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -7,16 +7,24 @@ D=/dev/shm/lash_e2e_$$
 mkdir -p $D && cd $D
 python3 - <<PY
 import sys
-sys.path.insert(0, "$REPO/tests")
-import oracle_lib as O
+sys.path.insert(0, "$REPO")
+import torch, lash_amd
+ctx = lash_amd.Context(0)
 names = []
-for g in range($N):
-    s = O.synth_genome(g, 5_000_000).tobytes()
-    with open("g%d.fa" % g, "wb") as f:
-        f.write(b">g%d\n" % g)
-        f.write(b"\n".join(s[i:i + 80] for i in range(0, len(s), 80)))
-        f.write(b"\n")
-    names.append("$D/g%d.fa" % g)
+L = 5_000_000
+for g0 in range(0, $N, 100):                               # the library's own generator, 100 genomes a time
+    n = min(100, $N - g0)
+    d = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    ctx.synth_genomes_device(g0, n, L, d)
+    torch.cuda.synchronize()
+    host = d.cpu().numpy()
+    for g in range(g0, g0 + n):
+        s = host[(g - g0) * L:(g - g0 + 1) * L].tobytes()
+        with open("g%d.fa" % g, "wb") as f:
+            f.write(b">g%d\n" % g)
+            f.write(b"\n".join(s[i:i + 80] for i in range(0, len(s), 80)))
+            f.write(b"\n")
+        names.append("$D/g%d.fa" % g)
 open("list.txt", "w").write("\n".join(names) + "\n")
 PY
 for T in ${THREADS:-8 32 64}; do
