@@ -133,3 +133,27 @@ def test_direct_pass_backs_off_while_batches_are_dirty():
         same(c.sketch_batch("hmh", 16, 0, 42, sc, oc, gc), want_c, "clean batch")
     assert c.timing()["direct_launches"] - tried >= 2  # back on once a probe saw a clean batch
     c.close()
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 7, 0), ("hll", 32, 10), ("ull", 17, 9)])
+def test_every_short_length_on_the_direct_pass(an, k, p):
+    """Clean genomes of every length 0..420 in one batch (so every byte alignment and every position of the genome end
+    relative to a lane's 96-byte window occurs), once as single records and once cut into two records."""
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    rng = random.Random(11)
+    base = O.synth_genome(123, 1000).tobytes()
+    gs = []
+    for n in range(421):
+        s = base[n % 7: n % 7 + n]
+        gs.append([s])
+        cut = rng.randint(0, n)
+        gs.append([s[:cut], s[cut:]])
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    assert tm["direct_launches"] == 1
+    assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+    same(got, oracle_images(an, k, p, 42, seq, off, goff), "short lengths %s k=%d" % (an, k))
+    ctx.close()
