@@ -6,15 +6,17 @@
 #include <cstdio>
 #include <cstring>
 
+#include "codec_dl.hpp"
 #include "zstd_dl.hpp"
 
 namespace lashhost {
 
 struct ByteStream::Impl {
-    int kind = 0;               // 0 plain, 1 gzip, 2 zstd
+    int kind = 0;               // 0 plain, 1 gzip, 2 zstd, 3 bzip2 / xz
     FILE *f = nullptr;
     gzFile g = nullptr;
     ZstdReader z;
+    DlDecoder d;
 };
 
 ByteStream::ByteStream() : impl_(new Impl()) {}
@@ -39,9 +41,9 @@ std::string ByteStream::open(const std::string &path)
         impl_->kind = 1;
         return "";
     }
-    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') { fclose(f); return "Invalid input file: bzip2 input is not supported by this build (" + path + ")"; }
-    if (got >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) { fclose(f); return "Invalid input file: xz input is not supported by this build (" + path + ")"; }
     rewind(f);
+    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') { impl_->kind = 3; return impl_->d.open(f, Codec::BZIP2); }
+    if (got >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) { impl_->kind = 3; return impl_->d.open(f, Codec::XZ); }
     if (got >= 4 && m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) {
         impl_->kind = 2;
         return impl_->z.open(f);
@@ -54,6 +56,7 @@ long ByteStream::read(uint8_t *dst, size_t n, std::string &err)
 {
     if (impl_->kind == 0) return (long)fread(dst, 1, n, impl_->f);
     if (impl_->kind == 2) return impl_->z.read(dst, n, err);
+    if (impl_->kind == 3) return impl_->d.read(dst, n, err);
     size_t done = 0;
     while (done < n) {
         const int r = gzread(impl_->g, dst + done, (unsigned)std::min<size_t>(n - done, 1u << 30));
@@ -98,10 +101,22 @@ std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t>
         std::string err = zstd_decompress_all(raw.data(), raw.size(), out);
         return err.empty() ? "" : "Invalid input file: " + err + " (" + path + ")";
     }
-    if (got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h')
-        return "Invalid input file: bzip2 input is not supported by this build (" + path + ")";
-    if (got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z' && magic[5] == 0)
-        return "Invalid input file: xz input is not supported by this build (" + path + ")";
+    const bool bz = got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h';
+    const bool xz = got >= 6 && magic[0] == 0xfd && magic[1] == '7' && magic[2] == 'z' && magic[3] == 'X' && magic[4] == 'Z' && magic[5] == 0;
+    if (bz || xz) {
+        std::vector<uint8_t>().swap(raw);
+        ByteStream bs;
+        std::string err = bs.open(path);
+        if (!err.empty()) return err;
+        std::vector<uint8_t> buf(1 << 22);
+        for (;;) {
+            const long n = bs.read(buf.data(), buf.size(), err);
+            if (n < 0) return err + " (" + path + ")";
+            if (n == 0) break;
+            out.insert(out.end(), buf.begin(), buf.begin() + n);
+        }
+        return "";
+    }
     out.swap(raw);
     return "";
 }

@@ -1,7 +1,7 @@
 // fastx.hpp — FASTA/FASTQ record reader for the host side of lash-gfx950 (replaces needletail::parse_fastx_file,
 // /root/reference/src/utils.rs:453-459; semantics per SURVEY.md App. A.5).
-//   * compression is sniffed from magic bytes: gzip (zlib), zstd (dlopen'd libzstd), plain; bzip2 / xz are reported
-//     as unsupported (the image has no headers for them);
+//   * compression is sniffed from magic bytes like needletail does: gzip (zlib), bzip2 and xz (dlopen'd libbz2 /
+//     liblzma, codec_dl.hpp), zstd (dlopen'd libzstd), plain;
 //   * '>' => FASTA: header line, then sequence lines up to the next '>' with '\n' and '\r' stripped;
 //     '@' => FASTQ: 4-line records, the sequence is line 2;
 //   * seq() bytes are appended UNFILTERED: deleting non-ACGT bytes is the pack kernel's job (utils.rs:459 -> 33-41).
@@ -26,7 +26,7 @@ std::string read_fastx_file(const std::string &path, RecordBatch &out);
 // Parses an in-memory (already decompressed) FASTA/FASTQ buffer.
 std::string parse_fastx_buffer(const uint8_t *data, size_t n, RecordBatch &out);
 
-// Sequential reader of a file's uncompressed bytes (plain, gzip via zlib, zstd via the dlopen'd streaming API): the
+// Sequential reader of a file's uncompressed bytes (plain, gzip via zlib, bzip2 / xz / zstd via dlopen'd libraries): the
 // large-file path streams chunks through it instead of holding a whole metagenome in memory.
 class ByteStream {
 public:
@@ -40,7 +40,7 @@ private:
     Impl *impl_;
 };
 
-// Whole file into memory, transparently inflating gzip / zstd.
+// Whole file into memory, transparently inflating gzip / bzip2 / xz / zstd.
 std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t> &out);
 
 }  // namespace lashhost

@@ -145,7 +145,7 @@ bool peek_compressed(const std::string &path, uint64_t &size, std::string &err)
     fclose(f);
     if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) return true;
     if (got >= 4 && m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) return true;
-    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') return true;               // reported as unsupported by slurp
+    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') return true;
     if (got >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) return true;
     return false;
 }

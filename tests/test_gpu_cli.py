@@ -76,6 +76,12 @@ def test_large_files_are_streamed_in_chunks(tmp_path):
     with gzip.open(tmp_path / "reads.fq.gz", "wb", compresslevel=1) as g:
         g.write(fq)
     paths.append(str(tmp_path / "reads.fq.gz"))
+    import bz2
+    import lzma
+    (tmp_path / "big.fa.bz2").write_bytes(bz2.compress(fa, 1))            # streamed (large once inflated)
+    (tmp_path / "small1.fa.xz").write_bytes(lzma.compress(small, format=lzma.FORMAT_XZ, preset=1))   # batch path
+    (tmp_path / "reads.fq.xz").write_bytes(lzma.compress(fq, format=lzma.FORMAT_XZ, preset=0))
+    paths += [str(tmp_path / "big.fa.bz2"), str(tmp_path / "small1.fa.xz"), str(tmp_path / "reads.fq.xz")]
     lst = tmp_path / "l.txt"
     lst.write_text("\n".join(paths) + "\n")
     for algo, k, p in (("hmh", 16, 10), ("ull", 21, 12)):
@@ -87,7 +93,7 @@ def test_large_files_are_streamed_in_chunks(tmp_path):
         ib = O.image_bytes(ALGO[algo], p)
         assert len(blob) == ib * len(paths)
         for i, path in enumerate(paths):
-            src = path[:-3] if path.endswith(".gz") else path
+            src = path.rsplit(".", 1)[0] if path.endswith((".gz", ".bz2", ".xz")) else path
             recs = read_fastx(src)
             seq = np.frombuffer(b"".join(recs), np.uint8)
             off = np.cumsum([0] + [len(x) for x in recs]).astype(np.uint64)

@@ -1,6 +1,8 @@
 """CPU tests of the C++ host side (lash_amd/csrc/host): FASTX reader, list-file rules, JSON writers, zstd stream,
 and the `lash` command line's behaviour without a GPU."""
+import bz2
 import gzip
+import lzma
 import json
 import os
 import subprocess
@@ -27,6 +29,35 @@ def test_fastx_reader_matches_needletail_semantics(name, tmp_path):
     zs = tmp_path / (name + ".zst")
     H.zstd_write(str(zs), open(path, "rb").read())
     assert H.read_fastx(str(zs)) == want
+    raw = open(path, "rb").read()
+    bz = tmp_path / (name + ".bz2")                      # needletail's default features also inflate bzip2 and xz
+    bz.write_bytes(bz2.compress(raw))
+    assert H.read_fastx(str(bz)) == want
+    xz = tmp_path / (name + ".xz")
+    xz.write_bytes(lzma.compress(raw, format=lzma.FORMAT_XZ))
+    assert H.read_fastx(str(xz)) == want
+
+
+def test_bzip2_and_xz_streams_large_concatenated_and_corrupt(tmp_path):
+    rec = b">r%d\n" + b"ACGTTGCA" * 4000 + b"\n"
+    parts = [rec % i for i in range(40)]                  # 1.3 MB: several refills of the 1 MiB input buffer
+    want = [b"ACGTTGCA" * 4000] * 40
+    p = tmp_path / "m.fa.bz2"
+    p.write_bytes(b"".join(bz2.compress(b"".join(parts[i:i + 10])) for i in range(0, 40, 10)))   # 4 concatenated streams
+    assert H.read_fastx(str(p)) == want
+    p = tmp_path / "m.fa.xz"
+    p.write_bytes(b"".join(lzma.compress(b"".join(parts[i:i + 20]), format=lzma.FORMAT_XZ) for i in range(0, 40, 20)))
+    assert H.read_fastx(str(p)) == want
+    good = bz2.compress(b"".join(parts))
+    p = tmp_path / "t.fa.bz2"
+    p.write_bytes(good[:len(good) // 2])
+    with pytest.raises(ValueError, match="bzip2"):
+        H.read_fastx(str(p))
+    good = lzma.compress(b"".join(parts), format=lzma.FORMAT_XZ)
+    p = tmp_path / "t.fa.xz"
+    p.write_bytes(good[:len(good) // 2] + b"\x00" * 64)
+    with pytest.raises(ValueError, match="xz"):
+        H.read_fastx(str(p))
 
 
 def test_fastx_reader_edge_cases(tmp_path):
