@@ -42,3 +42,23 @@ def gather_images(local_images, counts, group=None):
     dist.all_gather_into_tensor(out, padded, group=group)
     parts = [out[r * cmax:r * cmax + counts[r]] for r in range(world)]
     return torch.cat(parts, dim=0) if parts else out[:0]
+
+
+def merge_partial_images(local_images, merge_into, group=None):
+    """One huge input cut into positional chunks over the ranks (BASELINE configs[4]): every rank holds
+    PARTIAL sketches [n, image_bytes] of the same n inputs.  All ranks end with the union.
+
+    The union is not always an elementwise max (UltraLogLog's packed registers, the HyperLogLog header), so instead of an
+    all-reduce the partial images are all-gathered — world_size x n x image_bytes, a few MB — and folded in rank order with
+    `merge_into(dst, src)`, the caller's binding of `lash_merge_images[_device]` (Sketch::union / HyperLogLog::union /
+    UltraLogLog::merge, utils.rs:171,261,357).  max / OR are commutative and idempotent: every rank gets identical bytes."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n, ib = local_images.shape
+    out = torch.empty((world * n, ib), dtype=torch.uint8, device=local_images.device)
+    dist.all_gather_into_tensor(out, local_images.contiguous(), group=group)
+    acc = out[:n].clone()
+    for r in range(1, world):
+        merge_into(acc, out[r * n:(r + 1) * n])
+    return acc

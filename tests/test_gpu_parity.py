@@ -261,3 +261,36 @@ def test_kmer_census_with_messy_records(ctx):
         ctx.sketch_batch("hmh", k, 0, 42, seq, off, goff)
         assert ctx.timing()["kmers"] == want, k
     ctx.enable_timing(False)
+
+
+def test_partial_sketches_of_one_input_merge_across_ranks():
+    """configs[4] shape on the GPU path: two halves of a read set sketched separately (as two ranks would), all-gathered
+    over RCCL (world_size 1 here: one GPU per box) and folded with lash_merge_images_device == the sketch of the whole."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import lash_amd
+    from lash_amd.shard import merge_partial_images
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        c = lash_amd.Context(0, stream=torch.cuda.current_stream())
+        g = O.synth_genome(55, 600_000).tobytes()
+        reads = [g[i:i + 150] for i in range(0, len(g) - 150, 97)]
+        half = len(reads) // 2
+        for an, k, p in (("hmh", 16, 0), ("hll", 21, 12), ("ull", 16, 11)):
+            parts = []
+            for chunk in (reads[:half], reads[half:]):
+                seq, off, goff = lash_amd.records_to_arrays([chunk])
+                parts.append(torch.from_numpy(c.sketch_batch(an, k, p, 42, seq, off, goff)).cuda())
+            ib = parts[0].shape[1]
+            merged = merge_partial_images(parts[0], lambda d, s_: c.merge_images_device(an, p, d, s_, d.shape[0]))
+            c.merge_images_device(an, p, merged, parts[1], 1)           # the "other rank's" partial
+            torch.cuda.synchronize()
+            seq, off, goff = lash_amd.records_to_arrays([reads])
+            assert_same(merged.cpu().numpy(), oracle_images(ALGO[an], k, p, 42, seq, off, goff), "merged " + an)
+        c.close()
+    finally:
+        dist.destroy_process_group()

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lash_amd.shard import gather_images, shard_genomes
+from lash_amd.shard import gather_images, merge_partial_images, shard_genomes
 
 
 def test_shard_genomes_properties():
@@ -68,6 +68,44 @@ def test_gather_images_in_file_order_gloo(world, lens):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, lens, 257, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert all(res[r] for r in range(world)), res
+
+
+def _hmh_union_cpu(dst, src):
+    # test stand-in for lash_merge_images on HyperMinHash images: register-wise max of the u16 registers
+    a = dst.numpy().view(np.uint16)
+    np.maximum(a, src.numpy().view(np.uint16), out=a)
+
+
+def _merge_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(100 + rank)
+        local = torch.from_numpy(rng.integers(0, 60000, size=(3, 64), dtype=np.uint16).view(np.uint8).copy())
+        merged = merge_partial_images(local, _hmh_union_cpu)
+        want = np.zeros((3, 64), np.uint16)
+        for r in range(world):
+            want = np.maximum(want, np.random.default_rng(100 + r).integers(0, 60000, size=(3, 64), dtype=np.uint16))
+        q.put((rank, bool(np.array_equal(merged.numpy().view(np.uint16), want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_merge_partial_images_gloo(world):
+    """configs[4] shape: every rank sketched a different chunk of the same inputs; all ranks end with the union."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_merge_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
