@@ -18,12 +18,14 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <thread>
 #include <vector>
 
 #include "../../../include/lash_gfx950.h"
@@ -91,7 +93,7 @@ double hmh_cardinality(const uint8_t *img)
         const uint32_t reg = img[2 * i] | (img[2 * i + 1] << 8);
         const uint32_t lz = reg >> (16 - HQ);
         if (lz == 0) ez += 1.0;
-        sum += 1.0 / std::pow(2.0, (double)lz);
+        sum += std::ldexp(1.0, -(int)lz);                       // == 1 / 2^lz exactly
     }
     const double m = (double)HM;
     const double alpha = 0.7213 / (1.0 + 1.079 / m);
@@ -201,16 +203,29 @@ std::string run_dist(const DistOptions &opt)
     std::vector<double> rcard(nr), qcard(nq);
     const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which "
                            "this build does not have (sketch with a smaller -p)";
-    for (uint32_t i = 0; i < nr; ++i) {
-        const uint8_t *im = rimg.data() + i * ib;
-        if (!hll) rcard[i] = hmh_cardinality(im);
-        else if (!hll_len(prec, rd_f64(im), rd_u64(im + 8), rd_f64(im + 16), rcard[i])) return rnames[i] + bias_msg;   // utils.rs:314-315
-    }
-    for (uint32_t j = 0; j < nq; ++j) {
-        const uint8_t *im = qimg.data() + j * ib;
-        if (!hll) qcard[j] = hmh_cardinality(im);
-        else if (!hll_len(prec, rd_f64(im), rd_u64(im + 8), rd_f64(im + 16), qcard[j])) return qnames[j] + bias_msg;
-    }
+    // per-sketch cardinalities (utils.rs:101-103, 314-315), on `-t` host threads
+    auto cards = [&](const std::vector<uint8_t> &img, const std::vector<std::string> &names, std::vector<double> &card) -> std::string {
+        const uint32_t n = (uint32_t)names.size();
+        std::vector<uint8_t> bad(n, 0);
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+                const uint8_t *im = img.data() + (size_t)i * ib;
+                if (!hll) card[i] = hmh_cardinality(im);
+                else if (!hll_len(prec, rd_f64(im), rd_u64(im + 8), rd_f64(im + 16), card[i])) bad[i] = 1;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < std::min<int>(opt.threads, (int)n); ++t) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        for (uint32_t i = 0; i < n; ++i)
+            if (bad[i]) return names[i] + bias_msg;
+        return "";
+    };
+    if (!(err = cards(rimg, rnames, rcard)).empty()) return err;
+    if (same_files && rf["sketches"] == qf["sketches"]) qcard = rcard;
+    else if (!(err = cards(qimg, qnames, qcard)).empty()) return err;
     const double hll_alpha = hll && nr ? rd_f64(rimg.data()) : 0.0;
 
     FILE *out = fopen(opt.output_file.c_str(), "w");
@@ -234,7 +249,12 @@ std::string run_dist(const DistOptions &opt)
         const int rc = hll ? lash_hll_pair_union_stats(ctx, prec, rimg.data() + (size_t)i0 * ib, i1 - i0, qimg.data(), nq, C.data(), usum.data())
                            : lash_hmh_pair_counts(ctx, rimg.data() + (size_t)i0 * ib, i1 - i0, qimg.data(), nq, C.data(), N.data());
         if (rc != LASH_OK) { fail = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx); break; }
-        for (uint32_t i = i0; i < i1 && fail.empty(); ++i) {
+        // rows of the block are formatted by `-t` host threads (the reference's par_iter over reference sketches,
+        // utils.rs:146,336), then written in file order
+        std::vector<std::string> row_text(i1 - i0), row_fail(i1 - i0);
+        auto do_row = [&](uint32_t i) {
+            std::string &txt = row_text[i - i0];
+            char buf[64];
             bool first = true;
             const size_t row = (size_t)(i - i0) * nq;
             for (uint32_t j = 0; j < nq; ++j) {
@@ -243,8 +263,8 @@ std::string run_dist(const DistOptions &opt)
                 if (hll) {                                                                            // utils.rs:352-365
                     double u;
                     if (!hll_len(prec, hll_alpha, C[row + j], usum[row + j], u)) {
-                        fail = "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
-                        break;
+                        row_fail[i - i0] = "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
+                        return;
                     }
                     sim = (rcard[i] + qcard[j] - u) / u;
                 } else {
@@ -260,13 +280,30 @@ std::string run_dist(const DistOptions &opt)
                 if (qnames[j] == rnames[i]) d = 0.0;                                                  // main.rs:452-453
                 else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
                 else d = compute_distance<double>(frac, k, opt.model);
-                if (!opt.matrix) fprintf(out, "%s\t%s\t%.6f\n", rnames[i].c_str(), qnames[j].c_str(), d);
-                else {
-                    if (first) fprintf(out, "\n%s", rnames[i].c_str());
-                    fprintf(out, "\t%.6f", d);
+                if (!opt.matrix) {
+                    txt += rnames[i]; txt += '\t'; txt += qnames[j];
+                    snprintf(buf, sizeof buf, "\t%.6f\n", d);
+                    txt += buf;
+                } else {
+                    if (first) { txt += '\n'; txt += rnames[i]; }
+                    snprintf(buf, sizeof buf, "\t%.6f", d);
+                    txt += buf;
                 }
                 first = false;
             }
+        };
+        {
+            const uint32_t nthreads = (uint32_t)std::max(1, std::min<int>(opt.threads, (int)(i1 - i0)));
+            std::atomic<uint32_t> next{i0};
+            std::vector<std::thread> pool;
+            auto work = [&]() { for (uint32_t i = next.fetch_add(1); i < i1; i = next.fetch_add(1)) do_row(i); };
+            for (uint32_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+            work();
+            for (auto &t : pool) t.join();
+        }
+        for (uint32_t i = i0; i < i1; ++i) {
+            if (!row_fail[i - i0].empty()) { fail = row_fail[i - i0]; break; }
+            fwrite(row_text[i - i0].data(), 1, row_text[i - i0].size(), out);
         }
     }
     lash_ctx_destroy(ctx);
