@@ -61,7 +61,9 @@ typedef struct {
 
 /* Sums over every sketch call since lash_ctx_enable_timing(ctx, 1) (HIP events on the ctx stream). */
 typedef struct {
-    float    pack_ms;           /* ASCII -> 2-bit + record-break bitmap (incl. the small table uploads)   */
+    float    pack_ms;           /* ASCII -> 2-bit + record-break bitmap (incl. the small table uploads); calls
+                                   that took the direct route spend nothing here: their dirty-genome pack is
+                                   queued behind the direct pass and counted in sketch_ms */
     float    sketch_ms;         /* k-mer / xxh3 / register-update kernels (direct pass + dirty-genome fallback) */
     float    finalize_ms;       /* partial-sketch reduction + byte images                                  */
     uint32_t calls;             /* sketch calls summed                                                     */
