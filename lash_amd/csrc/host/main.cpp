@@ -2,7 +2,7 @@
 // (/root/reference/src/main.rs:26-177) on top of liblash_gfx950.so.
 //   lash sketch -f LIST [-o sketch] [-k 16] [-t N] [-a hmh|hll|ull] [-p 10] [-s 42]        (main.rs:30-96, 180-279)
 //   lash dist   -q PREFIX -r PREFIX [-o dist] [-t N] [-e fgra|ml] [-m 1|0] [--fp32] [--dm]   (main.rs:107-176, 280-617)
-// Extras that do not exist upstream: --gpus N / --device D (which GPUs to use), --batch-mb M, --stream-mb M (files
+// Extras that do not exist upstream: --gpus N / --device D / --devices LIST (which GPUs to use, one worker each), --batch-mb M, --stream-mb M (files
 // larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low; dist: --device D, --block-rows N
 // (reference rows per GPU call).
 #include <chrono>
@@ -44,7 +44,7 @@ void usage()
             "  -a, --algorithm <algorithm>  HyperMinHash (hmh), UltraLogLog (ull), or HyperLogLog (hll) [default: hmh]\n"
             "  -p, --precision <precision>  Specifiy precision, for ull and hll only. [default: 10]\n"
             "  -s, --seed <seed>            Random seed [default: 42]\n"
-            "      --gpus <n> | --device <d>  GPUs to use [default: device 0]\n"
+            "      --gpus <n> | --device <d> | --devices <d,d,...>  GPUs to use, one worker each [default: device 0]\n"
             "dist options:\n"
             "  -q, --query <prefix>  -r, --reference <prefix>  -o, --output_file <name> [default: dist]\n"
             "  -t, --threads <n>  -e, --estimator <fgra|ml>  -m, --model <1|0>  --fp32  --dm\n");
@@ -120,7 +120,18 @@ int cmd_sketch(int argc, char **argv)
     opt.batch_bytes = std::max<uint64_t>(1, batch_mb) << 20;
     opt.stream_bytes = std::max<uint64_t>(1, stream_mb) << 20;
     opt.flags = a.flags.count("hmh-x-low") ? LASH_F_HMH_X_LOW : 0;
-    if (gpus > 0) for (uint64_t d = 0; d < gpus; ++d) opt.devices.push_back((int)d);
+    if (a.kv.count("devices")) {                              // explicit worker list, e.g. 0,1,2,3 (repeats allowed: 0,0 = two workers on GPU 0)
+        const std::string &l = a.kv["devices"];
+        size_t at = 0;
+        while (at <= l.size()) {
+            const size_t c = l.find(',', at);
+            uint64_t d = 0;
+            if (!to_u64(l.substr(at, c == std::string::npos ? std::string::npos : c - at), d)) { fprintf(stderr, "error: invalid value for --devices\n"); return 2; }
+            opt.devices.push_back((int)d);
+            if (c == std::string::npos) break;
+            at = c + 1;
+        }
+    } else if (gpus > 0) for (uint64_t d = 0; d < gpus; ++d) opt.devices.push_back((int)d);
     else opt.devices.push_back((int)dev);
 
     std::vector<std::string> files;

@@ -18,7 +18,10 @@ ALGO = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}
 
 
 @pytest.mark.parametrize("algo,k,p,extra", [("hmh", 16, 10, []), ("hll", 21, 14, []), ("ull", 16, 12, ["--batch-mb", "1"]),
-                                            ("hmh", 11, 10, ["-t", "3", "--batch-mb", "1"])])
+                                            ("hmh", 11, 10, ["-t", "3", "--batch-mb", "1"]),
+                                            # the multi-GPU path: three workers (here all on GPU 0) finish batches out of
+                                            # order, the writer must still emit images in file order
+                                            ("ull", 19, 11, ["--devices", "0,0,0", "--batch-mb", "1"])])
 def test_lash_sketch_cli_outputs(tmp_path, algo, k, p, extra):
     names = ["fixture_A.fasta", "fixture_B.fasta", "fixture_C.fasta", "fixture_B40.fastq", "fixture_A.fasta"]
     paths = [os.path.join(GOLD, n) for n in names]
@@ -86,8 +89,9 @@ def test_large_files_are_streamed_in_chunks(tmp_path):
     lst.write_text("\n".join(paths) + "\n")
     for algo, k, p in (("hmh", 16, 10), ("ull", 21, 12)):
         out = str(tmp_path / ("big_" + algo))
+        workers = ["--devices", "0,0"] if algo == "ull" else []        # two GPU workers: batches finish out of order
         r = subprocess.run([H.CLI, "sketch", "-f", str(lst), "-o", out, "-a", algo, "-k", str(k), "-p", str(p),
-                            "--stream-mb", "2", "--batch-mb", "1", "-t", "4"], capture_output=True, text=True)
+                            "--stream-mb", "2", "--batch-mb", "1", "-t", "4"] + workers, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         blob = H.zstd_read(out + "_sketches.bin")
         ib = O.image_bytes(ALGO[algo], p)
