@@ -414,7 +414,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         const uint64_t per = (((nw + ns - 1) / ns) + 3) & ~3ull;
         uint32_t s = 0;
         for (uint64_t b = 0; b < nw; b += per, ++s)
-            items.push_back(WorkItem{g, (uint32_t)b, (uint32_t)std::min(nw, b + per), s});
+            for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)                   // slice index | pass << 16
+                items.push_back(WorkItem{g, (uint32_t)b, (uint32_t)std::min(nw, b + per), (s & 0xFFFFu) | (part << 16)});
     }
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
@@ -484,7 +485,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     sa.safe = static_cast<const uint8_t *>(ctx->counter.ptr) + 128;
     sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
     sa.partial_stride = plan.partial_stride;
-    sa.nreg32 = plan.nreg32;
+    sa.nreg32 = plan.nreg32 >> plan.parts_log2;                 // register words of one pass
     sa.k = prm->k;
     sa.p = prm->p;
     if (pk->direct) {
@@ -519,6 +520,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.p = prm->p;
     fa.k = prm->k;
     fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
+    fa.parts_log2 = plan.parts_log2;
     HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
     if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
     TRACE("finalize: launched");

@@ -27,7 +27,7 @@ struct WorkItem {
     uint32_t genome;
     uint32_t word_begin;  // slice = packed words [word_begin, word_end) of the genome, multiples of 4
     uint32_t word_end;
-    uint32_t slice;       // slice index inside the genome
+    uint32_t slice;       // bits 15:0 slice index inside the genome; bits 31:16 which bucket-space pass (LdsPartRegs)
 };
 
 constexpr int      PAD_WORDS        = 8;       // readable slack after every genome (look-ahead words)

@@ -38,6 +38,7 @@ struct SketchPlan {
     uint32_t threads;             // 512 (<= 64 KiB of LDS, two workgroups per CU) or 1024
     uint32_t lds_bytes;
     uint32_t nreg32;
+    uint32_t parts_log2;          // > 0: the bucket space is covered in 2^parts_log2 passes, nreg32 / lds_bytes are per pass
     uint32_t partial_bytes;       // bytes of one partial sketch (register array only)
     uint32_t partial_stride;      // rounded up to 16
 };
@@ -63,6 +64,7 @@ struct FinalizeArgs {
     uint64_t        alpha_bits;          // HLL alpha as f64 bits
     int             algo, p, k;
     int             accumulate;          // union into the registers already in images[]
+    uint32_t        parts_log2;          // see SketchPlan: a partial holds only the registers of its item's pass
 };
 hipError_t launch_finalize(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream);
 

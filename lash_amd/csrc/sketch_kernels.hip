@@ -61,6 +61,26 @@ struct GlobalRegs {
     static __device__ __forceinline__ void lds_wait() {}
 };
 
+// A register table larger than 128 KiB of LDS but no more than 16 times that (HLL p=16; ULL p=15..18) is covered in
+// 2..16 PASSES over the slice: each pass (its own work item) owns one contiguous 1/2^lp of the bucket space in a 128 KiB
+// LDS table and drops the updates of the other buckets (value 0: max / OR no-ops).  Hashing every k-mer 2^lp times
+// still beats per-k-mer global atomics (HLL p=16: 2.7e10 -> 3e11 k-mers/s).  Indices are register-word indices of the
+// FULL table; the part is their top lp bits.
+struct LdsPartRegs {
+    uint32_t *base;
+    uint32_t local_mask;      // (words per part) - 1
+    uint32_t part_shift;      // log2(words per part)
+    uint32_t part;
+    __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const
+    { asm volatile("ds_max_u32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : 0u) : "memory"); }
+    __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const
+    { asm volatile("ds_or_b32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : 0u) : "memory"); }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i]; }       // i: local word index
+    static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+};
+
+enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_LDS_PARTS = 2 };
+
 // ------------------------------------------------------------------------------------------------------------
 // the three add_kmer rules.  `vm` is 0 or ~0: invalid k-mers degrade to max(x,0) / OR 0.
 //
@@ -266,7 +286,7 @@ __device__ __forceinline__ uint32_t ascii16_slow(const uint8_t *gseq, uint64_t o
     return (uint32_t)r;
 }
 
-template <int ALGO, int KMODE, bool XLOW, bool USE_LDS, bool DIRECT>
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT>
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
     // dynamic LDS: [nreg32 register words][16 words of per-wave census]; registers start at LDS offset 0 so the
@@ -281,12 +301,20 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint64_t nk = L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0;     // k-mer start positions of the genome
     if ((uint64_t)it.word_begin * 16 >= nk) return;                       // slice beyond the surviving bases
 
-    using Regs = typename std::conditional<USE_LDS, LdsRegs, GlobalRegs>::type;
+    constexpr bool USE_LDS = REGS != REGS_GLOBAL;
+    using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type;
     Regs regs;
     uint32_t *census;
+    const uint32_t part = it.slice >> 16;                                  // REGS_LDS_PARTS: which 1/2^lp of the buckets
     if constexpr (USE_LDS) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
+        if constexpr (REGS == REGS_LDS_PARTS) {
+            regs.local_mask = a.nreg32 - 1u;                               // a.nreg32: words of ONE part (a power of two)
+            regs.part_shift = 31u - (uint32_t)__builtin_clz(a.nreg32);
+            regs.part = part;
+        }
         census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
     } else {
@@ -421,7 +449,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     if (threadIdx.x == 0) {
         unsigned long long tot = 0;
         for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) tot += census[i];
-        a.item_kmers[blockIdx.x] = (uint32_t)tot;          // a slice holds < 2^32 positions; summed by finalize_kernel
+        a.item_kmers[blockIdx.x] = part == 0u ? (uint32_t)tot : 0u;   // < 2^32 per slice; summed by finalize_kernel (the
+                                                                      // passes of one slice count the same k-mers: once)
     }
 
     // flush the partial sketch in image register format (u16 LE for HMH, u8 for HLL / ULL)
@@ -430,11 +459,13 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
             out[i] = regs.get(2 * i) | (regs.get(2 * i + 1) << 16);
     } else if constexpr (ALGO == 1) {
-        const uint32_t nw = (1u << p) >> 2;
+        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
+        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
         for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
             out[i] = regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24);
     } else {
-        const uint32_t nw = (1u << p) >> 2;
+        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
+        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
         for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
             uint32_t o = 0;
 #pragma unroll
@@ -530,8 +561,10 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
 
     for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
         uint32_t acc = a.accumulate ? load_u32_any(img + hdr + 4ull * wi) : 0u;
+        const uint32_t part = a.parts_log2 ? wi / (nwords >> a.parts_log2) : 0u;   // whose pass wrote this word
         for (uint32_t it = i0; it < i1; ++it) {
             if ((uint64_t)a.items[it].word_begin * 16 >= nk) continue;     // slice never ran (see sketch_kernel)
+            if (a.parts_log2 && (a.items[it].slice >> 16) != part) continue;
             const uint8_t *src = a.partials + (uint64_t)it * a.partial_stride + a.partial_base_off;
             acc = merge_word<ALGO>(acc, load_u32_any(src + 4ull * wi));
         }
@@ -584,7 +617,11 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     else { s.nreg32 = 2u << p; s.partial_bytes = 1u << p; }
     s.partial_stride = (s.partial_bytes + 15u) & ~15u;
     s.lds_bytes = s.nreg32 * 4u;
-    s.use_lds = s.lds_bytes <= 128u * 1024u;
+    s.parts_log2 = 0;
+    while ((s.lds_bytes >> s.parts_log2) > 128u * 1024u) ++s.parts_log2;   // bucket-partitioned passes (LdsPartRegs)
+    s.use_lds = s.parts_log2 <= 4u;
+    if (!s.use_lds) s.parts_log2 = 0;
+    s.lds_bytes >>= s.parts_log2;
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU
     if (const char *e = getenv("LASH_SKETCH_THREADS")) {                    // tuning knob (tools/)
         const int t = atoi(e);
@@ -595,10 +632,10 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     return s;
 }
 
-template <int ALGO, int KMODE, bool XLOW, bool USE_LDS, bool DIRECT>
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
-    auto kern = sketch_kernel<ALGO, KMODE, XLOW, USE_LDS, DIRECT>;
+    auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT>;
     if (plan.lds_bytes > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
@@ -612,14 +649,21 @@ template <int ALGO, bool XLOW, bool DIRECT>
 static hipError_t launch_kmode(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
-    if (plan.use_lds) {
-        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, true, DIRECT>(plan, args, n, s);
-        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, true, DIRECT>(plan, args, n, s);
-        return launch_one<ALGO, KM_GT16, XLOW, true, DIRECT>(plan, args, n, s);
+    if constexpr (ALGO != 0) {                                  // HMH's table always fits
+        if (plan.use_lds && plan.parts_log2) {
+            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS_PARTS, DIRECT>(plan, args, n, s);
+            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS_PARTS, DIRECT>(plan, args, n, s);
+            return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS_PARTS, DIRECT>(plan, args, n, s);
+        }
     }
-    if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, false, DIRECT>(plan, args, n, s);
-    if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, false, DIRECT>(plan, args, n, s);
-    return launch_one<ALGO, KM_GT16, XLOW, false, DIRECT>(plan, args, n, s);
+    if (plan.use_lds) {
+        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
+        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
+        return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
+    }
+    if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
+    if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
+    return launch_one<ALGO, KM_GT16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
 }
 
 template <bool DIRECT>

@@ -151,13 +151,22 @@ def test_short_reads_fastq_like(ctx):
         assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), oracle_images(ALGO[an], k, p, 42, seq, off, goff), an)
 
 
-@pytest.mark.parametrize("an,k,p", [("hll", 16, 16), ("ull", 16, 15), ("ull", 21, 18), ("ull", 9, 20)])
-def test_global_register_variant(ctx, an, k, p):
-    """2^p registers that do not fit in LDS live in HBM/L2 and are updated with global atomics."""
+@pytest.mark.parametrize("an,k,p", [("hll", 16, 16), ("hll", 25, 16), ("ull", 16, 15), ("ull", 12, 16), ("ull", 21, 17),
+                                    ("ull", 21, 18), ("ull", 9, 19), ("ull", 16, 20), ("ull", 30, 21)])
+def test_register_tables_larger_than_lds(ctx, an, k, p):
+    """2^p registers beyond 128 KiB of LDS: up to 16x that (hll p=16, ull p=15..18) the bucket space is covered in 2..16
+    passes with a 128 KiB LDS table each; larger tables (ull p>=19) live in HBM/L2 and take global atomics.  Multi-record,
+    multi-slice, dirty and empty genomes, through the direct route and the pack-first route."""
     import lash_amd
-    gs = [[O.synth_genome(7, 200_000).tobytes()], [b"ACGTNACGT" * 50], []]
+    g = O.synth_genome(8, 1_300_000)
+    gs = [[O.synth_genome(7, 200_000).tobytes()], [b"ACGTNACGT" * 50], [], [g[:700_000].tobytes(), g[700_000:].tobytes()]]
     seq, off, goff = lash_amd.records_to_arrays(gs)
-    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), oracle_images(ALGO[an], k, p, 42, seq, off, goff), an)
+    want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
+    ctx.enable_timing(True)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), want, an)
+    assert ctx.timing()["kmers"] == sum(len(O.record_kmers(r, k)) for g_ in gs for r in g_)
+    ctx.enable_timing(False)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, an + " pack-first")
 
 
 def test_parameter_errors_mirror_reference_panics(ctx):
