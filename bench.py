@@ -131,6 +131,10 @@ def main():
     def step():
         ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img)
 
+    # the GPU's clocks take some tens of milliseconds of load to settle after idle (the first launches run 6.4 ms, later
+    # ones 5.2): a fixed untimed pre-heat, then the W warm-up steps the caller asked for, then exactly K timed steps
+    for _ in range(12):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
