@@ -628,6 +628,10 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
         if (t == 256 || t == 512 || t == 1024) s.threads = (uint32_t)t;
     }
     if (!s.use_lds) s.lds_bytes = 0;
+    // Small tables (hll p<=13, ull p<=12) would let 4 workgroups = 8 waves/SIMD share a CU; the kernel is VALU-issue
+    // bound and the extra waves only add LDS-atomic contention (hll p=13: 7.4e11 vs 8.1e11 k-mers/s).  Asking for 64 KiB
+    // keeps it at the two workgroups per CU that the 64 KiB tables get.
+    else if (s.threads == 512u && s.lds_bytes < 64u * 1024u) s.lds_bytes = 64u * 1024u;
     s.lds_bytes += 64u;                                                    // per-wave census words after the registers
     return s;
 }
