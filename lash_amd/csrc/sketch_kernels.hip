@@ -625,7 +625,7 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU
     if (const char *e = getenv("LASH_SKETCH_THREADS")) {                    // tuning knob (tools/)
         const int t = atoi(e);
-        if (t == 256 || t == 512 || t == 1024) s.threads = (uint32_t)t;
+        if (t >= 64 && t <= 1024 && t % 64 == 0) s.threads = (uint32_t)t;
     }
     if (!s.use_lds) s.lds_bytes = 0;
     // Small tables (hll p<=13, ull p<=12) would let 4 workgroups = 8 waves/SIMD share a CU; the kernel is VALU-issue
