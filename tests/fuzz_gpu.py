@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""tests/fuzz_gpu.py [iterations] [seed] — randomized GPU-vs-oracle parity runs (not collected by pytest; run it on the
+GPU box when a kernel changed: `python tests/fuzz_gpu.py 300`).  Random sketch type, k, p, seed, flags and batch shapes:
+clean / dirty / mixed genomes, many or few records, lengths around lane, tile and slice boundaries."""
+import os
+import random
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import lash_amd
+import oracle_lib as O
+
+ALGO = {"hmh": 0, "hll": 1, "ull": 2}
+
+
+def random_genome(rng):
+    kind = rng.random()
+    n_rec = rng.choice([1, 1, 1, 2, 3, rng.randint(4, 40)])
+    recs = []
+    for _ in range(n_rec):
+        L = rng.choice([rng.randint(0, 120), rng.randint(0, 5000), rng.randint(0, 200_000),
+                        rng.choice([63, 64, 65, 95, 96, 97, 2047, 2048, 2049, 4096, 16384, 16385, 32768])])
+        s = bytearray(O.synth_genome(rng.randint(0, 10**6), max(L, 1)).tobytes()[:L])
+        if kind < 0.45:
+            pass                                            # clean
+        elif kind < 0.7 and L:
+            for _ in range(rng.randint(1, 3)):              # sparse dirt
+                i = rng.randrange(L)
+                s[i:i + rng.choice([1, 1, 2, 10, 100])] = rng.choice([b"N", b"n", b"a", b"-", b"R"]) * min(rng.choice([1, 1, 2, 10, 100]), L - i)
+        elif L:
+            for i in range(L):                              # dense dirt
+                if rng.random() < 0.2:
+                    s[i] = rng.choice(b"NnacgtRYKM-*")
+        recs.append(bytes(s))
+    return recs
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    ctx = lash_amd.Context(0)
+    for it in range(iters):
+        rng = random.Random(seed0 * 100003 + it)
+        an = rng.choice(["hmh", "hll", "ull"])
+        k = rng.choice([rng.randint(1, 32), 16, 21, 31, 32])
+        p = 0 if an == "hmh" else rng.choice([rng.randint(4, 16)] if an == "hll" else [rng.randint(3, 20), rng.randint(3, 14)])
+        seed = rng.choice([0, 42, rng.getrandbits(64)])
+        flags = rng.choice([0, 0, lash_amd.F_NO_DIRECT]) | (lash_amd.F_HMH_X_LOW if an == "hmh" and rng.random() < 0.2 else 0)
+        gs = [random_genome(rng) for _ in range(rng.randint(1, 12))]
+        seq, off, goff = lash_amd.records_to_arrays(gs)
+        ctx.enable_timing(True)
+        got = ctx.sketch_batch(an, k, p, seed, seq, off, goff, flags=flags)
+        kmers = ctx.timing()["kmers"]
+        ctx.enable_timing(False)
+        want = O.sketch_genomes(ALGO[an], k, p, seed, seq, off, goff, threads=8, hmh_x_is_low=1 if flags & lash_amd.F_HMH_X_LOW else 0)
+        want_kmers = sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+        if not np.array_equal(got, want) or kmers != want_kmers:
+            bad = sorted({int(r) for r in np.argwhere(got != want)[:, 0]}) if got.shape == want.shape else "shape"
+            print("MISMATCH it=%d %s k=%d p=%d seed=%d flags=%d genomes=%s census %d vs %d" % (it, an, k, p, seed, flags, bad, kmers, want_kmers))
+            sys.exit(1)
+    print("fuzz ok: %d iterations from seed %d" % (iters, seed0))
+
+
+if __name__ == "__main__":
+    main()
