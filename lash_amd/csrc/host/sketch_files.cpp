@@ -180,21 +180,40 @@ int sniff_format(const uint8_t *p, uint64_t n)
 //          chunk so that no k-mer across the cut is lost (repeated k-mers are harmless: max / OR are idempotent).
 //   FASTQ: before the last line that starts with '@' and whose line-after-next starts with '+' (a quality line that
 //          happens to start with '@' fails that test).
-size_t find_cut(const uint8_t *b, size_t n, int fmt, size_t &overlap)
+// Where to end this chunk of a file that is streamed in pieces, and what the next chunk has to start with.
+// FASTA: before the last '\n>' of the second half when there is one (nothing to carry).  Otherwise the record continues
+// in the next chunk: cut at the last line end (or at the chunk end inside one enormous line) and carry the last <= 32
+// SURVIVING bases of the current record as a synthetic sequence line.  Those are exactly the bases a k-mer spanning the
+// cut can reach back to (k - 1 <= 31; filter_out_n deletes everything else anyway), so the k-mer set of the pieces
+// equals that of the whole record however long an N run at the cut is; the few k-mers inside the carried line are
+// repeats, which max / OR ignore.  FASTQ: before the last complete record start of the second half; nothing carried.
+size_t find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry)
 {
-    overlap = 0;
+    carry.clear();
     if (fmt == LASH_FMT_FASTA) {
         for (size_t q = n - 1; q > n / 2; --q)
             if (b[q] == '>' && b[q - 1] == '\n') return q;
         size_t cut = n;
         while (cut > n / 2 && b[cut - 1] != '\n') --cut;
-        if (cut <= n / 2) {                               // one enormous line: cut anywhere inside it
-            overlap = n > 8192 ? 4096 : 0;
-            return n;
+        if (cut <= n / 2) cut = n;                        // one enormous line: cut inside it
+        // walk back line by line from the cut, collecting surviving bases, until 32 are found or a header line is met
+        std::vector<uint8_t> rev;                         // collected bases, last one first
+        size_t line_stop = cut;                           // one past the last byte of the line being looked at
+        while (rev.size() < 32 && line_stop > 0) {
+            size_t ls = line_stop;                        // start of that line
+            if (ls > 0 && b[ls - 1] == '\n') --ls;        // (step over the terminator of the previous line)
+            while (ls > 0 && b[ls - 1] != '\n') --ls;
+            if (b[ls] == '>') break;                      // the record began here: nothing before it belongs to it
+            for (size_t i = line_stop; i > ls && rev.size() < 32; --i) {
+                const uint8_t ch = b[i - 1];
+                if (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T') rev.push_back(ch);
+            }
+            line_stop = ls;
         }
-        size_t o = cut > 4096 ? cut - 4096 : 0;
-        while (o > 0 && b[o - 1] != '\n') --o;
-        overlap = cut - o;
+        if (!rev.empty()) {
+            carry.assign(rev.rbegin(), rev.rend());
+            carry.push_back('\n');
+        }
         return cut;
     }
     auto line_end = [&](size_t p) { const void *e = memchr(b + p, '\n', n - p); return e ? (size_t)((const uint8_t *)e - b) : n; };
@@ -232,8 +251,8 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
             fmt = sniff_format(buf.p, have);
             if (!fmt) return "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + path;
         }
-        size_t overlap = 0;
-        const size_t cut = eof ? have : find_cut(buf.p, have, fmt, overlap);
+        std::vector<uint8_t> carry;
+        const size_t cut = eof ? have : find_cut(buf.p, have, fmt, carry);
         if (!eof && cut == 0) return "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path;
         lash_params prm = prm0;
         if (!first) prm.flags |= LASH_F_ACCUMULATE;
@@ -244,9 +263,10 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
             if (rc != LASH_OK) return std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
             first = false;
         }
-        const size_t keep_from = cut - overlap;
-        have -= keep_from;
-        if (have) memmove(buf.p, buf.p + keep_from, have);
+        const size_t rest = have - cut;                   // cut > have / 2, carry <= 33 bytes: the buffer always drains
+        if (rest) memmove(buf.p + carry.size(), buf.p + cut, rest);
+        if (!carry.empty()) memcpy(buf.p, carry.data(), carry.size());
+        have = carry.size() + rest;
     }
     if (first) return "Invalid input file: empty (" + path + ")";
     return "";
