@@ -202,7 +202,8 @@ __device__ __forceinline__ uint4 load16_clipped(const uint8_t *seq, int64_t off,
 // needletail semantics: FASTA = '>' header line, then sequence lines up to the next '>';
 // FASTQ = 4-line records, line 2 is the sequence.  Newlines, '\r' and everything else that is not ACGT are dropped by
 // the same filter that implements filter_out_n; what is added here is (a) header / '+' / quality lines are dropped
-// even where they contain ACGT, (b) a record starts at every '>' (FASTA) or header-ending newline (FASTQ).
+// even where they contain ACGT, (b) a record starts at every '>' that opens a line (FASTA) or header-ending newline
+// (FASTQ).
 // Line state is a prefix property of the file: "last of {'>' -> header, '\n' -> sequence}" for FASTA, "newlines so far
 // mod 4" for FASTQ.  Inside a tile it is resolved with ballots / shuffles, across tiles with a second, 4-byte
 // look-back descriptor (bits 1:0 status, FASTA: bit 2 = tile has a setter, bit 3 = state after it; FASTQ: bits 3:2 =
@@ -352,7 +353,19 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
 #pragma unroll
                 for (int c = 0; c < P2_CHUNKS; ++c) {
                     nl[c] = eqmask16(q[c], 0x0A0A0A0Au) & keep[c];
-                    gt[c] = fasta ? (eqmask16(q[c], 0x3E3E3E3Eu) & keep[c]) : 0u;
+                    uint32_t g = fasta ? (eqmask16(q[c], 0x3E3E3E3Eu) & keep[c]) : 0u;
+                    if (g) {
+                        // needletail finds the next record at "\n>": a '>' in the middle of a line is sequence text (and is
+                        // then deleted by the ACGT filter).  Bytes 1..15 look at their left neighbour in the chunk; byte 0
+                        // at the byte before the chunk (rare: one global byte load), or at nothing when it opens the file.
+                        uint32_t after_nl = (nl[c] << 1) & 0xFFFFu;
+                        const int32_t cs = (c * P2_THREADS + (int)tid) * 16;
+                        const int32_t first = (ti.flags & TF_FIRST) ? ti.rel_lo - cs : -1;     // the file's first byte, if in this chunk
+                        if (first >= 0 && first < 16) after_nl |= 1u << first;
+                        else if ((g & 1u) && a.seq[ti.toff + cs - 1] == (uint8_t)'\n') after_nl |= 1u;
+                        g &= after_nl;
+                    }
+                    gt[c] = g;
                 }
                 if (fasta) {
 #pragma unroll

@@ -38,6 +38,9 @@ def fasta_file(rng):
         out.append(hdr + nl)
         s = seq_bytes(rng, rng.choice([0, rng.randint(1, 300), rng.randint(1, 60000)]))
         w = rng.choice([60, 70, 80, 1, 17, 10**9])
+        if s and rng.random() < 0.15:                       # a '>' (or '@') in the middle of a sequence line is sequence text
+            i = rng.randrange(len(s))
+            s = s[:i] + rng.choice([b">", b">r9 x", b"@"]) + s[i:]
         for i in range(0, len(s), w):
             out.append(s[i:i + w] + nl)
             if rng.random() < 0.02:
@@ -56,9 +59,9 @@ def fastq_file(rng):
         q = bytes(rng.choice(b"@+>IIIIFF#ACGT") for _ in range(len(s)))
         out.append(b"@" + rng.choice([b"r%d" % r, b"r%d/1 @+ACGT" % r]) + nl + s + nl + b"+" + rng.choice([b"", b"r%d" % r]) + nl + q + nl)
     data = b"".join(out)
-    if rng.random() < 0.3 and data.endswith(nl):
-        data = data[:-len(nl)]
-    return data
+    if rng.random() < 0.3 and data.endswith(nl) and out and len(s):
+        data = data[:-len(nl)]                              # no newline after the last quality line (if it is not empty:
+    return data                                             # an empty last line would vanish and truncate the record)
 
 
 def main():

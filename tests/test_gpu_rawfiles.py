@@ -86,3 +86,20 @@ def test_raw_large_wrapped_fasta(ctx, tmp_path):
     assert np.array_equal(got[0], want0)
     want = oracle_for_files(tmp_path, files[1:], "hmh", 16, 0)
     assert np.array_equal(got[1:], want)
+
+
+def test_header_only_where_a_line_opens(ctx, tmp_path):
+    """needletail finds the next FASTA record at "\\n>": a '>' in the middle of a line is sequence text (deleted by the
+    ACGT filter, so its flanks join).  Checked at every position of a 16-byte lane chunk and across a tile boundary."""
+    g = O.synth_genome(66, 40_000).tobytes()
+    files = []
+    for shift in range(0, 18):
+        body = g[:100 + shift] + b">not a header ACGTACGT" + g[100 + shift:300] + b"\n" + g[300:16_390 - shift] + b">" + g[16_390 - shift:20_000]
+        files.append(b">r0\n" + body + b"\n>r1\n" + g[20_000:20_100] + b"\n")
+    files.append(b">a\nACGT>b\nACGT\n")                     # one record: the flanks of the deleted text join
+    (tmp_path / "one").write_bytes(files[-1])
+    assert read_fastx(str(tmp_path / "one")) == [b"ACGT>bACGT"]
+    got = ctx.sketch_files_raw("hmh", 16, 0, 42, files)
+    assert np.array_equal(got, oracle_for_files(tmp_path, files, "hmh", 16, 0))
+    got = ctx.sketch_files_raw("ull", 4, 8, 42, files)
+    assert np.array_equal(got, oracle_for_files(tmp_path, files, "ull", 4, 8))
