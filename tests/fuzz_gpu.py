@@ -51,15 +51,42 @@ def main():
         flags = rng.choice([0, 0, lash_amd.F_NO_DIRECT]) | (lash_amd.F_HMH_X_LOW if an == "hmh" and rng.random() < 0.2 else 0)
         gs = [random_genome(rng) for _ in range(rng.randint(1, 12))]
         seq, off, goff = lash_amd.records_to_arrays(gs)
+        mode = rng.choice(["host", "host", "accumulate", "device", "packed"])
         ctx.enable_timing(True)
-        got = ctx.sketch_batch(an, k, p, seed, seq, off, goff, flags=flags)
+        if mode == "host" or len(seq) == 0:
+            got = ctx.sketch_batch(an, k, p, seed, seq, off, goff, flags=flags)
+        elif mode == "accumulate":
+            # every genome's records in two calls: the first ones, then the rest unioned into the same images
+            cut = [rng.randint(0, len(g)) for g in gs]
+            s1, o1, g1 = lash_amd.records_to_arrays([g[:c] for g, c in zip(gs, cut)])
+            s2, o2, g2 = lash_amd.records_to_arrays([g[c:] for g, c in zip(gs, cut)])
+            got = ctx.sketch_batch(an, k, p, seed, s1, o1, g1, flags=flags)
+            got = ctx.sketch_batch(an, k, p, seed, s2, o2, g2, flags=flags | lash_amd.F_ACCUMULATE, out=got)
+        else:
+            import torch
+            d_seq = torch.from_numpy(seq).cuda()
+            d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+            gbo = off[goff.astype(np.int64)]
+            d_img = torch.zeros(len(gs) * lash_amd.image_bytes(an, p), dtype=torch.uint8, device="cuda")
+            if mode == "device":
+                ctx.sketch_batch_device(an, k, p, seed, d_seq, d_off, len(off) - 1, goff, gbo, d_img, flags=flags)
+            else:
+                pk = ctx.pack_device(d_seq, d_off, len(off) - 1, goff, gbo)
+                ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=flags & ~lash_amd.F_NO_DIRECT)
+                ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=(flags & ~lash_amd.F_NO_DIRECT) | lash_amd.F_ACCUMULATE)   # idempotent
+            ctx.synchronize()
+            got = d_img.cpu().numpy().reshape(len(gs), -1)
+            if mode == "packed":
+                pk.free()
         kmers = ctx.timing()["kmers"]
         ctx.enable_timing(False)
+        if mode == "packed":
+            kmers //= 2                                      # sketched twice
         want = O.sketch_genomes(ALGO[an], k, p, seed, seq, off, goff, threads=8, hmh_x_is_low=1 if flags & lash_amd.F_HMH_X_LOW else 0)
         want_kmers = sum(len(O.record_kmers(r, k)) for g in gs for r in g)
         if not np.array_equal(got, want) or kmers != want_kmers:
             bad = sorted({int(r) for r in np.argwhere(got != want)[:, 0]}) if got.shape == want.shape else "shape"
-            print("MISMATCH it=%d %s k=%d p=%d seed=%d flags=%d genomes=%s census %d vs %d" % (it, an, k, p, seed, flags, bad, kmers, want_kmers))
+            print("MISMATCH it=%d mode=%s %s k=%d p=%d seed=%d flags=%d genomes=%s census %d vs %d" % (it, mode, an, k, p, seed, flags, bad, kmers, want_kmers))
             sys.exit(1)
     print("fuzz ok: %d iterations from seed %d" % (iters, seed0))
 
