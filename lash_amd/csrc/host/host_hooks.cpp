@@ -1,5 +1,6 @@
 // host_hooks.cpp — extern "C" test hooks over the host-side C++ (FASTX reader, JSON writers, zstd, list files) so
 // that tests/ can drive them through ctypes.  Not part of the product ABI (that is include/lash_gfx950.h).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -52,6 +53,16 @@ char *lash_host_json_array(const char *items_nl, uint64_t n_items)
         p = e ? e + 1 : p + strlen(p);
     }
     return dup_str(json_pretty_string_array(v));
+}
+
+// chunk-cut rule of the large-file streamer: returns the cut, copies the carry (<= 64 bytes) out
+uint64_t lash_host_stream_find_cut(const uint8_t *buf, uint64_t n, int fmt, uint8_t *carry_out, uint64_t *carry_len)
+{
+    std::vector<uint8_t> carry;
+    const size_t cut = stream_find_cut(buf, (size_t)n, fmt, carry);
+    *carry_len = carry.size();
+    if (!carry.empty()) memcpy(carry_out, carry.data(), std::min<size_t>(carry.size(), 64));
+    return cut;
 }
 
 char *lash_host_write_parameters(const char *output_name, const char *algorithm, int k, int precision, uint64_t seed)

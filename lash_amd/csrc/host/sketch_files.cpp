@@ -274,6 +274,9 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
 
 }  // namespace
 
+// test hook (host_hooks.cpp): the chunk-cut rule of the large-file streamer
+size_t stream_find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry) { return find_cut(b, n, fmt, carry); }
+
 std::string sketch_files(const SketchOptions &opt, const std::vector<std::string> &files, const std::string &output_name,
                          SketchStats *stats)
 {

@@ -40,4 +40,7 @@ std::string read_list_file(const std::string &path, std::vector<std::string> &fi
 std::string write_parameters_json(const std::string &output_name, const std::string &algorithm, int k, int precision,
                                   uint64_t seed);
 
+// where a streamed chunk ends (0 = no boundary found) and the bytes the next chunk must start with (tests)
+size_t stream_find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry);
+
 }  // namespace lashhost

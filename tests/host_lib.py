@@ -28,6 +28,8 @@ def _load():
     lib.lash_host_read_list.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
     lib.lash_host_zstd_write.restype = C.c_void_p
     lib.lash_host_zstd_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
+    lib.lash_host_stream_find_cut.restype = C.c_uint64
+    lib.lash_host_stream_find_cut.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.POINTER(C.c_uint64)]
     lib.lash_host_zstd_read.restype = C.c_void_p
     lib.lash_host_zstd_read.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     return lib
@@ -90,3 +92,11 @@ def zstd_read(path) -> bytes:
     b = C.string_at(out, n.value)
     lib.lash_host_free(out)
     return b
+
+
+def stream_find_cut(buf: bytes, fmt: int):
+    """(cut, carry) of the CLI's large-file streamer for one chunk; fmt 1 = FASTA, 2 = FASTQ."""
+    carry = C.create_string_buffer(64)
+    n = C.c_uint64()
+    cut = lib.lash_host_stream_find_cut(buf, len(buf), fmt, carry, C.byref(n))
+    return int(cut), carry.raw[:n.value]

@@ -126,3 +126,54 @@ def test_cli_without_gpu_fails_loudly(tmp_path):
     assert r.returncode != 0 and "Algorithm must be either hmh, ull, or hll" in r.stderr
     r = subprocess.run([H.CLI, "sketch"], capture_output=True, text=True)
     assert r.returncode == 2 and "--file" in r.stderr
+
+
+def _kmer_set(path_bytes, k, tmp_path, name):
+    """canonical k-mers of a FASTA/FASTQ byte string, via the host reader (needletail semantics) + the oracle"""
+    import oracle_lib as O
+    p = tmp_path / name
+    p.write_bytes(path_bytes)
+    out = set()
+    for rec in H.read_fastx(str(p)):
+        out.update(int(x) for x in O.record_kmers(rec, k))
+    return out
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_streaming_chunks_cover_exactly_the_kmers_of_the_file(tmp_path, seed):
+    """The large-file streamer cuts a file into chunks (`stream_find_cut`) and sketches them into one image.  Property: the
+    union of the chunks' k-mer sets equals the file's, whatever the record sizes, line widths and N runs at the cuts
+    (a record larger than a chunk is cut at a line end, or inside one enormous line, and the last <= 32 surviving bases are
+    carried over)."""
+    import random
+    import oracle_lib as O
+    rng = random.Random(seed)
+    g = O.synth_genome(900 + seed, 400_000).tobytes()
+    parts, pos = [], 0
+    while pos < 300_000:
+        n = rng.choice([rng.randint(1, 300), rng.randint(5_000, 40_000), rng.randint(60_000, 120_000)])
+        s = bytearray(g[pos:pos + n])
+        if rng.random() < 0.6 and len(s) > 10:
+            i = rng.randrange(len(s))
+            run = rng.choice([1, 40, 3_000, 30_000])
+            s[i:i + run] = b"N" * len(s[i:i + run])
+        w = rng.choice([60, 80, 10**9, 7])
+        parts.append(b">r%d\n" % len(parts) + b"\n".join(bytes(s[i:i + w]) for i in range(0, len(s), w)) + b"\n")
+        pos += n
+    data = b"".join(parts)
+    chunk = rng.choice([20_000, 33_333, 50_000])
+    for k in (16, 31):
+        want = _kmer_set(data, k, tmp_path, "whole.fa")
+        got, buf, rest = set(), b"", data
+        while rest or buf:
+            take = chunk - len(buf)
+            buf, rest = buf + rest[:take], rest[take:]
+            if rest:
+                cut, carry = H.stream_find_cut(buf, 1)
+                assert len(buf) // 2 < cut <= len(buf) and len(carry) <= 33
+            else:
+                cut, carry = len(buf), b""
+            piece = buf[:cut]
+            got |= _kmer_set(piece if piece.startswith(b">") else b">continued\n" + piece, k, tmp_path, "piece.fa")
+            buf = carry + buf[cut:]
+        assert got == want, (seed, k, len(got ^ want))
