@@ -177,3 +177,35 @@ def test_streaming_chunks_cover_exactly_the_kmers_of_the_file(tmp_path, seed):
             got |= _kmer_set(piece if piece.startswith(b">") else b">continued\n" + piece, k, tmp_path, "piece.fa")
             buf = carry + buf[cut:]
         assert got == want, (seed, k, len(got ^ want))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_streaming_chunks_of_fastq_split_between_records(tmp_path, seed):
+    """FASTQ chunks end just before a record start: an '@' that opens a line whose line-after-next starts with '+'
+    (quality lines may start with '@' or '+').  The records of the chunks, in order, are the records of the file."""
+    import random
+    rng = random.Random(100 + seed)
+    recs = []
+    for i in range(3000):
+        L = rng.choice([1, 36, 100, 150, rng.randint(1, 300)])
+        s = bytes(rng.choice(b"ACGTN") for _ in range(L))
+        q = bytes(rng.choice(b"@+I#F>A") for _ in range(L))
+        recs.append(b"@r%d %s\n" % (i, rng.choice([b"", b"@+x"])) + s + b"\n+" + rng.choice([b"", b"r%d" % i]) + b"\n" + q + b"\n")
+    data = b"".join(recs)
+    (tmp_path / "w.fq").write_bytes(data)
+    want = H.read_fastx(str(tmp_path / "w.fq"))
+    assert len(want) == 3000
+    chunk = rng.choice([4_000, 10_007, 50_000])
+    got, buf, rest = [], b"", data
+    while rest or buf:
+        take = chunk - len(buf)
+        buf, rest = buf + rest[:take], rest[take:]
+        if rest:
+            cut, carry = H.stream_find_cut(buf, 2)
+            assert carry == b"" and len(buf) // 2 < cut <= len(buf)
+        else:
+            cut = len(buf)
+        (tmp_path / "p.fq").write_bytes(buf[:cut])
+        got += H.read_fastx(str(tmp_path / "p.fq"))
+        buf = buf[cut:]
+    assert got == want
