@@ -209,3 +209,17 @@ def test_streaming_chunks_of_fastq_split_between_records(tmp_path, seed):
         got += H.read_fastx(str(tmp_path / "p.fq"))
         buf = buf[cut:]
     assert got == want
+
+
+def test_json_array_matches_a_reference_pretty_printer_on_odd_names():
+    """File names go into {o}_files.json verbatim (utils.rs:577-580, serde_json::to_string_pretty).  Python's json module
+    with indent=2 / ensure_ascii=False writes the same text as serde_json for arrays of strings: same escapes
+    (\\" \\\\ \\b \\f \\n \\r \\t, \\u00XX for the other control characters), non-ASCII left as UTF-8."""
+    import random
+    rng = random.Random(5)
+    alphabet = [chr(c) for c in list(range(1, 10)) + list(range(11, 128))] + ["é", "λ", "雪", "𝄞", '"', "\\", "/", "\t", "\x7f"]
+    for _ in range(200):
+        items = ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 30))) for _ in range(rng.randint(0, 6))]
+        got = H.json_array(items)
+        assert got == json.dumps(items, indent=2, ensure_ascii=False) or (items == [] and got == "[]")
+        assert json.loads(got) == items
