@@ -22,7 +22,8 @@ def random_genome(rng):
     recs = []
     for _ in range(n_rec):
         L = rng.choice([rng.randint(0, 120), rng.randint(0, 5000), rng.randint(0, 200_000),
-                        rng.choice([63, 64, 65, 95, 96, 97, 2047, 2048, 2049, 4096, 16384, 16385, 32768])])
+                        rng.choice([63, 64, 65, 95, 96, 97, 2047, 2048, 2049, 4096, 16384, 16385, 32768]),
+                        rng.choice([262_144, 262_145, rng.randint(300_000, 2_500_000)]) if rng.random() < 0.3 else 1000])   # several slices
         s = bytearray(O.synth_genome(rng.randint(0, 10**6), max(L, 1)).tobytes()[:L])
         if kind < 0.45:
             pass                                            # clean
