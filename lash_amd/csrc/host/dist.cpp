@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -280,15 +281,14 @@ std::string run_dist(const DistOptions &opt)
                 if (qnames[j] == rnames[i]) d = 0.0;                                                  // main.rs:452-453
                 else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
                 else d = compute_distance<double>(frac, k, opt.model);
+                // "{:.6}" (main.rs:456,461): std::to_chars is correctly rounded like printf("%.6f") and several times faster
+                buf[0] = '\t';
+                char *end = std::to_chars(buf + 1, buf + sizeof buf - 2, d, std::chars_format::fixed, 6).ptr;
                 if (!opt.matrix) {
                     txt += rnames[i]; txt += '\t'; txt += qnames[j];
-                    snprintf(buf, sizeof buf, "\t%.6f\n", d);
-                    txt += buf;
-                } else {
-                    if (first) { txt += '\n'; txt += rnames[i]; }
-                    snprintf(buf, sizeof buf, "\t%.6f", d);
-                    txt += buf;
-                }
+                    *end++ = '\n';
+                } else if (first) { txt += '\n'; txt += rnames[i]; }
+                txt.append(buf, end);
                 first = false;
             }
         };
