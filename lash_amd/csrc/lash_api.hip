@@ -63,6 +63,7 @@ struct lash_packed {
     std::vector<uint32_t> h_tile_begin;
     std::vector<uint64_t> h_nvalid;
     const uint64_t *d_rec_off = nullptr;
+    uint64_t n_rec = 0;
     PackArgs pa{};
     PackV2Args v2{};
     PackMapArgs pm{};
@@ -303,6 +304,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
         any_multi = descs[g].format != 0u || descs[g].rec_end - descs[g].rec_begin > 1;
     pk->any_multi = any_multi;
     pk->d_rec_off = d_rec_off;
+    pk->n_rec = n_rec;
     // surviving bases per genome: written by the pack kernel; direct mode starts from "nothing deleted" (= bytes) and
     // the deferred pack overwrites the genomes that turn out dirty
     pk->h_nvalid.assign(n_genomes + 1, 0);
@@ -404,6 +406,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     uint64_t target = total_words / (slots * 8) + 1;
     target = std::max(target, min_slice);
     std::vector<WorkItem> items;
+    uint32_t max_slices = 0;                                       // most slices any genome is cut into
     std::vector<uint32_t> item_begin(n_genomes + 1, 0);
     items.reserve(n_genomes * 2);
     for (uint32_t g = 0; g < n_genomes; ++g) {
@@ -413,6 +416,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         const uint64_t ns = (nw + target - 1) / target;
         const uint64_t per = (((nw + ns - 1) / ns) + 3) & ~3ull;
         uint32_t s = 0;
+        max_slices = std::max<uint32_t>(max_slices, (uint32_t)((nw + per - 1) / per));
         for (uint64_t b = 0; b < nw; b += per, ++s)
             for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)                   // slice index | pass << 16
                 items.push_back(WorkItem{g, (uint32_t)b, (uint32_t)std::min(nw, b + per), (s & 0xFFFFu) | (part << 16)});
@@ -456,7 +460,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             if (pk->any_multi) {
                 HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, ctx->stream));
                 HIPCHK(ctx, hipMemsetAsync(pk->brk_bytes.ptr, 0, pk->total_brk * 4, ctx->stream));
-                HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, static_cast<uint32_t *>(pk->brk_bytes.ptr),
+                HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, static_cast<uint32_t *>(pk->brk_bytes.ptr),
                                              ctx->stream));
             }
         }
@@ -521,6 +525,12 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.k = prm->k;
     fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
     fa.parts_log2 = plan.parts_log2;
+    // one finalize workgroup walks all of a genome's partials: fine for a handful of slices, 20 ms for the 4 096 slices of
+    // a metagenome-sized input (BASELINE configs[4]) -> fold groups of 32 slices first, one workgroup per group
+    fa.group = 0;
+    if (max_slices > 64u && n_genomes <= 65535u)
+        for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 64u; fa.group *= 32u) {}
+    HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
     HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
     if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
     TRACE("finalize: launched");

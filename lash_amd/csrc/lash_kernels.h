@@ -47,8 +47,8 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
                          bool direct = false);
 // record starts of multi-record format-0 genomes -> args.brk_bytes (zeroed before the launch)
-hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint32_t *brk_bytes,
-                            hipStream_t stream);
+hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec,
+                            uint32_t *brk_bytes, hipStream_t stream);
 
 struct FinalizeArgs {
     const uint8_t  *partials;
@@ -65,7 +65,12 @@ struct FinalizeArgs {
     int             algo, p, k;
     int             accumulate;          // union into the registers already in images[]
     uint32_t        parts_log2;          // see SketchPlan: a partial holds only the registers of its item's pass
+    uint32_t        group;               // 0, or G: launch_reduce_groups() has folded every G consecutive slices (per
+                                         // pass) into the first one's partial; only those group heads are read
 };
+// Many slices per genome (one metagenome-sized input: thousands of work items, one finalize workgroup): fold every R
+// consecutive slices into the first one's partial, in place, with one workgroup per (genome, pass, group).
+hipError_t launch_reduce_groups(const FinalizeArgs &args, uint32_t n_genomes, uint32_t max_slices, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream);
 
 // ---- pack stage -------------------------------------------------------------------------------------------

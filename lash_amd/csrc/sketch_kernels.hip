@@ -19,6 +19,7 @@
 //     value with a 0/~0 mask taken from the record-break bitmap: max(x,0) and OR 0 are no-ops (no divergence).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -538,6 +539,65 @@ __device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
     }
 }
 
+// One level of the fold: units are slices (stride 1) or the heads an earlier level left (stride = slices per head); every
+// R consecutive units are merged into the first one's partial.
+template <int ALGO>
+__global__ void __launch_bounds__(256) reduce_groups_kernel(FinalizeArgs a, uint32_t R, uint32_t stride)
+{
+    const uint32_t g = blockIdx.y, P = 1u << a.parts_log2, part = blockIdx.x % P, j = blockIdx.x / P;
+    const uint32_t i0 = a.genome_item_begin[g], i1 = a.genome_item_begin[g + 1];
+    const uint32_t n_slices = (i1 - i0) / P, n_units = (n_slices + stride - 1) / stride, u0 = j * R;
+    if (u0 >= n_units) return;
+    const uint32_t u1 = u0 + R < n_units ? u0 + R : n_units;
+    uint64_t nk = ~0ull;
+    if (a.nvalid) { const uint64_t L = a.nvalid[g]; nk = L >= (uint64_t)a.k ? L - (uint64_t)a.k + 1 : 0; }
+    auto live = [&](uint32_t it) { return stride > 1u || (uint64_t)a.items[it].word_begin * 16 < nk; };   // heads always are
+    const uint32_t nwords = (ALGO == 0 ? HMH_M * 2 : (1u << a.p)) >> 2, nw_part = nwords >> a.parts_log2, wbase = part * nw_part;
+    const uint32_t head = i0 + u0 * stride * P + part;
+    uint8_t *dst = const_cast<uint8_t *>(a.partials) + (uint64_t)head * a.partial_stride + a.partial_base_off;
+    // blockIdx.z splits the pass's words so that a thread folds one word: R independent loads, no serial walk
+    for (uint32_t wi = wbase + blockIdx.z * blockDim.x + threadIdx.x; wi < wbase + nw_part; wi += gridDim.z * blockDim.x) {
+        uint32_t acc = 0;
+#pragma unroll 8
+        for (uint32_t u = u0; u < u1; ++u) {
+            const uint32_t it = i0 + u * stride * P + part;
+            if (!live(it)) continue;                                       // slice never ran: its partial is not defined
+            acc = merge_word<ALGO>(acc, load_u32_any(a.partials + (uint64_t)it * a.partial_stride + a.partial_base_off + 4ull * wi));
+        }
+        store_u32_any(dst + 4ull * wi, acc);                               // the head's own word was read above, by this thread
+    }
+    if (a.item_kmers && threadIdx.x == 0 && blockIdx.z == 0) {
+        uint32_t tot = 0;
+        for (uint32_t u = u0; u < u1; ++u) {
+            const uint32_t it = i0 + u * stride * P + part;
+            if (live(it)) tot += a.item_kmers[it];
+        }
+        const_cast<uint32_t *>(a.item_kmers)[head] = tot;
+    }
+}
+
+// args.group = slices per head after all levels (a power of R): R = 32 slices per level until <= 64 heads remain
+hipError_t launch_reduce_groups(const FinalizeArgs &args, uint32_t n_genomes, uint32_t max_slices, hipStream_t stream)
+{
+    if (n_genomes == 0 || args.group == 0) return hipSuccess;
+    if (n_genomes > 65535u) return hipErrorInvalidValue;                   // (the caller only groups when genomes are few)
+    constexpr uint32_t R = 32;
+    for (uint32_t stride = 1; stride < args.group; stride *= R) {
+        const uint32_t units = (max_slices + stride - 1) / stride, groups = (units + R - 1) / R;
+        const uint32_t nw_part = ((args.algo == 0 ? HMH_M * 2 : (1u << args.p)) >> 2) >> args.parts_log2;
+        dim3 grid(groups << args.parts_log2, n_genomes, std::max(1u, std::min(nw_part / 256u, 64u)));
+        switch (args.algo) {
+        case 0: hipLaunchKernelGGL(reduce_groups_kernel<0>, grid, dim3(256), 0, stream, args, R, stride); break;
+        case 1: hipLaunchKernelGGL(reduce_groups_kernel<1>, grid, dim3(256), 0, stream, args, R, stride); break;
+        case 2: hipLaunchKernelGGL(reduce_groups_kernel<2>, grid, dim3(256), 0, stream, args, R, stride); break;
+        default: return hipErrorInvalidValue;
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 template <int ALGO>
 __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
 {
@@ -552,19 +612,21 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
     uint8_t *img = a.images + (uint64_t)g * a.image_bytes;
     if (threadIdx.x < 72) hist[threadIdx.x] = 0;
     __syncthreads();
+    // items of a genome are ordered slice-major, pass-minor: item = i0 + slice * P + pass.  After launch_reduce_groups()
+    // only every `group`-th slice (a group head, always treated as live) still matters.
+    const uint32_t P = 1u << a.parts_log2, step = (a.group ? a.group : 1u) * P;
     if (a.item_kmers && threadIdx.x == 0) {
         unsigned long long tot = 0;
-        for (uint32_t it = i0; it < i1; ++it)
-            if ((uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];
+        for (uint32_t it = i0; it < i1; it += step)                        // pass 0 carries the count of its slice
+            if (a.group || (uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];
         if (tot) atomicAdd(a.kmer_counter, tot);
     }
 
     for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
         uint32_t acc = a.accumulate ? load_u32_any(img + hdr + 4ull * wi) : 0u;
         const uint32_t part = a.parts_log2 ? wi / (nwords >> a.parts_log2) : 0u;   // whose pass wrote this word
-        for (uint32_t it = i0; it < i1; ++it) {
-            if ((uint64_t)a.items[it].word_begin * 16 >= nk) continue;     // slice never ran (see sketch_kernel)
-            if (a.parts_log2 && (a.items[it].slice >> 16) != part) continue;
+        for (uint32_t it = i0 + part; it < i1; it += step) {
+            if (!a.group && (uint64_t)a.items[it].word_begin * 16 >= nk) continue;   // slice never ran (see sketch_kernel)
             const uint8_t *src = a.partials + (uint64_t)it * a.partial_stride + a.partial_base_off;
             acc = merge_word<ALGO>(acc, load_u32_any(src + 4ull * wi));
         }
@@ -703,11 +765,14 @@ __global__ void __launch_bounds__(256) brk_bytes_kernel(const GenomeDesc *genome
     }
 }
 
-hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint32_t *brk_bytes,
-                            hipStream_t stream)
+hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec,
+                            uint32_t *brk_bytes, hipStream_t stream)
 {
     if (n_genomes == 0) return hipSuccess;
-    hipLaunchKernelGGL(brk_bytes_kernel, dim3(8, n_genomes < 65535u ? n_genomes : 65535u), dim3(256), 0, stream, genomes,
+    // x: enough 256-thread blocks per genome for ~4 records per thread (a read set is one genome with millions of records)
+    const uint64_t per_genome = n_rec / n_genomes + 1;
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(8, per_genome / 1024 + 1));
+    hipLaunchKernelGGL(brk_bytes_kernel, dim3(gx, n_genomes < 65535u ? n_genomes : 65535u), dim3(256), 0, stream, genomes,
                        rec_off, n_genomes, brk_bytes);
     return hipGetLastError();
 }

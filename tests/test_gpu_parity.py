@@ -303,3 +303,25 @@ def test_partial_sketches_of_one_input_merge_across_ranks():
         c.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("ull", 16, 12), ("hll", 21, 16)])
+def test_one_input_with_very_many_slices(ctx, an, k, p):
+    """A metagenome-sized input (BASELINE configs[4] shape, scaled): one 'genome' of 150-bp reads cut into far more than 64
+    work-item slices, whose partial sketches are folded in groups before the per-genome finalize (and, for hll p=16, in
+    two bucket-space passes as well), next to a small genome in the same batch."""
+    import lash_amd
+    g = O.synth_genome(77, 40_000_000)
+    reads = [g[i:i + 150].tobytes() for i in range(0, len(g) - 150, 150)]
+    reads[1000] = b"ACGTN" * 30
+    small = [O.synth_genome(78, 40_000).tobytes()]
+    seq, off, goff = lash_amd.records_to_arrays([reads, small])
+    want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    assert tm["sketch_workgroups"] > 64 * (2 if p == 16 else 1)      # more than 64 slices per pass: the grouped fold runs
+    assert tm["kmers"] == (len(reads) - 1) * (150 - k + 1) + sum(len(O.record_kmers(r, k)) for r in (reads[1000], small[0]))
+    assert_same(got, want, an)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, an + " pack-first")
