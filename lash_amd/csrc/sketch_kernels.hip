@@ -268,23 +268,29 @@ __device__ __forceinline__ uint32_t ascii16_to_word(const uint4 q, uint32_t &bad
     return (ascii4_to_2bit(q.x, bad) << 24) | (ascii4_to_2bit(q.y, bad) << 16) | (ascii4_to_2bit(q.z, bad) << 8) |
            ascii4_to_2bit(q.w, bad);
 }
-// tail lanes: 16 bytes at genome offset o, byte by byte; bytes at or past L read as 'A' (their k-mers are masked)
-__device__ __noinline__ uint64_t ascii16_slow_raw(const uint8_t *gseq, uint64_t o, uint64_t L)
+// tail lanes (the last <= 2 lanes of a genome, whose 96 bytes are not all inside it): bytes at or past L read as 'A' (their
+// k-mers are masked).  All 96 byte loads are unconditional on a clamped index, so they are issued together: one memory
+// round trip per genome tail instead of 96 (many small genomes: 41 us -> a few us per genome).
+struct TailWords { uint32_t w[6]; uint32_t bad; };
+__device__ __noinline__ TailWords ascii96_tail(const uint8_t *gseq, uint64_t o, uint64_t L)
 {
-    uint32_t w = 0, bad = 0;
-    for (uint32_t b = 0; b < 16; ++b) {
-        const uint32_t c = (o + b < L) ? gseq[o + b] : 0x41u;
-        const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;
-        bad |= c ^ ((0x54474341u >> (8 * code)) & 0xFFu);
-        w = (w << 2) | code;
+    uint32_t d[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint64_t pos = o + (uint64_t)(4 * i + b);
+            const uint32_t ch = gseq[pos < L ? pos : L - 1];               // L >= 1: the lane is active
+            x |= (pos < L ? ch : 0x41u) << (8 * b);
+        }
+        d[i] = x;
     }
-    return ((uint64_t)bad << 32) | w;                   // by value: a reference argument would live in scratch memory
-}
-__device__ __forceinline__ uint32_t ascii16_slow(const uint8_t *gseq, uint64_t o, uint64_t L, uint32_t &bad)
-{
-    const uint64_t r = ascii16_slow_raw(gseq, o, L);
-    bad |= (uint32_t)(r >> 32);
-    return (uint32_t)r;
+    TailWords t;
+    t.bad = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t.w[j] = ascii16_to_word(make_uint4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]), t.bad);
+    return t;
 }
 
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT>
@@ -379,8 +385,14 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         const bool active = tile_active(tile);
         const TileRegs cur = nxt;
         tile_load(tile + step, nxt);
+        // A wave with no lane inside the slice has nothing to hash (a 10 kbp genome fills 2.5 of a workgroup's 8 waves).
+        // Letting it run the masked body is worse than wasted issue slots: its lanes would all hash the same all-zero
+        // words and hit ONE LDS address with 64-way serialized atomics (46 us per small genome instead of ~10).
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
 
-        uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+        // inactive lanes of an active wave: distinct garbage words (their updates are masked to no-ops), for the same reason
+        const uint32_t junk = (threadIdx.x + 1u) * 0x9E3779B1u;
+        uint32_t c0 = junk, c1 = ~junk, c2 = junk, c3 = ~junk, c4 = junk, c5 = ~junk;
         uint64_t kv = 0;
         if constexpr (DIRECT) {
             // another workgroup (or an earlier tile) met a byte outside ACGT: this genome goes to the fallback path
@@ -392,11 +404,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     c3 = ascii16_to_word(cur.a3, bad); c4 = ascii16_to_word(cur.la, bad);
                     if constexpr (KMODE == KM_GT16) c5 = ascii16_to_word(cur.lb, bad);
                 } else {
-                    const uint64_t o = (uint64_t)w0 * 16;
-                    c0 = ascii16_slow(gseq, o, L, bad); c1 = ascii16_slow(gseq, o + 16, L, bad);
-                    c2 = ascii16_slow(gseq, o + 32, L, bad); c3 = ascii16_slow(gseq, o + 48, L, bad);
-                    c4 = ascii16_slow(gseq, o + 64, L, bad);
-                    if constexpr (KMODE == KM_GT16) c5 = ascii16_slow(gseq, o + 80, L, bad);
+                    const TailWords t = ascii96_tail(gseq, (uint64_t)w0 * 16, L);
+                    c0 = t.w[0]; c1 = t.w[1]; c2 = t.w[2]; c3 = t.w[3]; c4 = t.w[4];
+                    if constexpr (KMODE == KM_GT16) c5 = t.w[5];
+                    bad |= t.bad;
                 }
                 kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
             }
