@@ -407,19 +407,22 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     target = std::max(target, min_slice);
     std::vector<WorkItem> items;
     uint32_t max_slices = 0;                                       // most slices any genome is cut into
+    bool all_sole = plan.parts_log2 == 0 && plan.use_lds && n_genomes > 0;   // every genome has exactly one work item
     std::vector<uint32_t> item_begin(n_genomes + 1, 0);
     items.reserve(n_genomes * 2);
     for (uint32_t g = 0; g < n_genomes; ++g) {
         item_begin[g] = (uint32_t)items.size();
         const uint64_t nw = ((pk->byte_len[g] + 15) / 16 + 3) & ~3ull;
-        if (nw == 0) continue;
+        if (nw == 0) { all_sole = false; continue; }               // no work item at all: finalize writes the empty image
         const uint64_t ns = (nw + target - 1) / target;
         const uint64_t per = (((nw + ns - 1) / ns) + 3) & ~3ull;
         uint32_t s = 0;
         max_slices = std::max<uint32_t>(max_slices, (uint32_t)((nw + per - 1) / per));
+        if (ns != 1) all_sole = false;
         for (uint64_t b = 0; b < nw; b += per, ++s)
             for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)                   // slice index | pass << 16
-                items.push_back(WorkItem{g, (uint32_t)b, (uint32_t)std::min(nw, b + per), (s & 0xFFFFu) | (part << 16)});
+                items.push_back(WorkItem{g, (uint32_t)b, (uint32_t)std::min(nw, b + per),
+                                         (s & 0x7FFFu) | (part << 16) | ((ns == 1 && plan.parts_log2 == 0 && plan.use_lds) ? ITEM_SOLE : 0u)});
     }
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
@@ -487,6 +490,13 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
     sa.item_kmers = static_cast<uint32_t *>(ctx->item_kmers.ptr);
     sa.safe = static_cast<const uint8_t *>(ctx->counter.ptr) + 128;
+    sa.images = d_out_images;
+    sa.image_bytes = image_bytes;
+    {
+        const double alpha0 = hll_alpha(prm->p);
+        memcpy(&sa.alpha_bits, &alpha0, 8);
+    }
+    sa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
     sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
     sa.partial_stride = plan.partial_stride;
     sa.nreg32 = plan.nreg32 >> plan.parts_log2;                 // register words of one pass
@@ -530,8 +540,12 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.group = 0;
     if (max_slices > 64u && n_genomes <= 65535u)
         for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 64u; fa.group *= 32u) {}
-    HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
-    HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
+    if (all_sole) {
+        HIPCHK(ctx, launch_census(fa, n_genomes, ctx->stream));            // every image was written by its one work item
+    } else {
+        HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
+        HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
+    }
     if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
     TRACE("finalize: launched");
     ctx->last_packed.push_back(pk);

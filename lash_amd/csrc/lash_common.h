@@ -27,9 +27,10 @@ struct WorkItem {
     uint32_t genome;
     uint32_t word_begin;  // slice = packed words [word_begin, word_end) of the genome, multiples of 4
     uint32_t word_end;
-    uint32_t slice;       // bits 15:0 slice index inside the genome; bits 31:16 which bucket-space pass (LdsPartRegs)
+    uint32_t slice;       // bits 14:0 slice index inside the genome, bit 15 ITEM_SOLE; bits 31:16 which bucket-space pass
 };
 
+constexpr uint32_t ITEM_SOLE        = 0x8000u;   // WorkItem::slice flag: the genome's only work item (writes the image itself)
 constexpr int      PAD_WORDS        = 8;       // readable slack after every genome (look-ahead words)
 constexpr int      SKETCH_WORDS_PER_THREAD = 4;   // one global_load_dwordx4 per lane per step
 constexpr int      HMH_P            = 14;

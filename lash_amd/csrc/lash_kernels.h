@@ -18,6 +18,10 @@ struct SketchArgs {
     uint8_t          *partials;   // [n_items][partial_stride] partial sketches in image register format
     uint32_t         *gregs;      // [n_items][nreg32] zeroed u32 words, only for the global-register variant
     uint32_t         *item_kmers; // [n_items] valid k-mers of each work item (summed per genome by finalize_kernel)
+    uint8_t          *images;     // ITEM_SOLE work items write their genome's image themselves
+    uint64_t          image_bytes;
+    uint64_t          alpha_bits; // HLL alpha as f64 bits
+    int               accumulate;
     // direct mode (sketch_kernel<..., DIRECT>): format-0 genomes are read as ASCII straight from the caller's buffer
     const uint8_t    *seq;        // the caller's record bytes
     const uint32_t   *brk_bytes;  // record-break bitmap in BYTE positions (== base positions while nothing is deleted)
@@ -72,6 +76,7 @@ struct FinalizeArgs {
 // consecutive slices into the first one's partial, in place, with one workgroup per (genome, pass, group).
 hipError_t launch_reduce_groups(const FinalizeArgs &args, uint32_t n_genomes, uint32_t max_slices, hipStream_t stream);
 hipError_t launch_finalize(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream);
+hipError_t launch_census(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream);   // all genomes ITEM_SOLE
 
 // ---- pack stage -------------------------------------------------------------------------------------------
 struct PackArgs {

@@ -242,6 +242,75 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
 #define LASH_SKETCH_WAVES_PER_EU_ATTR __attribute__((amdgpu_waves_per_eu(LASH_SKETCH_WAVES_PER_EU, LASH_SKETCH_WAVES_PER_EU)))
 #endif
 
+// ---- helpers shared by the sketch kernel's flush and the finalize kernels ------------------------------------------------
+__device__ __forceinline__ uint32_t ull_unpack32pair(uint32_t r, uint32_t &hi)
+{
+    // hash4j unpack(): (4 | (r & 3)) << ((r >> 2) - 2); r == 0 -> 0.  Returns low word, hi by reference.
+    if (r < 8) { hi = 0; return 0; }
+    const uint64_t x = (uint64_t)(4u | (r & 3u)) << ((r >> 2) - 2u);
+    hi = (uint32_t)(x >> 32);
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t ull_merge_reg(uint32_t a, uint32_t b)
+{
+    if (a == 0) return b;
+    if (b == 0) return a;
+    uint32_t ah, bh;
+    const uint32_t al = ull_unpack32pair(a, ah), bl = ull_unpack32pair(b, bh);
+    const uint64_t x = (((uint64_t)(ah | bh)) << 32) | (al | bl);
+    const uint32_t top = 63u - (uint32_t)__builtin_clzll(x);
+    return (top << 2) | ((uint32_t)(x >> (top - 2)) & 3u);               // top >= 2 because r >= 8
+}
+
+__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) return *reinterpret_cast<const uint32_t *>(p);
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+__device__ __forceinline__ void store_u32_any(uint8_t *p, uint32_t v)
+{
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) { *reinterpret_cast<uint32_t *>(p) = v; return; }
+    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
+template <int ALGO>
+__device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
+{
+    if constexpr (ALGO == 0) {
+        const uint32_t al = a & 0xFFFFu, ah = a >> 16, bl = b & 0xFFFFu, bh = b >> 16;
+        return (al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16);
+    } else {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t x = (a >> (8 * i)) & 0xFFu, y = (b >> (8 * i)) & 0xFFu;
+            const uint32_t m = ALGO == 1 ? (x > y ? x : y) : ull_merge_reg(x, y);
+            o |= m << (8 * i);
+        }
+        return o;
+    }
+}
+
+// streaming_algorithms HyperLogLog header: alpha f64, zero u64, sum f64, p u8, len u64.  zero and sum
+// are recomputed from the final registers' histogram; sum = sum_j 2^-m[j] is exact in f64 here (largest exponent first).
+__device__ __forceinline__ void write_hll_header(uint8_t *img, const uint32_t *hist, uint64_t alpha_bits, int p)
+{
+    double sum = 0.0;
+    for (int r = 66; r >= 0; --r) {
+        if (hist[r]) sum += (double)hist[r] * __longlong_as_double((long long)(1023 - r) << 52);
+    }
+    const uint64_t zero = hist[0];
+    const uint64_t sum_bits = (uint64_t)__double_as_longlong(sum);
+    const uint64_t len = 1ull << p;
+    for (int b = 0; b < 8; ++b) {
+        img[b] = (uint8_t)(alpha_bits >> (8 * b));
+        img[8 + b] = (uint8_t)(zero >> (8 * b));
+        img[16 + b] = (uint8_t)(sum_bits >> (8 * b));
+        img[25 + b] = (uint8_t)(len >> (8 * b));
+    }
+    img[24] = (uint8_t)p;
+}
+
 // ---- direct mode: 2-bit words straight from ASCII ------------------------------------------------------------
 // While a genome holds nothing but upper-case ACGT, filter_out_n (utils.rs:33-41) deletes nothing, base i IS byte i,
 // and the pack stage's scan has nothing to compute: the sketch kernel can read the caller's bytes itself and save
@@ -306,7 +375,27 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
     const int k = a.k, p = a.p;
     const uint64_t nk = L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0;     // k-mer start positions of the genome
-    if ((uint64_t)it.word_begin * 16 >= nk) return;                       // slice beyond the surviving bases
+    if ((uint64_t)it.word_begin * 16 >= nk) {                             // slice beyond the surviving bases
+        // the only work item of a genome too short for a single k-mer still owes the (empty) image; when the call
+        // unions into existing images there is nothing to add
+        if ((it.slice & ITEM_SOLE) && !a.accumulate) {
+            uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
+            for (uint64_t i = threadIdx.x; i < a.image_bytes; i += blockDim.x) img[i] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if constexpr (ALGO == 1) {
+                    uint32_t hist0[72];
+                    for (int i = 0; i < 72; ++i) hist0[i] = 0;
+                    hist0[0] = 1u << p;
+                    write_hll_header(img, hist0, a.alpha_bits, p);
+                } else if constexpr (ALGO == 2) {
+                    const uint64_t len = 1ull << p;
+                    for (int b = 0; b < 8; ++b) img[b] = (uint8_t)(len >> (8 * b));
+                }
+            }
+        }
+        return;
+    }
 
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
@@ -465,16 +554,45 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                                                                       // passes of one slice count the same k-mers: once)
     }
 
-    // flush the partial sketch in image register format (u16 LE for HMH, u8 for HLL / ULL)
+    // flush in image register format (u16 LE for HMH, u8 for HLL / ULL): into this item's partial sketch, or — when the
+    // item is the only one of its genome (ITEM_SOLE: many small genomes) — straight into the genome's image, header
+    // included, so that neither a partial nor a finalize pass is needed for it
+    const bool sole = (it.slice & ITEM_SOLE) != 0u;
     uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)blockIdx.x * a.partial_stride);
+    uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
+    constexpr uint32_t HDR = ALGO == 0 ? 0u : ALGO == 1 ? 33u : 8u;
+    uint32_t *hist = census + 16;                                          // 72 words after the census (HLL header)
+    if constexpr (ALGO == 1) {
+        if (sole) {
+            if (threadIdx.x < 72) hist[threadIdx.x] = 0;
+            __syncthreads();
+        }
+    }
+    auto put = [&](uint32_t i, uint32_t v) {
+        if (!sole) { out[i] = v; return; }
+        uint8_t *dst = img + HDR + 4ull * i;
+        if (a.accumulate) v = merge_word<ALGO>(load_u32_any(dst), v);
+        store_u32_any(dst, v);
+        if constexpr (ALGO == 1) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t rho = (v >> (8 * b)) & 0xFFu;
+                atomicAdd(&hist[rho < 71u ? rho : 71u], 1u);
+            }
+        }
+    };
     if constexpr (ALGO == 0) {
         for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
-            out[i] = regs.get(2 * i) | (regs.get(2 * i + 1) << 16);
+            put(i, regs.get(2 * i) | (regs.get(2 * i + 1) << 16));
     } else if constexpr (ALGO == 1) {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
         if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
         for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
-            out[i] = regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24);
+            put(i, regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24));
+        if (sole) {
+            __syncthreads();
+            if (threadIdx.x == 0) write_hll_header(img, hist, a.alpha_bits, p);
+        }
     } else {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
         if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
@@ -493,7 +611,11 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 }
                 o |= r << (8 * b);
             }
-            out[i] = o;
+            put(i, o);
+        }
+        if (sole && threadIdx.x == 0) {
+            const uint64_t len = 1ull << p;                                // bincode Vec<u8> length prefix (switch U4)
+            for (int b = 0; b < 8; ++b) img[b] = (uint8_t)(len >> (8 * b));
         }
     }
 }
@@ -502,54 +624,6 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 // finalize: reduce a genome's partial sketches (max / ULL merge), add the image header, optionally union into
 // what is already in the image (LASH_F_ACCUMULATE, lash_merge_images).  One workgroup per genome.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ull_unpack32pair(uint32_t r, uint32_t &hi)
-{
-    // hash4j unpack(): (4 | (r & 3)) << ((r >> 2) - 2); r == 0 -> 0.  Returns low word, hi by reference.
-    if (r < 8) { hi = 0; return 0; }
-    const uint64_t x = (uint64_t)(4u | (r & 3u)) << ((r >> 2) - 2u);
-    hi = (uint32_t)(x >> 32);
-    return (uint32_t)x;
-}
-__device__ __forceinline__ uint32_t ull_merge_reg(uint32_t a, uint32_t b)
-{
-    if (a == 0) return b;
-    if (b == 0) return a;
-    uint32_t ah, bh;
-    const uint32_t al = ull_unpack32pair(a, ah), bl = ull_unpack32pair(b, bh);
-    const uint64_t x = (((uint64_t)(ah | bh)) << 32) | (al | bl);
-    const uint32_t top = 63u - (uint32_t)__builtin_clzll(x);
-    return (top << 2) | ((uint32_t)(x >> (top - 2)) & 3u);               // top >= 2 because r >= 8
-}
-
-__device__ __forceinline__ uint32_t load_u32_any(const uint8_t *p)
-{
-    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) return *reinterpret_cast<const uint32_t *>(p);
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
-__device__ __forceinline__ void store_u32_any(uint8_t *p, uint32_t v)
-{
-    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) { *reinterpret_cast<uint32_t *>(p) = v; return; }
-    p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
-}
-
-template <int ALGO>
-__device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
-{
-    if constexpr (ALGO == 0) {
-        const uint32_t al = a & 0xFFFFu, ah = a >> 16, bl = b & 0xFFFFu, bh = b >> 16;
-        return (al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16);
-    } else {
-        uint32_t o = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t x = (a >> (8 * i)) & 0xFFu, y = (b >> (8 * i)) & 0xFFu;
-            const uint32_t m = ALGO == 1 ? (x > y ? x : y) : ull_merge_reg(x, y);
-            o |= m << (8 * i);
-        }
-        return o;
-    }
-}
-
 // One level of the fold: units are slices (stride 1) or the heads an earlier level left (stride = slices per head); every
 // R consecutive units are merged into the first one's partial.
 template <int ALGO>
@@ -632,6 +706,8 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
             if (a.group || (uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];
         if (tot) atomicAdd(a.kmer_counter, tot);
     }
+    // a genome sketched by a single work item has had its image written by that item (ITEM_SOLE, sketch_kernel)
+    if (i1 - i0 == 1u && (a.items[i0].slice & ITEM_SOLE)) return;
 
     for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
         uint32_t acc = a.accumulate ? load_u32_any(img + hdr + 4ull * wi) : 0u;
@@ -651,25 +727,8 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
         }
     }
     if constexpr (ALGO == 1) {
-        // streaming_algorithms HyperLogLog header: alpha f64, zero u64, sum f64, p u8, len u64.
-        // zero and sum are recomputed from the final registers; sum = sum_j 2^-m[j] is exact in f64 here.
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double sum = 0.0;
-            for (int r = 66; r >= 0; --r) {
-                if (hist[r]) sum += (double)hist[r] * __longlong_as_double((long long)(1023 - r) << 52);
-            }
-            const uint64_t zero = hist[0];
-            const uint64_t sum_bits = (uint64_t)__double_as_longlong(sum);
-            const uint64_t len = 1ull << a.p;
-            for (int b = 0; b < 8; ++b) {
-                img[b] = (uint8_t)(a.alpha_bits >> (8 * b));
-                img[8 + b] = (uint8_t)(zero >> (8 * b));
-                img[16 + b] = (uint8_t)(sum_bits >> (8 * b));
-                img[25 + b] = (uint8_t)(len >> (8 * b));
-            }
-            img[24] = (uint8_t)a.p;
-        }
+        if (threadIdx.x == 0) write_hll_header(img, hist, a.alpha_bits, a.p);
     } else if constexpr (ALGO == 2) {
         if (threadIdx.x == 0) {
             const uint64_t len = 1ull << a.p;                              // bincode Vec<u8> length prefix (switch U4)
@@ -705,7 +764,7 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     // bound and the extra waves only add LDS-atomic contention (hll p=13: 7.4e11 vs 8.1e11 k-mers/s).  Asking for 64 KiB
     // keeps it at the two workgroups per CU that the 64 KiB tables get.
     else if (s.threads == 512u && s.lds_bytes < 64u * 1024u) s.lds_bytes = 64u * 1024u;
-    s.lds_bytes += 64u;                                                    // per-wave census words after the registers
+    s.lds_bytes += 64u + 288u;                                             // per-wave census words + HLL header histogram after the registers
     return s;
 }
 
@@ -785,6 +844,28 @@ hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, 
     const uint32_t gx = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(8, per_genome / 1024 + 1));
     hipLaunchKernelGGL(brk_bytes_kernel, dim3(gx, n_genomes < 65535u ? n_genomes : 65535u), dim3(256), 0, stream, genomes,
                        rec_off, n_genomes, brk_bytes);
+    return hipGetLastError();
+}
+
+// every genome of the batch was ITEM_SOLE: nothing to reduce, only the k-mer census to add up
+__global__ void __launch_bounds__(256) census_kernel(FinalizeArgs a, uint32_t n_genomes)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long tot = 0;
+    if (g < n_genomes) {
+        const uint32_t i0 = a.genome_item_begin[g], i1 = a.genome_item_begin[g + 1];
+        const uint64_t L = a.nvalid[g], nk = L >= (uint64_t)a.k ? L - (uint64_t)a.k + 1 : 0;
+        for (uint32_t it = i0; it < i1; ++it)
+            if ((uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];
+    }
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(a.kmer_counter, tot);
+}
+
+hipError_t launch_census(const FinalizeArgs &args, uint32_t n_genomes, hipStream_t stream)
+{
+    if (n_genomes == 0) return hipSuccess;
+    hipLaunchKernelGGL(census_kernel, dim3((n_genomes + 255) / 256), dim3(256), 0, stream, args, n_genomes);
     return hipGetLastError();
 }
 
