@@ -293,13 +293,8 @@ __device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
 
 // streaming_algorithms HyperLogLog header: alpha f64, zero u64, sum f64, p u8, len u64.  zero and sum
 // are recomputed from the final registers' histogram; sum = sum_j 2^-m[j] is exact in f64 here (largest exponent first).
-__device__ __forceinline__ void write_hll_header(uint8_t *img, const uint32_t *hist, uint64_t alpha_bits, int p)
+__device__ __forceinline__ void write_hll_header_raw(uint8_t *img, uint64_t alpha_bits, uint64_t zero, double sum, int p)
 {
-    double sum = 0.0;
-    for (int r = 66; r >= 0; --r) {
-        if (hist[r]) sum += (double)hist[r] * __longlong_as_double((long long)(1023 - r) << 52);
-    }
-    const uint64_t zero = hist[0];
     const uint64_t sum_bits = (uint64_t)__double_as_longlong(sum);
     const uint64_t len = 1ull << p;
     for (int b = 0; b < 8; ++b) {
@@ -309,6 +304,14 @@ __device__ __forceinline__ void write_hll_header(uint8_t *img, const uint32_t *h
         img[25 + b] = (uint8_t)(len >> (8 * b));
     }
     img[24] = (uint8_t)p;
+}
+__device__ __forceinline__ void write_hll_header(uint8_t *img, const uint32_t *hist, uint64_t alpha_bits, int p)
+{
+    double sum = 0.0;
+    for (int r = 66; r >= 0; --r) {
+        if (hist[r]) sum += (double)hist[r] * __longlong_as_double((long long)(1023 - r) << 52);
+    }
+    write_hll_header_raw(img, alpha_bits, hist[0], sum, p);
 }
 
 // ---- direct mode: 2-bit words straight from ASCII ------------------------------------------------------------
@@ -384,10 +387,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             __syncthreads();
             if (threadIdx.x == 0) {
                 if constexpr (ALGO == 1) {
-                    uint32_t hist0[72];
-                    for (int i = 0; i < 72; ++i) hist0[i] = 0;
-                    hist0[0] = 1u << p;
-                    write_hll_header(img, hist0, a.alpha_bits, p);
+                    write_hll_header_raw(img, a.alpha_bits, 1ull << p, (double)(1u << p), p);   // all registers 0: sum = m * 2^-0
                 } else if constexpr (ALGO == 2) {
                     const uint64_t len = 1ull << p;
                     for (int b = 0; b < 8; ++b) img[b] = (uint8_t)(len >> (8 * b));
