@@ -403,7 +403,9 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     for (uint32_t g = 0; g < n_genomes; ++g) total_words += (pk->byte_len[g] + 15) / 16;
     const uint64_t step = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
     const uint64_t min_slice = step * 8;                           // amortise the LDS clear + flush
-    uint64_t target = total_words / (slots * 8) + 1;
+    static const uint64_t slice_factor = getenv("LASH_SLICE_FACTOR") ? std::max(1, atoi(getenv("LASH_SLICE_FACTOR"))) : 4;   // tuning knob: the
+    // sketch time is flat from 2x to 24x the slots (4.87-4.91 ms on the default bench), the finalize time grows with it
+    uint64_t target = total_words / (slots * slice_factor) + 1;
     target = std::max(target, min_slice);
     std::vector<WorkItem> items;
     uint32_t max_slices = 0;                                       // most slices any genome is cut into
@@ -536,10 +538,10 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
     fa.parts_log2 = plan.parts_log2;
     // one finalize workgroup walks all of a genome's partials: fine for a handful of slices, 20 ms for the 4 096 slices of
-    // a metagenome-sized input (BASELINE configs[4]) -> fold groups of 32 slices first, one workgroup per group
+    // a metagenome-sized input (BASELINE configs[4]) -> fold groups of 32 slices first (until <= 16 heads remain)
     fa.group = 0;
-    if (max_slices > 64u && n_genomes <= 65535u)
-        for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 64u; fa.group *= 32u) {}
+    if (max_slices > 32u && n_genomes <= 65535u)
+        for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
     if (all_sole) {
         HIPCHK(ctx, launch_census(fa, n_genomes, ctx->stream));            // every image was written by its one work item
     } else {
