@@ -36,7 +36,7 @@ char *lash_host_read_fastx(const char *path, uint8_t **seq, uint64_t *seq_bytes,
     *seq_bytes = rb.seq.size();
     *n_rec = rb.n_rec();
     *seq = (uint8_t *)malloc(rb.seq.size() + 1);
-    memcpy(*seq, rb.seq.data(), rb.seq.size());
+    if (!rb.seq.empty()) memcpy(*seq, rb.seq.data(), rb.seq.size());
     *rec_off = (uint64_t *)malloc(rb.rec_off.size() * 8);
     memcpy(*rec_off, rb.rec_off.data(), rb.rec_off.size() * 8);
     return nullptr;

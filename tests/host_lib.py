@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "lash_amd", "liblash_host.so")
+SO = os.environ.get("LASH_HOST_LIB") or os.path.join(ROOT, "lash_amd", "liblash_host.so")   # override: sanitizer builds
 CLI = os.path.join(ROOT, "lash_amd", "bin", "lash")
 
 
