@@ -100,7 +100,7 @@ char *lash_host_zstd_read(const char *path, uint8_t **out, uint64_t *n)
     if (!err.empty()) return dup_str(err);
     *n = v.size();
     *out = (uint8_t *)malloc(v.size() + 1);
-    memcpy(*out, v.data(), v.size());
+    if (!v.empty()) memcpy(*out, v.data(), v.size());
     return nullptr;
 }
 
