@@ -10,7 +10,7 @@ import numpy as np
 
 HMH, HLL, ULL = 0, 1, 2
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "liblash_oracle.so")
+_SO = os.environ.get("LASH_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "liblash_oracle.so")   # override: sanitizer builds
 
 
 class Params(C.Structure):
