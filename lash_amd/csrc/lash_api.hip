@@ -393,7 +393,10 @@ int pack_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, EvSet *ev)
 {
     const uint32_t n_genomes = pk->n_genomes;
-    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, (prm->flags & LASH_F_HMH_X_LOW) != 0);
+    uint64_t total_bytes = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) total_bytes += pk->byte_len[g];
+    const bool small_items = n_genomes > 0 && total_bytes / n_genomes < 100000u;
+    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, (prm->flags & LASH_F_HMH_X_LOW) != 0, small_items);
     const uint64_t image_bytes = lash_sketch_image_bytes(prm->algo, prm->p);
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----

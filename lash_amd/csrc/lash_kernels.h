@@ -47,7 +47,8 @@ struct SketchPlan {
     uint32_t partial_stride;      // rounded up to 16
 };
 
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low);
+// small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)
+SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
                          bool direct = false);
 // record starts of multi-record format-0 genomes -> args.brk_bytes (zeroed before the launch)

@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
 // ------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
+SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items)
 {
     SketchPlan s{};
     s.algo = algo; s.k = k; s.p = p; s.x_low = x_low;
@@ -755,6 +755,12 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     if (!s.use_lds) s.parts_log2 = 0;
     s.lds_bytes >>= s.parts_log2;
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU
+    // Small genomes with a small table (hll p<=13, ull p<=12): a 10 kbp genome fills 2.5 waves, and what limits such a
+    // batch is per-workgroup latency (item / descriptor / first tile loads, flush), not issue slots -> 256-thread
+    // workgroups, as many per CU as the table allows (100 000 x 10 kbp, hll p=10: 4.4 -> 2.7 ms).  HyperMinHash's 64 KiB
+    // table admits two workgroups per CU whatever their size, and smaller ones only lose lanes.
+    const bool many_small = small_items && s.use_lds && s.parts_log2 == 0 && s.lds_bytes <= 32u * 1024u;
+    if (many_small) s.threads = 256u;
     if (const char *e = getenv("LASH_SKETCH_THREADS")) {                    // tuning knob (tools/)
         const int t = atoi(e);
         if (t >= 64 && t <= 1024 && t % 64 == 0) s.threads = (uint32_t)t;
@@ -763,7 +769,7 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low)
     // Small tables (hll p<=13, ull p<=12) would let 4 workgroups = 8 waves/SIMD share a CU; the kernel is VALU-issue
     // bound and the extra waves only add LDS-atomic contention (hll p=13: 7.4e11 vs 8.1e11 k-mers/s).  Asking for 64 KiB
     // keeps it at the two workgroups per CU that the 64 KiB tables get.
-    else if (s.threads == 512u && s.lds_bytes < 64u * 1024u) s.lds_bytes = 64u * 1024u;
+    else if (!many_small && s.threads == 512u && s.lds_bytes < 64u * 1024u) s.lds_bytes = 64u * 1024u;
     s.lds_bytes += 64u + 288u;                                             // per-wave census words + HLL header histogram after the registers
     return s;
 }
