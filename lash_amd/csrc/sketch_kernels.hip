@@ -412,12 +412,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             regs.part = part;
         }
         census = lds_regs + a.nreg32;
-        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
     } else {
         regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;           // zeroed by the host (hipMemsetAsync)
         census = lds_regs;
     }
-    __syncthreads();
 
     const uint32_t *__restrict__ w = a.words + gd.word_off;
     // A genome with a single record has no interior record boundary: its lanes read three always-zero words (one
@@ -468,6 +466,14 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     };
     TileRegs nxt;
     tile_load(it.word_begin, nxt);
+    // the table is cleared while the first tile's loads are in flight; a raw barrier, because __syncthreads() would also
+    // drain vmcnt and with it those loads
+    if constexpr (USE_LDS) {
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     for (uint32_t tile = it.word_begin; tile < it.word_end; tile += step) {
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
         const uint64_t pos0 = (uint64_t)w0 * 16;
