@@ -157,3 +157,40 @@ def test_every_short_length_on_the_direct_pass(an, k, p):
     assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
     same(got, oracle_images(an, k, p, 42, seq, off, goff), "short lengths %s k=%d" % (an, k))
     ctx.close()
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hll", 21, 10), ("ull", 13, 9)])
+def test_many_small_genomes_write_their_own_images(an, k, p):
+    """A batch of thousands of small genomes: each is a single work item that writes its image (header included) from the
+    sketch kernel; only a census kernel follows.  Clean and dirty genomes, genomes shorter than k (empty image owed),
+    union into existing images, and the pack-first route must all agree with the oracle."""
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    rng = random.Random(17)
+    base = O.synth_genome(321, 400_000).tobytes()
+    gs = []
+    for i in range(3000):
+        n = rng.choice([rng.randint(0, 40), rng.randint(40, 3000), rng.randint(3000, 12_000)])
+        s = bytearray(base[(i * 97) % 300_000:][:n])
+        if n and rng.random() < 0.3:
+            j = rng.randrange(n)
+            s[j:j + rng.choice([1, 5, 200])] = b"N" * len(s[j:j + rng.choice([1, 5, 200])])
+        cut = rng.randint(0, n) if rng.random() < 0.2 else n
+        gs.append([bytes(s[:cut]), bytes(s[cut:])] if cut < n else [bytes(s)])
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    want = oracle_images(an, k, p, 42, seq, off, goff)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    assert tm["sketch_workgroups"] == sum(1 for g in gs if sum(len(r) for r in g) > 0)     # one work item per non-empty genome
+    assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+    same(got, want, "small genomes " + an)
+    same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, "pack-first")
+    # union of two halves of every genome's records into the same images
+    s1, o1, g1 = lash_amd.records_to_arrays([g[:1] for g in gs])
+    s2, o2, g2 = lash_amd.records_to_arrays([g[1:] for g in gs])
+    acc = ctx.sketch_batch(an, k, p, 42, s1, o1, g1)
+    acc = ctx.sketch_batch(an, k, p, 42, s2, o2, g2, flags=lash_amd.F_ACCUMULATE, out=acc)
+    same(acc, want, "accumulate")
+    ctx.close()
