@@ -89,6 +89,13 @@ def main():
     ap.add_argument("-k", type=int, default=16)
     ap.add_argument("-p", type=int, default=14)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--workload", choices=["genomes", "reads"], default="genomes",
+                    help="genomes: --genomes x --length bp, one record each (configs[1]/[2]); reads: ONE sketch of --reads "
+                         "150-bp records (configs[4] shape; use with --algo ull -p 12)")
+    ap.add_argument("--reads", type=int, default=20_000_000, help="--workload reads: 150-bp records per step and GPU")
+    ap.add_argument("--dirty", choices=["none", "nrun", "lower"], default="none",
+                    help="nrun: one 100-byte run of N per genome; lower: every other 10 kb block lower-case (soft-masked "
+                         "assembly: filter_out_n deletes those bytes, utils.rs:33-41)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
@@ -119,17 +126,52 @@ def main():
     ctx = lash_amd.Context(local_rank, stream=stream)     # raises without GPU / library: no fallback
 
     # ---- synthetic input, generated in HBM (the same generator as oracle/lash_oracle.c) ----
-    d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
-    first = rank * G
-    ctx.synth_genomes_device(first, G, L, d_seq)
-    rec_off = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)        # one record per genome
-    goff = np.arange(G + 1, dtype=np.uint64)
-    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+    reads = args.workload == "reads"
+    if reads:
+        # configs[4] shape: ONE sketch of N 150-bp records (a long synthetic sequence cut into reads)
+        RL = 150
+        n_rec, G, L = args.reads, 1, args.reads * RL
+        assert L <= 0xFFFFFFFF - 64, "one call takes at most 2^32-64 bytes per sketch (stream larger inputs with F_ACCUMULATE)"
+        first = 900_000 + rank
+        d_seq = torch.empty(L, dtype=torch.uint8, device=dev)
+        ctx.synth_genomes_device(first, 1, L, d_seq)
+        rec_off = np.array([0, L], dtype=np.uint64)                      # byte offsets of the genome's first / last record
+        goff = np.array([0, n_rec], dtype=np.uint64)
+        d_rec = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * RL
+        kmers_per_genome = n_rec * (RL - k + 1)
+    else:
+        n_rec = G
+        d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
+        first = rank * G
+        ctx.synth_genomes_device(first, G, L, d_seq)
+        rec_off = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)        # one record per genome
+        goff = np.arange(G + 1, dtype=np.uint64)
+        d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+        kmers_per_genome = L - k + 1
+    torch.cuda.synchronize()
+    surviving = L
+    if args.dirty != "none":
+        assert not reads, "--dirty applies to the genomes workload"
+        ctx.synchronize()
+        v = d_seq.view(G, L)
+        if args.dirty == "nrun":
+            # one run of 100 N per genome at a genome-dependent position (assembly gap)
+            pos = (torch.arange(G, device=dev, dtype=torch.int64) * 2654435761 + 12345) % (L - 1000) + 500
+            idx = pos[:, None] + torch.arange(100, device=dev, dtype=torch.int64)[None, :]
+            v.scatter_(1, idx, torch.full(idx.shape, ord("N"), dtype=torch.uint8, device=dev))
+            surviving = L - 100
+        else:
+            B = 10_000
+            assert L % (2 * B) == 0
+            v.view(G, L // B, B)[:, 1::2, :] |= 0x20                     # lower-case: deleted by filter_out_n
+            surviving = L // 2
+        kmers_per_genome = surviving - k + 1
+        torch.cuda.synchronize()
     d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     def step():
-        ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img)
+        ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, n_rec, goff, rec_off, d_img)
 
     # the GPU's clocks take some tens of milliseconds of load to settle after idle (the first launches run 6.4 ms, later
     # ones 5.2): a fixed untimed pre-heat, then the W warm-up steps the caller asked for, then exactly K timed steps
@@ -157,7 +199,7 @@ def main():
         elapsed = float(t.item())
 
     # informational: the same batch kept resident as 2-bit (lash_pack_device once, then only the sketch + finalize stages)
-    pk = ctx.pack_device(d_seq, d_rec, G, goff, rec_off)
+    pk = ctx.pack_device(d_seq, d_rec, n_rec, goff, rec_off)
     ctx.sketch_packed_device(algo, k, p, seed, pk, d_img)
     torch.cuda.synchronize()
     tp0 = time.perf_counter()
@@ -170,11 +212,11 @@ def main():
     # oracle-free cross-check on every rank: the pack-first route (a different kernel chain) must give the same images
     # (timed with the same HIP events: gives the pack kernels' own HBM rate for the secondary roofline entry)
     d_img2 = torch.zeros_like(d_img)
-    ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img2, flags=lash_amd.F_NO_DIRECT)
+    ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, n_rec, goff, rec_off, d_img2, flags=lash_amd.F_NO_DIRECT)
     torch.cuda.synchronize()
     ctx.enable_timing(True)
     for _ in range(3):
-        ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img2, flags=lash_amd.F_NO_DIRECT)
+        ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, n_rec, goff, rec_off, d_img2, flags=lash_amd.F_NO_DIRECT)
     torch.cuda.synchronize()
     tm_pf = ctx.timing()
     ctx.enable_timing(False)
@@ -182,7 +224,6 @@ def main():
     del d_img2
     assert routes_agree, "direct and pack-first routes disagree"
 
-    kmers_per_genome = L - k + 1
     kmers_step_rank = G * kmers_per_genome
     assert tm["kmers"] == kmers_step_rank * args.steps, "device k-mer census disagrees with the workload"
     total_kmers = kmers_step_rank * world * args.steps
@@ -211,10 +252,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "%d synthetic %d-bp genomes per GPU, -a %s -k %d%s, seed %d, ASCII records resident in HBM "
-                                   "-> sketch images in HBM (lash_sketch_batch_device: filter_out_n + k-mers + xxh3 + registers + images)"
-                                   % (G, L, algo, k, "" if algo == "hmh" else " -p %d" % p, seed),
-                       "genomes_per_gpu": G, "genome_length": L, "algo": algo, "k": k, "p": p, "sharding": "genomes across ranks"},
+            "config": {"workload": ("ONE sketch of %d synthetic 150-bp records (%d bp) per GPU" % (n_rec, L) if reads else
+                                    "%d synthetic %d-bp genomes per GPU%s" % (G, L, {"none": "", "nrun": ", one 100-byte N run in each",
+                                                                                     "lower": ", every other 10 kb block lower-case"}[args.dirty]))
+                                   + ", -a %s -k %d%s, seed %d, ASCII records resident in HBM -> sketch images in HBM "
+                                     "(lash_sketch_batch_device: filter_out_n + k-mers + xxh3 + registers + images)"
+                                   % (algo, k, "" if algo == "hmh" else " -p %d" % p, seed),
+                       "genomes_per_gpu": G, "genome_length": L, "records_per_gpu": n_rec, "dirty": args.dirty,
+                       "algo": algo, "k": k, "p": p, "sharding": "genomes across ranks"},
             "roofline": {"bound": "hbm", "kernel": "sketch_kernel<DIRECT>" if direct else "sketch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sketch_ms,
@@ -236,7 +281,7 @@ def main():
     # ---- the CPU leg (rank 0, N = 1 only, outside the timed region): the oracle timed as the baseline and used as the
     #      checker of three of the images this run produced ----
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not reads and args.dirty == "none":
             img = d_img.view(G, ib)
             check = {g: img[g].cpu().numpy() for g in sorted({0, G // 2, G - 1})} if not args.no_parity_check else {}
             out["cpu_baseline"], ok = cpu_baseline(algo, k, p, seed, L, args.cpu_seconds, first, check)

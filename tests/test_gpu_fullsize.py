@@ -151,3 +151,66 @@ def test_streamed_metagenome_chunks(env):
     sub = O.sketch_genomes(O.ULL, 16, 12, 42, host, off, np.array([0, head], np.uint64), threads=8)[0]
     merged = O.merge_images(O.ULL, 12, one.cpu().numpy(), sub)
     assert np.array_equal(merged, one.cpu().numpy())
+
+
+def test_config4_full_100gbp(env):
+    """BASELINE configs[4] at its stated size: ull p=12 k=16 over 100 Gbp of 150-bp reads (6.67e8 records), ASCII resident
+    in HBM (100 GB), streamed through lash_sketch_batch_device in chunks of <= 2^32-64 bytes with on-device accumulation
+    (utils.rs:453-459: one sketch per file, however many records).  The oracle cannot finish 9e10 k-mers, so:
+      * census: the device counts exactly n_reads * (150 - 16 + 1) k-mers;
+      * two different chunkings give the identical image;
+      * three disjoint windows of 1 M reads are sketched alone on the GPU and must equal the oracle bit for bit, and the
+        oracle's window sketches merged into the full sketch change nothing (every register they set is in it)."""
+    ctx, torch, lash_amd = env
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info()
+    total = 100_000_000_050 if FULL else 3_000_000_000
+    if free < total + 24 * 2**30:
+        pytest.skip("needs %.0f GB of free HBM" % ((total + 24 * 2**30) / 1e9))
+    RL, k, p = 150, 16, 12
+    total -= total % RL
+    n_reads = total // RL
+    d_seq = torch.empty(total, dtype=torch.uint8, device=dev)
+    ctx.synth_genomes_device(910_000, 1, total, d_seq)
+    ctx.synchronize()
+    ib = lash_amd.image_bytes("ull", p)
+
+    def run(chunks):
+        d_img = torch.zeros(ib, dtype=torch.uint8, device=dev)
+        per = (n_reads + chunks - 1) // chunks
+        assert per * RL <= 0xFFFFFFFF - 64
+        torch.cuda.synchronize()
+        ctx.enable_timing(True)
+        for c in range(chunks):
+            r0, r1 = c * per, min(n_reads, (c + 1) * per)
+            if r1 <= r0:
+                break
+            d_rec = torch.arange(r0, r1 + 1, dtype=torch.int64, device=dev) * RL
+            torch.cuda.synchronize()
+            ctx.sketch_batch_device("ull", k, p, 42, d_seq, d_rec, r1 - r0, np.array([0, r1 - r0], np.uint64),
+                                    np.array([r0 * RL, r1 * RL], np.uint64), d_img, flags=lash_amd.F_ACCUMULATE if c else 0)
+            ctx.synchronize()
+        t = ctx.timing()
+        ctx.enable_timing(False)
+        return d_img, t
+
+    a, ta = run(25 if FULL else 3)
+    b, tb = run(37 if FULL else 5)
+    assert ta["kmers"] == tb["kmers"] == n_reads * (RL - k + 1)
+    assert torch.equal(a, b)
+    full = a.cpu().numpy()
+    assert int(np.frombuffer(full[:8].tobytes(), "<u8")[0]) == 1 << p and (full[8:] != 0).all()   # 9e10 k-mers fill every register
+    win = 1_000_000
+    for w0 in (0, n_reads // 2 - 333_333, n_reads - win):
+        d_rec = torch.arange(w0, w0 + win + 1, dtype=torch.int64, device=dev) * RL
+        d_one = torch.zeros(ib, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.sketch_batch_device("ull", k, p, 42, d_seq, d_rec, win, np.array([0, win], np.uint64),
+                                np.array([w0 * RL, (w0 + win) * RL], np.uint64), d_one)
+        ctx.synchronize()
+        host = d_seq[w0 * RL:(w0 + win) * RL].cpu().numpy()
+        want = O.sketch_genomes(O.ULL, k, p, 42, host, np.arange(win + 1, dtype=np.uint64) * RL, np.array([0, win], np.uint64))[0]
+        assert np.array_equal(d_one.cpu().numpy(), want), w0
+        assert np.array_equal(O.merge_images(O.ULL, p, full, want), full), w0
+    print("configs[4] full size: %d reads, %.3e k-mers; device time pack %.1f + sketch %.1f + finalize %.1f ms over %d calls"
+          % (n_reads, ta["kmers"], ta["pack_ms"], ta["sketch_ms"], ta["finalize_ms"], ta["calls"]))
