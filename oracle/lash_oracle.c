@@ -101,38 +101,89 @@ uint64_t lash_or_mask_bits(uint64_t v, int k)
 }
 
 /* ------------------------------------------------------------------------------------------
- * kmerutils 0.0.14 restated [UNPINNED, switch U5]: Alphabet2b A=0 C=1 G=2 T=3; Sequence::new(.,2)
- * packs 4 bases per byte; k-mers are built by shift-left-and-OR (first base most significant);
- * reverse_complement = reverse the 2-bit groups, complement (3-b), right-align to 2k bits;
- * Ord compares the packed value.  All of U5 lives in base_code(), kseq_*() and revcomp().
+ * The layout: every unverified crate-internal choice as data (lash_oracle.h)
  * ---------------------------------------------------------------------------------------- */
-static inline unsigned base_code(uint8_t c)
+static const lash_or_layout DEFAULT_LAYOUT = { {0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l" };
+static inline const lash_or_layout *lay_of(const lash_or_params *prm) { return prm->layout ? prm->layout : &DEFAULT_LAYOUT; }
+
+void lash_or_layout_default(lash_or_layout *out) { *out = DEFAULT_LAYOUT; }
+
+static size_t field_bytes(char c)
 {
-    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; default: return 3; /* 'T' */ }
+    switch (c) {
+    case 'a': case 'z': case 's': case 'Q': case 'l': return 8;
+    case 'Z': case 'P': case 'L': return 4;
+    case 'p': return 1;
+    default: return (size_t)-1;
+    }
+}
+static size_t header_len(const char *tpl)
+{
+    size_t n = 0;
+    for (int i = 0; i < 8 && tpl[i]; i++) n += field_bytes(tpl[i]);
+    return n;
+}
+static const char *header_tpl(const lash_or_layout *lay, int algo)
+{
+    return algo == LASH_OR_HMH ? lay->hmh_header : algo == LASH_OR_HLL ? lay->hll_header : lay->ull_header;
+}
+size_t lash_or_header_bytes(const lash_or_layout *lay, int algo) { return header_len(header_tpl(lay ? lay : &DEFAULT_LAYOUT, algo)); }
+
+int lash_or_layout_check(const lash_or_layout *lay)
+{
+    unsigned seen = 0;
+    for (int i = 0; i < 4; i++) { if (lay->base_code[i] > 3) return -1; seen |= 1u << lay->base_code[i]; }
+    if (seen != 15u) return -1;
+    if ((lay->base_code[0] ^ lay->base_code[3]) != (lay->base_code[1] ^ lay->base_code[2])) return -1;   /* always true for a permutation */
+    const char *t[3] = { lay->hmh_header, lay->hll_header, lay->ull_header };
+    for (int a = 0; a < 3; a++) {
+        int i = 0;
+        for (; i < 8 && t[a][i]; i++) if (field_bytes(t[a][i]) == (size_t)-1) return -1;
+        if (i == 8) return -1;                                           /* must be NUL-terminated inside its 8 bytes */
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * kmerutils 0.0.14 restated [UNPINNED, switch U5 = layout.base_code / layout.kmer_lsb_first]: Alphabet2b
+ * A=0 C=1 G=2 T=3; Sequence::new(.,2) packs 4 bases per byte; k-mers are built by shift-left-and-OR (first
+ * base most significant); reverse_complement = reverse the 2-bit groups, complement, right-align to 2k bits;
+ * Ord compares the packed value.
+ * ---------------------------------------------------------------------------------------- */
+static inline unsigned base_code(const lash_or_layout *lay, uint8_t c)
+{
+    switch (c) { case 'A': return lay->base_code[0]; case 'C': return lay->base_code[1]; case 'G': return lay->base_code[2];
+    default: return lay->base_code[3]; /* 'T' */ }
 }
 
 typedef struct { uint8_t *bytes; size_t n_bases; } kseq_t;   /* KSeq::new(&seq, 2) */
 
-static void kseq_pack(kseq_t *ks, const uint8_t *filtered, size_t n)
+static void kseq_pack(const lash_or_layout *lay, kseq_t *ks, const uint8_t *filtered, size_t n)
 {
     ks->n_bases = n;
     ks->bytes = (uint8_t *)calloc((n + 3) / 4 + 1, 1);
     for (size_t i = 0; i < n; i++)
-        ks->bytes[i >> 2] |= (uint8_t)(base_code(filtered[i]) << (6 - 2 * (i & 3)));
+        ks->bytes[i >> 2] |= (uint8_t)(base_code(lay, filtered[i]) << (6 - 2 * (i & 3)));
 }
 static inline unsigned kseq_get(const kseq_t *ks, size_t i)
 {
     return (ks->bytes[i >> 2] >> (6 - 2 * (i & 3))) & 3u;
 }
 
-static inline uint64_t revcomp(uint64_t v, int k)
+/* order of the k 2-bit groups reversed, nothing complemented: plain loop on purpose (the GPU uses bit tricks) */
+static inline uint64_t groups_reversed(uint64_t v, int k)
 {
-    /* complement every 2-bit group, reverse group order inside the 64-bit word, right-align */
-    uint64_t x = ~v;
-    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
-    x = __builtin_bswap64(x);
-    return x >> (64 - 2 * k);
+    uint64_t o = 0;
+    for (int i = 0; i < k; i++) { o = (o << 2) | (v & 3u); v >>= 2; }
+    return o;
+}
+/* complement every base (code -> code of the complementary letter: A<->T, C<->G), reverse their order */
+static inline uint64_t revcomp(const lash_or_layout *lay, uint64_t v, int k)
+{
+    const unsigned cx = (unsigned)(lay->base_code[0] ^ lay->base_code[3]);      /* == code[C] ^ code[G] */
+    uint64_t o = 0;
+    for (int i = 0; i < k; i++) { o = (o << 2) | ((v & 3u) ^ cx); v >>= 2; }
+    return o;
 }
 
 typedef void (*kmer_sink)(void *ctx, uint64_t masked);
@@ -140,17 +191,18 @@ typedef void (*kmer_sink)(void *ctx, uint64_t masked);
 /* The `while let Some(km) = it.next()` loops, utils.rs:469-476 / 481-488 / 493-498.
  * The three container types differ only in width; min() and mask_bits() see the same numbers
  * (Kmer32bit's 4-bit length tag is equal on both sides of min() and removed by mask_bits). */
-static uint64_t iterate_kmers(const kseq_t *ks, int k, kmer_sink sink, void *ctx, uint64_t *out)
+static uint64_t iterate_kmers(const lash_or_layout *lay, const kseq_t *ks, int k, kmer_sink sink, void *ctx, uint64_t *out)
 {
     size_t L = ks->n_bases;
     if (L < (size_t)k) return 0;
     uint64_t kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
     uint64_t fwd = 0, count = 0;
     for (size_t i = 0; i < L; i++) {
-        fwd = ((fwd << 2) | kseq_get(ks, i)) & kmask;           /* iterator advance */
+        fwd = ((fwd << 2) | kseq_get(ks, i)) & kmask;           /* window with the first base most significant */
         if (i + 1 < (size_t)k) continue;
-        uint64_t rc = revcomp(fwd, k);                           /* km.reverse_complement() */
-        uint64_t canon = fwd < rc ? fwd : rc;                    /* km.min(rc) */
+        uint64_t km = lay->kmer_lsb_first ? groups_reversed(fwd, k) : fwd;   /* the iterator's value (switch U5) */
+        uint64_t rc = revcomp(lay, km, k);                       /* km.reverse_complement() */
+        uint64_t canon = km < rc ? km : rc;                      /* km.min(rc) */
         uint64_t masked;
         if (k <= 14 || k == 16)                                  /* u32 containers (utils.rs:471-474,483-486) */
             masked = lash_or_mask_bits((uint64_t)(uint32_t)canon, k);
@@ -171,8 +223,8 @@ uint64_t lash_or_record_kmers(const uint8_t *seq, size_t n, int k, uint64_t *out
     uint64_t cnt = 0;
     if (m >= (size_t)k) {                                        /* utils.rs:460-462 */
         kseq_t ks;
-        kseq_pack(&ks, filt, m);                                 /* utils.rs:464 */
-        cnt = iterate_kmers(&ks, k, NULL, NULL, out);
+        kseq_pack(&DEFAULT_LAYOUT, &ks, filt, m);                /* utils.rs:464 */
+        cnt = iterate_kmers(&DEFAULT_LAYOUT, &ks, k, NULL, NULL, out);
         free(ks.bytes);
     }
     free(filt);
@@ -190,6 +242,7 @@ typedef struct {
     int algo, p;
     uint64_t seed;
     int hmh_x_is_low;
+    const lash_or_layout *lay;
     uint16_t *hmh;     /* hyperminhash::Sketch: 16384 x u16            [UNPINNED, A.2] */
     uint8_t *reg;      /* HLL m[] / ULL state[]: 2^p x u8              [UNPINNED, A.3/A.4] */
     uint64_t hll_zero; /* streaming_algorithms HyperLogLog.zero        */
@@ -231,8 +284,9 @@ static void hll_add_kmer(void *ctx, uint64_t masked)
 {
     sketch_t *s = (sketch_t *)ctx;
     uint64_t x = lash_or_xxh3_64_8b(masked, s->seed);
-    uint64_t j = x & ((1ULL << s->p) - 1);
-    uint64_t w = x >> s->p;
+    uint64_t j, w;
+    if (!s->lay->hll_bucket_high) { j = x & ((1ULL << s->p) - 1); w = x >> s->p; }            /* upstream `push` */
+    else { j = x >> (64 - s->p); w = x & (~0ULL >> s->p); }                                     /* switch U3, alternative */
     unsigned bitlen = w ? 64u - (unsigned)__builtin_clzll(w) : 0u;
     uint8_t rho = (uint8_t)((64 - s->p) - bitlen + 1);           /* 1..=65-p */
     uint8_t old = s->reg[j];
@@ -282,19 +336,22 @@ static int check_params(int algo, int k, int p)
     return -1;                                                   /* main.rs:245 */
 }
 
-size_t lash_or_image_bytes(int algo, int p)
+size_t lash_or_image_bytes_layout(const lash_or_layout *lay, int algo, int p)
 {
+    if (!lay) lay = &DEFAULT_LAYOUT;
+    const size_t hdr = header_len(header_tpl(lay, algo));
     switch (algo) {
-    case LASH_OR_HMH: return (size_t)HMH_M * 2;                   /* U2: 16384 x u16 LE, no header */
-    case LASH_OR_HLL: return 33 + ((size_t)1 << p);               /* U3: bincode(alpha,zero,sum,p,len,m) */
-    case LASH_OR_ULL: return 8 + ((size_t)1 << p);                /* U4: bincode(Vec<u8>) = u64 len + bytes */
+    case LASH_OR_HMH: return hdr + (size_t)HMH_M * 2;             /* U2: header + 16384 x u16 */
+    case LASH_OR_HLL: return hdr + ((size_t)1 << p);              /* U3: bincode(alpha,zero,sum,p,len) + m */
+    case LASH_OR_ULL: return hdr + ((size_t)1 << p);              /* U4: bincode(Vec<u8>) = u64 len + bytes */
     default: return 0;
     }
 }
+size_t lash_or_image_bytes(int algo, int p) { return lash_or_image_bytes_layout(&DEFAULT_LAYOUT, algo, p); }
 
+static void put_u32(uint8_t *dst, uint32_t v) { for (int i = 0; i < 4; i++) dst[i] = (uint8_t)(v >> (8 * i)); }
 static void put_u64(uint8_t *dst, uint64_t v) { for (int i = 0; i < 8; i++) dst[i] = (uint8_t)(v >> (8 * i)); }
 static void put_f64(uint8_t *dst, double d) { uint64_t b; memcpy(&b, &d, 8); put_u64(dst, b); }
-static uint64_t get_u64(const uint8_t *src) { uint64_t v = 0; for (int i = 0; i < 8; i++) v |= (uint64_t)src[i] << (8 * i); return v; }
 
 static double hll_alpha(int p)
 {
@@ -302,31 +359,55 @@ static double hll_alpha(int p)
     default: return 0.7213 / (1.0 + 1.079 / (double)(1u << p)); }
 }
 
-static void hmh_save(const uint16_t *regs, uint8_t *image)       /* U2 */
+/* writes the header the template describes, returns its length (switches U2-U4) */
+static size_t write_header(const char *tpl, uint8_t *image, int p, uint64_t n_regs, uint64_t zero, double sum)
 {
-    for (uint32_t i = 0; i < HMH_M; i++) { image[2 * i] = (uint8_t)regs[i]; image[2 * i + 1] = (uint8_t)(regs[i] >> 8); }
+    size_t at = 0;
+    for (int i = 0; i < 8 && tpl[i]; i++) {
+        switch (tpl[i]) {
+        case 'a': put_f64(image + at, hll_alpha(p)); break;
+        case 'z': put_u64(image + at, zero); break;
+        case 'Z': put_u32(image + at, (uint32_t)zero); break;
+        case 's': put_f64(image + at, sum); break;
+        case 'p': image[at] = (uint8_t)p; break;
+        case 'P': put_u32(image + at, (uint32_t)p); break;
+        case 'Q': put_u64(image + at, (uint64_t)p); break;
+        case 'l': put_u64(image + at, n_regs); break;
+        case 'L': put_u32(image + at, (uint32_t)n_regs); break;
+        }
+        at += field_bytes(tpl[i]);
+    }
+    return at;
 }
-static void hll_save(int p, const uint8_t *m, uint64_t zero, double sum, uint8_t *image)   /* U3 */
+
+static void hmh_save(const lash_or_layout *lay, const uint16_t *regs, uint8_t *image)       /* U2 */
+{
+    image += write_header(lay->hmh_header, image, HMH_P, HMH_M, 0, 0.0);
+    for (uint32_t i = 0; i < HMH_M; i++) {
+        const uint8_t lo = (uint8_t)regs[i], hi = (uint8_t)(regs[i] >> 8);
+        image[2 * i] = lay->hmh_reg_be ? hi : lo;
+        image[2 * i + 1] = lay->hmh_reg_be ? lo : hi;
+    }
+}
+static void hll_save(const lash_or_layout *lay, int p, const uint8_t *m, uint64_t zero, double sum, uint8_t *image)   /* U3 */
 {
     size_t n = (size_t)1 << p;
-    put_f64(image + 0, hll_alpha(p));
-    put_u64(image + 8, zero);
-    put_f64(image + 16, sum);
-    image[24] = (uint8_t)p;
-    put_u64(image + 25, (uint64_t)n);
-    memcpy(image + 33, m, n);
+    image += write_header(lay->hll_header, image, p, n, zero, sum);
+    memcpy(image, m, n);
 }
-static void ull_save(int p, const uint8_t *state, uint8_t *image)   /* U4 */
+static void ull_save(const lash_or_layout *lay, int p, const uint8_t *state, uint8_t *image)   /* U4 */
 {
     size_t n = (size_t)1 << p;
-    put_u64(image, (uint64_t)n);
-    memcpy(image + 8, state, n);
+    image += write_header(lay->ull_header, image, p, n, 0, 0.0);
+    memcpy(image, state, n);
 }
 
 static int sketch_new(sketch_t *s, const lash_or_params *prm)
 {
     memset(s, 0, sizeof *s);
-    s->algo = prm->algo; s->p = prm->p; s->seed = prm->seed; s->hmh_x_is_low = prm->hmh_x_is_low;
+    s->algo = prm->algo; s->p = prm->p; s->seed = prm->seed;
+    s->lay = lay_of(prm);
+    s->hmh_x_is_low = prm->hmh_x_is_low || s->lay->hmh_x_low;
     if (prm->algo == LASH_OR_HMH) {
         s->hmh = (uint16_t *)calloc(HMH_M, 2);                    /* Sketch::default() */
     } else {
@@ -367,7 +448,7 @@ int lash_or_sketch_genome(const lash_or_params *prm, const uint8_t *seq,
 static int sketch_genome_with(const lash_or_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
                               uint8_t *image, scratch_t *sc)
 {
-    if (check_params(prm->algo, prm->k, prm->p)) return -1;
+    if (check_params(prm->algo, prm->k, prm->p) || lash_or_layout_check(lay_of(prm))) return -1;
     sketch_t s;
     sketch_new(&s, prm);                                         /* utils.rs:454 */
     kmer_sink sink = prm->algo == LASH_OR_HMH ? hmh_add_kmer : prm->algo == LASH_OR_HLL ? hll_add_kmer : ull_add_kmer;
@@ -382,13 +463,13 @@ static int sketch_genome_with(const lash_or_params *prm, const uint8_t *seq, con
             ks.bytes = sc->packed;
             memset(ks.bytes, 0, (m + 3) / 4 + 1);
             for (size_t i = 0; i < m; i++)
-                ks.bytes[i >> 2] |= (uint8_t)(base_code(sc->filt[i]) << (6 - 2 * (i & 3)));
-            iterate_kmers(&ks, prm->k, sink, &s, NULL);
+                ks.bytes[i >> 2] |= (uint8_t)(base_code(s.lay, sc->filt[i]) << (6 - 2 * (i & 3)));
+            iterate_kmers(s.lay, &ks, prm->k, sink, &s, NULL);
         }
     }
-    if (prm->algo == LASH_OR_HMH) hmh_save(s.hmh, image);
-    else if (prm->algo == LASH_OR_HLL) hll_save(s.p, s.reg, s.hll_zero, s.hll_sum, image);
-    else ull_save(s.p, s.reg, image);
+    if (prm->algo == LASH_OR_HMH) hmh_save(s.lay, s.hmh, image);
+    else if (prm->algo == LASH_OR_HLL) hll_save(s.lay, s.p, s.reg, s.hll_zero, s.hll_sum, image);
+    else ull_save(s.lay, s.p, s.reg, image);
     sketch_free(&s);
     return 0;
 }
@@ -422,7 +503,7 @@ int lash_or_sketch_genomes(const lash_or_params *prm, const uint8_t *seq, const 
     if (check_params(prm->algo, prm->k, prm->p)) return -1;
     if (threads < 1) threads = 1;
     volatile uint32_t next = 0;
-    mt_job job = { prm, seq, rec_off, genome_rec_off, n_genomes, images, lash_or_image_bytes(prm->algo, prm->p), &next, 0 };
+    mt_job job = { prm, seq, rec_off, genome_rec_off, n_genomes, images, lash_or_image_bytes_layout(lay_of(prm), prm->algo, prm->p), &next, 0 };
     if (threads == 1) { mt_worker(&job); return job.err; }
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
     mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)threads);
@@ -437,42 +518,170 @@ int lash_or_sketch_genomes(const lash_or_params *prm, const uint8_t *seq, const 
  * Union of serialized sketches (dist side: utils.rs:171 Sketch::union, :261 UltraLogLog::merge,
  * :357 HyperLogLog::union) — used by tests of the on-device merge.
  * ---------------------------------------------------------------------------------------- */
-int lash_or_merge_images(int algo, int p, const uint8_t *a, const uint8_t *b, uint8_t *out)
+int lash_or_merge_images_layout(const lash_or_layout *lay, int algo, int p, const uint8_t *a, const uint8_t *b, uint8_t *out)
 {
+    if (!lay) lay = &DEFAULT_LAYOUT;
+    const size_t hdr = header_len(header_tpl(lay, algo));
     if (algo == LASH_OR_HMH) {
+        uint16_t *regs = (uint16_t *)malloc(HMH_M * 2);
+        const int lo = lay->hmh_reg_be ? 1 : 0, hi = 1 - lo;
         for (uint32_t i = 0; i < HMH_M; i++) {
-            uint16_t x = (uint16_t)(a[2 * i] | (a[2 * i + 1] << 8)), y = (uint16_t)(b[2 * i] | (b[2 * i + 1] << 8));
-            uint16_t m = x > y ? x : y;
-            out[2 * i] = (uint8_t)m; out[2 * i + 1] = (uint8_t)(m >> 8);
+            uint16_t x = (uint16_t)(a[hdr + 2 * i + lo] | (a[hdr + 2 * i + hi] << 8));
+            uint16_t y = (uint16_t)(b[hdr + 2 * i + lo] | (b[hdr + 2 * i + hi] << 8));
+            regs[i] = x > y ? x : y;
         }
+        hmh_save(lay, regs, out);
+        free(regs);
         return 0;
     }
     size_t n = (size_t)1 << p;
     if (algo == LASH_OR_HLL) {
-        if (a[24] != p || b[24] != p || get_u64(a + 25) != n || get_u64(b + 25) != n) return -1;
         uint8_t *m = (uint8_t *)malloc(n);
         uint64_t zero = 0; double sum = 0.0;
         for (size_t i = 0; i < n; i++) {
-            m[i] = a[33 + i] > b[33 + i] ? a[33 + i] : b[33 + i];
+            m[i] = a[hdr + i] > b[hdr + i] ? a[hdr + i] : b[hdr + i];
             zero += (m[i] == 0);
             sum += pow2_neg(m[i]);
         }
-        hll_save(p, m, zero, sum, out);
+        hll_save(lay, p, m, zero, sum, out);
         free(m);
         return 0;
     }
     if (algo == LASH_OR_ULL) {
-        if (get_u64(a) != n || get_u64(b) != n) return -1;
-        put_u64(out, (uint64_t)n);
+        uint8_t *st = (uint8_t *)malloc(n);
         for (size_t i = 0; i < n; i++) {
-            uint8_t x = a[8 + i], y = b[8 + i];
-            if (x == 0) out[8 + i] = y;
-            else if (y == 0) out[8 + i] = x;
-            else out[8 + i] = ull_pack(ull_unpack(x) | ull_unpack(y));
+            uint8_t x = a[hdr + i], y = b[hdr + i];
+            if (x == 0) st[i] = y;
+            else if (y == 0) st[i] = x;
+            else st[i] = ull_pack(ull_unpack(x) | ull_unpack(y));
         }
+        ull_save(lay, p, st, out);
+        free(st);
         return 0;
     }
     return -1;
+}
+int lash_or_merge_images(int algo, int p, const uint8_t *a, const uint8_t *b, uint8_t *out)
+{
+    return lash_or_merge_images_layout(&DEFAULT_LAYOUT, algo, p, a, b, out);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * From file bytes: needletail 0.6.3's behaviour for uncompressed input as lash uses it
+ * (utils.rs:453-459) [UNPINNED: restated from needletail's documented format rules].
+ *   FASTA: a record is a '>' header line, then sequence lines up to the next line that starts with '>';
+ *          seq() strips '\n' and '\r'.  FASTQ: '@' header line, sequence line, '+' line, quality line of the
+ *          same length; a record that breaks this ends the iteration with an error (the loop keeps what came before).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { const lash_or_params *prm; sketch_t *s; scratch_t *sc; kmer_sink sink; } rec_ctx;
+
+static void sketch_record(rec_ctx *rc, const uint8_t *rec, size_t n)
+{
+    scratch_reserve(rc->sc, n);
+    size_t m = lash_or_filter_out_n(rec, n, rc->sc->filt);          /* utils.rs:459 */
+    if (m < (size_t)rc->prm->k) return;                             /* utils.rs:460-462 */
+    kseq_t ks;
+    ks.n_bases = m;
+    ks.bytes = rc->sc->packed;
+    memset(ks.bytes, 0, (m + 3) / 4 + 1);
+    for (size_t i = 0; i < m; i++)
+        ks.bytes[i >> 2] |= (uint8_t)(base_code(rc->s->lay, rc->sc->filt[i]) << (6 - 2 * (i & 3)));
+    iterate_kmers(rc->s->lay, &ks, rc->prm->k, rc->sink, rc->s, NULL);
+}
+
+static const uint8_t *line_end(const uint8_t *p, const uint8_t *end)
+{
+    const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+    return nl ? nl : end;
+}
+
+static int sketch_file_with(const lash_or_params *prm, const uint8_t *buf, uint64_t len, uint8_t *image, scratch_t *sc)
+{
+    if (check_params(prm->algo, prm->k, prm->p) || lash_or_layout_check(lay_of(prm))) return -1;
+    if (len == 0 || (buf[0] != '>' && buf[0] != '@')) return -2;    /* parse_fastx_file(..).expect("Invalid input file") */
+    sketch_t s;
+    sketch_new(&s, prm);
+    rec_ctx rc = { prm, &s, sc, prm->algo == LASH_OR_HMH ? hmh_add_kmer : prm->algo == LASH_OR_HLL ? hll_add_kmer : ull_add_kmer };
+    const uint8_t *p = buf, *end = buf + len;
+    uint8_t *joined = NULL; size_t joined_cap = 0;
+    if (buf[0] == '>') {
+        while (p < end) {
+            const uint8_t *e = line_end(p, end);                    /* header line */
+            p = e < end ? e + 1 : end;
+            size_t n = 0;
+            while (p < end && *p != '>') {                           /* sequence lines, joined without line ends */
+                e = line_end(p, end);
+                size_t ll = (size_t)(e - p);
+                while (ll && p[ll - 1] == '\r') ll--;
+                if (joined_cap < n + ll + 1) { joined_cap = (n + ll + 1) * 2; joined = (uint8_t *)realloc(joined, joined_cap); }
+                memcpy(joined + n, p, ll);
+                n += ll;
+                p = e < end ? e + 1 : end;
+            }
+            sketch_record(&rc, joined ? joined : buf, n);
+        }
+    } else {
+        while (p < end) {
+            if (*p != '@') break;                                    /* malformed: iteration ends */
+            const uint8_t *e = line_end(p, end);
+            if (e >= end) break;
+            const uint8_t *sq = e + 1, *se = line_end(sq, end);
+            if (se >= end) break;
+            const uint8_t *pl = se + 1;
+            if (pl >= end || *pl != '+') break;
+            const uint8_t *pe = line_end(pl, end);
+            if (pe >= end) break;
+            const uint8_t *ql = pe + 1, *qe = line_end(ql, end);
+            size_t sl = (size_t)(se - sq), qn = (size_t)(qe - ql);
+            while (sl && sq[sl - 1] == '\r') sl--;
+            while (qn && ql[qn - 1] == '\r') qn--;
+            if (sl != qn) break;                                     /* sequence and quality lengths differ */
+            sketch_record(&rc, sq, sl);
+            p = qe < end ? qe + 1 : end;
+        }
+    }
+    free(joined);
+    if (prm->algo == LASH_OR_HMH) hmh_save(s.lay, s.hmh, image);
+    else if (prm->algo == LASH_OR_HLL) hll_save(s.lay, s.p, s.reg, s.hll_zero, s.hll_sum, image);
+    else ull_save(s.lay, s.p, s.reg, image);
+    sketch_free(&s);
+    return 0;
+}
+
+typedef struct {
+    const lash_or_params *prm; const uint8_t *const *bufs; const uint64_t *lens;
+    uint32_t n_files; uint8_t *images; size_t image_bytes; volatile uint32_t *next; int err;
+} file_job;
+
+static void *file_worker(void *arg)
+{
+    file_job *j = (file_job *)arg;
+    scratch_t sc = {0};
+    for (;;) {
+        uint32_t f = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED);
+        if (f >= j->n_files) break;
+        int rc = sketch_file_with(j->prm, j->bufs[f], j->lens[f], j->images + (size_t)f * j->image_bytes, &sc);
+        if (rc) j->err = rc;
+    }
+    scratch_free(&sc);
+    return NULL;
+}
+
+int lash_or_sketch_file_buffers(const lash_or_params *prm, const uint8_t *const *bufs, const uint64_t *lens,
+                                uint32_t n_files, uint8_t *images, int threads)
+{
+    if (check_params(prm->algo, prm->k, prm->p)) return -1;
+    if (threads < 1) threads = 1;
+    volatile uint32_t next = 0;
+    file_job job = { prm, bufs, lens, n_files, images, lash_or_image_bytes_layout(lay_of(prm), prm->algo, prm->p), &next, 0 };
+    if (threads == 1) { file_worker(&job); return job.err; }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    file_job *jobs = (file_job *)malloc(sizeof(file_job) * (size_t)threads);
+    for (int t = 0; t < threads; t++) { jobs[t] = job; pthread_create(&th[t], NULL, file_worker, &jobs[t]); }
+    int err = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); if (jobs[t].err) err = jobs[t].err; }
+    free(th); free(jobs);
+    return err;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -58,14 +58,36 @@ def filter_out_n(seq: str) -> str:
     return "".join(c for c in seq if c in "ACGT")
 
 
-def pack(kmer: str) -> int:
+class Lay:
+    """SURVEY App. D's unknowns as data (mirrors oracle_lib.make_layout's keyword arguments)."""
+
+    def __init__(self, codes="ACGT", kmer="msb", hmh_x="high", hmh_reg="le", hll_bucket="low", hmh_hdr="", hll_hdr="azspl",
+                 ull_hdr="l"):
+        self.code = {letter: c for c, letter in enumerate(codes)}
+        self.lsb_first = kmer == "lsb"
+        self.x_low = hmh_x == "low"
+        self.reg_be = hmh_reg == "be"
+        self.bucket_high = hll_bucket == "high"
+        self.hdr = {"hmh": hmh_hdr, "hll": hll_hdr, "ull": ull_hdr}
+
+    def header(self, algo, p, n_regs, zero=0, tot=0.0):
+        alpha = {4: 0.673, 5: 0.697, 6: 0.709}.get(p, 0.7213 / (1.0 + 1.079 / (1 << p)))
+        enc = {"a": ("<d", alpha), "z": ("<Q", zero), "Z": ("<I", zero), "s": ("<d", tot), "p": ("<B", p), "P": ("<I", p),
+               "Q": ("<Q", p), "l": ("<Q", n_regs), "L": ("<I", n_regs)}
+        return b"".join(struct.pack(*enc[c]) for c in self.hdr[algo])
+
+
+DEFAULT = Lay()
+
+
+def pack(kmer: str, lay=DEFAULT) -> int:
     v = 0
-    for c in kmer:
-        v = (v << 2) | CODE[c]
+    for c in (reversed(kmer) if lay.lsb_first else kmer):      # lsb-first: the first base ends up in the lowest bits
+        v = (v << 2) | lay.code[c]
     return v
 
 
-def canonical_kmers(record: str, k: int):
+def canonical_kmers(record: str, k: int, lay=DEFAULT):
     s = filter_out_n(record)
     if len(s) < k:
         return []
@@ -73,7 +95,7 @@ def canonical_kmers(record: str, k: int):
     for i in range(len(s) - k + 1):
         km = s[i:i + k]
         rc = "".join(COMP[c] for c in reversed(km))
-        canon = min(pack(km), pack(rc))
+        canon = min(pack(km, lay), pack(rc, lay))
         if k <= 14 or k == 16:
             canon &= 0xFFFFFFFF
         if 2 * k < 64:
@@ -86,33 +108,34 @@ def clz64(x):
     return 64 - x.bit_length()
 
 
-def hmh_sketch(records, k, seed, x_is_low=False):
+def hmh_sketch(records, k, seed, x_is_low=False, lay=DEFAULT):
     regs = [0] * 16384
     for rec in records:
-        for km in canonical_kmers(rec, k):
+        for km in canonical_kmers(rec, k, lay):
             lo, hi = xxh3_128_4b(km & 0xFFFFFFFF, seed)
-            x, y = (lo, hi) if x_is_low else (hi, lo)
+            x, y = (lo, hi) if (x_is_low or lay.x_low) else (hi, lo)
             bucket = x >> 50
             lz = clz64(((x << 14) & M64) ^ 0x3FFF) + 1
             reg = (lz << 10) | (y & 0x3FF)
             if regs[bucket] < reg:
                 regs[bucket] = reg
-    return b"".join(struct.pack("<H", r) for r in regs)
+    return lay.header("hmh", 14, 16384) + b"".join(struct.pack(">H" if lay.reg_be else "<H", r) for r in regs)
 
 
-def hll_sketch(records, k, p, seed):
+def hll_sketch(records, k, p, seed, lay=DEFAULT):
     m = [0] * (1 << p)
     for rec in records:
-        for km in canonical_kmers(rec, k):
+        for km in canonical_kmers(rec, k, lay):
             x = xxh3_64_8b(km, seed)
-            j = x & ((1 << p) - 1)
-            w = x >> p
+            if lay.bucket_high:
+                j, w = x >> (64 - p), x & ((1 << (64 - p)) - 1)
+            else:
+                j, w = x & ((1 << p) - 1), x >> p
             rho = (64 - p) - w.bit_length() + 1
             m[j] = max(m[j], rho)
     zero = sum(1 for r in m if r == 0)
     tot = sum(2.0 ** (-r) for r in m)
-    alpha = {4: 0.673, 5: 0.697, 6: 0.709}.get(p, 0.7213 / (1.0 + 1.079 / (1 << p)))
-    return struct.pack("<dQdBQ", alpha, zero, tot, p, 1 << p) + bytes(m)
+    return lay.header("hll", p, 1 << p, zero, tot) + bytes(m)
 
 
 def ull_unpack(r):
@@ -124,16 +147,16 @@ def ull_pack(x):
     return (top << 2) | ((x >> (top - 2)) & 3 if top >= 2 else (x << (2 - top)) & 3)
 
 
-def ull_sketch(records, k, p, seed):
+def ull_sketch(records, k, p, seed, lay=DEFAULT):
     st = [0] * (1 << p)
     for rec in records:
-        for km in canonical_kmers(rec, k):
+        for km in canonical_kmers(rec, k, lay):
             h = xxh3_64_8b(km, seed)
             idx = h >> (64 - p)
             t = (~((~h & M64) << p)) & M64
             nlz = clz64(t)
             st[idx] = ull_pack(ull_unpack(st[idx]) | (1 << (nlz + p - 1)))
-    return struct.pack("<Q", 1 << p) + bytes(st)
+    return lay.header("ull", p, 1 << p) + bytes(st)
 
 
 # ---- dist side: hyperminhash similarity as published by axiomhq/hyperminhash (the crate hyperminhash 0.1.4 ports it)

@@ -166,3 +166,63 @@ def test_fixture_digests():
         seq, off = _as_arrays(recs)
         img = O.sketch_genomes(algos[an], int(k[1:]), int(p[1:]), 42, seq, off, np.array([0, len(recs)], np.uint64))[0]
         assert hashlib.sha256(img.tobytes()).hexdigest() == dig, key
+
+
+# ---- the layout switches: every alternative the C oracle implements is cross-checked against the
+# naive Python restatement, so that tools/ref_probe/fit_layout.py searches a space whose every point is independently stated
+ALT_LAYOUTS = [
+    dict(codes="ACTG"), dict(codes="TGCA", kmer="lsb"), dict(kmer="lsb"), dict(hmh_x="low", hmh_reg="be", hmh_hdr="l"),
+    dict(hll_bucket="high", hll_hdr="pzsal"), dict(hll_hdr="PZ", ull_hdr="pL"), dict(ull_hdr="", hmh_hdr="Q", codes="GATC"),
+]
+
+
+@pytest.mark.parametrize("li", range(len(ALT_LAYOUTS)))
+@pytest.mark.parametrize("algo,k,p", [(O.HMH, 16, 0), (O.HMH, 11, 0), (O.HMH, 27, 0), (O.HLL, 21, 10), (O.ULL, 16, 9), (O.ULL, 32, 5)])
+def test_layout_alternatives_match_pyref(li, algo, k, p):
+    kw = ALT_LAYOUTS[li]
+    lay, rlay = O.make_layout(**kw), R.Lay(**kw)
+    rng = random.Random(100 * li + k)
+    recs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(0, 300))) for _ in range(4)]
+    recs[1] = recs[1][:20] + "NnRY" + recs[1][20:]
+    seq, off = _as_arrays([r.encode() for r in recs])
+    img = O.sketch_genomes(algo, k, p, 42, seq, off, np.array([0, len(recs)], np.uint64), layout=lay)[0].tobytes()
+    want = (R.hmh_sketch(recs, k, 42, lay=rlay) if algo == O.HMH else
+            R.hll_sketch(recs, k, p, 42, lay=rlay) if algo == O.HLL else R.ull_sketch(recs, k, p, 42, lay=rlay))
+    assert img == want
+    assert len(img) == O.image_bytes(algo, p, lay)
+    # union through the same layout
+    parts = O.sketch_genomes(algo, k, p, 42, seq, off, np.array([0, 2, len(recs)], np.uint64), layout=lay)
+    assert O.merge_images(algo, p, parts[0], parts[1], layout=lay).tobytes() == img
+    assert O.parse_layout(lay.spec()).spec() == lay.spec()
+
+
+def test_default_layout_is_the_survey_hypothesis():
+    d = O.default_layout()
+    assert d.spec() == "codes=ACGT,kmer=msb,hmh_x=high,hmh_reg=le,hll_bucket=low,hmh_hdr=,hll_hdr=azspl,ull_hdr=l"
+    assert O.header_bytes(O.HMH) == 0 and O.header_bytes(O.HLL) == 33 and O.header_bytes(O.ULL) == 8
+    bad = O.make_layout()
+    bad.base_code[0] = 1                                    # A and C share a code: not a permutation
+    assert O.lib.lash_or_layout_check(bad) != 0
+    with pytest.raises(ValueError):
+        O.sketch_genomes(O.HMH, 16, 0, 42, np.frombuffer(b"ACGT" * 9, np.uint8), np.array([0, 36], np.uint64),
+                         np.array([0, 1], np.uint64), layout=bad)
+
+
+def test_file_buffers_equal_parsed_records():
+    """lash_or_sketch_file_buffers (the oracle's needletail-like parse) == host parse (tests/fastx.py) + record path."""
+    files = []
+    for name in ("fixture_A.fasta", "fixture_B.fasta", "fixture_C.fasta", "fixture_B40.fastq"):
+        files.append(open(os.path.join(GOLD, name), "rb").read())
+    for algo, k, p in [(O.HMH, 16, 0), (O.HLL, 21, 12), (O.ULL, 31, 10)]:
+        got = O.sketch_files(algo, k, p, 42, files, threads=3)
+        for i, name in enumerate(("fixture_A.fasta", "fixture_B.fasta", "fixture_C.fasta", "fixture_B40.fastq")):
+            recs = read_fastx(os.path.join(GOLD, name))
+            seq, off = _as_arrays(recs)
+            want = O.sketch_genomes(algo, k, p, 42, seq, off, np.array([0, len(recs)], np.uint64))[0]
+            assert np.array_equal(got[i], want), (name, algo)
+    with pytest.raises(ValueError):
+        O.sketch_files(O.HMH, 16, 0, 42, [b"\n>late header\nACGT\n"])         # first byte must be '>' or '@'
+    # a malformed FASTQ record ends the iteration; what came before is kept (utils.rs:457 `while let Some(Ok(..))`)
+    good = b"@a\nACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIII\n"
+    broken = good + b"@b\nACGTACGTACGTACGTACGTAA\n+\nIII\n" + good.replace(b"ACGTACGT", b"TTTTGGGG")
+    assert np.array_equal(O.sketch_files(O.HMH, 16, 0, 42, [broken]), O.sketch_files(O.HMH, 16, 0, 42, [good]))
