@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LASH_ABI_VERSION 1
+#define LASH_ABI_VERSION 2
 
 /* error codes */
 #define LASH_OK       0
@@ -40,7 +40,8 @@ extern "C" {
 #define LASH_ULL 2
 
 /* flags */
-#define LASH_F_HMH_X_LOW   1u  /* SURVEY App. D switch U1: take x (bucket, lz) from the LOW 64 bits of xxh3_128 */
+#define LASH_F_HMH_X_LOW   1u  /* SURVEY App. D switch U1: take x (bucket, lz) from the LOW 64 bits of xxh3_128
+                                  (per call; OR-ed with the context layout's hmh_x_low) */
 #define LASH_F_ACCUMULATE  2u  /* out_images already hold sketches of the same algo/p: union the new ones in */
 #define LASH_F_NO_DIRECT   4u  /* lash_sketch_batch[_device]: always pack first.  By default the sketch kernel first reads
                                   the record bytes itself, which is exact while a genome holds only upper-case ACGT
@@ -58,6 +59,26 @@ typedef struct {
     uint32_t flags;   /* LASH_F_*                                                              */
     uint64_t seed;    /* -s (main.rs:88-95); handed to xxh3 exactly as utils.rs:397,412,428 do  */
 } lash_params;
+
+/* ---- layout: the crate-internal rules of the reference's dependencies, as data ----------------------------------------
+ * lash's k-mer values, register rules and `save` bytes are fixed inside kmerutils 0.0.14, hyperminhash 0.1.4,
+ * streaming_algorithms 0.3.3 and ultraloglog 0.1.6 (Cargo.lock:917,713,1834,2012; called at utils.rs:397,412,428,464-499
+ * and 401,416,432).  Those crates are not in the reference tree, so each rule that could not be verified here (SURVEY App. D,
+ * U1-U5) is ONE field of this struct; the default is the hypothesis of SURVEY App. A.  tools/ref_probe/ produces images with
+ * the real `lash` and fits this struct to them; a mismatch is then a field change, not a code change.
+ * Header templates are strings of field codes written before the register array, all little-endian (bincode fixint):
+ *   'a' alpha f64 | 'z' zero u64 | 'Z' zero u32 | 's' sum f64 | 'p' p u8 | 'P' p u32 | 'Q' p u64 |
+ *   'l' register count u64 | 'L' register count u32 */
+typedef struct {
+    uint8_t base_code[4];     /* U5  2-bit codes of 'A','C','G','T' (a permutation of 0..3)                 {0,1,2,3} */
+    uint8_t kmer_lsb_first;   /* U5  0: a k-mer's first base is its MOST significant 2 bits; 1: least                0 */
+    uint8_t hmh_x_low;        /* U1  0: x (bucket, lz) = high 64 bits of xxh3_128, y = low; 1: swapped               0 */
+    uint8_t hmh_reg_be;       /* U2  HyperMinHash registers saved as u16 little- (0) or big-endian (1)               0 */
+    uint8_t hll_bucket_high;  /* U3  0: HLL bucket = low p bits of the hash, rho from the rest; 1: top p bits        0 */
+    char    hmh_header[8];    /* U2  ""       */
+    char    hll_header[8];    /* U3  "azspl"  */
+    char    ull_header[8];    /* U4  "l"      */
+} lash_layout;                /* 32 bytes */
 
 /* Sums over every sketch call since lash_ctx_enable_timing(ctx, 1) (HIP events on the ctx stream). */
 typedef struct {
@@ -96,7 +117,19 @@ void        lash_host_free_pinned(void *p);
 
 /* ---- parameters / sizes (host only, no GPU needed) -------------------------------------------------------- */
 int         lash_params_check(const lash_params *prm);     /* LASH_OK or LASH_EINVAL */
-size_t      lash_sketch_image_bytes(int algo, int p);      /* bytes S::save writes per sketch; 0 if invalid */
+size_t      lash_sketch_image_bytes(int algo, int p);      /* bytes S::save writes per sketch (default layout); 0 if invalid */
+
+/* ---- layout (host only) ------------------------------------------------------------------------------------------ */
+void        lash_layout_default(lash_layout *out);
+int         lash_layout_check(const lash_layout *lay);     /* LASH_OK or LASH_EINVAL */
+/* "key=value,..." on top of the default: codes=ACGT (the four letters in code order) kmer=msb|lsb hmh_x=high|low
+ * hmh_reg=le|be hll_bucket=low|high hmh_hdr= hll_hdr=azspl ull_hdr=l.  NULL / "" = the default. */
+int         lash_layout_parse(const char *spec, lash_layout *out);
+size_t      lash_layout_header_bytes(const lash_layout *lay, int algo);
+size_t      lash_layout_image_bytes(const lash_layout *lay, int algo, int p);   /* lay NULL = default; 0 if invalid */
+/* Every entry below that reads or writes images through `ctx` uses the context's layout (default until set). */
+int         lash_ctx_set_layout(lash_ctx *ctx, const lash_layout *lay);         /* NULL = back to the default */
+int         lash_ctx_get_layout(lash_ctx *ctx, lash_layout *out);
 
 /* ---- the hot path --------------------------------------------------------------------------------------- */
 /* Replaces the body of files.par_iter().map(...) (utils.rs:450-509) for a batch of files ("genomes").

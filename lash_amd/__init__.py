@@ -4,10 +4,12 @@ The product is lash_amd/liblash_gfx950.so (HIP kernels + C ABI, include/lash_gfx
 lash_amd/csrc/host.  This Python package is the thin binding used by tests/ and bench.py: it owns no algorithm and
 has no CPU fallback.
 """
-from ._lib import (EHIP, EINVAL, ELIMIT, ENODEV, ENOMEM, F_ACCUMULATE, F_HMH_X_LOW, F_NO_DIRECT, HLL, HMH, OK, ULL, Params, Timing,
-                   load)
-from .sketch import ALGOS, Context, LashError, Packed, image_bytes, params_check, records_to_arrays
+from ._lib import (EHIP, EINVAL, ELIMIT, ENODEV, ENOMEM, F_ACCUMULATE, F_HMH_X_LOW, F_NO_DIRECT, HLL, HMH, OK, ULL, Layout, Params,
+                   Timing, load)
+from .sketch import (ALGOS, Context, LashError, Packed, header_bytes, image_bytes, params_check, parse_layout,
+                     records_to_arrays)
 
-__all__ = ["ALGOS", "Context", "LashError", "Packed", "Params", "Timing", "image_bytes", "params_check",
+__all__ = ["ALGOS", "Context", "LashError", "Layout", "Packed", "Params", "Timing", "header_bytes", "image_bytes", "params_check",
+           "parse_layout",
            "records_to_arrays", "load", "HMH", "HLL", "ULL", "F_ACCUMULATE", "F_HMH_X_LOW", "F_NO_DIRECT", "OK", "EINVAL", "ENODEV",
            "EHIP", "ENOMEM", "ELIMIT"]

@@ -13,11 +13,18 @@ OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT = 0, -1, -2, -3, -4, -5
 HMH, HLL, ULL = 0, 1, 2
 F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT = 1, 2, 4
 FMT_FASTA, FMT_FASTQ = 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Params(C.Structure):
     _fields_ = [("algo", C.c_int32), ("k", C.c_int32), ("p", C.c_int32), ("flags", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class Layout(C.Structure):
+    """lash_layout: the reference's crate-internal rules as data."""
+    _fields_ = [("base_code", C.c_uint8 * 4), ("kmer_lsb_first", C.c_uint8), ("hmh_x_low", C.c_uint8),
+                ("hmh_reg_be", C.c_uint8), ("hll_bucket_high", C.c_uint8),
+                ("hmh_header", C.c_char * 8), ("hll_header", C.c_char * 8), ("ull_header", C.c_char * 8)]
 
 
 class Timing(C.Structure):
@@ -29,6 +36,7 @@ class Timing(C.Structure):
 
 _vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
 _PP = C.POINTER(Params)
+_LP = C.POINTER(Layout)
 
 # name -> (restype, argtypes); must list every function include/lash_gfx950.h declares (tests check this)
 PROTOTYPES = {
@@ -46,6 +54,13 @@ PROTOTYPES = {
     "lash_host_free_pinned": (None, [_vp]),
     "lash_params_check": (_int, [_PP]),
     "lash_sketch_image_bytes": (C.c_size_t, [_int, _int]),
+    "lash_layout_default": (None, [_LP]),
+    "lash_layout_check": (_int, [_LP]),
+    "lash_layout_parse": (_int, [C.c_char_p, _LP]),
+    "lash_layout_header_bytes": (C.c_size_t, [_LP, _int]),
+    "lash_layout_image_bytes": (C.c_size_t, [_LP, _int, _int]),
+    "lash_ctx_set_layout": (_int, [_vp, _LP]),
+    "lash_ctx_get_layout": (_int, [_vp, _LP]),
     "lash_sketch_batch": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),
     "lash_sketch_batch_device": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
     "lash_sketch_files_raw": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),

@@ -29,9 +29,19 @@ constexpr int HSTRIDE = HT + 4;        // LDS row (one word of 64 sketches), pad
 
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
-__global__ void __launch_bounds__(256) hmh_pairs_kernel(const uint32_t *__restrict__ ref, uint32_t n_ref,
-                                                        const uint32_t *__restrict__ qry, uint32_t n_qry,
-                                                        uint32_t *__restrict__ out_c, uint32_t *__restrict__ out_n)
+// Images: `hdr` bytes of header, then 16384 u16 registers; consecutive images `stride` bytes apart.  C and N only ask
+// "zero?" and "equal?", so the byte order of the registers (layout.hmh_reg_be) does not matter here.
+__device__ __forceinline__ uint32_t hmh_word(const uint8_t *img, uint32_t w)
+{
+    const uint8_t *p = img + 4ull * w;
+    if ((reinterpret_cast<uintptr_t>(p) & 3u) == 0) return *reinterpret_cast<const uint32_t *>(p);
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+__global__ void __launch_bounds__(256) hmh_pairs_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
+                                                        const uint8_t *__restrict__ qry, uint32_t n_qry, uint32_t hdr,
+                                                        uint64_t stride, uint32_t *__restrict__ out_c,
+                                                        uint32_t *__restrict__ out_n)
 {
     __shared__ __attribute__((aligned(16))) uint32_t R[HCW][HSTRIDE], Q[HCW][HSTRIDE];
     const uint32_t tid = threadIdx.x, tr = tid / 16, tq = tid % 16;           // lane block: rows tr*4.., columns tq*4..
@@ -50,8 +60,8 @@ __global__ void __launch_bounds__(256) hmh_pairs_kernel(const uint32_t *__restri
         // stage: global reads run along the words of a sketch (coalesced), LDS is written word-major
         for (uint32_t i = tid; i < HT * HCW; i += 256) {
             const uint32_t row = i / HCW, col = i % HCW;
-            R[col][row] = (r0 + row < n_ref) ? ref[(uint64_t)(r0 + row) * WORDS + w0 + col] : 0u;
-            Q[col][row] = (q0 + row < n_qry) ? qry[(uint64_t)(q0 + row) * WORDS + w0 + col] : 0u;
+            R[col][row] = (r0 + row < n_ref) ? hmh_word(ref + (uint64_t)(r0 + row) * stride + hdr, w0 + col) : 0u;
+            Q[col][row] = (q0 + row < n_qry) ? hmh_word(qry + (uint64_t)(q0 + row) * stride + hdr, w0 + col) : 0u;
         }
         __syncthreads();
 #pragma unroll 2
@@ -97,14 +107,14 @@ constexpr int HCHUNK = 1024;                 // registers per sketch per chunk
 constexpr int HROW = HCHUNK / 4 + 1;         // LDS row in words, padded
 
 __global__ void __launch_bounds__(256) hll_pairs_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
-                                                        const uint8_t *__restrict__ qry, uint32_t n_qry, int p,
+                                                        const uint8_t *__restrict__ qry, uint32_t n_qry, int p, uint32_t hdr,
                                                         uint32_t *__restrict__ out_zero, double *__restrict__ out_sum)
 {
     __shared__ uint32_t R[DT][HROW], Q[DT][HROW];
     const uint32_t tid = threadIdx.x, tr = tid / DT, tq = tid % DT;
     const uint32_t r0 = blockIdx.y * DT, q0 = blockIdx.x * DT;
     const uint32_t m = 1u << p;
-    const uint64_t stride = 33ull + m;
+    const uint64_t stride = (uint64_t)hdr + m;
     unsigned long long s1 = 0, s2 = 0;          // sum of 2^(32-r) over r <= 32 ; sum of 2^(64-r) over r > 32
     uint32_t zero = 0;
     for (uint32_t c0 = 0; c0 < m; c0 += HCHUNK) {
@@ -113,11 +123,11 @@ __global__ void __launch_bounds__(256) hll_pairs_kernel(const uint8_t *__restric
             const uint32_t row = i / (n / 4), col = i % (n / 4);
             uint32_t a = 0, b = 0;
             if (r0 + row < n_ref) {
-                const uint8_t *s = ref + (uint64_t)(r0 + row) * stride + 33 + c0 + 4 * col;
+                const uint8_t *s = ref + (uint64_t)(r0 + row) * stride + hdr + c0 + 4 * col;
                 a = s[0] | (s[1] << 8) | (s[2] << 16) | ((uint32_t)s[3] << 24);
             }
             if (q0 + row < n_qry) {
-                const uint8_t *s = qry + (uint64_t)(q0 + row) * stride + 33 + c0 + 4 * col;
+                const uint8_t *s = qry + (uint64_t)(q0 + row) * stride + hdr + c0 + 4 * col;
                 b = s[0] | (s[1] << 8) | (s[2] << 16) | ((uint32_t)s[3] << 24);
             }
             R[row][col] = a;
@@ -144,22 +154,21 @@ __global__ void __launch_bounds__(256) hll_pairs_kernel(const uint8_t *__restric
     }
 }
 
-hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p,
+hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
                             uint32_t *d_zero, double *d_sum, hipStream_t stream)
 {
     if (n_ref == 0 || n_qry == 0) return hipSuccess;
     dim3 grid((n_qry + DT - 1) / DT, (n_ref + DT - 1) / DT);
-    hipLaunchKernelGGL(hll_pairs_kernel, grid, dim3(256), 0, stream, d_ref, n_ref, d_qry, n_qry, p, d_zero, d_sum);
+    hipLaunchKernelGGL(hll_pairs_kernel, grid, dim3(256), 0, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, d_zero, d_sum);
     return hipGetLastError();
 }
 
-hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t *d_c,
-                            uint32_t *d_n, hipStream_t stream)
+hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t hdr,
+                            uint64_t stride, uint32_t *d_c, uint32_t *d_n, hipStream_t stream)
 {
     if (n_ref == 0 || n_qry == 0) return hipSuccess;
     dim3 grid((n_qry + HT - 1) / HT, (n_ref + HT - 1) / HT);
-    hipLaunchKernelGGL(hmh_pairs_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const uint32_t *>(d_ref), n_ref,
-                       reinterpret_cast<const uint32_t *>(d_qry), n_qry, d_c, d_n);
+    hipLaunchKernelGGL(hmh_pairs_kernel, grid, dim3(256), 0, stream, d_ref, n_ref, d_qry, n_qry, hdr, stride, d_c, d_n);
     return hipGetLastError();
 }
 

@@ -4,7 +4,8 @@
 //   lash dist   -q PREFIX -r PREFIX [-o dist] [-t N] [-e fgra|ml] [-m 1|0] [--fp32] [--dm]   (main.rs:107-176, 280-617)
 // Extras that do not exist upstream: --gpus N / --device D / --devices LIST (which GPUs to use, one worker each), --batch-mb M, --stream-mb M (files
 // larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low; dist: --device D, --block-rows N
-// (reference rows per GPU call).
+// (reference rows per GPU call); both: --layout SPEC (or $LASH_LAYOUT): the crate-internal rules as data, see `lash_layout`
+// in include/lash_gfx950.h.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -120,6 +121,8 @@ int cmd_sketch(int argc, char **argv)
     opt.batch_bytes = std::max<uint64_t>(1, batch_mb) << 20;
     opt.stream_bytes = std::max<uint64_t>(1, stream_mb) << 20;
     opt.flags = a.flags.count("hmh-x-low") ? LASH_F_HMH_X_LOW : 0;
+    err = layout_from_option(a.kv.count("layout") ? a.kv["layout"] : "", opt.layout);
+    if (!err.empty()) { fprintf(stderr, "error: %s\n", err.c_str()); return 2; }
     if (a.kv.count("devices")) {                              // explicit worker list, e.g. 0,1,2,3 (repeats allowed: 0,0 = two workers on GPU 0)
         const std::string &l = a.kv["devices"];
         size_t at = 0;

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <fstream>
@@ -24,6 +25,16 @@
 #include "zstd_dl.hpp"
 
 namespace lashhost {
+
+std::string layout_from_option(const std::string &spec, lash_layout &out)
+{
+    const char *env = getenv("LASH_LAYOUT");
+    const std::string text = !spec.empty() ? spec : (env ? env : "");
+    if (lash_layout_parse(text.c_str(), &out) != LASH_OK)
+        return "bad layout '" + text + "' (codes=ACGT,kmer=msb|lsb,hmh_x=high|low,hmh_reg=le|be,hll_bucket=low|high,"
+               "hmh_hdr=,hll_hdr=azspl,ull_hdr=l)";
+    return "";
+}
 
 std::string read_list_file(const std::string &path, std::vector<std::string> &files)
 {
@@ -293,7 +304,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     };
     lash_params prm{opt.algo, opt.k, opt.precision, opt.flags, opt.seed};
     if (lash_params_check(&prm) != LASH_OK) return lash_strerror(LASH_EINVAL);
-    const size_t ib = lash_sketch_image_bytes(opt.algo, opt.precision);
+    const size_t ib = lash_layout_image_bytes(&opt.layout, opt.algo, opt.precision);
     std::vector<int> devices = opt.devices.empty() ? std::vector<int>{0} : opt.devices;
     const int n_dev_avail = lash_device_count();
     if (n_dev_avail <= 0) return lash_strerror(LASH_ENODEV);
@@ -316,6 +327,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     auto gpu_worker = [&](int device) {
         lash_ctx *ctx = nullptr;
         int rc = lash_ctx_create(&ctx, device);
+        if (rc == LASH_OK) rc = lash_ctx_set_layout(ctx, &opt.layout);
         mark("context ready on device", (uint64_t)device);
         for (;;) {
             std::shared_ptr<Batch> b;
@@ -483,7 +495,8 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                 b->f1 = i + 1;
                 b->images.assign(ib, 0);
                 if (!stream_ctx) {
-                    const int rc = lash_ctx_create(&stream_ctx, devices[0]);
+                    int rc = lash_ctx_create(&stream_ctx, devices[0]);
+                    if (rc == LASH_OK) rc = lash_ctx_set_layout(stream_ctx, &opt.layout);
                     if (rc != LASH_OK) { err = lash_strerror(rc); break; }
                 }
                 uint64_t seen = 0;

@@ -9,7 +9,12 @@
 #include <string>
 #include <vector>
 
+#include "../../../include/lash_gfx950.h"
+
 namespace lashhost {
+
+// --layout SPEC, else $LASH_LAYOUT, else the default (include/lash_gfx950.h `lash_layout`); "" on success
+std::string layout_from_option(const std::string &spec, lash_layout &out);
 
 struct SketchOptions {
     int algo = 0;                    // LASH_HMH / LASH_HLL / LASH_ULL
@@ -22,6 +27,8 @@ struct SketchOptions {
     uint64_t stream_bytes = 1ull << 30;  // files larger than this (compressed: > 1/3 of it on disk) are streamed in chunks
                                          // of this size with on-device accumulation (BASELINE configs[4]); < 4 GiB
     uint32_t flags = 0;              // LASH_F_HMH_X_LOW
+    lash_layout layout;              // set by layout_from_option(); every context gets it
+    SketchOptions() { lash_layout_default(&layout); }
 };
 
 struct SketchStats {

@@ -33,12 +33,34 @@ struct EvSet {
     bool pack = false, done = false, direct = false;                            // finalize end; end of the direct pass
 };
 
+// LASH_TRACE_HOST=1: host-side microsecond marks of one call on stderr (tools/, DESIGN.md "Host cost of a call").
+// The object lives in the context that makes the call: contexts on different host threads never share it.
+struct HostTrace {
+    bool on = false;
+    std::chrono::steady_clock::time_point t0;
+    void begin()
+    {
+        static const bool env_on = getenv("LASH_TRACE_HOST") != nullptr;
+        on = env_on;
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    void end() { on = false; }
+    void mark(const char *what) const
+    {
+        if (!on) return;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "[lash host] %8.1f us  %s\n", us, what);
+    }
+};
+
 struct HostStage {
     void *ptr = nullptr;
     size_t cap = 0;
     hipEvent_t done = nullptr;
     bool pending = false;
 };
+
+const lash_layout kDefaultLayout = {{0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l"};
 
 }  // namespace
 
@@ -76,6 +98,8 @@ struct lash_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    lash_layout layout = kDefaultLayout;  // SURVEY App. D's unknowns as data (lash_ctx_set_layout)
+    HostTrace trace;
     bool timing = false;
     std::deque<EvSet> ev_pool;           // one event set per timed (chunk of a) call; deque: stable addresses on growth
     size_t ev_used = 0;
@@ -109,6 +133,14 @@ int fail(lash_ctx *ctx, int code, const char *what, hipError_t e)
     }
     return code;
 }
+
+#define TRACE(what) ctx->trace.mark(what)
+// marks end with the entry point that began them, on every return path
+struct TraceScope {
+    HostTrace &t;
+    explicit TraceScope(HostTrace &tr) : t(tr) { t.begin(); }
+    ~TraceScope() { t.end(); }
+};
 
 #define HIPCHK(ctx, expr)                                              \
     do {                                                               \
@@ -209,21 +241,6 @@ int timing_begin(lash_ctx *ctx)      // sets ctx->cur_ev to a fresh event set (o
     return LASH_OK;
 }
 
-// LASH_TRACE_HOST=1: host-side microsecond marks of one call on stderr (tools/, DESIGN.md "Host cost of a call")
-struct HostTrace {
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    HostTrace() : on(getenv("LASH_TRACE_HOST") != nullptr), t0(std::chrono::steady_clock::now()) {}
-    void mark(const char *what)
-    {
-        if (!on) return;
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        fprintf(stderr, "[lash host] %8.1f us  %s\n", us, what);
-    }
-};
-HostTrace *g_trace = nullptr;
-#define TRACE(what) do { if (g_trace) g_trace->mark(what); } while (0)
-
 double hll_alpha(int p)
 {
     switch (p) {
@@ -234,7 +251,69 @@ double hll_alpha(int p)
     }
 }
 
-uint64_t header_bytes(int algo) { return algo == LASH_HMH ? 0 : algo == LASH_HLL ? 33 : 8; }
+// ---- layout (include/lash_gfx950.h) ----
+size_t field_bytes(char c)
+{
+    switch (c) {
+    case 'a': case 'z': case 's': case 'Q': case 'l': return 8;
+    case 'Z': case 'P': case 'L': return 4;
+    case 'p': return 1;
+    default: return (size_t)-1;
+    }
+}
+const char *header_tpl(const lash_layout &lay, int algo)
+{
+    return algo == LASH_HMH ? lay.hmh_header : algo == LASH_HLL ? lay.hll_header : lay.ull_header;
+}
+uint64_t header_bytes(const lash_layout &lay, int algo)
+{
+    uint64_t n = 0;
+    const char *t = header_tpl(lay, algo);
+    for (int i = 0; i < 8 && t[i]; ++i) n += field_bytes(t[i]);
+    return n;
+}
+bool layout_ok(const lash_layout &lay)
+{
+    unsigned seen = 0;
+    for (int i = 0; i < 4; ++i) { if (lay.base_code[i] > 3) return false; seen |= 1u << lay.base_code[i]; }
+    if (seen != 15u) return false;
+    for (int a = 0; a < 3; ++a) {
+        const char *t = header_tpl(lay, a);
+        int i = 0;
+        for (; i < 8 && t[i]; ++i) if (field_bytes(t[i]) == (size_t)-1) return false;
+        if (i == 8) return false;
+    }
+    return true;
+}
+// non-default k-mer / bucket rule -> ALT kernels on packed input
+bool layout_alt(const lash_layout &lay, int algo) { return lay.kmer_lsb_first || (algo == LASH_HLL && lay.hll_bucket_high); }
+
+LayoutDev layout_dev(const lash_layout &lay, int algo)
+{
+    LayoutDev d{};
+    const uint32_t A = lay.base_code[0], Cc = lay.base_code[1], G = lay.base_code[2], T = lay.base_code[3];
+    d.code_lo = (A << 8) | (Cc << 24);                   // keys (byte & 7): A = 1, C = 3
+    d.code_hi = T | (G << 24);                           // T = 4, G = 7
+    d.code_tab4 = A | (Cc << 8) | (G << 16) | (T << 24); // index = hypothesis code A,C,G,T = 0,1,2,3
+    d.comp_mask = (A ^ T) * 0x55555555u;
+    d.hdr_bytes = (uint32_t)header_bytes(lay, algo);
+    const char *t = header_tpl(lay, algo);
+    for (int i = 0; i < 8; ++i) d.hdr_tpl[i] = (uint8_t)t[i];
+    d.hmh_reg_be = lay.hmh_reg_be;
+    d.kmer_lsb_first = lay.kmer_lsb_first;
+    d.hll_bucket_high = lay.hll_bucket_high;
+    return d;
+}
+
+size_t image_bytes(const lash_layout &lay, int algo, int p)
+{
+    switch (algo) {
+    case LASH_HMH: return header_bytes(lay, algo) + (size_t)HMH_M * 2;                            // [header] 16384 x u16
+    case LASH_HLL: return (p >= 4 && p <= 16) ? header_bytes(lay, algo) + ((size_t)1 << p) : 0;   // bincode(alpha, zero, sum, p, len) + m
+    case LASH_ULL: return (p >= 3 && p <= 26) ? header_bytes(lay, algo) + ((size_t)1 << p) : 0;   // bincode(Vec<u8>)
+    default: return 0;
+    }
+}
 
 // Packs genomes [0, n_genomes) described by genome_rec_off / genome_byte_off (absolute record indices / byte offsets
 // into d_seq) on `stream`.  `ev`, when set, gets its pack-start / pack-end events recorded on that stream.
@@ -338,6 +417,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pa.words = static_cast<uint32_t *>(pk->words.ptr);
     pa.brk = static_cast<uint32_t *>(pk->brk.ptr);
     pa.nvalid = pk->d_nvalid;
+    pa.code_tab4 = layout_dev(ctx->layout, LASH_HMH).code_tab4;
     uint64_t *lb = static_cast<uint64_t *>(pk->lookback.ptr);
     PackV2Args v2{};
     v2.tiles = static_cast<const TileInfo *>(pk->tiles.ptr);
@@ -396,8 +476,9 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     uint64_t total_bytes = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) total_bytes += pk->byte_len[g];
     const bool small_items = n_genomes > 0 && total_bytes / n_genomes < 100000u;
-    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, (prm->flags & LASH_F_HMH_X_LOW) != 0, small_items);
-    const uint64_t image_bytes = lash_sketch_image_bytes(prm->algo, prm->p);
+    const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
+    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo));
+    const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
     const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(plan.lds_bytes, 1u)) : 4u;   // 64 KiB + census -> 2
@@ -503,6 +584,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     }
     sa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
     sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
+    sa.lay = layout_dev(ctx->layout, prm->algo);
     sa.partial_stride = plan.partial_stride;
     sa.nreg32 = plan.nreg32 >> plan.parts_log2;                 // register words of one pass
     sa.k = prm->k;
@@ -540,6 +622,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.k = prm->k;
     fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
     fa.parts_log2 = plan.parts_log2;
+    fa.lay = sa.lay;
+    fa.src_images = 0;
     // one finalize workgroup walks all of a genome's partials: fine for a handful of slices, 20 ms for the 4 096 slices of
     // a metagenome-sized input (BASELINE configs[4]) -> fold groups of 32 slices first (until <= 16 heads remain)
     fa.group = 0;
@@ -612,14 +696,86 @@ int lash_params_check(const lash_params *prm)
     }
 }
 
-size_t lash_sketch_image_bytes(int algo, int p)
+size_t lash_sketch_image_bytes(int algo, int p) { return image_bytes(kDefaultLayout, algo, p); }
+
+void lash_layout_default(lash_layout *out) { if (out) *out = kDefaultLayout; }
+
+int lash_layout_check(const lash_layout *lay) { return lay && layout_ok(*lay) ? LASH_OK : LASH_EINVAL; }
+
+size_t lash_layout_header_bytes(const lash_layout *lay, int algo)
 {
-    switch (algo) {
-    case LASH_HMH: return (size_t)HMH_M * 2;                               // 16384 x u16 LE
-    case LASH_HLL: return (p >= 4 && p <= 16) ? 33 + ((size_t)1 << p) : 0;   // bincode(alpha, zero, sum, p, len) + m
-    case LASH_ULL: return (p >= 3 && p <= 26) ? 8 + ((size_t)1 << p) : 0;    // bincode(Vec<u8>)
-    default: return 0;
+    if (algo < LASH_HMH || algo > LASH_ULL) return 0;
+    return (size_t)header_bytes(lay ? *lay : kDefaultLayout, algo);
+}
+
+size_t lash_layout_image_bytes(const lash_layout *lay, int algo, int p)
+{
+    if (lay && !layout_ok(*lay)) return 0;
+    return image_bytes(lay ? *lay : kDefaultLayout, algo, p);
+}
+
+int lash_layout_parse(const char *spec, lash_layout *out)
+{
+    if (!out) return LASH_EINVAL;
+    lash_layout lay = kDefaultLayout;
+    std::string text = spec ? spec : "";
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t end = text.find(',', pos);
+        if (end == std::string::npos) end = text.size();
+        const std::string item = text.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        if (eq == std::string::npos) return LASH_EINVAL;
+        const std::string key = item.substr(0, eq), val = item.substr(eq + 1);
+        auto two = [&](const char *zero, const char *one, uint8_t &dst) {
+            if (val == zero) { dst = 0; return true; }
+            if (val == one) { dst = 1; return true; }
+            return false;
+        };
+        auto hdr = [&](char (&dst)[8]) {
+            if (val.size() > 7) return false;
+            memset(dst, 0, 8);
+            memcpy(dst, val.data(), val.size());
+            return true;
+        };
+        bool ok;
+        if (key == "codes") {
+            ok = val.size() == 4;
+            for (size_t c = 0; ok && c < 4; ++c) {
+                const char *at = strchr("ACGT", val[c]);
+                if (!at || !val[c]) { ok = false; break; }
+                lay.base_code[at - "ACGT"] = (uint8_t)c;
+            }
+        } else if (key == "kmer") ok = two("msb", "lsb", lay.kmer_lsb_first);
+        else if (key == "hmh_x") ok = two("high", "low", lay.hmh_x_low);
+        else if (key == "hmh_reg") ok = two("le", "be", lay.hmh_reg_be);
+        else if (key == "hll_bucket") ok = two("low", "high", lay.hll_bucket_high);
+        else if (key == "hmh_hdr") ok = hdr(lay.hmh_header);
+        else if (key == "hll_hdr") ok = hdr(lay.hll_header);
+        else if (key == "ull_hdr") ok = hdr(lay.ull_header);
+        else ok = false;
+        if (!ok) return LASH_EINVAL;
     }
+    if (!layout_ok(lay)) return LASH_EINVAL;
+    *out = lay;
+    return LASH_OK;
+}
+
+int lash_ctx_set_layout(lash_ctx *ctx, const lash_layout *lay)
+{
+    if (!ctx) return LASH_EINVAL;
+    if (lay && !layout_ok(*lay)) return LASH_EINVAL;
+    ctx->layout = lay ? *lay : kDefaultLayout;
+    return LASH_OK;
+}
+
+int lash_ctx_get_layout(lash_ctx *ctx, lash_layout *out)
+{
+    if (!ctx || !out) return LASH_EINVAL;
+    *out = ctx->layout;
+    return LASH_OK;
 }
 
 int lash_ctx_create(lash_ctx **out, int device)
@@ -822,8 +978,7 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     // sketch workgroup fits, and the step got 20-40 % slower.
     if ((rc = timing_begin(ctx))) return rc;
     EvSet *ev = ctx->cur_ev;
-    HostTrace trace;
-    g_trace = trace.on ? &trace : nullptr;
+    TraceScope trace_scope(ctx->trace);
     TRACE("call");
     static const bool env_no_direct = getenv("LASH_NO_DIRECT") != nullptr;          // A/B knob for tools/
     // A genome that turns out dirty late has cost a wasted direct pass, so the optimistic pass only pays while most of a
@@ -832,7 +987,8 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
         ctx->dirty_frac = ctx->probe_tiles ? (float)ctx->probe_host[0] / (float)ctx->probe_tiles : 0.f;
         ctx->probe_pending = false;
     }
-    bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct;
+    // (the alternative k-mer / bucket rules of a non-default layout exist for packed input only)
+    bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct && !layout_alt(ctx->layout, prm->algo);
     if (direct && ctx->dirty_frac > 0.2f) {
         if (++ctx->direct_skipped < 8) direct = false;          // pack first; try again every 8th call
         else ctx->direct_skipped = 0;
@@ -842,7 +998,6 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     if (rc) return rc;
     rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
     ctx->cur_ev = nullptr;
-    g_trace = nullptr;
     return rc;
 }
 
@@ -862,7 +1017,7 @@ int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq,
         if (genome_rec_off[g] > n_rec) return LASH_EINVAL;
         gbo[g] = rec_off[genome_rec_off[g]];
     }
-    const size_t img_bytes = (size_t)n_genomes * lash_sketch_image_bytes(prm->algo, prm->p);
+    const size_t img_bytes = (size_t)n_genomes * image_bytes(ctx->layout, prm->algo, prm->p);
     if ((rc = reserve(ctx, ctx->st_seq, seq_bytes + 64))) return rc;
     if ((rc = reserve(ctx, ctx->st_rec, (size_t)(n_rec + 1) * 8))) return rc;
     if ((rc = reserve(ctx, ctx->st_img, img_bytes + 64))) return rc;
@@ -898,7 +1053,6 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
     if (rc) return rc;
     rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
     ctx->cur_ev = nullptr;
-    g_trace = nullptr;
     return rc;
 }
 
@@ -911,7 +1065,7 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     (void)hipSetDevice(ctx->device);
     const uint64_t bytes = file_off[n_files];
     if (bytes && !raw) return LASH_EINVAL;
-    const size_t img_bytes = (size_t)n_files * lash_sketch_image_bytes(prm->algo, prm->p);
+    const size_t img_bytes = (size_t)n_files * image_bytes(ctx->layout, prm->algo, prm->p);
     if ((rc = reserve(ctx, ctx->st_seq, bytes + 64))) return rc;
     if ((rc = reserve(ctx, ctx->st_img, img_bytes + 64))) return rc;
     if (bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->st_seq.ptr, raw, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -950,9 +1104,11 @@ int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, con
     fa.genome_item_begin = static_cast<const uint32_t *>(ctx->item_begin.ptr);
     fa.nvalid = nullptr;
     fa.images = d_dst;
-    fa.image_bytes = lash_sketch_image_bytes(algo, p);
+    fa.image_bytes = image_bytes(ctx->layout, algo, p);
     fa.partial_stride = fa.image_bytes;
-    fa.partial_base_off = header_bytes(algo);
+    fa.partial_base_off = header_bytes(ctx->layout, algo);
+    fa.lay = layout_dev(ctx->layout, algo);
+    fa.src_images = 1;
     const double alpha = hll_alpha(p);
     memcpy(&fa.alpha_bits, &alpha, 8);
     fa.algo = algo;
@@ -966,7 +1122,7 @@ int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, con
 int lash_merge_images(lash_ctx *ctx, int algo, int p, uint8_t *dst, const uint8_t *src, uint64_t n_images)
 {
     if (!ctx || (n_images && (!dst || !src))) return LASH_EINVAL;
-    const size_t ib = lash_sketch_image_bytes(algo, p);
+    const size_t ib = image_bytes(ctx->layout, algo, p);
     if (!ib) return LASH_EINVAL;
     (void)hipSetDevice(ctx->device);
     const size_t bytes = ib * (size_t)n_images;
@@ -988,7 +1144,8 @@ int lash_hmh_pair_counts_device(lash_ctx *ctx, const uint8_t *d_ref_images, uint
 {
     if (!ctx || ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_c || !d_out_n))) return LASH_EINVAL;
     (void)hipSetDevice(ctx->device);
-    HIPCHK(ctx, launch_hmh_pairs(d_ref_images, n_ref, d_qry_images, n_qry, d_out_c, d_out_n, ctx->stream));
+    HIPCHK(ctx, launch_hmh_pairs(d_ref_images, n_ref, d_qry_images, n_qry, (uint32_t)header_bytes(ctx->layout, LASH_HMH),
+                                 image_bytes(ctx->layout, LASH_HMH, 0), d_out_c, d_out_n, ctx->stream));
     return LASH_OK;
 }
 
@@ -998,7 +1155,7 @@ int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_re
     if (!ctx || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_c || !out_n))) return LASH_EINVAL;
     if (n_ref == 0 || n_qry == 0) return LASH_OK;
     (void)hipSetDevice(ctx->device);
-    const size_t ib = (size_t)HMH_M * 2, rb = ib * n_ref, qb = ib * n_qry, pb = (size_t)n_ref * n_qry * 4;
+    const size_t ib = image_bytes(ctx->layout, LASH_HMH, 0), rb = ib * n_ref, qb = ib * n_qry, pb = (size_t)n_ref * n_qry * 4;
     int rc;
     if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
     if ((rc = reserve(ctx, ctx->st_img, 2 * pb + 64))) return rc;
@@ -1019,7 +1176,8 @@ int lash_hll_pair_union_stats_device(lash_ctx *ctx, int p, const uint8_t *d_ref_
     if (!ctx || p < 4 || p > 16 || ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_zero || !d_out_sum)))
         return LASH_EINVAL;
     (void)hipSetDevice(ctx->device);
-    HIPCHK(ctx, launch_hll_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, d_out_zero, d_out_sum, ctx->stream));
+    HIPCHK(ctx, launch_hll_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, (uint32_t)header_bytes(ctx->layout, LASH_HLL), d_out_zero,
+                                 d_out_sum, ctx->stream));
     return LASH_OK;
 }
 
@@ -1029,7 +1187,7 @@ int lash_hll_pair_union_stats(lash_ctx *ctx, int p, const uint8_t *ref_images, u
     if (!ctx || p < 4 || p > 16 || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_zero || !out_sum))) return LASH_EINVAL;
     if (n_ref == 0 || n_qry == 0) return LASH_OK;
     (void)hipSetDevice(ctx->device);
-    const size_t ib = lash_sketch_image_bytes(LASH_HLL, p), rb = ib * n_ref, qb = ib * n_qry, np = (size_t)n_ref * n_qry;
+    const size_t ib = image_bytes(ctx->layout, LASH_HLL, p), rb = ib * n_ref, qb = ib * n_qry, np = (size_t)n_ref * n_qry;
     int rc;
     if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
     if ((rc = reserve(ctx, ctx->st_img, np * 12 + 64))) return rc;

@@ -36,6 +36,19 @@ constexpr int      SKETCH_WORDS_PER_THREAD = 4;   // one global_load_dwordx4 per
 constexpr int      HMH_P            = 14;
 constexpr uint32_t HMH_M            = 1u << HMH_P;
 
+// The context's lash_layout (include/lash_gfx950.h: SURVEY App. D's unknowns as data) in the form the kernels consume.
+struct LayoutDev {
+    uint32_t code_lo, code_hi;   // direct route: v_perm tables indexed by (byte & 7): A=1 C=3 T=4 G=7 -> 2-bit code
+    uint32_t code_tab4;          // pack route: byte i = layout code of the letter whose kmerutils-hypothesis code is i
+    uint32_t comp_mask;          // complement of 16 packed bases = word ^ comp_mask  (code[A]^code[T] in every 2-bit group)
+    uint32_t hdr_bytes;          // bytes written before the register array of this algo's image
+    uint8_t  hdr_tpl[8];         // that header's field codes (see lash_layout), 0-terminated
+    uint8_t  hmh_reg_be;         // HyperMinHash registers big-endian in images
+    uint8_t  kmer_lsb_first;     // (ALT kernels only) a k-mer's first base is its least significant 2 bits
+    uint8_t  hll_bucket_high;    // (ALT kernels only) HLL bucket = top p bits of the hash
+    uint8_t  pad;
+};
+
 // XXH3 constants (XXH 0.8 spec; closed forms in SURVEY.md Appendix C, pinned by tests/golden/xxh3_vectors.json)
 constexpr uint64_t XXH_PRIME64_1 = 0x9E3779B185EBCA87ULL;
 constexpr uint64_t XXH_PRIME_MX1 = 0x165667919E3779F9ULL;

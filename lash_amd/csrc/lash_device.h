@@ -16,10 +16,12 @@ __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t 
     return __builtin_amdgcn_alignbit(hi, lo, s);        // ({hi,lo} >> (s & 31))[31:0]
 }
 
-// reverse complement of the 16 bases of one packed word (first base in bits 31:30 on both sides)
-__device__ __forceinline__ uint32_t rcword(uint32_t x)
+// reverse complement of the 16 bases of one packed word (first base in bits 31:30 on both sides).  Complementing a base
+// is an XOR of its 2-bit code with code[A]^code[T] (== code[C]^code[G] for every code assignment): `cm` holds that value
+// in all 16 groups (LayoutDev::comp_mask; ~x for kmerutils' A,C,G,T = 0,1,2,3).
+__device__ __forceinline__ uint32_t rcword(uint32_t x, uint32_t cm = 0xFFFFFFFFu)
 {
-    uint32_t y = __builtin_bitreverse32(~x);            // groups reversed, bits inside each group swapped
+    uint32_t y = __builtin_bitreverse32(x ^ cm);        // groups reversed, bits inside each group swapped
     return ((y & 0x55555555u) << 1) | ((y >> 1) & 0x55555555u);
 }
 

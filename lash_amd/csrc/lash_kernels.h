@@ -29,6 +29,7 @@ struct SketchArgs {
     uint32_t         *dirty;      // [n_genomes + 1] per genome: a byte outside {A,C,G,T} was met; [n_genomes] = how many.
                                   // non-direct launches with dirty != NULL run only the genomes flagged here
     uint64_t          bitflip;    // xxh3 seed-folded constant (64- or 128-bit variant by algo)
+    LayoutDev         lay;
     uint32_t          partial_stride;
     uint32_t          nreg32;     // u32 words of register state (HMH 16384, HLL 2^p, ULL 2*2^p)
     int               k;
@@ -38,6 +39,7 @@ struct SketchArgs {
 struct SketchPlan {
     int      algo, k, p;
     bool     x_low;
+    bool     alt;                 // non-default k-mer / bucket rule (layout.kmer_lsb_first, hll_bucket_high): ALT kernels, packed input only
     bool     use_lds;
     uint32_t threads;             // 512 (<= 64 KiB of LDS, two workgroups per CU) or 1024
     uint32_t lds_bytes;
@@ -48,7 +50,7 @@ struct SketchPlan {
 };
 
 // small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false);
+SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
                          bool direct = false);
 // record starts of multi-record format-0 genomes -> args.brk_bytes (zeroed before the launch)
@@ -70,6 +72,8 @@ struct FinalizeArgs {
     int             algo, p, k;
     int             accumulate;          // union into the registers already in images[]
     uint32_t        parts_log2;          // see SketchPlan: a partial holds only the registers of its item's pass
+    LayoutDev       lay;
+    int             src_images;          // the "partials" are images (lash_merge_images): HMH registers in image byte order
     uint32_t        group;               // 0, or G: launch_reduce_groups() has folded every G consecutive slices (per
                                          // pass) into the first one's partial; only those group heads are read
 };
@@ -88,6 +92,7 @@ struct PackArgs {
     uint32_t         *words;
     uint32_t         *brk;        // zeroed before the launch
     uint64_t         *nvalid;
+    uint32_t          code_tab4;  // LayoutDev::code_tab4
 };
 // one 16 KiB tile of one genome (filled by pack_map_kernel)
 struct TileInfo {
@@ -133,10 +138,11 @@ hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackM
                           hipStream_t stream);
 
 // ---- dist side (HyperMinHash pair statistics) ------------------------------------------------------------------
-hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t *d_c,
-                            uint32_t *d_n, hipStream_t stream);
+// images: `hdr` header bytes, then the registers; consecutive images are `stride` bytes apart
+hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t hdr,
+                            uint64_t stride, uint32_t *d_c, uint32_t *d_n, hipStream_t stream);
 
-hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p,
+hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
                             uint32_t *d_zero, double *d_sum, hipStream_t stream);
 
 // ---- synthetic genomes --------------------------------------------------------------------

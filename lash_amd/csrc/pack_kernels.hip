@@ -26,7 +26,8 @@ namespace lash {
 // Four ASCII bytes -> four 2-bit codes (byte 0 first, in bits 7:6 of the result) and a 4-bit validity mask.
 // code = (c >> 1) & 3 maps A C T G -> 0 1 2 3; x ^ (x >> 1) swaps 2 and 3 to get kmerutils' A C G T = 0 1 2 3.
 // A byte is valid iff it equals the letter its own code would decode to (exact zero-byte test, no LUT).
-__device__ __forceinline__ void classify4(uint32_t w, uint32_t &codes8, uint32_t &valid4)
+// `tab4` (LayoutDev::code_tab4) maps those hypothesis codes to the context layout's, one v_perm per 4 bytes (0x03020100 = identity).
+__device__ __forceinline__ void classify4(uint32_t w, uint32_t tab4, uint32_t &codes8, uint32_t &valid4)
 {
     const uint32_t x = (w >> 1) & 0x03030303u;
     uint32_t e = (x << 1) | 0x41414141u;                   // 'A' 'C' 'E' 'G'
@@ -35,7 +36,7 @@ __device__ __forceinline__ void classify4(uint32_t w, uint32_t &codes8, uint32_t
     const uint32_t z = w ^ e;                              // zero byte <=> valid
     const uint32_t nz = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;
     const uint32_t v = (~nz & 0x80808080u) >> 7;           // 0x01 per valid byte
-    const uint32_t c = x ^ ((x >> 1) & 0x01010101u);
+    const uint32_t c = __builtin_amdgcn_perm(0u, tab4, x ^ ((x >> 1) & 0x01010101u));
     codes8 = (c * 0x40100401u) >> 24;                      // byte j -> bits 7-2j..6-2j
     valid4 = ((v * 0x01020408u) >> 24) & 0xFu;             // byte j -> bit j
 }
@@ -46,13 +47,13 @@ struct Lane16 {
     uint32_t vmask;   // bit j: byte j survives
 };
 
-__device__ __forceinline__ Lane16 classify16(const uint4 q, uint32_t keep)
+__device__ __forceinline__ Lane16 classify16(const uint4 q, uint32_t keep, uint32_t tab4)
 {
     uint32_t c0, c1, c2, c3, v0, v1, v2, v3;
-    classify4(q.x, c0, v0);
-    classify4(q.y, c1, v1);
-    classify4(q.z, c2, v2);
-    classify4(q.w, c3, v3);
+    classify4(q.x, tab4, c0, v0);
+    classify4(q.y, tab4, c1, v1);
+    classify4(q.z, tab4, c2, v2);
+    classify4(q.w, tab4, c3, v3);
     const uint32_t codes = (c0 << 24) | (c1 << 16) | (c2 << 8) | c3;
     const uint32_t vmask = (v0 | (v1 << 4) | (v2 << 8) | (v3 << 12)) & keep;
     Lane16 o;
@@ -492,7 +493,7 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
             bool allv = true;
 #pragma unroll
             for (int c = 0; c < P2_CHUNKS; ++c) {
-                l16[c] = keep[c] ? classify16(q[c], keep[c]) : Lane16{0, 0, 0};
+                l16[c] = keep[c] ? classify16(q[c], keep[c], a.code_tab4) : Lane16{0, 0, 0};
                 allv = allv && l16[c].vmask == 0xFFFFu;
             }
             const bool wave_all = __builtin_amdgcn_ballot_w64(!allv) == 0ull;

@@ -90,7 +90,7 @@ enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_LDS_PARTS = 2 };
 // (one v_ffbh_u32) and returns `t`; when t == 0 it has pushed a harmless under-estimate (max) or nothing (OR),
 // and the caller re-runs the word with FAST = false — legal because max/OR are idempotent.
 // ------------------------------------------------------------------------------------------------------------
-template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs>
+template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs, bool HLL_HIGH = false>
 __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, uint32_t c_hi, uint32_t vm,
                                              uint64_t bitflip, int p)
 {
@@ -132,6 +132,16 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
         const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
         const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
         const uint32_t pm = (1u << p) - 1u;
+        if constexpr (HLL_HIGH) {
+            // layout.hll_bucket_high (SURVEY App. D, U3 alternative; ALT kernels, exact form only): bucket = top p bits,
+            // rho = 1 + leading zeros of the lower 64-p bits = clz64((h << p) | 2^(p-1)) + 1
+            static_assert(!FAST || !HLL_HIGH, "the alternative bucket rule has no fast form");
+            const uint32_t jh = hh >> (32 - p);
+            uint32_t rho = clz64_nz(alignbit(hh, hl, 32 - p), (hl << p) | (1u << (p - 1))) + 1u;
+            if constexpr (MASKED) rho &= vm;
+            regs.umax(jh, rho);
+            return 1u;
+        }
         const uint32_t j = hl & pm;
         uint32_t rho;
         if constexpr (FAST) rho = ffbh_u32(hh) + 1u;                         // hh == 0 -> 0 (an under-estimate)
@@ -196,13 +206,18 @@ __device__ __forceinline__ uint64_t kmer_valid_mask(uint32_t b0, uint32_t b1, ui
 struct KParams {
     uint64_t bitflip;
     uint64_t mask_gt;      // KM_GT16: low 2k bits
+    uint64_t lsb_xor;      // ALT: 0, or (layout.kmer_lsb_first) the complement mask on the low 2k bits
     uint32_t sh_lt;        // KM_LT16: 32 - 2k
     uint32_t mask_lt;      // KM_LT16: low 2k bits
     uint32_t sh_gt;        // KM_GT16: 64 - 2k
     int p;
 };
 
-template <int ALGO, int KMODE, bool XLOW, bool MASKED, bool FAST, class Regs>
+// ALT (layout.kmer_lsb_first / hll_bucket_high; SURVEY App. D alternatives of U5 / U3): with the first base of a k-mer in
+// its LEAST significant bits the iterator's value is the group-reversed window, and
+//     groups_reversed(fwd) = rc ^ cm,   its reverse complement = fwd ^ cm      (cm = complement mask on 2k bits),
+// because rc = groups_reversed(fwd ^ cm) and cm reads the same in both directions.  Two extra XORs per k-mer, exact forms only.
+template <int ALGO, int KMODE, bool XLOW, bool MASKED, bool FAST, class Regs, bool ALT = false, bool HLL_HIGH = false>
 __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1,
                                                  uint32_t c2, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw)
 {
@@ -217,17 +232,20 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
             const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
             const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
             const uint32_t rh = r ? alignbit(r2, r1, 2 * r) : r1;
-            const uint64_t rc = (((uint64_t)rh << 32) | rl) & kp.mask_gt;
-            const uint64_t can = fwd < rc ? fwd : rc;                            // km.min(rc), utils.rs:494
+            uint64_t rc = (((uint64_t)rh << 32) | rl) & kp.mask_gt;
+            uint64_t km = fwd;
+            if constexpr (ALT) { km = rc ^ kp.lsb_xor; rc = fwd ^ kp.lsb_xor; }   // lsb_xor == 0 (msb-first): min(rc, fwd), the same
+            const uint64_t can = km < rc ? km : rc;                              // km.min(rc), utils.rs:494
             can_lo = (uint32_t)can;
             can_hi = (uint32_t)(can >> 32);
         } else {
             uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
             uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
             if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
+            if constexpr (ALT) { fwd ^= (uint32_t)kp.lsb_xor; rc ^= (uint32_t)kp.lsb_xor; }   // min() is symmetric: no swap needed
             can_lo = fwd < rc ? fwd : rc;                                        // utils.rs:470,482
         }
-        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p);
+        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, HLL_HIGH>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p);
         zacc = zacc < t ? zacc : t;
     }
     return zacc;
@@ -291,28 +309,40 @@ __device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
     }
 }
 
-// streaming_algorithms HyperLogLog header: alpha f64, zero u64, sum f64, p u8, len u64.  zero and sum
-// are recomputed from the final registers' histogram; sum = sum_j 2^-m[j] is exact in f64 here (largest exponent first).
-__device__ __forceinline__ void write_hll_header_raw(uint8_t *img, uint64_t alpha_bits, uint64_t zero, double sum, int p)
+// Image header by template (lash_layout header codes; defaults: HMH none, HLL "azspl" = bincode of streaming_algorithms'
+// alpha f64, zero u64, sum f64, p u8 + the Box<[u8]> length prefix, ULL "l" = bincode Vec<u8> length prefix).
+__device__ __forceinline__ void put_le(uint8_t *dst, uint64_t v, int n) { for (int b = 0; b < n; ++b) dst[b] = (uint8_t)(v >> (8 * b)); }
+__device__ __noinline__ void write_header(uint8_t *img, const LayoutDev &lay, uint64_t alpha_bits, uint64_t n_regs, uint64_t zero,
+                                          double sum, int p)
 {
-    const uint64_t sum_bits = (uint64_t)__double_as_longlong(sum);
-    const uint64_t len = 1ull << p;
-    for (int b = 0; b < 8; ++b) {
-        img[b] = (uint8_t)(alpha_bits >> (8 * b));
-        img[8 + b] = (uint8_t)(zero >> (8 * b));
-        img[16 + b] = (uint8_t)(sum_bits >> (8 * b));
-        img[25 + b] = (uint8_t)(len >> (8 * b));
+    uint32_t at = 0;
+    for (int i = 0; i < 8 && lay.hdr_tpl[i]; ++i) {
+        switch (lay.hdr_tpl[i]) {
+        case 'a': put_le(img + at, alpha_bits, 8); at += 8; break;
+        case 'z': put_le(img + at, zero, 8); at += 8; break;
+        case 'Z': put_le(img + at, zero, 4); at += 4; break;
+        case 's': put_le(img + at, (uint64_t)__double_as_longlong(sum), 8); at += 8; break;
+        case 'p': img[at] = (uint8_t)p; at += 1; break;
+        case 'P': put_le(img + at, (uint64_t)p, 4); at += 4; break;
+        case 'Q': put_le(img + at, (uint64_t)p, 8); at += 8; break;
+        case 'l': put_le(img + at, n_regs, 8); at += 8; break;
+        case 'L': put_le(img + at, n_regs, 4); at += 4; break;
+        default: break;
+        }
     }
-    img[24] = (uint8_t)p;
 }
-__device__ __forceinline__ void write_hll_header(uint8_t *img, const uint32_t *hist, uint64_t alpha_bits, int p)
+// HLL: zero and sum are recomputed from the final registers' histogram; sum = sum_j 2^-m[j] is exact in f64 here (largest
+// exponent first), equal to the reference's incremental f64 updates.
+__device__ __forceinline__ void write_hll_header(uint8_t *img, const LayoutDev &lay, const uint32_t *hist, uint64_t alpha_bits, int p)
 {
     double sum = 0.0;
     for (int r = 66; r >= 0; --r) {
         if (hist[r]) sum += (double)hist[r] * __longlong_as_double((long long)(1023 - r) << 52);
     }
-    write_hll_header_raw(img, alpha_bits, hist[0], sum, p);
+    write_header(img, lay, alpha_bits, 1ull << p, hist[0], sum, p);
 }
+// HyperMinHash registers travel as native little-endian u16 pairs; images may hold them big-endian (layout.hmh_reg_be)
+__device__ __forceinline__ uint32_t hmh_img_order(uint32_t v, uint32_t be) { return be ? (((v & 0x00FF00FFu) << 8) | ((v >> 8) & 0x00FF00FFu)) : v; }
 
 // ---- direct mode: 2-bit words straight from ASCII ------------------------------------------------------------
 // While a genome holds nothing but upper-case ACGT, filter_out_n (utils.rs:33-41) deletes nothing, base i IS byte i,
@@ -325,26 +355,27 @@ __device__ __forceinline__ uint4 load16_any(const uint8_t *p)    // any alignmen
     __builtin_memcpy(&v, p, 16);
     return v;
 }
-__device__ __forceinline__ uint32_t ascii4_to_2bit(uint32_t x, uint32_t &bad)
+struct CodeTabs { uint32_t lo, hi; };   // LayoutDev::code_lo / code_hi (defaults 0x01000000 / 0x02000003: A,C,G,T = 0,1,2,3)
+__device__ __forceinline__ uint32_t ascii4_to_2bit(uint32_t x, uint32_t &bad, const CodeTabs ct)
 {
     // The low 3 bits tell the four letters apart (A 1, C 3, T 4, G 7), so they index two 8-entry byte tables held in
     // v_perm operands: the letter that key stands for (0xFF for the keys no letter has: never equal to x, whose low
-    // bits ARE the key) and its 2-bit code.
+    // bits ARE the key) and its 2-bit code (the context layout's base codes: kernel arguments, same instruction count).
     const uint32_t key = x & 0x07070707u;
     bad |= x ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, key);        // entries 7..4 | 3..0
-    const uint32_t code = __builtin_amdgcn_perm(0x02000003u, 0x01000000u, key);
+    const uint32_t code = __builtin_amdgcn_perm(ct.hi, ct.lo, key);
     return (code * 0x40100401u) >> 24;                                       // b0<<6 | b1<<4 | b2<<2 | b3 (no carries)
 }
-__device__ __forceinline__ uint32_t ascii16_to_word(const uint4 q, uint32_t &bad)
+__device__ __forceinline__ uint32_t ascii16_to_word(const uint4 q, uint32_t &bad, const CodeTabs ct)
 {
-    return (ascii4_to_2bit(q.x, bad) << 24) | (ascii4_to_2bit(q.y, bad) << 16) | (ascii4_to_2bit(q.z, bad) << 8) |
-           ascii4_to_2bit(q.w, bad);
+    return (ascii4_to_2bit(q.x, bad, ct) << 24) | (ascii4_to_2bit(q.y, bad, ct) << 16) | (ascii4_to_2bit(q.z, bad, ct) << 8) |
+           ascii4_to_2bit(q.w, bad, ct);
 }
 // tail lanes (the last <= 2 lanes of a genome, whose 96 bytes are not all inside it): bytes at or past L read as 'A' (their
 // k-mers are masked).  All 96 byte loads are unconditional on a clamped index, so they are issued together: one memory
 // round trip per genome tail instead of 96 (many small genomes: 41 us -> a few us per genome).
 struct TailWords { uint32_t w[6]; uint32_t bad; };
-__device__ __noinline__ TailWords ascii96_tail(const uint8_t *gseq, uint64_t o, uint64_t L)
+__device__ __noinline__ TailWords ascii96_tail(const uint8_t *gseq, uint64_t o, uint64_t L, const CodeTabs ct)
 {
     uint32_t d[24];
 #pragma unroll
@@ -361,13 +392,14 @@ __device__ __noinline__ TailWords ascii96_tail(const uint8_t *gseq, uint64_t o, 
     TailWords t;
     t.bad = 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) t.w[j] = ascii16_to_word(make_uint4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]), t.bad);
+    for (int j = 0; j < 6; ++j) t.w[j] = ascii16_to_word(make_uint4(d[4 * j], d[4 * j + 1], d[4 * j + 2], d[4 * j + 3]), t.bad, ct);
     return t;
 }
 
-template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT>
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT = false>
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
+    static_assert(!(ALT && DIRECT), "the alternative k-mer / bucket rules run on packed input only");
     // dynamic LDS: [nreg32 register words][16 words of per-wave census]; registers start at LDS offset 0 so the
     // bucket offset goes straight into the ds_max / ds_or address
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
@@ -385,13 +417,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
             for (uint64_t i = threadIdx.x; i < a.image_bytes; i += blockDim.x) img[i] = 0;
             __syncthreads();
-            if (threadIdx.x == 0) {
-                if constexpr (ALGO == 1) {
-                    write_hll_header_raw(img, a.alpha_bits, 1ull << p, (double)(1u << p), p);   // all registers 0: sum = m * 2^-0
-                } else if constexpr (ALGO == 2) {
-                    const uint64_t len = 1ull << p;
-                    for (int b = 0; b < 8; ++b) img[b] = (uint8_t)(len >> (8 * b));
-                }
+            if (threadIdx.x == 0) {                                          // all registers 0: zero = m, sum = m * 2^-0
+                const uint64_t n_regs = ALGO == 0 ? HMH_M : (1ull << p);
+                write_header(img, a.lay, a.alpha_bits, n_regs, n_regs, (double)n_regs, ALGO == 0 ? HMH_P : p);
             }
         }
         return;
@@ -431,6 +459,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     kp.mask_lt = (KMODE == KM_LT16) ? ((1u << (2 * k)) - 1u) : 0xFFFFFFFFu;
     kp.sh_gt = 64u - 2u * (uint32_t)k;
     kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    kp.lsb_xor = (ALT && a.lay.kmer_lsb_first) ? ((((uint64_t)a.lay.comp_mask << 32) | a.lay.comp_mask) & kp.mask_gt) : 0ull;
+    const uint32_t cmask = a.lay.comp_mask;
+    const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
     uint32_t my_kmers = 0;
 
     // One tile = blockDim.x * 4 words.  The next tile's words and break bits are loaded into registers before the
@@ -495,11 +526,11 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             uint32_t bad = 0;
             if (active) {
                 if (direct_fast(w0)) {
-                    c0 = ascii16_to_word(cur.q, bad); c1 = ascii16_to_word(cur.a1, bad); c2 = ascii16_to_word(cur.a2, bad);
-                    c3 = ascii16_to_word(cur.a3, bad); c4 = ascii16_to_word(cur.la, bad);
-                    if constexpr (KMODE == KM_GT16) c5 = ascii16_to_word(cur.lb, bad);
+                    c0 = ascii16_to_word(cur.q, bad, ctabs); c1 = ascii16_to_word(cur.a1, bad, ctabs); c2 = ascii16_to_word(cur.a2, bad, ctabs);
+                    c3 = ascii16_to_word(cur.a3, bad, ctabs); c4 = ascii16_to_word(cur.la, bad, ctabs);
+                    if constexpr (KMODE == KM_GT16) c5 = ascii16_to_word(cur.lb, bad, ctabs);
                 } else {
-                    const TailWords t = ascii96_tail(gseq, (uint64_t)w0 * 16, L);
+                    const TailWords t = ascii96_tail(gseq, (uint64_t)w0 * 16, L, ctabs);
                     c0 = t.w[0]; c1 = t.w[1]; c2 = t.w[2]; c3 = t.w[3]; c4 = t.w[4];
                     if constexpr (KMODE == KM_GT16) c5 = t.w[5];
                     bad |= t.bad;
@@ -518,11 +549,17 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         // wave-uniform: every lane of this wave has 64 real k-mers -> no per-k-mer masking at all
         const bool all_valid = __builtin_amdgcn_ballot_w64(kv != ~0ull) == 0ull;
 
-        uint32_t r0 = rcword(c0), r1 = rcword(c1), r2 = (KMODE == KM_GT16) ? rcword(c2) : 0u;
+        uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
 #pragma unroll 1
         for (int wi = 0; wi < SKETCH_WORDS_PER_THREAD; ++wi) {
             uint32_t z;
-            if (all_valid) {
+            if constexpr (ALT) {
+                // non-default k-mer / bucket rule: exact forms only, always masked (a compatibility mode, not a fast path)
+                uint32_t kvw = (uint32_t)kv;
+                if (a.lay.hll_bucket_high) (void)process_word<ALGO, KMODE, XLOW, true, false, Regs, true, ALGO == 1>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+                else (void)process_word<ALGO, KMODE, XLOW, true, false, Regs, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+                z = 0xFFFFFFFFu;
+            } else if (all_valid) {
                 z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
             } else {
                 // the masks are taken from an opaque copy so that hipcc cannot hoist the 16 v_bfe_i32 above the
@@ -542,7 +579,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             // rotate the window by one word
             c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = 0;
             r0 = r1;
-            if constexpr (KMODE == KM_GT16) { r1 = r2; r2 = rcword(c2); } else { r1 = rcword(c1); }
+            if constexpr (KMODE == KM_GT16) { r1 = r2; r2 = rcword(c2, cmask); } else { r1 = rcword(c1, cmask); }
             kv >>= 16;
         }
     }
@@ -566,7 +603,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const bool sole = (it.slice & ITEM_SOLE) != 0u;
     uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)blockIdx.x * a.partial_stride);
     uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
-    constexpr uint32_t HDR = ALGO == 0 ? 0u : ALGO == 1 ? 33u : 8u;
+    const uint32_t HDR = a.lay.hdr_bytes, reg_be = ALGO == 0 ? a.lay.hmh_reg_be : 0u;
     uint32_t *hist = census + 16;                                          // 72 words after the census (HLL header)
     if constexpr (ALGO == 1) {
         if (sole) {
@@ -577,8 +614,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     auto put = [&](uint32_t i, uint32_t v) {
         if (!sole) { out[i] = v; return; }
         uint8_t *dst = img + HDR + 4ull * i;
-        if (a.accumulate) v = merge_word<ALGO>(load_u32_any(dst), v);
-        store_u32_any(dst, v);
+        if (a.accumulate) v = merge_word<ALGO>(hmh_img_order(load_u32_any(dst), reg_be), v);
+        store_u32_any(dst, hmh_img_order(v, reg_be));
         if constexpr (ALGO == 1) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -590,6 +627,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     if constexpr (ALGO == 0) {
         for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
             put(i, regs.get(2 * i) | (regs.get(2 * i + 1) << 16));
+        if (sole && threadIdx.x == 0 && HDR) write_header(img, a.lay, a.alpha_bits, HMH_M, 0, 0.0, HMH_P);
     } else if constexpr (ALGO == 1) {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
         if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
@@ -597,7 +635,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             put(i, regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24));
         if (sole) {
             __syncthreads();
-            if (threadIdx.x == 0) write_hll_header(img, hist, a.alpha_bits, p);
+            if (threadIdx.x == 0) write_hll_header(img, a.lay, hist, a.alpha_bits, p);
         }
     } else {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
@@ -619,10 +657,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             }
             put(i, o);
         }
-        if (sole && threadIdx.x == 0) {
-            const uint64_t len = 1ull << p;                                // bincode Vec<u8> length prefix (switch U4)
-            for (int b = 0; b < 8; ++b) img[b] = (uint8_t)(len >> (8 * b));
-        }
+        if (sole && threadIdx.x == 0) write_header(img, a.lay, a.alpha_bits, 1ull << p, 0, 0.0, p);   // switch U4
     }
 }
 
@@ -697,7 +732,8 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
     const uint32_t i0 = a.genome_item_begin[g], i1 = a.genome_item_begin[g + 1];
     uint64_t nk = ~0ull;
     if (a.nvalid) { const uint64_t L = a.nvalid[g]; nk = L >= (uint64_t)a.k ? L - (uint64_t)a.k + 1 : 0; }
-    const uint32_t hdr = ALGO == 0 ? 0u : ALGO == 1 ? 33u : 8u;
+    const uint32_t hdr = a.lay.hdr_bytes, reg_be = ALGO == 0 ? a.lay.hmh_reg_be : 0u;
+    const uint32_t src_be = a.src_images ? reg_be : 0u;                    // merge of images: the "partials" are in image byte order
     const uint32_t nbytes = ALGO == 0 ? HMH_M * 2 : (1u << a.p);
     const uint32_t nwords = nbytes >> 2;                                   // p >= 3 -> at least 2 words
     uint8_t *img = a.images + (uint64_t)g * a.image_bytes;
@@ -716,14 +752,14 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
     if (i1 - i0 == 1u && (a.items[i0].slice & ITEM_SOLE)) return;
 
     for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
-        uint32_t acc = a.accumulate ? load_u32_any(img + hdr + 4ull * wi) : 0u;
+        uint32_t acc = a.accumulate ? hmh_img_order(load_u32_any(img + hdr + 4ull * wi), reg_be) : 0u;
         const uint32_t part = a.parts_log2 ? wi / (nwords >> a.parts_log2) : 0u;   // whose pass wrote this word
         for (uint32_t it = i0 + part; it < i1; it += step) {
             if (!a.group && (uint64_t)a.items[it].word_begin * 16 >= nk) continue;   // slice never ran (see sketch_kernel)
             const uint8_t *src = a.partials + (uint64_t)it * a.partial_stride + a.partial_base_off;
-            acc = merge_word<ALGO>(acc, load_u32_any(src + 4ull * wi));
+            acc = merge_word<ALGO>(acc, hmh_img_order(load_u32_any(src + 4ull * wi), src_be));
         }
-        store_u32_any(img + hdr + 4ull * wi, acc);
+        store_u32_any(img + hdr + 4ull * wi, hmh_img_order(acc, reg_be));
         if constexpr (ALGO == 1) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -734,22 +770,19 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
     }
     if constexpr (ALGO == 1) {
         __syncthreads();
-        if (threadIdx.x == 0) write_hll_header(img, hist, a.alpha_bits, a.p);
-    } else if constexpr (ALGO == 2) {
-        if (threadIdx.x == 0) {
-            const uint64_t len = 1ull << a.p;                              // bincode Vec<u8> length prefix (switch U4)
-            for (int b = 0; b < 8; ++b) img[b] = (uint8_t)(len >> (8 * b));
-        }
+        if (threadIdx.x == 0) write_hll_header(img, a.lay, hist, a.alpha_bits, a.p);
+    } else {
+        if (threadIdx.x == 0 && hdr) write_header(img, a.lay, a.alpha_bits, ALGO == 0 ? HMH_M : (1ull << a.p), 0, 0.0, ALGO == 0 ? HMH_P : a.p);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items)
+SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items, bool alt)
 {
     SketchPlan s{};
-    s.algo = algo; s.k = k; s.p = p; s.x_low = x_low;
+    s.algo = algo; s.k = k; s.p = p; s.x_low = x_low; s.alt = alt;
     if (algo == 0) { s.nreg32 = HMH_M; s.partial_bytes = HMH_M * 2; }
     else if (algo == 1) { s.nreg32 = 1u << p; s.partial_bytes = 1u << p; }
     else { s.nreg32 = 2u << p; s.partial_bytes = 1u << p; }
@@ -780,10 +813,10 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
     return s;
 }
 
-template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT>
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
-    auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT>;
+    auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT>;
     if (plan.lds_bytes > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
@@ -793,35 +826,38 @@ static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uin
     return hipGetLastError();
 }
 
-template <int ALGO, bool XLOW, bool DIRECT>
+template <int ALGO, bool XLOW, bool DIRECT, bool ALT>
 static hipError_t launch_kmode(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
     if constexpr (ALGO != 0) {                                  // HMH's table always fits
         if (plan.use_lds && plan.parts_log2) {
-            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS_PARTS, DIRECT>(plan, args, n, s);
-            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS_PARTS, DIRECT>(plan, args, n, s);
-            return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS_PARTS, DIRECT>(plan, args, n, s);
+            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS_PARTS, DIRECT, ALT>(plan, args, n, s);
+            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS_PARTS, DIRECT, ALT>(plan, args, n, s);
+            return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS_PARTS, DIRECT, ALT>(plan, args, n, s);
         }
     }
     if (plan.use_lds) {
-        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
-        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
-        return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
+        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS, DIRECT, ALT>(plan, args, n, s);
+        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS, DIRECT, ALT>(plan, args, n, s);
+        return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS, DIRECT, ALT>(plan, args, n, s);
     }
-    if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
-    if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
-    return launch_one<ALGO, KM_GT16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
+    if constexpr (ALGO == 2) {                                  // only ULL p >= 19 outgrows the partitioned LDS passes
+        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_GLOBAL, DIRECT, ALT>(plan, args, n, s);
+        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_GLOBAL, DIRECT, ALT>(plan, args, n, s);
+        return launch_one<ALGO, KM_GT16, XLOW, REGS_GLOBAL, DIRECT, ALT>(plan, args, n, s);
+    }
+    return hipErrorInvalidValue;
 }
 
-template <bool DIRECT>
+template <bool DIRECT, bool ALT>
 static hipError_t launch_algo(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
     switch (plan.algo) {
-    case 0: return plan.x_low ? launch_kmode<0, true, DIRECT>(plan, args, n_items, stream)
-                              : launch_kmode<0, false, DIRECT>(plan, args, n_items, stream);
-    case 1: return launch_kmode<1, false, DIRECT>(plan, args, n_items, stream);
-    case 2: return launch_kmode<2, false, DIRECT>(plan, args, n_items, stream);
+    case 0: return plan.x_low ? launch_kmode<0, true, DIRECT, ALT>(plan, args, n_items, stream)
+                              : launch_kmode<0, false, DIRECT, ALT>(plan, args, n_items, stream);
+    case 1: return launch_kmode<1, false, DIRECT, ALT>(plan, args, n_items, stream);
+    case 2: return launch_kmode<2, false, DIRECT, ALT>(plan, args, n_items, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -829,7 +865,8 @@ static hipError_t launch_algo(const SketchPlan &plan, const SketchArgs &args, ui
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream, bool direct)
 {
     if (n_items == 0) return hipSuccess;
-    return direct ? launch_algo<true>(plan, args, n_items, stream) : launch_algo<false>(plan, args, n_items, stream);
+    if (plan.alt) return direct ? hipErrorInvalidValue : launch_algo<false, true>(plan, args, n_items, stream);
+    return direct ? launch_algo<true, false>(plan, args, n_items, stream) : launch_algo<false, false>(plan, args, n_items, stream);
 }
 
 // one thread per record: the first byte of every record but a genome's first is a k-mer barrier (utils.rs:457-464)

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Params, Timing
+from ._lib import Layout, Params, Timing
 
 ALGOS = {"hmh": _lib.HMH, "hll": _lib.HLL, "ull": _lib.ULL}
 
@@ -27,8 +27,26 @@ def _algo(a):
     return int(a)
 
 
-def image_bytes(algo, p=0):
-    return int(_lib.load().lash_sketch_image_bytes(_algo(algo), int(p)))
+def parse_layout(spec):
+    """"key=value,..." (see lash_layout_parse in include/lash_gfx950.h) -> Layout; None / "" = the default."""
+    if isinstance(spec, Layout):
+        return spec
+    lay = Layout()
+    rc = _lib.load().lash_layout_parse((spec or "").encode(), C.byref(lay))
+    if rc != _lib.OK:
+        raise LashError(rc, "bad layout spec %r" % (spec,))
+    return lay
+
+
+def image_bytes(algo, p=0, layout=None):
+    if layout is None:
+        return int(_lib.load().lash_sketch_image_bytes(_algo(algo), int(p)))
+    return int(_lib.load().lash_layout_image_bytes(C.byref(parse_layout(layout)), _algo(algo), int(p)))
+
+
+def header_bytes(algo, layout=None):
+    lay = parse_layout(layout)
+    return int(_lib.load().lash_layout_header_bytes(C.byref(lay), _algo(algo)))
 
 
 def params_check(algo, k, p=0):
@@ -127,6 +145,14 @@ class Context:
     def synchronize(self):
         self._check(self._lib.lash_ctx_synchronize(self._h))
 
+    def set_layout(self, layout=None):
+        """layout: None (default), a spec string, or a Layout.  Every later call reads / writes images in that layout."""
+        self._layout = None if layout is None else parse_layout(layout)
+        self._check(self._lib.lash_ctx_set_layout(self._h, None if self._layout is None else C.byref(self._layout)))
+
+    def image_bytes(self, algo, p=0):
+        return image_bytes(algo, p, getattr(self, "_layout", None))
+
     def enable_timing(self, on=True):
         self._check(self._lib.lash_ctx_enable_timing(self._h, 1 if on else 0))
 
@@ -148,7 +174,7 @@ class Context:
         rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
         goff = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
         n_g, n_rec = len(goff) - 1, len(rec_off) - 1
-        ib = image_bytes(prm.algo, prm.p)
+        ib = self.image_bytes(prm.algo, prm.p)
         if out is None:
             out = np.zeros((n_g, ib), dtype=np.uint8)
         assert out.dtype == np.uint8 and out.size == n_g * ib and out.flags.c_contiguous
@@ -167,7 +193,7 @@ class Context:
         if files_bytes:
             off[1:] = np.cumsum([len(f) for f in files_bytes], dtype=np.uint64)
         fmt = np.array([_lib.FMT_FASTQ if f.lstrip(b"\r\n")[:1] == b"@" else _lib.FMT_FASTA for f in files_bytes], dtype=np.uint8)
-        ib = image_bytes(prm.algo, prm.p)
+        ib = self.image_bytes(prm.algo, prm.p)
         out = np.zeros((len(files_bytes), ib), dtype=np.uint8)
         self._check(self._lib.lash_sketch_files_raw(self._h, C.byref(prm), raw.ctypes.data if raw.size else None,
                                                     off.ctypes.data, fmt.ctypes.data if fmt.size else None,
@@ -214,7 +240,8 @@ class Context:
         [n_ref, n_qry] arrays out (hyperminhash Sketch::similarity's register scan, utils.rs:164)."""
         ref = np.ascontiguousarray(ref_images, dtype=np.uint8)
         qry = np.ascontiguousarray(qry_images, dtype=np.uint8)
-        assert ref.ndim == 2 and qry.ndim == 2 and ref.shape[1] == 32768 and qry.shape[1] == 32768
+        ib = self.image_bytes("hmh")
+        assert ref.ndim == 2 and qry.ndim == 2 and ref.shape[1] == ib and qry.shape[1] == ib
         c = np.zeros((ref.shape[0], qry.shape[0]), dtype=np.uint32)
         n = np.zeros_like(c)
         self._check(self._lib.lash_hmh_pair_counts(self._h, ref.ctypes.data, ref.shape[0], qry.ctypes.data, qry.shape[0],
@@ -226,7 +253,7 @@ class Context:
         [n_ref, n_qry] out — what `len()` reads after `union` (utils.rs:355-363)."""
         ref = np.ascontiguousarray(ref_images, dtype=np.uint8)
         qry = np.ascontiguousarray(qry_images, dtype=np.uint8)
-        ib = 33 + (1 << int(p))
+        ib = self.image_bytes("hll", p)
         assert ref.ndim == 2 and qry.ndim == 2 and ref.shape[1] == ib and qry.shape[1] == ib
         zero = np.zeros((ref.shape[0], qry.shape[0]), dtype=np.uint32)
         usum = np.zeros((ref.shape[0], qry.shape[0]), dtype=np.float64)

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(raw, n), "liblash_gfx950.so does not export %s" % n
         assert n in _lib.PROTOTYPES, "lash_amd/_lib.py has no prototype for %s" % n
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.lash_abi_version() == 1
+    assert lib.lash_abi_version() == 2
 
 
 def test_image_sizes_and_param_checks():
@@ -44,6 +44,28 @@ def test_image_sizes_and_param_checks():
         assert lash_amd.params_check(a, k, p) == lash_amd.EINVAL, (a, k, p)
     with pytest.raises(lash_amd.LashError):          # main.rs:245 "Algorithm must be either hmh, ull, or hll"
         lash_amd.params_check("minhash", 16, 0)
+
+
+def test_layout_host_entries():
+    """lash_layout (SURVEY App. D's unknowns as data): default, parse, sizes — host only."""
+    import oracle_lib as O
+    d = lash_amd.parse_layout(None)
+    assert bytes(d) == bytes(O.default_layout())                      # the product's and the oracle's structs are the same 32 bytes
+    assert C.sizeof(_lib.Layout) == 32 == C.sizeof(O.Layout)
+    spec = "codes=ACTG,kmer=lsb,hmh_x=low,hmh_reg=be,hll_bucket=high,hmh_hdr=l,hll_hdr=pzsal,ull_hdr=pL"
+    lay = lash_amd.parse_layout(spec)
+    assert bytes(lay) == bytes(O.parse_layout(spec))
+    assert lash_amd.image_bytes("hmh", 0, lay) == 8 + 32768 == O.image_bytes(O.HMH, 0, O.parse_layout(spec))
+    assert lash_amd.image_bytes("hll", 10, lay) == 33 + 1024 and lash_amd.image_bytes("ull", 9, lay) == 5 + 512
+    assert lash_amd.header_bytes("hll") == 33 and lash_amd.header_bytes("ull") == 8 and lash_amd.header_bytes("hmh") == 0
+    for bad in ("codes=ACGA", "codes=ACG", "kmer=middle", "hll_hdr=azsplazspl", "hll_hdr=x", "nonsense", "what=ever"):
+        with pytest.raises(lash_amd.LashError):
+            lash_amd.parse_layout(bad)
+    assert _lib.load().lash_layout_check(C.byref(lay)) == lash_amd.OK
+    broken = lash_amd.parse_layout(None)
+    broken.base_code[2] = 0
+    assert _lib.load().lash_layout_check(C.byref(broken)) == lash_amd.EINVAL
+    assert lash_amd.image_bytes("hmh", 0, broken) == 0
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

@@ -1,0 +1,111 @@
+"""GPU side of the layout switches (include/lash_gfx950.h `lash_layout`): for every alternative the
+oracle implements, the HIP path with the same layout set on the context must give the oracle's bytes — through the direct
+(ASCII-reading) route, the pack-first route, the raw-file route, the merge entry and the dist-side pair kernels.
+This is what makes a mismatch against real `lash` images (tools/ref_probe) a field change instead of a code change."""
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ALGO = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}
+
+SPECS = [
+    "codes=ACTG",
+    "codes=TGCA,kmer=lsb",
+    "kmer=lsb",
+    "hmh_x=low,hmh_reg=be,hmh_hdr=l",
+    "hll_bucket=high,hll_hdr=pzsal",
+    "hll_hdr=PZ,ull_hdr=pL,hmh_hdr=p",
+    "codes=GATC,ull_hdr=,hmh_hdr=Q,hll_bucket=high,kmer=lsb",
+]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lash_amd
+    c = lash_amd.Context(0)
+    yield c
+    c.set_layout(None)
+    c.close()
+
+
+def _genomes(rng, clean):
+    gs = []
+    for g in range(5):
+        recs = []
+        for _ in range(rng.randint(1, 4)):
+            n = rng.randint(0, 6000)
+            s = "".join(rng.choice("ACGT") for _ in range(n))
+            if not clean and n > 100 and rng.random() < 0.7:
+                cut = rng.randint(0, n - 50)
+                s = s[:cut] + rng.choice(["N" * rng.randint(1, 40), "acgtn", "RY"]) + s[cut:]
+            recs.append(s.encode())
+        gs.append(recs)
+    gs.append([O.synth_genome(77, 300_000).tobytes()])              # several slices
+    return gs
+
+
+@pytest.mark.parametrize("spec", SPECS)
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 11, 0), ("hmh", 31, 0), ("hll", 21, 14), ("hll", 16, 16),
+                                    ("ull", 16, 12), ("ull", 32, 16), ("ull", 9, 19)])
+def test_layout_alternatives_match_oracle(ctx, spec, an, k, p):
+    import lash_amd
+    lay = O.parse_layout(spec)
+    ctx.set_layout(spec)
+    try:
+        seed = zlib.crc32(repr((spec, an, k, p)).encode())
+        rng = random.Random(seed)
+        for clean in (True, False):
+            seq, off, goff = lash_amd.records_to_arrays(_genomes(rng, clean))
+            want = O.sketch_genomes(ALGO[an], k, p, 42, seq, off, goff, threads=8, layout=lay)
+            for flags in (0, lash_amd.F_NO_DIRECT):
+                got = ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=flags)
+                assert got.shape == want.shape and np.array_equal(got, want), (spec, an, k, p, clean, flags, seed)
+        # union of serialized sketches through the same layout (header offsets, HMH byte order, HLL header fields)
+        a, b = want[:3].copy(), want[3:6].copy()
+        m = ctx.merge_images(an, p, a.copy(), b)
+        for i in range(3):
+            assert np.array_equal(m[i], O.merge_images(ALGO[an], p, a[i], b[i], layout=lay)), (spec, an, i)
+    finally:
+        ctx.set_layout(None)
+
+
+@pytest.mark.parametrize("spec", ["codes=ACTG,hmh_hdr=l,hmh_reg=be", "hll_bucket=high,hll_hdr=pzsal,kmer=lsb"])
+def test_layout_raw_files_and_pair_kernels(ctx, spec):
+    lay = O.parse_layout(spec)
+    ctx.set_layout(spec)
+    try:
+        rng = random.Random(zlib.crc32(spec.encode()))
+        files = []
+        for f in range(4):
+            body = "".join(rng.choice("ACGT") for _ in range(20_000))
+            lines = "\n".join(body[i:i + 70] for i in range(0, len(body), 70))
+            files.append((">f%d\n%s\n>second\nACGTNNNNACGTACGTACGTTTGACCA\n" % (f, lines)).encode())
+        for an, k, p in (("hmh", 16, 0), ("hll", 21, 12), ("ull", 16, 10)):
+            got = ctx.sketch_files_raw(an, k, p, 42, files)
+            want = O.sketch_files(ALGO[an], k, p, 42, files, threads=4, layout=lay)
+            assert np.array_equal(got, want), (spec, an)
+        # dist side: pair statistics read registers behind the layout's header; HMH counts do not depend on byte order
+        hm = O.sketch_files(O.HMH, 16, 0, 42, files, layout=lay)
+        hd = O.sketch_files(O.HMH, 16, 0, 42, files)                   # default layout, same registers
+        c, n = ctx.hmh_pair_counts(hm, hm)
+        hb = O.header_bytes(O.HMH, lay)
+        ra = hd.view("<u2").astype(np.int64)
+        for i in range(4):
+            for j in range(4):
+                assert c[i, j] == int(((ra[i] != 0) & (ra[i] == ra[j])).sum()) and n[i, j] == int(((ra[i] != 0) | (ra[j] != 0)).sum())
+        assert hm.shape[1] == hb + 32768
+        hl = O.sketch_files(O.HLL, 21, 12, 42, files, layout=lay)
+        zero, usum = ctx.hll_pair_union_stats(12, hl, hl)
+        hh = O.header_bytes(O.HLL, lay)
+        regs = hl[:, hh:].astype(np.int64)
+        for i in range(4):
+            for j in range(4):
+                u = np.maximum(regs[i], regs[j])
+                assert zero[i, j] == int((u == 0).sum()) and abs(usum[i, j] - float(np.sum(2.0 ** -u.astype(np.float64)))) < 1e-9
+    finally:
+        ctx.set_layout(None)

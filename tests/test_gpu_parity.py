@@ -4,6 +4,7 @@ import hashlib
 import json
 import os
 import random
+import zlib
 
 import numpy as np
 import pytest
@@ -74,7 +75,7 @@ def test_fixture_files_match_oracle_and_digests(ctx):
                                     ("ull", 16, 12), ("ull", 1, 3), ("ull", 19, 14), ("ull", 27, 8), ("ull", 32, 10)])
 def test_messy_batches_match_oracle(ctx, an, k, p):
     import lash_amd
-    rng = random.Random(hash((an, k, p)) & 0xFFFF)
+    rng = random.Random(zlib.crc32(repr((an, k, p)).encode()))     # reproducible across processes (no PYTHONHASHSEED)
     gs = messy_genomes(rng, 23)
     gs[5] = []                              # genome without records
     gs[7] = [b"", b"", b"ACGT"]             # empty records
