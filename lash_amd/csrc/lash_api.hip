@@ -298,7 +298,7 @@ LayoutDev layout_dev(const lash_layout &lay, int algo)
     d.comp_mask = (A ^ T) * 0x55555555u;
     d.hdr_bytes = (uint32_t)header_bytes(lay, algo);
     const char *t = header_tpl(lay, algo);
-    for (int i = 0; i < 8; ++i) d.hdr_tpl[i] = (uint8_t)t[i];
+    for (int i = 0; i < 8 && t[i]; ++i) d.hdr_tpl |= (uint64_t)(uint8_t)t[i] << (8 * i);
     d.hmh_reg_be = lay.hmh_reg_be;
     d.kmer_lsb_first = lay.kmer_lsb_first;
     d.hll_bucket_high = lay.hll_bucket_high;

@@ -42,11 +42,11 @@ struct LayoutDev {
     uint32_t code_tab4;          // pack route: byte i = layout code of the letter whose kmerutils-hypothesis code is i
     uint32_t comp_mask;          // complement of 16 packed bases = word ^ comp_mask  (code[A]^code[T] in every 2-bit group)
     uint32_t hdr_bytes;          // bytes written before the register array of this algo's image
-    uint8_t  hdr_tpl[8];         // that header's field codes (see lash_layout), 0-terminated
-    uint8_t  hmh_reg_be;         // HyperMinHash registers big-endian in images
-    uint8_t  kmer_lsb_first;     // (ALT kernels only) a k-mer's first base is its least significant 2 bits
-    uint8_t  hll_bucket_high;    // (ALT kernels only) HLL bucket = top p bits of the hash
-    uint8_t  pad;
+    uint32_t hmh_reg_be;         // HyperMinHash registers big-endian in images
+    uint32_t kmer_lsb_first;     // (ALT kernels only) a k-mer's first base is its least significant 2 bits
+    uint32_t hll_bucket_high;    // (ALT kernels only) HLL bucket = top p bits of the hash
+    uint64_t hdr_tpl;            // that header's field codes (see lash_layout), first field in the low byte, 0-terminated
+                                 // (a scalar, not an array: a dynamically indexed kernel-argument array would live in scratch)
 };
 
 // XXH3 constants (XXH 0.8 spec; closed forms in SURVEY.md Appendix C, pinned by tests/golden/xxh3_vectors.json)

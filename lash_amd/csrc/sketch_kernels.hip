@@ -312,12 +312,12 @@ __device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
 // Image header by template (lash_layout header codes; defaults: HMH none, HLL "azspl" = bincode of streaming_algorithms'
 // alpha f64, zero u64, sum f64, p u8 + the Box<[u8]> length prefix, ULL "l" = bincode Vec<u8> length prefix).
 __device__ __forceinline__ void put_le(uint8_t *dst, uint64_t v, int n) { for (int b = 0; b < n; ++b) dst[b] = (uint8_t)(v >> (8 * b)); }
-__device__ __noinline__ void write_header(uint8_t *img, const LayoutDev &lay, uint64_t alpha_bits, uint64_t n_regs, uint64_t zero,
+__device__ __noinline__ void write_header(uint8_t *img, uint64_t tpl, uint64_t alpha_bits, uint64_t n_regs, uint64_t zero,
                                           double sum, int p)
 {
     uint32_t at = 0;
-    for (int i = 0; i < 8 && lay.hdr_tpl[i]; ++i) {
-        switch (lay.hdr_tpl[i]) {
+    for (; tpl & 0xFFu; tpl >>= 8) {
+        switch ((uint32_t)(tpl & 0xFFu)) {
         case 'a': put_le(img + at, alpha_bits, 8); at += 8; break;
         case 'z': put_le(img + at, zero, 8); at += 8; break;
         case 'Z': put_le(img + at, zero, 4); at += 4; break;
@@ -333,13 +333,13 @@ __device__ __noinline__ void write_header(uint8_t *img, const LayoutDev &lay, ui
 }
 // HLL: zero and sum are recomputed from the final registers' histogram; sum = sum_j 2^-m[j] is exact in f64 here (largest
 // exponent first), equal to the reference's incremental f64 updates.
-__device__ __forceinline__ void write_hll_header(uint8_t *img, const LayoutDev &lay, const uint32_t *hist, uint64_t alpha_bits, int p)
+__device__ __forceinline__ void write_hll_header(uint8_t *img, uint64_t tpl, const uint32_t *hist, uint64_t alpha_bits, int p)
 {
     double sum = 0.0;
     for (int r = 66; r >= 0; --r) {
         if (hist[r]) sum += (double)hist[r] * __longlong_as_double((long long)(1023 - r) << 52);
     }
-    write_header(img, lay, alpha_bits, 1ull << p, hist[0], sum, p);
+    write_header(img, tpl, alpha_bits, 1ull << p, hist[0], sum, p);
 }
 // HyperMinHash registers travel as native little-endian u16 pairs; images may hold them big-endian (layout.hmh_reg_be)
 __device__ __forceinline__ uint32_t hmh_img_order(uint32_t v, uint32_t be) { return be ? (((v & 0x00FF00FFu) << 8) | ((v >> 8) & 0x00FF00FFu)) : v; }
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             __syncthreads();
             if (threadIdx.x == 0) {                                          // all registers 0: zero = m, sum = m * 2^-0
                 const uint64_t n_regs = ALGO == 0 ? HMH_M : (1ull << p);
-                write_header(img, a.lay, a.alpha_bits, n_regs, n_regs, (double)n_regs, ALGO == 0 ? HMH_P : p);
+                write_header(img, a.lay.hdr_tpl, a.alpha_bits, n_regs, n_regs, (double)n_regs, ALGO == 0 ? HMH_P : p);
             }
         }
         return;
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     if constexpr (ALGO == 0) {
         for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
             put(i, regs.get(2 * i) | (regs.get(2 * i + 1) << 16));
-        if (sole && threadIdx.x == 0 && HDR) write_header(img, a.lay, a.alpha_bits, HMH_M, 0, 0.0, HMH_P);
+        if (sole && threadIdx.x == 0 && HDR) write_header(img, a.lay.hdr_tpl, a.alpha_bits, HMH_M, 0, 0.0, HMH_P);
     } else if constexpr (ALGO == 1) {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
         if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
@@ -635,7 +635,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             put(i, regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24));
         if (sole) {
             __syncthreads();
-            if (threadIdx.x == 0) write_hll_header(img, a.lay, hist, a.alpha_bits, p);
+            if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p);
         }
     } else {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
@@ -657,7 +657,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             }
             put(i, o);
         }
-        if (sole && threadIdx.x == 0) write_header(img, a.lay, a.alpha_bits, 1ull << p, 0, 0.0, p);   // switch U4
+        if (sole && threadIdx.x == 0) write_header(img, a.lay.hdr_tpl, a.alpha_bits, 1ull << p, 0, 0.0, p);   // switch U4
     }
 }
 
@@ -770,9 +770,9 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
     }
     if constexpr (ALGO == 1) {
         __syncthreads();
-        if (threadIdx.x == 0) write_hll_header(img, a.lay, hist, a.alpha_bits, a.p);
+        if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, a.p);
     } else {
-        if (threadIdx.x == 0 && hdr) write_header(img, a.lay, a.alpha_bits, ALGO == 0 ? HMH_M : (1ull << a.p), 0, 0.0, ALGO == 0 ? HMH_P : a.p);
+        if (threadIdx.x == 0 && hdr) write_header(img, a.lay.hdr_tpl, a.alpha_bits, ALGO == 0 ? HMH_M : (1ull << a.p), 0, 0.0, ALGO == 0 ? HMH_P : a.p);
     }
 }
 

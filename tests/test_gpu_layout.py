@@ -91,10 +91,9 @@ def test_layout_raw_files_and_pair_kernels(ctx, spec):
             assert np.array_equal(got, want), (spec, an)
         # dist side: pair statistics read registers behind the layout's header; HMH counts do not depend on byte order
         hm = O.sketch_files(O.HMH, 16, 0, 42, files, layout=lay)
-        hd = O.sketch_files(O.HMH, 16, 0, 42, files)                   # default layout, same registers
         c, n = ctx.hmh_pair_counts(hm, hm)
         hb = O.header_bytes(O.HMH, lay)
-        ra = hd.view("<u2").astype(np.int64)
+        ra = np.ascontiguousarray(hm[:, hb:]).view(">u2" if lay.hmh_reg_be else "<u2").astype(np.int64)
         for i in range(4):
             for j in range(4):
                 assert c[i, j] == int(((ra[i] != 0) & (ra[i] == ra[j])).sum()) and n[i, j] == int(((ra[i] != 0) | (ra[j] != 0)).sum())
