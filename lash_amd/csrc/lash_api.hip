@@ -79,7 +79,8 @@ struct lash_packed {
     // on the device, to the genomes the direct sketch pass flagged dirty
     bool direct = false, any_multi = false;
     const uint8_t *d_seq = nullptr;
-    uint32_t *d_dirty = nullptr;         // inside `lookback` (zeroed by the same memset)
+    uint32_t *d_dirty = nullptr;         // inside `lookback` (zeroed by the same memset): [n+1] dirty flags, then [n] slow
+                                         // wave-tile counts and [n] in-place deleted-byte counts of the direct pass
     DevBuf tile_begin_c, brk_bytes;
     std::vector<GenomeDesc> h_descs;     // host copies, uploaded together with the work items
     std::vector<uint32_t> h_tile_begin;
@@ -373,7 +374,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
     if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
     const size_t lb_bytes = (((size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512) + 15) & ~(size_t)15;
-    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(n_genomes + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(3 * (size_t)n_genomes + 2) * 4))) return rc;
     pk->d_dirty = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(pk->lookback.ptr) + lb_bytes);
     if (direct && (rc = reserve(ctx, pk->tile_begin_c, (size_t)(n_genomes + 2) * 4))) return rc;
     if (n_genomes == 0) return LASH_OK;
@@ -545,7 +546,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             mpk->pa.nvalid = pk->d_nvalid;
             mpk->pm.tile_begin = pk->d_tile_begin;
             const size_t lb_bytes = reinterpret_cast<uint8_t *>(pk->d_dirty) - static_cast<uint8_t *>(pk->lookback.ptr);
-            HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (size_t)(n_genomes + 1) * 4, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (size_t)(3 * (size_t)n_genomes + 2) * 4, ctx->stream));
             if (pk->any_multi) {
                 HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, ctx->stream));
                 HIPCHK(ctx, hipMemsetAsync(pk->brk_bytes.ptr, 0, pk->total_brk * 4, ctx->stream));
@@ -593,6 +594,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.seq = pk->d_seq;
         sa.brk_bytes = static_cast<const uint32_t *>(pk->brk_bytes.ptr);
         sa.dirty = pk->d_dirty;
+        sa.nslow = pk->d_dirty + n_genomes + 1;
+        sa.ndel = sa.nslow + n_genomes;
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true));     // ASCII in, exact while nothing is deleted
         if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
         if ((rc = pack_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
@@ -907,6 +910,13 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
         std::vector<uint64_t> nv(pk->n_genomes);
         HIPCHK(ctx, hipMemcpy(nv.data(), pk->d_nvalid, nv.size() * 8, hipMemcpyDeviceToHost));
         for (uint64_t v : nv) t.bases_last += v;
+        if (pk->direct) {                                          // bytes the direct pass deleted in place (genomes it kept)
+            const uint32_t n = pk->n_genomes;
+            std::vector<uint32_t> fl(3 * (size_t)n + 1);
+            HIPCHK(ctx, hipMemcpy(fl.data(), pk->d_dirty, fl.size() * 4, hipMemcpyDeviceToHost));
+            for (uint32_t g = 0; g < n; ++g)
+                if (!fl[g]) t.bases_last -= fl[2 * (size_t)n + 1 + g];
+        }
     }
     *out = t;
     return LASH_OK;

@@ -26,8 +26,10 @@ struct SketchArgs {
     const uint8_t    *seq;        // the caller's record bytes
     const uint32_t   *brk_bytes;  // record-break bitmap in BYTE positions (== base positions while nothing is deleted)
     const uint8_t    *safe;       // >= 128 readable bytes: load target of lanes that are not on the fast path
-    uint32_t         *dirty;      // [n_genomes + 1] per genome: a byte outside {A,C,G,T} was met; [n_genomes] = how many.
-                                  // non-direct launches with dirty != NULL run only the genomes flagged here
+    uint32_t         *dirty;      // [n_genomes + 1] per genome: the direct pass gave this genome up (dense dirt or a long run of
+                                  // deleted bytes); [n_genomes] = how many.  Non-direct launches with dirty != NULL run only these
+    uint32_t         *nslow;      // [n_genomes] wave-tiles of the direct pass that met deleted bytes (budget: sketch_kernels.hip)
+    uint32_t         *ndel;       // [n_genomes] bytes the direct pass deleted in place (surviving bases = nvalid - ndel while !dirty)
     uint64_t          bitflip;    // xxh3 seed-folded constant (64- or 128-bit variant by algo)
     LayoutDev         lay;
     uint32_t          partial_stride;

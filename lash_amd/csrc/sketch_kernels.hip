@@ -396,6 +396,120 @@ __device__ __noinline__ TailWords ascii96_tail(const uint8_t *gseq, uint64_t o, 
     return t;
 }
 
+// ---- direct mode, sparse dirt in place ---------------------------------------------------------------------
+// filter_out_n (utils.rs:33-41) DELETES a byte that is not upper-case ACGT and joins the flanks.  Seen from a k-mer's
+// first base b (a surviving byte): if the k bytes [b, b+k) all survive, the k-mer is the raw window (the fast path, with
+// every window that holds a deleted byte masked out); otherwise it is b plus the next k-1 SURVIVING bytes, wherever they
+// are — a "junction" k-mer.  Junction k-mers are few (at most k-1 per run of deleted bytes) and belong to the lane that
+// owns b; that lane walks forward from its first junction start, skipping deleted bytes, and hashes them one by one.
+// One assembly gap or a sprinkle of IUPAC codes therefore costs a few microseconds of one lane instead of sending
+// the genome through the pack stage after a wasted direct pass; dense dirt (soft-masked assemblies) and runs longer
+// than WALK_MAX still take the fallback, decided per genome by a budget of slow wave-tiles.
+constexpr uint32_t WALK_MAX = 4096;          // bytes a junction walk may read past its lane's 64 positions
+
+__device__ __forceinline__ uint32_t inv4(uint32_t x)            // bit j: byte j is not one of A C G T
+{
+    const uint32_t z = x ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x & 0x07070707u);
+    const uint32_t nz = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;
+    return ((((nz >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+}
+__device__ __forceinline__ uint32_t inv16(const uint4 q) { return inv4(q.x) | (inv4(q.y) << 4) | (inv4(q.z) << 8) | (inv4(q.w) << 12); }
+
+struct InvMask { uint64_t lo; uint32_t hi; };                  // deleted bytes among the lane's 96: own 64 + look-ahead 32
+// re-reads the lane's bytes (L1 / L2 hits: they were loaded a moment ago) so that the fast path keeps no raw bytes alive
+__device__ __noinline__ InvMask lane_inv_mask(const uint8_t *gseq, uint64_t o, uint64_t L)
+{
+    InvMask m{0, 0};
+    if (o + 96 <= L) {
+        const uint8_t *src = gseq + o;
+        m.lo = (uint64_t)inv16(load16_any(src)) | ((uint64_t)inv16(load16_any(src + 16)) << 16) |
+               ((uint64_t)inv16(load16_any(src + 32)) << 32) | ((uint64_t)inv16(load16_any(src + 48)) << 48);
+        m.hi = inv16(load16_any(src + 64)) | (inv16(load16_any(src + 80)) << 16);
+    } else {
+        for (uint32_t i = 0; i < 96 && o + i < L; ++i) {         // the genome's last lanes: bytes at or past L are nobody's
+            const uint32_t c = gseq[o + i];
+            const bool ok = c == 0x41u || c == 0x43u || c == 0x47u || c == 0x54u;
+            if (!ok) { if (i < 64) m.lo |= 1ull << i; else m.hi |= 1u << (i - 64); }
+        }
+    }
+    return m;
+}
+// bit i = OR of bits i .. i+n-1 of the 96-bit value {hi, lo}, for i < 64 and 1 <= n <= 32
+__device__ __forceinline__ uint64_t window_or(uint64_t lo, uint32_t hi32, int n)
+{
+    uint64_t hi = hi32;
+    int len = 1;
+    while (len * 2 <= n) {
+        lo |= (lo >> len) | (hi << (64 - len));
+        hi |= hi >> len;
+        len *= 2;
+    }
+    if (len < n) {
+        const int s = n - len;
+        lo |= (lo >> s) | (hi << (64 - s));
+    }
+    return lo;
+}
+
+// The junction k-mers whose first base is one of this lane's 64 positions (set J; `starts` = the lane's surviving bytes
+// from the first junction start on).  Bases are collected in order, deleted bytes skipped, a record start resets the
+// window (k-mers never span records, utils.rs:457-464); every completed k-mer consumes the lowest remaining start, and
+// is hashed iff that start is in J (the others are whole windows the fast path has done).  Returns how many it added.
+template <int ALGO, bool XLOW, class Regs>
+__device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *gseq, uint64_t L, uint64_t pos0, uint64_t J,
+                                               uint64_t starts, const uint32_t *bk, int k, uint64_t bitflip, int p,
+                                               uint32_t cmask, const CodeTabs ct, uint32_t *dirty)
+{
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t s0 = (uint32_t)__builtin_ctzll(J);
+    uint64_t pos = pos0 + s0, fwd = 0;
+    uint32_t have = 0, added = 0;
+    while (starts && pos < L) {
+        if (pos - pos0 > 64 + WALK_MAX) {                       // a long run of deleted bytes: leave the genome to the pack stage
+            atomicOr(dirty, 1u);
+            break;
+        }
+        // next 16 bytes (clamped at the genome's end), their codes, which of them survive, which start a record
+        uint4 q;
+        uint32_t nb = 16;
+        if (pos + 16 <= L) q = load16_any(gseq + pos);
+        else {
+            nb = (uint32_t)(L - pos);
+            uint32_t d[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+            for (uint32_t i = 0; i < nb; ++i) d[i >> 2] = (d[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)gseq[pos + i] << (8 * (i & 3)));
+            q = make_uint4(d[0], d[1], d[2], d[3]);
+        }
+        uint32_t bad = 0;
+        const uint32_t codes = ascii16_to_word(q, bad, ct);      // byte j -> bits 31-2j..30-2j
+        uint32_t ok = ~inv16(q) & ((1u << nb) - 1u);
+        uint32_t brk = 0;
+        if (bk) {
+            const uint64_t two = ((uint64_t)bk[(pos >> 5) + 1] << 32) | bk[pos >> 5];
+            brk = (uint32_t)(two >> (pos & 31)) & 0xFFFFu;
+        }
+        for (uint32_t j = 0; j < nb && starts; ++j) {
+            if ((brk >> j) & 1u) {                               // a record starts at this byte
+                have = 0;
+                const uint64_t rel = pos + j - pos0;
+                starts = rel < 64 ? starts & ~((1ull << rel) - 1ull) : 0ull;
+            }
+            if (!((ok >> j) & 1u)) continue;
+            fwd = ((fwd << 2) | ((codes >> (30 - 2 * j)) & 3u)) & kmask;
+            if (++have < (uint32_t)k || !starts) continue;
+            const uint32_t st = (uint32_t)__builtin_ctzll(starts);
+            starts &= starts - 1;
+            if (!((J >> st) & 1ull)) continue;
+            const uint64_t x = fwd << (64 - 2 * k);              // left-aligned: rcword() of each half, halves swapped
+            const uint64_t rc = ((((uint64_t)rcword((uint32_t)x, cmask)) << 32) | rcword((uint32_t)(x >> 32), cmask)) & kmask;
+            const uint64_t can = fwd < rc ? fwd : rc;            // km.min(km.reverse_complement()), utils.rs:470,482,494
+            (void)add_kmer<ALGO, XLOW, false, false>(regs, (uint32_t)can, (uint32_t)(can >> 32), 0xFFFFFFFFu, bitflip, p);
+            ++added;
+        }
+        pos += nb;
+    }
+    return added;
+}
+
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT = false>
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
@@ -538,8 +652,39 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
             }
             if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull) {
-                if ((threadIdx.x & 63) == 0) atomicOr(dirty, 1u);
-                break;
+                // bytes outside the alphabet in this wave's tile: handled in place while the genome stays within its
+                // budget of such wave-tiles (sparse dirt), else the whole genome goes to the pack stage (dense dirt)
+                uint32_t over = 0;
+                if ((threadIdx.x & 63) == 0) over = atomicAdd(a.nslow + it.genome, 1u) >= 32u + (uint32_t)(gd.byte_len >> 16);
+                if (__builtin_amdgcn_readfirstlane((int)over) != 0) {
+                    if ((threadIdx.x & 63) == 0) atomicOr(dirty, 1u);
+                    break;
+                }
+                uint32_t nd = 0;
+                uint64_t junc = 0, jstarts = 0;
+                if (active && bad != 0u) {
+                    const InvMask im = lane_inv_mask(gseq, pos0, L);
+                    const uint64_t W = window_or(im.lo, im.hi, k);            // windows that hold a deleted byte
+                    const uint64_t in_gen = L - pos0 >= 64 ? ~0ull : ((1ull << (L - pos0)) - 1ull);
+                    junc = ~im.lo & W & in_gen;                                // surviving first base, broken window
+                    jstarts = junc ? (~im.lo & in_gen & ~((1ull << __builtin_ctzll(junc)) - 1ull)) : 0ull;
+                    kv &= ~W;
+                    // deleted bytes this lane accounts for: its own 64, and the genome's last <= k-1 bytes when no lane starts there
+                    const uint64_t own = pos0 + 64 >= nk ? L - pos0 : 64;
+                    nd = (uint32_t)__builtin_popcountll(im.lo & in_gen) +
+                         (own > 64 ? (uint32_t)__builtin_popcount(im.hi & ((own >= 96 ? 0u : (1u << (own - 64))) - 1u)) : 0u);
+                }
+                // more than a quarter of this wave's 4 KiB deleted: dense dirt (soft-masked block, long gap) -> pack stage, now
+                uint32_t wave_nd = nd;
+                for (int o = 32; o > 0; o >>= 1) wave_nd += __shfl_xor(wave_nd, o, 64);
+                if (wave_nd > 1024u) {
+                    if ((threadIdx.x & 63) == 0) atomicOr(dirty, 1u);
+                    break;
+                }
+                if (nd && part == 0u) atomicAdd(a.ndel + it.genome, nd);         // (the passes of a partitioned table see the same bytes)
+                if (junc)                                                      // (here, not after the hashing: nothing of it stays live)
+                    my_kmers += junction_walk<ALGO, XLOW, Regs>(regs, gseq, L, pos0, junc, jstarts, multi_rec ? bk : nullptr, k, kp.bitflip, p,
+                                                                cmask, ctabs, dirty);
             }
         } else if (active) {
             c0 = cur.q.x; c1 = cur.q.y; c2 = cur.q.z; c3 = cur.q.w; c4 = cur.c4; c5 = cur.c5;

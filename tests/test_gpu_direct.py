@@ -119,7 +119,12 @@ def test_direct_pass_backs_off_while_batches_are_dirty():
     batches keep turning out dirty, probing again every 8th call.  Results never change."""
     import lash_amd
     c = lash_amd.Context(0)
-    dirty = [[(O.synth_genome(40 + i, 200_000).tobytes()[:-1] + b"N")] for i in range(6)]
+    # dense dirt (every 97th byte lower-case: far over the in-place budget), so the direct pass gives these genomes up
+    dirty = []
+    for i in range(6):
+        g = O.synth_genome(40 + i, 200_000).copy()
+        g[::97] |= 0x20
+        dirty.append([g.tobytes()])
     clean = [[O.synth_genome(50 + i, 200_000).tobytes()] for i in range(6)]
     sd, od, gd = lash_amd.records_to_arrays(dirty)
     sc, oc, gc = lash_amd.records_to_arrays(clean)
@@ -195,3 +200,78 @@ def test_many_small_genomes_write_their_own_images(an, k, p):
     acc = ctx.sketch_batch(an, k, p, 42, s2, o2, g2, flags=lash_amd.F_ACCUMULATE, out=acc)
     same(acc, want, "accumulate")
     ctx.close()
+
+
+def _sparse_dirt_genomes(rng, k):
+    """genomes with few, short deletions at positions chosen to hit lane (64 B), wave (4 KiB), tile and slice boundaries,
+    the genome's ends, record boundaries, and each other (runs closer than k)"""
+    gs, L = [], 300_000
+    for i in range(10):
+        g = bytearray(O.synth_genome(1200 + i, L + 13 * i).tobytes())
+        spots = [0, 1, k - 1, k, 63, 64, 65, 4095, 4096, 4097, 32767, 32768, len(g) - 1, len(g) - k, len(g) - k - 1,
+                 len(g) // 2, 100_000 + i, 100_000 + i + k - 2, 100_000 + i + k + 1]
+        for s_ in rng.sample(spots, 6):
+            run = rng.choice([1, 1, 2, k - 1, k, k + 1, 37, 100, 129, 700])
+            fill = rng.choice([b"N", b"n", b"a", b"R", b"\x00", b"\xff", b"-"])
+            if rng.random() < 0.3:
+                fill = bytes(rng.choice(b"NnacgtRYKMSW") for _ in range(run))
+                g[s_:s_ + run] = fill[:max(0, min(run, len(g) - s_))]
+            else:
+                g[s_:s_ + run] = fill * max(0, min(run, len(g) - s_))
+        cuts = {0, len(g)}
+        if i % 2:
+            cuts |= {rng.randint(0, len(g)) for _ in range(4)} | {100_000 + i + 3, 4096, 64}
+        cuts = sorted(cuts)
+        gs.append([bytes(g[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    # a short genome that is mostly dirt, one that is only dirt, one with a single valid k-mer spread over three islands
+    gs.append([b"ACGT" * 5 + b"N" * 50 + b"ACGTTGCA" * 6])
+    gs.append([b"N" * 500])
+    island = b"ACGTTGCATGCATCGATCGGATTACAGGATC"
+    gs.append([island[:5] + b"nn" + island[5:11] + b"N" * 90 + island[11:]])
+    return gs
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 11, 0), ("hmh", 31, 0), ("hmh", 1, 0), ("hll", 21, 14), ("hll", 32, 9),
+                                    ("ull", 16, 12), ("ull", 14, 16), ("ull", 5, 4)])
+def test_sparse_dirt_is_handled_in_place(an, k, p):
+    """Few short deletions per genome: the direct pass keeps the genome (no pack-stage fallback: pack time stays ~0) and
+    hashes the junction k-mers — those whose window spans a deleted byte — from the joined flanks, exactly as
+    filter_out_n + the per-record iterator do (utils.rs:33-41, 457-499).  Census and surviving-base count included."""
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    rng = random.Random(zlib.crc32(repr(("sparse", an, k, p)).encode()))
+    gs = _sparse_dirt_genomes(rng, k)
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    want = oracle_images(an, k, p, 42, seq, off, goff)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    assert tm["direct_launches"] == 1
+    same(got, want, "sparse dirt in place %s k=%d" % (an, k))
+    assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+    assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g in gs for r in g)
+    same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, "pack-first")
+    ctx.close()
+
+
+def test_long_runs_and_dense_dirt_still_fall_back(ctx):
+    """A run of deleted bytes longer than the junction walk's reach, and a genome with far more dirty wave-tiles than the
+    in-place budget, are given up by the direct pass and re-done through the pack stage in the same call."""
+    import lash_amd
+    a = bytearray(O.synth_genome(1300, 400_000).tobytes())
+    a[200_000:230_000] = b"N" * 30_000                                  # one long gap
+    b = np.frombuffer(O.synth_genome(1301, 400_000).tobytes(), np.uint8).copy()
+    b[::53] |= 0x20                                                      # soft-masked confetti
+    c = bytearray(O.synth_genome(1302, 400_000).tobytes())
+    c[123_456] = ord("N")                                               # stays in place
+    gs = [[bytes(a)], [b.tobytes()], [bytes(c)]]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    for an, k, p in (("hmh", 16, 0), ("hll", 25, 12), ("ull", 16, 10)):
+        ctx.enable_timing(True)
+        got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+        tm = ctx.timing()
+        ctx.enable_timing(False)
+        same(got, oracle_images(an, k, p, 42, seq, off, goff), "fallback " + an)
+        assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+        assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g in gs for r in g)
