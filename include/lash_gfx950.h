@@ -193,6 +193,19 @@ int lash_hll_pair_union_stats_device(lash_ctx *ctx, int p, const uint8_t *d_ref_
 int lash_hll_pair_union_stats(lash_ctx *ctx, int p, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
                               uint32_t n_qry, uint32_t *out_zero, double *out_sum);
 
+/* dist side, UltraLogLog (/root/reference/src/utils.rs:186-288): for every (reference, query) pair the distinct-count
+ * estimate of the merged sketch — UltraLogLog::merge (utils.rs:260-262) followed by get_distinct_count_estimate()
+ * (estimator LASH_ULL_FGRA) or MaximumLikelihoodEstimator.estimate() (LASH_ULL_ML), utils.rs:265-269:
+ * out_est[r * n_qry + q].  Images are ULL sketches of precision p as written by `save`. */
+#define LASH_ULL_FGRA 0
+#define LASH_ULL_ML   1
+int lash_ull_pair_union_estimates_device(lash_ctx *ctx, int p, int estimator, const uint8_t *d_ref_images, uint32_t n_ref,
+                                         const uint8_t *d_qry_images, uint32_t n_qry, double *d_out_est);
+int lash_ull_pair_union_estimates(lash_ctx *ctx, int p, int estimator, const uint8_t *ref_images, uint32_t n_ref,
+                                  const uint8_t *qry_images, uint32_t n_qry, double *out_est);
+/* The same two estimators for ONE sketch (utils.rs:213-217), host only: `registers` = the 2^p state bytes (no header). */
+double lash_ull_estimate(const uint8_t *registers, int p, int estimator);
+
 /* Synthetic genomes of SURVEY.md §8(d) generated in HBM (bench / tests): genome ids first..first+n-1,
  * n_bases ASCII bytes each, written back to back at d_out. */
 int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out);

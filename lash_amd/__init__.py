@@ -7,9 +7,9 @@ has no CPU fallback.
 from ._lib import (EHIP, EINVAL, ELIMIT, ENODEV, ENOMEM, F_ACCUMULATE, F_HMH_X_LOW, F_NO_DIRECT, HLL, HMH, OK, ULL, Layout, Params,
                    Timing, load)
 from .sketch import (ALGOS, Context, LashError, Packed, header_bytes, image_bytes, params_check, parse_layout,
-                     records_to_arrays)
+                     records_to_arrays, ull_estimate)
 
 __all__ = ["ALGOS", "Context", "LashError", "Layout", "Packed", "Params", "Timing", "header_bytes", "image_bytes", "params_check",
-           "parse_layout",
+           "parse_layout", "ull_estimate",
            "records_to_arrays", "load", "HMH", "HLL", "ULL", "F_ACCUMULATE", "F_HMH_X_LOW", "F_NO_DIRECT", "OK", "EINVAL", "ENODEV",
            "EHIP", "ENOMEM", "ELIMIT"]

@@ -75,6 +75,9 @@ PROTOTYPES = {
     "lash_hmh_pair_counts": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp]),
     "lash_hll_pair_union_stats_device": (_int, [_vp, _int, _vp, _u32, _vp, _u32, _vp, _vp]),
     "lash_hll_pair_union_stats": (_int, [_vp, _int, _vp, _u32, _vp, _u32, _vp, _vp]),
+    "lash_ull_pair_union_estimates_device": (_int, [_vp, _int, _int, _vp, _u32, _vp, _u32, _vp]),
+    "lash_ull_pair_union_estimates": (_int, [_vp, _int, _int, _vp, _u32, _vp, _u32, _vp]),
+    "lash_ull_estimate": (C.c_double, [_vp, _int, _int]),
     "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),
 }
 

@@ -7,7 +7,9 @@
 // Both kernels tile the pair matrix and walk the registers in chunks staged in LDS (details at each kernel).
 #include <hip/hip_runtime.h>
 
+#include "lash_device.h"
 #include "lash_kernels.h"
+#include "ull_estimators.h"
 
 namespace lash {
 
@@ -152,6 +154,96 @@ __global__ void __launch_bounds__(256) hll_pairs_kernel(const uint8_t *__restric
         out_zero[o] = zero;
         out_sum[o] = (double)s1 * 2.3283064365386963e-10 + (double)s2 * 5.421010862427522e-20;   // 2^-32, 2^-64
     }
+}
+
+
+// ---- UltraLogLog: distinct-count estimate of the union of every pair (utils.rs:260-270: UltraLogLog::merge + estimate) -----
+// The union's registers are pack(unpack(a) | unpack(b)) (ull_merge_reg); both estimators of ultraloglog 0.1.6 (FGRA, ML)
+// are functions of the register HISTOGRAM alone (ull_estimators.h), so no union sketch is materialised: a lane owns one
+// (reference, query) pair and a private 256-bin histogram in LDS — bin-major, lane-minor, so that the 64 lanes of a wave
+// always touch 64 different banks whatever values their registers hold — filled with fire-and-forget ds_add_u32.
+// Narrow form (p <= 15: a bin counts at most 2^15): two 16-bit bins per word, 256 lanes = a 16 x 16 tile, 128 KiB;
+// wide form (p >= 16): 32-bit bins, 128 lanes = an 8 x 16 tile, 128 KiB.  The estimator runs in the same kernel, one f64
+// per pair leaves it.
+constexpr int UQ = 16;                       // tile columns (queries)
+constexpr int UCHUNK = 512;                  // registers per sketch per staging round
+constexpr int UROW = UCHUNK / 4 + 1;
+
+template <bool WIDE>
+struct UllLaneHist {
+    const uint32_t *w;
+    uint32_t lanes, lane;
+    __device__ __forceinline__ uint32_t operator()(uint32_t r) const
+    {
+        if constexpr (WIDE) return w[r * lanes + lane];
+        else return (w[(r >> 1) * lanes + lane] >> (16u * (r & 1u))) & 0xFFFFu;
+    }
+};
+
+template <bool WIDE>
+__global__ void __launch_bounds__(WIDE ? 128 : 256) ull_pairs_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
+                                                                      const uint8_t *__restrict__ qry, uint32_t n_qry, int p,
+                                                                      uint32_t hdr, int estimator, double *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr uint32_t LANES = WIDE ? 128u : 256u, TR = LANES / UQ, HW = (WIDE ? 256u : 128u) * LANES;
+    uint32_t *hist = lds;                                   // [bin (pair)][lane]
+    uint32_t(*R)[UROW] = reinterpret_cast<uint32_t(*)[UROW]>(lds + HW);
+    uint32_t(*Q)[UROW] = reinterpret_cast<uint32_t(*)[UROW]>(lds + HW + TR * UROW);
+    const uint32_t tid = threadIdx.x, tr = tid / UQ, tq = tid % UQ;
+    const uint32_t r0 = blockIdx.y * TR, q0 = blockIdx.x * UQ;
+    const uint64_t m = 1ull << p, stride = (uint64_t)hdr + m;
+    for (uint32_t i = tid; i < HW; i += LANES) hist[i] = 0;
+    __syncthreads();
+    for (uint64_t c0 = 0; c0 < m; c0 += UCHUNK) {
+        const uint32_t n = m - c0 < (uint64_t)UCHUNK ? (uint32_t)(m - c0) : (uint32_t)UCHUNK;    // m >= 8: a multiple of 4
+        for (uint32_t i = tid; i < (TR + UQ) * (n / 4); i += LANES) {
+            const uint32_t row = i / (n / 4), col = i % (n / 4);
+            const bool is_q = row >= TR;
+            const uint32_t g = is_q ? q0 + row - TR : r0 + row;
+            uint32_t v = 0;
+            if (g < (is_q ? n_qry : n_ref)) {
+                const uint8_t *s = (is_q ? qry : ref) + (uint64_t)g * stride + hdr + c0 + 4 * col;
+                v = s[0] | (s[1] << 8) | (s[2] << 16) | ((uint32_t)s[3] << 24);
+            }
+            if (is_q) Q[row - TR][col] = v; else R[row][col] = v;
+        }
+        __syncthreads();
+        for (uint32_t w = 0; w < n / 4; ++w) {
+            const uint32_t a = R[tr][w], b = Q[tq][w];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t r = ull_merge_reg((a >> (8 * j)) & 0xFFu, (b >> (8 * j)) & 0xFFu);
+                if constexpr (WIDE) asm volatile("ds_add_u32 %0, %1" ::"v"((r * LANES + tid) << 2), "v"(1u) : "memory");
+                else asm volatile("ds_add_u32 %0, %1" ::"v"(((r >> 1) * LANES + tid) << 2), "v"(1u << (16u * (r & 1u))) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (r0 + tr < n_ref && q0 + tq < n_qry) {
+        const UllLaneHist<WIDE> h{hist, LANES, tid};
+        out[(uint64_t)(r0 + tr) * n_qry + q0 + tq] = estimator == 1 ? ull::ml(h, p) : ull::fgra(h, p);
+    }
+}
+
+hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
+                            int estimator, double *d_est, hipStream_t stream)
+{
+    if (n_ref == 0 || n_qry == 0) return hipSuccess;
+    const bool wide = p >= 16;
+    const uint32_t lanes = wide ? 128u : 256u, tr = lanes / UQ;
+    const size_t lds = ((wide ? 256u : 128u) * lanes + (tr + UQ) * UROW) * 4u;
+    dim3 grid((n_qry + UQ - 1) / UQ, (n_ref + tr - 1) / tr);
+    hipError_t e;
+    if (wide) {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(ull_pairs_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(ull_pairs_kernel<true>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est);
+    } else {
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(ull_pairs_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(ull_pairs_kernel<false>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,

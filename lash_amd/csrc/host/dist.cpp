@@ -1,17 +1,20 @@
 // dist.cpp — `lash dist` for the gfx950 build.
 //
 // Mirrors /root/reference/src/main.rs:280-617 (file discovery, parameter checks, output formats, distance formula)
-// and utils.rs:84-184 (hmh_distance).  The O(N_ref * N_qry * 16384) register scan runs on the GPU
-// (lash_hmh_pair_counts); cardinalities (LogLog-beta) and the expected-collision correction are restated from
-// axiomhq/hyperminhash, which the crate hyperminhash 0.1.4 ports [PARITY UNPINNED, like every crate-internal rule].
+// and utils.rs:84-373 (hmh_distance, ull_distance, hll_distance).  The O(N_ref * N_qry * registers) scans run on the GPU(s);
+// what is O(sketches) or O(pairs) runs on `-t` host threads.  Every estimator is restated from the published algorithm the
+// crate ports [PARITY UNPINNED, like every crate-internal rule; tools/ref_probe pins them through `<case>.dist.tsv`]:
+//   hmh  C / N pair counts (lash_hmh_pair_counts) + LogLog-beta cardinalities + expected-collision correction of
+//        axiomhq/hyperminhash (crate hyperminhash 0.1.4);
+//   hll  union zero / sum per pair (lash_hll_pair_union_stats) + streaming_algorithms' HLL++ `len()`: linear counting below
+//        the published per-precision threshold, else alpha*m^2/sum.  Its third regime (estimate <= 5m: subtract a
+//        k-nearest-neighbour bias read from the HLL++ empirical tables) needs data that is not in this image; a sketch
+//        or union that falls there is refused with a message instead of being estimated differently;
+//   ull  union estimate per pair on the GPU (lash_ull_pair_union_estimates: merged-register histogram + FGRA or ML,
+//        ull_estimators.h), per-sketch estimates with lash_ull_estimate; similarity by inclusion-exclusion (utils.rs:272).
 // Row order: the reference iterates hashbrown maps under rayon (nondeterministic); here rows come in
 // file order, so parity with the reference is on the SET of rows.
-// HyperLogLog (utils.rs:290-373): per pair union -> len -> inclusion-exclusion Jaccard.  The union's zero / sum come
-// from the GPU (lash_hll_pair_union_stats); `len()` is streaming_algorithms' HLL++ estimator restated [PARITY
-// UNPINNED]: linear counting below the published per-precision threshold, else alpha*m^2/sum.  Its third regime
-// (estimate <= 5m: subtract a k-nearest-neighbour bias read from the HLL++ empirical tables) needs data that is not
-// in this image; a sketch or union that falls there is refused with a message instead of being estimated differently.
-// UltraLogLog distances need the FGRA / ML estimator constants of ultraloglog 0.1.6 and are not built.
+// Several GPUs (--devices 0,1,..): blocks of reference rows are handed to one worker per device and written in order.
 #include "dist.hpp"
 
 #include <dirent.h>
@@ -24,7 +27,9 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <thread>
 #include <vector>
@@ -87,11 +92,11 @@ double hmh_beta(double ez)
            0.00042419 * std::pow(zl, 7);
 }
 
-double hmh_cardinality(const uint8_t *img)
+double hmh_cardinality(const uint8_t *regs, bool big_endian)
 {
     double sum = 0.0, ez = 0.0;
     for (uint32_t i = 0; i < HM; ++i) {
-        const uint32_t reg = img[2 * i] | (img[2 * i + 1] << 8);
+        const uint32_t reg = big_endian ? (regs[2 * i + 1] | (regs[2 * i] << 8)) : (regs[2 * i] | (regs[2 * i + 1] << 8));
         const uint32_t lz = reg >> (16 - HQ);
         if (lz == 0) ez += 1.0;
         sum += std::ldexp(1.0, -(int)lz);                       // == 1 / 2^lz exactly
@@ -153,8 +158,26 @@ bool hll_len(int p, double alpha, uint64_t zero, double sum, double &out)
     return true;
 }
 
-uint64_t rd_u64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
-double rd_f64(const uint8_t *p) { double v; memcpy(&v, p, 8); return v; }
+double hll_alpha(int p)
+{
+    switch (p) {
+    case 4: return 0.673;
+    case 5: return 0.697;
+    case 6: return 0.709;
+    default: return 0.7213 / (1.0 + 1.079 / (double)(1u << p));
+    }
+}
+
+// zero and sum of one sketch from its registers (the header's copies are layout-dependent; these are not)
+void hll_zero_sum(const uint8_t *regs, int p, uint64_t &zero, double &sum)
+{
+    uint32_t hist[256] = {0};
+    for (size_t i = 0, m = (size_t)1 << p; i < m; ++i) hist[regs[i]]++;
+    zero = hist[0];
+    sum = 0.0;
+    for (int r = 255; r >= 0; --r)
+        if (hist[r]) sum += (double)hist[r] * std::ldexp(1.0, -r);      // exact powers of two, largest exponent first
+}
 
 template <class T>
 T compute_distance(T frac, int k, int model)
@@ -183,20 +206,27 @@ std::string run_dist(const DistOptions &opt)
         return algo + " was not sketched with same precision btwn genomes";
     const int k = atoi(rp["k"].c_str());
     if (opt.model != 0 && opt.model != 1) return "model needs to be 0 or 1";
+    const bool hll = algo == "hll", ull = algo == "ull";
+    if (!hll && !ull && algo != "hmh") return "Algorithm must be either hmh, ull, or hll";
+    int ull_est = LASH_ULL_FGRA;
+    if (ull) {                                                                                        // utils.rs:213-217
+        if (opt.estimator == "ml") ull_est = LASH_ULL_ML;
+        else if (opt.estimator != "fgra") return "estimator needs to be either fgra or ml";
+    }
     std::vector<std::string> rnames, qnames;
     if (!(err = slurp(rf["files"], txt)).empty() || !json_parse_string_array(txt, rnames)) return err.empty() ? "bad names JSON " + rf["files"] : err;
     if (!(err = slurp(qf["files"], txt)).empty() || !json_parse_string_array(txt, qnames)) return err.empty() ? "bad names JSON " + qf["files"] : err;
-    if (algo == "ull")
-        return "lash dist for -a ull is not built in the gfx950 port yet (it needs the ultraloglog FGRA/ML estimator constants)";
     const bool same_files = qf["files"] == rf["files"];                                               // main.rs:404
 
     std::vector<uint8_t> rimg, qimg;
     if (!(err = zstd_decompress_file(rf["sketches"], rimg)).empty()) return err;
     if (!(err = zstd_decompress_file(qf["sketches"], qimg)).empty()) return err;
-    const bool hll = algo == "hll";
-    const int prec = hll ? atoi(rp["precision"].c_str()) : 0;
+    const int algo_id = hll ? LASH_HLL : ull ? LASH_ULL : LASH_HMH;
+    const int prec = (hll || ull) ? atoi(rp["precision"].c_str()) : 0;
     if (hll && (prec < 4 || prec > 16)) return "bad precision in " + rf["params"];
-    const size_t ib = hll ? lash_sketch_image_bytes(LASH_HLL, prec) : (size_t)HM * 2;
+    if (ull && (prec < 3 || prec > 26)) return "bad precision in " + rf["params"];
+    const size_t ib = lash_layout_image_bytes(&opt.layout, algo_id, prec), hdr = lash_layout_header_bytes(&opt.layout, algo_id);
+    if (!ib) return "bad layout";
     if (rimg.size() < rnames.size() * ib) return "Error with reading from " + rf["sketches"];
     if (qimg.size() < qnames.size() * ib) return "Error with reading from " + qf["sketches"];
     const uint32_t nr = (uint32_t)rnames.size(), nq = (uint32_t)qnames.size();
@@ -204,16 +234,22 @@ std::string run_dist(const DistOptions &opt)
     std::vector<double> rcard(nr), qcard(nq);
     const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which "
                            "this build does not have (sketch with a smaller -p)";
-    // per-sketch cardinalities (utils.rs:101-103, 314-315), on `-t` host threads
+    const double alpha = hll ? hll_alpha(prec) : 0.0;
+    // per-sketch cardinalities (utils.rs:101-103, 213-217, 314-315), on `-t` host threads
     auto cards = [&](const std::vector<uint8_t> &img, const std::vector<std::string> &names, std::vector<double> &card) -> std::string {
         const uint32_t n = (uint32_t)names.size();
         std::vector<uint8_t> bad(n, 0);
         std::atomic<uint32_t> next{0};
         auto work = [&]() {
             for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-                const uint8_t *im = img.data() + (size_t)i * ib;
-                if (!hll) card[i] = hmh_cardinality(im);
-                else if (!hll_len(prec, rd_f64(im), rd_u64(im + 8), rd_f64(im + 16), card[i])) bad[i] = 1;
+                const uint8_t *regs = img.data() + (size_t)i * ib + hdr;
+                if (ull) card[i] = lash_ull_estimate(regs, prec, ull_est);
+                else if (!hll) card[i] = hmh_cardinality(regs, opt.layout.hmh_reg_be != 0);
+                else {
+                    uint64_t zero; double sum;
+                    hll_zero_sum(regs, prec, zero, sum);
+                    if (!hll_len(prec, alpha, zero, sum, card[i])) bad[i] = 1;
+                }
             }
         };
         std::vector<std::thread> pool;
@@ -227,89 +263,124 @@ std::string run_dist(const DistOptions &opt)
     if (!(err = cards(rimg, rnames, rcard)).empty()) return err;
     if (same_files && rf["sketches"] == qf["sketches"]) qcard = rcard;
     else if (!(err = cards(qimg, qnames, qcard)).empty()) return err;
-    const double hll_alpha = hll && nr ? rd_f64(rimg.data()) : 0.0;
 
     FILE *out = fopen(opt.output_file.c_str(), "w");
     if (!out) return "cannot create " + opt.output_file;
     if (!opt.matrix) fprintf(out, "Reference\tQuery\tDistance\n");                                   // main.rs:409-412
     else for (uint32_t j = 0; j < nq; ++j) fprintf(out, "\t%s", qnames[j].c_str());                   // main.rs:439-441
     // ---- GPU: the O(N_ref * N_qry * registers) scan, in blocks of reference rows so that the per-pair tables stay
-    //      bounded (all-vs-all on 10^5 sketches is 10^10 pairs) ----
-    lash_ctx *ctx = nullptr;
-    {
-        const int rc = lash_ctx_create(&ctx, opt.device);
-        if (rc != LASH_OK) { fclose(out); return lash_strerror(rc); }
-    }
+    //      bounded (all-vs-all on 10^5 sketches is 10^10 pairs); one worker (context + host thread) per device ----
+    std::vector<int> devices = opt.devices.empty() ? std::vector<int>{opt.device} : opt.devices;
     const uint32_t rows_per_block = opt.block_rows ? std::min(opt.block_rows, std::max(nr, 1u))
                                                    : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nr, (64ull << 20) / std::max<uint32_t>(nq, 1)));
-    std::vector<uint32_t> C((size_t)rows_per_block * nq), N(hll ? 0 : (size_t)rows_per_block * nq);   // hll: C = zero registers of the union
-    std::vector<double> usum(hll ? (size_t)rows_per_block * nq : 0);
-    std::string fail;
-    for (uint32_t i0 = 0; i0 < nr && fail.empty(); i0 += rows_per_block) {
-        const uint32_t i1 = std::min(nr, i0 + rows_per_block);
-        const int rc = hll ? lash_hll_pair_union_stats(ctx, prec, rimg.data() + (size_t)i0 * ib, i1 - i0, qimg.data(), nq, C.data(), usum.data())
-                           : lash_hmh_pair_counts(ctx, rimg.data() + (size_t)i0 * ib, i1 - i0, qimg.data(), nq, C.data(), N.data());
-        if (rc != LASH_OK) { fail = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx); break; }
-        // rows of the block are formatted by `-t` host threads (the reference's par_iter over reference sketches,
-        // utils.rs:146,336), then written in file order
-        std::vector<std::string> row_text(i1 - i0), row_fail(i1 - i0);
-        auto do_row = [&](uint32_t i) {
-            std::string &txt = row_text[i - i0];
-            char buf[64];
-            bool first = true;
-            const size_t row = (size_t)(i - i0) * nq;
-            for (uint32_t j = 0; j < nq; ++j) {
-                if (same_files && j > i) continue;                                                    // utils.rs:158-160
-                double sim = 0.0;
-                if (hll) {                                                                            // utils.rs:352-365
-                    double u;
-                    if (!hll_len(prec, hll_alpha, C[row + j], usum[row + j], u)) {
-                        row_fail[i - i0] = "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
-                        return;
-                    }
-                    sim = (rcard[i] + qcard[j] - u) / u;
-                } else {
-                    const double c = (double)C[row + j], n = (double)N[row + j];
-                    if (c != 0.0) {                                                                   // Sketch::similarity
-                        const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
-                        sim = c < ec ? 0.0 : (c - ec) / n;
-                    }
-                }
-                if (sim < 0.0) sim = 0.0;                                                             // .max(0.0), utils.rs:164,362
-                const double frac = 2.0 * sim / (1.0 + sim);                                          // utils.rs:165-167
-                double d;
-                if (qnames[j] == rnames[i]) d = 0.0;                                                  // main.rs:452-453
-                else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
-                else d = compute_distance<double>(frac, k, opt.model);
-                // "{:.6}" (main.rs:456,461): std::to_chars is correctly rounded like printf("%.6f") and several times faster
-                buf[0] = '\t';
-                char *end = std::to_chars(buf + 1, buf + sizeof buf - 2, d, std::chars_format::fixed, 6).ptr;
-                if (!opt.matrix) {
-                    txt += rnames[i]; txt += '\t'; txt += qnames[j];
-                    *end++ = '\n';
-                } else if (first) { txt += '\n'; txt += rnames[i]; }
-                txt.append(buf, end);
-                first = false;
+    const uint32_t n_blocks = nr ? (nr + rows_per_block - 1) / rows_per_block : 0;
+    if (devices.size() > n_blocks) devices.resize(std::max<uint32_t>(n_blocks, 1));
+    const int fmt_threads = std::max(1, opt.threads / (int)devices.size());
+    std::atomic<uint32_t> next_block{0};
+    std::mutex wmu;
+    std::condition_variable wcv;
+    uint32_t next_to_write = 0;
+    std::string fail;                                            // guarded by wmu
+
+    auto worker = [&](int device) {
+        lash_ctx *ctx = nullptr;
+        int rc = lash_ctx_create(&ctx, device);
+        if (rc == LASH_OK) rc = lash_ctx_set_layout(ctx, &opt.layout);
+        std::string my_fail = rc == LASH_OK ? "" : std::string(lash_strerror(rc));
+        std::vector<uint32_t> C, N;                              // hmh: C / N; hll: C = zero registers of the union
+        std::vector<double> U;                                   // hll: union sum; ull: union estimate
+        for (;;) {
+            const uint32_t blk = next_block.fetch_add(1);
+            if (blk >= n_blocks) break;
+            const uint32_t i0 = blk * rows_per_block, i1 = std::min(nr, i0 + rows_per_block);
+            std::vector<std::string> row_text(i1 - i0), row_fail(i1 - i0);
+            bool skip;
+            { std::lock_guard<std::mutex> lk(wmu); skip = !fail.empty(); }
+            if (my_fail.empty() && !skip) {
+                const size_t np = (size_t)(i1 - i0) * nq;
+                if (!ull) C.resize(np);
+                if (!hll && !ull) N.resize(np);
+                if (hll || ull) U.resize(np);
+                const uint8_t *rblk = rimg.data() + (size_t)i0 * ib;
+                rc = hll ? lash_hll_pair_union_stats(ctx, prec, rblk, i1 - i0, qimg.data(), nq, C.data(), U.data())
+                   : ull ? lash_ull_pair_union_estimates(ctx, prec, ull_est, rblk, i1 - i0, qimg.data(), nq, U.data())
+                         : lash_hmh_pair_counts(ctx, rblk, i1 - i0, qimg.data(), nq, C.data(), N.data());
+                if (rc != LASH_OK) my_fail = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
             }
-        };
-        {
-            const uint32_t nthreads = (uint32_t)std::max(1, std::min<int>(opt.threads, (int)(i1 - i0)));
-            std::atomic<uint32_t> next{i0};
-            std::vector<std::thread> pool;
-            auto work = [&]() { for (uint32_t i = next.fetch_add(1); i < i1; i = next.fetch_add(1)) do_row(i); };
-            for (uint32_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
-            work();
-            for (auto &t : pool) t.join();
+            if (my_fail.empty() && !skip) {
+                // rows of the block are formatted by host threads (the reference's par_iter over reference sketches,
+                // utils.rs:146,248,342), then written in file order
+                auto do_row = [&](uint32_t i) {
+                    std::string &text = row_text[i - i0];
+                    char buf[64];
+                    bool first = true;
+                    const size_t row = (size_t)(i - i0) * nq;
+                    for (uint32_t j = 0; j < nq; ++j) {
+                        if (same_files && j > i) continue;                                            // utils.rs:158-160
+                        double sim = 0.0;
+                        if (hll) {                                                                    // utils.rs:352-365
+                            double u;
+                            if (!hll_len(prec, alpha, C[row + j], U[row + j], u)) {
+                                row_fail[i - i0] = "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
+                                return;
+                            }
+                            sim = (rcard[i] + qcard[j] - u) / u;
+                        } else if (ull) {                                                             // utils.rs:256-274
+                            const double u = U[row + j];
+                            sim = (rcard[i] + qcard[j] - u) / u;
+                        } else {
+                            const double c = (double)C[row + j], n = (double)N[row + j];
+                            if (c != 0.0) {                                                           // Sketch::similarity
+                                const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
+                                sim = c < ec ? 0.0 : (c - ec) / n;
+                            }
+                        }
+                        if (!(sim >= 0.0)) sim = 0.0;                                                 // .max(0.0) / `if similarity < 0.0`
+                        const double frac = 2.0 * sim / (1.0 + sim);                                  // utils.rs:165-167
+                        double d;
+                        if (qnames[j] == rnames[i]) d = 0.0;                                          // main.rs:452-453
+                        else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
+                        else d = compute_distance<double>(frac, k, opt.model);
+                        // "{:.6}" (main.rs:456,461): std::to_chars is correctly rounded like printf("%.6f") and several times faster
+                        buf[0] = '\t';
+                        char *end = std::to_chars(buf + 1, buf + sizeof buf - 2, d, std::chars_format::fixed, 6).ptr;
+                        if (!opt.matrix) {
+                            text += rnames[i]; text += '\t'; text += qnames[j];
+                            *end++ = '\n';
+                        } else if (first) { text += '\n'; text += rnames[i]; }
+                        text.append(buf, end);
+                        first = false;
+                    }
+                };
+                const uint32_t nthreads = (uint32_t)std::max(1, std::min<int>(fmt_threads, (int)(i1 - i0)));
+                std::atomic<uint32_t> next{i0};
+                std::vector<std::thread> pool;
+                auto work = [&]() { for (uint32_t i = next.fetch_add(1); i < i1; i = next.fetch_add(1)) do_row(i); };
+                for (uint32_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
+                work();
+                for (auto &t : pool) t.join();
+                for (const std::string &f : row_fail) if (!f.empty() && my_fail.empty()) my_fail = f;
+            }
+            // in block order, whatever order the devices finish in
+            std::unique_lock<std::mutex> lk(wmu);
+            wcv.wait(lk, [&] { return next_to_write == blk; });
+            if (!my_fail.empty() && fail.empty()) fail = my_fail;
+            if (fail.empty())
+                for (const std::string &t : row_text) fwrite(t.data(), 1, t.size(), out);
+            ++next_to_write;
+            lk.unlock();
+            wcv.notify_all();
         }
-        for (uint32_t i = i0; i < i1; ++i) {
-            if (!row_fail[i - i0].empty()) { fail = row_fail[i - i0]; break; }
-            fwrite(row_text[i - i0].data(), 1, row_text[i - i0].size(), out);
-        }
+        if (ctx) lash_ctx_destroy(ctx);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t d = 1; d < devices.size(); ++d) pool.emplace_back(worker, devices[d]);
+        worker(devices[0]);
+        for (auto &t : pool) t.join();
     }
-    lash_ctx_destroy(ctx);
-    if (!fail.empty()) { fclose(out); return fail; }
     fclose(out);
-    return "";
+    return fail;
 }
 
 }  // namespace lashhost

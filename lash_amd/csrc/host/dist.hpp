@@ -2,6 +2,9 @@
 // SURVEY.md §8(f) row f2 ("next"): not part of the round-1 hot path.
 #pragma once
 #include <string>
+#include <vector>
+
+#include "../../../include/lash_gfx950.h"
 
 namespace lashhost {
 
@@ -11,7 +14,10 @@ struct DistOptions {
     int threads = 1;
     bool fp32 = false, matrix = false;
     int device = 0;
+    std::vector<int> devices;  // --devices 0,1,...: one worker per entry, blocks of reference rows in turn; empty = {device}
     uint32_t block_rows = 0;   // reference rows per GPU call; 0 = as many as keep the pair tables under ~0.5 GB
+    lash_layout layout;        // --layout / $LASH_LAYOUT (include/lash_gfx950.h)
+    DistOptions() { lash_layout_default(&layout); }
 };
 
 std::string run_dist(const DistOptions &opt);

@@ -177,6 +177,20 @@ int cmd_dist(int argc, char **argv)
     opt.fp32 = a.flags.count("fp32") != 0;
     opt.matrix = a.flags.count("dm") != 0;
     opt.device = (int)dev;
+    if (a.kv.count("devices")) {
+        const std::string &l = a.kv["devices"];
+        size_t at = 0;
+        while (at <= l.size()) {
+            const size_t c = l.find(',', at);
+            uint64_t d = 0;
+            if (!to_u64(l.substr(at, c == std::string::npos ? std::string::npos : c - at), d)) { fprintf(stderr, "error: invalid value for --devices\n"); return 2; }
+            opt.devices.push_back((int)d);
+            if (c == std::string::npos) break;
+            at = c + 1;
+        }
+    }
+    err = layout_from_option(a.kv.count("layout") ? a.kv["layout"] : "", opt.layout);
+    if (!err.empty()) { fprintf(stderr, "error: %s\n", err.c_str()); return 2; }
     err = run_dist(opt);
     if (!err.empty()) { fprintf(stderr, "Error: %s\n", err.c_str()); return 1; }
     printf("Distances computed.\n");                                                          // main.rs:615

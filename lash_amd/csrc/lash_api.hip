@@ -18,6 +18,7 @@
 
 #include "../../include/lash_gfx950.h"
 #include "lash_kernels.h"
+#include "ull_estimators.h"
 
 using namespace lash;
 
@@ -1211,6 +1212,47 @@ int lash_hll_pair_union_stats(lash_ctx *ctx, int p, const uint8_t *ref_images, u
     HIPCHK(ctx, hipMemcpyAsync(out_sum, d_s, np * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return LASH_OK;
+}
+
+int lash_ull_pair_union_estimates_device(lash_ctx *ctx, int p, int estimator, const uint8_t *d_ref_images, uint32_t n_ref,
+                                         const uint8_t *d_qry_images, uint32_t n_qry, double *d_out_est)
+{
+    if (!ctx || p < 3 || p > 26 || (estimator != LASH_ULL_FGRA && estimator != LASH_ULL_ML) ||
+        ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_est)))
+        return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(ctx, launch_ull_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, (uint32_t)header_bytes(ctx->layout, LASH_ULL), estimator,
+                                 d_out_est, ctx->stream));
+    return LASH_OK;
+}
+
+int lash_ull_pair_union_estimates(lash_ctx *ctx, int p, int estimator, const uint8_t *ref_images, uint32_t n_ref,
+                                  const uint8_t *qry_images, uint32_t n_qry, double *out_est)
+{
+    if (!ctx || p < 3 || p > 26 || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_est))) return LASH_EINVAL;
+    if (n_ref == 0 || n_qry == 0) return LASH_OK;
+    (void)hipSetDevice(ctx->device);
+    const size_t ib = image_bytes(ctx->layout, LASH_ULL, p), rb = ib * n_ref, qb = ib * n_qry, np = (size_t)n_ref * n_qry;
+    int rc;
+    if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->st_img, np * 8 + 64))) return rc;
+    uint8_t *d_r = static_cast<uint8_t *>(ctx->st_seq.ptr), *d_q = d_r + rb;
+    double *d_e = static_cast<double *>(ctx->st_img.ptr);
+    HIPCHK(ctx, hipMemcpyAsync(d_r, ref_images, rb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_q, qry_images, qb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = lash_ull_pair_union_estimates_device(ctx, p, estimator, d_r, n_ref, d_q, n_qry, d_e))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(out_est, d_e, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
+double lash_ull_estimate(const uint8_t *registers, int p, int estimator)
+{
+    if (!registers || p < 3 || p > 26) return -1.0;
+    uint32_t hist[256] = {0};
+    for (size_t i = 0, m = (size_t)1 << p; i < m; ++i) hist[registers[i]]++;
+    auto h = [&](uint32_t r) { return hist[r]; };
+    return estimator == LASH_ULL_ML ? lash::ull::ml(h, p) : lash::ull::fgra(h, p);
 }
 
 int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out)

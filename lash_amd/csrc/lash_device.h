@@ -110,4 +110,24 @@ __device__ __forceinline__ uint64_t xxh3_64_8b(uint32_t v_lo, uint32_t v_hi, uin
     return h ^ (h >> 28);
 }
 
+// ---- UltraLogLog registers (hash4j pack / unpack as ported by crate ultraloglog) ------------------------
+__device__ __forceinline__ uint32_t ull_unpack32pair(uint32_t r, uint32_t &hi)
+{
+    // hash4j unpack(): (4 | (r & 3)) << ((r >> 2) - 2); r == 0 -> 0.  Returns low word, hi by reference.
+    if (r < 8) { hi = 0; return 0; }
+    const uint64_t x = (uint64_t)(4u | (r & 3u)) << ((r >> 2) - 2u);
+    hi = (uint32_t)(x >> 32);
+    return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t ull_merge_reg(uint32_t a, uint32_t b)
+{
+    if (a == 0) return b;
+    if (b == 0) return a;
+    uint32_t ah, bh;
+    const uint32_t al = ull_unpack32pair(a, ah), bl = ull_unpack32pair(b, bh);
+    const uint64_t x = (((uint64_t)(ah | bh)) << 32) | (al | bl);
+    const uint32_t top = 63u - (uint32_t)__builtin_clzll(x);
+    return (top << 2) | ((uint32_t)(x >> (top - 2)) & 3u);               // top >= 2 because r >= 8
+}
+
 }  // namespace lash

@@ -147,6 +147,10 @@ hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t 
 hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
                             uint32_t *d_zero, double *d_sum, hipStream_t stream);
 
+// estimator: 0 = FGRA, 1 = ML (ull_estimators.h); d_est[r * n_qry + q] = estimated distinct count of the union
+hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
+                            int estimator, double *d_est, hipStream_t stream);
+
 // ---- synthetic genomes --------------------------------------------------------------------
 hipError_t launch_synth(uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out, hipStream_t stream);
 

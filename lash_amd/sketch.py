@@ -10,6 +10,14 @@ from . import _lib
 from ._lib import Layout, Params, Timing
 
 ALGOS = {"hmh": _lib.HMH, "hll": _lib.HLL, "ull": _lib.ULL}
+ULL_ESTIMATORS = {"fgra": 0, "ml": 1}
+
+
+def ull_estimate(registers, p, estimator="fgra"):
+    """FGRA / ML distinct-count estimate of ONE UltraLogLog sketch from its 2^p register bytes (host only; utils.rs:213-217)."""
+    regs = np.ascontiguousarray(registers, dtype=np.uint8)
+    assert regs.size == 1 << int(p)
+    return float(_lib.load().lash_ull_estimate(regs.ctypes.data, int(p), ULL_ESTIMATORS[estimator]))
 
 
 class LashError(RuntimeError):
@@ -260,6 +268,18 @@ class Context:
         self._check(self._lib.lash_hll_pair_union_stats(self._h, int(p), ref.ctypes.data, ref.shape[0], qry.ctypes.data,
                                                         qry.shape[0], zero.ctypes.data, usum.ctypes.data))
         return zero, usum
+
+    def ull_pair_union_estimates(self, p, ref_images, qry_images, estimator="fgra"):
+        """UltraLogLog: estimated distinct count of merge(ref_i, qry_j) for every pair (utils.rs:260-270): numpy uint8
+        [n, header + 2^p] in, float64 [n_ref, n_qry] out."""
+        ref = np.ascontiguousarray(ref_images, dtype=np.uint8)
+        qry = np.ascontiguousarray(qry_images, dtype=np.uint8)
+        ib = self.image_bytes("ull", p)
+        assert ref.ndim == 2 and qry.ndim == 2 and ref.shape[1] == ib and qry.shape[1] == ib
+        est = np.zeros((ref.shape[0], qry.shape[0]), dtype=np.float64)
+        self._check(self._lib.lash_ull_pair_union_estimates(self._h, int(p), ULL_ESTIMATORS[estimator], ref.ctypes.data, ref.shape[0],
+                                                            qry.ctypes.data, qry.shape[0], est.ctypes.data))
+        return est
 
     def synth_genomes_device(self, first_genome, n_genomes, n_bases, d_out):
         self._check(self._lib.lash_synth_genomes_device(self._h, int(first_genome), int(n_genomes), int(n_bases),

@@ -171,17 +171,97 @@ def test_lash_dist_cli_hll(tmp_path, matrix, model, p):
     assert 0 < got[frozenset((0, 1))] < got[frozenset((0, 2))] < got[frozenset((0, 3))] <= 1.0
 
 
-def test_lash_dist_hll_refuses_the_bias_table_regime_and_ull(tmp_path):
+def test_lash_dist_hll_refuses_the_bias_table_regime(tmp_path):
     """A 20 kbp genome at p = 14: the raw estimate is below 5 * 2^14, where streaming_algorithms subtracts a bias read from
     the HLL++ tables.  Those tables are not available here, so the command must fail loudly, never estimate differently."""
     g = O.synth_genome(3, 20_000)
     (tmp_path / "s.fa").write_bytes(b">s\n" + g.tobytes() + b"\n")
     (tmp_path / "l.txt").write_text(str(tmp_path / "s.fa") + "\n")
     env = dict(os.environ)
-    for algo, pre in (("hll", "sm"), ("ull", "ul")):
+    for algo, pre in (("hll", "sm"),):
         r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "l.txt"), "-o", pre, "-a", algo, "-p", "14"], cwd=tmp_path, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
     r = subprocess.run([H.CLI, "dist", "-q", "sm", "-r", "sm"], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "bias tables" in r.stderr
-    r = subprocess.run([H.CLI, "dist", "-q", "ul", "-r", "ul"], cwd=tmp_path, capture_output=True, text=True, env=env)
-    assert r.returncode != 0 and "ull" in r.stderr
+
+
+def _ull_regs(img, p):
+    return np.frombuffer(img, np.uint8)[8:]
+
+
+@pytest.mark.parametrize("p", [5, 12, 15, 16, 18])
+def test_ull_pair_union_estimates_match_host_estimators(p):
+    """GPU: histogram of pack(unpack(a) | unpack(b)) per pair + FGRA / ML in the kernel (narrow form p <= 15, wide form above)
+    == the host entry on the oracle-merged sketch (the same ull_estimators.h compiled for the host)."""
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    n_gen = 5 if p < 16 else 3
+    base = O.synth_genome(277, 250_000)
+    genomes = [base, _mutated(base, 0.003, 1), _mutated(base, 0.05, 2), O.synth_genome(278, 60_000), np.frombuffer(b"ACGTTGCATGCATCGATCGGATTACA", np.uint8)][:n_gen]
+    imgs = np.stack([O.sketch_genomes(O.ULL, 16, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0] for g in genomes])
+    empty = imgs[:1].copy()
+    empty[0, 8:] = 0
+    ref = np.concatenate([imgs, empty])
+    for est, tol in (("fgra", 1e-9), ("ml", 2e-4)):
+        got = ctx.ull_pair_union_estimates(p, ref, imgs, estimator=est)
+        assert got.shape == (len(ref), len(imgs))
+        for i in range(len(ref)):
+            for j in range(len(imgs)):
+                merged = O.merge_images(O.ULL, p, ref[i], imgs[j])
+                want = lash_amd.ull_estimate(merged[8:], p, est)
+                assert got[i, j] == pytest.approx(want, rel=tol, abs=1e-9), (p, est, i, j)
+        # a sketch merged with itself is itself
+        for j in range(len(imgs)):
+            assert got[j, j] == pytest.approx(lash_amd.ull_estimate(imgs[j][8:], p, est), rel=tol)
+    ctx.close()
+
+
+@pytest.mark.parametrize("matrix,model,p,est", [(False, 1, 12, "fgra"), (True, 0, 10, "ml"), (False, 1, 14, "ml")])
+def test_lash_dist_cli_ull(tmp_path, matrix, model, p, est):
+    """`lash dist` on UltraLogLog sketches (utils.rs:186-288) vs the per-register Python restatement of merge + estimator +
+    inclusion-exclusion + Mash distance.  ML: the product stops its iteration at a relative step of 7.6e-4 / sqrt(m)."""
+    base = O.synth_genome(377, 300_000)
+    genomes = [base, _mutated(base, 0.002, 1), _mutated(base, 0.02, 2), O.synth_genome(378, 300_000)]
+    paths = []
+    for i, g in enumerate(genomes):
+        f = tmp_path / ("u%d.fa" % i)
+        f.write_bytes(b">g\n" + g.tobytes() + b"\n")
+        paths.append(str(f))
+    (tmp_path / "all.txt").write_text("\n".join(paths) + "\n")
+    env = dict(os.environ)
+    r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "all.txt"), "-o", "ul", "-k", "16", "-a", "ull", "-p", str(p)],
+                       cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    imgs = [O.sketch_genomes(O.ULL, 16, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0].tobytes() for g in genomes]
+    estimate = R.ull_fgra if est == "fgra" else R.ull_ml
+    card = [estimate(list(im[8:]), p) for im in imgs]
+    flags = (["--dm"] if matrix else []) + ["-m", str(model), "-e", est]
+    r = subprocess.run([H.CLI, "dist", "-q", "ul", "-r", "ul", "-o", "d.txt", "--devices", "0,0"] + flags, cwd=tmp_path, capture_output=True,
+                       text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    text = (tmp_path / "d.txt").read_text()
+
+    def expected(i, j):
+        u = estimate(list(R.ull_merge(imgs[i][8:], imgs[j][8:])), p)
+        return R.mash_distance((card[i] + card[j] - u) / u, 16, model, i == j)
+
+    got = {}
+    if not matrix:
+        for ln in text.strip().split("\n")[1:]:
+            a, b, d = ln.split("\t")
+            got[frozenset((paths.index(a), paths.index(b)))] = float(d)
+    else:
+        for i, ln in enumerate(text.split("\n")[1:]):
+            cells = ln.split("\t")
+            assert cells[0] == paths[i] and len(cells) == i + 2
+            for j, d in enumerate(cells[1:]):
+                got[frozenset((i, j))] = float(d)
+    assert len(got) == 4 * 5 // 2
+    tol = 1.1e-6 if est == "fgra" else 1e-3
+    for i in range(4):
+        for j in range(i + 1):
+            assert abs(got[frozenset((i, j))] - expected(i, j)) <= tol, (i, j, got[frozenset((i, j))], expected(i, j))
+    assert 0 < got[frozenset((0, 1))] < got[frozenset((0, 2))] < got[frozenset((0, 3))] <= 1.0
+    # a bad estimator name is refused like the reference's panic (utils.rs:216)
+    r = subprocess.run([H.CLI, "dist", "-q", "ul", "-r", "ul", "-e", "median"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "fgra or ml" in r.stderr
