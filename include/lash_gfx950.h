@@ -32,6 +32,8 @@ extern "C" {
 #define LASH_ENODEV  (-2)   /* no usable HIP device */
 #define LASH_EHIP    (-3)   /* HIP runtime error; text via lash_ctx_last_error() */
 #define LASH_ENOMEM  (-4)
+#define LASH_ERANGE  (-6)   /* HyperLogLog estimate <= 5 * 2^p: streaming_algorithms subtracts a bias read from the HLL++
+                               empirical tables there; the tables are not in this build, so the case is refused */
 #define LASH_ELIMIT  (-5)   /* a genome has more than 2^32-64 bases in one call (split it and merge images) */
 
 /* -a {hmh,hll,ull}  (main.rs:69-76, 210-246) */
@@ -205,6 +207,21 @@ int lash_ull_pair_union_estimates(lash_ctx *ctx, int p, int estimator, const uin
                                   const uint8_t *qry_images, uint32_t n_qry, double *out_est);
 /* The same two estimators for ONE sketch (utils.rs:213-217), host only: `registers` = the 2^p state bytes (no header). */
 double lash_ull_estimate(const uint8_t *registers, int p, int estimator);
+
+/* ---- dist side, host arithmetic (no GPU): what is O(sketches) or O(pairs) in utils.rs:84-373 ------------------------------
+ * Per-sketch cardinalities from the register bytes (no header): hyperminhash's LogLog-beta (`cardinality()`, utils.rs:170-173),
+ * streaming_algorithms' `len()` (utils.rs:315; LASH_ERANGE in the bias-table regime), lash_ull_estimate above. */
+double lash_hmh_cardinality(const uint8_t *registers, int big_endian);
+int    lash_hll_cardinality(const uint8_t *registers, int p, double *out);
+/* The distance the reference prints for every pair of an [n_ref x n_qry] block, from the GPU's pair statistics and the
+ * per-sketch cardinalities: similarity (hmh: C, N + expected-collision correction, utils.rs:164; hll: len() of the union from
+ * zero / sum, utils.rs:355-362; ull: the union estimate, utils.rs:272) -> .max(0) -> 2s/(1+s) -> model 1: min(-ln(f)/k, 1),
+ * model 0: 1 - f^(1/k) (main.rs:415-423), in f32 arithmetic when fp32 (main.rs --fp32).  The caller applies the
+ * "same name -> 0" rule (main.rs:452-453).  hmh: c_or_zero = C, n_counts = N; hll: c_or_zero = zero, sum_or_union = sum;
+ * ull: sum_or_union = union estimates.  LASH_ERANGE: a union fell into the HLL bias-table regime (*bad_pair = its index). */
+int    lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, uint32_t n_qry, const double *ref_card,
+                      const double *qry_card, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union,
+                      double *out_dist, uint64_t *bad_pair);
 
 /* Synthetic genomes of SURVEY.md §8(d) generated in HBM (bench / tests): genome ids first..first+n-1,
  * n_bases ASCII bytes each, written back to back at d_out. */

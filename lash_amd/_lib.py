@@ -9,7 +9,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx950.so")   # override: A/B builds
 
-OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT = 0, -1, -2, -3, -4, -5
+OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE = 0, -1, -2, -3, -4, -5, -6
 HMH, HLL, ULL = 0, 1, 2
 F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT = 1, 2, 4
 FMT_FASTA, FMT_FASTQ = 1, 2
@@ -78,6 +78,9 @@ PROTOTYPES = {
     "lash_ull_pair_union_estimates_device": (_int, [_vp, _int, _int, _vp, _u32, _vp, _u32, _vp]),
     "lash_ull_pair_union_estimates": (_int, [_vp, _int, _int, _vp, _u32, _vp, _u32, _vp]),
     "lash_ull_estimate": (C.c_double, [_vp, _int, _int]),
+    "lash_hmh_cardinality": (C.c_double, [_vp, _int]),
+    "lash_hll_cardinality": (_int, [_vp, _int, C.POINTER(C.c_double)]),
+    "lash_dist_rows": (_int, [_int, _int, _int, _int, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),
 }
 

@@ -1,0 +1,163 @@
+// dist_estimators.hip — the O(sketches) and O(pairs) arithmetic of `lash dist`, host only (no GPU needed), behind the C ABI
+// so that the C++ command line (host/dist.cpp) and the multi-rank Python driver (lash_amd/allpairs.py) run the same code.
+//
+// Reference: /root/reference/src/utils.rs:150-180 (hmh), 248-282 (ull), 342-369 (hll); main.rs:415-423 (distance).
+// Every estimator is restated from the published algorithm its crate ports [PARITY UNPINNED; tools/ref_probe]:
+//   hyperminhash 0.1.4      LogLog-beta cardinality + expected-collision correction of axiomhq/hyperminhash
+//   streaming_algorithms    HLL++ len(): linear counting below the per-precision threshold, else alpha m^2 / sum; the
+//                           bias-table regime (estimate <= 5m) is REFUSED (LASH_ERANGE): the tables are not in this image
+//   ultraloglog 0.1.6       FGRA / ML (ull_estimators.h)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "../../include/lash_gfx950.h"
+#include "lash_common.h"
+
+namespace {
+
+constexpr int HP = 14, HQ = 6, HR = 10;
+constexpr uint32_t HM = 1u << HP;
+
+double hmh_beta(double ez)
+{
+    const double zl = std::log(ez + 1.0);
+    return -0.370393911 * ez + 0.070471823 * zl + 0.17393686 * std::pow(zl, 2) + 0.16339839 * std::pow(zl, 3) +
+           -0.09237745 * std::pow(zl, 4) + 0.03738027 * std::pow(zl, 5) + -0.005384159 * std::pow(zl, 6) +
+           0.00042419 * std::pow(zl, 7);
+}
+
+double hmh_expected_collision(double n, double m)
+{
+    const double two_q = 64.0, two_r = 1024.0;
+    double x = 0.0;
+    for (double i = 1.0; i <= two_q; i += 1.0) {
+        for (double j = 1.0; j <= two_r; j += 1.0) {
+            double b1, b2;
+            if (i != two_q) {
+                const double den = std::pow(2.0, HP + HR + i);
+                b1 = (two_r + j) / den;
+                b2 = (two_r + j + 1.0) / den;
+            } else {
+                const double den = std::pow(2.0, HP + HR + i - 1.0);
+                b1 = j / den;
+                b2 = (j + 1.0) / den;
+            }
+            const double prx = std::pow(1.0 - b2, n) - std::pow(1.0 - b1, n);
+            const double pry = std::pow(1.0 - b2, m) - std::pow(1.0 - b1, m);
+            x += prx * pry;
+        }
+    }
+    return x * (double)HP + 0.5;
+}
+
+double hmh_approx_expected_collisions(double n, double m)
+{
+    if (n < m) std::swap(n, m);
+    if (n > std::pow(2.0, std::pow(2.0, (double)HQ) + (double)HR)) return 1.8446744073709552e19;   // u64::MAX
+    if (n > std::pow(2.0, (double)(HP + 5))) {
+        const double d = (4.0 * n / m) / std::pow((1.0 + n) / m, 2.0);
+        return 0.169919487159739093975315012348 * std::pow(2.0, (double)(HP - HR)) * d + 0.5;
+    }
+    return hmh_expected_collision(n, m) / (double)HP;
+}
+
+// streaming_algorithms 0.3.3 len() thresholds (HLL++, Heule et al.), p = 4..18
+constexpr double HLL_THRESHOLD[15] = {10, 20, 40, 80, 220, 400, 900, 1800, 3100, 6500, 11500, 20000, 50000, 120000, 350000};
+
+double hll_alpha(int p)
+{
+    switch (p) {
+    case 4: return 0.673;
+    case 5: return 0.697;
+    case 6: return 0.709;
+    default: return 0.7213 / (1.0 + 1.079 / (double)(1u << p));
+    }
+}
+
+bool hll_len(int p, uint64_t zero, double sum, double &out)
+{
+    const double m = (double)(1u << p);
+    if (zero > 0) {
+        const double h = m * std::log(m / (double)zero);
+        if (h <= HLL_THRESHOLD[p - 4]) { out = h; return true; }
+    }
+    const double e = hll_alpha(p) * m * m / sum;
+    if (e <= 5.0 * m) return false;                                  // bias-corrected regime: tables absent
+    out = e;
+    return true;
+}
+
+template <class T>
+T compute_distance(T frac, int k, int model)
+{
+    const T kk = (T)k;
+    if (model == 1) { const T d = -std::log(frac) / kk; return d < (T)1 ? d : (T)1; }      // (-frac.ln() / k).min(1)
+    return (T)1 - std::pow(frac, (T)1 / kk);
+}
+
+}  // namespace
+
+extern "C" {
+
+double lash_hmh_cardinality(const uint8_t *regs, int big_endian)
+{
+    if (!regs) return -1.0;
+    double sum = 0.0, ez = 0.0;
+    for (uint32_t i = 0; i < HM; ++i) {
+        const uint32_t reg = big_endian ? (regs[2 * i + 1] | (regs[2 * i] << 8)) : (regs[2 * i] | (regs[2 * i + 1] << 8));
+        const uint32_t lz = reg >> (16 - HQ);
+        if (lz == 0) ez += 1.0;
+        sum += std::ldexp(1.0, -(int)lz);                       // == 1 / 2^lz exactly
+    }
+    const double m = (double)HM;
+    const double alpha = 0.7213 / (1.0 + 1.079 / m);
+    return alpha * m * (m - ez) / (hmh_beta(ez) + sum);
+}
+
+int lash_hll_cardinality(const uint8_t *regs, int p, double *out)
+{
+    if (!regs || !out || p < 4 || p > 16) return LASH_EINVAL;
+    uint32_t hist[256] = {0};
+    for (size_t i = 0, m = (size_t)1 << p; i < m; ++i) hist[regs[i]]++;
+    double sum = 0.0;
+    for (int r = 255; r >= 0; --r)
+        if (hist[r]) sum += (double)hist[r] * std::ldexp(1.0, -r);      // exact powers of two, largest exponent first
+    return hll_len(p, hist[0], sum, *out) ? LASH_OK : LASH_ERANGE;
+}
+
+int lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, uint32_t n_qry, const double *ref_card,
+                   const double *qry_card, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union,
+                   double *out_dist, uint64_t *bad_pair)
+{
+    if (k < 1 || k > 32 || (model != 0 && model != 1) || !ref_card || !qry_card || !out_dist) return LASH_EINVAL;
+    if (algo == LASH_HMH ? (!c_or_zero || !n_counts) : algo == LASH_HLL ? (!c_or_zero || !sum_or_union || p < 4 || p > 16)
+                         : algo == LASH_ULL ? !sum_or_union : true)
+        return LASH_EINVAL;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        for (uint32_t j = 0; j < n_qry; ++j) {
+            const uint64_t at = (uint64_t)i * n_qry + j;
+            double sim = 0.0;
+            if (algo == LASH_HLL) {                                                               // utils.rs:352-365
+                double u;
+                if (!hll_len(p, c_or_zero[at], sum_or_union[at], u)) { if (bad_pair) *bad_pair = at; return LASH_ERANGE; }
+                sim = (ref_card[i] + qry_card[j] - u) / u;
+            } else if (algo == LASH_ULL) {                                                        // utils.rs:256-274
+                const double u = sum_or_union[at];
+                sim = (ref_card[i] + qry_card[j] - u) / u;
+            } else {
+                const double c = (double)c_or_zero[at], n = (double)n_counts[at];
+                if (c != 0.0) {                                                                   // Sketch::similarity
+                    const double ec = hmh_approx_expected_collisions(qry_card[j], ref_card[i]);
+                    sim = c < ec ? 0.0 : (c - ec) / n;
+                }
+            }
+            if (!(sim >= 0.0)) sim = 0.0;                                                         // .max(0.0) / `if similarity < 0.0`
+            const double frac = 2.0 * sim / (1.0 + sim);                                          // utils.rs:165-167
+            out_dist[at] = fp32 ? (double)compute_distance<float>((float)frac, k, model) : compute_distance<double>(frac, k, model);
+        }
+    }
+    return LASH_OK;
+}
+
+}  // extern "C"

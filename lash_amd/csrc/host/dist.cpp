@@ -41,9 +41,6 @@
 namespace lashhost {
 namespace {
 
-constexpr int HP = 14, HQ = 6, HR = 10;
-constexpr uint32_t HM = 1u << HP;
-
 // main.rs:284-337
 std::string find_files(const std::string &prefix, std::map<std::string, std::string> &out)
 {
@@ -81,110 +78,6 @@ std::string slurp(const std::string &path, std::string &out)
     ss << in.rdbuf();
     out = ss.str();
     return "";
-}
-
-// hyperminhash (axiomhq) restated: LogLog-beta cardinality of one sketch
-double hmh_beta(double ez)
-{
-    const double zl = std::log(ez + 1.0);
-    return -0.370393911 * ez + 0.070471823 * zl + 0.17393686 * std::pow(zl, 2) + 0.16339839 * std::pow(zl, 3) +
-           -0.09237745 * std::pow(zl, 4) + 0.03738027 * std::pow(zl, 5) + -0.005384159 * std::pow(zl, 6) +
-           0.00042419 * std::pow(zl, 7);
-}
-
-double hmh_cardinality(const uint8_t *regs, bool big_endian)
-{
-    double sum = 0.0, ez = 0.0;
-    for (uint32_t i = 0; i < HM; ++i) {
-        const uint32_t reg = big_endian ? (regs[2 * i + 1] | (regs[2 * i] << 8)) : (regs[2 * i] | (regs[2 * i + 1] << 8));
-        const uint32_t lz = reg >> (16 - HQ);
-        if (lz == 0) ez += 1.0;
-        sum += std::ldexp(1.0, -(int)lz);                       // == 1 / 2^lz exactly
-    }
-    const double m = (double)HM;
-    const double alpha = 0.7213 / (1.0 + 1.079 / m);
-    return alpha * m * (m - ez) / (hmh_beta(ez) + sum);
-}
-
-double hmh_expected_collision(double n, double m)
-{
-    const double two_q = 64.0, two_r = 1024.0;
-    double x = 0.0;
-    for (double i = 1.0; i <= two_q; i += 1.0) {
-        for (double j = 1.0; j <= two_r; j += 1.0) {
-            double b1, b2;
-            if (i != two_q) {
-                const double den = std::pow(2.0, HP + HR + i);
-                b1 = (two_r + j) / den;
-                b2 = (two_r + j + 1.0) / den;
-            } else {
-                const double den = std::pow(2.0, HP + HR + i - 1.0);
-                b1 = j / den;
-                b2 = (j + 1.0) / den;
-            }
-            const double prx = std::pow(1.0 - b2, n) - std::pow(1.0 - b1, n);
-            const double pry = std::pow(1.0 - b2, m) - std::pow(1.0 - b1, m);
-            x += prx * pry;
-        }
-    }
-    return x * (double)HP + 0.5;
-}
-
-double hmh_approx_expected_collisions(double n, double m)
-{
-    if (n < m) std::swap(n, m);
-    if (n > std::pow(2.0, std::pow(2.0, (double)HQ) + (double)HR)) return 1.8446744073709552e19;   // u64::MAX
-    if (n > std::pow(2.0, (double)(HP + 5))) {
-        const double d = (4.0 * n / m) / std::pow((1.0 + n) / m, 2.0);
-        return 0.169919487159739093975315012348 * std::pow(2.0, (double)(HP - HR)) * d + 0.5;
-    }
-    return hmh_expected_collision(n, m) / (double)HP;
-}
-
-// ---- HyperLogLog len() (streaming_algorithms 0.3.3, HLL++ as published by Heule et al.) ----
-constexpr double HLL_THRESHOLD[15] = {10, 20, 40, 80, 220, 400, 900, 1800, 3100, 6500, 11500, 20000, 50000, 120000, 350000};  // p = 4..18
-
-// returns false when the estimate falls in the bias-corrected regime (no tables here)
-bool hll_len(int p, double alpha, uint64_t zero, double sum, double &out)
-{
-    const double m = (double)(1u << p);
-    if (zero > 0) {
-        const double h = m * std::log(m / (double)zero);
-        if (h <= HLL_THRESHOLD[p - 4]) { out = h; return true; }
-    }
-    const double e = alpha * m * m / sum;
-    if (e <= 5.0 * m) return false;
-    out = e;
-    return true;
-}
-
-double hll_alpha(int p)
-{
-    switch (p) {
-    case 4: return 0.673;
-    case 5: return 0.697;
-    case 6: return 0.709;
-    default: return 0.7213 / (1.0 + 1.079 / (double)(1u << p));
-    }
-}
-
-// zero and sum of one sketch from its registers (the header's copies are layout-dependent; these are not)
-void hll_zero_sum(const uint8_t *regs, int p, uint64_t &zero, double &sum)
-{
-    uint32_t hist[256] = {0};
-    for (size_t i = 0, m = (size_t)1 << p; i < m; ++i) hist[regs[i]]++;
-    zero = hist[0];
-    sum = 0.0;
-    for (int r = 255; r >= 0; --r)
-        if (hist[r]) sum += (double)hist[r] * std::ldexp(1.0, -r);      // exact powers of two, largest exponent first
-}
-
-template <class T>
-T compute_distance(T frac, int k, int model)
-{
-    const T kk = (T)k;
-    if (model == 1) { const T d = -std::log(frac) / kk; return d < (T)1 ? d : (T)1; }      // (-frac.ln() / k).min(1)
-    return (T)1 - std::pow(frac, (T)1 / kk);
 }
 
 }  // namespace
@@ -234,7 +127,6 @@ std::string run_dist(const DistOptions &opt)
     std::vector<double> rcard(nr), qcard(nq);
     const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which "
                            "this build does not have (sketch with a smaller -p)";
-    const double alpha = hll ? hll_alpha(prec) : 0.0;
     // per-sketch cardinalities (utils.rs:101-103, 213-217, 314-315), on `-t` host threads
     auto cards = [&](const std::vector<uint8_t> &img, const std::vector<std::string> &names, std::vector<double> &card) -> std::string {
         const uint32_t n = (uint32_t)names.size();
@@ -244,12 +136,8 @@ std::string run_dist(const DistOptions &opt)
             for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
                 const uint8_t *regs = img.data() + (size_t)i * ib + hdr;
                 if (ull) card[i] = lash_ull_estimate(regs, prec, ull_est);
-                else if (!hll) card[i] = hmh_cardinality(regs, opt.layout.hmh_reg_be != 0);
-                else {
-                    uint64_t zero; double sum;
-                    hll_zero_sum(regs, prec, zero, sum);
-                    if (!hll_len(prec, alpha, zero, sum, card[i])) bad[i] = 1;
-                }
+                else if (!hll) card[i] = lash_hmh_cardinality(regs, opt.layout.hmh_reg_be != 0);
+                else if (lash_hll_cardinality(regs, prec, &card[i]) != LASH_OK) bad[i] = 1;
             }
         };
         std::vector<std::thread> pool;
@@ -315,32 +203,16 @@ std::string run_dist(const DistOptions &opt)
                     char buf[64];
                     bool first = true;
                     const size_t row = (size_t)(i - i0) * nq;
+                    std::vector<double> dist(nq);
+                    uint64_t bad_pair = 0;
+                    const int drc = lash_dist_rows(algo_id, prec, k, opt.model, opt.fp32 ? 1 : 0, 1, nq, &rcard[i], qcard.data(),
+                                                   ull ? nullptr : C.data() + row, (hll || ull) ? nullptr : N.data() + row,
+                                                   (hll || ull) ? U.data() + row : nullptr, dist.data(), &bad_pair);
+                    if (drc == LASH_ERANGE) { row_fail[i - i0] = "union of " + rnames[i] + " and " + qnames[bad_pair] + bias_msg; return; }
+                    if (drc != LASH_OK) { row_fail[i - i0] = lash_strerror(drc); return; }
                     for (uint32_t j = 0; j < nq; ++j) {
                         if (same_files && j > i) continue;                                            // utils.rs:158-160
-                        double sim = 0.0;
-                        if (hll) {                                                                    // utils.rs:352-365
-                            double u;
-                            if (!hll_len(prec, alpha, C[row + j], U[row + j], u)) {
-                                row_fail[i - i0] = "union of " + rnames[i] + " and " + qnames[j] + bias_msg;
-                                return;
-                            }
-                            sim = (rcard[i] + qcard[j] - u) / u;
-                        } else if (ull) {                                                             // utils.rs:256-274
-                            const double u = U[row + j];
-                            sim = (rcard[i] + qcard[j] - u) / u;
-                        } else {
-                            const double c = (double)C[row + j], n = (double)N[row + j];
-                            if (c != 0.0) {                                                           // Sketch::similarity
-                                const double ec = hmh_approx_expected_collisions(qcard[j], rcard[i]);
-                                sim = c < ec ? 0.0 : (c - ec) / n;
-                            }
-                        }
-                        if (!(sim >= 0.0)) sim = 0.0;                                                 // .max(0.0) / `if similarity < 0.0`
-                        const double frac = 2.0 * sim / (1.0 + sim);                                  // utils.rs:165-167
-                        double d;
-                        if (qnames[j] == rnames[i]) d = 0.0;                                          // main.rs:452-453
-                        else if (opt.fp32) d = (double)compute_distance<float>((float)frac, k, opt.model);
-                        else d = compute_distance<double>(frac, k, opt.model);
+                        const double d = qnames[j] == rnames[i] ? 0.0 : dist[j];                      // main.rs:452-453
                         // "{:.6}" (main.rs:456,461): std::to_chars is correctly rounded like printf("%.6f") and several times faster
                         buf[0] = '\t';
                         char *end = std::to_chars(buf + 1, buf + sizeof buf - 2, d, std::chars_format::fixed, 6).ptr;

@@ -671,6 +671,7 @@ const char *lash_strerror(int code)
     case LASH_ENODEV: return "no usable HIP device (liblash_gfx950 has no CPU fallback)";
     case LASH_EHIP: return "HIP runtime error";
     case LASH_ENOMEM: return "out of device memory";
+    case LASH_ERANGE: return "HyperLogLog estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which this build does not have (sketch with a smaller -p)";
     case LASH_ELIMIT: return "a genome exceeds 2^32-64 bytes in one call; split it and merge the images";
     default: return "unknown error";
     }

@@ -13,6 +13,45 @@ ALGOS = {"hmh": _lib.HMH, "hll": _lib.HLL, "ull": _lib.ULL}
 ULL_ESTIMATORS = {"fgra": 0, "ml": 1}
 
 
+def sketch_cardinality(algo, p, image, layout=None, estimator="fgra"):
+    """Distinct-count estimate of ONE serialized sketch, as `lash dist` computes it per sketch (utils.rs:101-103, 213-217, 314-315):
+    hmh LogLog-beta, hll `len()` (LashError(ERANGE) in the bias-table regime), ull FGRA / ML.  Host only."""
+    lib = _lib.load()
+    a = _algo(algo)
+    lay = parse_layout(layout)
+    img = np.ascontiguousarray(image, dtype=np.uint8).reshape(-1)
+    regs = img[header_bytes(a, lay):]
+    if a == _lib.HMH:
+        return float(lib.lash_hmh_cardinality(regs.ctypes.data, int(lay.hmh_reg_be)))
+    if a == _lib.ULL:
+        return float(lib.lash_ull_estimate(regs.ctypes.data, int(p), ULL_ESTIMATORS[estimator]))
+    out = C.c_double()
+    rc = lib.lash_hll_cardinality(regs.ctypes.data, int(p), C.byref(out))
+    if rc != _lib.OK:
+        raise LashError(rc, lib.lash_strerror(rc).decode())
+    return out.value
+
+
+def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=None, sum_or_union=None, fp32=False):
+    """The distances the reference prints for an [n_ref, n_qry] block, from the GPU's pair statistics and the per-sketch
+    cardinalities (lash_dist_rows; utils.rs:164-167, 272-278, 355-365 + main.rs:415-423).  numpy in, float64 [n_ref, n_qry] out."""
+    lib = _lib.load()
+    rc_ = np.ascontiguousarray(ref_card, dtype=np.float64)
+    qc_ = np.ascontiguousarray(qry_card, dtype=np.float64)
+    nr, nq = len(rc_), len(qc_)
+    a = None if c_or_zero is None else np.ascontiguousarray(c_or_zero, dtype=np.uint32)
+    b = None if n_counts is None else np.ascontiguousarray(n_counts, dtype=np.uint32)
+    d = None if sum_or_union is None else np.ascontiguousarray(sum_or_union, dtype=np.float64)
+    out = np.zeros((nr, nq), dtype=np.float64)
+    bad = C.c_uint64()
+    rc = lib.lash_dist_rows(_algo(algo), int(p or 0), int(k), int(model), 1 if fp32 else 0, nr, nq, rc_.ctypes.data, qc_.ctypes.data,
+                            None if a is None else a.ctypes.data, None if b is None else b.ctypes.data,
+                            None if d is None else d.ctypes.data, out.ctypes.data, C.byref(bad))
+    if rc != _lib.OK:
+        raise LashError(rc, lib.lash_strerror(rc).decode() + (" (pair %d)" % bad.value if rc == _lib.ERANGE else ""))
+    return out
+
+
 def ull_estimate(registers, p, estimator="fgra"):
     """FGRA / ML distinct-count estimate of ONE UltraLogLog sketch from its 2^p register bytes (host only; utils.rs:213-217)."""
     regs = np.ascontiguousarray(registers, dtype=np.uint8)
@@ -268,6 +307,18 @@ class Context:
         self._check(self._lib.lash_hll_pair_union_stats(self._h, int(p), ref.ctypes.data, ref.shape[0], qry.ctypes.data,
                                                         qry.shape[0], zero.ctypes.data, usum.ctypes.data))
         return zero, usum
+
+    # device-resident forms (asynchronous on the context's stream): image blocks and outputs are device pointers / torch tensors
+    def hmh_pair_counts_device(self, d_ref, n_ref, d_qry, n_qry, d_c, d_n):
+        self._check(self._lib.lash_hmh_pair_counts_device(self._h, _ptr(d_ref), int(n_ref), _ptr(d_qry), int(n_qry), _ptr(d_c), _ptr(d_n)))
+
+    def hll_pair_union_stats_device(self, p, d_ref, n_ref, d_qry, n_qry, d_zero, d_sum):
+        self._check(self._lib.lash_hll_pair_union_stats_device(self._h, int(p), _ptr(d_ref), int(n_ref), _ptr(d_qry), int(n_qry),
+                                                               _ptr(d_zero), _ptr(d_sum)))
+
+    def ull_pair_union_estimates_device(self, p, estimator, d_ref, n_ref, d_qry, n_qry, d_est):
+        self._check(self._lib.lash_ull_pair_union_estimates_device(self._h, int(p), ULL_ESTIMATORS[estimator], _ptr(d_ref), int(n_ref),
+                                                                   _ptr(d_qry), int(n_qry), _ptr(d_est)))
 
     def ull_pair_union_estimates(self, p, ref_images, qry_images, estimator="fgra"):
         """UltraLogLog: estimated distinct count of merge(ref_i, qry_j) for every pair (utils.rs:260-270): numpy uint8

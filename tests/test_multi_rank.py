@@ -113,3 +113,91 @@ def test_merge_partial_images_gloo(world):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
     assert all(res[r] for r in range(world)), res
+
+
+# ---- all-vs-all dist over ranks (BASELINE configs[3]; lash_amd/allpairs.py): REAL sketch images (made by the oracle: no GPU
+# here), gathered over gloo, every rank computes its block of reference rows; the union of the blocks must be the
+# single-process matrix.  The pair statistics — GPU kernels in the product — are a numpy stand-in here (test infrastructure);
+# everything else (shard, gather, row blocks, cardinalities, lash_dist_rows) is the product's code.
+def _numpy_pair_stats(algo, p, estimator, ref, qry):
+    import lash_amd
+    import oracle_lib as O
+    if algo == "hmh":
+        a, b = ref.view("<u2").astype(np.int64), qry.view("<u2").astype(np.int64)
+        c = ((a[:, None, :] == b[None, :, :]) & (a[:, None, :] != 0)).sum(axis=2).astype(np.uint32)
+        n = ((a[:, None, :] != 0) | (b[None, :, :] != 0)).sum(axis=2).astype(np.uint32)
+        return dict(c_or_zero=c, n_counts=n)
+    if algo == "hll":
+        u = np.maximum(ref[:, None, 33:], qry[None, :, 33:]).astype(np.int64)
+        return dict(c_or_zero=(u == 0).sum(axis=2).astype(np.uint32), sum_or_union=np.ldexp(1.0, -u).sum(axis=2))
+    est = np.zeros((len(ref), len(qry)))
+    for i in range(len(ref)):
+        for j in range(len(qry)):
+            est[i, j] = lash_amd.ull_estimate(O.merge_images(O.ULL, p, ref[i], qry[j])[8:], p, estimator)
+    return dict(sum_or_union=est)
+
+
+def _genomes_for_dist():
+    import oracle_lib as O
+    rng = np.random.default_rng(12)
+    base = O.synth_genome(600, 120_000)
+    gs = [base]
+    for i, rate in enumerate((0.001, 0.01, 0.05, 0.2)):
+        g = base.copy()
+        idx = rng.random(len(g)) < rate
+        g[idx] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(idx.sum()))
+        gs.append(g)
+    gs += [O.synth_genome(601, 90_000), O.synth_genome(602, 150_001)]
+    return gs
+
+
+def _allpairs_worker(rank, world, port, algo, p, k, q):
+    import oracle_lib as O
+    from lash_amd.allpairs import all_vs_all
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gs = _genomes_for_dist()
+        blocks = shard_genomes([len(g) for g in gs], world)
+        a, b = blocks[rank]
+        aid = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}[algo]
+        imgs = [O.sketch_genomes(aid, k, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0] for g in gs[a:b]]
+        local = torch.from_numpy(np.stack(imgs)) if imgs else torch.zeros((0, O.image_bytes(aid, p)), dtype=torch.uint8)
+        r0, r1, block = all_vs_all(algo, p, k, local, [e - s for s, e in blocks], pair_stats=_numpy_pair_stats, estimator="fgra")
+        q.put((rank, r0, r1, block))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,algo,p,k", [(2, "hmh", 0, 16), (3, "hmh", 0, 21), (2, "hll", 10, 16), (2, "ull", 10, 16)])
+def test_all_vs_all_rows_over_ranks_equal_single_process(world, algo, p, k):
+    import lash_amd
+    import oracle_lib as O
+    gs = _genomes_for_dist()
+    n = len(gs)
+    aid = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}[algo]
+    every = np.stack([O.sketch_genomes(aid, k, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0] for g in gs])
+    card = np.array([lash_amd.sketch_cardinality(algo, p, im) for im in every])
+    want = lash_amd.dist_rows(algo, p, k, 1, card, card, **_numpy_pair_stats(algo, p, "fgra", every, every))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allpairs_worker, args=(r, world, port, algo, p, k, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    got.sort()
+    assert got[0][1] == 0 and got[-1][2] == n and all(a[2] == b[1] for a, b in zip(got[:-1], got[1:]))   # rows partition [0, N)
+    full = np.concatenate([g[3] for g in got])
+    assert full.shape == (n, n) and np.array_equal(full, want)
+    if algo == "hmh":                                            # and the numbers are the reference's formula (pure-Python restatement)
+        import pyref as R
+        for i in (0, 3, n - 1):
+            for j in range(n):
+                d = R.mash_distance(R.hmh_similarity(every[j].tobytes(), every[i].tobytes()), k, 1, False)
+                assert abs(full[i, j] - d) < 1e-9
+    assert 0 < full[0, 1] < full[0, 2] < full[0, 3] < full[0, 4] <= 1.0
