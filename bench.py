@@ -31,17 +31,79 @@ def algorithmic_bytes_per_genome(L, image_bytes, ascii_input):
     return (L if ascii_input else (L + 3) // 4) + image_bytes
 
 
+def host_provenance():
+    """What the host side of this box really offers: logical CPUs, the affinity mask, the cgroup CPU
+    quota — the effective core count is the minimum of the three — and the CPU model."""
+    ncpu = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = ncpu
+    quota, quota_src = None, None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                     # cgroup v2
+        quota_src = "cpu.max=%s/%s" % (q, per)
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())                # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota_src = "cfs_quota_us=%d/cfs_period_us=%d" % (q, per)
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    eff = min(ncpu, aff, int(quota + 0.5) if quota else ncpu)
+    return {"logical_cpus": ncpu, "affinity": aff, "cgroup_quota_cpus": quota, "cgroup": quota_src, "effective_cores": max(1, eff),
+            "cpu_model": model}
+
+
+def native_oracle():
+    """the CPU leg is timed on an oracle built `-O3 -march=native` for THIS host when gcc is here (temporary
+    directory; the shipped generic .so otherwise).  Returns (path or None, flags string)."""
+    import shutil
+    import subprocess
+    import tempfile
+    gcc = shutil.which("gcc")
+    if not gcc:
+        return None, "shipped oracle/liblash_oracle.so (-O3, baseline x86-64; no gcc on this box)"
+    d = tempfile.mkdtemp(prefix="lash_oracle_native_")
+    so = os.path.join(d, "liblash_oracle_native.so")
+    flags = ["-O3", "-march=native", "-std=c11", "-fPIC", "-shared"]
+    try:
+        subprocess.check_call([gcc] + flags + ["-o", so, os.path.join(ROOT, "oracle", "lash_oracle.c"), "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        return so, "rebuilt on this host: gcc " + " ".join(flags[:2])
+    except Exception:
+        return None, "shipped oracle/liblash_oracle.so (-O3, baseline x86-64; the native rebuild failed)"
+
+
 def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
-    """The only place bench.py touches oracle/.  Times the CPU oracle (a port: the Rust reference cannot be built here) with the reference's parallel
-    structure — one task per genome, dynamic scheduling (utils.rs:450-452) — on a bounded sample of the same
-    synthetic workload.  The thread count is the best of a short scan (on many-core hosts all logical cores is
-    not always the fastest); `cores` reports the threads actually used.  `check_images` {genome index: GPU image}: the
-    oracle also sketches those genomes of the GPU workload and the images must be identical (returned as the flag)."""
+    """The only place bench.py touches oracle/.  Times the CPU oracle (a port: the Rust reference cannot be built here) with
+    the reference's parallel structure — one task per genome, dynamic scheduling (utils.rs:450-452) — on a bounded sample of
+    the same synthetic workload: (i) parse-inclusive, from FASTA text in memory (80-column lines; needletail-like parse +
+    the per-file closure, utils.rs:452-508), (ii) sketch-only, from pre-loaded sequences.  Threads = the EFFECTIVE cores
+    (affinity and cgroup quota honoured, see host_provenance()); a short scan around that number is reported.
+    `check_images` {genome index: GPU image}: the oracle also sketches those genomes of the GPU workload and the images must
+    be identical (returned as the flag)."""
+    prov = host_provenance()
+    so, flags = native_oracle()
+    if so:
+        os.environ["LASH_ORACLE_LIB"] = so
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
-    ncpu = os.cpu_count() or 1
-    n = min(2 * ncpu, 256)
+    eff = prov["effective_cores"]
+    n = max(8, min(2 * eff, 256))
     gen0 = 10_000_000                     # genome ids disjoint from the GPU workload
     seqs = np.concatenate([O.synth_genome(gen0 + g, L) for g in range(n)])
     rec_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
@@ -53,10 +115,10 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
         O.sketch_genomes(algo_id, k, p, seed, seqs[:genomes * L], rec_off[:genomes + 1], goff[:genomes + 1], threads=threads)
         return genomes * (L - k + 1) / (time.perf_counter() - t0)
 
-    cands = sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 64), min(ncpu, 32)}, reverse=True)
+    cands = sorted({eff, max(1, eff // 2), min(prov["affinity"], 2 * eff), min(prov["affinity"], 4 * eff)}, reverse=True)
     scan = {}
     for T in cands:
-        scan[T] = run(T, min(n, 2 * T))
+        scan[T] = run(T, min(n, max(2 * T, 8)))
     best = max(scan, key=scan.get)
     done, elapsed = 0, 0.0
     while elapsed < target_s:
@@ -65,6 +127,17 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
         elapsed += time.perf_counter() - t0
         done += n
     kmers = done * (L - k + 1)
+    # (i) parse-inclusive: the same genomes as 80-column FASTA text
+    nf = min(n, max(4, best))
+    files = []
+    for g in range(nf):
+        body = seqs[g * L:(g + 1) * L]
+        full = body[: (L // 80) * 80].reshape(-1, 80)
+        txt = np.concatenate([full, np.full((full.shape[0], 1), 10, np.uint8)], axis=1).reshape(-1)
+        files.append(b">g%d\n" % g + txt.tobytes() + body[(L // 80) * 80:].tobytes() + b"\n")
+    t0 = time.perf_counter()
+    O.sketch_files(algo_id, k, p, seed, files, threads=best)
+    parse_rate = nf * (L - k + 1) / (time.perf_counter() - t0)
     ok = True
     for g, got in check_images.items():
         host = O.synth_genome(first_genome + g, L)
@@ -72,10 +145,143 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
         ok = ok and bool(np.array_equal(got, want))
     return {"value": kmers / elapsed, "unit": "k-mers/s", "cores": best, "kind": "port",
             "sample": "%d synthetic %d-bp genomes, %s k=%d, in-memory sequences (no FASTA parse), %.1f s of CPU work; "
-                      "oracle/lash_oracle.c compiled -O3 for baseline x86-64, one task per genome over %d threads "
-                      "(best of a scan over %s threads on %d logical cores)"
-                      % (done, L, algo, k, elapsed, best, sorted(scan), ncpu),
+                      "oracle/lash_oracle.c (%s), one task per genome over %d threads (effective cores %d: %d logical, affinity %d, "
+                      "cgroup %s; scan over %s threads)"
+                      % (done, L, algo, k, elapsed, flags, best, eff, prov["logical_cpus"], prov["affinity"], prov["cgroup"], sorted(scan)),
+            "parse_inclusive_value": parse_rate,
+            "parse_inclusive_sample": "%d of those genomes as 80-column FASTA text in memory: needletail-like parse + filter + "
+                                      "2-bit copy + k-mers + sketch per file (utils.rs:452-508), %d threads" % (nf, best),
+            "host": prov, "oracle_build": flags,
             "thread_scan": {str(T): v for T, v in sorted(scan.items())}}, ok
+
+
+def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k):
+    """The binding roofline of the sketch kernel is integer-VALU issue, not HBM.  Its ceiling is
+    MEASURED: tools/ubench_hash runs the kernel's per-k-mer instruction stream (window, reverse complement, xxh3_128, register
+    rule, LDS atomic) from registers, no HBM, at the kernel's occupancy; run here when the binary is built, else the
+    committed round-2 figure.  insts_per_kmer comes from the committed SQ_INSTS_VALU counter pass (profiles/valu.json)."""
+    import re
+    import subprocess
+    floor, src = None, None
+    exe = os.path.join(ROOT, "tools", "ubench_hash")
+    if os.path.exists(exe) and algo == "hmh":
+        try:
+            out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+            m = re.search(r"\+ ds_max_u32.*\(([0-9.e+]+) k-mers/s chip-wide\)", out)
+            if m:
+                floor, src = float(m.group(1)), "tools/ubench_hash run in this process' job (hmh k=16 instruction stream from registers)"
+        except Exception:
+            pass
+    per, vsrc = None, None
+    vpath = os.path.join(ROOT, "profiles", "valu.json")
+    if os.path.exists(vpath):
+        try:
+            vj = json.load(open(vpath))
+            key = "%s%s_k%d" % ("direct_" if direct else "", algo, k)
+            if floor is None and "issue_floor_kmers_per_s" in vj.get(key, {}):
+                floor, src = vj[key]["issue_floor_kmers_per_s"], vj[key].get("floor_source", "profiles/valu.json")
+            per, vsrc = vj.get(key, {}).get("valu_insts_per_kmer"), vj.get(key, {}).get("source")
+        except Exception:
+            pass
+    rate = kmers_per_launch / (sketch_ms * 1e-3) if sketch_ms > 0 else 0.0
+    return {"bound": "valu-issue", "achieved": rate, "peak": floor, "unit": "k-mers/s", "frac": (rate / floor) if floor else None,
+            "insts_per_kmer": per, "insts_source": vsrc, "peak_source": src,
+            "note": "peak = measured ceiling of this instruction stream with no memory traffic, not a datasheet number"}
+
+
+def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L, G, d_seq, d_rec, goff, rec_off, d_img, ib):
+    """BASELINE configs[3] in the shape one node allows: every rank sketches its G genomes (shard), ONE collective — the
+    all-gather of the finished images over RCCL — then rank r owns reference rows [r*N/W, (r+1)*N/W) against all N sketches
+    (pair kernel on its GPU).  A step is timed by HIP-synchronised wall clock like the sketch bench; the O(pairs) host
+    arithmetic of the estimators (lash_dist_rows) is timed beside it on a bounded sample of the rows."""
+    import numpy as np
+    import lash_amd
+    from lash_amd.allpairs import cardinalities, row_block
+    N = G * world
+    every = torch.empty((N, ib), dtype=torch.uint8, device=dev)
+    r0, r1 = row_block(N, rank, world)
+    nr = r1 - r0
+    if algo == "hmh":
+        outs = (torch.empty((nr, N), dtype=torch.int32, device=dev), torch.empty((nr, N), dtype=torch.int32, device=dev))
+    elif algo == "hll":
+        outs = (torch.empty((nr, N), dtype=torch.int32, device=dev), torch.empty((nr, N), dtype=torch.float64, device=dev))
+    else:
+        outs = (torch.empty((nr, N), dtype=torch.float64, device=dev),)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def step(timed=False):
+        if timed:
+            ev[0].record()
+        ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img)
+        if timed:
+            ev[1].record()
+        if dist:
+            dist.all_gather_into_tensor(every.view(-1), d_img)
+        else:
+            every.view(-1).copy_(d_img)
+        if timed:
+            ev[2].record()
+        ref = every[r0:r1]
+        if algo == "hmh":
+            ctx.hmh_pair_counts_device(ref, nr, every, N, outs[0], outs[1])
+        elif algo == "hll":
+            ctx.hll_pair_union_stats_device(p, ref, nr, every, N, outs[0], outs[1])
+        else:
+            ctx.ull_pair_union_estimates_device(p, "fgra", ref, nr, every, N, outs[0])
+        if timed:
+            ev[3].record()
+
+    for _ in range(3 + args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    step(timed=True)
+    torch.cuda.synchronize()
+    stage = {"sketch": ev[0].elapsed_time(ev[1]), "gather": ev[1].elapsed_time(ev[2]), "pairs": ev[2].elapsed_time(ev[3])}
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # host arithmetic on a bounded sample of this rank's rows
+    host = every.cpu().numpy()
+    t1 = time.perf_counter()
+    card = cardinalities(algo, p, host[: min(N, 2000)])
+    card_s_per_sketch = (time.perf_counter() - t1) / min(N, 2000)
+    rows = min(nr, 64)
+    st = {}
+    if algo == "hmh":
+        st = dict(c_or_zero=outs[0][:rows].cpu().numpy().view(np.uint32), n_counts=outs[1][:rows].cpu().numpy().view(np.uint32))
+    elif algo == "hll":
+        st = dict(c_or_zero=outs[0][:rows].cpu().numpy().view(np.uint32), sum_or_union=outs[1][:rows].cpu().numpy())
+    else:
+        st = dict(sum_or_union=outs[0][:rows].cpu().numpy())
+    full_card = np.resize(card, N)
+    t1 = time.perf_counter()
+    d = lash_amd.dist_rows(algo, p, k, 1, full_card[:rows], full_card, **st)
+    host_pairs_per_s = rows * N / (time.perf_counter() - t1)
+    if rank == 0:
+        kmers = G * (L - k + 1) * world * args.steps
+        pairs = N * N * args.steps                       # all ranks' row blocks together: the full N x N matrix per step
+        print(json.dumps({
+            "metric": "k-mers/s sketched + all-vs-all (%s, k=%d)" % (algo, k), "value": kmers / elapsed, "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[3] shape: %d synthetic %d-bp genomes per GPU sketched (-a %s -k %d), images all-gathered over "
+                                   "RCCL (%d x %d B), every rank computes %d of the %d reference rows against all %d sketches"
+                                   % (G, L, algo, k, N, ib, nr, N, N), "genomes_per_gpu": G, "genome_length": L, "algo": algo, "k": k, "p": p},
+            "pairs_per_s": pairs / elapsed, "stage_ms_rank0": stage,
+            "host_arithmetic": {"cardinality_s_per_sketch": card_s_per_sketch, "dist_rows_pairs_per_s_one_thread": host_pairs_per_s,
+                                "note": "O(sketches) + O(pairs) estimator arithmetic (lash_dist_rows), outside the timed step; mean distance of the sample %.4f" % float(d.mean())},
+            "roofline": None, "cpu_baseline": None}))
 
 
 def main():
@@ -89,9 +295,11 @@ def main():
     ap.add_argument("-k", type=int, default=16)
     ap.add_argument("-p", type=int, default=14)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--workload", choices=["genomes", "reads"], default="genomes",
+    ap.add_argument("--workload", choices=["genomes", "reads", "allpairs"], default="genomes",
                     help="genomes: --genomes x --length bp, one record each (configs[1]/[2]); reads: ONE sketch of --reads "
-                         "150-bp records (configs[4] shape; use with --algo ull -p 12)")
+                         "150-bp records (configs[4] shape; use with --algo ull -p 12); allpairs: configs[3] shape — every rank "
+                         "sketches --genomes genomes, the images are all-gathered (RCCL), every rank computes its block of "
+                         "reference rows of the all-vs-all distance matrix")
     ap.add_argument("--reads", type=int, default=20_000_000, help="--workload reads: 150-bp records per step and GPU")
     ap.add_argument("--dirty", choices=["none", "nrun", "lower"], default="none",
                     help="nrun: one 100-byte run of N per genome; lower: every other 10 kb block lower-case (soft-masked "
@@ -169,6 +377,13 @@ def main():
         torch.cuda.synchronize()
     d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+
+    if args.workload == "allpairs":
+        allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L, G, d_seq, d_rec, goff, rec_off, d_img, ib)
+        ctx.close()
+        if dist:
+            dist.destroy_process_group()
+        return
 
     def step():
         ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, n_rec, goff, rec_off, d_img)
@@ -265,6 +480,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sketch_ms,
                          "input": "ASCII records (1 B/base)" if direct else "packed 2-bit words (0.25 B/base)",
                          "note": "integer-ALU/LDS-atomic bound kernel: see DESIGN.md 'Roofline'"},
+            "roofline_valu": valu_roofline(kmers_step_rank, sketch_ms, direct, algo, k),
             "stage_ms_per_step": {"pack": tm["pack_ms"] / max(tm["calls"], 1), "sketch": stage_sketch_ms,
                                   "finalize": tm["finalize_ms"] / max(tm["calls"], 1)},
             "packed_resident_kmers_per_s_this_rank": kmers_step_rank * args.steps / packed_elapsed,   # 2-bit genomes kept in HBM

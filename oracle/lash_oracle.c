@@ -177,10 +177,20 @@ static inline uint64_t groups_reversed(uint64_t v, int k)
     for (int i = 0; i < k; i++) { o = (o << 2) | (v & 3u); v >>= 2; }
     return o;
 }
-/* complement every base (code -> code of the complementary letter: A<->T, C<->G), reverse their order */
+/* complement every base (code -> code of the complementary letter: A<->T, C<->G), reverse their order.
+ * kmerutils does this with swaps on the whole word (complement, swap groups inside nibbles, nibbles inside bytes, bytes,
+ * then right-align): restated for the default codes, where complement is bitwise NOT; other code assignments (layout
+ * switch U5) take the plain loop. */
 static inline uint64_t revcomp(const lash_or_layout *lay, uint64_t v, int k)
 {
     const unsigned cx = (unsigned)(lay->base_code[0] ^ lay->base_code[3]);      /* == code[C] ^ code[G] */
+    if (cx == 3u) {
+        uint64_t x = ~v;
+        x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+        x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+        x = __builtin_bswap64(x);
+        return x >> (64 - 2 * k);
+    }
     uint64_t o = 0;
     for (int i = 0; i < k; i++) { o = (o << 2) | ((v & 3u) ^ cx); v >>= 2; }
     return o;
