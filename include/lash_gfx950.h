@@ -34,6 +34,7 @@ extern "C" {
 #define LASH_ENOMEM  (-4)
 #define LASH_ERANGE  (-6)   /* HyperLogLog estimate <= 5 * 2^p: streaming_algorithms subtracts a bias read from the HLL++
                                empirical tables there; the tables are not in this build, so the case is refused */
+#define LASH_EFORMAT (-7)   /* lash_sketch_files_raw_device: a FASTQ file's line structure broke; see lash_ctx_format_errors() */
 #define LASH_ELIMIT  (-5)   /* a genome has more than 2^32-64 bases in one call (split it and merge images) */
 
 /* -a {hmh,hll,ull}  (main.rs:69-76, 210-246) */
@@ -145,6 +146,16 @@ int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm,
                       const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
                       const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images);
 
+/* The same, without the wait: queues copy-in, kernels and copy-out and returns.  Two staging slots and separate copy streams
+ * inside the context let the H2D copy of the NEXT call and the D2H copy of the PREVIOUS one overlap this call's kernels, so
+ * a host that streams batches runs at the PCIe rate.  seq / rec_off / out_images must stay valid and
+ * untouched until lash_ctx_synchronize(ctx) (or until two further _async calls have been made); give them page-locked memory
+ * (lash_host_alloc_pinned) — copies from pageable memory are staged by the runtime and do not overlap.  genome_rec_off is
+ * consumed before the call returns. */
+int lash_sketch_batch_async(lash_ctx *ctx, const lash_params *prm,
+                            const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                            const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images);
+
 /* Same with seq / rec_off / out_images already in device memory (asynchronous on the ctx stream).
  * The two small per-genome tables stay on the host: genome_byte_off[g] == rec_off[genome_rec_off[g]]. */
 int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm,
@@ -162,6 +173,16 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
                           const uint8_t *file_fmt, uint32_t n_files, uint8_t *out_images);
 int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_raw, const uint64_t *file_off,
                                  const uint8_t *file_fmt, uint32_t n_files, uint8_t *d_out_images);
+/* Malformed FASTQ.  needletail's iterator ends with an error at a record that is not header / sequence / '+' / quality and
+ * lash keeps the records before it (`while let Some(Ok(..))`, utils.rs:457).  The device parse counts lines modulo 4 and
+ * cannot stop mid-file, but it CHECKS: a line in phase 0 must start with '@', one in phase 2 with '+'.  Files that fail:
+ *   lash_sketch_files_raw         (bytes on the host) re-does each such file through a host parse that stops at the first
+ *                                 malformed record and lash_sketch_batch — exact reference semantics, returns LASH_OK;
+ *   lash_sketch_files_raw_device  (bytes only in HBM) leaves their images unreliable; the next lash_ctx_synchronize() returns
+ *                                 LASH_EFORMAT.
+ * Either way the indices of those files (of the last raw call) are available here: returns how many, copies up to `cap`.
+ * The first byte of a file must be '>' or '@' (parse_fastx_file fails otherwise, utils.rs:453): LASH_EINVAL from both. */
+uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap);
 
 /* Two-stage form for callers that keep genomes resident in HBM as 2-bit (0.28 B/base incl. break bitmap):
  * pack once, sketch many times (other k / algo / seed).  The pack stage performs filter_out_n + KSeq::new

@@ -9,7 +9,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx950.so")   # override: A/B builds
 
-OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE, EFORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 HMH, HLL, ULL = 0, 1, 2
 F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT = 1, 2, 4
 FMT_FASTA, FMT_FASTQ = 1, 2
@@ -62,9 +62,11 @@ PROTOTYPES = {
     "lash_ctx_set_layout": (_int, [_vp, _LP]),
     "lash_ctx_get_layout": (_int, [_vp, _LP]),
     "lash_sketch_batch": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),
+    "lash_sketch_batch_async": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),
     "lash_sketch_batch_device": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _vp, _u32, _vp]),
     "lash_sketch_files_raw": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
     "lash_sketch_files_raw_device": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
+    "lash_ctx_format_errors": (_u32, [_vp, _vp, _u32]),
     "lash_pack_device": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
     "lash_sketch_packed_device": (_int, [_vp, _PP, _vp, _vp]),
     "lash_packed_free": (None, [_vp, _vp]),

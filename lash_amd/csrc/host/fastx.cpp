@@ -121,15 +121,16 @@ std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t>
     return "";
 }
 
+// needletail's record rules as lash sees them (utils.rs:453-459; the same rules as the library's host path for files the
+// device parse flags, and as the oracle): the first byte decides FASTA / FASTQ, anything else is "Invalid input file";
+// FASTQ iteration stops at the first record that is not header / sequence / '+' / quality of equal length.
 std::string parse_fastx_buffer(const uint8_t *d, size_t n, RecordBatch &out)
 {
-    size_t i = 0;
-    while (i < n && (d[i] == '\n' || d[i] == '\r')) ++i;            // leading blank lines
-    if (i >= n) return "";                                          // empty file: no records
+    if (n == 0) return "";                                          // empty file: no records
     auto line_end = [&](size_t p) { const void *q = memchr(d + p, '\n', n - p); return q ? (size_t)((const uint8_t *)q - d) : n; };
-    if (d[i] == '>') {
+    size_t i = 0;
+    if (d[0] == '>') {
         while (i < n) {
-            if (d[i] != '>') return "Invalid input file: expected '>' at record start";
             i = line_end(i);                                        // skip the header line
             if (i < n) ++i;
             while (i < n && d[i] != '>') {                          // sequence lines
@@ -142,22 +143,23 @@ std::string parse_fastx_buffer(const uint8_t *d, size_t n, RecordBatch &out)
         }
         return "";
     }
-    if (d[i] == '@') {
+    if (d[0] == '@') {
         while (i < n) {
-            while (i < n && (d[i] == '\n' || d[i] == '\r')) ++i;
-            if (i >= n) break;
-            if (d[i] != '@') return "";                             // malformed tail: records so far stand (utils.rs:458)
-            size_t e = line_end(i);                                 // header
+            if (d[i] != '@') return "";                             // malformed: records so far stand (utils.rs:457)
+            const size_t e = line_end(i);                           // header
             if (e >= n) break;
-            size_t s = e + 1, se = line_end(s), stop = se;          // sequence line
-            while (stop > s && d[stop - 1] == '\r') --stop;
-            if (se >= n) break;                                     // truncated record: skipped
-            size_t p = se + 1;
+            const size_t s = e + 1, se = line_end(s);               // sequence line
+            if (se >= n) break;
+            const size_t p = se + 1;
             if (p >= n || d[p] != '+') return "";
-            size_t pe = line_end(p);                                // '+' line
+            const size_t pe = line_end(p);                          // '+' line
             if (pe >= n) break;
-            size_t qs = pe + 1, qe = line_end(qs);                  // quality line
-            out.seq.insert(out.seq.end(), d + s, d + stop);
+            const size_t qs = pe + 1, qe = line_end(qs);            // quality line
+            size_t sl = se - s, ql = qe - qs;
+            while (sl && d[s + sl - 1] == '\r') --sl;
+            while (ql && d[qs + ql - 1] == '\r') --ql;
+            if (sl != ql) return "";
+            out.seq.insert(out.seq.end(), d + s, d + s + sl);
             out.rec_off.push_back(out.seq.size());
             i = qe < n ? qe + 1 : n;
         }

@@ -176,13 +176,11 @@ std::string read_exact(const std::string &path, uint8_t *dst, uint64_t size)
 }
 
 // needletail sniffs '>' / '@' (SURVEY App. A.5); anything else is "Invalid input file" (utils.rs:453)
+// needletail decides by the FIRST byte of the (decompressed) file and fails on anything else (parse_fastx_file, utils.rs:453)
 int sniff_format(const uint8_t *p, uint64_t n)
 {
-    for (uint64_t i = 0; i < n; ++i) {
-        if (p[i] == '\n' || p[i] == '\r' || p[i] == ' ' || p[i] == '\t') continue;
-        return p[i] == '>' ? LASH_FMT_FASTA : p[i] == '@' ? LASH_FMT_FASTQ : 0;
-    }
-    return 0;
+    if (n == 0) return 0;
+    return p[0] == '>' ? LASH_FMT_FASTA : p[0] == '@' ? LASH_FMT_FASTQ : 0;
 }
 
 // Where to cut a chunk of a large file so that the next chunk starts at a record boundary.
@@ -273,6 +271,9 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
             const int rc = lash_sketch_files_raw(ctx, &prm, buf.p, off, &f, 1, image);
             if (rc != LASH_OK) return std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
             first = false;
+            // a malformed FASTQ record ends needletail's iteration (utils.rs:457): the library kept this chunk's records
+            // before it; nothing after it belongs to the sketch
+            if (lash_ctx_format_errors(ctx, nullptr, 0) != 0) return "";
         }
         const size_t rest = have - cut;                   // cut > have / 2, carry <= 33 bytes: the buffer always drains
         if (rest) memmove(buf.p + carry.size(), buf.p + cut, rest);

@@ -112,8 +112,16 @@ struct lash_ctx {
     std::vector<const lash_packed *> last_packed;   // what the last sketch call consumed (for bases_last / error flags)
     DevBuf items, item_begin, item_kmers, partials, gregs, counter;   // items: [work items | item_begin] of a sketch call
     bool counter_zeroed = false;
-    DevBuf st_seq, st_rec, st_img;       // staging for the host-buffer entry
+    DevBuf st_seq, st_rec, st_img;       // staging for the synchronous host-buffer entries (files_raw, merge, pair statistics)
+    // lash_sketch_batch[_async]: two staging slots and two copy streams, so that the H2D copy of batch n+1 and the D2H copy of
+    // batch n-1 run while the kernels of batch n do (PCIe Gen5 moves 1 B/base: the host-buffer entry is link-bound)
+    struct AsyncSlot { DevBuf seq, rec, img; hipEvent_t h2d = nullptr, kern = nullptr, d2h = nullptr; bool busy = false; };
+    AsyncSlot slot[2];
+    unsigned slot_next = 0;
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
+    std::vector<uint32_t> bad_files;     // lash_ctx_format_errors(): files of the last raw call whose FASTQ structure broke
+    uint32_t raw_files_pending = 0;      // files of a lash_sketch_files_raw_device call whose error flags have not been read yet
     // direct-mode feedback: the dirty-tile count of the last direct call comes back through a pinned word, is looked at
     // (never waited for) by the next call, and switches the optimistic pass off while batches keep turning out dirty
     uint32_t *probe_host = nullptr;      // pinned: [0] = dirty tiles of the last probed call
@@ -375,7 +383,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
     if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
     const size_t lb_bytes = (((size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512) + 15) & ~(size_t)15;
-    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(3 * (size_t)n_genomes + 2) * 4))) return rc;
+    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(4 * (size_t)n_genomes + 2) * 4))) return rc;
     pk->d_dirty = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(pk->lookback.ptr) + lb_bytes);
     if (direct && (rc = reserve(ctx, pk->tile_begin_c, (size_t)(n_genomes + 2) * 4))) return rc;
     if (n_genomes == 0) return LASH_OK;
@@ -404,7 +412,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
         pk->d_nvalid = reinterpret_cast<uint64_t *>(tb + sec[2].off);
         TRACE("pack: tables uploaded");
         if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
-        HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes, stream));
+        HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (formats ? (size_t)(4 * (size_t)n_genomes + 2) * 4 : 0), stream));
         TRACE("pack: memsets queued");
     } else {
         // direct mode: tables go up together with the work items (sketch_from), the pack launch follows the direct pass
@@ -420,6 +428,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pa.brk = static_cast<uint32_t *>(pk->brk.ptr);
     pa.nvalid = pk->d_nvalid;
     pa.code_tab4 = layout_dev(ctx->layout, LASH_HMH).code_tab4;
+    pa.file_err = formats ? pk->d_dirty + 3 * (size_t)n_genomes + 1 : nullptr;      // raw files: FASTQ structure flags
     uint64_t *lb = static_cast<uint64_t *>(pk->lookback.ptr);
     PackV2Args v2{};
     v2.tiles = static_cast<const TileInfo *>(pk->tiles.ptr);
@@ -672,6 +681,7 @@ const char *lash_strerror(int code)
     case LASH_EHIP: return "HIP runtime error";
     case LASH_ENOMEM: return "out of device memory";
     case LASH_ERANGE: return "HyperLogLog estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which this build does not have (sketch with a smaller -p)";
+    case LASH_EFORMAT: return "malformed FASTQ record (the images of the files listed by lash_ctx_format_errors are unreliable)";
     case LASH_ELIMIT: return "a genome exceeds 2^32-64 bytes in one call; split it and merge the images";
     default: return "unknown error";
     }
@@ -825,6 +835,13 @@ void lash_ctx_destroy(lash_ctx *ctx)
             if (e) (void)hipEventDestroy(e);
     if (ctx->probe_host) (void)hipHostFree(ctx->probe_host);
     if (ctx->probe_ev) (void)hipEventDestroy(ctx->probe_ev);
+    for (auto &sl : ctx->slot) {
+        if (sl.busy && sl.d2h) (void)hipEventSynchronize(sl.d2h);
+        for (DevBuf *b : {&sl.seq, &sl.rec, &sl.img}) release(*b);
+        for (hipEvent_t e : {sl.h2d, sl.kern, sl.d2h}) if (e) (void)hipEventDestroy(e);
+    }
+    if (ctx->h2d_stream) (void)hipStreamDestroy(ctx->h2d_stream);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     for (auto &hs : ctx->ring) {
         if (hs.done) (void)hipEventDestroy(hs.done);
         if (hs.ptr) (void)hipHostFree(hs.ptr);
@@ -848,6 +865,19 @@ int lash_ctx_set_stream(lash_ctx *ctx, void *hip_stream)
     return LASH_OK;
 }
 
+static int read_format_errors(lash_ctx *ctx)
+{
+    const uint32_t n = ctx->raw_files_pending;
+    ctx->raw_files_pending = 0;
+    ctx->bad_files.clear();
+    if (!n || !ctx->scratch.d_dirty) return LASH_OK;
+    std::vector<uint32_t> fl(n);
+    HIPCHK(ctx, hipMemcpy(fl.data(), ctx->scratch.d_dirty + 3 * (size_t)n + 1, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t g = 0; g < n; ++g)
+        if (fl[g]) ctx->bad_files.push_back(g);
+    return LASH_OK;
+}
+
 static int check_pack_flag(lash_ctx *ctx, const lash_packed *pk)
 {
     if (!pk || !pk->error_flag) return LASH_OK;
@@ -862,6 +892,13 @@ int lash_ctx_synchronize(lash_ctx *ctx)
     if (!ctx) return LASH_EINVAL;
     (void)hipSetDevice(ctx->device);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &sl : ctx->slot)                                   // results of lash_sketch_batch_async are in the caller's buffers
+        if (sl.busy) { HIPCHK(ctx, hipEventSynchronize(sl.d2h)); sl.busy = false; }
+    if (ctx->raw_files_pending) {                                // FASTQ structure flags of the last raw-file call
+        const int rc = read_format_errors(ctx);
+        if (rc) return rc;
+        if (!ctx->bad_files.empty()) return LASH_EFORMAT;
+    }
     for (const lash_packed *pk : ctx->last_packed) {
         const int rc = check_pack_flag(ctx, pk);
         if (rc) return rc;
@@ -1013,8 +1050,8 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     return rc;
 }
 
-int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
-                      const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images)
+int lash_sketch_batch_async(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                            const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images)
 {
     if (!ctx || !rec_off || !genome_rec_off || (n_genomes && !out_images)) return LASH_EINVAL;
     int rc = lash_params_check(prm);
@@ -1029,23 +1066,49 @@ int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq,
         if (genome_rec_off[g] > n_rec) return LASH_EINVAL;
         gbo[g] = rec_off[genome_rec_off[g]];
     }
+    if (!ctx->h2d_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->h2d_stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+        for (auto &sl : ctx->slot)
+            for (hipEvent_t *e : {&sl.h2d, &sl.kern, &sl.d2h}) HIPCHK(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    lash_ctx::AsyncSlot &sl = ctx->slot[ctx->slot_next++ & 1u];
+    if (sl.busy) { HIPCHK(ctx, hipEventSynchronize(sl.d2h)); sl.busy = false; }   // the batch two calls ago has landed
     const size_t img_bytes = (size_t)n_genomes * image_bytes(ctx->layout, prm->algo, prm->p);
-    if ((rc = reserve(ctx, ctx->st_seq, seq_bytes + 64))) return rc;
-    if ((rc = reserve(ctx, ctx->st_rec, (size_t)(n_rec + 1) * 8))) return rc;
-    if ((rc = reserve(ctx, ctx->st_img, img_bytes + 64))) return rc;
-    if (seq_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->st_seq.ptr, seq, seq_bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->st_rec.ptr, rec_off, (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    auto grow = [&](DevBuf &b, size_t bytes) -> int {            // the slot is idle: no stream uses its buffers
+        if (bytes <= b.cap) return LASH_OK;
+        release(b);
+        const size_t want = bytes + bytes / 8 + 256;
+        HIPCHK(ctx, hipMalloc(&b.ptr, want));
+        b.cap = want;
+        return LASH_OK;
+    };
+    if ((rc = grow(sl.seq, seq_bytes + 64))) return rc;
+    if ((rc = grow(sl.rec, (size_t)(n_rec + 1) * 8))) return rc;
+    if ((rc = grow(sl.img, img_bytes + 64))) return rc;
+    if (seq_bytes) HIPCHK(ctx, hipMemcpyAsync(sl.seq.ptr, seq, seq_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
+    HIPCHK(ctx, hipMemcpyAsync(sl.rec.ptr, rec_off, (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, ctx->h2d_stream));
     if ((prm->flags & LASH_F_ACCUMULATE) && img_bytes)
-        HIPCHK(ctx, hipMemcpyAsync(ctx->st_img.ptr, out_images, img_bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = lash_sketch_batch_device(ctx, prm, static_cast<const uint8_t *>(ctx->st_seq.ptr),
-                                  static_cast<const uint64_t *>(ctx->st_rec.ptr), n_rec, genome_rec_off, gbo.data(),
-                                  n_genomes, static_cast<uint8_t *>(ctx->st_img.ptr));
+        HIPCHK(ctx, hipMemcpyAsync(sl.img.ptr, out_images, img_bytes, hipMemcpyHostToDevice, ctx->h2d_stream));
+    HIPCHK(ctx, hipEventRecord(sl.h2d, ctx->h2d_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, sl.h2d, 0));
+    rc = lash_sketch_batch_device(ctx, prm, static_cast<const uint8_t *>(sl.seq.ptr), static_cast<const uint64_t *>(sl.rec.ptr), n_rec,
+                                  genome_rec_off, gbo.data(), n_genomes, static_cast<uint8_t *>(sl.img.ptr));
     if (rc) return rc;
-    if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    for (const lash_packed *pk : ctx->last_packed)
-        if ((rc = check_pack_flag(ctx, pk))) return rc;
+    HIPCHK(ctx, hipEventRecord(sl.kern, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->d2h_stream, sl.kern, 0));
+    if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, sl.img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->d2h_stream));
+    HIPCHK(ctx, hipEventRecord(sl.d2h, ctx->d2h_stream));
+    sl.busy = true;
     return LASH_OK;
+}
+
+int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
+                      const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images)
+{
+    const int rc = lash_sketch_batch_async(ctx, prm, seq, rec_off, n_rec, genome_rec_off, n_genomes, out_images);
+    if (rc) return rc;
+    return lash_ctx_synchronize(ctx);
 }
 
 int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_raw, const uint64_t *file_off,
@@ -1055,6 +1118,12 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
     int rc = lash_params_check(prm);
     if (rc) return rc;
     (void)hipSetDevice(ctx->device);
+    if (ctx->raw_files_pending) {                                // flags of an earlier raw call nobody has looked at yet
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = read_format_errors(ctx))) return rc;
+        if (!ctx->bad_files.empty()) return LASH_EFORMAT;
+    }
+    ctx->bad_files.clear();
     ctx->last_packed.clear();
     ctx->last.calls += 1;
     if (n_files == 0) return LASH_OK;
@@ -1065,7 +1134,59 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
     if (rc) return rc;
     rc = sketch_from(ctx, prm, &ctx->scratch, d_out_images, ev);
     ctx->cur_ev = nullptr;
+    if (rc == LASH_OK) ctx->raw_files_pending = n_files;
     return rc;
+}
+
+uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap)
+{
+    if (!ctx) return 0;
+    const uint32_t n = (uint32_t)ctx->bad_files.size();
+    for (uint32_t i = 0; i < n && i < cap && file_index; ++i) file_index[i] = ctx->bad_files[i];
+    return n;
+}
+
+// needletail's record rules for uncompressed input as lash uses it (utils.rs:453-459), on the host: the exact
+// path for the rare file the device parse flags.  FASTA: '>' header line, sequence lines up to the next line that starts with
+// '>', line ends stripped.  FASTQ: '@' header, sequence line, '+' line, quality line of the same length; iteration STOPS at
+// the first record that breaks this (the records before it stand).
+static void parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off)
+{
+    auto line_end = [&](size_t p) { const void *q = memchr(d + p, '\n', n - p); return q ? (size_t)((const uint8_t *)q - d) : n; };
+    size_t i = 0;
+    if (n && d[0] == '>') {
+        while (i < n) {
+            i = line_end(i);
+            if (i < n) ++i;
+            while (i < n && d[i] != '>') {
+                size_t e = line_end(i), stop = e;
+                while (stop > i && d[stop - 1] == '\r') --stop;
+                seq.insert(seq.end(), d + i, d + stop);
+                i = e < n ? e + 1 : n;
+            }
+            rec_off.push_back(seq.size());
+        }
+    } else {
+        while (i < n) {
+            if (d[i] != '@') break;
+            const size_t e = line_end(i);
+            if (e >= n) break;
+            const size_t s = e + 1, se = line_end(s);
+            if (se >= n) break;
+            const size_t pl = se + 1;
+            if (pl >= n || d[pl] != '+') break;
+            const size_t pe = line_end(pl);
+            if (pe >= n) break;
+            const size_t ql = pe + 1, qe = line_end(ql);
+            size_t sl = se - s, qn = qe - ql;
+            while (sl && d[s + sl - 1] == '\r') --sl;
+            while (qn && d[ql + qn - 1] == '\r') --qn;
+            if (sl != qn) break;
+            seq.insert(seq.end(), d + s, d + s + sl);
+            rec_off.push_back(seq.size());
+            i = qe < n ? qe + 1 : n;
+        }
+    }
 }
 
 int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *raw, const uint64_t *file_off,
@@ -1077,7 +1198,7 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     (void)hipSetDevice(ctx->device);
     const uint64_t bytes = file_off[n_files];
     if (bytes && !raw) return LASH_EINVAL;
-    const size_t img_bytes = (size_t)n_files * image_bytes(ctx->layout, prm->algo, prm->p);
+    const size_t ib = image_bytes(ctx->layout, prm->algo, prm->p), img_bytes = (size_t)n_files * ib;
     if ((rc = reserve(ctx, ctx->st_seq, bytes + 64))) return rc;
     if ((rc = reserve(ctx, ctx->st_img, img_bytes + 64))) return rc;
     if (bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->st_seq.ptr, raw, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1086,10 +1207,37 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     rc = lash_sketch_files_raw_device(ctx, prm, static_cast<const uint8_t *>(ctx->st_seq.ptr), file_off, file_fmt, n_files,
                                       static_cast<uint8_t *>(ctx->st_img.ptr));
     if (rc) return rc;
-    if (img_bytes) HIPCHK(ctx, hipMemcpyAsync(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    // files whose FASTQ structure broke are re-done below from the caller's copy of the images (accumulate) or from scratch:
+    // their device images are not copied back over out_images
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (const lash_packed *pk : ctx->last_packed)
         if ((rc = check_pack_flag(ctx, pk))) return rc;
+    if ((rc = read_format_errors(ctx))) return rc;
+    const std::vector<uint32_t> bad = ctx->bad_files;
+    if (bad.empty()) {
+        if (img_bytes) HIPCHK(ctx, hipMemcpy(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost));
+        return LASH_OK;
+    }
+    std::vector<uint8_t> is_bad(n_files, 0);
+    for (uint32_t g : bad) is_bad[g] = 1;
+    for (uint32_t g = 0; g < n_files;) {                          // copy back the runs of good images
+        if (is_bad[g]) { ++g; continue; }
+        uint32_t e = g;
+        while (e < n_files && !is_bad[e]) ++e;
+        HIPCHK(ctx, hipMemcpy(out_images + (size_t)g * ib, static_cast<uint8_t *>(ctx->st_img.ptr) + (size_t)g * ib, (size_t)(e - g) * ib,
+                              hipMemcpyDeviceToHost));
+        g = e;
+    }
+    for (uint32_t g : bad) {                                       // exact reference semantics for the malformed ones
+        std::vector<uint8_t> seq;
+        std::vector<uint64_t> rec_off(1, 0);
+        parse_fastx_strict(raw + file_off[g], (size_t)(file_off[g + 1] - file_off[g]), seq, rec_off);
+        const uint64_t goff[2] = {0, (uint64_t)rec_off.size() - 1};
+        const uint8_t dummy = 0;
+        rc = lash_sketch_batch(ctx, prm, seq.empty() ? &dummy : seq.data(), rec_off.data(), rec_off.size() - 1, goff, 1, out_images + (size_t)g * ib);
+        if (rc) return rc;
+    }
+    ctx->bad_files = bad;                                          // still reported (the host may want to stop streaming this file)
     return LASH_OK;
 }
 

@@ -95,6 +95,7 @@ struct PackArgs {
     uint32_t         *brk;        // zeroed before the launch
     uint64_t         *nvalid;
     uint32_t          code_tab4;  // LayoutDev::code_tab4
+    uint32_t         *file_err;   // NULL, or [n_genomes] zeroed: raw FASTQ files whose line structure broke (pack_kernels.hip)
 };
 // one 16 KiB tile of one genome (filled by pack_map_kernel)
 struct TileInfo {

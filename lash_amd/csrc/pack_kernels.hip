@@ -255,6 +255,26 @@ __device__ __forceinline__ void fastq_chunk(uint32_t nl, uint32_t in_phase, uint
     if (ph == 1u) seqmask |= 0xFFFFu & ~((1u << prev) - 1u);
 }
 
+// FASTQ structure check (needletail stops iterating at a record that is not header / sequence / '+' / quality, and lash keeps
+// what came before: utils.rs:457): a line in phase 0 must start with '@', one in phase 2 with '+'.  Returns true when one of
+// this lane's 16 bytes starts such a line with another character.  (Quality lines may start with anything, '@' included:
+// that is why the phase, not the character, says which line this is.)
+__device__ __forceinline__ bool fastq_bad_line_start(uint32_t nl, uint32_t at, uint32_t plus, uint32_t keep, uint32_t in_phase,
+                                                     int start_pos)
+{
+    uint32_t ph = in_phase, bad = 0;
+    if (start_pos >= 0 && start_pos < 16 && ((keep >> start_pos) & 1u))
+        bad |= (ph == 0u && !((at >> start_pos) & 1u)) || (ph == 2u && !((plus >> start_pos) & 1u));
+    uint32_t S = nl;
+    while (S) {
+        const uint32_t nx = (uint32_t)__builtin_ctz(S) + 1u;
+        S &= S - 1;
+        ph = (ph + 1u) & 3u;
+        if (nx < 16u && ((keep >> nx) & 1u)) bad |= (ph == 0u && !((at >> nx) & 1u)) || (ph == 2u && !((plus >> nx) & 1u));
+    }
+    return bad != 0u;
+}
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -350,10 +370,16 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
             if constexpr (RAW) if (raw) {
                 const bool fasta = (ti.flags & TF_FASTA) != 0;                                 // uniform
                 uint32_t nl[P2_CHUNKS], gt[P2_CHUNKS], lane_in[P2_CHUNKS];
+                uint32_t at_m[P2_CHUNKS], plus_m[P2_CHUNKS], q_last[P2_CHUNKS];   // FASTQ structure check (a.file_err)
                 uint32_t unresolved = 0;                       // bit c: lane_in[c] still needs the group / tile state
 #pragma unroll
                 for (int c = 0; c < P2_CHUNKS; ++c) {
                     nl[c] = eqmask16(q[c], 0x0A0A0A0Au) & keep[c];
+                    if (!fasta && a.file_err) {
+                        at_m[c] = eqmask16(q[c], 0x40404040u);
+                        plus_m[c] = eqmask16(q[c], 0x2B2B2B2Bu);
+                        q_last[c] = q[c].w >> 24;
+                    } else { at_m[c] = 0; plus_m[c] = 0; q_last[c] = 0; }
                     uint32_t g = fasta ? (eqmask16(q[c], 0x3E3E3E3Eu) & keep[c]) : 0u;
                     if (g) {
                         // needletail finds the next record at "\n>": a '>' in the middle of a line is sequence text (and is
@@ -473,6 +499,21 @@ __global__ void __launch_bounds__(P2_THREADS) pack_lookback_kernel(PackArgs a, P
                     } else {
                         uint32_t before = tile_in;
                         for (int k = 0; k < g; ++k) before += grp[k];
+                        if (a.file_err) {
+                            // which byte of this chunk, if any, starts a line whose phase is the chunk's incoming phase: the
+                            // file's first byte (first tile: offset rel_lo of chunk 0), else byte 0 when a newline precedes it
+                            // (the lane before holds that byte; a wave's first lane reads it from memory)
+                            const int32_t cs = (c * P2_THREADS + (int)tid) * 16;
+                            uint32_t prev = __shfl_up(q_last[c], 1, 64);
+                            int start_pos = -1;
+                            if ((ti.flags & TF_FIRST) && cs == 0) start_pos = ti.rel_lo;
+                            else if (cs < ti.rel_hi) {
+                                if (lane == 0) prev = a.seq[ti.toff + cs - 1];
+                                if (prev == 0x0Au) start_pos = 0;
+                            }
+                            if (fastq_bad_line_start(nl[c], at_m[c], plus_m[c], keep[c], (in + before) & 3u, start_pos))
+                                atomicOr(a.file_err + ti.g, 1u);
+                        }
                         uint32_t seqmask, rs;
                         fastq_chunk(nl[c], (in + before) & 3u, seqmask, rs);
                         keep[c] &= seqmask;

@@ -52,6 +52,25 @@ def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=No
     return out
 
 
+class PinnedArray:
+    """numpy view of page-locked host memory from lash_host_alloc_pinned (freed with the object)"""
+
+    def __init__(self, nbytes, dtype=np.uint8):
+        self._lib = _lib.load()
+        self._p = self._lib.lash_host_alloc_pinned(int(max(nbytes, 1)))
+        if not self._p:
+            raise MemoryError("lash_host_alloc_pinned(%d)" % nbytes)
+        self.array = np.ctypeslib.as_array((C.c_uint8 * int(max(nbytes, 1))).from_address(self._p)).view(dtype)
+
+    def __del__(self):
+        try:
+            if self._p:
+                self._lib.lash_host_free_pinned(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
 def ull_estimate(registers, p, estimator="fgra"):
     """FGRA / ML distinct-count estimate of ONE UltraLogLog sketch from its 2^p register bytes (host only; utils.rs:213-217)."""
     regs = np.ascontiguousarray(registers, dtype=np.uint8)
@@ -230,6 +249,17 @@ class Context:
                                                 goff.ctypes.data, n_g, out.ctypes.data if out.size else None))
         return out
 
+    def sketch_batch_async(self, algo, k, p, seed, seq, rec_off, genome_rec_off, out, flags=0):
+        """lash_sketch_batch_async: queue one batch (host buffers in, images into `out`) and return; synchronize() before
+        reading `out` or touching seq / rec_off.  Pass page-locked arrays (pinned_array) for the copies to overlap."""
+        prm = self._params(algo, k, p, seed, flags)
+        assert seq.dtype == np.uint8 and rec_off.dtype == np.uint64 and out.dtype == np.uint8
+        assert seq.flags.c_contiguous and rec_off.flags.c_contiguous and out.flags.c_contiguous
+        goff = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
+        self._keep_async = getattr(self, "_keep_async", [])[-4:] + [(seq, rec_off, out)]
+        self._check(self._lib.lash_sketch_batch_async(self._h, C.byref(prm), seq.ctypes.data if seq.size else None, rec_off.ctypes.data,
+                                                      len(rec_off) - 1, goff.ctypes.data, len(goff) - 1, out.ctypes.data if out.size else None))
+
     def sketch_files_raw(self, algo, k, p, seed, files_bytes, flags=0):
         """files_bytes: list of uncompressed FASTA / FASTQ file contents (bytes).  The parse runs on the GPU.
         Returns images[n_files, image_bytes]."""
@@ -239,13 +269,23 @@ class Context:
         off = np.zeros(len(files_bytes) + 1, dtype=np.uint64)
         if files_bytes:
             off[1:] = np.cumsum([len(f) for f in files_bytes], dtype=np.uint64)
-        fmt = np.array([_lib.FMT_FASTQ if f.lstrip(b"\r\n")[:1] == b"@" else _lib.FMT_FASTA for f in files_bytes], dtype=np.uint8)
+        for f in files_bytes:                                   # parse_fastx_file(..).expect("Invalid input file"), utils.rs:453
+            if f[:1] not in (b">", b"@"):
+                raise LashError(_lib.EINVAL, "Invalid input file: the first byte must be '>' (FASTA) or '@' (FASTQ)")
+        fmt = np.array([_lib.FMT_FASTQ if f[:1] == b"@" else _lib.FMT_FASTA for f in files_bytes], dtype=np.uint8)
         ib = self.image_bytes(prm.algo, prm.p)
         out = np.zeros((len(files_bytes), ib), dtype=np.uint8)
         self._check(self._lib.lash_sketch_files_raw(self._h, C.byref(prm), raw.ctypes.data if raw.size else None,
                                                     off.ctypes.data, fmt.ctypes.data if fmt.size else None,
                                                     len(files_bytes), out.ctypes.data if out.size else None))
         return out
+
+    def format_errors(self):
+        """indices of the files of the last raw call whose FASTQ structure broke (lash_ctx_format_errors)"""
+        n = int(self._lib.lash_ctx_format_errors(self._h, None, 0))
+        idx = (C.c_uint32 * max(n, 1))()
+        self._lib.lash_ctx_format_errors(self._h, idx, n)
+        return [int(idx[i]) for i in range(n)]
 
     def sketch_batch_device(self, algo, k, p, seed, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, d_out,
                             flags=0):

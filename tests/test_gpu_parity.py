@@ -326,3 +326,37 @@ def test_one_input_with_very_many_slices(ctx, an, k, p):
     assert tm["kmers"] == (len(reads) - 1) * (150 - k + 1) + sum(len(O.record_kmers(r, k)) for r in (reads[1000], small[0]))
     assert_same(got, want, an)
     assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, an + " pack-first")
+
+
+def test_async_host_entry_overlaps_and_matches(ctx):
+    """lash_sketch_batch_async: several batches in flight over the context's two staging slots, page-locked and pageable
+    buffers, accumulate included; after lash_ctx_synchronize every image equals the oracle's."""
+    import lash_amd
+    rng = random.Random(99)
+    batches = []
+    for b in range(5):
+        gs = messy_genomes(rng, 6, max_len=20_000)
+        seq, off, goff = lash_amd.records_to_arrays(gs)
+        batches.append((seq, off, goff))
+    for an, k, p in (("hmh", 16, 0), ("ull", 21, 12)):
+        ib = lash_amd.image_bytes(an, p)
+        keep, outs = [], []
+        for seq, off, goff in batches:
+            ps, po = lash_amd.PinnedArray(max(len(seq), 1)), lash_amd.PinnedArray(len(off) * 8, np.uint64)
+            ps.array[:len(seq)] = seq
+            po.array[:] = off
+            out = lash_amd.PinnedArray(6 * ib)
+            keep.append((ps, po, out))
+            ctx.sketch_batch_async(an, k, p, 42, ps.array[:len(seq)], po.array, goff, out.array)
+            outs.append(out)
+        ctx.synchronize()
+        for (seq, off, goff), out in zip(batches, outs):
+            assert_same(out.array.reshape(6, ib), oracle_images(ALGO[an], k, p, 42, seq, off, goff), "async " + an)
+        # pageable memory + accumulate: batch 1's records unioned into batch 0's images
+        acc = outs[0].array.reshape(6, ib).copy()
+        s1, o1, g1 = batches[1]
+        ctx.sketch_batch_async(an, k, p, 42, s1, o1, g1, acc.reshape(-1), flags=lash_amd.F_ACCUMULATE)
+        ctx.synchronize()
+        s0, o0, g0 = batches[0]
+        want = O.merge_images(ALGO[an], p, oracle_images(ALGO[an], k, p, 42, s0, o0, g0)[0], oracle_images(ALGO[an], k, p, 42, s1, o1, g1)[0])
+        assert np.array_equal(acc[0], want)

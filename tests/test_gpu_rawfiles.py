@@ -103,3 +103,74 @@ def test_header_only_where_a_line_opens(ctx, tmp_path):
     assert np.array_equal(got, oracle_for_files(tmp_path, files, "hmh", 16, 0))
     got = ctx.sketch_files_raw("ull", 4, 8, 42, files)
     assert np.array_equal(got, oracle_for_files(tmp_path, files, "ull", 4, 8))
+
+
+def _fastq(reads, qual=b"I"):
+    return b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, qual * len(r)) for i, r in enumerate(reads))
+
+
+def test_malformed_fastq_is_detected_on_the_device_and_redone_exactly(ctx):
+    """the device FASTQ parse is "newlines so far mod 4"; a broken record would mis-phase everything after it and
+    quality lines (ACGT are valid Phred characters) would be hashed as sequence.  Now: a line in phase 0 that does not start
+    with '@', or one in phase 2 that does not start with '+', flags the file; the host-buffer entry re-does a flagged file
+    with needletail's rule — iteration stops at the malformed record, what came before stands (utils.rs:457) — and the
+    device-buffer entry reports LASH_EFORMAT.  Well-formed files in the same call are untouched."""
+    import lash_amd
+    import torch
+    rng = random.Random(5)
+    reads = ["".join(rng.choice("ACGT") for _ in range(rng.randint(30, 300))).encode() for _ in range(400)]
+    good = _fastq(reads, b"A")                                   # qualities that look like sequence
+    cases = {
+        "blank line inside": _fastq(reads[:100], b"C") + b"\n" + _fastq(reads[100:], b"G"),
+        "missing plus": _fastq(reads[:57], b"T") + b"@x\nACGTACGTACGTACGTACGTACGT\nACGTACGTACGTACGTACGTACGT\n" + _fastq(reads[57:], b"A"),
+        "header without @": _fastq(reads[:200]) + b"r200\n" + reads[200] + b"\n+\n" + b"I" * len(reads[200]) + b"\n" + _fastq(reads[201:]),
+        "first record broken": b"@a\nACGTACGTACGTACGTACGTTTGA\nIIIIIIIIIIIIIIIIIIIIIIII\n" + good,
+        "trailing blank lines": good + b"\n\n",
+        "quality starts with @ and +": _fastq(reads[:50], b"@") + _fastq(reads[50:120], b"+") + _fastq(reads[120:]),   # well-formed!
+        "crlf": good.replace(b"\n", b"\r\n"),                       # well-formed
+    }
+    names = list(cases)
+    files = [cases[n] for n in names] + [good]
+    for an, k, p in (("hmh", 16, 0), ("ull", 21, 10)):
+        want = O.sketch_files(ALGO[an], k, p, 42, files, threads=4)     # the oracle's parse stops at the first malformed record
+        got = ctx.sketch_files_raw(an, k, p, 42, files)
+        bad = ctx.format_errors()
+        for i, n in enumerate(names + ["good"]):
+            assert np.array_equal(got[i], want[i]), (an, n)
+        flagged = {names[i] for i in bad if i < len(names)}
+        assert flagged == {"blank line inside", "missing plus", "header without @", "first record broken", "trailing blank lines"}, flagged
+        # accumulate into existing images takes the same path
+        acc = ctx.sketch_files_raw(an, k, p, 42, [good] * len(files))
+        prm_files = files
+        raw = np.frombuffer(b"".join(prm_files), np.uint8)
+        off = np.cumsum([0] + [len(f) for f in prm_files]).astype(np.uint64)
+        fmt = np.full(len(prm_files), 2, np.uint8)
+        import ctypes as C
+        from lash_amd import _lib
+        prm = _lib.Params(lash_amd.ALGOS[an], k, p, lash_amd.F_ACCUMULATE, 42)
+        rc = _lib.load().lash_sketch_files_raw(ctx._h, C.byref(prm), raw.ctypes.data, off.ctypes.data, fmt.ctypes.data, len(prm_files), acc.ctypes.data)
+        assert rc == 0
+        for i in range(len(files)):
+            assert np.array_equal(acc[i], O.merge_images(ALGO[an], p, want[-1], want[i])), (an, i)
+    # device-buffer entry: no host copy to fall back to -> LASH_EFORMAT at synchronize, indices reported
+    d_raw = torch.from_numpy(np.frombuffer(b"".join(files), np.uint8).copy()).cuda()
+    off = np.cumsum([0] + [len(f) for f in files]).astype(np.uint64)
+    fmt = np.full(len(files), 2, np.uint8)
+    d_img = torch.zeros(len(files) * lash_amd.image_bytes("hmh"), dtype=torch.uint8, device="cuda")
+    import ctypes as C
+    from lash_amd import _lib
+    prm = _lib.Params(0, 16, 0, 0, 42)
+    rc = _lib.load().lash_sketch_files_raw_device(ctx._h, C.byref(prm), d_raw.data_ptr(), off.ctypes.data, fmt.ctypes.data, len(files), d_img.data_ptr())
+    assert rc == 0
+    with pytest.raises(lash_amd.LashError) as e:
+        ctx.synchronize()
+    assert e.value.code == _lib.EFORMAT
+    assert {names[i] for i in ctx.format_errors()} == {"blank line inside", "missing plus", "header without @", "first record broken", "trailing blank lines"}
+    img = d_img.cpu().numpy().reshape(len(files), -1)
+    want = O.sketch_files(O.HMH, 16, 0, 42, files, threads=4)
+    for i, n in enumerate(names + ["good"]):
+        if i not in ctx.format_errors():
+            assert np.array_equal(img[i], want[i]), n              # the well-formed ones are right
+    ctx.synchronize()                                              # the error was consumed
+    with pytest.raises(lash_amd.LashError):                        # first byte rule (parse_fastx_file fails, utils.rs:453)
+        ctx.sketch_files_raw("hmh", 16, 0, 42, [b"\n" + good])
