@@ -320,8 +320,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # LASH_BENCH_BACKEND=gloo: a launch-logic dry run on fewer GPUs than ranks (ranks share devices, the barrier / max-time
+        # reduction run on host tensors).  Never a scaling measurement; the JSON says so.
+        backend = os.environ.get("LASH_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
@@ -409,7 +417,7 @@ def main():
     tm = ctx.timing()
     ctx.enable_timing(False)
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -466,7 +474,7 @@ def main():
             "metric": "k-mers/s sketched (%s, k=%d)" % (algo, k), "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
-            "data": "synthetic",
+            "data": "synthetic" if not dist or dist.get_backend() == "nccl" else "synthetic (LAUNCH DRY RUN: ranks share GPUs over gloo, not a scaling measurement)",
             "config": {"workload": ("ONE sketch of %d synthetic 150-bp records (%d bp) per GPU" % (n_rec, L) if reads else
                                     "%d synthetic %d-bp genomes per GPU%s" % (G, L, {"none": "", "nrun": ", one 100-byte N run in each",
                                                                                      "lower": ", every other 10 kb block lower-case"}[args.dirty]))

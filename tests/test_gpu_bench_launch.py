@@ -1,0 +1,35 @@
+"""bench.py's multi-rank launch logic on real hardware ("--gpus N has never executed with N > 1 anywhere"):
+the driver's exact command line with N = 2, as a dry run on ONE GPU — LASH_BENCH_BACKEND=gloo lets the two ranks share
+device 0, the barrier and the max-over-ranks time reduction run on host tensors.  Checks rank / genome-id arithmetic, the
+census of both ranks, the JSON contract.  It is not a scaling measurement and the JSON line says so."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_dry_run_on_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LASH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--genomes", "40"],
+                       cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["unit"] == "k-mers/s"
+    assert j["cpu_baseline"] is None                            # N > 1: no CPU leg
+    assert "DRY RUN" in j["data"]
+    kmers = 2 * 40 * (5_000_000 - 16 + 1) * 3                    # both ranks' genomes, every step
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 * 3 / kmers - 1) < 1e-6
+    assert j["roofline"]["frac"] > 0 and j["roofline_valu"]["bound"] == "valu-issue"
