@@ -49,6 +49,7 @@ def gpu_pair_stats(ctx, algo, p, estimator, ref, qry):
     import torch
     nr, nq, dev = ref.shape[0], qry.shape[0], ref.device
     ref, qry = ref.contiguous(), qry.contiguous()
+    torch.cuda.current_stream(dev).synchronize()              # the images come from torch's stream (the all-gather); the context runs on its own
     if a == _lib.HMH:
         c = torch.empty((nr, nq), dtype=torch.int32, device=dev)
         n = torch.empty_like(c)
