@@ -180,6 +180,8 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
  *                                 malformed record and lash_sketch_batch — exact reference semantics, returns LASH_OK;
  *   lash_sketch_files_raw_device  (bytes only in HBM) leaves their images unreliable; the next lash_ctx_synchronize() returns
  *                                 LASH_EFORMAT.
+ * Not detected: a quality line whose LENGTH differs from its sequence line's (needletail's other FASTQ error).  The 4-line
+ * structure is intact then, nothing is mis-phased, and such a file is sketched to its end where the reference stops.
  * Either way the indices of those files (of the last raw call) are available here: returns how many, copies up to `cap`.
  * The first byte of a file must be '>' or '@' (parse_fastx_file fails otherwise, utils.rs:453): LASH_EINVAL from both. */
 uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap);

@@ -31,7 +31,7 @@ def main():
             paths, recs = [], []
             for i in range(rng.randint(1, 40)):
                 data = b""
-                while data.lstrip(b"\r\n")[:1] not in (b">", b"@"):
+                while data[:1] not in (b">", b"@"):
                     data = fasta_file(rng) if rng.random() < 0.6 else fastq_file(rng)
                 if rng.random() < 0.2:                       # larger files -> several batches at --batch-mb 1
                     if not data.endswith(b"\n"):

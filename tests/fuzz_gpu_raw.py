@@ -32,7 +32,7 @@ def seq_bytes(rng, n):
 
 def fasta_file(rng):
     nl = rng.choice([b"\n", b"\n", b"\r\n"])
-    out = [b"\n" * rng.choice([0, 0, 1])]
+    out = []                                                # (the first byte of a file must be '>' or '@': needletail)
     for r in range(rng.randint(0, 12)):
         hdr = b">" + rng.choice([b"r%d" % r, b"r%d ACGT ACGT description with > inside" % r, b"", b"x" * rng.choice([5, 300, 20000])])
         out.append(hdr + nl)
@@ -58,6 +58,18 @@ def fastq_file(rng):
         s = seq_bytes(rng, rng.choice([0, 36, 100, 150, 151, rng.randint(1, 400)]))
         q = bytes(rng.choice(b"@+>IIIIFF#ACGT") for _ in range(len(s)))
         out.append(b"@" + rng.choice([b"r%d" % r, b"r%d/1 @+ACGT" % r]) + nl + s + nl + b"+" + rng.choice([b"", b"r%d" % r]) + nl + q + nl)
+    if out and rng.random() < 0.25:                         # malformed: needletail stops there, the records before it stand
+        i = rng.randrange(len(out))
+        kind = rng.random()
+        if kind < 0.3:
+            out.insert(i, nl)                               # blank line between records
+        elif kind < 0.6:
+            out[i] = out[i].replace(nl + b"+", nl + b"-", 1)   # the '+' line does not start with '+'
+        else:
+            out[i] = b"r" + out[i][1:]                      # header without '@'
+        # (a quality line whose LENGTH differs from its sequence line's — needletail's other FASTQ error — keeps the 4-line
+        # structure intact; the device parse does not detect it and sketches the file to its end: documented divergence,
+        # tests/test_gpu_rawfiles.py)
     data = b"".join(out)
     if rng.random() < 0.3 and data.endswith(nl) and out and len(s):
         data = data[:-len(nl)]                              # no newline after the last quality line (if it is not empty:
@@ -75,15 +87,16 @@ def main():
             k = rng.choice([rng.randint(1, 32), 16, 21])
             p = 0 if an == "hmh" else rng.randint(4, 14)
             files = [fasta_file(rng) if rng.random() < 0.6 else fastq_file(rng) for _ in range(rng.randint(1, 6))]
-            files = [f for f in files if f.lstrip(b"\r\n")[:1] in (b">", b"@")] or [b">only\nACGT\n"]
+            files = [f for f in files if f[:1] in (b">", b"@")] or [b">only\nACGT\n"]
             got = ctx.sketch_files_raw(an, k, p, 42, files)
+            want = O.sketch_files(ALGO[an], k, p, 42, files, threads=8)   # the oracle's own needletail-like parse (stops at a malformed record)
             gs = []
             for i, f in enumerate(files):
                 path = os.path.join(td, "f%d" % i)
                 open(path, "wb").write(f)
-                gs.append(H.read_fastx(path))               # the C++ host reader (needletail semantics)
+                gs.append(H.read_fastx(path))               # the C++ host reader must agree with it
             seq, off, goff = lash_amd.records_to_arrays(gs)
-            want = O.sketch_genomes(ALGO[an], k, p, 42, seq, off, goff, threads=8)
+            assert np.array_equal(want, O.sketch_genomes(ALGO[an], k, p, 42, seq, off, goff, threads=8)), "host reader != oracle parse (it=%d)" % it
             if not np.array_equal(got, want):
                 bad = sorted({int(r) for r in np.argwhere(got != want)[:, 0]})
                 for b in bad:

@@ -172,5 +172,14 @@ def test_malformed_fastq_is_detected_on_the_device_and_redone_exactly(ctx):
         if i not in ctx.format_errors():
             assert np.array_equal(img[i], want[i]), n              # the well-formed ones are right
     ctx.synchronize()                                              # the error was consumed
+    # DOCUMENTED DIVERGENCE: a quality line whose length differs from its sequence line's is needletail's other FASTQ error
+    # (the reference stops there).  The 4-line structure is intact, nothing is mis-phased, and the device parse — which checks
+    # line starts, not line lengths — sketches the file to its end: the image equals that of the repaired file.
+    short_q = _fastq(reads[:10]) + b"@x\n" + reads[10] + b"\n+\n" + b"I" * (len(reads[10]) - 1) + b"\n" + _fastq(reads[11:])
+    repaired = _fastq(reads[:10]) + b"@x\n" + reads[10] + b"\n+\n" + b"I" * len(reads[10]) + b"\n" + _fastq(reads[11:])
+    got = ctx.sketch_files_raw("hmh", 16, 0, 42, [short_q])
+    assert ctx.format_errors() == []
+    assert np.array_equal(got, O.sketch_files(O.HMH, 16, 0, 42, [repaired]))
+    assert not np.array_equal(got, O.sketch_files(O.HMH, 16, 0, 42, [short_q]))     # the oracle (needletail's rule) stops at record 10
     with pytest.raises(lash_amd.LashError):                        # first byte rule (parse_fastx_file fails, utils.rs:453)
         ctx.sketch_files_raw("hmh", 16, 0, 42, [b"\n" + good])
