@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "codec_dl.hpp"
+#include "pgzip.hpp"
 #include "zstd_dl.hpp"
 
 namespace lashhost {
@@ -15,6 +16,8 @@ struct ByteStream::Impl {
     int kind = 0;               // 0 plain, 1 gzip, 2 zstd, 3 bzip2 / xz
     FILE *f = nullptr;
     gzFile g = nullptr;
+    ParallelGzip pg;                // kind 4: multi-member aware, several inflate threads (set_threads() > 1)
+    int threads = 1;
     ZstdReader z;
     DlDecoder d;
 };
@@ -27,12 +30,19 @@ ByteStream::~ByteStream()
     delete impl_;
 }
 
+void ByteStream::set_threads(int t) { impl_->threads = t < 1 ? 1 : t; }
+
 std::string ByteStream::open(const std::string &path)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return "Invalid input file: cannot open " + path;
     unsigned char m[6] = {0, 0, 0, 0, 0, 0};
     const size_t got = fread(m, 1, 6, f);
+    if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b && impl_->threads > 1) {
+        fclose(f);
+        impl_->kind = 4;
+        return impl_->pg.open(path, impl_->threads);
+    }
     if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) {
         fclose(f);
         impl_->g = gzopen(path.c_str(), "rb");
@@ -57,6 +67,7 @@ long ByteStream::read(uint8_t *dst, size_t n, std::string &err)
     if (impl_->kind == 0) return (long)fread(dst, 1, n, impl_->f);
     if (impl_->kind == 2) return impl_->z.read(dst, n, err);
     if (impl_->kind == 3) return impl_->d.read(dst, n, err);
+    if (impl_->kind == 4) return impl_->pg.read(dst, n, err);
     size_t done = 0;
     while (done < n) {
         const int r = gzread(impl_->g, dst + done, (unsigned)std::min<size_t>(n - done, 1u << 30));

@@ -32,6 +32,8 @@ class ByteStream {
 public:
     ByteStream();
     ~ByteStream();
+    // > 1: a gzip file is read by pgzip.hpp's multi-member reader with that many inflate threads (call before open())
+    void set_threads(int threads);
     std::string open(const std::string &path);
     // reads up to n bytes; returns the count (0 = end of data) or -1 with err set
     long read(uint8_t *dst, size_t n, std::string &err);

@@ -8,6 +8,7 @@
 
 #include "fastx.hpp"
 #include "json_out.hpp"
+#include "pgzip.hpp"
 #include "sketch_files.hpp"
 #include "zstd_dl.hpp"
 
@@ -53,6 +54,28 @@ char *lash_host_json_array(const char *items_nl, uint64_t n_items)
         p = e ? e + 1 : p + strlen(p);
     }
     return dup_str(json_pretty_string_array(v));
+}
+
+// pgzip.hpp: inflates a (multi-member) gzip file with `threads` inflate threads, reading in `read_size` pieces.  Returns NULL and
+// the malloc'd bytes on success, else the error text; counts[0] / counts[1] = members served by workers / sequentially.
+char *lash_host_pgzip_read(const char *path, int threads, uint64_t read_size, uint8_t **out, uint64_t *out_bytes, uint64_t *counts)
+{
+    ParallelGzip pg;
+    std::string err = pg.open(path, threads);
+    if (!err.empty()) return dup_str(err);
+    std::vector<uint8_t> all, buf(read_size ? read_size : 1);
+    for (;;) {
+        const long r = pg.read(buf.data(), buf.size(), err);
+        if (r < 0) return dup_str(err);
+        if (r == 0) break;
+        all.insert(all.end(), buf.begin(), buf.begin() + r);
+    }
+    *out_bytes = all.size();
+    *out = (uint8_t *)malloc(all.size() + 1);
+    if (!all.empty()) memcpy(*out, all.data(), all.size());
+    counts[0] = pg.members_parallel();
+    counts[1] = pg.members_sequential();
+    return nullptr;
 }
 
 // chunk-cut rule of the large-file streamer: returns the cut, copies the carry (<= 64 bytes) out

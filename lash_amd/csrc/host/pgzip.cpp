@@ -1,0 +1,276 @@
+#include "pgzip.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace lashhost {
+
+namespace {
+
+size_t member_cap()                                // a speculative worker gives up on a member that inflates beyond this
+{
+    static const size_t cap = getenv("LASH_PGZIP_MEMBER_CAP") ? (size_t)strtoull(getenv("LASH_PGZIP_MEMBER_CAP"), nullptr, 10) : (512ull << 20);
+    return cap;
+}
+constexpr size_t BUFFER_CAP = 4ull << 30;          // inflated bytes held ahead of the reader, all workers together
+constexpr size_t SCAN_AHEAD = 1ull << 30;          // compressed bytes ahead of the read position scanned for candidates
+
+constexpr size_t BLOCK = 4u << 20;                 // inflated bytes are kept in blocks of this size (no regrowth copies)
+
+struct Blocks {
+    std::vector<std::unique_ptr<uint8_t[]>> blk;
+    size_t bytes = 0;
+    size_t size() const { return bytes; }
+};
+
+struct Member {
+    uint64_t start = 0, end = 0;                   // compressed offsets [start, end)
+    Blocks data;
+    int state = 0;                                 // 0 queued, 1 running, 2 done ok, 3 failed / too big
+};
+
+// inflate ONE gzip member starting at src[0] straight into blocks (up to cap bytes); returns consumed bytes, 0 on any failure
+size_t inflate_member(const uint8_t *src, size_t avail, Blocks &out, size_t cap)
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 16) != Z_OK) return 0;
+    size_t used = 0;
+    int rc = Z_OK;
+    while (rc != Z_STREAM_END) {
+        if (z.avail_in == 0) {
+            const size_t chunk = std::min<size_t>(avail - used, 1u << 30);
+            if (chunk == 0) break;                     // ran out of file before the member ended
+            z.next_in = const_cast<Bytef *>(src + used);
+            z.avail_in = (uInt)chunk;
+            used += chunk;
+        }
+        const size_t in_blk = out.bytes % BLOCK;
+        if (out.blk.size() * BLOCK == out.bytes) {          // the last block is full (or there is none yet)
+            if (out.bytes + 1 > cap) { inflateEnd(&z); return 0; }
+            out.blk.emplace_back(new uint8_t[BLOCK]);
+        }
+        z.next_out = out.blk.back().get() + in_blk;
+        z.avail_out = (uInt)(BLOCK - in_blk);
+        rc = inflate(&z, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&z); return 0; }
+        out.bytes += (BLOCK - in_blk) - z.avail_out;
+    }
+    const size_t consumed = used - z.avail_in;
+    inflateEnd(&z);
+    return rc == Z_STREAM_END && out.bytes <= cap ? consumed : 0;
+}
+
+}  // namespace
+
+struct ParallelGzip::Impl {
+    const uint8_t *map = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    int threads = 1;
+    // sequential decoder state (the member at the read position, when no speculative result serves it)
+    z_stream z;
+    bool z_open = false;
+    uint64_t pos = 0;                              // compressed offset of the member at the read position (always a member boundary)
+    uint64_t in_pos = 0;                           // how far the sequential decoder has been fed (>= pos while z_open)
+    // speculative side
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::map<uint64_t, std::shared_ptr<Member>> members;   // by start offset, all > pos or == pos
+    std::deque<std::shared_ptr<Member>> todo;
+    std::vector<std::thread> pool;
+    size_t buffered = 0;
+    uint64_t scanned_to = 0;
+    bool stop = false;
+    // the member currently being served from a worker's buffer
+    std::shared_ptr<Member> cur;
+    size_t cur_at = 0;
+    uint64_t n_par = 0, n_seq = 0;
+
+    void scan_candidates()                         // call with mu held
+    {
+        const uint64_t limit = std::min<uint64_t>(size, pos + SCAN_AHEAD);
+        uint64_t from = std::max<uint64_t>(scanned_to, pos);         // pos is a member boundary: itself a candidate
+        while (from + 10 <= limit) {
+            const void *hit = memchr(map + from, 0x1f, limit - 9 - from);
+            if (!hit) break;
+            const uint64_t at = (const uint8_t *)hit - map;
+            const uint8_t *h = map + at;
+            // ID1 ID2 CM=8, no reserved flag bits, XFL one of {0, 2, 4}
+            if (h[1] == 0x8b && h[2] == 8 && (h[3] & 0xE0) == 0 && (h[8] == 0 || h[8] == 2 || h[8] == 4)) {
+                if (!members.count(at)) {
+                    auto m = std::make_shared<Member>();
+                    m->start = at;
+                    members[at] = m;
+                    todo.push_back(m);
+                }
+            }
+            from = at + 1;
+        }
+        scanned_to = std::max<uint64_t>(scanned_to, limit > 9 ? limit - 9 : 0);
+        cv_work.notify_all();
+    }
+
+    void worker()
+    {
+        for (;;) {
+            std::shared_ptr<Member> m;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                // (the member the reader is waiting for is never held back by the buffer cap)
+                cv_work.wait(lk, [&] { return stop || (!todo.empty() && (buffered < BUFFER_CAP || todo.front()->start <= pos)); });
+                if (stop) return;
+                m = todo.front();
+                todo.pop_front();
+                if (m->start < pos) { m->state = 3; continue; }       // the reader has passed it: a false candidate
+                m->state = 1;
+            }
+            Blocks out;
+            const size_t used = inflate_member(map + m->start, size - m->start, out, member_cap());
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (used) { m->data = std::move(out); m->end = m->start + used; m->state = 2; buffered += m->data.size(); }
+                else m->state = 3;
+            }
+            cv_done.notify_all();
+        }
+    }
+};
+
+ParallelGzip::ParallelGzip() : impl_(new Impl()) {}
+
+ParallelGzip::~ParallelGzip()
+{
+    {
+        std::lock_guard<std::mutex> lk(impl_->mu);
+        impl_->stop = true;
+    }
+    impl_->cv_work.notify_all();
+    for (auto &t : impl_->pool) t.join();
+    if (impl_->z_open) inflateEnd(&impl_->z);
+    if (impl_->map) munmap(const_cast<uint8_t *>(impl_->map), impl_->size);
+    if (impl_->fd >= 0) close(impl_->fd);
+    delete impl_;
+}
+
+std::string ParallelGzip::open(const std::string &path, int threads)
+{
+    impl_->fd = ::open(path.c_str(), O_RDONLY);
+    if (impl_->fd < 0) return "Invalid input file: cannot open " + path;
+    struct stat st;
+    if (fstat(impl_->fd, &st) != 0) return "Invalid input file: cannot stat " + path;
+    impl_->size = (size_t)st.st_size;
+    if (impl_->size) {
+        void *p = mmap(nullptr, impl_->size, PROT_READ, MAP_PRIVATE, impl_->fd, 0);
+        if (p == MAP_FAILED) return "Invalid input file: cannot map " + path;
+        impl_->map = static_cast<const uint8_t *>(p);
+        madvise(p, impl_->size, MADV_SEQUENTIAL);
+    }
+    impl_->threads = std::max(1, threads);
+    if (impl_->threads > 1) {
+        for (int t = 0; t < impl_->threads; ++t) impl_->pool.emplace_back([this] { impl_->worker(); });
+        std::lock_guard<std::mutex> lk(impl_->mu);
+        impl_->scan_candidates();
+    }
+    return "";
+}
+
+uint64_t ParallelGzip::members_parallel() const { return impl_->n_par; }
+uint64_t ParallelGzip::members_sequential() const { return impl_->n_seq; }
+
+long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
+{
+    Impl &I = *impl_;
+    size_t done = 0;
+    while (done < n) {
+        // 1. bytes of a member a worker has inflated
+        if (I.cur) {
+            const size_t take = std::min(std::min(n - done, I.cur->data.size() - I.cur_at), BLOCK - I.cur_at % BLOCK);
+            if (take) memcpy(dst + done, I.cur->data.blk[I.cur_at / BLOCK].get() + I.cur_at % BLOCK, take);
+            done += take;
+            I.cur_at += take;
+            if (I.cur_at == I.cur->data.size()) {
+                std::lock_guard<std::mutex> lk(I.mu);
+                I.buffered -= I.cur->data.size();
+                I.pos = I.cur->end;
+                I.members.erase(I.cur->start);
+                // candidates the finished member ran over were false
+                while (!I.members.empty() && I.members.begin()->first < I.pos) {
+                    auto m = I.members.begin()->second;
+                    if (m->state == 2) I.buffered -= m->data.size();
+                    I.members.erase(I.members.begin());
+                }
+                I.cur.reset();
+                I.cur_at = 0;
+                I.scan_candidates();
+            }
+            continue;
+        }
+        // 2. inside a member that is being inflated sequentially
+        if (I.z_open) {
+            if (I.z.avail_in == 0) {
+                const size_t chunk = std::min<size_t>(I.size - I.in_pos, 1u << 30);
+                if (chunk == 0) { err = "Invalid input file: truncated gzip stream"; return -1; }
+                I.z.next_in = const_cast<Bytef *>(I.map + I.in_pos);
+                I.z.avail_in = (uInt)chunk;
+                I.in_pos += chunk;
+            }
+            I.z.next_out = dst + done;
+            I.z.avail_out = (uInt)std::min<size_t>(n - done, 1u << 30);
+            const uInt before = I.z.avail_out;
+            const int rc = inflate(&I.z, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END) { err = "Invalid input file: corrupt gzip stream"; return -1; }
+            done += before - I.z.avail_out;
+            if (rc == Z_STREAM_END) {
+                const uint64_t end = I.in_pos - I.z.avail_in;    // the member ended here
+                inflateEnd(&I.z);
+                I.z_open = false;
+                ++I.n_seq;
+                if (I.threads > 1) {
+                    std::lock_guard<std::mutex> lk(I.mu);
+                    I.pos = end;
+                    while (!I.members.empty() && I.members.begin()->first < I.pos) {
+                        auto m = I.members.begin()->second;
+                        if (m->state == 2) I.buffered -= m->data.size();
+                        I.members.erase(I.members.begin());
+                    }
+                    I.scan_candidates();
+                } else I.pos = end;
+            }
+            continue;
+        }
+        // 3. at a member boundary
+        if (I.pos >= I.size) break;                                // end of data
+        if (I.threads > 1) {
+            std::unique_lock<std::mutex> lk(I.mu);
+            auto it = I.members.find(I.pos);
+            if (it != I.members.end()) {
+                auto m = it->second;
+                I.cv_done.wait(lk, [&] { return m->state >= 2; });
+                if (m->state == 2) { I.cur = m; I.cur_at = 0; ++I.n_par; continue; }
+                I.members.erase(it);                               // too big for a worker (or broken): sequentially, from here
+            }
+        }
+        memset(&I.z, 0, sizeof I.z);
+        if (inflateInit2(&I.z, 15 + 16) != Z_OK) { err = "zlib: inflateInit2 failed"; return -1; }
+        I.z_open = true;
+        I.in_pos = I.pos;
+    }
+    return (long)done;
+}
+
+}  // namespace lashhost

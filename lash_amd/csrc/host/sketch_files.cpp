@@ -239,9 +239,10 @@ size_t find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry
 
 // One file too large for a batch: chunks of it are sketched into the same image with LASH_F_ACCUMULATE.
 std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::string &path, uint64_t chunk_bytes,
-                            PinnedBuf &buf, uint8_t *image, uint64_t &bytes_seen)
+                            PinnedBuf &buf, uint8_t *image, uint64_t &bytes_seen, int threads)
 {
     ByteStream bs;
+    bs.set_threads(threads);                              // multi-member .gz: members inflate in parallel (pgzip.hpp)
     std::string err = bs.open(path);
     if (!err.empty()) return err;
     if (!buf.reserve(chunk_bytes + 64)) return "out of pinned host memory";
@@ -501,7 +502,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                     if (rc != LASH_OK) { err = lash_strerror(rc); break; }
                 }
                 uint64_t seen = 0;
-                b->err = stream_big_file(stream_ctx, prm, files[i], stream_bytes, stream_buf, b->images.data(), seen);
+                b->err = stream_big_file(stream_ctx, prm, files[i], stream_bytes, stream_buf, b->images.data(), seen, opt.threads);
                 n_bytes += seen;
                 std::lock_guard<std::mutex> lk(qmu);
                 b->index = batch_index++;

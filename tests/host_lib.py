@@ -30,6 +30,8 @@ def _load():
     lib.lash_host_zstd_write.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int]
     lib.lash_host_stream_find_cut.restype = C.c_uint64
     lib.lash_host_stream_find_cut.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.POINTER(C.c_uint64)]
+    lib.lash_host_pgzip_read.restype = C.c_void_p
+    lib.lash_host_pgzip_read.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.lash_host_zstd_read.restype = C.c_void_p
     lib.lash_host_zstd_read.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     return lib
@@ -100,3 +102,17 @@ def stream_find_cut(buf: bytes, fmt: int):
     n = C.c_uint64()
     cut = lib.lash_host_stream_find_cut(buf, len(buf), fmt, carry, C.byref(n))
     return int(cut), carry.raw[:n.value]
+
+
+def pgzip_read(path, threads, read_size=1 << 20):
+    """(bytes, members served by workers, members inflated sequentially); raises ValueError with the reader's message"""
+    out, n = C.c_void_p(), C.c_uint64()
+    counts = (C.c_uint64 * 2)()
+    err = lib.lash_host_pgzip_read(path.encode(), threads, read_size, C.byref(out), C.byref(n), counts)
+    if err:
+        msg = C.string_at(err).decode()
+        lib.lash_host_free(err)
+        raise ValueError(msg)
+    data = C.string_at(out.value, n.value)
+    lib.lash_host_free(out)
+    return data, int(counts[0]), int(counts[1])

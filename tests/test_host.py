@@ -223,3 +223,69 @@ def test_json_array_matches_a_reference_pretty_printer_on_odd_names():
         got = H.json_array(items)
         assert got == json.dumps(items, indent=2, ensure_ascii=False) or (items == [] and got == "[]")
         assert json.loads(got) == items
+
+
+def test_parallel_multi_member_gzip_reader(tmp_path, monkeypatch):
+    """pgzip.hpp: members of a concatenated .gz inflate in parallel, speculatively from candidate magic bytes; a result is used
+    only when the previous member ended exactly there.  Whatever the file looks like, the bytes must equal gzip's."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(8)
+
+    def blob(n):
+        return bytes(np.frombuffer(b"ACGTN\n@+I", np.uint8)[rng.integers(0, 9, size=n)])
+    magic = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x04\x03"             # a plausible member header as PAYLOAD: false candidates
+    parts = [blob(300_000), b"", blob(17), magic * 50 + blob(100_000) + magic, blob(1_500_000), magic, blob(64)]
+    cases = {
+        "many members": b"".join(gzip.compress(p, 1) for p in parts),
+        "single member": gzip.compress(b"".join(parts), 6),
+        # stored (level 0) members keep the fake headers verbatim in the compressed stream
+        "false candidates inside stored members": b"".join(gzip.compress(p, 0) for p in parts),
+        # a member header with FNAME + FCOMMENT (flags 0x18): the scan accepts any reserved-bit-free flag byte
+        "named members": b"".join(_gz_named(p, b"lane%d.fastq" % i) for i, p in enumerate(parts)),
+        "empty file": b"",
+    }
+    want_all = b"".join(parts)
+    for name, data in cases.items():
+        f = tmp_path / (name.replace(" ", "_") + ".gz")
+        f.write_bytes(data)
+        want = want_all if data else b""
+        for threads in (1, 2, 8):
+            for read_size in (1 << 20, 4097):
+                got, n_par, n_seq = H.pgzip_read(str(f), threads, read_size)
+                assert got == want, (name, threads, read_size)
+                if threads > 1 and name == "many members":
+                    assert n_par >= 5, (n_par, n_seq)
+                if threads == 1:
+                    assert n_par == 0
+    # a member larger than the per-member buffer is handed to the sequential path (no unbounded buffering)
+    monkeypatch.setenv("LASH_PGZIP_MEMBER_CAP", "200000")
+    # (the cap is read once per process: exercise it in a fresh one)
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import host_lib as H; d, p, s = H.pgzip_read(%r, 4); "
+            "import gzip; assert d == gzip.open(%r).read(); print(p, s)" % (os.path.dirname(os.path.abspath(__file__)),
+                                                                         str(tmp_path / "many_members.gz"), str(tmp_path / "many_members.gz")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, LASH_PGZIP_MEMBER_CAP="200000"))
+    assert r.returncode == 0, r.stderr
+    n_par, n_seq = map(int, r.stdout.split())
+    assert n_seq >= 2 and n_par >= 3                              # the 300 kB and 1.5 MB members went sequentially
+    # corruption and truncation are errors, not silence
+    good = cases["many members"]
+    (tmp_path / "trunc.gz").write_bytes(good[:len(good) - 7])
+    bad = bytearray(good)
+    bad[len(gzip.compress(parts[0], 1)) + 5000] ^= 0x55
+    (tmp_path / "corrupt.gz").write_bytes(bytes(bad))
+    for name in ("trunc.gz", "corrupt.gz"):
+        for threads in (1, 4):
+            with pytest.raises(ValueError):
+                H.pgzip_read(str(tmp_path / name), threads)
+
+
+def _gz_named(payload, fname):
+    import struct
+    import zlib
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    body = co.compress(payload) + co.flush()
+    hdr = b"\x1f\x8b\x08\x18" + b"\x00\x00\x00\x00" + b"\x04\x03" + fname + b"\x00" + b"a comment\x00"
+    return hdr + body + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload) & 0xFFFFFFFF)
