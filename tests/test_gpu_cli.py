@@ -79,6 +79,11 @@ def test_large_files_are_streamed_in_chunks(tmp_path):
     with gzip.open(tmp_path / "reads.fq.gz", "wb", compresslevel=1) as g:
         g.write(fq)
     paths.append(str(tmp_path / "reads.fq.gz"))
+    # the same reads as MANY concatenated gzip members cut at arbitrary bytes (mid-line): with -t > 1 the members inflate in
+    # parallel (host/pgzip.hpp) and must come out as one seamless stream
+    cuts = sorted({0, len(fq)} | {rng.randrange(len(fq)) for _ in range(37)})
+    (tmp_path / "reads_mm.fq.gz").write_bytes(b"".join(gzip.compress(fq[a:b], 1) for a, b in zip(cuts[:-1], cuts[1:])))
+    paths.append(str(tmp_path / "reads_mm.fq.gz"))
     import bz2
     import lzma
     (tmp_path / "big.fa.bz2").write_bytes(bz2.compress(fa, 1))            # streamed (large once inflated)
@@ -97,7 +102,7 @@ def test_large_files_are_streamed_in_chunks(tmp_path):
         ib = O.image_bytes(ALGO[algo], p)
         assert len(blob) == ib * len(paths)
         for i, path in enumerate(paths):
-            src = path.rsplit(".", 1)[0] if path.endswith((".gz", ".bz2", ".xz")) else path
+            src = path.rsplit(".", 1)[0].replace("reads_mm.fq", "reads.fq") if path.endswith((".gz", ".bz2", ".xz")) else path
             recs = read_fastx(src)
             seq = np.frombuffer(b"".join(recs), np.uint8)
             off = np.cumsum([0] + [len(x) for x in recs]).astype(np.uint64)

@@ -44,4 +44,18 @@ for p in (12, 14):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     print("hll p=%d pairs: %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (p, n, n, dt * 1e3, n * n / dt, n * n * (1 << p) / dt))
+# UltraLogLog: realistic register values (genome-like sketches: values within a band of ~24 around 4 * (p + log2(n/m)))
+for p, est in ((12, "fgra"), (12, "ml"), (10, "fgra"), (16, "fgra")):
+    ib = 8 + (1 << p)
+    nn = n if p < 16 else max(64, n // 8)
+    u = torch.randint(60, 92, (nn, ib), dtype=torch.uint8, device="cuda", generator=g)
+    e = torch.zeros((nn, nn), dtype=torch.float64, device="cuda")
+    def run_ull():
+        ctx.ull_pair_union_estimates_device(p, est, u, nn, u, nn, e)
+    run_ull(); torch.cuda.synchronize(); ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): run_ull()
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print("ull p=%d %s pairs: %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (p, est, nn, nn, dt * 1e3, nn * nn / dt, nn * nn * (1 << p) / dt))
 print("ok")
