@@ -180,11 +180,20 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
  *                                 malformed record and lash_sketch_batch — exact reference semantics, returns LASH_OK;
  *   lash_sketch_files_raw_device  (bytes only in HBM) leaves their images unreliable; the next lash_ctx_synchronize() returns
  *                                 LASH_EFORMAT.
- * Not detected: a quality line whose LENGTH differs from its sequence line's (needletail's other FASTQ error).  The 4-line
- * structure is intact then, nothing is mis-phased, and such a file is sketched to its end where the reference stops.
+ * Not detected ON THE DEVICE: a quality line whose LENGTH differs from its sequence line's (needletail's other FASTQ
+ * error).  The 4-line structure is intact then, nothing is mis-phased, and such a file is sketched to its end where the
+ * reference stops — unless the caller validates first with lash_fastq_valid_prefix (below), as the `lash` CLI does.
  * Either way the indices of those files (of the last raw call) are available here: returns how many, copies up to `cap`.
  * The first byte of a file must be '>' or '@' (parse_fastx_file fails otherwise, utils.rs:453): LASH_EINVAL from both. */
 uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap);
+/* Host-side twin for callers that want needletail's FASTQ rules in full before the bytes go to the device (the `lash` CLI
+ * does this in its reader threads, ~4 GB/s per thread): the length of the longest prefix of `buf` that is a sequence of
+ * well-formed records — '@' header, sequence, '+' line, quality of EQUAL length (CR stripped); the last record may lack its
+ * final newline.  == n for a well-formed file, 0 if the first byte is not '@'.  What follows the prefix is what needletail's
+ * iterator never yields; lash_fastq_neutralise_tail overwrites such a tail (inside a batch buffer whose file offsets must stay
+ * contiguous) with a well-formed stand-in that contributes no base.  Host only. */
+uint64_t lash_fastq_valid_prefix(const uint8_t *buf, uint64_t n);
+void     lash_fastq_neutralise_tail(uint8_t *tail, uint64_t n);
 
 /* Two-stage form for callers that keep genomes resident in HBM as 2-bit (0.28 B/base incl. break bitmap):
  * pack once, sketch many times (other k / algo / seed).  The pack stage performs filter_out_n + KSeq::new

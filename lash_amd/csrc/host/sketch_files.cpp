@@ -262,13 +262,18 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
             if (!fmt) return "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + path;
         }
         std::vector<uint8_t> carry;
-        const size_t cut = eof ? have : find_cut(buf.p, have, fmt, carry);
+        size_t cut = eof ? have : find_cut(buf.p, have, fmt, carry);
         if (!eof && cut == 0) return "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path;
+        bool stop_here = false;
+        if (fmt == LASH_FMT_FASTQ) {                      // the chunk starts and ends at record boundaries: validate it whole
+            const uint64_t ok = lash_fastq_valid_prefix(buf.p, cut);
+            if (ok < cut) { cut = (size_t)ok; stop_here = true; }   // needletail stops at the malformed record (utils.rs:457)
+        }
         lash_params prm = prm0;
         if (!first) prm.flags |= LASH_F_ACCUMULATE;
         const uint64_t off[2] = {0, (uint64_t)cut};
         const uint8_t f = (uint8_t)fmt;
-        if (cut) {
+        if (cut || (stop_here && first)) {                // (a file whose FIRST record is malformed still owes its empty sketch)
             const int rc = lash_sketch_files_raw(ctx, &prm, buf.p, off, &f, 1, image);
             if (rc != LASH_OK) return std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
             first = false;
@@ -276,6 +281,7 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
             // before it; nothing after it belongs to the sketch
             if (lash_ctx_format_errors(ctx, nullptr, 0) != 0) return "";
         }
+        if (stop_here) return "";
         const size_t rest = have - cut;                   // cut > have / 2, carry <= 33 bytes: the buffer always drains
         if (rest) memmove(buf.p + carry.size(), buf.p + cut, rest);
         if (!carry.empty()) memcpy(buf.p, carry.data(), carry.size());
@@ -467,6 +473,12 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                             const int f = sniff_format(dst, s.size);
                             if (!f) e = "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + files[i];
                             b->fmt[i - b->f0] = (uint8_t)(f ? f : LASH_FMT_FASTA);
+                            if (f == LASH_FMT_FASTQ) {
+                                // needletail's iterator ends at the first malformed record and lash keeps what came before
+                                // (utils.rs:457): validate here, in the reader thread, and blank out what it would never yield
+                                const uint64_t ok = lash_fastq_valid_prefix(dst, s.size);
+                                if (ok < s.size) lash_fastq_neutralise_tail(dst + ok, s.size - ok);
+                            }
                         }
                     }
                     if (!e.empty()) { std::lock_guard<std::mutex> lk(b->emu); if (b->err.empty()) b->err = e; }

@@ -1149,8 +1149,9 @@ uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t ca
 // needletail's record rules for uncompressed input as lash uses it (utils.rs:453-459), on the host: the exact
 // path for the rare file the device parse flags.  FASTA: '>' header line, sequence lines up to the next line that starts with
 // '>', line ends stripped.  FASTQ: '@' header, sequence line, '+' line, quality line of the same length; iteration STOPS at
-// the first record that breaks this (the records before it stand).
-static void parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> &seq, std::vector<uint64_t> &rec_off)
+// the first record that breaks this (the records before it stand).  Returns the offset at which the iteration stopped
+// (n when the whole buffer parsed); seq / rec_off may be NULL (validation only).
+static size_t parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> *seq, std::vector<uint64_t> *rec_off)
 {
     auto line_end = [&](size_t p) { const void *q = memchr(d + p, '\n', n - p); return q ? (size_t)((const uint8_t *)q - d) : n; };
     size_t i = 0;
@@ -1161,31 +1162,53 @@ static void parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> 
             while (i < n && d[i] != '>') {
                 size_t e = line_end(i), stop = e;
                 while (stop > i && d[stop - 1] == '\r') --stop;
-                seq.insert(seq.end(), d + i, d + stop);
+                if (seq) seq->insert(seq->end(), d + i, d + stop);
                 i = e < n ? e + 1 : n;
             }
-            rec_off.push_back(seq.size());
+            if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
         }
+        return n;
+    }
+    while (i < n) {
+        if (d[i] != '@') break;
+        const size_t e = line_end(i);
+        if (e >= n) break;
+        const size_t s = e + 1, se = line_end(s);
+        if (se >= n) break;
+        const size_t pl = se + 1;
+        if (pl >= n || d[pl] != '+') break;
+        const size_t pe = line_end(pl);
+        if (pe >= n) break;
+        const size_t ql = pe + 1, qe = line_end(ql);
+        size_t sl = se - s, qn = qe - ql;
+        while (sl && d[s + sl - 1] == '\r') --sl;
+        while (qn && d[ql + qn - 1] == '\r') --qn;
+        if (sl != qn) break;
+        if (seq) seq->insert(seq->end(), d + s, d + s + sl);
+        if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
+        i = qe < n ? qe + 1 : n;
+    }
+    return i;
+}
+
+uint64_t lash_fastq_valid_prefix(const uint8_t *buf, uint64_t n)
+{
+    if (!buf || n == 0) return 0;
+    if (buf[0] != '@') return 0;
+    return (uint64_t)parse_fastx_strict(buf, (size_t)n, nullptr, nullptr);
+}
+
+void lash_fastq_neutralise_tail(uint8_t *tail, uint64_t n)
+{
+    // a well-formed stand-in that contributes no base: ONE record with an empty sequence, "@xxx...\n\n+\n\n", or what fits of it
+    if (!tail || n == 0) return;
+    static const char end5[] = "\n\n+\n\n";
+    tail[0] = '@';
+    if (n >= 6) {
+        for (uint64_t i = 1; i < n - 5; ++i) tail[i] = 'x';
+        memcpy(tail + n - 5, end5, 5);
     } else {
-        while (i < n) {
-            if (d[i] != '@') break;
-            const size_t e = line_end(i);
-            if (e >= n) break;
-            const size_t s = e + 1, se = line_end(s);
-            if (se >= n) break;
-            const size_t pl = se + 1;
-            if (pl >= n || d[pl] != '+') break;
-            const size_t pe = line_end(pl);
-            if (pe >= n) break;
-            const size_t ql = pe + 1, qe = line_end(ql);
-            size_t sl = se - s, qn = qe - ql;
-            while (sl && d[s + sl - 1] == '\r') --sl;
-            while (qn && d[ql + qn - 1] == '\r') --qn;
-            if (sl != qn) break;
-            seq.insert(seq.end(), d + s, d + s + sl);
-            rec_off.push_back(seq.size());
-            i = qe < n ? qe + 1 : n;
-        }
+        for (uint64_t i = 1; i < n; ++i) tail[i] = (uint8_t)end5[i - 1];
     }
 }
 
@@ -1231,7 +1254,7 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     for (uint32_t g : bad) {                                       // exact reference semantics for the malformed ones
         std::vector<uint8_t> seq;
         std::vector<uint64_t> rec_off(1, 0);
-        parse_fastx_strict(raw + file_off[g], (size_t)(file_off[g + 1] - file_off[g]), seq, rec_off);
+        parse_fastx_strict(raw + file_off[g], (size_t)(file_off[g + 1] - file_off[g]), &seq, &rec_off);
         const uint64_t goff[2] = {0, (uint64_t)rec_off.size() - 1};
         const uint8_t dummy = 0;
         rc = lash_sketch_batch(ctx, prm, seq.empty() ? &dummy : seq.data(), rec_off.data(), rec_off.size() - 1, goff, 1, out_images + (size_t)g * ib);

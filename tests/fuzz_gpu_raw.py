@@ -51,7 +51,7 @@ def fasta_file(rng):
     return data
 
 
-def fastq_file(rng):
+def fastq_file(rng, length_errors=False):
     nl = rng.choice([b"\n", b"\n", b"\r\n"])
     out = []
     for r in range(rng.randint(0, 400)):
@@ -65,8 +65,10 @@ def fastq_file(rng):
             out.insert(i, nl)                               # blank line between records
         elif kind < 0.6:
             out[i] = out[i].replace(nl + b"+", nl + b"-", 1)   # the '+' line does not start with '+'
-        else:
+        elif kind < 0.8 or not length_errors:
             out[i] = b"r" + out[i][1:]                      # header without '@'
+        else:                                               # quality one character short: only the CLI (host validation) stops there
+            out[i] = out[i][:-len(nl) - 1] + nl if len(out[i]) > len(nl) + 1 else out[i]
         # (a quality line whose LENGTH differs from its sequence line's — needletail's other FASTQ error — keeps the 4-line
         # structure intact; the device parse does not detect it and sketches the file to its end: documented divergence,
         # tests/test_gpu_rawfiles.py)

@@ -108,3 +108,43 @@ def test_large_files_are_streamed_in_chunks(tmp_path):
             off = np.cumsum([0] + [len(x) for x in recs]).astype(np.uint64)
             want = O.sketch_genomes(ALGO[algo], k, p, 42, seq, off, np.array([0, len(recs)], np.uint64), threads=8)[0].tobytes()
             assert blob[i * ib:(i + 1) * ib] == want, (algo, os.path.basename(path))
+
+
+def test_cli_stops_at_malformed_fastq_records_like_needletail(tmp_path):
+    """`lash sketch` validates FASTQ in its reader threads (lash_fastq_valid_prefix): structure AND sequence/quality length, so a
+    malformed record ends the file's contribution exactly where needletail's iterator would end (utils.rs:457) — in the
+    batch path (tail blanked inside the batch buffer) and in the streamed path (large file: streaming stops at that chunk)."""
+    import random
+    rng = random.Random(77)
+    base = O.synth_genome(55, 3_000_000).tobytes()
+
+    def reads(n, off):
+        return [base[off + 131 * i: off + 131 * i + rng.choice([100, 150, 151])] for i in range(n)]
+
+    def fq(rs, q=b"F"):
+        return b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, q * len(r)) for i, r in enumerate(rs))
+    a, b = reads(3000, 0), reads(3000, 500_000)
+    files = {
+        "ok.fq": fq(a) + fq(b),
+        "short_quality.fq": fq(a) + b"@bad\n" + b[0] + b"\n+\n" + b"F" * (len(b[0]) - 1) + b"\n" + fq(b),
+        "blank_line.fq": fq(a) + b"\n" + fq(b),
+        "no_plus.fq": fq(a) + b"@bad\n" + b[0] + b"\n" + b[1] + b"\n" + fq(b),
+        "first_bad.fq": b"@bad\nACGTACGTACGTACGTACGTACGT\n+\nFFF\n" + fq(a),
+        "big_short_quality.fq": fq(reads(12_000, 100)) + b"@bad\n" + b[0] + b"\n+\nF\n" + fq(reads(12_000, 900_000)),   # > --stream-mb: streamed
+    }
+    paths = []
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+        paths.append(str(tmp_path / name))
+    (tmp_path / "l.txt").write_text("\n".join(paths) + "\n")
+    for algo, k, p in (("hmh", 16, 10), ("hll", 21, 12)):
+        out = str(tmp_path / ("mal_" + algo))
+        r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "l.txt"), "-o", out, "-a", algo, "-k", str(k), "-p", str(p), "--stream-mb", "2",
+                            "--batch-mb", "1", "-t", "3"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        blob = H.zstd_read(out + "_sketches.bin")
+        want = O.sketch_files(ALGO[algo], k, p if algo != "hmh" else 0, 42, list(files.values()), threads=4)
+        ib = want.shape[1]
+        for i, name in enumerate(files):
+            assert blob[i * ib:(i + 1) * ib] == want[i].tobytes(), (algo, name)
+        assert blob[ib:2 * ib] != blob[:ib]                      # the truncation is real: not the same sketch as the clean file

@@ -289,3 +289,42 @@ def _gz_named(payload, fname):
     body = co.compress(payload) + co.flush()
     hdr = b"\x1f\x8b\x08\x18" + b"\x00\x00\x00\x00" + b"\x04\x03" + fname + b"\x00" + b"a comment\x00"
     return hdr + body + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload) & 0xFFFFFFFF)
+
+
+def test_fastq_valid_prefix_is_needletails_rule():
+    """lash_fastq_valid_prefix (C ABI, host only): where needletail's FASTQ iterator stops == where the oracle's parse stops."""
+    import ctypes as C
+    import lash_amd
+    import oracle_lib as O
+    lib = lash_amd.load()
+    rec = lambda i, s, q=None: b"@r%d\n%s\n+\n%s\n" % (i, s, (b"I" * len(s)) if q is None else q)
+    good = b"".join(rec(i, b"ACGT" * (5 + i)) for i in range(20))
+    cases = [
+        (good, len(good)),
+        (good[:-1], len(good) - 1),                                              # no final newline: still a record
+        (good + b"\n", len(good)),                                               # trailing blank line: stops there
+        (good + rec(99, b"ACGTACGT", b"III"), len(good)),                        # quality shorter than sequence
+        (good + b"@x\nACGT\n-\nIIII\n" + good, len(good)),                       # '+' line missing
+        (good + b"x\nACGT\n+\nIIII\n", len(good)),                               # header without '@'
+        (good + b"@trunc\nACGT\n+\n", len(good)),                                # file ends inside a record
+        (good.replace(b"\n", b"\r\n"), len(good.replace(b"\n", b"\r\n"))),       # CRLF
+        (b"", 0), (b">fasta\nACGT\n", 0), (b"\n" + good, 0),
+    ]
+    for data, want in cases:
+        buf = np.frombuffer(data, np.uint8).copy() if data else np.zeros(1, np.uint8)
+        got = int(lib.lash_fastq_valid_prefix(buf.ctypes.data, len(data)))
+        assert got == want, (data[-40:], got, want)
+        if data[:1] == b"@":
+            # the oracle sketches exactly that prefix
+            a = O.sketch_files(O.HMH, 16, 0, 42, [data])
+            b = O.sketch_files(O.HMH, 16, 0, 42, [data[:got]]) if got else O.sketch_files(O.HMH, 16, 0, 42, [b"@e\n\n+\n\n"])
+            assert np.array_equal(a, b)
+            # and the neutralised buffer is well-formed to its end, with the same records
+            if got < len(data):
+                lib.lash_fastq_neutralise_tail(buf.ctypes.data + got, len(data) - got)
+                fixed = buf.tobytes()[:len(data)]
+                if len(data) - got >= 6:                         # room for a whole (empty-sequence) record
+                    assert int(lib.lash_fastq_valid_prefix(buf.ctypes.data, len(data))) == len(data), fixed[got:got + 20]
+                else:                                            # a record cut short by the end of the file: '@' and '+' lines still in phase
+                    assert fixed[got:] == b"@\n\n+\n"[:len(data) - got]
+                assert np.array_equal(O.sketch_files(O.HMH, 16, 0, 42, [fixed]), a)
