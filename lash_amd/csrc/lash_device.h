@@ -90,8 +90,17 @@ __device__ __forceinline__ void xxh3_128_4b_hmh_fast(uint32_t w, uint64_t bitfli
     h += l << 1;
     l ^= h >> 3;
     l ^= l >> 35;
-    l *= XXH_PRIME_MX2;
-    sig10 = ((uint32_t)l ^ (uint32_t)(l >> 28)) & 0x3FFu;
+    // (the two xorshifts in hand-written 32-bit halves — alignbit + xor3 — were tried: hipcc then folds the doubling above back
+    // into the multiply chain, or pays an s_nop for the pair hazard: 41 instead of 37 instructions per k-mer.  Left as is.)
+    // sig10 = bits 9:0 of (m ^ m >> 28), m = l * MX2: only bits 37:0 of the product matter.  Bits 31:0 come from
+    // l_lo * MX2_lo; bits 37:32 are the low 6 bits of hi32(l_lo * MX2_lo) + l_lo * MX2_hi + l_hi * MX2_lo, and both halves of
+    // MX2 end in the same six bits (0x25), so the two cross products collapse into ONE 24-bit multiply:
+    // 37 * (l_lo + l_hi).  Two v_mul_lo_u32 + v_add3 become v_add + v_mad_u32_u24 (-6 of ~146 cycles per k-mer).
+    static_assert(((uint32_t)XXH_PRIME_MX2 & 63u) == 37u && ((uint32_t)(XXH_PRIME_MX2 >> 32) & 63u) == 37u, "low six bits of both halves");
+    const uint64_t pm = (uint64_t)(uint32_t)l * (uint32_t)XXH_PRIME_MX2;
+    uint32_t top;                                                                 // bits 5:0 valid
+    asm("v_mad_u32_u24 %0, %1, 37, %2" : "=v"(top) : "v"((uint32_t)l + (uint32_t)(l >> 32)), "v"((uint32_t)(pm >> 32)));
+    sig10 = ((uint32_t)pm ^ alignbit(top, (uint32_t)pm, 28)) & 0x3FFu;
     h ^= h >> 37;
     constexpr uint32_t m0 = (uint32_t)XXH_PRIME_MX1, m1 = (uint32_t)(XXH_PRIME_MX1 >> 32);
     const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);

@@ -29,19 +29,18 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
             uint32_t can = fwd < rc ? fwd : rc;
             if constexpr (MODE == 0) {            // k-mer extraction only
                 acc ^= can;
-            } else {
+            } else if constexpr (MODE == 1) {     // + the full xxh3_128 of 4 bytes (both halves, every bit)
                 uint64_t lo, hi;
                 xxh3_128_4b(can, bitflip, lo, hi);
-                if constexpr (MODE == 1) {        // + hash
-                    acc ^= (uint32_t)lo ^ (uint32_t)(hi >> 32) ^ (uint32_t)hi;
-                } else {                          // + register rule (+ atomic for MODE 3)
-                    const uint32_t xh = (uint32_t)(hi >> 32), xl = (uint32_t)hi;
-                    const uint32_t th = alignbit(xh, xl, 18);
-                    const uint32_t reg = ((ffbh_u32(th) << 10) | ((uint32_t)lo & 0x3FFu)) + 0x400u;
-                    const uint32_t bucket = xh >> 18;
-                    if constexpr (MODE == 2) acc ^= reg + bucket;
-                    else (void)__hip_atomic_fetch_max(lds + bucket, reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                acc ^= (uint32_t)lo ^ (uint32_t)(hi >> 32) ^ (uint32_t)hi;
+            } else {                              // the sketch kernel's own fast path (add_kmer<HMH, x = high half, FAST>):
+                uint32_t xh, sig;                 // only the bits the register rule reads, + the rule (+ the LDS atomic, MODE 3)
+                xxh3_128_4b_hmh_fast(can, bitflip, xh, sig);
+                const uint32_t t18 = (xh << 14) | 0x3FFFu;
+                const uint32_t reg = ((ffbh_u32(t18) << 10) | sig) + 0x400u;
+                const uint32_t bucket = xh >> 18;
+                if constexpr (MODE == 2) acc ^= reg + bucket;
+                else asm volatile("ds_max_u32 %0, %1" ::"v"(bucket << 2), "v"(reg) : "memory");
             }
         }
         c0 = c1; c1 = c1 * 1664525u + 1013904223u + acc;
