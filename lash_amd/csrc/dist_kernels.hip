@@ -7,6 +7,8 @@
 // Both kernels tile the pair matrix and walk the registers in chunks staged in LDS (details at each kernel).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "lash_device.h"
 #include "lash_kernels.h"
 #include "ull_estimators.h"
@@ -183,11 +185,27 @@ struct UllLaneHist {
 template <bool WIDE>
 __global__ void __launch_bounds__(WIDE ? 128 : 256) ull_pairs_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
                                                                       const uint8_t *__restrict__ qry, uint32_t n_qry, int p,
-                                                                      uint32_t hdr, int estimator, double *__restrict__ out)
+                                                                      uint32_t hdr, int estimator, double *__restrict__ out, int fixup)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t LANES = WIDE ? 128u : 256u, TR = LANES / UQ, HW = (WIDE ? 256u : 128u) * LANES;
+    // the histogram is addressed with raw LDS addresses (ds_add below): the dynamic array must start at LDS address 0, i.e. this
+    // kernel must own no static LDS — which rules out __syncthreads_or() (HIP implements it with a __shared__ word)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0u) __builtin_trap();   // ds_add below takes raw LDS addresses
     uint32_t *hist = lds;                                   // [bin (pair)][lane]
+    if (fixup) {
+        // second launch after ull_fgra_fast_kernel: only the tiles in which that kernel left a NaN (a pair that met an empty,
+        // small-range or saturated register) are redone here; the others return at once
+        const uint32_t fr = blockIdx.y * TR + threadIdx.x / UQ, fq = blockIdx.x * UQ + threadIdx.x % UQ;
+        const bool mine = fr < n_ref && fq < n_qry && isnan(out[(uint64_t)fr * n_qry + fq]);
+        if (threadIdx.x == 0) lds[0] = 0u;
+        __syncthreads();
+        if (mine) lds[0] = 1u;
+        __syncthreads();
+        const uint32_t any = lds[0];
+        __syncthreads();
+        if (!any) return;
+    }
     uint32_t(*R)[UROW] = reinterpret_cast<uint32_t(*)[UROW]>(lds + HW);
     uint32_t(*Q)[UROW] = reinterpret_cast<uint32_t(*)[UROW]>(lds + HW + TR * UROW);
     const uint32_t tid = threadIdx.x, tr = tid / UQ, tq = tid % UQ;
@@ -213,7 +231,7 @@ __global__ void __launch_bounds__(WIDE ? 128 : 256) ull_pairs_kernel(const uint8
             const uint32_t a = R[tr][w], b = Q[tq][w];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t r = ull_merge_reg((a >> (8 * j)) & 0xFFu, (b >> (8 * j)) & 0xFFu);
+                const uint32_t r = ull_merge_fast((a >> (8 * j)) & 0xFFu, (b >> (8 * j)) & 0xFFu);
                 if constexpr (WIDE) asm volatile("ds_add_u32 %0, %1" ::"v"((r * LANES + tid) << 2), "v"(1u) : "memory");
                 else asm volatile("ds_add_u32 %0, %1" ::"v"(((r >> 1) * LANES + tid) << 2), "v"(1u << (16u * (r & 1u))) : "memory");
             }
@@ -223,7 +241,57 @@ __global__ void __launch_bounds__(WIDE ? 128 : 256) ull_pairs_kernel(const uint8
     }
     if (r0 + tr < n_ref && q0 + tq < n_qry) {
         const UllLaneHist<WIDE> h{hist, LANES, tid};
-        out[(uint64_t)(r0 + tr) * n_qry + q0 + tq] = estimator == 1 ? ull::ml(h, p) : ull::fgra(h, p);
+        double *dst = out + (uint64_t)(r0 + tr) * n_qry + q0 + tq;
+        if (!fixup || isnan(*dst)) *dst = estimator == 1 ? ull::ml(h, p) : ull::fgra(h, p);
+    }
+}
+
+// FGRA when every merged register is "regular" (largest update value >= 3, not saturated — every register of a genome-sized
+// sketch): n = lambda_p * (sum_i g(r_i))^(-1/tau) needs no histogram.  A lane owns one pair and adds g(r) from a 256-entry f64
+// table in LDS; the entries of the special registers (empty, 4p-4, 4p, 4p+2, >= 252) are NaN, so a pair that meets one
+// comes out NaN and the histogram kernel redoes it (fixup launch).  2 KiB + 33 KiB of LDS instead of 128 KiB: full occupancy.
+constexpr int FCHUNK = 1024;
+constexpr int FROW = FCHUNK / 4 + 1;
+
+__global__ void __launch_bounds__(256) ull_fgra_fast_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
+                                                            const uint8_t *__restrict__ qry, uint32_t n_qry, int p, uint32_t hdr,
+                                                            double *__restrict__ out)
+{
+    __shared__ double G[256];
+    __shared__ uint32_t R[UQ][FROW], Q[UQ][FROW];
+    const uint32_t tid = threadIdx.x, tr = tid / UQ, tq = tid % UQ;
+    const uint32_t r0 = blockIdx.y * UQ, q0 = blockIdx.x * UQ;
+    const uint64_t m = 1ull << p, stride = (uint64_t)hdr + m;
+    {
+        const uint32_t r = tid, off = 4u * (uint32_t)p + 4u;
+        G[r] = (r >= off && r < 252u) ? ull::eta(r & 3u) * pow(2.0, -ull::TAU * (double)((r >> 2) - (uint32_t)p + 2u)) : __longlong_as_double(0x7FF8000000000000ll);
+    }
+    __syncthreads();
+    double sum = 0.0;
+    for (uint64_t c0 = 0; c0 < m; c0 += FCHUNK) {
+        const uint32_t n = m - c0 < (uint64_t)FCHUNK ? (uint32_t)(m - c0) : (uint32_t)FCHUNK;
+        for (uint32_t i = tid; i < 2 * UQ * (n / 4); i += 256) {
+            const uint32_t row = i / (n / 4), col = i % (n / 4);
+            const bool is_q = row >= UQ;
+            const uint32_t g = is_q ? q0 + row - UQ : r0 + row;
+            uint32_t v = 0;
+            if (g < (is_q ? n_qry : n_ref)) {
+                const uint8_t *s = (is_q ? qry : ref) + (uint64_t)g * stride + hdr + c0 + 4 * col;
+                v = s[0] | (s[1] << 8) | (s[2] << 16) | ((uint32_t)s[3] << 24);
+            }
+            if (is_q) Q[row - UQ][col] = v; else R[row][col] = v;
+        }
+        __syncthreads();
+        for (uint32_t w = 0; w < n / 4; ++w) {
+            const uint32_t a = R[tr][w], b = Q[tq][w];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += G[ull_merge_fast((a >> (8 * j)) & 0xFFu, (b >> (8 * j)) & 0xFFu)];
+        }
+        __syncthreads();
+    }
+    if (r0 + tr < n_ref && q0 + tq < n_qry) {
+        const double factor = pow((double)m, 1.0 + 1.0 / ull::TAU) / (1.0 + ull::V * (1.0 + ull::TAU) / (2.0 * (double)m));
+        out[(uint64_t)(r0 + tr) * n_qry + q0 + tq] = isnan(sum) ? sum : factor * pow(sum, -1.0 / ull::TAU);
     }
 }
 
@@ -236,12 +304,20 @@ hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t 
     const size_t lds = ((wide ? 256u : 128u) * lanes + (tr + UQ) * UROW) * 4u;
     dim3 grid((n_qry + UQ - 1) / UQ, (n_ref + tr - 1) / tr);
     hipError_t e;
+    int fixup = 0;
+    static const bool no_fast = getenv("LASH_ULL_NO_FAST") != nullptr;    // A/B knob (tools/dist_rate.py)
+    if (estimator == 0 && !no_fast) {                     // FGRA: the histogram-free kernel first, the histogram kernel only where it gave up
+        hipLaunchKernelGGL(ull_fgra_fast_kernel, dim3((n_qry + UQ - 1) / UQ, (n_ref + UQ - 1) / UQ), dim3(256), 0, stream, d_ref, n_ref,
+                           d_qry, n_qry, p, hdr, d_est);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        fixup = 1;
+    }
     if (wide) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(ull_pairs_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(ull_pairs_kernel<true>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est);
+        hipLaunchKernelGGL(ull_pairs_kernel<true>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est, fixup);
     } else {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(ull_pairs_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(ull_pairs_kernel<false>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est);
+        hipLaunchKernelGGL(ull_pairs_kernel<false>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est, fixup);
     }
     return hipGetLastError();
 }

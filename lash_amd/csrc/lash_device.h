@@ -139,4 +139,16 @@ __device__ __forceinline__ uint32_t ull_merge_reg(uint32_t a, uint32_t b)
     return (top << 2) | ((uint32_t)(x >> (top - 2)) & 3u);               // top >= 2 because r >= 8
 }
 
+// The same merge without 64-bit bitmaps (exhaustively equal for every pair of valid registers, 0 or 8..255; tools/ & tests):
+// with hi >= lo, d = top(hi) - top(lo): lo's leading one and the bit below it land on hi's two low bits only when d <= 2 —
+//   d = 0: hi | (lo & 3);   d = 1: hi | 2 | ((lo >> 1) & 1);   d = 2: hi | 1;   else hi      (table of 16 two-bit entries).
+__device__ __forceinline__ uint32_t ull_merge_fast(uint32_t a, uint32_t b)
+{
+    const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    uint32_t d = (hi >> 2) - (lo >> 2);
+    d = d < 3u ? d : 3u;
+    d = lo ? d : 3u;                                          // an empty register adds nothing
+    return hi | ((0x55FAE4u >> (2u * (4u * d + (lo & 3u)))) & 3u);
+}
+
 }  // namespace lash
