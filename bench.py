@@ -173,12 +173,15 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True)
     import subprocess
     floor, src = None, None
     exe = os.path.join(ROOT, "tools", "ubench_hash")
-    if run_ubench and os.path.exists(exe) and algo == "hmh":
+    line = {"hmh": r"\+ ds_max_u32", "hll": "hll p14 k21 stream", "ull": "ull p12 k16 stream"}[algo]
+    if run_ubench and os.path.exists(exe):
         try:
             out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
-            m = re.search(r"\+ ds_max_u32.*\(([0-9.e+]+) k-mers/s chip-wide\)", out)
+            m = re.search(line + r".*\(([0-9.e+]+) k-mers/s chip-wide\)", out)
             if m:
-                floor, src = float(m.group(1)), "tools/ubench_hash run in this process' job (hmh k=16 instruction stream from registers)"
+                floor, src = float(m.group(1)), ("tools/ubench_hash run in this process' job (%s instruction stream from registers%s)"
+                                                  % (line.replace("\\", "").replace("+ ds_max_u32", "hmh k=16"),
+                                                     "" if (algo, k) in (("hmh", 16), ("hll", 21), ("ull", 16)) else "; measured for that k, not this one"))
         except Exception:
             pass
     per, vsrc = None, None

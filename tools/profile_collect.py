@@ -37,12 +37,15 @@ def main():
     traffic_path, valu_path = "profiles/traffic.json", "profiles/valu.json"
     traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
     valu = json.load(open(valu_path)) if os.path.exists(valu_path) else {}
-    floor = None
+    floors = {}
     ub = os.path.join(src, "ubench_hash.txt")
     if os.path.exists(ub):
         shutil.copy(ub, os.path.join(dst, "ubench_hash.txt"))
-        m = re.search(r"\+ ds_max_u32.*\(([0-9.e+]+) k-mers/s chip-wide\)", open(ub).read())
-        floor = float(m.group(1)) if m else None
+        txt = open(ub).read()
+        for key, pat in ((("hmh", 16), r"\+ ds_max_u32"), (("hll", 21), "hll p14 k21 stream"), (("ull", 16), "ull p12 k16 stream")):
+            m = re.search(pat + r".*\(([0-9.e+]+) k-mers/s chip-wide\)", txt)
+            if m:
+                floors[key] = float(m.group(1))
     cal = os.path.join(src, "calibration", "calibration.txt")
     if os.path.exists(cal):
         shutil.copy(cal, os.path.join(dst, "hbm_calibration.txt"))
@@ -95,8 +98,8 @@ def main():
                 valu[vkey] = {"valu_insts_per_kmer": insts / (kmers / 64.0),
                               "note": "SQ_INSTS_VALU counts wave-instructions: per k-mer = SQ_INSTS_VALU / (k-mers / 64)",
                               "source": "profiles/r02/%s/pmc_summary.txt" % name, "round": 2}
-                if floor and cfg["algo"] == "hmh" and cfg["k"] == 16:
-                    valu[vkey]["issue_floor_kmers_per_s"] = floor
+                if (cfg["algo"], cfg["k"]) in floors:
+                    valu[vkey]["issue_floor_kmers_per_s"] = floors[(cfg["algo"], cfg["k"])]
                     valu[vkey]["floor_source"] = "profiles/r02/ubench_hash.txt (tools/ubench_hash, same session)"
         alg = roof["algorithmic_bytes_per_launch"]
         rows.append((name, short, dom_calls, dom_ms, roof["avg_launch_ms"], alg, alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK if dom_ms else None,

@@ -33,6 +33,22 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
                 uint64_t lo, hi;
                 xxh3_128_4b(can, bitflip, lo, hi);
                 acc ^= (uint32_t)lo ^ (uint32_t)(hi >> 32) ^ (uint32_t)hi;
+            } else if constexpr (MODE == 4) {     // hll p=14 k=21 (BASELINE configs[2]): 64-bit windows + xxh3_64 + rule + ds_max
+                const uint32_t c2 = c1 * 0x9E3779B1u, r2 = rcword(c2);
+                const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0, fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
+                const uint64_t f64 = (((uint64_t)fh << 32) | fl) >> 22;              // 64 - 2k, k = 21
+                const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0, rh = r ? alignbit(r2, r1, 2 * r) : r1;
+                const uint64_t r64 = (((uint64_t)rh << 32) | rl) & ((1ull << 42) - 1ull);
+                const uint64_t cn = f64 < r64 ? f64 : r64;
+                const uint64_t hh64 = xxh3_64_8b((uint32_t)cn, (uint32_t)(cn >> 32), bitflip);
+                const uint32_t hh = (uint32_t)(hh64 >> 32), hl = (uint32_t)hh64;
+                asm volatile("ds_max_u32 %0, %1" ::"v"((hl & 16383u) << 2), "v"(ffbh_u32(hh) + 1u) : "memory");
+            } else if constexpr (MODE == 5) {     // ull p=12 k=16 (configs[4]): xxh3_64 + rule + ds_or
+                const uint64_t hh64 = xxh3_64_8b(can, 0u, bitflip);
+                const uint32_t hh = (uint32_t)(hh64 >> 32), hl = (uint32_t)hh64;
+                const uint32_t th = alignbit(hh, hl, 32 - 12);
+                const uint32_t bit = ffbh_u32(th) + 11u;
+                asm volatile("ds_or_b32 %0, %1" ::"v"(((hh >> 20) * 2u + ((bit >> 5) & 1u)) << 2), "v"((th < 1u ? th : 1u) << (bit & 31u)) : "memory");
             } else {                              // the sketch kernel's own fast path (add_kmer<HMH, x = high half, FAST>):
                 uint32_t xh, sig;                 // only the bits the register rule reads, + the rule (+ the LDS atomic, MODE 3)
                 xxh3_128_4b_hmh_fast(can, bitflip, xh, sig);
@@ -93,5 +109,7 @@ int main()
     run<1>("+ xxh3_128", 200, d_cyc, d_sink);
     run<2>("+ register rule", 200, d_cyc, d_sink);
     run<3>("+ ds_max_u32", 200, d_cyc, d_sink);
+    run<4>("hll p14 k21 stream", 200, d_cyc, d_sink);
+    run<5>("ull p12 k16 stream", 200, d_cyc, d_sink);
     return 0;
 }
