@@ -11,7 +11,8 @@ concatenated in rank order (= file order).  Nothing else crosses the links.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         -m lash_amd.allpairs -f list.txt -a hmh -k 16 -o dist.tsv
 
-Row order is file order; the reference's is nondeterministic (hashbrown iteration under rayon), so parity is on the set of rows.
+Row order is file order (`lash dist --file-order` prints the same); the reference's own order is its seeded hash map's key order,
+which the C++ `lash dist` reproduces (lash_amd/csrc/host/name_order.cpp).
 """
 import argparse
 import gzip

@@ -12,8 +12,10 @@
 //        or union that falls there is refused with a message instead of being estimated differently;
 //   ull  union estimate per pair on the GPU (lash_ull_pair_union_estimates: merged-register histogram + FGRA or ML,
 //        ull_estimators.h), per-sketch estimates with lash_ull_estimate; similarity by inclusion-exclusion (utils.rs:272).
-// Row order: the reference iterates hashbrown maps under rayon (nondeterministic); here rows come in
-// file order, so parity with the reference is on the SET of rows.
+// Order: the reference keeps its sketches in hashbrown maps seeded with XXH3(93) and takes the column order, the
+// same-files triangle and (under rayon: up to scheduling) the row order from `.keys()`; name_order.hpp
+// restates that order, so rows, columns and the (Reference, Query) orientation of each triangle pair come out as the
+// reference's `-t 1` run writes them.  --file-order keeps list-file order instead.
 // Several GPUs (--devices 0,1,..): blocks of reference rows are handed to one worker per device and written in order.
 #include "dist.hpp"
 
@@ -31,11 +33,14 @@
 #include <map>
 #include <mutex>
 #include <sstream>
+#include <numeric>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../../include/lash_gfx950.h"
 #include "json_out.hpp"
+#include "name_order.hpp"
 #include "zstd_dl.hpp"
 
 namespace lashhost {
@@ -110,6 +115,18 @@ std::string run_dist(const DistOptions &opt)
     if (!(err = slurp(rf["files"], txt)).empty() || !json_parse_string_array(txt, rnames)) return err.empty() ? "bad names JSON " + rf["files"] : err;
     if (!(err = slurp(qf["files"], txt)).empty() || !json_parse_string_array(txt, qnames)) return err.empty() ? "bad names JSON " + qf["files"] : err;
     const bool same_files = qf["files"] == rf["files"];                                               // main.rs:404
+    // utils.rs:111-127: the maps' key order (a repeated name is one entry carrying its last sketch)
+    std::vector<uint32_t> rorder, qorder;
+    if (opt.file_order) {
+        rorder.resize(rnames.size()); std::iota(rorder.begin(), rorder.end(), 0u);
+        qorder.resize(qnames.size()); std::iota(qorder.begin(), qorder.end(), 0u);
+    } else {
+        rorder = hashbrown_key_order(rnames);
+        qorder = same_files ? rorder : hashbrown_key_order(qnames);
+    }
+    std::unordered_map<std::string, uint32_t> qpos;                                                   // utils.rs:130-142 file_idx
+    if (same_files && !opt.file_order)
+        for (uint32_t jj = 0; jj < qorder.size(); ++jj) qpos[qnames[qorder[jj]]] = jj;
 
     std::vector<uint8_t> rimg, qimg;
     if (!(err = zstd_decompress_file(rf["sketches"], rimg)).empty()) return err;
@@ -122,7 +139,7 @@ std::string run_dist(const DistOptions &opt)
     if (!ib) return "bad layout";
     if (rimg.size() < rnames.size() * ib) return "Error with reading from " + rf["sketches"];
     if (qimg.size() < qnames.size() * ib) return "Error with reading from " + qf["sketches"];
-    const uint32_t nr = (uint32_t)rnames.size(), nq = (uint32_t)qnames.size();
+    const uint32_t nr = (uint32_t)rorder.size(), nq = (uint32_t)qnames.size();   // rows: map entries; columns of the pair tables: every query image
 
     std::vector<double> rcard(nr), qcard(nq);
     const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which "
@@ -155,7 +172,7 @@ std::string run_dist(const DistOptions &opt)
     FILE *out = fopen(opt.output_file.c_str(), "w");
     if (!out) return "cannot create " + opt.output_file;
     if (!opt.matrix) fprintf(out, "Reference\tQuery\tDistance\n");                                   // main.rs:409-412
-    else for (uint32_t j = 0; j < nq; ++j) fprintf(out, "\t%s", qnames[j].c_str());                   // main.rs:439-441
+    else for (uint32_t j : qorder) fprintf(out, "\t%s", qnames[j].c_str());                          // main.rs:439-441
     // ---- GPU: the O(N_ref * N_qry * registers) scan, in blocks of reference rows so that the per-pair tables stay
     //      bounded (all-vs-all on 10^5 sketches is 10^10 pairs); one worker (context + host thread) per device ----
     std::vector<int> devices = opt.devices.empty() ? std::vector<int>{opt.device} : opt.devices;
@@ -177,6 +194,7 @@ std::string run_dist(const DistOptions &opt)
         std::string my_fail = rc == LASH_OK ? "" : std::string(lash_strerror(rc));
         std::vector<uint32_t> C, N;                              // hmh: C / N; hll: C = zero registers of the union
         std::vector<double> U;                                   // hll: union sum; ull: union estimate
+        std::vector<uint8_t> gathered;                           // the block's reference images when rows are not in file order
         for (;;) {
             const uint32_t blk = next_block.fetch_add(1);
             if (blk >= n_blocks) break;
@@ -190,6 +208,11 @@ std::string run_dist(const DistOptions &opt)
                 if (!hll && !ull) N.resize(np);
                 if (hll || ull) U.resize(np);
                 const uint8_t *rblk = rimg.data() + (size_t)i0 * ib;
+                if (!opt.file_order) {
+                    gathered.resize((size_t)(i1 - i0) * ib);
+                    for (uint32_t i = i0; i < i1; ++i) memcpy(gathered.data() + (size_t)(i - i0) * ib, rimg.data() + (size_t)rorder[i] * ib, ib);
+                    rblk = gathered.data();
+                }
                 rc = hll ? lash_hll_pair_union_stats(ctx, prec, rblk, i1 - i0, qimg.data(), nq, C.data(), U.data())
                    : ull ? lash_ull_pair_union_estimates(ctx, prec, ull_est, rblk, i1 - i0, qimg.data(), nq, U.data())
                          : lash_hmh_pair_counts(ctx, rblk, i1 - i0, qimg.data(), nq, C.data(), N.data());
@@ -205,21 +228,25 @@ std::string run_dist(const DistOptions &opt)
                     const size_t row = (size_t)(i - i0) * nq;
                     std::vector<double> dist(nq);
                     uint64_t bad_pair = 0;
-                    const int drc = lash_dist_rows(algo_id, prec, k, opt.model, opt.fp32 ? 1 : 0, 1, nq, &rcard[i], qcard.data(),
+                    const uint32_t ri = rorder[i];
+                    const std::string &rname = rnames[ri];
+                    const uint32_t my_pos = !same_files ? 0 : opt.file_order ? i : qpos.at(rname);
+                    const int drc = lash_dist_rows(algo_id, prec, k, opt.model, opt.fp32 ? 1 : 0, 1, nq, &rcard[ri], qcard.data(),
                                                    ull ? nullptr : C.data() + row, (hll || ull) ? nullptr : N.data() + row,
                                                    (hll || ull) ? U.data() + row : nullptr, dist.data(), &bad_pair);
-                    if (drc == LASH_ERANGE) { row_fail[i - i0] = "union of " + rnames[i] + " and " + qnames[bad_pair] + bias_msg; return; }
+                    if (drc == LASH_ERANGE) { row_fail[i - i0] = "union of " + rname + " and " + qnames[bad_pair] + bias_msg; return; }
                     if (drc != LASH_OK) { row_fail[i - i0] = lash_strerror(drc); return; }
-                    for (uint32_t j = 0; j < nq; ++j) {
-                        if (same_files && j > i) continue;                                            // utils.rs:158-160
-                        const double d = qnames[j] == rnames[i] ? 0.0 : dist[j];                      // main.rs:452-453
+                    for (uint32_t jj = 0; jj < qorder.size(); ++jj) {
+                        if (same_files && jj > my_pos) continue;                                      // utils.rs:158-160
+                        const uint32_t j = qorder[jj];
+                        const double d = qnames[j] == rname ? 0.0 : dist[j];                          // main.rs:452-453
                         // "{:.6}" (main.rs:456,461): std::to_chars is correctly rounded like printf("%.6f") and several times faster
                         buf[0] = '\t';
                         char *end = std::to_chars(buf + 1, buf + sizeof buf - 2, d, std::chars_format::fixed, 6).ptr;
                         if (!opt.matrix) {
-                            text += rnames[i]; text += '\t'; text += qnames[j];
+                            text += rname; text += '\t'; text += qnames[j];
                             *end++ = '\n';
-                        } else if (first) { text += '\n'; text += rnames[i]; }
+                        } else if (first) { text += '\n'; text += rname; }
                         text.append(buf, end);
                         first = false;
                     }

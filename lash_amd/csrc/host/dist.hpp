@@ -13,6 +13,7 @@ struct DistOptions {
     int model = 1;          // 1 = Poisson: min(-ln(f)/k, 1); 0 = binomial: 1 - f^(1/k)   (main.rs:415-423)
     int threads = 1;
     bool fp32 = false, matrix = false;
+    bool file_order = false;   // rows / columns / triangle in list-file order instead of the reference's map order (name_order.hpp)
     int device = 0;
     std::vector<int> devices;  // --devices 0,1,...: one worker per entry, blocks of reference rows in turn; empty = {device}
     uint32_t block_rows = 0;   // reference rows per GPU call; 0 = as many as keep the pair tables under ~0.5 GB

@@ -8,6 +8,7 @@
 
 #include "fastx.hpp"
 #include "json_out.hpp"
+#include "name_order.hpp"
 #include "pgzip.hpp"
 #include "sketch_files.hpp"
 #include "zstd_dl.hpp"
@@ -54,6 +55,24 @@ char *lash_host_json_array(const char *items_nl, uint64_t n_items)
         p = e ? e + 1 : p + strlen(p);
     }
     return dup_str(json_pretty_string_array(v));
+}
+
+// name_order.hpp: XXH3-64 with a seed, and the hashbrown key order of '\n'-separated names (order_out holds n_items
+// slots; returns the number of distinct names written)
+uint64_t lash_host_xxh3_64(const uint8_t *p, uint64_t n, uint64_t seed) { return xxh3_64_seeded(p, n, seed); }
+
+uint64_t lash_host_name_order(const char *items_nl, uint64_t n_items, uint64_t seed, uint32_t *order_out)
+{
+    std::vector<std::string> v;
+    const char *p = items_nl;
+    for (uint64_t i = 0; i < n_items; ++i) {
+        const char *e = strchr(p, '\n');
+        v.emplace_back(p, e ? (size_t)(e - p) : strlen(p));
+        p = e ? e + 1 : p + strlen(p);
+    }
+    const std::vector<uint32_t> o = hashbrown_key_order(v, seed);
+    std::copy(o.begin(), o.end(), order_out);
+    return o.size();
 }
 
 // pgzip.hpp: inflates a (multi-member) gzip file with `threads` inflate threads, reading in `read_size` pieces.  Returns NULL and

@@ -3,7 +3,8 @@
 //   lash sketch -f LIST [-o sketch] [-k 16] [-t N] [-a hmh|hll|ull] [-p 10] [-s 42]        (main.rs:30-96, 180-279)
 //   lash dist   -q PREFIX -r PREFIX [-o dist] [-t N] [-e fgra|ml] [-m 1|0] [--fp32] [--dm]   (main.rs:107-176, 280-617)
 // Extras that do not exist upstream: --gpus N / --device D / --devices LIST (which GPUs to use, one worker each), --batch-mb M, --stream-mb M (files
-// larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low; dist: --device D, --block-rows N
+// larger than M MiB are streamed in chunks with on-device accumulation), --hmh-x-low; dist: --device D, --block-rows N,
+// --file-order (rows / columns in list-file order instead of the reference's seeded hash-map order)
 // (reference rows per GPU call); both: --layout SPEC (or $LASH_LAYOUT): the crate-internal rules as data, see `lash_layout`
 // in include/lash_gfx950.h.
 #include <chrono>
@@ -48,7 +49,8 @@ void usage()
             "      --gpus <n> | --device <d> | --devices <d,d,...>  GPUs to use, one worker each [default: device 0]\n"
             "dist options:\n"
             "  -q, --query <prefix>  -r, --reference <prefix>  -o, --output_file <name> [default: dist]\n"
-            "  -t, --threads <n>  -e, --estimator <fgra|ml>  -m, --model <1|0>  --fp32  --dm\n");
+            "  -t, --threads <n>  -e, --estimator <fgra|ml>  -m, --model <1|0>  --fp32  --dm\n"
+            "      --file-order   rows and columns in list-file order (default: the reference's hash-map key order)\n");
 }
 
 bool parse(int argc, char **argv, int first, const std::map<std::string, std::string> &alias,
@@ -156,7 +158,7 @@ int cmd_dist(int argc, char **argv)
     std::string err;
     const std::map<std::string, std::string> alias = {{"q", "query"}, {"r", "reference"}, {"o", "output_file"}, {"t", "threads"},
                                                       {"e", "estimator"}, {"m", "model"}};
-    if (!parse(argc, argv, 2, alias, {"fp32", "dm"}, a, err)) { fprintf(stderr, "error: %s\n", err.c_str()); return 2; }
+    if (!parse(argc, argv, 2, alias, {"fp32", "dm", "file-order"}, a, err)) { fprintf(stderr, "error: %s\n", err.c_str()); return 2; }
     if (!a.kv.count("query") || !a.kv.count("reference")) {
         fprintf(stderr, "error: the following required arguments were not provided:\n  --query <query>\n  --reference <reference>\n");
         return 2;
@@ -176,6 +178,7 @@ int cmd_dist(int argc, char **argv)
     opt.threads = (int)std::max<uint64_t>(1, threads);
     opt.fp32 = a.flags.count("fp32") != 0;
     opt.matrix = a.flags.count("dm") != 0;
+    opt.file_order = a.flags.count("file-order") != 0;
     opt.device = (int)dev;
     if (a.kv.count("devices")) {
         const std::string &l = a.kv["devices"];

@@ -56,6 +56,11 @@ def main():
             q = "refs" if same else "qry"
             cmd = [H.CLI, "dist", "-q", q, "-r", "refs", "-o", "d.txt", "-m", str(model), "-t", str(rng.choice([1, 3, 8]))]
             cmd += (["--fp32"] if fp32 else []) + (["--dm"] if matrix else []) + rng.choice([[], ["--block-rows", "2"]])
+            file_order = rng.random() < 0.4
+            cmd += ["--file-order"] if file_order else []
+            # rows / columns: list-file order, or the reference's seeded hash-map key order (name_order.hpp)
+            ro = list(range(len(paths))) if file_order else R.hashbrown_name_order(paths)
+            qo = ro if same else list(range(nq)) if file_order else R.hashbrown_name_order(paths[:nq])
             r = subprocess.run(cmd, cwd=td, capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
             text = open(os.path.join(td, "d.txt")).read()
@@ -68,20 +73,23 @@ def main():
             got = {}
             if matrix:
                 lines = text.split("\n")
-                assert lines[0] == "".join("\t" + x for x in paths), "matrix header"
-                for i, ln in enumerate(lines[1:]):
+                assert lines[0] == "".join("\t" + paths[j] for j in qo), "matrix header"
+                for a, ln in enumerate(lines[1:]):
                     cells = ln.split("\t")
-                    assert cells[0] == paths[i] and len(cells) == i + 2
-                    for j, d in enumerate(cells[1:]):
-                        got[(i, j)] = float(d)
-                want_pairs = [(i, j) for i in range(len(paths)) for j in range(i + 1)]
+                    assert cells[0] == paths[ro[a]] and len(cells) == a + 2
+                    for b, d in enumerate(cells[1:]):
+                        got[(ro[a], qo[b])] = float(d)
+                want_pairs = [(ro[a], ro[b]) for a in range(len(paths)) for b in range(a + 1)]
             else:
                 lines = text.strip().split("\n")
                 assert lines[0] == "Reference\tQuery\tDistance"
                 for ln in lines[1:]:
                     a, b, d = ln.split("\t")
                     got[(paths.index(a), paths.index(b))] = float(d)
-                want_pairs = [(i, j) for i in range(len(paths)) for j in range(i + 1)] if same else [(i, j) for i in range(len(paths)) for j in range(nq)]
+                want_pairs = [(ro[a], ro[b]) for a in range(len(paths)) for b in range(a + 1)] if same else [(i, j) for i in ro for j in qo]
+                if [(paths.index(ln.split("\t")[0]), paths.index(ln.split("\t")[1])) for ln in lines[1:]] != want_pairs:
+                    print("MISMATCH it=%d: row order differs" % it)
+                    sys.exit(1)
             if sorted(got) != sorted(want_pairs):
                 print("MISMATCH it=%d: pair set differs: %s vs %s" % (it, sorted(got), sorted(want_pairs)))
                 sys.exit(1)

@@ -34,6 +34,10 @@ def _load():
     lib.lash_host_pgzip_read.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.lash_host_zstd_read.restype = C.c_void_p
     lib.lash_host_zstd_read.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.lash_host_xxh3_64.restype = C.c_uint64
+    lib.lash_host_xxh3_64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
+    lib.lash_host_name_order.restype = C.c_uint64
+    lib.lash_host_name_order.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     return lib
 
 
@@ -116,3 +120,14 @@ def pgzip_read(path, threads, read_size=1 << 20):
     data = C.string_at(out.value, n.value)
     lib.lash_host_free(out)
     return data, int(counts[0]), int(counts[1])
+
+
+def xxh3_64(data: bytes, seed=0):
+    return int(lib.lash_host_xxh3_64(data, len(data), seed))
+
+
+def name_order(names, seed=93):
+    """indices into `names` in the order the reference's seeded hashbrown map yields its keys"""
+    out = (C.c_uint32 * max(len(names), 1))()
+    n = lib.lash_host_name_order("\n".join(names).encode(), len(names), seed, out)
+    return [int(out[i]) for i in range(n)]

@@ -359,3 +359,124 @@ def ull_ml(regs, p):
 
 def ull_merge(a, b):
     return bytes(ull_pack(ull_unpack(x) | ull_unpack(y)) if x and y else (x or y) for x, y in zip(a, b))
+
+
+# ---- hashbrown 0.15 RawTable, written out control byte by control byte (x86-64: 16-wide groups) -------------------
+# The host code (lash_amd/csrc/host/name_order.cpp) uses a simplified circular scan; this restatement keeps the
+# control array with its EMPTY padding and mirrored tail, group loads, fix_insert_slot and the resize policy as the
+# crate has them, so that the two formulations check each other.  /root/reference/src/utils.rs:111-127 builds
+# HashMap<&String, &Sketch, Xxh3Builder{seed: 93}>; Cargo.lock pins hashbrown 0.15.4.
+class HashbrownOrder:
+    WIDTH = 16
+    EMPTY = 0xFF
+
+    def __init__(self, hash_fn):
+        self.hash_fn = hash_fn
+        self.mask = 0                    # the static empty singleton: one bucket, no capacity
+        self.ctrl = [self.EMPTY] * (1 + self.WIDTH)
+        self.keys = [None]
+        self.vals = [None]
+        self.items = 0
+        self.growth_left = 0
+
+    @staticmethod
+    def _cap(mask):                      # bucket_mask_to_capacity
+        return mask if mask < 8 else (mask + 1) // 8 * 7
+
+    @staticmethod
+    def _buckets(cap):                   # capacity_to_buckets for 16-byte entries
+        if cap < 15:
+            cap = max(cap, 3)
+            return 4 if cap < 4 else 8 if cap < 8 else 16
+        adj = cap * 8 // 7
+        b = 1
+        while b < adj:
+            b <<= 1
+        return b
+
+    def _group(self, pos):
+        return self.ctrl[pos:pos + self.WIDTH]
+
+    def _set_ctrl(self, i, c):
+        i2 = ((i - self.WIDTH) & self.mask) + self.WIDTH
+        self.ctrl[i] = c
+        self.ctrl[i2] = c
+
+    def _fix(self, idx):                 # fix_insert_slot
+        if self.ctrl[idx] & 0x80 == 0:   # bucket is full: only possible when the table is smaller than a group
+            assert self.mask < self.WIDTH
+            g = self._group(0)
+            return next(b for b in range(self.WIDTH) if g[b] & 0x80)
+        return idx
+
+    def _probe(self, h, key):
+        """find_or_find_insert_slot_inner -> ('found', idx) or ('slot', idx)"""
+        tag = (h >> 57) & 0x7F
+        pos, stride, slot = h & self.mask, 0, None
+        while True:
+            g = self._group(pos)
+            for b in range(self.WIDTH):
+                if g[b] == tag:
+                    idx = (pos + b) & self.mask
+                    if self.keys[idx] == key:
+                        return "found", idx
+            if slot is None:
+                for b in range(self.WIDTH):
+                    if g[b] & 0x80:
+                        slot = (pos + b) & self.mask
+                        break
+            if slot is not None and any(c == self.EMPTY for c in g):
+                return "slot", self._fix(slot)
+            stride += self.WIDTH
+            pos = (pos + stride) & self.mask
+
+    def _find_insert_slot(self, h):
+        pos, stride = h & self.mask, 0
+        while True:
+            g = self._group(pos)
+            for b in range(self.WIDTH):
+                if g[b] & 0x80:
+                    return self._fix((pos + b) & self.mask)
+            stride += self.WIDTH
+            pos = (pos + stride) & self.mask
+
+    def _resize(self, capacity):
+        old = [(self.keys[i], self.vals[i]) for i in range(self.mask + 1) if self.ctrl[i] & 0x80 == 0]
+        buckets = self._buckets(capacity)
+        self.mask = buckets - 1
+        self.ctrl = [self.EMPTY] * (buckets + self.WIDTH)
+        self.keys = [None] * buckets
+        self.vals = [None] * buckets
+        self.growth_left = self._cap(self.mask) - self.items
+        for k, v in old:                 # full buckets in index order
+            h = self.hash_fn(k)
+            idx = self._find_insert_slot(h)
+            self._set_ctrl(idx, (h >> 57) & 0x7F)
+            self.keys[idx], self.vals[idx] = k, v
+
+    def insert(self, key, val):
+        h = self.hash_fn(key)
+        if self.growth_left < 1:         # reserve(1) comes before the lookup
+            self._resize(max(self.items + 1, self._cap(self.mask) + 1))
+        kind, idx = self._probe(h, key)
+        if kind == "found":
+            self.vals[idx] = val
+            return
+        self.growth_left -= 1            # the slot was EMPTY (nothing is ever deleted)
+        self._set_ctrl(idx, (h >> 57) & 0x7F)
+        self.keys[idx], self.vals[idx] = key, val
+        self.items += 1
+
+    def values_in_key_order(self):
+        return [self.vals[i] for i in range(self.mask + 1) if self.ctrl[i] & 0x80 == 0]
+
+
+def hashbrown_name_order(names, seed=93, hash_fn=None):
+    """indices of `names` in `.keys()` order of the reference's seeded map (Hash for str = bytes + 0xFF)"""
+    if hash_fn is None:
+        import xxhash
+        hash_fn = lambda s: xxhash.xxh3_64_intdigest(s.encode() + b"\xff", seed=seed)
+    t = HashbrownOrder(hash_fn)
+    for i, n in enumerate(names):
+        t.insert(n, i)
+    return t.values_in_key_order()

@@ -48,7 +48,7 @@ def test_two_ranks_on_one_gpu_equal_the_cli(tmp_path, algo, p, k, extra):
     assert "Distances computed." in r.stdout
     r = subprocess.run([H.CLI, "sketch", "-o", "one"] + args, cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([H.CLI, "dist", "-q", "one", "-r", "one", "-o", "one.tsv"] + extra, cwd=tmp_path, capture_output=True, text=True, env=env)
+    r = subprocess.run([H.CLI, "dist", "-q", "one", "-r", "one", "-o", "one.tsv", "--file-order"] + extra, cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr
     multi, one = (tmp_path / "multi.tsv").read_text(), (tmp_path / "one.tsv").read_text()
     assert multi == one                                          # same rows, same order (file order), same digits

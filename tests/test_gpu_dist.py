@@ -79,6 +79,9 @@ def test_lash_dist_cli_hmh(tmp_path, matrix, model, fp32):
             a, b, d = ln.split("\t")
             rows[frozenset((a, b))] = float(d)
         assert len(rows) == 5 * 6 // 2 and len(lines) - 1 == 15
+        # rows, and which name of a pair is the Reference, in the reference's map order (name_order.hpp)
+        order = R.hashbrown_name_order(paths)
+        assert [tuple(ln.split("\t")[:2]) for ln in lines[1:]] == [(paths[order[a]], paths[order[b]]) for a in range(5) for b in range(a + 1)]
         for i in range(5):
             for j in range(i + 1):
                 assert abs(rows[frozenset((paths[i], paths[j]))] - expected(i, j)) <= tol, (i, j)
@@ -87,10 +90,21 @@ def test_lash_dist_cli_hmh(tmp_path, matrix, model, fp32):
         d04 = rows[frozenset((paths[0], paths[4]))]
         assert 0 < d01 < rows[frozenset((paths[0], paths[2]))] < d03 <= d04 <= 1.0
     else:
+        order = R.hashbrown_name_order(paths)
         lines = text.split("\n")
-        assert lines[0] == "".join("\t" + p for p in paths)
+        assert lines[0] == "".join("\t" + paths[j] for j in order)
         assert len(lines) == 6 and not text.endswith("\n")
-        for i, ln in enumerate(lines[1:]):
+        for a, ln in enumerate(lines[1:]):
+            cells = ln.split("\t")
+            assert cells[0] == paths[order[a]] and len(cells) == a + 2
+            for b, d in enumerate(cells[1:]):
+                assert abs(float(d) - expected(order[a], order[b])) <= tol
+        # --file-order: the same numbers with rows and columns as the list file has them
+        r = subprocess.run([H.CLI, "dist", "-q", "refs", "-r", "refs", "-o", "d_fo.txt", "--file-order"] + flags, cwd=tmp_path, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        fo = (tmp_path / "d_fo.txt").read_text().split("\n")
+        assert fo[0] == "".join("\t" + p for p in paths)
+        for i, ln in enumerate(fo[1:]):
             cells = ln.split("\t")
             assert cells[0] == paths[i] and len(cells) == i + 2
             for j, d in enumerate(cells[1:]):
@@ -100,6 +114,8 @@ def test_lash_dist_cli_hmh(tmp_path, matrix, model, fp32):
     assert r.returncode == 0, r.stderr
     lines = (tmp_path / "d_qr.txt").read_text().strip().split("\n")
     assert len(lines) == 1 + 5 * 2
+    ro, qo = R.hashbrown_name_order(paths), R.hashbrown_name_order(paths[:2])
+    assert [tuple(ln.split("\t")[:2]) for ln in lines[1:]] == [(paths[i], paths[j]) for i in ro for j in qo]
     for ln in lines[1:]:
         a, b, d = ln.split("\t")
         assert abs(float(d) - R.mash_distance(R.hmh_similarity(imgs[paths.index(b)], imgs[paths.index(a)]), 16, model, a == b)) <= 1.1e-6
@@ -159,11 +175,13 @@ def test_lash_dist_cli_hll(tmp_path, matrix, model, p):
             a, b, d = ln.split("\t")
             got[frozenset((paths.index(a), paths.index(b)))] = float(d)
     else:
-        for i, ln in enumerate(text.split("\n")[1:]):
+        order = R.hashbrown_name_order(paths)
+        assert text.split("\n")[0] == "".join("\t" + paths[j] for j in order)
+        for a, ln in enumerate(text.split("\n")[1:]):
             cells = ln.split("\t")
-            assert cells[0] == paths[i] and len(cells) == i + 2
-            for j, d in enumerate(cells[1:]):
-                got[frozenset((i, j))] = float(d)
+            assert cells[0] == paths[order[a]] and len(cells) == a + 2
+            for b, d in enumerate(cells[1:]):
+                got[frozenset((order[a], order[b]))] = float(d)
     assert len(got) == 4 * 5 // 2
     for i in range(4):
         for j in range(i + 1):
@@ -251,11 +269,13 @@ def test_lash_dist_cli_ull(tmp_path, matrix, model, p, est):
             a, b, d = ln.split("\t")
             got[frozenset((paths.index(a), paths.index(b)))] = float(d)
     else:
-        for i, ln in enumerate(text.split("\n")[1:]):
+        order = R.hashbrown_name_order(paths)
+        assert text.split("\n")[0] == "".join("\t" + paths[j] for j in order)
+        for a, ln in enumerate(text.split("\n")[1:]):
             cells = ln.split("\t")
-            assert cells[0] == paths[i] and len(cells) == i + 2
-            for j, d in enumerate(cells[1:]):
-                got[frozenset((i, j))] = float(d)
+            assert cells[0] == paths[order[a]] and len(cells) == a + 2
+            for b, d in enumerate(cells[1:]):
+                got[frozenset((order[a], order[b]))] = float(d)
     assert len(got) == 4 * 5 // 2
     tol = 1.1e-6 if est == "fgra" else 1e-3
     for i in range(4):

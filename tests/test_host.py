@@ -328,3 +328,36 @@ def test_fastq_valid_prefix_is_needletails_rule():
                 else:                                            # a record cut short by the end of the file: '@' and '+' lines still in phase
                     assert fixed[got:] == b"@\n\n+\n"[:len(data) - got]
                 assert np.array_equal(O.sketch_files(O.HMH, 16, 0, 42, [fixed]), a)
+
+
+def test_xxh3_64_seeded_equals_python_xxhash():
+    """name_order.cpp's XXH3-64 against the python-xxhash module (an independent binding of the C library): every
+    length class (0, 1-3, 4-8, 9-16, 17-128, 129-240, > 240 incl. block boundaries) and the seeds that matter."""
+    xxhash = pytest.importorskip("xxhash")
+    rng = np.random.default_rng(11)
+    for n in list(range(0, 300)) + [511, 512, 513, 1023, 1024, 1025, 1087, 1088, 1089, 2048, 2049, 4097, 10_000]:
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for seed in (0, 93, 42, 2**64 - 1, 0x0123456789ABCDEF):
+            assert H.xxh3_64(data, seed) == xxhash.xxh3_64_intdigest(data, seed=seed), (n, seed)
+
+
+def test_name_order_equals_the_control_byte_restatement():
+    """The host's simplified table walk against tests/pyref.py's hashbrown restatement that keeps the control bytes,
+    group loads and fix_insert_slot: every table size from the empty singleton to 4096 buckets, with repeated names."""
+    pytest.importorskip("xxhash")
+    import pyref as R
+    rng = np.random.default_rng(12)
+    for n in [0, 1, 2, 3, 4, 5, 7, 8, 9, 14, 15, 16, 17, 28, 29, 30, 56, 57, 58, 112, 113, 300, 1000, 3500]:
+        for rep in range(3):
+            names = ["dir%d/genome_%d.fna.gz" % (int(rng.integers(0, 50)), int(rng.integers(0, 10**9))) for _ in range(n)]
+            if rep == 2 and n > 3:
+                for _ in range(n // 3):
+                    names[int(rng.integers(0, n))] = names[int(rng.integers(0, n))]
+            got = H.name_order(names)
+            assert got == R.hashbrown_name_order(names), (n, rep)
+            assert sorted(names[i] for i in got) == sorted(set(names))
+            last = {nm: i for i, nm in enumerate(names)}
+            assert all(last[names[i]] == i for i in got)           # a repeated name carries its last sketch
+    # nothing about the order is file order
+    names = ["g%03d.fa" % i for i in range(64)]
+    assert H.name_order(names) != list(range(64))

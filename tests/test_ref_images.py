@@ -119,6 +119,27 @@ def test_reference_dist_rows_equal_cli(tmp_path):
                 assert (ra, qa) == (rb, qb) and abs(float(da) - float(db)) <= 1e-6, (case["name"], key, a, b)
 
 
+@needs_ref
+def test_reference_map_order_equals_name_order():
+    """`dist --dm -t 1` of the real lash on the kit's 40 names: column order, row order and the triangle are the key
+    order lash_amd/csrc/host/name_order.cpp computes (XXH3-64 seed 93 + hashbrown 0.15 table walk).  CPU only."""
+    import host_lib as H
+    m = _manifest()
+    if "order" not in m:
+        pytest.skip("this kit run predates the map-order probe")
+    names = m["order"]["names"]
+    order = H.name_order(names)
+    lines = open(os.path.join(REF, m["order"]["dm"])).read().split("\n")
+    assert lines[0] == "".join("\t" + names[j] for j in order), "column order of --dm"
+    by_name = {ln.split("\t")[0]: ln.split("\t")[1:] for ln in lines[1:] if ln}
+    for a, j in enumerate(order):
+        assert len(by_name[names[j]]) == a + 1, "triangle: row %s" % names[j]
+    assert [ln.split("\t")[0] for ln in lines[1:] if ln] == [names[j] for j in order], "row order with one rayon thread"
+    if "rows" in m["order"]:
+        rows = open(os.path.join(REF, m["order"]["rows"])).read().splitlines()[1:]
+        assert sorted(tuple(r.split("\t")[:2]) for r in rows) == sorted((names[order[a]], names[order[b]]) for a in range(len(order)) for b in range(a + 1))
+
+
 def test_probe_kit_selftest():
     """The kit's search and report work: oracle-made images under a non-default layout are fitted back to a layout that
     reproduces them (tools/ref_probe/selftest.py).  Says nothing about lash itself."""

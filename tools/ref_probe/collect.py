@@ -29,7 +29,7 @@ def sorted_rows(path):
 
 def main(work, out):
     sys.path.insert(0, HERE)
-    from make_inputs import INPUTS
+    from make_inputs import INPUTS, ORDER_NAMES
     cases = []
     for line in open(os.path.join(HERE, "cases.tsv")):
         if line.startswith("#") or not line.strip():
@@ -59,6 +59,14 @@ def main(work, out):
                            "ultraloglog": "0.1.6", "xxhash-rust": "0.8.15", "needletail": "0.6.3"},
                 "inputs": INPUTS, "inputs_dir": "tests/golden (appendix_b.fasta: '>appendix_b' + ACGTTGCATGCATCGATCGGATTACA)",
                 "cases": cases}
+    # the map-order probe, verbatim (its order IS the datum)
+    od = os.path.join(work, "order")
+    if os.path.exists(os.path.join(od, "order.dm.raw")):
+        manifest["order"] = {"names": ORDER_NAMES}
+        for src, key in (("order.dm.raw", "dm"), ("order.rows.raw", "rows")):
+            if os.path.exists(os.path.join(od, src)):
+                shutil.copy(os.path.join(od, src), os.path.join(out, src.replace(".raw", ".txt")))
+                manifest["order"][key] = src.replace(".raw", ".txt")
     with open(os.path.join(out, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("wrote %d cases to %s" % (len(cases), out))

@@ -28,6 +28,14 @@ grep -v '^#' "$HERE/cases.tsv" | while IFS=$'\t' read -r name algo k p seed; do
       if [ "$algo" = ull ]; then "$LASH_BIN" dist -q "$name" -r "$name" -e ml -o "$name.dist_ml.raw" -t 2 >> dist.log 2>&1 || true; fi
     )
 done
+# map-order probe: 40 names; `dist --dm` prints its columns in the query map's key order, and with one rayon thread its
+# rows in the reference map's (utils.rs:111-160) — pins lash_amd/csrc/host/name_order.cpp
+d=$WORK/order; rm -rf "$d"; mkdir -p "$d"; cp "$WORK"/in_order/* "$d"/
+( cd "$d"
+  "$LASH_BIN" sketch -f list.txt -o order -a hmh -k 16 -t 2 > sketch.log 2>&1
+  "$LASH_BIN" dist -q order -r order --dm -t 1 -o order.dm.raw > dist.log 2>&1
+  "$LASH_BIN" dist -q order -r order -t 1 -o order.rows.raw >> dist.log 2>&1
+) || echo "map-order probe failed" >&2
 python3 "$HERE/collect.py" "$WORK" "$OUT"
 ( cd "$HERE/kmer_probe" && cargo +nightly run --release > "$OUT/kmer_probe.txt" 2> "$WORK/kmer_probe.err" ) || echo "kmer_probe did not build/run (optional)" >&2
 python3 "$HERE/fit_layout.py" "$OUT"
