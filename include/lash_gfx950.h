@@ -241,19 +241,31 @@ int lash_ull_pair_union_estimates(lash_ctx *ctx, int p, int estimator, const uin
 double lash_ull_estimate(const uint8_t *registers, int p, int estimator);
 
 /* ---- dist side, host arithmetic (no GPU): what is O(sketches) or O(pairs) in utils.rs:84-373 ------------------------------
- * Per-sketch cardinalities from the register bytes (no header): hyperminhash's LogLog-beta (`cardinality()`, utils.rs:170-173),
- * streaming_algorithms' `len()` (utils.rs:315; LASH_ERANGE in the bias-table regime), lash_ull_estimate above. */
+ * HLL++ empirical bias tables.  streaming_algorithms' `len()` (utils.rs:315, 355-363) subtracts, when its raw estimate is
+ * <= 5 * 2^p, the mean bias of the 6 nearest samples of a per-precision table of Monte-Carlo measurements (Heule et al. 2013,
+ * appendix; the crate carries them as constants).  The numbers are neither in /root/reference nor derivable, so they are NOT
+ * in this library: lash_hll_bias_load reads them from a text file ('#' comments; "p <p> <n>" then n lines "<raw> <bias>", any
+ * subset of p = 4..18) that tools/ref_probe/extract_hll_bias.py writes from the crate's source.  With `tables` NULL (or no
+ * table for p) that regime returns LASH_ERANGE instead of a different estimate. */
+typedef struct lash_hll_bias lash_hll_bias;
+int  lash_hll_bias_load(const char *path, lash_hll_bias **out);               /* LASH_EINVAL: cannot open; LASH_EFORMAT: malformed */
+int  lash_hll_bias_from_arrays(lash_hll_bias **inout, int p, const double *raw, const double *bias, uint32_t n);  /* *inout NULL: created */
+int  lash_hll_bias_has(const lash_hll_bias *tables, int p);
+void lash_hll_bias_free(lash_hll_bias *tables);
+/* Per-sketch cardinalities from the register bytes (no header): hyperminhash's LogLog-beta (`cardinality()`, utils.rs:170-173),
+ * streaming_algorithms' `len()` (utils.rs:315), lash_ull_estimate above. */
 double lash_hmh_cardinality(const uint8_t *registers, int big_endian);
-int    lash_hll_cardinality(const uint8_t *registers, int p, double *out);
+int    lash_hll_cardinality(const uint8_t *registers, int p, const lash_hll_bias *tables, double *out);
 /* The distance the reference prints for every pair of an [n_ref x n_qry] block, from the GPU's pair statistics and the
  * per-sketch cardinalities: similarity (hmh: C, N + expected-collision correction, utils.rs:164; hll: len() of the union from
  * zero / sum, utils.rs:355-362; ull: the union estimate, utils.rs:272) -> .max(0) -> 2s/(1+s) -> model 1: min(-ln(f)/k, 1),
  * model 0: 1 - f^(1/k) (main.rs:415-423), in f32 arithmetic when fp32 (main.rs --fp32).  The caller applies the
  * "same name -> 0" rule (main.rs:452-453).  hmh: c_or_zero = C, n_counts = N; hll: c_or_zero = zero, sum_or_union = sum;
- * ull: sum_or_union = union estimates.  LASH_ERANGE: a union fell into the HLL bias-table regime (*bad_pair = its index). */
+ * ull: sum_or_union = union estimates.  LASH_ERANGE: a union fell into the HLL bias-table regime and `tables` does not cover
+ * it (*bad_pair = its index). */
 int    lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, uint32_t n_qry, const double *ref_card,
                       const double *qry_card, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union,
-                      double *out_dist, uint64_t *bad_pair);
+                      const lash_hll_bias *tables, double *out_dist, uint64_t *bad_pair);
 
 /* Synthetic genomes of SURVEY.md §8(d) generated in HBM (bench / tests): genome ids first..first+n-1,
  * n_bases ASCII bytes each, written back to back at d_out. */

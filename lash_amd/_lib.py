@@ -83,8 +83,12 @@ PROTOTYPES = {
     "lash_ull_pair_union_estimates": (_int, [_vp, _int, _int, _vp, _u32, _vp, _u32, _vp]),
     "lash_ull_estimate": (C.c_double, [_vp, _int, _int]),
     "lash_hmh_cardinality": (C.c_double, [_vp, _int]),
-    "lash_hll_cardinality": (_int, [_vp, _int, C.POINTER(C.c_double)]),
-    "lash_dist_rows": (_int, [_int, _int, _int, _int, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "lash_hll_bias_load": (_int, [C.c_char_p, C.POINTER(_vp)]),
+    "lash_hll_bias_from_arrays": (_int, [C.POINTER(_vp), _int, _vp, _vp, _u32]),
+    "lash_hll_bias_has": (_int, [_vp, _int]),
+    "lash_hll_bias_free": (None, [_vp]),
+    "lash_hll_cardinality": (_int, [_vp, _int, _vp, C.POINTER(C.c_double)]),
+    "lash_dist_rows": (_int, [_int, _int, _int, _int, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),
 }
 

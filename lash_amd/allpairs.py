@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _lib
 from .shard import gather_images, shard_genomes
-from .sketch import ALGOS, Context, dist_rows, header_bytes, image_bytes, sketch_cardinality
+from .sketch import ALGOS, Context, HllBias, dist_rows, header_bytes, image_bytes, sketch_cardinality
 
 
 def row_block(n, rank, world):
@@ -31,8 +31,8 @@ def row_block(n, rank, world):
     return n * rank // world, n * (rank + 1) // world
 
 
-def cardinalities(algo, p, images, layout=None, estimator="fgra"):
-    return np.array([sketch_cardinality(algo, p, images[i], layout, estimator) for i in range(images.shape[0])], dtype=np.float64)
+def cardinalities(algo, p, images, layout=None, estimator="fgra", hll_bias=None):
+    return np.array([sketch_cardinality(algo, p, images[i], layout, estimator, hll_bias) for i in range(images.shape[0])], dtype=np.float64)
 
 
 def gpu_pair_stats(ctx, algo, p, estimator, ref, qry):
@@ -70,7 +70,7 @@ def gpu_pair_stats(ctx, algo, p, estimator, ref, qry):
 
 
 def all_vs_all(algo, p, k, local_images, counts, *, ctx=None, model=1, fp32=False, estimator="fgra", layout=None, group=None,
-               pair_stats=None, max_block_pairs=1 << 25):
+               pair_stats=None, max_block_pairs=1 << 25, hll_bias=None):
     """local_images: this rank's sketches, torch uint8 [counts[rank], image_bytes] (CUDA under nccl, CPU under gloo).
     Returns (r0, r1, dist) — float64 [r1 - r0, N]: this rank's rows of the distance matrix against ALL N sketches, before the
     "same name -> 0" rule.  pair_stats(algo, p, estimator, ref_block, all_images) -> dict of lash_dist_rows' arrays; default:
@@ -81,7 +81,7 @@ def all_vs_all(algo, p, k, local_images, counts, *, ctx=None, model=1, fp32=Fals
     n = every.shape[0]
     r0, r1 = row_block(n, rank, world)
     host = every.cpu().numpy() if every.is_cuda else every.numpy()
-    card = cardinalities(algo, p, host, layout, estimator)                   # O(N * registers) host work, every rank the same
+    card = cardinalities(algo, p, host, layout, estimator, hll_bias)                # O(N * registers) host work, every rank the same
     if pair_stats is None:
         if ctx is None:
             raise ValueError("all_vs_all needs a lash_amd.Context (the pair kernels have no CPU fallback) or an explicit pair_stats")
@@ -92,7 +92,7 @@ def all_vs_all(algo, p, k, local_images, counts, *, ctx=None, model=1, fp32=Fals
         b1 = min(r1, b0 + step)
         ref = every[b0:b1] if every.is_cuda else host[b0:b1]
         st = pair_stats(algo, p, estimator, ref, every if every.is_cuda else host)
-        out[b0 - r0:b1 - r0] = dist_rows(algo, p, k, model, card[b0:b1], card, fp32=fp32, **st)
+        out[b0 - r0:b1 - r0] = dist_rows(algo, p, k, model, card[b0:b1], card, fp32=fp32, hll_bias=hll_bias, **st)
     return r0, r1, out
 
 
@@ -134,6 +134,8 @@ def main(argv=None):
     ap.add_argument("--dm", action="store_true")
     ap.add_argument("--backend", default=None, help="nccl (one GPU per rank, default) or gloo (ranks may share a GPU; images gathered on the host)")
     ap.add_argument("--device", type=int, default=None, help="GPU of this rank (default LOCAL_RANK; with --backend gloo several ranks may name the same one)")
+    ap.add_argument("--hll-bias", default=os.environ.get("LASH_HLL_BIAS"), help="HLL++ bias tables (tools/ref_probe/extract_hll_bias.py); without them "
+                    "hll estimates <= 5 * 2^p are refused")
     args = ap.parse_args(argv)
     import torch
     import torch.distributed as dist
@@ -161,7 +163,7 @@ def main(argv=None):
     if backend == "nccl":
         local_images = local_images.cuda(device)
     r0, r1, block = all_vs_all(algo, p, args.kmer, local_images, [b - a for a, b in blocks], ctx=ctx, model=args.model, fp32=args.fp32,
-                               estimator=args.estimator)
+                               estimator=args.estimator, hll_bias=HllBias(args.hll_bias) if args.hll_bias else None)
     part = "%s.part%d" % (args.output_file, rank)
     with open(part, "w") as f:
         f.write(format_rows(names, r0, block, matrix=args.dm))

@@ -4,12 +4,18 @@
 // Reference: /root/reference/src/utils.rs:150-180 (hmh), 248-282 (ull), 342-369 (hll); main.rs:415-423 (distance).
 // Every estimator is restated from the published algorithm its crate ports [PARITY UNPINNED; tools/ref_probe]:
 //   hyperminhash 0.1.4      LogLog-beta cardinality + expected-collision correction of axiomhq/hyperminhash
-//   streaming_algorithms    HLL++ len(): linear counting below the per-precision threshold, else alpha m^2 / sum; the
-//                           bias-table regime (estimate <= 5m) is REFUSED (LASH_ERANGE): the tables are not in this image
+//   streaming_algorithms    HLL++ len(): linear counting below the per-precision threshold, else alpha m^2 / sum, minus
+//                           (estimate <= 5m) the mean bias of the 6 nearest raw estimates in the HLL++ empirical tables.
+//                           The tables are Monte-Carlo output that is not in this image or this repository: they come
+//                           from a file (lash_hll_bias_load; tools/ref_probe/extract_hll_bias.py writes it from the
+//                           crate's source), and WITHOUT them that regime is REFUSED (LASH_ERANGE), never approximated
 //   ultraloglog 0.1.6       FGRA / ML (ull_estimators.h)
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 #include "../../include/lash_gfx950.h"
 #include "lash_common.h"
@@ -75,7 +81,37 @@ double hll_alpha(int p)
     }
 }
 
-bool hll_len(int p, uint64_t zero, double sum, double &out)
+}  // namespace
+
+// p = 4..18: raw estimate -> bias samples, as the HLL++ appendix publishes them (rawEstimateData / biasData)
+struct lash_hll_bias {
+    std::vector<double> raw[15], bias[15];
+};
+
+namespace {
+
+// estimate_bias: mean bias of the 6 samples whose raw estimate is nearest to e (squared distance, ties to the lower
+// index, summed nearest first)
+bool hll_estimate_bias(const lash_hll_bias *t, int p, double e, double &out)
+{
+    if (!t || t->raw[p - 4].size() < 6) return false;
+    const std::vector<double> &raw = t->raw[p - 4], &bias = t->bias[p - 4];
+    std::pair<double, size_t> best[7];
+    size_t n = 0;
+    for (size_t i = 0; i < raw.size(); ++i) {
+        const double d = (e - raw[i]) * (e - raw[i]);
+        size_t at = n;
+        while (at > 0 && d < best[at - 1].first) { best[at] = best[at - 1]; --at; }   // strict <: an equal distance stays behind the lower index
+        if (at < 6) best[at] = {d, i};
+        if (n < 6) ++n;
+    }
+    double s = 0.0;
+    for (size_t j = 0; j < 6; ++j) s += bias[best[j].second];
+    out = s / 6.0;
+    return true;
+}
+
+bool hll_len(int p, uint64_t zero, double sum, const lash_hll_bias *tables, double &out)
 {
     const double m = (double)(1u << p);
     if (zero > 0) {
@@ -83,7 +119,12 @@ bool hll_len(int p, uint64_t zero, double sum, double &out)
         if (h <= HLL_THRESHOLD[p - 4]) { out = h; return true; }
     }
     const double e = hll_alpha(p) * m * m / sum;
-    if (e <= 5.0 * m) return false;                                  // bias-corrected regime: tables absent
+    if (e <= 5.0 * m) {                                              // bias-corrected regime
+        double b;
+        if (!hll_estimate_bias(tables, p, e, b)) return false;       // tables absent: refuse
+        out = e - b;
+        return true;
+    }
     out = e;
     return true;
 }
@@ -115,7 +156,52 @@ double lash_hmh_cardinality(const uint8_t *regs, int big_endian)
     return alpha * m * (m - ez) / (hmh_beta(ez) + sum);
 }
 
-int lash_hll_cardinality(const uint8_t *regs, int p, double *out)
+// Text format: '#' comment lines; "p <p> <n>" then n lines "<raw estimate> <bias>", for any subset of p = 4..18.
+int lash_hll_bias_load(const char *path, lash_hll_bias **out)
+{
+    if (!path || !out) return LASH_EINVAL;
+    *out = nullptr;
+    FILE *f = fopen(path, "r");
+    if (!f) return LASH_EINVAL;
+    lash_hll_bias *t = new lash_hll_bias();
+    char line[512];
+    int cur = -1;
+    long left = 0;
+    bool ok = true;
+    while (ok && fgets(line, sizeof line, f)) {
+        const char *s = line;
+        while (*s == ' ' || *s == '\t') ++s;
+        if (*s == '#' || *s == '\n' || *s == '\r' || *s == 0) continue;
+        if (*s == 'p') {
+            int p = 0; long n = 0;
+            ok = left == 0 && sscanf(s + 1, "%d %ld", &p, &n) == 2 && p >= 4 && p <= 18 && n >= 6 && n < (1l << 20) && t->raw[p - 4].empty();
+            cur = p; left = n;
+        } else {
+            double r, b;
+            ok = cur >= 4 && left > 0 && sscanf(s, "%lf %lf", &r, &b) == 2;
+            if (ok) { t->raw[cur - 4].push_back(r); t->bias[cur - 4].push_back(b); --left; }
+        }
+    }
+    fclose(f);
+    if (!ok || left != 0 || cur < 0) { delete t; return LASH_EFORMAT; }
+    *out = t;
+    return LASH_OK;
+}
+
+int lash_hll_bias_from_arrays(lash_hll_bias **inout, int p, const double *raw, const double *bias, uint32_t n)
+{
+    if (!inout || !raw || !bias || p < 4 || p > 18 || n < 6) return LASH_EINVAL;
+    if (!*inout) *inout = new lash_hll_bias();
+    (*inout)->raw[p - 4].assign(raw, raw + n);
+    (*inout)->bias[p - 4].assign(bias, bias + n);
+    return LASH_OK;
+}
+
+void lash_hll_bias_free(lash_hll_bias *t) { delete t; }
+
+int lash_hll_bias_has(const lash_hll_bias *t, int p) { return t && p >= 4 && p <= 18 && t->raw[p - 4].size() >= 6 ? 1 : 0; }
+
+int lash_hll_cardinality(const uint8_t *regs, int p, const lash_hll_bias *tables, double *out)
 {
     if (!regs || !out || p < 4 || p > 16) return LASH_EINVAL;
     uint32_t hist[256] = {0};
@@ -123,12 +209,12 @@ int lash_hll_cardinality(const uint8_t *regs, int p, double *out)
     double sum = 0.0;
     for (int r = 255; r >= 0; --r)
         if (hist[r]) sum += (double)hist[r] * std::ldexp(1.0, -r);      // exact powers of two, largest exponent first
-    return hll_len(p, hist[0], sum, *out) ? LASH_OK : LASH_ERANGE;
+    return hll_len(p, hist[0], sum, tables, *out) ? LASH_OK : LASH_ERANGE;
 }
 
 int lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, uint32_t n_qry, const double *ref_card,
                    const double *qry_card, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union,
-                   double *out_dist, uint64_t *bad_pair)
+                   const lash_hll_bias *tables, double *out_dist, uint64_t *bad_pair)
 {
     if (k < 1 || k > 32 || (model != 0 && model != 1) || !ref_card || !qry_card || !out_dist) return LASH_EINVAL;
     if (algo == LASH_HMH ? (!c_or_zero || !n_counts) : algo == LASH_HLL ? (!c_or_zero || !sum_or_union || p < 4 || p > 16)
@@ -140,7 +226,7 @@ int lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, 
             double sim = 0.0;
             if (algo == LASH_HLL) {                                                               // utils.rs:352-365
                 double u;
-                if (!hll_len(p, c_or_zero[at], sum_or_union[at], u)) { if (bad_pair) *bad_pair = at; return LASH_ERANGE; }
+                if (!hll_len(p, c_or_zero[at], sum_or_union[at], tables, u)) { if (bad_pair) *bad_pair = at; return LASH_ERANGE; }
                 sim = (ref_card[i] + qry_card[j] - u) / u;
             } else if (algo == LASH_ULL) {                                                        // utils.rs:256-274
                 const double u = sum_or_union[at];

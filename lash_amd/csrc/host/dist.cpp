@@ -142,8 +142,14 @@ std::string run_dist(const DistOptions &opt)
     const uint32_t nr = (uint32_t)rorder.size(), nq = (uint32_t)qnames.size();   // rows: map entries; columns of the pair tables: every query image
 
     std::vector<double> rcard(nr), qcard(nq);
-    const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which "
-                           "this build does not have (sketch with a smaller -p)";
+    const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which are "
+                           "not built in (pass --hll-bias <file from tools/ref_probe/extract_hll_bias.py>, or sketch with a smaller -p)";
+    lash_hll_bias *bias = nullptr;
+    if (hll && !opt.hll_bias_file.empty()) {
+        const int brc = lash_hll_bias_load(opt.hll_bias_file.c_str(), &bias);
+        if (brc != LASH_OK) return "cannot read HLL++ bias tables from " + opt.hll_bias_file + ": " + lash_strerror(brc);
+    }
+    struct BiasGuard { lash_hll_bias *b; ~BiasGuard() { lash_hll_bias_free(b); } } bias_guard{bias};
     // per-sketch cardinalities (utils.rs:101-103, 213-217, 314-315), on `-t` host threads
     auto cards = [&](const std::vector<uint8_t> &img, const std::vector<std::string> &names, std::vector<double> &card) -> std::string {
         const uint32_t n = (uint32_t)names.size();
@@ -154,7 +160,7 @@ std::string run_dist(const DistOptions &opt)
                 const uint8_t *regs = img.data() + (size_t)i * ib + hdr;
                 if (ull) card[i] = lash_ull_estimate(regs, prec, ull_est);
                 else if (!hll) card[i] = lash_hmh_cardinality(regs, opt.layout.hmh_reg_be != 0);
-                else if (lash_hll_cardinality(regs, prec, &card[i]) != LASH_OK) bad[i] = 1;
+                else if (lash_hll_cardinality(regs, prec, bias, &card[i]) != LASH_OK) bad[i] = 1;
             }
         };
         std::vector<std::thread> pool;
@@ -233,7 +239,7 @@ std::string run_dist(const DistOptions &opt)
                     const uint32_t my_pos = !same_files ? 0 : opt.file_order ? i : qpos.at(rname);
                     const int drc = lash_dist_rows(algo_id, prec, k, opt.model, opt.fp32 ? 1 : 0, 1, nq, &rcard[ri], qcard.data(),
                                                    ull ? nullptr : C.data() + row, (hll || ull) ? nullptr : N.data() + row,
-                                                   (hll || ull) ? U.data() + row : nullptr, dist.data(), &bad_pair);
+                                                   (hll || ull) ? U.data() + row : nullptr, bias, dist.data(), &bad_pair);
                     if (drc == LASH_ERANGE) { row_fail[i - i0] = "union of " + rname + " and " + qnames[bad_pair] + bias_msg; return; }
                     if (drc != LASH_OK) { row_fail[i - i0] = lash_strerror(drc); return; }
                     for (uint32_t jj = 0; jj < qorder.size(); ++jj) {

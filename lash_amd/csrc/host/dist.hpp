@@ -17,6 +17,7 @@ struct DistOptions {
     int device = 0;
     std::vector<int> devices;  // --devices 0,1,...: one worker per entry, blocks of reference rows in turn; empty = {device}
     uint32_t block_rows = 0;   // reference rows per GPU call; 0 = as many as keep the pair tables under ~0.5 GB
+    std::string hll_bias_file; // --hll-bias / $LASH_HLL_BIAS: HLL++ bias tables (lash_hll_bias_load); empty = that regime is refused
     lash_layout layout;        // --layout / $LASH_LAYOUT (include/lash_gfx950.h)
     DistOptions() { lash_layout_default(&layout); }
 };

@@ -50,7 +50,9 @@ void usage()
             "dist options:\n"
             "  -q, --query <prefix>  -r, --reference <prefix>  -o, --output_file <name> [default: dist]\n"
             "  -t, --threads <n>  -e, --estimator <fgra|ml>  -m, --model <1|0>  --fp32  --dm\n"
-            "      --file-order   rows and columns in list-file order (default: the reference's hash-map key order)\n");
+            "      --file-order   rows and columns in list-file order (default: the reference's hash-map key order)\n"
+            "      --hll-bias <file>  HLL++ bias tables (tools/ref_probe/extract_hll_bias.py) [default: $LASH_HLL_BIAS];\n"
+            "                     without them hll estimates <= 5 * 2^p are refused\n");
 }
 
 bool parse(int argc, char **argv, int first, const std::map<std::string, std::string> &alias,
@@ -179,6 +181,8 @@ int cmd_dist(int argc, char **argv)
     opt.fp32 = a.flags.count("fp32") != 0;
     opt.matrix = a.flags.count("dm") != 0;
     opt.file_order = a.flags.count("file-order") != 0;
+    if (a.kv.count("hll-bias")) opt.hll_bias_file = a.kv["hll-bias"];
+    else if (const char *e = getenv("LASH_HLL_BIAS")) opt.hll_bias_file = e;
     opt.device = (int)dev;
     if (a.kv.count("devices")) {
         const std::string &l = a.kv["devices"];

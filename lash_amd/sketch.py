@@ -13,9 +13,44 @@ ALGOS = {"hmh": _lib.HMH, "hll": _lib.HLL, "ull": _lib.ULL}
 ULL_ESTIMATORS = {"fgra": 0, "ml": 1}
 
 
-def sketch_cardinality(algo, p, image, layout=None, estimator="fgra"):
+class HllBias:
+    """HLL++ empirical bias tables (include/lash_gfx950.h: lash_hll_bias).  They are not part of this repository: load the
+    text file tools/ref_probe/extract_hll_bias.py writes, or build from arrays (tests).  Without them the estimate <= 5 * 2^p
+    regime of streaming_algorithms' len() is refused with ERANGE."""
+
+    def __init__(self, path=None):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        if path is not None:
+            rc = self._lib.lash_hll_bias_load(str(path).encode(), C.byref(self._h))
+            if rc != _lib.OK:
+                raise LashError(rc, "%s: %s" % (path, self._lib.lash_strerror(rc).decode()))
+
+    def set(self, p, raw, bias):
+        r = np.ascontiguousarray(raw, dtype=np.float64)
+        b = np.ascontiguousarray(bias, dtype=np.float64)
+        assert r.shape == b.shape and r.ndim == 1
+        rc = self._lib.lash_hll_bias_from_arrays(C.byref(self._h), int(p), r.ctypes.data, b.ctypes.data, len(r))
+        if rc != _lib.OK:
+            raise LashError(rc, self._lib.lash_strerror(rc).decode())
+        return self
+
+    def has(self, p):
+        return bool(self._lib.lash_hll_bias_has(self._h, int(p)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lash_hll_bias_free(self._h)
+            self._h = C.c_void_p()
+
+
+def _bias_handle(hll_bias):
+    return None if hll_bias is None else hll_bias._h
+
+
+def sketch_cardinality(algo, p, image, layout=None, estimator="fgra", hll_bias=None):
     """Distinct-count estimate of ONE serialized sketch, as `lash dist` computes it per sketch (utils.rs:101-103, 213-217, 314-315):
-    hmh LogLog-beta, hll `len()` (LashError(ERANGE) in the bias-table regime), ull FGRA / ML.  Host only."""
+    hmh LogLog-beta, hll `len()` (LashError(ERANGE) in the bias-table regime unless `hll_bias` covers p), ull FGRA / ML.  Host only."""
     lib = _lib.load()
     a = _algo(algo)
     lay = parse_layout(layout)
@@ -26,13 +61,13 @@ def sketch_cardinality(algo, p, image, layout=None, estimator="fgra"):
     if a == _lib.ULL:
         return float(lib.lash_ull_estimate(regs.ctypes.data, int(p), ULL_ESTIMATORS[estimator]))
     out = C.c_double()
-    rc = lib.lash_hll_cardinality(regs.ctypes.data, int(p), C.byref(out))
+    rc = lib.lash_hll_cardinality(regs.ctypes.data, int(p), _bias_handle(hll_bias), C.byref(out))
     if rc != _lib.OK:
         raise LashError(rc, lib.lash_strerror(rc).decode())
     return out.value
 
 
-def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=None, sum_or_union=None, fp32=False):
+def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=None, sum_or_union=None, fp32=False, hll_bias=None):
     """The distances the reference prints for an [n_ref, n_qry] block, from the GPU's pair statistics and the per-sketch
     cardinalities (lash_dist_rows; utils.rs:164-167, 272-278, 355-365 + main.rs:415-423).  numpy in, float64 [n_ref, n_qry] out."""
     lib = _lib.load()
@@ -46,7 +81,7 @@ def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=No
     bad = C.c_uint64()
     rc = lib.lash_dist_rows(_algo(algo), int(p or 0), int(k), int(model), 1 if fp32 else 0, nr, nq, rc_.ctypes.data, qc_.ctypes.data,
                             None if a is None else a.ctypes.data, None if b is None else b.ctypes.data,
-                            None if d is None else d.ctypes.data, out.ctypes.data, C.byref(bad))
+                            None if d is None else d.ctypes.data, _bias_handle(hll_bias), out.ctypes.data, C.byref(bad))
     if rc != _lib.OK:
         raise LashError(rc, lib.lash_strerror(rc).decode() + (" (pair %d)" % bad.value if rc == _lib.ERANGE else ""))
     return out

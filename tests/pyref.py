@@ -233,8 +233,21 @@ def hll_alpha(p: int) -> float:
     return {4: 0.673, 5: 0.697, 6: 0.709}.get(p, 0.7213 / (1.0 + 1.079 / (1 << p)))
 
 
-def hll_len_from_regs(p: int, regs) -> float:
-    """None when the estimate falls into the bias-corrected regime (tables not available)."""
+def hll_estimate_bias(tables, p: int, e: float):
+    """streaming_algorithms' estimate_bias: mean bias of the 6 samples of the HLL++ table for p whose raw estimate is
+    nearest to e (squared distance; equal distances in table order).  tables = {p: (raw list, bias list)}."""
+    if not tables or p not in tables:
+        return None
+    raw, bias = tables[p]
+    near = sorted(range(len(raw)), key=lambda i: ((e - raw[i]) * (e - raw[i]), i))[:6]
+    s = 0.0
+    for i in near:
+        s += bias[i]
+    return s / 6.0
+
+
+def hll_len_from_regs(p: int, regs, tables=None) -> float:
+    """None when the estimate falls into the bias-corrected regime and `tables` has nothing for p."""
     m = float(1 << p)
     zero = sum(1 for r in regs if r == 0)
     if zero:
@@ -242,13 +255,16 @@ def hll_len_from_regs(p: int, regs) -> float:
         if h <= HLL_THRESHOLD[p - 4]:
             return h
     e = hll_alpha(p) * m * m / math.fsum(2.0 ** -int(r) for r in regs)
-    return None if e <= 5.0 * m else e
+    if e <= 5.0 * m:
+        b = hll_estimate_bias(tables, p, e)
+        return None if b is None else e - b
+    return e
 
 
-def hll_similarity(p: int, a: bytes, b: bytes) -> float:
+def hll_similarity(p: int, a: bytes, b: bytes, tables=None) -> float:
     ra, rb = a[33:], b[33:]
-    la, lb = hll_len_from_regs(p, ra), hll_len_from_regs(p, rb)
-    u = hll_len_from_regs(p, [max(x, y) for x, y in zip(ra, rb)])
+    la, lb = hll_len_from_regs(p, ra, tables), hll_len_from_regs(p, rb, tables)
+    u = hll_len_from_regs(p, [max(x, y) for x, y in zip(ra, rb)], tables)
     return max((la + lb - u) / u, 0.0)
 
 

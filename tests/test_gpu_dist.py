@@ -199,7 +199,55 @@ def test_lash_dist_hll_refuses_the_bias_table_regime(tmp_path):
     for algo, pre in (("hll", "sm"),):
         r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "l.txt"), "-o", pre, "-a", algo, "-p", "14"], cwd=tmp_path, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr
+    env.pop("LASH_HLL_BIAS", None)
     r = subprocess.run([H.CLI, "dist", "-q", "sm", "-r", "sm"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "bias tables" in r.stderr
+
+
+@pytest.mark.parametrize("via", ["flag", "env"])
+def test_lash_dist_hll_small_range_with_tables(tmp_path, via):
+    """The same regime WITH tables (--hll-bias / $LASH_HLL_BIAS): 6-nearest-neighbour bias subtracted from the raw estimate,
+    per sketch and per union (utils.rs:315, 355-363).  The tables here are synthetic — the real ones are external data
+    (tools/ref_probe/extract_hll_bias.py) — so this checks the mechanism against tests/pyref.py, not the numbers of HLL++."""
+    p, k = 14, 21
+    m = float(1 << p)
+    rng = np.random.default_rng(8)
+    raw = np.sort(rng.uniform(0.7 * m, 5.0 * m, 200))
+    bias = 0.6 * m * np.exp(-(raw - 0.7 * m) / m)
+    tables = {p: (raw.tolist(), bias.tolist())}
+    with open(tmp_path / "bias.txt", "w") as f:
+        f.write("# synthetic\np %d %d\n" % (p, len(raw)) + "".join("%r %r\n" % (float(a), float(b)) for a, b in zip(raw, bias)))
+    base = O.synth_genome(31, 40_000)                              # ~40 k distinct 21-mers: between the linear-counting threshold and 5m
+    genomes = [base, _mutated(base, 0.01, 1), _mutated(base, 0.05, 2), O.synth_genome(32, 30_000)]
+    paths = []
+    for i, g in enumerate(genomes):
+        f = tmp_path / ("s%d.fa" % i)
+        f.write_bytes(b">s\n" + g.tobytes() + b"\n")
+        paths.append(str(f))
+    (tmp_path / "l.txt").write_text("\n".join(paths) + "\n")
+    env = dict(os.environ)
+    env.pop("LASH_HLL_BIAS", None)
+    r = subprocess.run([H.CLI, "sketch", "-f", "l.txt", "-o", "sm", "-a", "hll", "-p", str(p), "-k", str(k)], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    imgs = [O.sketch_genomes(O.HLL, k, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0].tobytes() for g in genomes]
+    assert all(R.hll_len_from_regs(p, im[33:]) is None for im in imgs)            # every sketch is in the refused regime without tables
+    cmd = [H.CLI, "dist", "-q", "sm", "-r", "sm", "-o", "d.txt"]
+    if via == "flag":
+        cmd += ["--hll-bias", "bias.txt"]
+    else:
+        env["LASH_HLL_BIAS"] = str(tmp_path / "bias.txt")
+    r = subprocess.run(cmd, cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    rows = (tmp_path / "d.txt").read_text().strip().split("\n")[1:]
+    assert len(rows) == 4 * 5 // 2
+    for ln in rows:
+        a, b, d = ln.split("\t")
+        i, j = paths.index(a), paths.index(b)
+        want = R.mash_distance(R.hll_similarity(p, imgs[i], imgs[j], tables), k, 1, i == j)
+        assert abs(float(d) - want) <= 1.1e-6, (i, j)
+    # a malformed table file is an error, not a silent fallback
+    (tmp_path / "broken.txt").write_text("p 14 200\n1 2\n")
+    r = subprocess.run([H.CLI, "dist", "-q", "sm", "-r", "sm", "--hll-bias", "broken.txt"], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "bias tables" in r.stderr
 
 

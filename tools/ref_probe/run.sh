@@ -16,6 +16,14 @@ if [ -z "${LASH_BIN:-}" ]; then
 fi
 "$LASH_BIN" --version | tail -1 > "$WORK/lash_version.txt" || true
 
+# HLL++ bias tables: streaming_algorithms' source is unpacked in the cargo registry once lash-rs has been built; without
+# them `lash dist` of this repository refuses HyperLogLog estimates <= 5 * 2^p (the hll_p14_k21 case below is in that regime)
+for reg in "${CARGO_HOME:-$HOME/.cargo}"/registry/src/*/streaming_algorithms-0.3.3 ${STREAMING_ALGORITHMS_SRC:-}; do
+    [ -d "$reg" ] || continue
+    python3 "$HERE/extract_hll_bias.py" "$reg" "$OUT/hllpp_bias.txt" && break || echo "no bias tables found in $reg" >&2
+done
+[ -f "$OUT/hllpp_bias.txt" ] || echo "HLL++ bias tables not extracted (set STREAMING_ALGORITHMS_SRC=<crate dir>): hll small-range rows stay refused" >&2
+
 python3 "$HERE/make_inputs.py" "$WORK/in"
 grep -v '^#' "$HERE/cases.tsv" | while IFS=$'\t' read -r name algo k p seed; do
     [ -n "$name" ] || continue
