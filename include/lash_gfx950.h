@@ -186,6 +186,16 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
  * Either way the indices of those files (of the last raw call) are available here: returns how many, copies up to `cap`.
  * The first byte of a file must be '>' or '@' (parse_fastx_file fails otherwise, utils.rs:453): LASH_EINVAL from both. */
 uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap);
+
+/* HyperLogLog images carry `sum` = sum_j 2^-m[j] (f64).  streaming_algorithms keeps it incrementally per k-mer (sum -= 2^-old;
+ * sum += 2^-new); that is exactly the sum over the final registers as long as every register is <= 53 - p, and the HIP path
+ * writes that sum.  A register above 53 - p (one k-mer in 2^(52-p): p = 14 -> 1 in 2.7e11) makes the incremental value depend
+ * on the order of its f64 roundings — it can differ from the correctly rounded sum written here by the terms below the
+ * 2^(p-53) grid (< 2^(p-52) absolute, ~1e-14 relative: the low bits of those 8 header bytes); registers, `zero` and every
+ * other byte are unaffected.  This call synchronizes the context's stream and lists
+ * the genomes of the LAST HyperLogLog sketch call that are in that corner (indices into that call's genomes; returns how many,
+ * writes at most `cap`).  tests/test_gpu_hll_corner.py holds k-mers that reach it. */
+uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32_t cap);
 /* Host-side twin for callers that want needletail's FASTQ rules in full before the bytes go to the device (the `lash` CLI
  * does this in its reader threads, ~4 GB/s per thread): the length of the longest prefix of `buf` that is a sequence of
  * well-formed records — '@' header, sequence, '+' line, quality of EQUAL length (CR stripped); the last record may lack its

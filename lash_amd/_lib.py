@@ -67,6 +67,7 @@ PROTOTYPES = {
     "lash_sketch_files_raw": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
     "lash_sketch_files_raw_device": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
     "lash_ctx_format_errors": (_u32, [_vp, _vp, _u32]),
+    "lash_ctx_hll_inexact_sums": (_u32, [_vp, _vp, _u32]),
     "lash_fastq_valid_prefix": (_u64, [_vp, _u64]),
     "lash_fastq_neutralise_tail": (None, [_vp, _u64]),
     "lash_pack_device": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),

@@ -247,7 +247,7 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
     if (!err.empty()) return err;
     if (!buf.reserve(chunk_bytes + 64)) return "out of pinned host memory";
     size_t have = 0;                                      // bytes at the front of buf carried from the previous chunk
-    bool first = true, eof = false;
+    bool first = true, eof = false, corner_noted = false;
     int fmt = 0;
     while (!eof) {
         while (have < chunk_bytes) {
@@ -277,6 +277,11 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
             const int rc = lash_sketch_files_raw(ctx, &prm, buf.p, off, &f, 1, image);
             if (rc != LASH_OK) return std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
             first = false;
+            if (prm.algo == LASH_HLL && !corner_noted && lash_ctx_hll_inexact_sums(ctx, nullptr, 0) != 0) {
+                corner_noted = true;      // registers only grow: once above 53 - p the final image is, too
+                fprintf(stderr, "note: %s: a HyperLogLog register exceeds 53 - p; the header's sum field is the exact sum and may differ "
+                                "from lash's incrementally rounded value in its last bits\n", path.c_str());
+            }
             // a malformed FASTQ record ends needletail's iteration (utils.rs:457): the library kept this chunk's records
             // before it; nothing after it belongs to the sketch
             if (lash_ctx_format_errors(ctx, nullptr, 0) != 0) return "";
@@ -355,6 +360,15 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                     int r2 = lash_sketch_files_raw(ctx, &prm, b->buf->p, b->file_off.data(), b->fmt.data(), ng, b->images.data());
                     mark("GPU done, batch", b->index, std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count());
                     if (r2 != LASH_OK) b->err = std::string(lash_strerror(r2)) + " " + lash_ctx_last_error(ctx);
+                    else if (prm.algo == LASH_HLL) {
+                        // a register above 53 - p: the image's `sum` field is the exact sum, the reference's incrementally
+                        // rounded one may differ in its last bits (include/lash_gfx950.h: lash_ctx_hll_inexact_sums)
+                        std::vector<uint32_t> idx(ng);
+                        const uint32_t nc = lash_ctx_hll_inexact_sums(ctx, idx.data(), ng);
+                        for (uint32_t i = 0; i < nc && i < ng; ++i)
+                            fprintf(stderr, "note: %s: a HyperLogLog register exceeds 53 - p; the header's sum field is the exact sum and may "
+                                            "differ from lash's incrementally rounded value in its last bits\n", files[b->f0 + idx[i]].c_str());
+                    }
                 }
             }
             std::lock_guard<std::mutex> lk(qmu);

@@ -120,6 +120,8 @@ struct lash_ctx {
     unsigned slot_next = 0;
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
+    DevBuf hll_flags;                    // [hll_flags_n] per genome of the last HyperLogLog sketch call: a register > 53 - p
+    uint32_t hll_flags_n = 0;            // (lash_ctx_hll_inexact_sums)
     std::vector<uint32_t> bad_files;     // lash_ctx_format_errors(): files of the last raw call whose FASTQ structure broke
     uint32_t raw_files_pending = 0;      // files of a lash_sketch_files_raw_device call whose error flags have not been read yet
     // direct-mode feedback: the dirty-tile count of the last direct call comes back through a pinned word, is looked at
@@ -600,6 +602,13 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     sa.nreg32 = plan.nreg32 >> plan.parts_log2;                 // register words of one pass
     sa.k = prm->k;
     sa.p = prm->p;
+    ctx->hll_flags_n = 0;
+    if (prm->algo == LASH_HLL) {                                // which genomes end with a register above 53 - p (write_hll_header)
+        if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
+        sa.hll_corner = static_cast<uint32_t *>(ctx->hll_flags.ptr);
+        ctx->hll_flags_n = n_genomes;
+    }
     if (pk->direct) {
         sa.seq = pk->d_seq;
         sa.brk_bytes = static_cast<const uint32_t *>(pk->brk_bytes.ptr);
@@ -637,6 +646,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.parts_log2 = plan.parts_log2;
     fa.lay = sa.lay;
     fa.src_images = 0;
+    fa.hll_corner = sa.hll_corner;
     // one finalize workgroup walks all of a genome's partials: fine for a handful of slices, 20 ms for the 4 096 slices of
     // a metagenome-sized input (BASELINE configs[4]) -> fold groups of 32 slices first (until <= 16 heads remain)
     fa.group = 0;
@@ -823,7 +833,7 @@ void lash_ctx_destroy(lash_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->item_kmers, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
-                      &ctx->st_img})
+                      &ctx->st_img, &ctx->hll_flags})
         release(*b);
     {
         lash_packed &sc = ctx->scratch;
@@ -1136,6 +1146,22 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
     ctx->cur_ev = nullptr;
     if (rc == LASH_OK) ctx->raw_files_pending = n_files;
     return rc;
+}
+
+uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32_t cap)
+{
+    if (!ctx || !ctx->hll_flags_n || !ctx->hll_flags.ptr) return 0;
+    (void)hipSetDevice(ctx->device);
+    std::vector<uint32_t> fl(ctx->hll_flags_n);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(fl.data(), ctx->hll_flags.ptr, fl.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        ctx->err = "lash_ctx_hll_inexact_sums: reading the flags failed";
+        return 0;
+    }
+    uint32_t n = 0;
+    for (uint32_t g = 0; g < fl.size(); ++g)
+        if (fl[g]) { if (genome_index && n < cap) genome_index[n] = g; ++n; }
+    return n;
 }
 
 uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap)

@@ -30,6 +30,7 @@ struct SketchArgs {
                                   // deleted bytes); [n_genomes] = how many.  Non-direct launches with dirty != NULL run only these
     uint32_t         *nslow;      // [n_genomes] wave-tiles of the direct pass that met deleted bytes (budget: sketch_kernels.hip)
     uint32_t         *ndel;       // [n_genomes] bytes the direct pass deleted in place (surviving bases = nvalid - ndel while !dirty)
+    uint32_t         *hll_corner; // NULL or [n_genomes], see FinalizeArgs (genomes whose one work item writes the image itself)
     uint64_t          bitflip;    // xxh3 seed-folded constant (64- or 128-bit variant by algo)
     LayoutDev         lay;
     uint32_t          partial_stride;
@@ -75,6 +76,8 @@ struct FinalizeArgs {
     int             accumulate;          // union into the registers already in images[]
     uint32_t        parts_log2;          // see SketchPlan: a partial holds only the registers of its item's pass
     LayoutDev       lay;
+    uint32_t       *hll_corner;          // NULL, or [n_genomes] zeroed: set when a genome holds a HyperLogLog register > 53 - p
+                                         // (write_hll_header, sketch_kernels.hip)
     int             src_images;          // the "partials" are images (lash_merge_images): HMH registers in image byte order
     uint32_t        group;               // 0, or G: launch_reduce_groups() has folded every G consecutive slices (per
                                          // pass) into the first one's partial; only those group heads are read

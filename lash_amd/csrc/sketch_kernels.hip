@@ -312,14 +312,22 @@ __device__ __noinline__ void write_header(uint8_t *img, uint64_t tpl, uint64_t a
         }
     }
 }
-// HLL: zero and sum are recomputed from the final registers' histogram; sum = sum_j 2^-m[j] is exact in f64 here (largest
-// exponent first), equal to the reference's incremental f64 updates.
-__device__ __forceinline__ void write_hll_header(uint8_t *img, uint64_t tpl, const uint32_t *hist, uint64_t alpha_bits, int p)
+// HLL: zero and sum are recomputed from the final registers' histogram.  The reference keeps `sum` incrementally
+// (sum -= 2^-old; sum += 2^-new per k-mer).  While every register is <= 53 - p each of those
+// updates is exact — sum < 2^p after the first one and every term is a multiple of 2^(p-53), so nothing ever needs more
+// than 53 bits — and the incremental value IS sum_j 2^-m[j], which the histogram gives exactly in any order.  A register
+// above 53 - p (one k-mer in 2^(52-p)) brings terms below the grid: the reference's value then depends on the order of
+// its roundings, the one here is the correctly rounded exact sum; `corner` reports the genome (lash_ctx_hll_inexact_sums).
+__device__ __forceinline__ void write_hll_header(uint8_t *img, uint64_t tpl, const uint32_t *hist, uint64_t alpha_bits, int p,
+                                                 uint32_t *corner)
 {
     double sum = 0.0;
-    for (int r = 66; r >= 0; --r) {
+    uint32_t above = 0;
+    for (int r = 71; r >= 0; --r) {
         if (hist[r]) sum += (double)hist[r] * __longlong_as_double((long long)(1023 - r) << 52);
+        if (r > 53 - p) above |= hist[r];
     }
+    if (corner && above) *corner = 1u;
     write_header(img, tpl, alpha_bits, 1ull << p, hist[0], sum, p);
 }
 // HyperMinHash registers travel as native little-endian u16 pairs; images may hold them big-endian (layout.hmh_reg_be)
@@ -761,7 +769,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             put(i, regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24));
         if (sole) {
             __syncthreads();
-            if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p);
+            if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
         }
     } else {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
@@ -896,7 +904,7 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
     }
     if constexpr (ALGO == 1) {
         __syncthreads();
-        if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, a.p);
+        if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, a.p, a.hll_corner ? a.hll_corner + g : nullptr);
     } else {
         if (threadIdx.x == 0 && hdr) write_header(img, a.lay.hdr_tpl, a.alpha_bits, ALGO == 0 ? HMH_M : (1ull << a.p), 0, 0.0, ALGO == 0 ? HMH_P : a.p);
     }

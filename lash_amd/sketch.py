@@ -322,6 +322,14 @@ class Context:
         self._lib.lash_ctx_format_errors(self._h, idx, n)
         return [int(idx[i]) for i in range(n)]
 
+    def hll_inexact_sums(self):
+        """genomes of the last HyperLogLog sketch call with a register above 53 - p (include/lash_gfx950.h:
+        lash_ctx_hll_inexact_sums); synchronizes the stream"""
+        n = int(self._lib.lash_ctx_hll_inexact_sums(self._h, None, 0))
+        idx = (C.c_uint32 * max(n, 1))()
+        self._lib.lash_ctx_hll_inexact_sums(self._h, idx, n)
+        return [int(idx[i]) for i in range(n)]
+
     def sketch_batch_device(self, algo, k, p, seed, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, d_out,
                             flags=0):
         """Device-resident records in, device images out; asynchronous on the context's stream."""

@@ -1,0 +1,117 @@
+"""The one known corner where the HIP path's HyperLogLog image can differ from the reference's by construction: the `sum`
+field when a register exceeds 53 - p (include/lash_gfx950.h: lash_ctx_hll_inexact_sums).
+
+streaming_algorithms updates `sum` per k-mer in f64; up to 53 - p every update is exact, so the histogram sum the kernels
+write IS the reference's value (all other tests).  Above it the incremental value depends on rounding order.  A k-mer that
+gets there turns up once per 2^(52-p) hashes; tools/find_hll_corner.py found the ones below with the sketch kernel itself
+(seed 42, k = 21; profiles/r02/hll_corner_kmers.txt).  What is asserted here:
+  * the oracle (which restates the incremental rule) agrees these k-mers have rank 38..40;
+  * registers, `zero` and every byte outside `sum` are identical between the HIP path and the oracle, on every route;
+  * the HIP path's `sum` is the correctly rounded exact sum, the genome is reported, clean genomes are not;
+  * the divergence is real (a case where the oracle's incremental value differs is pinned) and bounded by the sub-grid
+    terms themselves: < 2^(p-52) absolute, ~1e-14 relative."""
+import struct
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CORNER = {  # k-mer -> rank (= leading zeros of the hash above the bucket bits + 1), the same for p = 14 and p = 16
+    "CTGAGTGTGTCAGGCGTCATT": 40,
+    "CGCTCAGTTGGAACGGTGCTT": 39,
+    "CACCATGCTATGTGCATGACC": 40,
+    "TTACGAATCATAAGGTCGATA": 38,
+}
+
+
+def _oracle(p, g):
+    return O.sketch_genomes(O.HLL, 21, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0]
+
+
+def _exact_sum(regs):
+    s = sum(Fraction(1, 1 << int(r)) for r in regs)
+    return float(s)                                  # Fraction -> float is correctly rounded
+
+
+def test_corner_kmers_reach_the_stated_rank_in_the_oracle():
+    for km, rho in CORNER.items():
+        for p in (14, 16):
+            img = _oracle(p, np.frombuffer(km.encode(), np.uint8))
+            assert int(img[33:].max()) == rho and int((img[33:] != 0).sum()) == 1
+
+
+@pytest.mark.parametrize("p", [14, 16])
+@pytest.mark.parametrize("where", ["first", "middle"])
+@pytest.mark.parametrize("size", [30_000, 3_000_000])          # one work item writes the image / slices + finalize
+def test_corner_genomes_match_the_oracle_outside_sum_and_are_reported(p, where, size):
+    import lash_amd
+    kms = [km for km, rho in CORNER.items() if rho > 53 - p]
+    assert kms
+    genomes = []
+    for i, km in enumerate(kms):
+        rest = O.synth_genome(900 + i, size)
+        kb = np.frombuffer(km.encode(), np.uint8)
+        genomes.append(np.concatenate([kb, rest]) if where == "first" else np.concatenate([rest[:size // 2], kb, rest[size // 2:]]))
+    genomes.append(O.synth_genome(950, size))                                  # a clean one between them
+    genomes.insert(1, O.synth_genome(951, size // 3))
+    corner_idx = [i for i, g in enumerate(genomes) if any(km.encode() in g.tobytes() for km in kms)]
+    recs = [[g.tobytes()] for g in genomes]
+    seq, off, goff = lash_amd.records_to_arrays(recs)
+    want = np.stack([_oracle(p, g) for g in genomes])
+    with lash_amd.Context(0) as ctx:
+        for flags in (0, lash_amd.F_NO_DIRECT):
+            got = ctx.sketch_batch("hll", 21, p, 42, seq, off, goff, flags=flags)
+            assert ctx.hll_inexact_sums() == corner_idx
+            assert np.array_equal(got[:, :16], want[:, :16]) and np.array_equal(got[:, 24:], want[:, 24:])   # all but `sum`
+            for i in range(len(genomes)):
+                gs = struct.unpack("<d", got[i, 16:24].tobytes())[0]
+                ws = struct.unpack("<d", want[i, 16:24].tobytes())[0]
+                assert gs == _exact_sum(got[i, 33:])                                           # correctly rounded exact sum
+                if i not in corner_idx:
+                    assert gs == ws                                                             # outside the corner: bit-identical
+                else:
+                    assert abs(gs - ws) <= 2.0 ** -(52 - p)              # at most the few terms that sit below the 2^(p-53) grid
+        # a call without such genomes reports nothing
+        s2, o2, g2 = lash_amd.records_to_arrays([[genomes[-1].tobytes()]])
+        ctx.sketch_batch("hll", 21, p, 42, s2, o2, g2)
+        assert ctx.hll_inexact_sums() == []
+        ctx.sketch_batch("ull", 21, 12, 42, s2, o2, g2)
+        assert ctx.hll_inexact_sums() == []
+
+
+def test_the_divergence_is_real():
+    """p = 14, the rank-40 k-mer first: the reference's first update is 16383 + 2^-40, a tie that rounds to even and drops the
+    term; 300 kbp later the sum is ~650 and 2^-40 is representable, so the exact sum (what the HIP path writes) has it."""
+    import lash_amd
+    g = np.concatenate([np.frombuffer(b"CTGAGTGTGTCAGGCGTCATT", np.uint8), O.synth_genome(5, 300_000)])
+    want = _oracle(14, g)
+    seq, off, goff = lash_amd.records_to_arrays([[g.tobytes()]])
+    with lash_amd.Context(0) as ctx:
+        got = ctx.sketch_batch("hll", 21, 14, 42, seq, off, goff)
+        assert ctx.hll_inexact_sums() == [0]
+    gs = struct.unpack("<d", got[0, 16:24].tobytes())[0]
+    ws = struct.unpack("<d", want[16:24].tobytes())[0]
+    assert gs == _exact_sum(got[0, 33:]) and gs - ws == 2.0 ** -40
+    assert np.array_equal(got[0, 24:], want[24:]) and np.array_equal(got[0, :16], want[:16])
+
+
+def test_cli_notes_the_corner(tmp_path):
+    import os
+    import subprocess
+    import host_lib as H
+    g = np.concatenate([np.frombuffer(b"CTGAGTGTGTCAGGCGTCATT", np.uint8), O.synth_genome(5, 300_000)])
+    (tmp_path / "c.fa").write_bytes(b">c\n" + g.tobytes() + b"\n")
+    (tmp_path / "d.fa").write_bytes(b">d\n" + O.synth_genome(6, 100_000).tobytes() + b"\n")
+    (tmp_path / "l.txt").write_text("d.fa\nc.fa\n")
+    for extra in ([], ["--stream-mb", "0"]):
+        r = subprocess.run([H.CLI, "sketch", "-f", "l.txt", "-o", "h", "-a", "hll", "-p", "14", "-k", "21"] + extra, cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        notes = [ln for ln in r.stderr.splitlines() if ln.startswith("note:")]
+        assert len(notes) == 1 and "c.fa" in notes[0] and "53 - p" in notes[0], r.stderr
+        imgs = np.frombuffer(H.zstd_read(str(tmp_path / "h_sketches.bin")), np.uint8).reshape(2, -1)
+        assert np.array_equal(imgs[0], _oracle(14, O.synth_genome(6, 100_000)))
+        assert np.array_equal(imgs[1, 24:], _oracle(14, g)[24:])
