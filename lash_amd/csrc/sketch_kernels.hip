@@ -159,6 +159,11 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
         uint32_t bit, one;
         if constexpr (FAST) {
             bit = ffbh_u32(th) + (uint32_t)p - 1u;                           // valid when th != 0
+            if constexpr (MASKED) {                                           // th == 0 or an invalid k-mer (vm == 0) -> push nothing:
+                asm("v_min3_u32 %0, %1, 1, %2" : "=v"(one) : "v"(th), "v"(vm));   // one instruction for both conditions
+                regs.bor(idx * 2u + ((bit >> 5) & 1u), one << (bit & 31u));
+                return th;
+            }
             one = th < 1u ? th : 1u;                                          // th == 0 -> push nothing
         } else {
             const uint32_t tl = (hl << p) | pm_of(p);
