@@ -360,3 +360,24 @@ def test_async_host_entry_overlaps_and_matches(ctx):
         s0, o0, g0 = batches[0]
         want = O.merge_images(ALGO[an], p, oracle_images(ALGO[an], k, p, 42, s0, o0, g0)[0], oracle_images(ALGO[an], k, p, 42, s1, o1, g1)[0])
         assert np.array_equal(acc[0], want)
+
+
+@pytest.mark.parametrize("flags", [0, 4])                  # direct route / F_NO_DIRECT
+def test_runs_of_empty_and_tiny_records_share_break_words(ctx, flags):
+    """Many record starts inside one 32-byte stretch: runs of empty records (any number of starts at ONE position) and
+    1..3-base records.  The break bitmap of the direct route is written one word per "head" record looking 32 records
+    ahead, with an atomic fallback beyond that (brk_bytes_kernel): both branches, at word boundaries too."""
+    import lash_amd
+    rng = random.Random(4242)
+    acgt = lambda n: bytes(rng.choice(b"ACGT") for _ in range(n))
+    gs = []
+    for n_empty in (1, 30, 31, 32, 33, 64, 200):
+        gs.append([acgt(100 + n_empty)] + [b""] * n_empty + [acgt(90)] + [b""] * (n_empty // 2) + [acgt(3), acgt(40)])
+    gs.append([acgt(rng.choice([0, 1, 1, 2, 3, 20])) for _ in range(400)])                 # starts packed 1-3 bytes apart
+    gs.append([acgt(31)] + [acgt(1)] * 70 + [acgt(64)] + [b""] * 40 + [acgt(1)] * 33 + [acgt(25)])
+    gs.append([b""] * 50 + [acgt(60)] + [b""] * 50)                                        # empty records first and last
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    for an, k, p in (("hmh", 16, 0), ("ull", 5, 10), ("hll", 21, 12), ("hmh", 2, 0)):
+        got = ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=flags)
+        want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
+        assert_same(got, want, "%s k=%d flags=%d" % (an, k, flags))
