@@ -1,5 +1,5 @@
 #!/bin/bash
-OUT=gpurun_out/${1:-r02_longfuzz}; mkdir -p $OUT
+OUT=gpurun_out/${1:-gpu_longfuzz}; mkdir -p $OUT
 S=${2:-101}
 for f in "fuzz_gpu.py 1500 $S" "fuzz_gpu_raw.py 800 $((S+1))" "fuzz_gpu_cli.py 100 $((S+2))" "fuzz_gpu_stream.py 60 $((S+3))" "fuzz_gpu_dist.py 30 $((S+4))"; do
     set -- $f
