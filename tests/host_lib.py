@@ -34,6 +34,13 @@ def _load():
     lib.lash_host_pgzip_read.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.lash_host_zstd_read.restype = C.c_void_p
     lib.lash_host_zstd_read.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.lash_host_gunzip.restype = C.c_void_p
+    lib.lash_host_gunzip.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.lash_host_gunzip_windowed.restype = C.c_void_p
+    lib.lash_host_gunzip_windowed.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint64)]
+    lib.lash_host_crc32.restype = C.c_uint32
+    lib.lash_host_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64]
     lib.lash_host_xxh3_64.restype = C.c_uint64
     lib.lash_host_xxh3_64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
     lib.lash_host_name_order.restype = C.c_uint64
@@ -131,3 +138,29 @@ def name_order(names, seed=93):
     out = (C.c_uint32 * max(len(names), 1))()
     n = lib.lash_host_name_order("\n".join(names).encode(), len(names), seed, out)
     return [int(out[i]) for i in range(n)]
+
+
+def gunzip(data: bytes) -> bytes:
+    """inflate_fast.hpp: every member of a gzip image (raises ValueError with the decoder's message)"""
+    out, n = C.c_void_p(), C.c_uint64()
+    err = lib.lash_host_gunzip(data, len(data), C.byref(out), C.byref(n))
+    if err:
+        raise ValueError(_take_str(err))
+    res = C.string_at(out.value, n.value)
+    lib.lash_host_free(out)
+    return res
+
+
+def gunzip_windowed(data: bytes, window=4096, piece=1000):
+    """(bytes of the FIRST member, compressed bytes consumed) through the bounded-memory sequential reader"""
+    out, n, used = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    err = lib.lash_host_gunzip_windowed(data, len(data), window, piece, C.byref(out), C.byref(n), C.byref(used))
+    if err:
+        raise ValueError(_take_str(err))
+    res = C.string_at(out.value, n.value)
+    lib.lash_host_free(out)
+    return res, int(used.value)
+
+
+def crc32(data: bytes, crc=0) -> int:
+    return int(lib.lash_host_crc32(crc, data, len(data)))

@@ -361,3 +361,37 @@ def test_name_order_equals_the_control_byte_restatement():
     # nothing about the order is file order
     names = ["g%03d.fa" % i for i in range(64)]
     assert H.name_order(names) != list(range(64))
+
+
+def test_gzip_reader_padding_fallback_and_zlib_only(tmp_path):
+    """(i) bytes after the last member that do not start a member end the data — with 1 or many threads alike, and through
+    the whole-file reader; (ii) when the fast decoder gives a member up midway (simulated), zlib takes it over from the
+    member's start and the caller sees every byte exactly once; (iii) LASH_NO_FAST_INFLATE reads the same bytes with zlib."""
+    import gzip
+    import subprocess
+    import sys
+    rng = np.random.default_rng(21)
+    parts = [bytes(np.frombuffer(b"ACGT\n", np.uint8)[rng.integers(0, 5, size=n)]) for n in (700_000, 5, 9_000_000, 123_456)]
+    want = b"".join(parts)
+    multi = b"".join(gzip.compress(p, 6) for p in parts)
+    single = gzip.compress(want, 4)
+    for name, data in (("multi", multi), ("single", single)):
+        (tmp_path / (name + ".gz")).write_bytes(data)
+        (tmp_path / (name + "_padded.gz")).write_bytes(data + b"\x00" * 1024)
+    for name in ("multi", "single", "multi_padded", "single_padded"):
+        for threads in (1, 4):
+            got, _, _ = H.pgzip_read(str(tmp_path / (name + ".gz")), threads, 1 << 18)
+            assert got == want, (name, threads)
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); import host_lib as H\n"
+            "for name in ('multi', 'single'):\n"
+            "    for threads in (1, 4):\n"
+            "        for rs in (4097, 1 << 20):\n"
+            "            d, p, s = H.pgzip_read(%r + '/' + name + '.gz', threads, rs)\n"
+            "            assert d == open(%r, 'rb').read(), (name, threads, rs)\n"
+            "print('same')\n" % (here, str(tmp_path), str(tmp_path / "want.bin")))
+    (tmp_path / "want.bin").write_bytes(want)
+    for env in ({"LASH_TEST_FAST_INFLATE_FAIL_AFTER": "0"}, {"LASH_TEST_FAST_INFLATE_FAIL_AFTER": "100000"},
+                {"LASH_TEST_FAST_INFLATE_FAIL_AFTER": "5000000", "LASH_PGZIP_MEMBER_CAP": "1000000"}, {"LASH_NO_FAST_INFLATE": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=os.path.dirname(here), **env))
+        assert r.returncode == 0 and "same" in r.stdout, (env, r.stderr[-2000:])

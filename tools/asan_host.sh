@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/asan_host.sh — the C++ host side (FASTX / gzip / zstd readers, parallel gzip, FASTQ validation, name order, JSON) built
-# with AddressSanitizer + UBSan and driven through tests/test_host.py.  CPU only (sanitizers are not available on the GPU pool;
+# with AddressSanitizer + UBSan and driven through tests/test_host.py and tests/test_inflate.py (the DEFLATE decoder sees truncated and corrupted streams there).  CPU only (sanitizers are not available on the GPU pool;
 # this file is listed in .gpurunignore).  The HIP library itself is linked as built: only the host objects are instrumented.
 set -euo pipefail
 REPO=$(cd "$(dirname "$0")/.." && pwd)
@@ -17,4 +17,4 @@ g++ -O1 -g -std=c++17 -fPIC -Wall -pthread -fsanitize=address,undefined -fno-omi
 cd "$REPO"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \
 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 LASH_HOST_LIB="$OUT/liblash_host.so" \
-    python3 -m pytest tests/test_host.py -x -q -p no:cacheprovider "$@"
+    python3 -m pytest tests/test_host.py tests/test_inflate.py -x -q -p no:cacheprovider "$@"
