@@ -9,6 +9,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <utility>
 
 namespace lashhost {
 
@@ -61,6 +62,7 @@ struct ByteSink {                      // contiguous growable output (realloc; t
     ByteSink &operator=(const ByteSink &) = delete;
     bool reserve(size_t want);
     void release();
+    void swap(ByteSink &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(limit, o.limit); }
 };
 const char *gunzip_members(const uint8_t *src, size_t n, ByteSink &out, bool one_member, size_t *consumed);
 

@@ -76,12 +76,25 @@ struct ParallelGzip::Impl {
     std::deque<std::shared_ptr<Member>> todo;
     std::vector<std::thread> pool;
     size_t buffered = 0;
+    // buffers of consumed members, handed to the next worker with their pages still mapped: a 300 MB member in a fresh
+    // allocation is 80 000 page faults, and 16 workers faulting at once queue up in the kernel (measured: the parallel
+    // reader got SLOWER with the faster decoder until the buffers were recycled)
+    std::vector<std::unique_ptr<ByteSink>> spare;
     uint64_t scanned_to = 0;
     bool stop = false;
     // the member currently being served from a worker's buffer
     std::shared_ptr<Member> cur;
     size_t cur_at = 0;
     uint64_t n_par = 0, n_seq = 0;
+
+    void recycle(ByteSink &b)                      // call with mu held
+    {
+        if (!b.p) return;
+        if (spare.size() >= (size_t)threads + 2) { b.release(); return; }
+        spare.emplace_back(new ByteSink());
+        spare.back()->swap(b);
+        spare.back()->n = 0;
+    }
 
     void scan_candidates()                         // call with mu held
     {
@@ -120,12 +133,19 @@ struct ParallelGzip::Impl {
                 todo.pop_front();
                 if (m->start < pos) { m->state = 3; continue; }       // the reader has passed it: a false candidate
                 m->state = 1;
+                if (!spare.empty()) {                                 // the largest spare buffer
+                    size_t best = 0;
+                    for (size_t i = 1; i < spare.size(); ++i) if (spare[i]->cap > spare[best]->cap) best = i;
+                    m->data.swap(*spare[best]);
+                    spare.erase(spare.begin() + best);
+                }
             }
             const size_t used = inflate_member(map + m->start, size - m->start, m->data, member_cap());   // (only this worker touches m->data)
             {
                 std::lock_guard<std::mutex> lk(mu);
-                if (used) { m->end = m->start + used; m->state = 2; buffered += m->data.n; }
-                else m->state = 3;
+                // (a candidate the reader has meanwhile passed was a false one: its bytes must not count as buffered)
+                if (used && m->start >= pos) { m->end = m->start + used; m->state = 2; buffered += m->data.n; }
+                else { m->state = 3; recycle(m->data); }
             }
             cv_done.notify_all();
         }
@@ -189,10 +209,11 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
                 I.buffered -= I.cur->data.n;
                 I.pos = I.cur->end;
                 I.members.erase(I.cur->start);
+                I.recycle(I.cur->data);
                 // candidates the finished member ran over were false
                 while (!I.members.empty() && I.members.begin()->first < I.pos) {
                     auto m = I.members.begin()->second;
-                    if (m->state == 2) I.buffered -= m->data.n;
+                    if (m->state == 2) { I.buffered -= m->data.n; I.recycle(m->data); }
                     I.members.erase(I.members.begin());
                 }
                 I.cur.reset();
@@ -209,7 +230,7 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
                 I.pos = end;
                 while (!I.members.empty() && I.members.begin()->first < I.pos) {
                     auto m = I.members.begin()->second;
-                    if (m->state == 2) I.buffered -= m->data.n;
+                    if (m->state == 2) { I.buffered -= m->data.n; I.recycle(m->data); }
                     I.members.erase(I.members.begin());
                 }
                 I.scan_candidates();

@@ -237,69 +237,197 @@ size_t find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry
     return 0;                                             // no FASTQ record boundary in the second half
 }
 
+// lash_fastq_valid_prefix over a chunk of hundreds of MiB on several threads.  Well-formedness composes: if a piece is valid
+// through its very end, validating the next piece from there is exactly what the sequential scan would do next.  So the
+// chunk (which starts at a record) is split at guessed record starts ('@' opening a line whose second next line opens with
+// '+'), the pieces are checked concurrently, and only if one of them stops short — a malformed record, or a guess that was no
+// record start — the scan is redone sequentially from that piece's start.  The result equals the one-thread result always;
+// the guess only decides how often the slow path runs (never, on real data).  ~4-8 GB/s per thread: on one thread this was
+// the serial bottleneck of a streamed FASTQ.gz once the members inflated in parallel.
+uint64_t fastq_valid_prefix_mt(const uint8_t *b, uint64_t n, int threads)
+{
+    if (threads <= 1 || n < (32u << 20)) return lash_fastq_valid_prefix(b, n);
+    auto line_end = [&](uint64_t p) { const void *e = memchr(b + p, '\n', n - p); return e ? (uint64_t)((const uint8_t *)e - b) : n; };
+    std::vector<uint64_t> start{0};
+    for (int t = 1; t < threads; ++t) {
+        uint64_t q = n / (uint64_t)threads * (uint64_t)t;
+        const uint64_t stop = std::min<uint64_t>(n, q + (16u << 20));
+        uint64_t found = 0;
+        for (; q < stop; ++q) {
+            if (b[q] != '@' || b[q - 1] != '\n') continue;
+            const uint64_t e1 = line_end(q);
+            if (e1 >= n) break;
+            const uint64_t e2 = line_end(e1 + 1);
+            if (e2 + 1 >= n) break;
+            if (b[e2 + 1] == '+') { found = q; break; }
+        }
+        if (found > start.back()) start.push_back(found);
+    }
+    start.push_back(n);
+    const size_t pieces = start.size() - 1;
+    if (pieces < 2) return lash_fastq_valid_prefix(b, n);
+    std::vector<uint64_t> ok(pieces, 0);
+    std::vector<std::thread> pool;
+    for (size_t i = 1; i < pieces; ++i)
+        pool.emplace_back([&, i] { ok[i] = lash_fastq_valid_prefix(b + start[i], start[i + 1] - start[i]); });
+    ok[0] = lash_fastq_valid_prefix(b, start[1]);
+    for (auto &t : pool) t.join();
+    for (size_t i = 0; i < pieces; ++i)
+        if (ok[i] < start[i + 1] - start[i]) return start[i] + lash_fastq_valid_prefix(b + start[i], n - start[i]);
+    return n;
+}
+
 // One file too large for a batch: chunks of it are sketched into the same image with LASH_F_ACCUMULATE.
+// Two pinned chunk buffers: this thread fills and checks chunk n+1 (inflate wait + copy out of the members + FASTQ check)
+// while a second thread has the library sketch chunk n (H2D copy + kernels; the only user of `ctx` meanwhile).
 std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::string &path, uint64_t chunk_bytes,
-                            PinnedBuf &buf, uint8_t *image, uint64_t &bytes_seen, int threads)
+                            PinnedBuf &buf0, uint8_t *image, uint64_t &bytes_seen, int threads)
 {
     ByteStream bs;
     bs.set_threads(threads);                              // multi-member .gz: members inflate in parallel (pgzip.hpp)
     std::string err = bs.open(path);
     if (!err.empty()) return err;
-    if (!buf.reserve(chunk_bytes + 64)) return "out of pinned host memory";
-    size_t have = 0;                                      // bytes at the front of buf carried from the previous chunk
-    bool first = true, eof = false, corner_noted = false;
+    PinnedBuf buf1;
+    if (!buf0.reserve(chunk_bytes + 64) || !buf1.reserve(chunk_bytes + 64)) return "out of pinned host memory";
+    PinnedBuf *bufs[2] = {&buf0, &buf1};
+
+    // ---- the sketching side ----
+    struct Job { int b; size_t cut; int fmt; bool force; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    bool busy[2] = {false, false}, no_more = false, halt = false, corner_noted = false;
+    std::string gpu_err;
+    uint64_t calls = 0;
+    double t_gpu = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(now() - t0).count(); };
+    std::thread sketcher([&]() {
+        for (;;) {
+            Job jb;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !jobs.empty() || no_more; });
+                if (jobs.empty()) return;
+                jb = jobs.front();
+                jobs.pop_front();
+            }
+            bool stop = false;
+            std::string e;
+            {
+                bool skip;
+                { std::lock_guard<std::mutex> lk(mu); skip = halt; }
+                if (!skip && (jb.cut || jb.force)) {          // (a file whose FIRST record is malformed still owes its empty sketch)
+                    const auto t0 = now();
+                    lash_params prm = prm0;
+                    if (calls) prm.flags |= LASH_F_ACCUMULATE;
+                    const uint64_t off[2] = {0, (uint64_t)jb.cut};
+                    const uint8_t f = (uint8_t)jb.fmt;
+                    const int rc = lash_sketch_files_raw(ctx, &prm, bufs[jb.b]->p, off, &f, 1, image);
+                    if (rc != LASH_OK) e = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
+                    else {
+                        ++calls;
+                        if (prm.algo == LASH_HLL && !corner_noted && lash_ctx_hll_inexact_sums(ctx, nullptr, 0) != 0) {
+                            corner_noted = true;  // registers only grow: once above 53 - p the final image is, too
+                            fprintf(stderr, "note: %s: a HyperLogLog register exceeds 53 - p; the header's sum field is the exact sum and may differ "
+                                            "from lash's incrementally rounded value in its last bits\n", path.c_str());
+                        }
+                        // a malformed FASTQ record ends needletail's iteration (utils.rs:457): the library kept this chunk's
+                        // records before it; nothing after it belongs to the sketch
+                        if (lash_ctx_format_errors(ctx, nullptr, 0) != 0) stop = true;
+                    }
+                    t_gpu += since(t0);
+                }
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (!e.empty() && gpu_err.empty()) gpu_err = e;
+            if (stop || !e.empty()) halt = true;
+            busy[jb.b] = false;
+            cv.notify_all();
+        }
+    });
+    auto finish = [&](std::string result) {
+        { std::lock_guard<std::mutex> lk(mu); no_more = true; }
+        cv.notify_all();
+        sketcher.join();
+        if (result.empty() && !gpu_err.empty()) result = gpu_err;
+        return result;
+    };
+
+    // ---- the reading side ----
+    int cur = 0;
+    size_t have = 0;                                      // bytes at the front of the current buffer carried from the previous chunk
+    bool first = true, eof = false;
     int fmt = 0;
+    // LASH_CLI_TIMING: where a streamed file's wall time goes (read = inflate wait + copy out of the members; check; waiting
+    // for the sketching side; its own time runs concurrently)
+    const bool timing = getenv("LASH_CLI_TIMING") != nullptr;
+    double t_read = 0, t_check = 0, t_wait = 0;
+    std::string result;
     while (!eof) {
+        uint8_t *b = bufs[cur]->p;
+        auto t0 = now();
         while (have < chunk_bytes) {
-            const long r = bs.read(buf.p + have, chunk_bytes - have, err);
-            if (r < 0) return err + " (" + path + ")";
+            const long r = bs.read(b + have, chunk_bytes - have, err);
+            if (r < 0) { result = err + " (" + path + ")"; break; }
             if (r == 0) { eof = true; break; }
             have += (size_t)r;
             bytes_seen += (uint64_t)r;
         }
+        if (!result.empty()) break;
+        t_read += since(t0);
         if (first) {
-            fmt = sniff_format(buf.p, have);
-            if (!fmt) return "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + path;
+            fmt = sniff_format(b, have);
+            if (!fmt) { result = "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + path; break; }
         }
+        t0 = now();
         std::vector<uint8_t> carry;
-        size_t cut = eof ? have : find_cut(buf.p, have, fmt, carry);
-        if (!eof && cut == 0) return "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path;
+        size_t cut = eof ? have : find_cut(b, have, fmt, carry);
+        if (!eof && cut == 0) { result = "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path; break; }
         bool stop_here = false;
         if (fmt == LASH_FMT_FASTQ) {                      // the chunk starts and ends at record boundaries: validate it whole
-            const uint64_t ok = lash_fastq_valid_prefix(buf.p, cut);
+            const uint64_t ok = fastq_valid_prefix_mt(b, cut, threads);
             if (ok < cut) { cut = (size_t)ok; stop_here = true; }   // needletail stops at the malformed record (utils.rs:457)
         }
-        lash_params prm = prm0;
-        if (!first) prm.flags |= LASH_F_ACCUMULATE;
-        const uint64_t off[2] = {0, (uint64_t)cut};
-        const uint8_t f = (uint8_t)fmt;
-        if (cut || (stop_here && first)) {                // (a file whose FIRST record is malformed still owes its empty sketch)
-            const int rc = lash_sketch_files_raw(ctx, &prm, buf.p, off, &f, 1, image);
-            if (rc != LASH_OK) return std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
-            first = false;
-            if (prm.algo == LASH_HLL && !corner_noted && lash_ctx_hll_inexact_sums(ctx, nullptr, 0) != 0) {
-                corner_noted = true;      // registers only grow: once above 53 - p the final image is, too
-                fprintf(stderr, "note: %s: a HyperLogLog register exceeds 53 - p; the header's sum field is the exact sum and may differ "
-                                "from lash's incrementally rounded value in its last bits\n", path.c_str());
-            }
-            // a malformed FASTQ record ends needletail's iteration (utils.rs:457): the library kept this chunk's records
-            // before it; nothing after it belongs to the sketch
-            if (lash_ctx_format_errors(ctx, nullptr, 0) != 0) return "";
+        t_check += since(t0);
+        // what follows the cut moves to the front of the other buffer — once the sketching side has let go of it
+        t0 = now();
+        const int other = cur ^ 1;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !busy[other]; });
+            if (halt) break;                              // an error, or the library found the record structure broken: nothing more to add
         }
-        if (stop_here) return "";
+        t_wait += since(t0);
         const size_t rest = have - cut;                   // cut > have / 2, carry <= 33 bytes: the buffer always drains
-        if (rest) memmove(buf.p + carry.size(), buf.p + cut, rest);
-        if (!carry.empty()) memcpy(buf.p, carry.data(), carry.size());
+        if (!stop_here && !eof) {
+            if (!carry.empty()) memcpy(bufs[other]->p, carry.data(), carry.size());
+            if (rest) memcpy(bufs[other]->p + carry.size(), b + cut, rest);
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            busy[cur] = true;
+            jobs.push_back(Job{cur, cut, fmt, stop_here && first});
+        }
+        cv.notify_all();
+        first = false;
+        if (stop_here) break;
         have = carry.size() + rest;
+        cur = other;
     }
-    if (first) return "Invalid input file: empty (" + path + ")";
-    return "";
+    result = finish(result);
+    if (timing)
+        fprintf(stderr, "[lash cli] streamed %s: read %.2f s, check %.2f s, waited for the sketching side %.2f s (its calls: %.2f s, concurrent)\n",
+                path.c_str(), t_read, t_check, t_wait, t_gpu);
+    if (result.empty() && calls == 0) return "Invalid input file: empty (" + path + ")";
+    return result;
 }
 
 }  // namespace
 
 // test hook (host_hooks.cpp): the chunk-cut rule of the large-file streamer
 size_t stream_find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry) { return find_cut(b, n, fmt, carry); }
+uint64_t stream_fastq_valid_prefix_mt(const uint8_t *b, uint64_t n, int threads) { return fastq_valid_prefix_mt(b, n, threads); }
 
 std::string sketch_files(const SketchOptions &opt, const std::vector<std::string> &files, const std::string &output_name,
                          SketchStats *stats)
