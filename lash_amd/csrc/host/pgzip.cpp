@@ -40,12 +40,50 @@ struct Member {
 // inflate ONE gzip member starting at src[0] (inflate_fast.hpp: header, deflate body, CRC-32 and length); returns the
 // consumed bytes, 0 on any failure — a false candidate, a member beyond `cap`, or a stream the fast decoder rejects: the
 // reader then takes the member sequentially, where zlib has the last word
+size_t inflate_member_zlib(const uint8_t *src, size_t avail, ByteSink &out, size_t cap)   // LASH_NO_FAST_INFLATE=1: zlib only
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 16) != Z_OK) return 0;
+    size_t used = 0;
+    int rc = Z_OK;
+    out.n = 0;
+    while (rc != Z_STREAM_END) {
+        if (z.avail_in == 0) {
+            const size_t chunk = std::min<size_t>(avail - used, 1u << 30);
+            if (chunk == 0) break;                     // ran out of file before the member ended
+            z.next_in = const_cast<Bytef *>(src + used);
+            z.avail_in = (uInt)chunk;
+            used += chunk;
+        }
+        if (out.cap - out.n < (1u << 16)) {
+            if (out.n > cap || !out.reserve(out.cap + out.cap / 2 + (4u << 20))) { rc = Z_MEM_ERROR; break; }
+        }
+        z.next_out = out.p + out.n;
+        z.avail_out = (uInt)std::min<size_t>(out.cap - out.n, 1u << 30);
+        const uInt before = z.avail_out;
+        rc = inflate(&z, Z_NO_FLUSH);
+        if (rc != Z_OK && rc != Z_STREAM_END) break;
+        out.n += before - z.avail_out;
+    }
+    const size_t consumed = used - z.avail_in;
+    inflateEnd(&z);
+    return rc == Z_STREAM_END && out.n <= cap ? consumed : 0;
+}
+
 size_t inflate_member(const uint8_t *src, size_t avail, ByteSink &out, size_t cap)
 {
+    static const bool no_fast = getenv("LASH_NO_FAST_INFLATE") != nullptr;
+    if (no_fast) {
+        const size_t used = inflate_member_zlib(src, avail, out, cap);
+        if (!used) out.n = 0;
+        return used;
+    }
     out.limit = cap;
+    out.n = 0;
     size_t used = 0;
     const char *e = gunzip_members(src, avail, out, true, &used);
-    if (e) { out.release(); return 0; }
+    if (e) { out.n = 0; return 0; }
     return used;
 }
 
