@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tests/fuzz_gpu_dist.py [iterations] [seed] — `lash dist` (HyperMinHash and HyperLogLog) on random small genome sets and
+"""tests/fuzz_gpu_dist.py [iterations] [seed] — `lash dist` (HyperMinHash, HyperLogLog, UltraLogLog FGRA / ML) on random small genome sets and
 random output options against the pure-Python restatement in tests/pyref.py.  GPU box, manual."""
 import os
 import random
@@ -23,13 +23,17 @@ def mutated(seq, rate, rng):
     return out
 
 
+WORST = {}
+
+
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     for it in range(iters):
         rng = random.Random(seed0 * 49979687 + it)
         nrng = np.random.default_rng(seed0 * 1000 + it)
-        algo = rng.choice(["hmh", "hll"])
+        algo = rng.choice(["hmh", "hll", "ull"])
+        est = rng.choice(["fgra", "ml"])
         k = rng.choice([16, 21, 12, 31])
         p = rng.randint(8, 14)
         L = rng.choice([300_000, 600_000])
@@ -47,14 +51,18 @@ def main():
             for pre, lst in (("refs", "r.txt"), ("qry", "q.txt")):
                 r = subprocess.run([H.CLI, "sketch", "-f", os.path.join(td, lst), "-o", pre, "-k", str(k), "-a", algo, "-p", str(p)], cwd=td, capture_output=True, text=True)
                 assert r.returncode == 0, r.stderr
-            algo_id = O.HMH if algo == "hmh" else O.HLL
-            imgs = [O.sketch_genomes(algo_id, k, p if algo == "hll" else 0, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0].tobytes() for g in genomes]
+            algo_id = O.HMH if algo == "hmh" else O.HLL if algo == "hll" else O.ULL
+            imgs = [O.sketch_genomes(algo_id, k, p if algo != "hmh" else 0, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0].tobytes() for g in genomes]
             model = rng.choice([0, 1])
             fp32 = rng.random() < 0.3
             same = rng.random() < 0.5
             matrix = same and rng.random() < 0.5
             q = "refs" if same else "qry"
             cmd = [H.CLI, "dist", "-q", q, "-r", "refs", "-o", "d.txt", "-m", str(model), "-t", str(rng.choice([1, 3, 8]))]
+            if algo == "ull":
+                cmd += ["-e", est]
+                estimate = R.ull_fgra if est == "fgra" else R.ull_ml
+                card = [estimate(list(im[8:]), p) for im in imgs]
             cmd += (["--fp32"] if fp32 else []) + (["--dm"] if matrix else []) + rng.choice([[], ["--block-rows", "2"]])
             file_order = rng.random() < 0.4
             cmd += ["--file-order"] if file_order else []
@@ -66,7 +74,11 @@ def main():
             text = open(os.path.join(td, "d.txt")).read()
 
             def expected(ri, qi):
-                sim = R.hmh_similarity(imgs[qi], imgs[ri]) if algo == "hmh" else R.hll_similarity(p, imgs[ri], imgs[qi])
+                if algo == "ull":
+                    u = estimate(list(R.ull_merge(imgs[ri][8:], imgs[qi][8:])), p)
+                    sim = (card[ri] + card[qi] - u) / u
+                else:
+                    sim = R.hmh_similarity(imgs[qi], imgs[ri]) if algo == "hmh" else R.hll_similarity(p, imgs[ri], imgs[qi])
                 return R.mash_distance(sim, k, model, paths[ri] == paths[qi])
 
             tol = 3e-6 if fp32 else 1.1e-6
@@ -95,9 +107,12 @@ def main():
                 sys.exit(1)
             for (i, j) in want_pairs:
                 e = expected(i, j)
+                key = algo + ("-" + est if algo == "ull" else "")
+                WORST[key] = max(WORST.get(key, 0.0), abs(got[(i, j)] - e))
                 if abs(got[(i, j)] - e) > tol:
                     print("MISMATCH it=%d %s k=%d p=%d model=%d fp32=%s pair=(%d,%d): %r vs %r" % (it, algo, k, p, model, fp32, i, j, got[(i, j)], e))
                     sys.exit(1)
+    print("largest |CLI - restatement| per estimator:", {k: "%.2e" % v for k, v in sorted(WORST.items())})
     print("dist fuzz ok: %d iterations from seed %d" % (iters, seed0))
 
 

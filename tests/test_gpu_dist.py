@@ -325,7 +325,7 @@ def test_lash_dist_cli_ull(tmp_path, matrix, model, p, est):
             for b, d in enumerate(cells[1:]):
                 got[frozenset((order[a], order[b]))] = float(d)
     assert len(got) == 4 * 5 // 2
-    tol = 1.1e-6 if est == "fgra" else 1e-3
+    tol = 1.1e-6                                                 # both estimators: only the 6-decimal print rounds
     for i in range(4):
         for j in range(i + 1):
             assert abs(got[frozenset((i, j))] - expected(i, j)) <= tol, (i, j, got[frozenset((i, j))], expected(i, j))
