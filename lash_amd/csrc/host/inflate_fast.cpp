@@ -78,7 +78,7 @@ bool build_table(const uint8_t *lens, unsigned n_sym, Kind kind, unsigned root, 
     for (unsigned i = 0; i < root_size; ++i) table[i] = E_BAD | 1u;
     // codes longer than the root: the longest code under each root-bit prefix sizes that prefix's sub-table
     uint16_t rev[288];
-    uint8_t sub_max[1u << 11];
+    uint8_t sub_max[1u << 12];                           // root <= 12
     const bool has_long = max_len > root;
     if (has_long) memset(sub_max, 0, root_size);
     for (unsigned s = 0; s < n_sym; ++s) {

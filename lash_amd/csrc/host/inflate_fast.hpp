@@ -28,7 +28,10 @@ public:
 
 private:
     enum Phase { PH_HEADER, PH_STORED, PH_HUFF, PH_DONE };
-    static constexpr int LL_ROOT = 11, D_ROOT = 8;
+#ifndef LASH_INFLATE_LL_ROOT
+#define LASH_INFLATE_LL_ROOT 11          // first-level bits of the literal/length table (tools/inflate_root_scan.sh measures 9..12)
+#endif
+    static constexpr int LL_ROOT = LASH_INFLATE_LL_ROOT, D_ROOT = 8;
     static constexpr int LL_CAP = (1 << LL_ROOT) + 1024, D_CAP = (1 << D_ROOT) + 512;
     template <bool FAST>
     int decode_block(const uint8_t *in, size_t in_n, size_t &ip, uint8_t *out, size_t &op, size_t out_cap);
