@@ -275,7 +275,19 @@ int    lash_hll_cardinality(const uint8_t *registers, int p, const lash_hll_bias
  * it (*bad_pair = its index). */
 int    lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, uint32_t n_qry, const double *ref_card,
                       const double *qry_card, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union,
-                      const lash_hll_bias *tables, double *out_dist, uint64_t *bad_pair);
+                      const lash_hll_bias *tables, const double *hmh_ec, double *out_dist, uint64_t *bad_pair);
+/* hmh_ec (HyperMinHash only, may be NULL): hyperminhash's expected_collisions(n, m) per pair, [n_ref x n_qry], as
+ * lash_hmh_pair_expected_collisions computes them on the GPU.  NULL: computed here on the host — O(1) for cardinalities above
+ * 2^19, but a walk over 65 536 cells with four pow() each (4 ms to 0.2 s PER PAIR, as in the crate) when both sketches are
+ * smaller: viruses, plasmids, short contigs. */
+
+/* hyperminhash's expected_collisions(n, m) for every pair of an [n_ref x n_qry] block from the per-sketch cardinalities (host
+ * arrays in, host array out).  Above 2^19 (either sketch) the crate's closed form; below, the 65 536-cell sum as a product of
+ * per-sketch cell-probability vectors: one vector kernel per sketch, one f64 MFMA matrix product per block (dist_kernels.hip).
+ * Summation order differs from the crate's loop: agreement ~1e-13 relative.  The query vectors are kept on the device while
+ * consecutive calls pass the same qry_card values (row blocks of one `dist` run). */
+int    lash_hmh_pair_expected_collisions(lash_ctx *ctx, const double *ref_card, uint32_t n_ref, const double *qry_card, uint32_t n_qry,
+                                         double *out_ec);
 
 /* Synthetic genomes of SURVEY.md §8(d) generated in HBM (bench / tests): genome ids first..first+n-1,
  * n_bases ASCII bytes each, written back to back at d_out. */

@@ -89,7 +89,8 @@ PROTOTYPES = {
     "lash_hll_bias_has": (_int, [_vp, _int]),
     "lash_hll_bias_free": (None, [_vp]),
     "lash_hll_cardinality": (_int, [_vp, _int, _vp, C.POINTER(C.c_double)]),
-    "lash_dist_rows": (_int, [_int, _int, _int, _int, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "lash_dist_rows": (_int, [_int, _int, _int, _int, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "lash_hmh_pair_expected_collisions": (_int, [_vp, _vp, _u32, _vp, _u32, _vp]),
     "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),
 }
 

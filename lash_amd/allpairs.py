@@ -92,6 +92,9 @@ def all_vs_all(algo, p, k, local_images, counts, *, ctx=None, model=1, fp32=Fals
         b1 = min(r1, b0 + step)
         ref = every[b0:b1] if every.is_cuda else host[b0:b1]
         st = pair_stats(algo, p, estimator, ref, every if every.is_cuda else host)
+        if ctx is not None and (ALGOS[algo] if isinstance(algo, str) else int(algo)) == ALGOS["hmh"]:
+            # hyperminhash's expected collisions: the 65 536-cell regime (both sketches <= 2^19 distinct k-mers) on the GPU
+            st["hmh_ec"] = ctx.hmh_pair_expected_collisions(card[b0:b1], card)
         out[b0 - r0:b1 - r0] = dist_rows(algo, p, k, model, card[b0:b1], card, fp32=fp32, hll_bias=hll_bias, **st)
     return r0, r1, out
 

@@ -33,7 +33,7 @@ double hmh_beta(double ez)
            0.00042419 * std::pow(zl, 7);
 }
 
-double hmh_expected_collision(double n, double m)
+double hmh_cell_sum(double n, double m)
 {
     const double two_q = 64.0, two_r = 1024.0;
     double x = 0.0;
@@ -54,18 +54,14 @@ double hmh_expected_collision(double n, double m)
             x += prx * pry;
         }
     }
-    return x * (double)HP + 0.5;
+    return x;
 }
 
 double hmh_approx_expected_collisions(double n, double m)
 {
-    if (n < m) std::swap(n, m);
-    if (n > std::pow(2.0, std::pow(2.0, (double)HQ) + (double)HR)) return 1.8446744073709552e19;   // u64::MAX
-    if (n > std::pow(2.0, (double)(HP + 5))) {
-        const double d = (4.0 * n / m) / std::pow((1.0 + n) / m, 2.0);
-        return 0.169919487159739093975315012348 * std::pow(2.0, (double)(HP - HR)) * d + 0.5;
-    }
-    return hmh_expected_collision(n, m) / (double)HP;
+    double out;
+    if (lash::hmh_ec_closed_form(n, m, &out)) return out;
+    return lash::hmh_ec_cell_walk(n, m);
 }
 
 // streaming_algorithms 0.3.3 len() thresholds (HLL++, Heule et al.), p = 4..18
@@ -82,6 +78,30 @@ double hll_alpha(int p)
 }
 
 }  // namespace
+
+namespace lash {
+
+bool hmh_ec_closed_form(double n, double m, double *out)
+{
+    if (n < m) std::swap(n, m);
+    if (n > std::pow(2.0, std::pow(2.0, (double)HQ) + (double)HR)) { *out = 1.8446744073709552e19; return true; }   // u64::MAX
+    if (n > std::pow(2.0, (double)(HP + 5))) {
+        const double d = (4.0 * n / m) / std::pow((1.0 + n) / m, 2.0);
+        *out = 0.169919487159739093975315012348 * std::pow(2.0, (double)(HP - HR)) * d + 0.5;
+        return true;
+    }
+    return false;
+}
+
+double hmh_ec_from_cell_sum(double x) { return (x * (double)HP + 0.5) / (double)HP; }
+
+double hmh_ec_cell_walk(double n, double m)
+{
+    if (n < m) std::swap(n, m);
+    return hmh_ec_from_cell_sum(hmh_cell_sum(n, m));
+}
+
+}  // namespace lash
 
 // p = 4..18: raw estimate -> bias samples, as the HLL++ appendix publishes them (rawEstimateData / biasData)
 struct lash_hll_bias {
@@ -214,7 +234,7 @@ int lash_hll_cardinality(const uint8_t *regs, int p, const lash_hll_bias *tables
 
 int lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, uint32_t n_qry, const double *ref_card,
                    const double *qry_card, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union,
-                   const lash_hll_bias *tables, double *out_dist, uint64_t *bad_pair)
+                   const lash_hll_bias *tables, const double *hmh_ec, double *out_dist, uint64_t *bad_pair)
 {
     if (k < 1 || k > 32 || (model != 0 && model != 1) || !ref_card || !qry_card || !out_dist) return LASH_EINVAL;
     if (algo == LASH_HMH ? (!c_or_zero || !n_counts) : algo == LASH_HLL ? (!c_or_zero || !sum_or_union || p < 4 || p > 16)
@@ -234,7 +254,7 @@ int lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, 
             } else {
                 const double c = (double)c_or_zero[at], n = (double)n_counts[at];
                 if (c != 0.0) {                                                                   // Sketch::similarity
-                    const double ec = hmh_approx_expected_collisions(qry_card[j], ref_card[i]);
+                    const double ec = hmh_ec ? hmh_ec[at] : hmh_approx_expected_collisions(qry_card[j], ref_card[i]);
                     sim = c < ec ? 0.0 : (c - ec) / n;
                 }
             }

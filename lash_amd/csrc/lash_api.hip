@@ -120,6 +120,8 @@ struct lash_ctx {
     unsigned slot_next = 0;
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
+    DevBuf ec_ref, ec_qry, ec_x, ec_card;   // lash_hmh_pair_expected_collisions: cell vectors [n][65536] f64, products, cardinalities
+    std::vector<double> ec_qry_cards;    // the small query cardinalities whose vectors ec_qry holds (reused across row blocks)
     DevBuf hll_flags;                    // [hll_flags_n] per genome of the last HyperLogLog sketch call: a register > 53 - p
     uint32_t hll_flags_n = 0;            // (lash_ctx_hll_inexact_sums)
     std::vector<uint32_t> bad_files;     // lash_ctx_format_errors(): files of the last raw call whose FASTQ structure broke
@@ -833,7 +835,7 @@ void lash_ctx_destroy(lash_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->item_kmers, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
-                      &ctx->st_img, &ctx->hll_flags})
+                      &ctx->st_img, &ctx->hll_flags, &ctx->ec_ref, &ctx->ec_qry, &ctx->ec_x, &ctx->ec_card})
         release(*b);
     {
         lash_packed &sc = ctx->scratch;
@@ -1376,6 +1378,68 @@ int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_re
     HIPCHK(ctx, hipMemcpyAsync(out_c, d_c, pb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(out_n, d_n, pb, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
+int lash_hmh_pair_expected_collisions(lash_ctx *ctx, const double *ref_card, uint32_t n_ref, const double *qry_card, uint32_t n_qry,
+                                      double *out_ec)
+{
+    if (!ctx || ((n_ref && n_qry) && (!ref_card || !qry_card || !out_ec))) return LASH_EINVAL;
+    if (n_ref == 0 || n_qry == 0) return LASH_OK;
+    (void)hipSetDevice(ctx->device);
+    // O(1) regimes on the host; what is left needs the cell sum: both sketches at or below 2^(p+5)
+    std::vector<uint32_t> rs, qs;                               // small sketches that occur in at least one such pair
+    std::vector<int32_t> rmap(n_ref, -1), qmap(n_qry, -1);
+    for (uint32_t i = 0; i < n_ref; ++i)
+        for (uint32_t j = 0; j < n_qry; ++j) {
+            double v;
+            if (hmh_ec_closed_form(qry_card[j], ref_card[i], &v)) { out_ec[(size_t)i * n_qry + j] = v; continue; }
+            if (rmap[i] < 0) { rmap[i] = (int32_t)rs.size(); rs.push_back(i); }
+            if (qmap[j] < 0) { qmap[j] = (int32_t)qs.size(); qs.push_back(j); }
+        }
+    if (rs.empty()) return LASH_OK;
+    constexpr size_t VEC = 65536 * sizeof(double);
+    constexpr size_t Q_CHUNK = (24ull << 30) / VEC, R_CHUNK = (4ull << 30) / VEC;      // <= 24 + 4 GiB of vectors at a time
+    int rc;
+    std::vector<double> cards, x;
+    for (size_t q0 = 0; q0 < qs.size(); q0 += Q_CHUNK) {
+        const uint32_t nq = (uint32_t)std::min(Q_CHUNK, qs.size() - q0);
+        cards.resize(nq);
+        for (uint32_t j = 0; j < nq; ++j) cards[j] = qry_card[qs[q0 + j]];
+        if ((rc = reserve(ctx, ctx->ec_card, (size_t)(nq + R_CHUNK) * 8))) return rc;
+        double *d_card = static_cast<double *>(ctx->ec_card.ptr);
+        const bool cached = qs.size() <= Q_CHUNK && ctx->ec_qry.ptr && cards == ctx->ec_qry_cards;
+        if (!cached) {
+            ctx->ec_qry_cards.clear();
+            if ((rc = reserve(ctx, ctx->ec_qry, (size_t)nq * VEC))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(d_card, cards.data(), (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, launch_collision_vectors(d_card, nq, static_cast<double *>(ctx->ec_qry.ptr), ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));    // (`cards` is reused below)
+            if (qs.size() <= Q_CHUNK) ctx->ec_qry_cards = cards;
+        }
+        for (size_t r0 = 0; r0 < rs.size(); r0 += R_CHUNK) {
+            const uint32_t nr = (uint32_t)std::min(R_CHUNK, rs.size() - r0);
+            std::vector<double> rcards(nr);
+            for (uint32_t i = 0; i < nr; ++i) rcards[i] = ref_card[rs[r0 + i]];
+            if ((rc = reserve(ctx, ctx->ec_ref, (size_t)nr * VEC))) return rc;
+            if ((rc = reserve(ctx, ctx->ec_x, (size_t)nr * nq * 8))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(d_card + nq, rcards.data(), (size_t)nr * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, launch_collision_vectors(d_card + nq, nr, static_cast<double *>(ctx->ec_ref.ptr), ctx->stream));
+            HIPCHK(ctx, launch_collision_gemm(static_cast<const double *>(ctx->ec_ref.ptr), nr, static_cast<const double *>(ctx->ec_qry.ptr), nq,
+                                              static_cast<double *>(ctx->ec_x.ptr), ctx->stream));
+            x.resize((size_t)nr * nq);
+            HIPCHK(ctx, hipMemcpyAsync(x.data(), ctx->ec_x.ptr, x.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint32_t i = 0; i < nr; ++i) {
+                const uint32_t ri = rs[r0 + i];
+                for (uint32_t j = 0; j < nq; ++j) {
+                    const uint32_t qj = qs[q0 + j];
+                    double v;
+                    if (!hmh_ec_closed_form(qry_card[qj], ref_card[ri], &v)) out_ec[(size_t)ri * n_qry + qj] = hmh_ec_from_cell_sum(x[(size_t)i * nq + j]);
+                }
+            }
+        }
+    }
     return LASH_OK;
 }
 

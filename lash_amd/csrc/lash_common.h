@@ -67,4 +67,11 @@ inline uint64_t xxh3_short_seed(uint64_t seed)
 inline uint64_t xxh3_bitflip64(uint64_t seed)  { return (XXH_SEC8 ^ XXH_SEC16) - xxh3_short_seed(seed); }   // 8-byte input, 64-bit hash
 inline uint64_t xxh3_bitflip128(uint64_t seed) { return (XXH_SEC16 ^ XXH_SEC24) + xxh3_short_seed(seed); }  // 4-byte input, 128-bit hash
 
+// hyperminhash's expected_collisions(n, m) split where the GPU takes over (dist_estimators.hip): the saturated and the
+// closed-form regimes are O(1) (returns true, *out set); below 2^(p+5) the crate walks 65 536 cells (returns false):
+// on the host with hmh_ec_cell_walk, or as lash_hmh_pair_expected_collisions' matrix product
+bool hmh_ec_closed_form(double n, double m, double *out);
+double hmh_ec_from_cell_sum(double x);               // the cell sum -> the value similarity() subtracts
+double hmh_ec_cell_walk(double n, double m);         // the crate's loop, term by term, on the host
+
 }  // namespace lash

@@ -155,6 +155,11 @@ hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t 
 hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
                             int estimator, double *d_est, hipStream_t stream);
 
+// HyperMinHash expected collisions of small sketches (dist_kernels.hip): P[n][65536] cell probabilities of each cardinality,
+// X[m][n] = A[m][65536] * B[n][65536]^T
+hipError_t launch_collision_vectors(const double *d_card, uint32_t n, double *d_P, hipStream_t stream);
+hipError_t launch_collision_gemm(const double *d_A, uint32_t m, const double *d_B, uint32_t n, double *d_X, hipStream_t stream);
+
 // ---- synthetic genomes --------------------------------------------------------------------
 hipError_t launch_synth(uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out, hipStream_t stream);
 

@@ -67,7 +67,8 @@ def sketch_cardinality(algo, p, image, layout=None, estimator="fgra", hll_bias=N
     return out.value
 
 
-def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=None, sum_or_union=None, fp32=False, hll_bias=None):
+def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=None, sum_or_union=None, fp32=False, hll_bias=None,
+              hmh_ec=None):
     """The distances the reference prints for an [n_ref, n_qry] block, from the GPU's pair statistics and the per-sketch
     cardinalities (lash_dist_rows; utils.rs:164-167, 272-278, 355-365 + main.rs:415-423).  numpy in, float64 [n_ref, n_qry] out."""
     lib = _lib.load()
@@ -79,9 +80,12 @@ def dist_rows(algo, p, k, model, ref_card, qry_card, c_or_zero=None, n_counts=No
     d = None if sum_or_union is None else np.ascontiguousarray(sum_or_union, dtype=np.float64)
     out = np.zeros((nr, nq), dtype=np.float64)
     bad = C.c_uint64()
+    ec = None if hmh_ec is None else np.ascontiguousarray(hmh_ec, dtype=np.float64)       # (kept alive across the call)
+    assert ec is None or ec.size == nr * nq
     rc = lib.lash_dist_rows(_algo(algo), int(p or 0), int(k), int(model), 1 if fp32 else 0, nr, nq, rc_.ctypes.data, qc_.ctypes.data,
                             None if a is None else a.ctypes.data, None if b is None else b.ctypes.data,
-                            None if d is None else d.ctypes.data, _bias_handle(hll_bias), out.ctypes.data, C.byref(bad))
+                            None if d is None else d.ctypes.data, _bias_handle(hll_bias),
+                            None if ec is None else ec.ctypes.data, out.ctypes.data, C.byref(bad))
     if rc != _lib.OK:
         raise LashError(rc, lib.lash_strerror(rc).decode() + (" (pair %d)" % bad.value if rc == _lib.ERANGE else ""))
     return out
@@ -364,6 +368,15 @@ class Context:
         n = dst.shape[0] if dst.ndim == 2 else 1
         self._check(self._lib.lash_merge_images(self._h, _algo(algo), int(p or 0), dst.ctypes.data, src.ctypes.data, n))
         return dst
+
+    def hmh_pair_expected_collisions(self, ref_card, qry_card):
+        """hyperminhash's expected_collisions(n, m) for every pair, float64 [n_ref, n_qry]; the 65 536-cell regime (both
+        cardinalities <= 2^19) runs on the GPU (include/lash_gfx950.h)"""
+        r = np.ascontiguousarray(ref_card, dtype=np.float64)
+        q = np.ascontiguousarray(qry_card, dtype=np.float64)
+        out = np.zeros((len(r), len(q)), dtype=np.float64)
+        self._check(self._lib.lash_hmh_pair_expected_collisions(self._h, r.ctypes.data, len(r), q.ctypes.data, len(q), out.ctypes.data))
+        return out
 
     def hmh_pair_counts(self, ref_images, qry_images):
         """HyperMinHash pair statistics (C, N) of serialized sketches: numpy uint8 [n, 32768] in, two uint32
