@@ -58,4 +58,12 @@ for p, est in ((12, "fgra"), (12, "ml"), (10, "fgra"), (16, "fgra")):
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / 3
     print("ull p=%d %s pairs: %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (p, est, nn, nn, dt * 1e3, nn * nn / dt, nn * nn * (1 << p) / dt))
+# hyperminhash's expected-collision term for small sketches: cell vectors + f64 MFMA product
+rc_, qc_ = np.random.default_rng(3).uniform(1e3, 5e5, n), np.random.default_rng(4).uniform(1e3, 5e5, n)
+ctx.hmh_pair_expected_collisions(rc_[:8], qc_[:8])
+t0 = time.perf_counter()
+ec = ctx.hmh_pair_expected_collisions(rc_, qc_)
+dt = time.perf_counter() - t0
+print("hmh expected collisions (both sketches < 2^19): %d x %d in %.1f ms -> %.3g pairs/s (%.2f TFLOP/s f64 incl. vectors and copy-back)"
+      % (n, n, dt * 1e3, n * n / dt, n * n * 131072 / dt / 1e12))
 print("ok")
