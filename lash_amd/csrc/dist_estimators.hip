@@ -83,11 +83,13 @@ namespace lash {
 
 bool hmh_ec_closed_form(double n, double m, double *out)
 {
+    // (constants: 2^(2^q + r) = 2^74, 2^(p + 5) = 2^19, 2^(p - r) = 16; the crate writes them as powf calls)
     if (n < m) std::swap(n, m);
-    if (n > std::pow(2.0, std::pow(2.0, (double)HQ) + (double)HR)) { *out = 1.8446744073709552e19; return true; }   // u64::MAX
-    if (n > std::pow(2.0, (double)(HP + 5))) {
-        const double d = (4.0 * n / m) / std::pow((1.0 + n) / m, 2.0);
-        *out = 0.169919487159739093975315012348 * std::pow(2.0, (double)(HP - HR)) * d + 0.5;
+    if (n > 18889465931478580854784.0) { *out = 1.8446744073709552e19; return true; }                 // u64::MAX
+    if (n > 524288.0) {
+        const double t = (1.0 + n) / m;
+        const double d = (4.0 * n / m) / (t * t);
+        *out = 0.169919487159739093975315012348 * 16.0 * d + 0.5;
         return true;
     }
     return false;

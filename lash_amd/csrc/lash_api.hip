@@ -1387,16 +1387,19 @@ int lash_hmh_pair_expected_collisions(lash_ctx *ctx, const double *ref_card, uin
     if (!ctx || ((n_ref && n_qry) && (!ref_card || !qry_card || !out_ec))) return LASH_EINVAL;
     if (n_ref == 0 || n_qry == 0) return LASH_OK;
     (void)hipSetDevice(ctx->device);
-    // O(1) regimes on the host; what is left needs the cell sum: both sketches at or below 2^(p+5)
-    std::vector<uint32_t> rs, qs;                               // small sketches that occur in at least one such pair
-    std::vector<int32_t> rmap(n_ref, -1), qmap(n_qry, -1);
-    for (uint32_t i = 0; i < n_ref; ++i)
-        for (uint32_t j = 0; j < n_qry; ++j) {
-            double v;
-            if (hmh_ec_closed_form(qry_card[j], ref_card[i], &v)) { out_ec[(size_t)i * n_qry + j] = v; continue; }
-            if (rmap[i] < 0) { rmap[i] = (int32_t)rs.size(); rs.push_back(i); }
-            if (qmap[j] < 0) { qmap[j] = (int32_t)qs.size(); qs.push_back(j); }
-        }
+    // O(1) regimes on the host; what is left needs the cell sum: pairs whose LARGER sketch is at or below 2^(p+5), i.e. both are
+    std::vector<uint32_t> rs, qs;
+    std::vector<uint8_t> rsmall(n_ref), qsmall(n_qry);
+    double dummy;
+    for (uint32_t i = 0; i < n_ref; ++i) rsmall[i] = !hmh_ec_closed_form(ref_card[i], ref_card[i], &dummy);
+    for (uint32_t j = 0; j < n_qry; ++j) qsmall[j] = !hmh_ec_closed_form(qry_card[j], qry_card[j], &dummy);
+    for (uint32_t j = 0; j < n_qry; ++j) if (qsmall[j]) qs.push_back(j);
+    if (!qs.empty()) for (uint32_t i = 0; i < n_ref; ++i) if (rsmall[i]) rs.push_back(i);
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        double *row = out_ec + (size_t)i * n_qry;
+        for (uint32_t j = 0; j < n_qry; ++j)
+            if (!(rsmall[i] && qsmall[j])) (void)hmh_ec_closed_form(qry_card[j], ref_card[i], &row[j]);
+    }
     if (rs.empty()) return LASH_OK;
     constexpr size_t VEC = 65536 * sizeof(double);
     constexpr size_t Q_CHUNK = (24ull << 30) / VEC, R_CHUNK = (4ull << 30) / VEC;      // <= 24 + 4 GiB of vectors at a time
@@ -1434,8 +1437,7 @@ int lash_hmh_pair_expected_collisions(lash_ctx *ctx, const double *ref_card, uin
                 const uint32_t ri = rs[r0 + i];
                 for (uint32_t j = 0; j < nq; ++j) {
                     const uint32_t qj = qs[q0 + j];
-                    double v;
-                    if (!hmh_ec_closed_form(qry_card[qj], ref_card[ri], &v)) out_ec[(size_t)ri * n_qry + qj] = hmh_ec_from_cell_sum(x[(size_t)i * nq + j]);
+                    out_ec[(size_t)ri * n_qry + qj] = hmh_ec_from_cell_sum(x[(size_t)i * nq + j]);
                 }
             }
         }
