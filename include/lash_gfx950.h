@@ -231,7 +231,9 @@ int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_re
 /* dist side, HyperLogLog: for every (reference, query) pair the two numbers `len()` needs from the union sketch
  * (/root/reference/src/utils.rs:355-363: ref_hll.union(q_hll); ref_hll.len()):
  * out_zero[r * n_qry + q] = #{i : max(a_i, b_i) == 0},  out_sum[r * n_qry + q] = sum_i 2^-max(a_i, b_i).
- * Images are HLL sketches of precision p as written by `save` (33-byte header + 2^p registers). */
+ * Images are HLL sketches of precision p as written by `save` (33-byte header + 2^p registers).
+ * (p >= 10 runs through per-threshold bitmaps and popcounts, which needs the range of register values first: the device entry
+ * synchronizes the stream once for that 8-byte read-back.) */
 int lash_hll_pair_union_stats_device(lash_ctx *ctx, int p, const uint8_t *d_ref_images, uint32_t n_ref,
                                      const uint8_t *d_qry_images, uint32_t n_qry, uint32_t *d_out_zero, double *d_out_sum);
 int lash_hll_pair_union_stats(lash_ctx *ctx, int p, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,

@@ -120,6 +120,7 @@ struct lash_ctx {
     unsigned slot_next = 0;
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     lash_packed scratch;                 // packed batch of lash_sketch_batch[_device]
+    DevBuf hll_bm_ref, hll_bm_qry, hll_lohi;   // lash_hll_pair_union_stats*: threshold bitmaps [n][band][m/32], range of register values
     DevBuf ec_ref, ec_qry, ec_x, ec_card;   // lash_hmh_pair_expected_collisions: cell vectors [n][65536] f64, products, cardinalities
     std::vector<double> ec_qry_cards;    // the small query cardinalities whose vectors ec_qry holds (reused across row blocks)
     DevBuf hll_flags;                    // [hll_flags_n] per genome of the last HyperLogLog sketch call: a register > 53 - p
@@ -835,7 +836,8 @@ void lash_ctx_destroy(lash_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->item_kmers, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
-                      &ctx->st_img, &ctx->hll_flags, &ctx->ec_ref, &ctx->ec_qry, &ctx->ec_x, &ctx->ec_card})
+                      &ctx->st_img, &ctx->hll_flags, &ctx->ec_ref, &ctx->ec_qry, &ctx->ec_x, &ctx->ec_card, &ctx->hll_bm_ref,
+                      &ctx->hll_bm_qry, &ctx->hll_lohi})
         release(*b);
     {
         lash_packed &sc = ctx->scratch;
@@ -1451,8 +1453,38 @@ int lash_hll_pair_union_stats_device(lash_ctx *ctx, int p, const uint8_t *d_ref_
     if (!ctx || p < 4 || p > 16 || ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_zero || !d_out_sum)))
         return LASH_EINVAL;
     (void)hipSetDevice(ctx->device);
-    HIPCHK(ctx, launch_hll_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, (uint32_t)header_bytes(ctx->layout, LASH_HLL), d_out_zero,
-                                 d_out_sum, ctx->stream));
+    const uint32_t hdr = (uint32_t)header_bytes(ctx->layout, LASH_HLL);
+    static const bool byte_kernel_only = getenv("LASH_HLL_PAIRS_BYTEWISE") != nullptr;
+    if (p >= 10 && n_ref && n_qry && !byte_kernel_only) {
+        // threshold-bitmap form (dist_kernels.hip): needs the range of register values first — one 8-byte read-back
+        int rc;
+        if ((rc = reserve(ctx, ctx->hll_lohi, 8))) return rc;
+        uint32_t *d_lohi = static_cast<uint32_t *>(ctx->hll_lohi.ptr);
+        HIPCHK(ctx, hipMemsetAsync(d_lohi, 0xFF, 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_lohi + 1, 0, 4, ctx->stream));
+        HIPCHK(ctx, launch_hll_minmax(d_ref_images, n_ref, p, hdr, d_lohi, ctx->stream));
+        const bool same = d_ref_images == d_qry_images && n_ref == n_qry;
+        if (!same) HIPCHK(ctx, launch_hll_minmax(d_qry_images, n_qry, p, hdr, d_lohi, ctx->stream));
+        uint32_t lohi[2] = {0, 0};
+        HIPCHK(ctx, hipMemcpyAsync(lohi, d_lohi, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const uint32_t lo = lohi[0], hi = lohi[1];
+        if (hi > lo && hi <= 64u) {                              // (all registers equal, or values no sketch can hold: the byte-wise kernel)
+            const uint32_t band = hi - lo;
+            const size_t per = (size_t)band * ((size_t)1 << p) / 8;
+            if ((rc = reserve(ctx, ctx->hll_bm_qry, (size_t)n_qry * per))) return rc;
+            uint32_t *bq = static_cast<uint32_t *>(ctx->hll_bm_qry.ptr), *br = bq;
+            HIPCHK(ctx, launch_hll_bitmaps(d_qry_images, n_qry, p, hdr, lo, band, bq, ctx->stream));
+            if (!same) {
+                if ((rc = reserve(ctx, ctx->hll_bm_ref, (size_t)n_ref * per))) return rc;
+                br = static_cast<uint32_t *>(ctx->hll_bm_ref.ptr);
+                HIPCHK(ctx, launch_hll_bitmaps(d_ref_images, n_ref, p, hdr, lo, band, br, ctx->stream));
+            }
+            HIPCHK(ctx, launch_hll_pairs_bitmap(br, n_ref, bq, n_qry, p, lo, band, d_out_zero, d_out_sum, ctx->stream));
+            return LASH_OK;
+        }
+    }
+    HIPCHK(ctx, launch_hll_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, hdr, d_out_zero, d_out_sum, ctx->stream));
     return LASH_OK;
 }
 

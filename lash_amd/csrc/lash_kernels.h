@@ -151,6 +151,12 @@ hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t 
 hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
                             uint32_t *d_zero, double *d_sum, hipStream_t stream);
 
+// the same statistics for p >= 10 through threshold bitmaps (dist_kernels.hip): range of register values -> bm[n][band][m/32] -> pairs
+hipError_t launch_hll_minmax(const uint8_t *d_img, uint32_t n, int p, uint32_t hdr, uint32_t *d_lohi, hipStream_t stream);
+hipError_t launch_hll_bitmaps(const uint8_t *d_img, uint32_t n, int p, uint32_t hdr, uint32_t lo, uint32_t band, uint32_t *d_bm, hipStream_t stream);
+hipError_t launch_hll_pairs_bitmap(const uint32_t *d_bm_ref, uint32_t n_ref, const uint32_t *d_bm_qry, uint32_t n_qry, int p, uint32_t lo,
+                                   uint32_t band, uint32_t *d_zero, double *d_sum, hipStream_t stream);
+
 // estimator: 0 = FGRA, 1 = ML (ull_estimators.h); d_est[r * n_qry + q] = estimated distinct count of the union
 hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
                             int estimator, double *d_est, hipStream_t stream);

@@ -30,9 +30,9 @@ a = img.view(torch.int16).reshape(n, 16384)
 for (i, j) in ((0, 0), (3, 17), (n - 1, 5)):
     wc = int(((a[i] == a[j]) & (a[i] != 0)).sum()); wn = int(((a[i] != 0) | (a[j] != 0)).sum())
     assert int(c[i, j]) == wc and int(m[i, j]) == wn, (i, j)
-for p in (12, 14):
+for p, lo_, hi_, what in ((12, 0, 30, "uniform 0..29"), (14, 0, 30, "uniform 0..29"), (14, 7, 27, "genome-like band 7..26")):
     ib = 33 + (1 << p)
-    h = torch.randint(0, 30, (n, ib), dtype=torch.uint8, device="cuda", generator=g)
+    h = torch.randint(lo_, hi_, (n, ib), dtype=torch.uint8, device="cuda", generator=g)
     z = torch.zeros((n, n), dtype=torch.int32, device="cuda")
     s = torch.zeros((n, n), dtype=torch.float64, device="cuda")
     def run_hll():
@@ -43,7 +43,7 @@ for p in (12, 14):
     for _ in range(3): run_hll()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print("hll p=%d pairs: %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (p, n, n, dt * 1e3, n * n / dt, n * n * (1 << p) / dt))
+    print("hll p=%d pairs (%s): %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (p, what, n, n, dt * 1e3, n * n / dt, n * n * (1 << p) / dt))
 # UltraLogLog: realistic register values (genome-like sketches: values within a band of ~24 around 4 * (p + log2(n/m)))
 for p, est in ((12, "fgra"), (12, "ml"), (10, "fgra"), (16, "fgra")):
     ib = 8 + (1 << p)
