@@ -114,9 +114,6 @@ __global__ void __launch_bounds__(256) hmh_pairs_kernel(const uint8_t *__restric
 // the query vectors (collision_gemm_kernel, v_mfma_f64_16x16x4_f64).  The sum runs in another order than the crate's
 // loop: results agree to ~1e-13 relative, far inside the 6 decimals `dist` prints.
 constexpr int EC_CELLS = 65536;              // 64 x 1024
-constexpr int EC_KC = 32;                    // cells per LDS stage
-constexpr int EC_LD = EC_KC + 1;             // padded LDS row (doubles)
-
 __global__ void __launch_bounds__(256) collision_vectors_kernel(const double *__restrict__ card, double *__restrict__ P)
 {
     const uint32_t cell = blockIdx.x * 256u + threadIdx.x, s = blockIdx.y;
@@ -138,48 +135,65 @@ __global__ void __launch_bounds__(256) collision_vectors_kernel(const double *__
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-// X[M][N] = A[M][65536] * B[N][65536]^T.  One workgroup = a 64 x 64 tile of X; its four waves own 32 x 32 quarters as
-// 2 x 2 MFMA blocks.  Operand layout of v_mfma_f64_16x16x4_f64: A lane l = A[row l&15][k l>>4], B lane l = B[k l>>4][col l&15],
+// X[M][N] = A[M][65536] * B[N][65536]^T.  One workgroup = a 128 x 128 tile of X; its four waves own 64 x 64 quarters as
+// 4 x 4 MFMA blocks (16 flop per byte of vector data read; 64 x 64 tiles at 8 flop/B were bound by re-reading the vectors:
+// 2.9 TB/s, 25 TFLOP/s).  The next 16 cells of the tile's 256 rows are fetched into registers while the current 16 are
+// multiplied out of LDS.  Tiles are numbered so that the workgroups an XCD receives (every 8th) form one band of rows: they
+// share A through that XCD's L2.
+// Operand layout of v_mfma_f64_16x16x4_f64: A lane l = A[row l&15][k l>>4], B lane l = B[k l>>4][col l&15],
 // D register i of lane l = D[row (l>>4) + 4i][col l&15].
+constexpr int EC_T = 128;                    // tile edge
+constexpr int EC_KC = 16;                    // cells per LDS stage
+constexpr int EC_LD = EC_KC + 1;             // padded LDS row (doubles)
+
 __global__ void __launch_bounds__(256) collision_gemm_kernel(const double *__restrict__ A, uint32_t M, const double *__restrict__ B,
-                                                             uint32_t N, double *__restrict__ X)
+                                                             uint32_t N, double *__restrict__ X, uint32_t tiles_x, uint32_t n_tiles)
 {
-    __shared__ double As[64][EC_LD], Bs[64][EC_LD];
+    __shared__ double As[EC_T][EC_LD], Bs[EC_T][EC_LD];
+    const uint32_t per_xcd = (n_tiles + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t r0 = blockIdx.y * 64u, q0 = blockIdx.x * 64u;
-    const uint32_t wr = (wave >> 1) * 32u, wq = (wave & 1u) * 32u;
-    v4f64 acc[2][2];
+    const uint32_t r0 = (tile / tiles_x) * EC_T, q0 = (tile % tiles_x) * EC_T;
+    const uint32_t wr = (wave >> 1) * 64u, wq = (wave & 1u) * 64u;
+    v4f64 acc[4][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
-    const uint32_t lrow = tid >> 2, lk = (tid & 3u) * 8u;         // staging: 4 threads x 8 cells per row
+        for (int b = 0; b < 4; ++b) acc[a][b] = v4f64{0.0, 0.0, 0.0, 0.0};
+    // staging: thread t moves 8 consecutive cells of row t/2 (of A and of B): 2 threads x 8 cells = the 16 cells of a stage
+    const uint32_t lrow = tid >> 1, lk = (tid & 1u) * 8u;
     const bool a_ok = r0 + lrow < M, b_ok = q0 + lrow < N;
     const double *ap = A + (uint64_t)(a_ok ? r0 + lrow : 0u) * EC_CELLS + lk;
     const double *bp = B + (uint64_t)(b_ok ? q0 + lrow : 0u) * EC_CELLS + lk;
+    double pa[8], pb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { pa[u] = a_ok ? ap[u] : 0.0; pb[u] = b_ok ? bp[u] : 0.0; }
     for (uint32_t k0 = 0; k0 < (uint32_t)EC_CELLS; k0 += EC_KC) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            As[lrow][lk + u] = a_ok ? ap[k0 + u] : 0.0;
-            Bs[lrow][lk + u] = b_ok ? bp[k0 + u] : 0.0;
-        }
+        for (int u = 0; u < 8; ++u) { As[lrow][lk + u] = pa[u]; Bs[lrow][lk + u] = pb[u]; }
         __syncthreads();
+        if (k0 + EC_KC < (uint32_t)EC_CELLS) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { pa[u] = a_ok ? ap[k0 + EC_KC + u] : 0.0; pb[u] = b_ok ? bp[k0 + EC_KC + u] : 0.0; }
+        }
 #pragma unroll
         for (int kk = 0; kk < EC_KC; kk += 4) {
             const uint32_t kc = kk + (lane >> 4), rr = lane & 15u;
-            const double a0 = As[wr + rr][kc], a1 = As[wr + 16u + rr][kc];
-            const double b0 = Bs[wq + rr][kc], b1 = Bs[wq + 16u + rr][kc];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            double av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { av[a] = As[wr + 16u * a + rr][kc]; bv[a] = Bs[wq + 16u * a + rr][kc]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t r = r0 + wr + 16u * a + (lane >> 4) + 4u * i, q = q0 + wq + 16u * b + (lane & 15u);
@@ -254,19 +268,29 @@ __global__ void __launch_bounds__(256) hll_pairs_kernel(const uint8_t *__restric
 __global__ void __launch_bounds__(256) hll_minmax_kernel(const uint8_t *__restrict__ img, uint32_t hdr, uint64_t stride, uint32_t m,
                                                          uint32_t *__restrict__ lohi)
 {
-    // block = 1 024 registers of sketch blockIdx.y, four consecutive bytes per lane (the rows sit at odd addresses)
-    const uint8_t *p = img + (uint64_t)blockIdx.y * stride + hdr + (uint64_t)blockIdx.x * 1024u + threadIdx.x * 4u;
-    (void)m;
-    const uint32_t a = p[0], b = p[1], c = p[2], d = p[3];
-    uint32_t lo = a < b ? a : b, hi = a > b ? a : b;
-    lo = c < lo ? c : lo; lo = d < lo ? d : lo;
-    hi = c > hi ? c : hi; hi = d > hi ? d : hi;
+    // one workgroup per sketch, four consecutive bytes per lane and step (the rows sit at odd addresses); two atomics per
+    // workgroup — per-wave atomics on the two words serialised into 2 ms for 2 048 sketches
+    __shared__ uint32_t wlo[4], whi[4];
+    const uint8_t *row = img + (uint64_t)blockIdx.x * stride + hdr;
+    uint32_t lo = 255u, hi = 0u;
+    for (uint32_t at = threadIdx.x * 4u; at < m; at += 1024u) {
+        const uint32_t a = row[at], b = row[at + 1], c = row[at + 2], d = row[at + 3];
+        const uint32_t l1 = a < b ? a : b, l2 = c < d ? c : d, h1 = a > b ? a : b, h2 = c > d ? c : d;
+        lo = l1 < lo ? l1 : lo; lo = l2 < lo ? l2 : lo;
+        hi = h1 > hi ? h1 : hi; hi = h2 > hi ? h2 : hi;
+    }
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x & 63u) == 0u) { atomicMin(&lohi[0], lo); atomicMax(&lohi[1], hi); }
+    if ((threadIdx.x & 63u) == 0u) { wlo[threadIdx.x >> 6] = lo; whi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { lo = wlo[w] < lo ? wlo[w] : lo; hi = whi[w] > hi ? whi[w] : hi; }
+        atomicMin(&lohi[0], lo);
+        atomicMax(&lohi[1], hi);
+    }
 }
 
 // bm[s][tt][w]: bit i of word w set <=> register 32 w + i of sketch s is <= lo + tt
@@ -545,11 +569,7 @@ hipError_t launch_hll_minmax(const uint8_t *d_img, uint32_t n, int p, uint32_t h
 {
     if (n == 0) return hipSuccess;
     const uint32_t m = 1u << p;                                          // p >= 10: a multiple of 1 024
-    for (uint32_t s0 = 0; s0 < n; s0 += 65535u) {
-        const uint32_t ns = std::min(65535u, n - s0);
-        hipLaunchKernelGGL(hll_minmax_kernel, dim3(m / 1024, ns), dim3(256), 0, stream, d_img + (uint64_t)s0 * ((uint64_t)hdr + m), hdr,
-                           (uint64_t)hdr + m, m, d_lohi);
-    }
+    hipLaunchKernelGGL(hll_minmax_kernel, dim3(n), dim3(256), 0, stream, d_img, hdr, (uint64_t)hdr + m, m, d_lohi);
     return hipGetLastError();
 }
 
@@ -587,7 +607,8 @@ hipError_t launch_collision_vectors(const double *d_card, uint32_t n, double *d_
 hipError_t launch_collision_gemm(const double *d_A, uint32_t m, const double *d_B, uint32_t n, double *d_X, hipStream_t stream)
 {
     if (m == 0 || n == 0) return hipSuccess;
-    hipLaunchKernelGGL(collision_gemm_kernel, dim3((n + 63) / 64, (m + 63) / 64), dim3(256), 0, stream, d_A, m, d_B, n, d_X);
+    const uint32_t tx = (n + EC_T - 1) / EC_T, ty = (m + EC_T - 1) / EC_T, tiles = tx * ty;
+    hipLaunchKernelGGL(collision_gemm_kernel, dim3(((tiles + 7u) / 8u) * 8u), dim3(256), 0, stream, d_A, m, d_B, n, d_X, tx, tiles);
     return hipGetLastError();
 }
 

@@ -60,7 +60,7 @@ for p, est in ((12, "fgra"), (12, "ml"), (10, "fgra"), (16, "fgra")):
     print("ull p=%d %s pairs: %d x %d in %.2f ms -> %.3g pairs/s (%.3g register pairs/s)" % (p, est, nn, nn, dt * 1e3, nn * nn / dt, nn * nn * (1 << p) / dt))
 # hyperminhash's expected-collision term for small sketches: cell vectors + f64 MFMA product
 rc_, qc_ = np.random.default_rng(3).uniform(1e3, 5e5, n), np.random.default_rng(4).uniform(1e3, 5e5, n)
-ctx.hmh_pair_expected_collisions(rc_[:8], qc_[:8])
+ctx.hmh_pair_expected_collisions(rc_, qc_[::-1].copy())          # (allocates the vector buffers; other queries than the timed call)
 t0 = time.perf_counter()
 ec = ctx.hmh_pair_expected_collisions(rc_, qc_)
 dt = time.perf_counter() - t0
