@@ -48,7 +48,7 @@ for p, lo_, hi_, what in ((12, 0, 30, "uniform 0..29"), (14, 0, 30, "uniform 0..
 for p, est in ((12, "fgra"), (12, "ml"), (10, "fgra"), (16, "fgra")):
     ib = 8 + (1 << p)
     nn = n if p < 16 else max(64, n // 8)
-    u = torch.randint(60, 92, (nn, ib), dtype=torch.uint8, device="cuda", generator=g)
+    u = torch.randint(4 * p + 12, 4 * p + 44, (nn, ib), dtype=torch.uint8, device="cuda", generator=g)   # (p = 12: 60..91)
     e = torch.zeros((nn, nn), dtype=torch.float64, device="cuda")
     def run_ull():
         ctx.ull_pair_union_estimates_device(p, est, u, nn, u, nn, e)
