@@ -442,3 +442,15 @@ def test_threaded_fastq_check_equals_the_sequential_one():
     # the last record without its final newline, and a buffer below the threshold
     assert H.fastq_valid_prefix_mt(good[:-1], 4) == seq_prefix(good[:-1]) == len(good) - 1
     assert H.fastq_valid_prefix_mt(good[:1000], 4) == seq_prefix(good[:1000])
+
+
+def test_name_order_with_odd_names():
+    """names of every XXH3 length class (0 .. > 240 bytes once the 0xFF terminator is added), non-ASCII paths, one-letter and
+    empty names: the two restatements agree and every name appears once"""
+    pytest.importorskip("xxhash")
+    import pyref as R
+    names = ["", "a", "ab"] + ["n" * k for k in (3, 7, 8, 15, 16, 17, 127, 128, 129, 239, 240, 241, 300, 1025)]
+    names += ["données/génome_%d.fa" % i for i in range(20)] + ["样本/基因组%d.fna.gz" % i for i in range(20)]
+    got = H.name_order(names)
+    assert got == R.hashbrown_name_order(names)
+    assert sorted(got) == list(range(len(names)))
