@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -89,6 +90,12 @@ std::string slurp(const std::string &path, std::string &out)
 
 std::string run_dist(const DistOptions &opt)
 {
+    // LASH_CLI_TIMING: where the wall time of a run goes
+    const bool timing = getenv("LASH_CLI_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (timing) fprintf(stderr, "[lash dist] %7.3f s  %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), what);
+    };
     std::map<std::string, std::string> rf, qf;
     std::string err = find_files(opt.ref_prefix, rf);
     if (err.empty()) err = find_files(opt.query_prefix, qf);
@@ -128,9 +135,12 @@ std::string run_dist(const DistOptions &opt)
     if (same_files && !opt.file_order)
         for (uint32_t jj = 0; jj < qorder.size(); ++jj) qpos[qnames[qorder[jj]]] = jj;
 
-    std::vector<uint8_t> rimg, qimg;
-    if (!(err = zstd_decompress_file(rf["sketches"], rimg)).empty()) return err;
-    if (!(err = zstd_decompress_file(qf["sketches"], qimg)).empty()) return err;
+    std::vector<uint8_t> rimg_store, qimg_store;
+    if (!(err = zstd_decompress_file(rf["sketches"], rimg_store)).empty()) return err;
+    const bool same_sketches = rf["sketches"] == qf["sketches"];                   // all-vs-all: one file, read once
+    if (!same_sketches && !(err = zstd_decompress_file(qf["sketches"], qimg_store)).empty()) return err;
+    const std::vector<uint8_t> &rimg = rimg_store, &qimg = same_sketches ? rimg_store : qimg_store;
+    mark("sketch files read and inflated");
     const int algo_id = hll ? LASH_HLL : ull ? LASH_ULL : LASH_HMH;
     const int prec = (hll || ull) ? atoi(rp["precision"].c_str()) : 0;
     if (hll && (prec < 4 || prec > 16)) return "bad precision in " + rf["params"];
@@ -175,15 +185,27 @@ std::string run_dist(const DistOptions &opt)
     if (same_files && rf["sketches"] == qf["sketches"]) qcard = rcard;
     else if (!(err = cards(qimg, qnames, qcard)).empty()) return err;
 
+    mark("per-sketch cardinalities");
+    // hyperminhash's expected collisions need the GPU only when some pair has both sketches at or below 2^19 distinct k-mers
+    bool small_ref = false, small_qry = false;
+    if (!hll && !ull) {
+        for (uint32_t i : rorder) small_ref = small_ref || !(rcard[i] > 524288.0);
+        for (double c : qcard) small_qry = small_qry || !(c > 524288.0);
+    }
+    const bool gpu_ec = small_ref && small_qry;
     FILE *out = fopen(opt.output_file.c_str(), "w");
     if (!out) return "cannot create " + opt.output_file;
     if (!opt.matrix) fprintf(out, "Reference\tQuery\tDistance\n");                                   // main.rs:409-412
     else for (uint32_t j : qorder) fprintf(out, "\t%s", qnames[j].c_str());                          // main.rs:439-441
     // ---- GPU: the O(N_ref * N_qry * registers) scan, in blocks of reference rows so that the per-pair tables stay
     //      bounded (all-vs-all on 10^5 sketches is 10^10 pairs); one worker (context + host thread) per device ----
-    std::vector<int> devices = opt.devices.empty() ? std::vector<int>{opt.device} : opt.devices;
+    // Without --devices, two workers share the GPU: while one formats and writes its block the other has the next block's
+    // pair statistics computed (a block is GPU work, then -t threads of formatting, then an ordered write).
+    std::vector<int> devices = opt.devices.empty() ? std::vector<int>{opt.device, opt.device} : opt.devices;
+    // rows per block: pair tables of at most 64 M entries, and at least ~16 blocks so that the workers overlap
     const uint32_t rows_per_block = opt.block_rows ? std::min(opt.block_rows, std::max(nr, 1u))
-                                                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nr, (64ull << 20) / std::max<uint32_t>(nq, 1)));
+                                                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(64, (nr + 15) / 16),
+                                                                                                       std::min<uint64_t>(nr, (64ull << 20) / std::max<uint32_t>(nq, 1))));
     const uint32_t n_blocks = nr ? (nr + rows_per_block - 1) / rows_per_block : 0;
     if (devices.size() > n_blocks) devices.resize(std::max<uint32_t>(n_blocks, 1));
     const int fmt_threads = std::max(1, opt.threads / (int)devices.size());
@@ -223,7 +245,7 @@ std::string run_dist(const DistOptions &opt)
                 rc = hll ? lash_hll_pair_union_stats(ctx, prec, rblk, i1 - i0, qimg.data(), nq, C.data(), U.data())
                    : ull ? lash_ull_pair_union_estimates(ctx, prec, ull_est, rblk, i1 - i0, qimg.data(), nq, U.data())
                          : lash_hmh_pair_counts(ctx, rblk, i1 - i0, qimg.data(), nq, C.data(), N.data());
-                if (rc == LASH_OK && !hll && !ull) {
+                if (rc == LASH_OK && gpu_ec) {
                     // hyperminhash's expected_collisions for the block: O(1) per pair above 2^19 distinct k-mers, a 65 536-cell sum
                     // below — on the host that is 4 ms to 0.2 s per pair; the library does it as one matrix product on the GPU
                     rc_blk.resize(i1 - i0);
@@ -248,7 +270,7 @@ std::string run_dist(const DistOptions &opt)
                     const uint32_t my_pos = !same_files ? 0 : opt.file_order ? i : qpos.at(rname);
                     const int drc = lash_dist_rows(algo_id, prec, k, opt.model, opt.fp32 ? 1 : 0, 1, nq, &rcard[ri], qcard.data(),
                                                    ull ? nullptr : C.data() + row, (hll || ull) ? nullptr : N.data() + row,
-                                                   (hll || ull) ? U.data() + row : nullptr, bias, (hll || ull) ? nullptr : EC.data() + row,
+                                                   (hll || ull) ? U.data() + row : nullptr, bias, gpu_ec ? EC.data() + row : nullptr,
                                                    dist.data(), &bad_pair);
                     if (drc == LASH_ERANGE) { row_fail[i - i0] = "union of " + rname + " and " + qnames[bad_pair] + bias_msg; return; }
                     if (drc != LASH_OK) { row_fail[i - i0] = lash_strerror(drc); return; }
@@ -295,6 +317,7 @@ std::string run_dist(const DistOptions &opt)
         for (auto &t : pool) t.join();
     }
     fclose(out);
+    mark("all rows written");
     return fail;
 }
 

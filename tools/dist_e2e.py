@@ -31,6 +31,7 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as td:
         r = subprocess.run([H.CLI, "dist", "-q", "s", "-r", "s", "-o", "d.txt", "-t", str(threads)], cwd=td, capture_output=True, text=True)
         dt = time.perf_counter() - t0
         assert r.returncode == 0, r.stderr
+        sys.stderr.write(r.stderr)
         rows = n * (n + 1) // 2
         print("lash dist -t %d: %d sketches, %d pairs in %.2f s -> %.3g pairs/s (output %.1f MB)" %
               (threads, n, rows, dt, rows / dt, os.path.getsize(os.path.join(td, "d.txt")) / 1e6))
