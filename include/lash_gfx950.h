@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LASH_ABI_VERSION 2
+#define LASH_ABI_VERSION 3
 
 /* error codes */
 #define LASH_OK       0
@@ -282,6 +282,45 @@ int    lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_re
  * lash_hmh_pair_expected_collisions computes them on the GPU.  NULL: computed here on the host — O(1) for cardinalities above
  * 2^19, but a walk over 65 536 cells with four pow() each (4 ms to 0.2 s PER PAIR, as in the crate) when both sketches are
  * smaller: viruses, plasmids, short contigs. */
+
+/* ---- dist side, resident form: all-vs-all on whole collections (BASELINE configs[3]: 10^5 sketches, 5 * 10^9 printed pairs) ----
+ * `lash dist` keeps both sketch files in memory for the run (utils.rs:95-127, 202-242, 303-337), takes one cardinality per
+ * sketch (utils.rs:170-173, 213-219, 314-315) and walks reference rows x query columns — the lower triangle only when both are
+ * the same files (utils.rs:150-180).  A lash_sketch_set is the device-side counterpart: N serialized sketches resident in HBM,
+ * uploaded (or adopted from device memory, e.g. the result of an all-gather) ONCE, plus what the pair kernels derive from them
+ * once: HyperMinHash register bit planes, HyperLogLog threshold bitmaps.
+ *   create          images: n_images serialized sketches of (algo, p) in the context's layout, host memory; member i of the set is
+ *                   images[order[i]] (order NULL: member i = image i, n == n_images) — `order` is how a caller puts the set into
+ *                   the reference's hash-map key order so that the printed triangle is the set's lower triangle
+ *   create_device   adopts d_images (n sketches, set order) without copying; they must outlive the set
+ *   cardinalities   per-member distinct-count estimates, the same numbers as lash_hmh_cardinality / lash_hll_cardinality /
+ *                   lash_ull_estimate give for each image: register histograms on the GPU, O(histogram) finish on the host.
+ *                   LASH_ERANGE: an HLL member fell into the bias-table regime and `tables` does not cover it (*bad_index)
+ *   prepare         builds what pair_block needs for this (reference, query) combination (may be the same set); call it once,
+ *                   from one thread, before the first pair_block of the combination.  Not needed for correctness: without it
+ *                   pair_block falls back to the kernels that read the images themselves (several times slower)
+ *   pair_block      statistics of set rows [r0, r1) of `ref` against columns [0, n_cols) of `qry`, row-major [r1 - r0][n_cols]:
+ *                   hmh: out_c_or_zero = C, out_n = N (lash_hmh_pair_counts); hll: out_c_or_zero = zero, out_sum_or_union = sum
+ *                   (lash_hll_pair_union_stats); ull: out_sum_or_union = the union estimate (lash_ull_pair_union_estimates).
+ *                   triangle != 0 (ref == qry): only entries with column <= r0 + row are defined — tiles wholly above the
+ *                   diagonal are skipped (utils.rs:158-160).  A caller that wants the triangle passes n_cols = r1.
+ *                   Sets are read-only here: several contexts (host threads) of the same device may call pair_block on the
+ *                   same prepared sets concurrently.  _device: outputs in device memory, asynchronous on the context's stream. */
+typedef struct lash_sketch_set lash_sketch_set;
+int      lash_sketch_set_create(lash_ctx *ctx, int algo, int p, const uint8_t *images, uint32_t n_images, const uint32_t *order, uint32_t n,
+                                lash_sketch_set **out);
+int      lash_sketch_set_create_device(lash_ctx *ctx, int algo, int p, const uint8_t *d_images, uint32_t n, lash_sketch_set **out);
+void     lash_sketch_set_free(lash_ctx *ctx, lash_sketch_set *set);
+uint32_t lash_sketch_set_size(const lash_sketch_set *set);
+int      lash_sketch_set_cardinalities(lash_ctx *ctx, const lash_sketch_set *set, int ull_estimator, const lash_hll_bias *tables,
+                                       double *out_card, uint32_t *bad_index);
+int      lash_sketch_set_prepare(lash_ctx *ctx, lash_sketch_set *ref, lash_sketch_set *qry);
+int      lash_sketch_set_pair_block(lash_ctx *ctx, const lash_sketch_set *ref, uint32_t r0, uint32_t r1, const lash_sketch_set *qry,
+                                    uint32_t n_cols, int triangle, int ull_estimator, uint32_t *out_c_or_zero, uint32_t *out_n,
+                                    double *out_sum_or_union);
+int      lash_sketch_set_pair_block_device(lash_ctx *ctx, const lash_sketch_set *ref, uint32_t r0, uint32_t r1, const lash_sketch_set *qry,
+                                           uint32_t n_cols, int triangle, int ull_estimator, uint32_t *d_c_or_zero, uint32_t *d_n,
+                                           double *d_sum_or_union);
 
 /* hyperminhash's expected_collisions(n, m) for every pair of an [n_ref x n_qry] block from the per-sketch cardinalities (host
  * arrays in, host array out).  Above 2^19 (either sketch) the crate's closed form; below, the 65 536-cell sum as a product of

@@ -13,7 +13,7 @@ OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE, EFORMAT = 0, -1, -2, -3, -4, -
 HMH, HLL, ULL = 0, 1, 2
 F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT = 1, 2, 4
 FMT_FASTA, FMT_FASTQ = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Params(C.Structure):
@@ -91,6 +91,14 @@ PROTOTYPES = {
     "lash_hll_cardinality": (_int, [_vp, _int, _vp, C.POINTER(C.c_double)]),
     "lash_dist_rows": (_int, [_int, _int, _int, _int, _int, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
     "lash_hmh_pair_expected_collisions": (_int, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "lash_sketch_set_create": (_int, [_vp, _int, _int, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),
+    "lash_sketch_set_create_device": (_int, [_vp, _int, _int, _vp, _u32, C.POINTER(_vp)]),
+    "lash_sketch_set_free": (None, [_vp, _vp]),
+    "lash_sketch_set_size": (_u32, [_vp]),
+    "lash_sketch_set_cardinalities": (_int, [_vp, _vp, _int, _vp, _vp, C.POINTER(_u32)]),
+    "lash_sketch_set_prepare": (_int, [_vp, _vp, _vp]),
+    "lash_sketch_set_pair_block": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _int, _int, _vp, _vp, _vp]),
+    "lash_sketch_set_pair_block_device": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _int, _int, _vp, _vp, _vp]),
     "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),
 }
 

@@ -8,8 +8,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "liblash_gfx950.so")
-SOURCES = ["lash_api.hip", "sketch_kernels.hip", "pack_kernels.hip", "dist_kernels.hip", "dist_estimators.hip"]
-HEADERS = ["lash_common.h", "lash_kernels.h", "lash_device.h", "ull_estimators.h", os.path.join(ROOT, "include", "lash_gfx950.h")]
+SOURCES = ["lash_api.hip", "sketch_set.hip", "sketch_kernels.hip", "pack_kernels.hip", "dist_kernels.hip", "pair_planes.hip", "dist_estimators.hip"]
+HEADERS = ["lash_common.h", "lash_ctx.h", "lash_kernels.h", "lash_device.h", "ull_estimators.h", os.path.join(ROOT, "include", "lash_gfx950.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 
@@ -20,21 +20,44 @@ def _hipcc():
     raise RuntimeError("hipcc not found: liblash_gfx950.so cannot be built (there is no CPU fallback)")
 
 
+OBJ_DIR = os.path.join(ROOT, "build", "obj")
+
+
+def _deps():
+    return [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _deps()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build_library(force=False, verbose=False):
+    """One object per source (only the stale ones are recompiled, in parallel), then one link."""
     if not force and not _stale():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdr_t = max(os.path.getmtime(d) for d in _deps())
+    compile_flags = [f for f in FLAGS if f != "-shared"] + ["-c"]
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src + ".o")
+        sp = os.path.join(CSRC, src)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(sp)):
+            jobs.append([hipcc] + compile_flags + ["-o", obj, sp])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(len(jobs) or 1, os.cpu_count() or 1, 8)) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [os.path.join(OBJ_DIR, s + ".o") for s in SOURCES])
     return LIB
 
 

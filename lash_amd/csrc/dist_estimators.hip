@@ -33,6 +33,13 @@ double hmh_beta(double ez)
            0.00042419 * std::pow(zl, 7);
 }
 
+double hmh_card_from_sums(double ez, double sum)
+{
+    const double m = (double)HM;
+    const double alpha = 0.7213 / (1.0 + 1.079 / m);
+    return alpha * m * (m - ez) / (hmh_beta(ez) + sum);
+}
+
 double hmh_cell_sum(double n, double m)
 {
     const double two_q = 64.0, two_r = 1024.0;
@@ -96,6 +103,23 @@ bool hmh_ec_closed_form(double n, double m, double *out)
 }
 
 double hmh_ec_from_cell_sum(double x) { return (x * (double)HP + 0.5) / (double)HP; }
+
+// hyperminhash's cardinality() from the histogram of the registers' 6-bit leading-zero fields (lash_sketch_set_cardinalities:
+// the histogram comes from the GPU).  The crate adds 2^-lz register by register; while no register has lz > 39 every partial
+// sum of that loop is exact (multiples of 2^-39 below 2^14 fit 53 bits), so any order gives the same bits.  Otherwise
+// *exact = false and the caller falls back to the register-order loop (lash_hmh_cardinality).
+double hmh_cardinality_from_hist(const uint32_t *hist64, bool *exact)
+{
+    double sum = 0.0;
+    bool ok = true;
+    for (int lz = 0; lz < 64; ++lz) {
+        if (!hist64[lz]) continue;
+        if (lz > 39) ok = false;
+        sum += (double)hist64[lz] * std::ldexp(1.0, -lz);
+    }
+    if (exact) *exact = ok;
+    return hmh_card_from_sums((double)hist64[0], sum);
+}
 
 double hmh_ec_cell_walk(double n, double m)
 {
@@ -161,6 +185,18 @@ T compute_distance(T frac, int k, int model)
 
 }  // namespace
 
+namespace lash {
+
+int hll_cardinality_from_hist(const uint32_t *hist256, int p, const lash_hll_bias *tables, double *out)
+{
+    double sum = 0.0;
+    for (int r = 255; r >= 0; --r)
+        if (hist256[r]) sum += (double)hist256[r] * std::ldexp(1.0, -r);      // exact powers of two, largest exponent first
+    return hll_len(p, hist256[0], sum, tables, *out) ? LASH_OK : LASH_ERANGE;
+}
+
+}  // namespace lash
+
 extern "C" {
 
 double lash_hmh_cardinality(const uint8_t *regs, int big_endian)
@@ -173,9 +209,7 @@ double lash_hmh_cardinality(const uint8_t *regs, int big_endian)
         if (lz == 0) ez += 1.0;
         sum += std::ldexp(1.0, -(int)lz);                       // == 1 / 2^lz exactly
     }
-    const double m = (double)HM;
-    const double alpha = 0.7213 / (1.0 + 1.079 / m);
-    return alpha * m * (m - ez) / (hmh_beta(ez) + sum);
+    return hmh_card_from_sums(ez, sum);
 }
 
 // Text format: '#' comment lines; "p <p> <n>" then n lines "<raw estimate> <bias>", for any subset of p = 4..18.
@@ -228,10 +262,7 @@ int lash_hll_cardinality(const uint8_t *regs, int p, const lash_hll_bias *tables
     if (!regs || !out || p < 4 || p > 16) return LASH_EINVAL;
     uint32_t hist[256] = {0};
     for (size_t i = 0, m = (size_t)1 << p; i < m; ++i) hist[regs[i]]++;
-    double sum = 0.0;
-    for (int r = 255; r >= 0; --r)
-        if (hist[r]) sum += (double)hist[r] * std::ldexp(1.0, -r);      // exact powers of two, largest exponent first
-    return hll_len(p, hist[0], sum, tables, *out) ? LASH_OK : LASH_ERANGE;
+    return lash::hll_cardinality_from_hist(hist, p, tables, out);
 }
 
 int lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, uint32_t n_qry, const double *ref_card,

@@ -18,6 +18,14 @@ namespace lash {
 
 constexpr int DT = 16;                 // HLL kernel: tile edge (pairs), one pair per lane
 
+// Triangular calls (reference set == query set, utils.rs:158-160: only pairs with column <= row are printed).  `tri` is the
+// set index of the call's first row (-1: rectangular call); a tile whose first column lies beyond its last row has nothing
+// wanted in it and returns at once — its outputs stay unwritten.
+__device__ __forceinline__ bool tile_above_diagonal(int64_t tri, uint32_t r0, uint32_t tile_rows, uint32_t q0)
+{
+    return tri >= 0 && (int64_t)q0 > tri + (int64_t)r0 + (int64_t)tile_rows - 1;
+}
+
 // ---- HyperMinHash: two u16 registers per u32, compared with packed 16-bit VALU ops --------------------------------------
 // per half h of a word pair (a, b):   [a_h != 0 and a_h != b_h] = min(a_h ^ b_h, min(a_h, 1))
 //                                     [a_h != 0 or  b_h != 0]   = min(a_h, 1) | min(b_h, 1)
@@ -46,11 +54,12 @@ __device__ __forceinline__ uint32_t hmh_word(const uint8_t *img, uint32_t w)
 __global__ void __launch_bounds__(256) hmh_pairs_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
                                                         const uint8_t *__restrict__ qry, uint32_t n_qry, uint32_t hdr,
                                                         uint64_t stride, uint32_t *__restrict__ out_c,
-                                                        uint32_t *__restrict__ out_n)
+                                                        uint32_t *__restrict__ out_n, int64_t tri)
 {
     __shared__ __attribute__((aligned(16))) uint32_t R[HCW][HSTRIDE], Q[HCW][HSTRIDE];
     const uint32_t tid = threadIdx.x, tr = tid / 16, tq = tid % 16;           // lane block: rows tr*4.., columns tq*4..
     const uint32_t r0 = blockIdx.y * HT, q0 = blockIdx.x * HT;
+    if (tile_above_diagonal(tri, r0, HT, q0)) return;
     constexpr uint32_t WORDS = HMH_M / 2;                                       // 8192 u32 per sketch
     uint32_t one = 0x00010001u;
     asm volatile("" : "+v"(one));                                              // keep it in a VGPR (VOP3P operand)
@@ -211,11 +220,12 @@ constexpr int HROW = HCHUNK / 4 + 1;         // LDS row in words, padded
 
 __global__ void __launch_bounds__(256) hll_pairs_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
                                                         const uint8_t *__restrict__ qry, uint32_t n_qry, int p, uint32_t hdr,
-                                                        uint32_t *__restrict__ out_zero, double *__restrict__ out_sum)
+                                                        uint32_t *__restrict__ out_zero, double *__restrict__ out_sum, int64_t tri)
 {
     __shared__ uint32_t R[DT][HROW], Q[DT][HROW];
     const uint32_t tid = threadIdx.x, tr = tid / DT, tq = tid % DT;
     const uint32_t r0 = blockIdx.y * DT, q0 = blockIdx.x * DT;
+    if (tile_above_diagonal(tri, r0, DT, q0)) return;
     const uint32_t m = 1u << p;
     const uint64_t stride = (uint64_t)hdr + m;
     unsigned long long s1 = 0, s2 = 0;          // sum of 2^(32-r) over r <= 32 ; sum of 2^(64-r) over r > 32
@@ -311,11 +321,12 @@ __global__ void __launch_bounds__(256) hll_bitmaps_kernel(const uint8_t *__restr
 template <bool WIDE, bool ZERO>
 __global__ void __launch_bounds__(256) hll_pairs_bitmap_kernel(const uint32_t *__restrict__ bmR, uint32_t n_ref, const uint32_t *__restrict__ bmQ,
                                                                uint32_t n_qry, uint32_t words, uint32_t lo, uint32_t band, uint32_t m,
-                                                               uint32_t *__restrict__ out_zero, double *__restrict__ out_sum)
+                                                               uint32_t *__restrict__ out_zero, double *__restrict__ out_sum, int64_t tri)
 {
     __shared__ __attribute__((aligned(16))) uint32_t R[HCW][HSTRIDE], Q[HCW][HSTRIDE];
     const uint32_t tid = threadIdx.x, tr = tid / 16, tq = tid % 16;
     const uint32_t r0 = blockIdx.y * HT, q0 = blockIdx.x * HT;
+    if (tile_above_diagonal(tri, r0, HT, q0)) return;
     const uint32_t chunk = words < (uint32_t)HCW ? words : (uint32_t)HCW;       // m >= 1024: 32 words or more
     unsigned long long s1[HB][HB], s2[WIDE ? HB : 1][WIDE ? HB : 1];
     uint32_t zero[ZERO ? HB : 1][ZERO ? HB : 1];
@@ -410,10 +421,12 @@ struct UllLaneHist {
 template <bool WIDE>
 __global__ void __launch_bounds__(WIDE ? 128 : 256) ull_pairs_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
                                                                       const uint8_t *__restrict__ qry, uint32_t n_qry, int p,
-                                                                      uint32_t hdr, int estimator, double *__restrict__ out, int fixup)
+                                                                      uint32_t hdr, int estimator, double *__restrict__ out, int fixup,
+                                                                      int64_t tri)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t LANES = WIDE ? 128u : 256u, TR = LANES / UQ, HW = (WIDE ? 256u : 128u) * LANES;
+    if (tile_above_diagonal(tri, blockIdx.y * TR, TR, blockIdx.x * UQ)) return;
     // the histogram is addressed with raw LDS addresses (ds_add below): the dynamic array must start at LDS address 0, i.e. this
     // kernel must own no static LDS — which rules out __syncthreads_or() (HIP implements it with a __shared__ word)
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0u) __builtin_trap();   // ds_add below takes raw LDS addresses
@@ -480,12 +493,13 @@ constexpr int FROW = FCHUNK / 4 + 1;
 
 __global__ void __launch_bounds__(256) ull_fgra_fast_kernel(const uint8_t *__restrict__ ref, uint32_t n_ref,
                                                             const uint8_t *__restrict__ qry, uint32_t n_qry, int p, uint32_t hdr,
-                                                            double *__restrict__ out)
+                                                            double *__restrict__ out, int64_t tri)
 {
     __shared__ double G[256];
     __shared__ uint32_t R[UQ][FROW], Q[UQ][FROW];
     const uint32_t tid = threadIdx.x, tr = tid / UQ, tq = tid % UQ;
     const uint32_t r0 = blockIdx.y * UQ, q0 = blockIdx.x * UQ;
+    if (tile_above_diagonal(tri, r0, UQ, q0)) return;
     const uint64_t m = 1ull << p, stride = (uint64_t)hdr + m;
     {
         const uint32_t r = tid, off = 4u * (uint32_t)p + 4u;
@@ -521,7 +535,7 @@ __global__ void __launch_bounds__(256) ull_fgra_fast_kernel(const uint8_t *__res
 }
 
 hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
-                            int estimator, double *d_est, hipStream_t stream)
+                            int estimator, double *d_est, hipStream_t stream, int64_t tri)
 {
     if (n_ref == 0 || n_qry == 0) return hipSuccess;
     const bool wide = p >= 16;
@@ -533,35 +547,35 @@ hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t 
     static const bool no_fast = getenv("LASH_ULL_NO_FAST") != nullptr;    // A/B knob (tools/dist_rate.py)
     if (estimator == 0 && !no_fast) {                     // FGRA: the histogram-free kernel first, the histogram kernel only where it gave up
         hipLaunchKernelGGL(ull_fgra_fast_kernel, dim3((n_qry + UQ - 1) / UQ, (n_ref + UQ - 1) / UQ), dim3(256), 0, stream, d_ref, n_ref,
-                           d_qry, n_qry, p, hdr, d_est);
+                           d_qry, n_qry, p, hdr, d_est, tri);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         fixup = 1;
     }
     if (wide) {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(ull_pairs_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(ull_pairs_kernel<true>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est, fixup);
+        hipLaunchKernelGGL(ull_pairs_kernel<true>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est, fixup, tri);
     } else {
         if ((e = hipFuncSetAttribute(reinterpret_cast<const void *>(ull_pairs_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(ull_pairs_kernel<false>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est, fixup);
+        hipLaunchKernelGGL(ull_pairs_kernel<false>, grid, dim3(lanes), lds, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, estimator, d_est, fixup, tri);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
-                            uint32_t *d_zero, double *d_sum, hipStream_t stream)
+                            uint32_t *d_zero, double *d_sum, hipStream_t stream, int64_t tri)
 {
     if (n_ref == 0 || n_qry == 0) return hipSuccess;
     dim3 grid((n_qry + DT - 1) / DT, (n_ref + DT - 1) / DT);
-    hipLaunchKernelGGL(hll_pairs_kernel, grid, dim3(256), 0, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, d_zero, d_sum);
+    hipLaunchKernelGGL(hll_pairs_kernel, grid, dim3(256), 0, stream, d_ref, n_ref, d_qry, n_qry, p, hdr, d_zero, d_sum, tri);
     return hipGetLastError();
 }
 
 hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t hdr,
-                            uint64_t stride, uint32_t *d_c, uint32_t *d_n, hipStream_t stream)
+                            uint64_t stride, uint32_t *d_c, uint32_t *d_n, hipStream_t stream, int64_t tri)
 {
     if (n_ref == 0 || n_qry == 0) return hipSuccess;
     dim3 grid((n_qry + HT - 1) / HT, (n_ref + HT - 1) / HT);
-    hipLaunchKernelGGL(hmh_pairs_kernel, grid, dim3(256), 0, stream, d_ref, n_ref, d_qry, n_qry, hdr, stride, d_c, d_n);
+    hipLaunchKernelGGL(hmh_pairs_kernel, grid, dim3(256), 0, stream, d_ref, n_ref, d_qry, n_qry, hdr, stride, d_c, d_n, tri);
     return hipGetLastError();
 }
 
@@ -586,14 +600,14 @@ hipError_t launch_hll_bitmaps(const uint8_t *d_img, uint32_t n, int p, uint32_t 
 }
 
 hipError_t launch_hll_pairs_bitmap(const uint32_t *d_bm_ref, uint32_t n_ref, const uint32_t *d_bm_qry, uint32_t n_qry, int p, uint32_t lo,
-                                   uint32_t band, uint32_t *d_zero, double *d_sum, hipStream_t stream)
+                                   uint32_t band, uint32_t *d_zero, double *d_sum, hipStream_t stream, int64_t tri)
 {
     if (n_ref == 0 || n_qry == 0) return hipSuccess;
     dim3 grid((n_qry + HT - 1) / HT, (n_ref + HT - 1) / HT);
     const bool wide = lo + band > 32u, zero = lo == 0u;
     auto kern = wide ? (zero ? hll_pairs_bitmap_kernel<true, true> : hll_pairs_bitmap_kernel<true, false>)
                      : (zero ? hll_pairs_bitmap_kernel<false, true> : hll_pairs_bitmap_kernel<false, false>);
-    hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, d_bm_ref, n_ref, d_bm_qry, n_qry, (1u << p) >> 5, lo, band, 1u << p, d_zero, d_sum);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream, d_bm_ref, n_ref, d_bm_qry, n_qry, (1u << p) >> 5, lo, band, 1u << p, d_zero, d_sum, tri);
     return hipGetLastError();
 }
 

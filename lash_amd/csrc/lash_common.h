@@ -2,6 +2,8 @@
 #pragma once
 #include <stdint.h>
 
+struct lash_hll_bias;      // include/lash_gfx950.h
+
 namespace lash {
 
 // ---- HBM layout of a packed batch (DESIGN.md "Data layout") ----------------------------------------------
@@ -73,5 +75,8 @@ inline uint64_t xxh3_bitflip128(uint64_t seed) { return (XXH_SEC16 ^ XXH_SEC24) 
 bool hmh_ec_closed_form(double n, double m, double *out);
 double hmh_ec_from_cell_sum(double x);               // the cell sum -> the value similarity() subtracts
 double hmh_ec_cell_walk(double n, double m);         // the crate's loop, term by term, on the host
+// per-sketch cardinalities from register histograms made on the GPU (sketch_set.hip; dist_estimators.hip)
+double hmh_cardinality_from_hist(const uint32_t *hist64, bool *exact);
+int    hll_cardinality_from_hist(const uint32_t *hist256, int p, const lash_hll_bias *tables, double *out);   // LASH_OK / LASH_ERANGE
 
 }  // namespace lash

@@ -145,21 +145,42 @@ hipError_t launch_pack_v2(const PackArgs &args, const PackV2Args &v, const PackM
 
 // ---- dist side (HyperMinHash pair statistics) ------------------------------------------------------------------
 // images: `hdr` header bytes, then the registers; consecutive images are `stride` bytes apart
+// tri (every pair launcher): -1, or the set index of the call's first row when the reference rows and the query columns come
+// from the SAME set in the same order (utils.rs:158-160: only pairs with column <= row are printed): tiles wholly above
+// the diagonal return at once and leave their outputs unwritten
 hipError_t launch_hmh_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, uint32_t hdr,
-                            uint64_t stride, uint32_t *d_c, uint32_t *d_n, hipStream_t stream);
+                            uint64_t stride, uint32_t *d_c, uint32_t *d_n, hipStream_t stream, int64_t tri = -1);
+// the same counts through register bit planes (pair_planes.hip).  Row layout T[(w * 17 + b) * ldT + s] (b = 16: the plane of
+// non-zero registers) with ldT a multiple of hmh_planes_row_pad(); column layout S[(w * n_pad + s) * 20 + b] with n_pad a multiple
+// of hmh_planes_col_pad(); members beyond n read as zero sketches.  Either layout pointer may be NULL (not wanted); buffer sizes
+// from hmh_planes_T_words / hmh_planes_S_words.  d_nzcount (NULL, or zeroed [n]) receives each member's number of non-zero registers.
+hipError_t launch_hmh_planes(const uint8_t *d_img, uint32_t hdr, uint64_t stride, uint32_t n, uint32_t *d_T, uint32_t ldT, uint32_t *d_S,
+                             uint32_t n_pad, uint32_t *d_nzcount, hipStream_t stream);
+uint32_t   hmh_planes_col_pad();
+uint32_t   hmh_planes_row_pad();
+size_t     hmh_planes_T_words(uint32_t ldT);
+size_t     hmh_planes_S_words(uint32_t n_pad);
+hipError_t launch_hmh_pairs_planes(const uint32_t *d_T, uint32_t ldT, uint32_t row0, uint32_t n_rows, const uint32_t *d_S, uint32_t n_pad,
+                                   uint32_t n_cols, bool full, bool triangle, uint32_t *d_c, uint32_t *d_n, uint64_t ld_out, hipStream_t stream);
 
 hipError_t launch_hll_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
-                            uint32_t *d_zero, double *d_sum, hipStream_t stream);
+                            uint32_t *d_zero, double *d_sum, hipStream_t stream, int64_t tri = -1);
 
 // the same statistics for p >= 10 through threshold bitmaps (dist_kernels.hip): range of register values -> bm[n][band][m/32] -> pairs
 hipError_t launch_hll_minmax(const uint8_t *d_img, uint32_t n, int p, uint32_t hdr, uint32_t *d_lohi, hipStream_t stream);
 hipError_t launch_hll_bitmaps(const uint8_t *d_img, uint32_t n, int p, uint32_t hdr, uint32_t lo, uint32_t band, uint32_t *d_bm, hipStream_t stream);
 hipError_t launch_hll_pairs_bitmap(const uint32_t *d_bm_ref, uint32_t n_ref, const uint32_t *d_bm_qry, uint32_t n_qry, int p, uint32_t lo,
-                                   uint32_t band, uint32_t *d_zero, double *d_sum, hipStream_t stream);
+                                   uint32_t band, uint32_t *d_zero, double *d_sum, hipStream_t stream, int64_t tri = -1);
 
 // estimator: 0 = FGRA, 1 = ML (ull_estimators.h); d_est[r * n_qry + q] = estimated distinct count of the union
 hipError_t launch_ull_pairs(const uint8_t *d_ref, uint32_t n_ref, const uint8_t *d_qry, uint32_t n_qry, int p, uint32_t hdr,
-                            int estimator, double *d_est, hipStream_t stream);
+                            int estimator, double *d_est, hipStream_t stream, int64_t tri = -1);
+// register histograms of n serialized sketches: hist[s][256] (HLL / ULL: register bytes; HyperMinHash: bins 0..63 = the
+// registers' leading-zero fields)
+hipError_t launch_sketch_hist(const uint8_t *d_img, uint32_t n, int algo, uint32_t n_regs, uint32_t hdr, uint64_t stride, uint32_t hmh_be,
+                              uint32_t *d_hist, hipStream_t stream);
+// dst row i = src row order[i] (row_bytes each)
+hipError_t launch_gather_rows(const uint8_t *d_src, const uint32_t *d_order, uint32_t n, uint64_t row_bytes, uint8_t *d_dst, hipStream_t stream);
 
 // HyperMinHash expected collisions of small sketches (dist_kernels.hip): P[n][65536] cell probabilities of each cardinality,
 // X[m][n] = A[m][65536] * B[n][65536]^T

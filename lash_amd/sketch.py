@@ -428,6 +428,87 @@ class Context:
                                                             qry.ctypes.data, qry.shape[0], est.ctypes.data))
         return est
 
+    # -- dist side, resident form (include/lash_gfx950.h: lash_sketch_set_*) ---------------------------------------------
+    def sketch_set(self, algo, p, images, order=None):
+        """N serialized sketches resident on the context's GPU: numpy uint8 [n, image_bytes] (uploaded once; `order` = member
+        indices into images) or a CUDA torch tensor (adopted, not copied: keep it alive)."""
+        return SketchSet(self, algo, p, images, order)
+
     def synth_genomes_device(self, first_genome, n_genomes, n_bases, d_out):
         self._check(self._lib.lash_synth_genomes_device(self._h, int(first_genome), int(n_genomes), int(n_bases),
                                                         _ptr(d_out)))
+
+
+class SketchSet:
+    """lash_sketch_set: the sketches of a `dist` run kept in HBM (reference: the two hash maps of utils.rs:107-127), with
+    per-member cardinalities from GPU register histograms and pair statistics by row block, lower triangle aware."""
+
+    def __init__(self, ctx, algo, p, images, order=None):
+        self._ctx, self._lib = ctx, ctx._lib
+        self.algo, self.p = _algo(algo), int(p or 0)
+        h = C.c_void_p()
+        ib = ctx.image_bytes(self.algo, self.p)
+        if isinstance(images, np.ndarray):
+            img = np.ascontiguousarray(images, dtype=np.uint8)
+            assert img.ndim == 2 and img.shape[1] == ib
+            o = None if order is None else np.ascontiguousarray(order, dtype=np.uint32)
+            n = img.shape[0] if o is None else len(o)
+            ctx._check(self._lib.lash_sketch_set_create(ctx._h, self.algo, self.p, img.ctypes.data if img.size else None, img.shape[0],
+                                                        None if o is None else o.ctypes.data, n, C.byref(h)))
+        else:
+            assert order is None and images.is_cuda and images.is_contiguous() and images.numel() % ib == 0
+            self._keep = images
+            n = images.numel() // ib
+            ctx._check(self._lib.lash_sketch_set_create_device(ctx._h, self.algo, self.p, images.data_ptr() if n else None, n, C.byref(h)))
+        self._h, self.n = h, n
+
+    def free(self):
+        if getattr(self, "_h", None) and self._ctx._h:
+            self._lib.lash_sketch_set_free(self._ctx._h, self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def cardinalities(self, estimator="fgra", hll_bias=None):
+        out = np.zeros(self.n, dtype=np.float64)
+        bad = C.c_uint32()
+        rc = self._lib.lash_sketch_set_cardinalities(self._ctx._h, self._h, ULL_ESTIMATORS[estimator], _bias_handle(hll_bias),
+                                                     out.ctypes.data, C.byref(bad))
+        if rc == _lib.ERANGE:
+            raise LashError(rc, self._lib.lash_strerror(rc).decode() + " (sketch %d)" % bad.value)
+        self._ctx._check(rc)
+        return out
+
+    def prepare(self, qry=None):
+        self._ctx._check(self._lib.lash_sketch_set_prepare(self._ctx._h, self._h, (qry or self)._h))
+
+    def pair_block(self, r0, r1, qry=None, n_cols=None, triangle=False, estimator="fgra", out=None):
+        """statistics of rows [r0, r1) against columns [0, n_cols) of `qry` (default: this set) as the dict lash_dist_rows takes.
+        `out`: optional dict of preallocated (e.g. pinned) flat arrays 'c', 'n' (uint32), 'u' (float64) of >= (r1-r0)*n_cols."""
+        q = qry or self
+        nc = q.n if n_cols is None else int(n_cols)
+        nr = int(r1) - int(r0)
+        np_ = nr * nc
+
+        def buf(key, dt):
+            if out is not None and key in out:
+                return out[key][:np_].reshape(nr, nc)
+            return np.empty((nr, nc), dtype=dt)
+        c = buf("c", np.uint32) if self.algo != _lib.ULL else None
+        n = buf("n", np.uint32) if self.algo == _lib.HMH else None
+        u = buf("u", np.float64) if self.algo != _lib.HMH else None
+        self._ctx._check(self._lib.lash_sketch_set_pair_block(self._ctx._h, self._h, int(r0), int(r1), q._h, nc, 1 if triangle else 0,
+                                                              ULL_ESTIMATORS[estimator], None if c is None else c.ctypes.data,
+                                                              None if n is None else n.ctypes.data, None if u is None else u.ctypes.data))
+        st = {}
+        if c is not None:
+            st["c_or_zero"] = c
+        if n is not None:
+            st["n_counts"] = n
+        if u is not None:
+            st["sum_or_union"] = u
+        return st
