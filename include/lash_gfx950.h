@@ -279,9 +279,9 @@ int    lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_re
                       const double *qry_card, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union,
                       const lash_hll_bias *tables, const double *hmh_ec, double *out_dist, uint64_t *bad_pair);
 /* hmh_ec (HyperMinHash only, may be NULL): hyperminhash's expected_collisions(n, m) per pair, [n_ref x n_qry], as
- * lash_hmh_pair_expected_collisions computes them on the GPU.  NULL: computed here on the host — O(1) for cardinalities above
- * 2^19, but a walk over 65 536 cells with four pow() each (4 ms to 0.2 s PER PAIR, as in the crate) when both sketches are
- * smaller: viruses, plasmids, short contigs. */
+ * lash_hmh_pair_expected_collisions / lash_sketch_set_hmh_expected_collisions compute them on the GPU; READ ONLY for pairs whose two
+ * cardinalities are both <= 2^19 (every other pair is a closed form, taken here).  NULL: those pairs are computed here on the host,
+ * a walk over 65 536 cells with four pow() each (4 ms to 0.2 s PER PAIR, as in the crate): viruses, plasmids, short contigs. */
 
 /* ---- dist side, resident form: all-vs-all on whole collections (BASELINE configs[3]: 10^5 sketches, 5 * 10^9 printed pairs) ----
  * `lash dist` keeps both sketch files in memory for the run (utils.rs:95-127, 202-242, 303-337), takes one cardinality per
@@ -302,8 +302,9 @@ int    lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_re
  *   pair_block      statistics of set rows [r0, r1) of `ref` against columns [0, n_cols) of `qry`, row-major [r1 - r0][n_cols]:
  *                   hmh: out_c_or_zero = C, out_n = N (lash_hmh_pair_counts); hll: out_c_or_zero = zero, out_sum_or_union = sum
  *                   (lash_hll_pair_union_stats); ull: out_sum_or_union = the union estimate (lash_ull_pair_union_estimates).
- *                   triangle != 0 (ref == qry): only entries with column <= r0 + row are defined — tiles wholly above the
- *                   diagonal are skipped (utils.rs:158-160).  A caller that wants the triangle passes n_cols = r1.
+ *                   triangle != 0 (the rows and the columns are the same names in the same order, normally the same set): only
+ *                   entries with column <= r0 + row are defined — tiles wholly above the diagonal are skipped
+ *                   (utils.rs:158-160).  A caller that wants the triangle passes n_cols = r1.
  *                   Sets are read-only here: several contexts (host threads) of the same device may call pair_block on the
  *                   same prepared sets concurrently.  _device: outputs in device memory, asynchronous on the context's stream. */
 typedef struct lash_sketch_set lash_sketch_set;
@@ -312,7 +313,7 @@ int      lash_sketch_set_create(lash_ctx *ctx, int algo, int p, const uint8_t *i
 int      lash_sketch_set_create_device(lash_ctx *ctx, int algo, int p, const uint8_t *d_images, uint32_t n, lash_sketch_set **out);
 void     lash_sketch_set_free(lash_ctx *ctx, lash_sketch_set *set);
 uint32_t lash_sketch_set_size(const lash_sketch_set *set);
-int      lash_sketch_set_cardinalities(lash_ctx *ctx, const lash_sketch_set *set, int ull_estimator, const lash_hll_bias *tables,
+int      lash_sketch_set_cardinalities(lash_ctx *ctx, lash_sketch_set *set, int ull_estimator, const lash_hll_bias *tables,
                                        double *out_card, uint32_t *bad_index);
 int      lash_sketch_set_prepare(lash_ctx *ctx, lash_sketch_set *ref, lash_sketch_set *qry);
 int      lash_sketch_set_pair_block(lash_ctx *ctx, const lash_sketch_set *ref, uint32_t r0, uint32_t r1, const lash_sketch_set *qry,
@@ -321,6 +322,14 @@ int      lash_sketch_set_pair_block(lash_ctx *ctx, const lash_sketch_set *ref, u
 int      lash_sketch_set_pair_block_device(lash_ctx *ctx, const lash_sketch_set *ref, uint32_t r0, uint32_t r1, const lash_sketch_set *qry,
                                            uint32_t n_cols, int triangle, int ull_estimator, uint32_t *d_c_or_zero, uint32_t *d_n,
                                            double *d_sum_or_union);
+
+/* HyperMinHash sets: hyperminhash's expected_collisions(n, m) for the pairs of a block in which BOTH sketches hold at most 2^19
+ * distinct k-mers (the regime in which the crate walks 65 536 cells per pair; lash_hmh_pair_expected_collisions below):
+ * out_ec[(r - r0) * n_cols + c] for exactly those pairs — the other entries are left untouched, lash_dist_rows derives theirs in
+ * O(1) — and *n_small_pairs says how many there were (0: out_ec was not touched and may be NULL).  Both sets must have had
+ * lash_sketch_set_cardinalities called (the set keeps them); lash_sketch_set_prepare builds the query side's cell vectors once. */
+int      lash_sketch_set_hmh_expected_collisions(lash_ctx *ctx, const lash_sketch_set *ref, uint32_t r0, uint32_t r1, const lash_sketch_set *qry,
+                                                 uint32_t n_cols, double *out_ec, uint64_t *n_small_pairs);
 
 /* hyperminhash's expected_collisions(n, m) for every pair of an [n_ref x n_qry] block from the per-sketch cardinalities (host
  * arrays in, host array out).  Above 2^19 (either sketch) the crate's closed form; below, the 65 536-cell sum as a product of

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "lash_sketch_set_size": (_u32, [_vp]),
     "lash_sketch_set_cardinalities": (_int, [_vp, _vp, _int, _vp, _vp, C.POINTER(_u32)]),
     "lash_sketch_set_prepare": (_int, [_vp, _vp, _vp]),
+    "lash_sketch_set_hmh_expected_collisions": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _vp, C.POINTER(_u64)]),
     "lash_sketch_set_pair_block": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _int, _int, _vp, _vp, _vp]),
     "lash_sketch_set_pair_block_device": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _int, _int, _vp, _vp, _vp]),
     "lash_synth_genomes_device": (_int, [_vp, _u64, _u32, _u64, _vp]),

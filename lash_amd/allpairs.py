@@ -3,10 +3,13 @@
 The reference parallelises `dist` over reference sketches (`reference_sketches.par_iter()`, utils.rs:150,248,342) inside one
 process.  Here: one process per GPU (`torch.distributed`, "nccl" = RCCL over xGMI).  Genomes shard across ranks in contiguous
 byte-balanced blocks (shard.shard_genomes), every rank sketches its block, ONE collective follows — an all-gather of the
-finished sketch images (32 KiB each for hmh: 100 000 genomes = 3.3 GB) — and rank r then owns reference rows
-[r*N/W, (r+1)*N/W) of the distance matrix: pair statistics on its GPU (lash_*_pair_*_device), the O(pairs) arithmetic of the
-reference's estimators on its host cores (lash_dist_rows), rows written by each rank into its own part file and
-concatenated in rank order (= file order).  Nothing else crosses the links.
+finished sketch images (32 KiB each for hmh: 100 000 genomes = 3.3 GB) — and every rank then holds all N sketches resident on its
+GPU (lash_sketch_set: cardinalities from register histograms made on the GPU, bit planes / threshold bitmaps built once) and
+owns a share of the reference rows.  Only the lower triangle is printed (utils.rs:158-160), so rows are handed out in 2W bands
+of equal height and rank r owns bands r and 2W-1-r: every rank prints the same number of pairs.  A band is processed in row
+blocks: pair statistics of rows [b0, b1) x columns [0, b1) on the GPU with the tiles above the diagonal skipped, the O(pairs)
+estimator arithmetic and the text of the rows on the rank's host cores in C++ (liblash_host.so, the code `lash dist` runs),
+written to one part file per band; the parts are concatenated in band order (= file order).  Nothing else crosses the links.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         -m lash_amd.allpairs -f list.txt -a hmh -k 16 -o dist.tsv
@@ -15,92 +18,178 @@ Row order is file order (`lash dist --file-order` prints the same); the referenc
 which the C++ `lash dist` reproduces (lash_amd/csrc/host/name_order.cpp).
 """
 import argparse
+import ctypes as C
 import gzip
 import os
 import sys
+import time
 
 import numpy as np
 
 from . import _lib
 from .shard import gather_images, shard_genomes
-from .sketch import ALGOS, Context, HllBias, dist_rows, header_bytes, image_bytes, sketch_cardinality
+from .sketch import ALGOS, ULL_ESTIMATORS, Context, HllBias, LashError, PinnedArray, _bias_handle, dist_rows, image_bytes, sketch_cardinality
 
 
 def row_block(n, rank, world):
-    """reference rows owned by `rank`: [rank*n/world, (rank+1)*n/world)"""
+    """contiguous share of n rows: [rank*n/world, (rank+1)*n/world)"""
     return n * rank // world, n * (rank + 1) // world
 
 
+def row_bands(n, rank, world):
+    """the reference rows `rank` owns when only the lower triangle is printed: bands rank and 2*world-1-rank of 2*world equal
+    bands — row i prints i+1 pairs, so a low band and its mirror image together print as much as any other such pair"""
+    nb = 2 * world
+    lo, hi = row_block(n, rank, nb), row_block(n, nb - 1 - rank, nb)
+    return [b for b in (lo, hi) if b[1] > b[0]]
+
+
 def cardinalities(algo, p, images, layout=None, estimator="fgra", hll_bias=None):
+    """host path (tests without a GPU): one lash_*_cardinality call per image"""
     return np.array([sketch_cardinality(algo, p, images[i], layout, estimator, hll_bias) for i in range(images.shape[0])], dtype=np.float64)
 
 
-def gpu_pair_stats(ctx, algo, p, estimator, ref, qry):
-    """pair statistics of ref[i] x qry[j] on the context's GPU.  ref / qry: numpy uint8 [n, image_bytes] (staged through the
-    host-buffer entries) or CUDA torch tensors (device entries, nothing leaves HBM but the statistics)."""
-    a = ALGOS[algo] if isinstance(algo, str) else int(algo)
-    if isinstance(ref, np.ndarray):
-        if a == _lib.HMH:
-            c, n = ctx.hmh_pair_counts(ref, qry)
-            return dict(c_or_zero=c, n_counts=n)
-        if a == _lib.HLL:
-            z, s = ctx.hll_pair_union_stats(p, ref, qry)
-            return dict(c_or_zero=z, sum_or_union=s)
-        return dict(sum_or_union=ctx.ull_pair_union_estimates(p, ref, qry, estimator))
-    import torch
-    nr, nq, dev = ref.shape[0], qry.shape[0], ref.device
-    ref, qry = ref.contiguous(), qry.contiguous()
-    torch.cuda.current_stream(dev).synchronize()              # the images come from torch's stream (the all-gather); the context runs on its own
-    if a == _lib.HMH:
-        c = torch.empty((nr, nq), dtype=torch.int32, device=dev)
-        n = torch.empty_like(c)
-        ctx.hmh_pair_counts_device(ref, nr, qry, nq, c, n)
-        ctx.synchronize()
-        return dict(c_or_zero=c.cpu().numpy().view(np.uint32), n_counts=n.cpu().numpy().view(np.uint32))
-    if a == _lib.HLL:
-        z = torch.empty((nr, nq), dtype=torch.int32, device=dev)
-        s = torch.empty((nr, nq), dtype=torch.float64, device=dev)
-        ctx.hll_pair_union_stats_device(p, ref, nr, qry, nq, z, s)
-        ctx.synchronize()
-        return dict(c_or_zero=z.cpu().numpy().view(np.uint32), sum_or_union=s.cpu().numpy())
-    u = torch.empty((nr, nq), dtype=torch.float64, device=dev)
-    ctx.ull_pair_union_estimates_device(p, estimator, ref, nr, qry, nq, u)
-    ctx.synchronize()
-    return dict(sum_or_union=u.cpu().numpy())
-
-
 def all_vs_all(algo, p, k, local_images, counts, *, ctx=None, model=1, fp32=False, estimator="fgra", layout=None, group=None,
-               pair_stats=None, max_block_pairs=1 << 25, hll_bias=None):
-    """local_images: this rank's sketches, torch uint8 [counts[rank], image_bytes] (CUDA under nccl, CPU under gloo).
-    Returns (r0, r1, dist) — float64 [r1 - r0, N]: this rank's rows of the distance matrix against ALL N sketches, before the
-    "same name -> 0" rule.  pair_stats(algo, p, estimator, ref_block, all_images) -> dict of lash_dist_rows' arrays; default:
-    the context's GPU kernels.  The one collective is gather_images()."""
+               pair_stats=None, hll_bias=None):
+    """Dense form (small N; tests): returns [(b0, b1, dist)] for this rank's bands — dist float64 [b1 - b0, N]: the band's rows
+    of the distance matrix against ALL N sketches, before the "same name -> 0" rule.  local_images: this rank's sketches, torch
+    uint8 [counts[rank], image_bytes] (CUDA under nccl, CPU under gloo).  pair_stats(algo, p, estimator, ref_block, all_images)
+    -> dict of lash_dist_rows' arrays replaces the GPU (CPU tests); default: a lash_sketch_set on the context's GPU.  The one
+    collective is gather_images()."""
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     every = gather_images(local_images, counts, group)                       # [N, image_bytes] on every rank, file order
     n = every.shape[0]
-    r0, r1 = row_block(n, rank, world)
-    host = every.cpu().numpy() if every.is_cuda else every.numpy()
-    card = cardinalities(algo, p, host, layout, estimator, hll_bias)                # O(N * registers) host work, every rank the same
-    if pair_stats is None:
-        if ctx is None:
-            raise ValueError("all_vs_all needs a lash_amd.Context (the pair kernels have no CPU fallback) or an explicit pair_stats")
-        pair_stats = lambda a, pp, e, ref, qry: gpu_pair_stats(ctx, a, pp, e, ref, qry)   # noqa: E731
-    out = np.zeros((r1 - r0, n), dtype=np.float64)
-    step = max(1, max_block_pairs // max(n, 1))
-    for b0 in range(r0, r1, step):
-        b1 = min(r1, b0 + step)
-        ref = every[b0:b1] if every.is_cuda else host[b0:b1]
-        st = pair_stats(algo, p, estimator, ref, every if every.is_cuda else host)
-        if ctx is not None and (ALGOS[algo] if isinstance(algo, str) else int(algo)) == ALGOS["hmh"]:
-            # hyperminhash's expected collisions: the 65 536-cell regime (both sketches <= 2^19 distinct k-mers) on the GPU
-            st["hmh_ec"] = ctx.hmh_pair_expected_collisions(card[b0:b1], card)
-        out[b0 - r0:b1 - r0] = dist_rows(algo, p, k, model, card[b0:b1], card, fp32=fp32, hll_bias=hll_bias, **st)
-    return r0, r1, out
+    a = ALGOS[algo] if isinstance(algo, str) else int(algo)
+    out = []
+    if pair_stats is not None:
+        host = every.cpu().numpy() if every.is_cuda else every.numpy()
+        card = cardinalities(algo, p, host, layout, estimator, hll_bias)
+        for b0, b1 in row_bands(n, rank, world):
+            st = pair_stats(algo, p, estimator, host[b0:b1], host)
+            out.append((b0, b1, dist_rows(algo, p, k, model, card[b0:b1], card, fp32=fp32, hll_bias=hll_bias, **st)))
+        return out
+    if ctx is None:
+        raise ValueError("all_vs_all needs a lash_amd.Context (the pair kernels have no CPU fallback) or an explicit pair_stats")
+    s = ctx.sketch_set(a, p, every if every.is_cuda else every.numpy())
+    card = s.cardinalities(estimator, hll_bias)
+    s.prepare()
+    for b0, b1 in row_bands(n, rank, world):
+        st = s.pair_block(b0, b1, estimator=estimator)
+        if a == _lib.HMH:
+            ec = s.hmh_expected_collisions(b0, b1)
+            if ec is not None:
+                st["hmh_ec"] = ec
+        out.append((b0, b1, dist_rows(algo, p, k, model, card[b0:b1], card, fp32=fp32, hll_bias=hll_bias, **st)))
+    s.free()
+    return out
+
+
+class _Formatter:
+    """liblash_host.so's row formatter (host/dist_format.cpp: the code `lash dist` runs): names and cardinalities go over once"""
+
+    def __init__(self, names, card):
+        from ctypes import CDLL
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "liblash_host.so")
+        if not os.path.exists(so):
+            from .build import build_host
+            build_host()
+        _lib.load()
+        self.lib = CDLL(so)
+        self.lib.lash_host_formatter_create.restype = C.c_void_p
+        self.lib.lash_host_formatter_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        self.lib.lash_host_formatter_block.restype = C.c_int64
+        self.lib.lash_host_formatter_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
+                                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
+        self.lib.lash_host_formatter_error.restype = C.c_char_p
+        self.lib.lash_host_formatter_error.argtypes = [C.c_void_p]
+        self.lib.lash_host_formatter_free.argtypes = [C.c_void_p]
+        n = len(names)
+        arr = (C.c_char_p * n)(*[s.encode() for s in names])
+        card = np.ascontiguousarray(card, dtype=np.float64)
+        self.h = self.lib.lash_host_formatter_create(arr, card.ctypes.data, n, arr, card.ctypes.data, n)
+
+    def block(self, a, p, k, model, fp32, hll_bias, b0, b1, st, ld, matrix, threads, fd):
+        g = lambda key: None if st.get(key) is None else st[key].ctypes.data   # noqa: E731
+        w = self.lib.lash_host_formatter_block(self.h, a, int(p or 0), int(k), int(model), 1 if fp32 else 0, _bias_handle(hll_bias), b0, b1, 1,
+                                               g("c_or_zero"), g("n_counts"), g("sum_or_union"), g("hmh_ec"), ld, 1 if matrix else 0, threads, fd)
+        if w < 0:
+            raise LashError(_lib.ERANGE, self.lib.lash_host_formatter_error(self.h).decode())
+        return w
+
+    def close(self):
+        if self.h:
+            self.lib.lash_host_formatter_free(self.h)
+            self.h = None
+
+
+def all_vs_all_stream(algo, p, k, local_images, counts, names, out_prefix, *, ctx, model=1, fp32=False, estimator="fgra", group=None,
+                      matrix=False, hll_bias=None, max_block_pairs=1 << 25, threads=None, stats=None):
+    """The production form: this rank's bands of the lower triangle, streamed block by block from the GPU's pair tables through the
+    C++ formatter into `<out_prefix>.band<i>` files (band i of 2 * world; concatenated in band order they are the body of `lash dist
+    --file-order`).  Memory is bounded by max_block_pairs whatever N is.  Returns the list of (band index, path, bytes)."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    t0 = time.perf_counter()
+    every = gather_images(local_images, counts, group)                       # [N, image_bytes] on every rank, file order
+    n = every.shape[0]
+    a = ALGOS[algo] if isinstance(algo, str) else int(algo)
+    if every.is_cuda:
+        import torch
+        torch.cuda.current_stream(every.device).synchronize()   # the images come from torch's stream (the all-gather); the context runs on its own
+    s = ctx.sketch_set(a, p, every if every.is_cuda else every.numpy())
+    t1 = time.perf_counter()
+    card = s.cardinalities(estimator, hll_bias)
+    s.prepare()
+    t2 = time.perf_counter()
+    threads = threads or max(1, (os.cpu_count() or 1) // max(1, world))
+    try:
+        threads = min(threads, max(1, len(os.sched_getaffinity(0)) // max(1, world)) * 2)
+    except Exception:
+        pass
+    fmt = _Formatter(names, card)
+    cap = max(max_block_pairs, n)
+    # the block's pair tables land in page-locked memory (the copy back runs at the link rate); the owners stay alive with `pins`
+    pins = {"c": PinnedArray(cap * 4, np.uint32) if a != _lib.ULL else None, "n": PinnedArray(cap * 4, np.uint32) if a == _lib.HMH else None,
+            "u": PinnedArray(cap * 8, np.float64) if a != _lib.HMH else None}
+    pin = {k_: v.array for k_, v in pins.items() if v is not None}
+    parts, t_gpu, t_host, pairs = [], 0.0, 0.0, 0
+    nb = 2 * world
+    for band in (rank, nb - 1 - rank):
+        b_lo, b_hi = row_block(n, band, nb)
+        path = "%s.band%d" % (out_prefix, band)
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        written = 0
+        b0 = b_lo
+        while b0 < b_hi:
+            b1 = min(b_hi, b0 + max(1, cap // max(b0 + 1, 1)))
+            while b1 > b0 + 1 and (b1 - b0) * b1 > cap:
+                b1 -= 1
+            tg = time.perf_counter()
+            st = s.pair_block(b0, b1, n_cols=b1, triangle=True, estimator=estimator, out=pin)
+            if a == _lib.HMH:
+                ec = s.hmh_expected_collisions(b0, b1, n_cols=b1)
+                if ec is not None:
+                    st["hmh_ec"] = ec
+            th = time.perf_counter()
+            written += fmt.block(a, p, k, model, fp32, hll_bias, b0, b1, st, b1, matrix, threads, fd)
+            t_gpu += th - tg
+            t_host += time.perf_counter() - th
+            pairs += sum(range(b0 + 1, b1 + 1))
+            b0 = b1
+        os.close(fd)
+        parts.append((band, path, written))
+    fmt.close()
+    s.free()
+    del pin, pins
+    if stats is not None:
+        stats.update(gather_s=t1 - t0, prepare_s=t2 - t1, pair_blocks_s=t_gpu, host_rows_s=t_host, printed_pairs=pairs, threads=threads)
+    return parts
 
 
 def format_rows(names, r0, block, *, matrix=False, lower_triangle=True):
-    """the text `lash dist` writes for reference rows r0.. (main.rs:436-466): TSV lines, or matrix rows ("\\n" + name + cells)"""
+    """pure-Python twin of the C++ formatter (tests): the text `lash dist` writes for reference rows r0.. (main.rs:436-466)"""
     lines = []
     for i in range(block.shape[0]):
         gi = r0 + i
@@ -133,6 +222,7 @@ def main(argv=None):
     ap.add_argument("-s", "--seed", type=int, default=42)
     ap.add_argument("-e", "--estimator", default="fgra")
     ap.add_argument("-m", "--model", type=int, default=1)
+    ap.add_argument("-t", "--threads", type=int, default=0, help="host threads of this rank for the row arithmetic and text (default: its share of the cores)")
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--dm", action="store_true")
     ap.add_argument("--backend", default=None, help="nccl (one GPU per rank, default) or gloo (ranks may share a GPU; images gathered on the host)")
@@ -165,19 +255,23 @@ def main(argv=None):
     local_images = torch.from_numpy(imgs)
     if backend == "nccl":
         local_images = local_images.cuda(device)
-    r0, r1, block = all_vs_all(algo, p, args.kmer, local_images, [b - a for a, b in blocks], ctx=ctx, model=args.model, fp32=args.fp32,
-                               estimator=args.estimator, hll_bias=HllBias(args.hll_bias) if args.hll_bias else None)
-    part = "%s.part%d" % (args.output_file, rank)
-    with open(part, "w") as f:
-        f.write(format_rows(names, r0, block, matrix=args.dm))
+    parts = all_vs_all_stream(algo, p, args.kmer, local_images, [b - a for a, b in blocks], names, args.output_file, ctx=ctx, model=args.model,
+                              fp32=args.fp32, estimator=args.estimator, matrix=args.dm, hll_bias=HllBias(args.hll_bias) if args.hll_bias else None,
+                              threads=args.threads or None)
+    del parts
     dist.barrier()
     if rank == 0:
-        with open(args.output_file, "w") as out:
-            out.write("".join("\t" + n for n in names) if args.dm else "Reference\tQuery\tDistance\n")   # main.rs:409-412, 439-441
-            for r in range(world):
-                with open("%s.part%d" % (args.output_file, r)) as f:
-                    out.write(f.read())
-                os.remove("%s.part%d" % (args.output_file, r))
+        with open(args.output_file, "wb") as out:
+            out.write(("".join("\t" + n for n in names) if args.dm else "Reference\tQuery\tDistance\n").encode())   # main.rs:409-412, 439-441
+            for band in range(2 * world):
+                path = "%s.band%d" % (args.output_file, band)
+                with open(path, "rb") as f:
+                    while True:
+                        chunk = f.read(1 << 24)
+                        if not chunk:
+                            break
+                        out.write(chunk)
+                os.remove(path)
         print("Distances computed.")
     ctx.close()
     dist.destroy_process_group()

@@ -62,7 +62,7 @@ def build_library(force=False, verbose=False):
 
 
 HOST_DIR = os.path.join(CSRC, "host")
-HOST_SOURCES = ["main.cpp", "sketch_files.cpp", "fastx.cpp", "pgzip.cpp", "inflate_fast.cpp", "zstd_dl.cpp", "codec_dl.cpp", "json_out.cpp", "name_order.cpp", "dist.cpp"]
+HOST_SOURCES = ["main.cpp", "sketch_files.cpp", "fastx.cpp", "pgzip.cpp", "inflate_fast.cpp", "zstd_dl.cpp", "codec_dl.cpp", "json_out.cpp", "name_order.cpp", "dist_format.cpp", "dist.cpp"]
 CLI = os.path.join(PKG, "bin", "lash")
 HOSTLIB = os.path.join(PKG, "liblash_host.so")
 

@@ -287,11 +287,15 @@ int lash_dist_rows(int algo, int p, int k, int model, int fp32, uint32_t n_ref, 
             } else {
                 const double c = (double)c_or_zero[at], n = (double)n_counts[at];
                 if (c != 0.0) {                                                                   // Sketch::similarity
-                    const double ec = hmh_ec ? hmh_ec[at] : hmh_approx_expected_collisions(qry_card[j], ref_card[i]);
+                    double ec;                                            // O(1) unless both sketches are small: then the caller's, if given
+                    if (!lash::hmh_ec_closed_form(qry_card[j], ref_card[i], &ec)) ec = hmh_ec ? hmh_ec[at] : lash::hmh_ec_cell_walk(qry_card[j], ref_card[i]);
                     sim = c < ec ? 0.0 : (c - ec) / n;
                 }
             }
-            if (!(sim >= 0.0)) sim = 0.0;                                                         // .max(0.0) / `if similarity < 0.0`
+            // hmh / hll: `.max(0.0)` (utils.rs:164, 362) — f64::max drops a NaN; ull: `if similarity < 0.0 {0.0} else {similarity}`
+            // (utils.rs:272-273) keeps it: two empty sketches give 0/0, model 1 then prints 1 (f64::min drops the NaN), model 0 NaN
+            if (algo == LASH_ULL) sim = sim < 0.0 ? 0.0 : sim;
+            else if (!(sim >= 0.0)) sim = 0.0;
             const double frac = 2.0 * sim / (1.0 + sim);                                          // utils.rs:165-167
             out_dist[at] = fp32 ? (double)compute_distance<float>((float)frac, k, model) : compute_distance<double>(frac, k, model);
         }

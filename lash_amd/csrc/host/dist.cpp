@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "../../../include/lash_gfx950.h"
+#include "dist_format.hpp"
 #include "json_out.hpp"
 #include "name_order.hpp"
 #include "zstd_dl.hpp"
@@ -131,9 +132,6 @@ std::string run_dist(const DistOptions &opt)
         rorder = hashbrown_key_order(rnames);
         qorder = same_files ? rorder : hashbrown_key_order(qnames);
     }
-    std::unordered_map<std::string, uint32_t> qpos;                                                   // utils.rs:130-142 file_idx
-    if (same_files && !opt.file_order)
-        for (uint32_t jj = 0; jj < qorder.size(); ++jj) qpos[qnames[qorder[jj]]] = jj;
 
     std::vector<uint8_t> rimg_store, qimg_store;
     if (!(err = zstd_decompress_file(rf["sketches"], rimg_store)).empty()) return err;
@@ -145,13 +143,21 @@ std::string run_dist(const DistOptions &opt)
     const int prec = (hll || ull) ? atoi(rp["precision"].c_str()) : 0;
     if (hll && (prec < 4 || prec > 16)) return "bad precision in " + rf["params"];
     if (ull && (prec < 3 || prec > 26)) return "bad precision in " + rf["params"];
-    const size_t ib = lash_layout_image_bytes(&opt.layout, algo_id, prec), hdr = lash_layout_header_bytes(&opt.layout, algo_id);
+    const size_t ib = lash_layout_image_bytes(&opt.layout, algo_id, prec);
     if (!ib) return "bad layout";
     if (rimg.size() < rnames.size() * ib) return "Error with reading from " + rf["sketches"];
     if (qimg.size() < qnames.size() * ib) return "Error with reading from " + qf["sketches"];
-    const uint32_t nr = (uint32_t)rorder.size(), nq = (uint32_t)qnames.size();   // rows: map entries; columns of the pair tables: every query image
+    // rows / columns: the ENTRIES of the two maps in key order (a repeated name is one entry carrying its last sketch,
+    // utils.rs:111-127) — everything below is indexed by position in rorder / qorder, never by name-file index
+    const uint32_t nr = (uint32_t)rorder.size(), nq = (uint32_t)qorder.size();
+    std::vector<std::string> row_name(nr), col_name(nq);
+    for (uint32_t i = 0; i < nr; ++i) row_name[i] = rnames[rorder[i]];
+    for (uint32_t j = 0; j < nq; ++j) col_name[j] = qnames[qorder[j]];
+    // "q_name == r_name prints 0" (main.rs:452-453) as an integer compare per pair
+    std::vector<uint32_t> row_id, col_id;
+    name_ids(row_name, col_name, row_id, col_id);
+    const std::vector<std::string> col_tab = opt.matrix ? std::vector<std::string>() : tabbed_names(col_name);
 
-    std::vector<double> rcard(nr), qcard(nq);
     const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which are "
                            "not built in (pass --hll-bias <file from tools/ref_probe/extract_hll_bias.py>, or sketch with a smaller -p)";
     lash_hll_bias *bias = nullptr;
@@ -160,53 +166,82 @@ std::string run_dist(const DistOptions &opt)
         if (brc != LASH_OK) return "cannot read HLL++ bias tables from " + opt.hll_bias_file + ": " + lash_strerror(brc);
     }
     struct BiasGuard { lash_hll_bias *b; ~BiasGuard() { lash_hll_bias_free(b); } } bias_guard{bias};
-    // per-sketch cardinalities (utils.rs:101-103, 213-217, 314-315), on `-t` host threads
-    auto cards = [&](const std::vector<uint8_t> &img, const std::vector<std::string> &names, std::vector<double> &card) -> std::string {
-        const uint32_t n = (uint32_t)names.size();
-        std::vector<uint8_t> bad(n, 0);
-        std::atomic<uint32_t> next{0};
-        auto work = [&]() {
-            for (uint32_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
-                const uint8_t *regs = img.data() + (size_t)i * ib + hdr;
-                if (ull) card[i] = lash_ull_estimate(regs, prec, ull_est);
-                else if (!hll) card[i] = lash_hmh_cardinality(regs, opt.layout.hmh_reg_be != 0);
-                else if (lash_hll_cardinality(regs, prec, bias, &card[i]) != LASH_OK) bad[i] = 1;
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < std::min<int>(opt.threads, (int)n); ++t) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
-        for (uint32_t i = 0; i < n; ++i)
-            if (bad[i]) return names[i] + bias_msg;
-        return "";
-    };
-    if (!(err = cards(rimg, rnames, rcard)).empty()) return err;
-    if (same_files && rf["sketches"] == qf["sketches"]) qcard = rcard;
-    else if (!(err = cards(qimg, qnames, qcard)).empty()) return err;
 
-    mark("per-sketch cardinalities");
+    // ---- the sketches go to every device ONCE (lash_sketch_set: images + what the pair kernels derive from them), in map order;
+    //      per-sketch cardinalities (utils.rs:101-103, 213-217, 314-315) come from register histograms made on the GPU ----
+    // Without --devices, two workers share the GPU: while one formats and writes its block the other has the next block's
+    // pair statistics computed (a block is GPU work, then -t threads of formatting, then an ordered write).
+    std::vector<int> devices = opt.devices.empty() ? std::vector<int>{opt.device, opt.device} : opt.devices;
+    struct DevSets { int device = 0; lash_ctx *ctx = nullptr; lash_sketch_set *ref = nullptr, *qry = nullptr; };
+    std::vector<DevSets> dev_sets;
+    auto free_sets = [&]() {
+        for (DevSets &d : dev_sets) {
+            if (d.qry && d.qry != d.ref) lash_sketch_set_free(d.ctx, d.qry);
+            if (d.ref) lash_sketch_set_free(d.ctx, d.ref);
+            if (d.ctx) lash_ctx_destroy(d.ctx);
+        }
+        dev_sets.clear();
+    };
+    struct SetsGuard { decltype(free_sets) &f; ~SetsGuard() { f(); } } sets_guard{free_sets};
+    const bool one_set = same_sketches && same_files;            // the same images in the same order: one set is both sides
+    std::vector<double> rcard(nr), qcard_store;
+    for (int dv : devices) {
+        bool seen = false;
+        for (const DevSets &d : dev_sets) seen = seen || d.device == dv;
+        if (seen) continue;
+        dev_sets.emplace_back();
+        DevSets &d = dev_sets.back();
+        d.device = dv;
+        int rc = lash_ctx_create(&d.ctx, dv);
+        if (rc == LASH_OK) rc = lash_ctx_set_layout(d.ctx, &opt.layout);
+        if (rc == LASH_OK) rc = lash_sketch_set_create(d.ctx, algo_id, prec, rimg.data(), (uint32_t)rnames.size(), rorder.data(), nr, &d.ref);
+        if (rc == LASH_OK) {
+            if (one_set) d.qry = d.ref;
+            else rc = lash_sketch_set_create(d.ctx, algo_id, prec, qimg.data(), (uint32_t)qnames.size(), qorder.data(), nq, &d.qry);
+        }
+        // (every device computes its sets' cardinalities: the sets keep them for the expected-collision vectors)
+        uint32_t bad = 0;
+        std::vector<double> qc(one_set ? 0 : nq);
+        if (rc == LASH_OK) {
+            rc = lash_sketch_set_cardinalities(d.ctx, d.ref, ull_est, bias, rcard.data(), &bad);
+            if (rc == LASH_ERANGE) return row_name[bad] + bias_msg;
+        }
+        if (rc == LASH_OK && !one_set) {
+            rc = lash_sketch_set_cardinalities(d.ctx, d.qry, ull_est, bias, qc.data(), &bad);
+            if (rc == LASH_ERANGE) return col_name[bad] + bias_msg;
+            qcard_store = qc;
+        }
+        if (rc == LASH_OK) rc = lash_sketch_set_prepare(d.ctx, d.ref, d.qry);
+        if (rc != LASH_OK) return std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(d.ctx);
+    }
+    const std::vector<double> &qcard = one_set ? rcard : qcard_store;
+    mark("sketches resident on the device(s), cardinalities, pair-kernel operands");
     // hyperminhash's expected collisions need the GPU only when some pair has both sketches at or below 2^19 distinct k-mers
     bool small_ref = false, small_qry = false;
     if (!hll && !ull) {
-        for (uint32_t i : rorder) small_ref = small_ref || !(rcard[i] > 524288.0);
+        for (double c : rcard) small_ref = small_ref || !(c > 524288.0);
         for (double c : qcard) small_qry = small_qry || !(c > 524288.0);
     }
     const bool gpu_ec = small_ref && small_qry;
     FILE *out = fopen(opt.output_file.c_str(), "w");
     if (!out) return "cannot create " + opt.output_file;
     if (!opt.matrix) fprintf(out, "Reference\tQuery\tDistance\n");                                   // main.rs:409-412
-    else for (uint32_t j : qorder) fprintf(out, "\t%s", qnames[j].c_str());                          // main.rs:439-441
-    // ---- GPU: the O(N_ref * N_qry * registers) scan, in blocks of reference rows so that the per-pair tables stay
-    //      bounded (all-vs-all on 10^5 sketches is 10^10 pairs); one worker (context + host thread) per device ----
-    // Without --devices, two workers share the GPU: while one formats and writes its block the other has the next block's
-    // pair statistics computed (a block is GPU work, then -t threads of formatting, then an ordered write).
-    std::vector<int> devices = opt.devices.empty() ? std::vector<int>{opt.device, opt.device} : opt.devices;
-    // rows per block: pair tables of at most 64 M entries, and at least ~16 blocks so that the workers overlap
-    const uint32_t rows_per_block = opt.block_rows ? std::min(opt.block_rows, std::max(nr, 1u))
-                                                   : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::max<uint64_t>(64, (nr + 15) / 16),
-                                                                                                       std::min<uint64_t>(nr, (64ull << 20) / std::max<uint32_t>(nq, 1))));
-    const uint32_t n_blocks = nr ? (nr + rows_per_block - 1) / rows_per_block : 0;
+    else for (uint32_t j = 0; j < nq; ++j) fprintf(out, "\t%s", col_name[j].c_str());                // main.rs:439-441
+    // ---- blocks of reference rows: bounded pair tables (all-vs-all on 10^5 sketches is 5 * 10^9 printed pairs), about the
+    //      same number of PRINTED pairs each — with same files row i prints i + 1 columns, so late blocks hold fewer rows ----
+    std::vector<uint32_t> block_begin{0};
+    {
+        const uint64_t total = same_files ? (uint64_t)nr * (nr + 1) / 2 : (uint64_t)nr * nq;
+        const uint64_t want = opt.block_rows ? 0 : std::max<uint64_t>(std::min<uint64_t>(32ull << 20, total / 16 + 1), 4096);   // pairs per block, >= ~16 blocks
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < nr; ++i) {
+            acc += same_files ? i + 1 : nq;
+            const bool cut = opt.block_rows ? (i + 1 - block_begin.back()) >= opt.block_rows : acc >= want;
+            if (cut && i + 1 < nr) { block_begin.push_back(i + 1); acc = 0; }
+        }
+        if (nr) block_begin.push_back(nr);
+    }
+    const uint32_t n_blocks = (uint32_t)block_begin.size() - 1;
     if (devices.size() > n_blocks) devices.resize(std::max<uint32_t>(n_blocks, 1));
     const int fmt_threads = std::max(1, opt.threads / (int)devices.size());
     std::atomic<uint32_t> next_block{0};
@@ -216,87 +251,56 @@ std::string run_dist(const DistOptions &opt)
     std::string fail;                                            // guarded by wmu
 
     auto worker = [&](int device) {
+        const DevSets *ds = nullptr;
+        for (const DevSets &d : dev_sets) if (d.device == device) ds = &d;
         lash_ctx *ctx = nullptr;
-        int rc = lash_ctx_create(&ctx, device);
+        int rc = lash_ctx_create(&ctx, device);                  // the worker's own stream and staging; the sets are shared, read-only
         if (rc == LASH_OK) rc = lash_ctx_set_layout(ctx, &opt.layout);
         std::string my_fail = rc == LASH_OK ? "" : std::string(lash_strerror(rc));
-        std::vector<uint32_t> C, N;                              // hmh: C / N; hll: C = zero registers of the union
-        std::vector<double> U;                                   // hll: union sum; ull: union estimate
-        std::vector<double> EC, rc_blk;                          // hmh: expected collisions of the block's pairs (GPU), its row cardinalities
-        std::vector<uint8_t> gathered;                           // the block's reference images when rows are not in file order
+        // pair tables in page-locked memory (the copy back runs at the link rate): hmh C / N; hll zero + sum; ull the union estimate
+        uint32_t *C = nullptr, *N = nullptr;
+        double *U = nullptr, *EC = nullptr;
+        size_t cap = 0, ec_cap = 0;
+        auto grow = [&](size_t np) {
+            if (np <= cap) return true;
+            lash_host_free_pinned(C); lash_host_free_pinned(N); lash_host_free_pinned(U);
+            C = N = nullptr; U = nullptr;
+            cap = np + np / 8;
+            if (!ull) C = static_cast<uint32_t *>(lash_host_alloc_pinned(cap * 4));
+            if (!hll && !ull) N = static_cast<uint32_t *>(lash_host_alloc_pinned(cap * 4));
+            if (hll || ull) U = static_cast<double *>(lash_host_alloc_pinned(cap * 8));
+            return (ull || C) && (hll || ull || N) && (!(hll || ull) || U);
+        };
         for (;;) {
             const uint32_t blk = next_block.fetch_add(1);
             if (blk >= n_blocks) break;
-            const uint32_t i0 = blk * rows_per_block, i1 = std::min(nr, i0 + rows_per_block);
-            std::vector<std::string> row_text(i1 - i0), row_fail(i1 - i0);
+            const uint32_t i0 = block_begin[blk], i1 = block_begin[blk + 1];
+            const uint32_t n_cols = same_files ? std::min(i1, nq) : nq;     // the triangle: no row of the block prints beyond its own column
+            std::vector<std::string> row_text(i1 - i0);
             bool skip;
             { std::lock_guard<std::mutex> lk(wmu); skip = !fail.empty(); }
+            bool have_ec = false;
             if (my_fail.empty() && !skip) {
-                const size_t np = (size_t)(i1 - i0) * nq;
-                if (!ull) C.resize(np);
-                if (!hll && !ull) N.resize(np);
-                if (hll || ull) U.resize(np);
-                const uint8_t *rblk = rimg.data() + (size_t)i0 * ib;
-                if (!opt.file_order) {
-                    gathered.resize((size_t)(i1 - i0) * ib);
-                    for (uint32_t i = i0; i < i1; ++i) memcpy(gathered.data() + (size_t)(i - i0) * ib, rimg.data() + (size_t)rorder[i] * ib, ib);
-                    rblk = gathered.data();
+                const size_t np = (size_t)(i1 - i0) * n_cols;
+                if (!grow(np)) my_fail = "out of page-locked host memory";
+                else {
+                    rc = lash_sketch_set_pair_block(ctx, ds->ref, i0, i1, ds->qry, n_cols, same_files ? 1 : 0, ull_est, C, N, U);
+                    if (rc == LASH_OK && gpu_ec) {
+                        // hyperminhash's expected_collisions below 2^19 distinct k-mers on both sides is a 65 536-cell sum — on the host
+                        // 4 ms to 0.2 s per pair; the library does the block's small pairs as one matrix product on the GPU
+                        if (np > ec_cap) { lash_host_free_pinned(EC); ec_cap = np + np / 8; EC = static_cast<double *>(lash_host_alloc_pinned(ec_cap * 8)); }
+                        uint64_t n_small = 0;
+                        rc = EC ? lash_sketch_set_hmh_expected_collisions(ctx, ds->ref, i0, i1, ds->qry, n_cols, EC, &n_small) : LASH_ENOMEM;
+                        have_ec = n_small != 0;
+                    }
+                    if (rc != LASH_OK) my_fail = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
                 }
-                rc = hll ? lash_hll_pair_union_stats(ctx, prec, rblk, i1 - i0, qimg.data(), nq, C.data(), U.data())
-                   : ull ? lash_ull_pair_union_estimates(ctx, prec, ull_est, rblk, i1 - i0, qimg.data(), nq, U.data())
-                         : lash_hmh_pair_counts(ctx, rblk, i1 - i0, qimg.data(), nq, C.data(), N.data());
-                if (rc == LASH_OK && gpu_ec) {
-                    // hyperminhash's expected_collisions for the block: O(1) per pair above 2^19 distinct k-mers, a 65 536-cell sum
-                    // below — on the host that is 4 ms to 0.2 s per pair; the library does it as one matrix product on the GPU
-                    rc_blk.resize(i1 - i0);
-                    for (uint32_t i = i0; i < i1; ++i) rc_blk[i - i0] = rcard[rorder[i]];
-                    EC.resize(np);
-                    rc = lash_hmh_pair_expected_collisions(ctx, rc_blk.data(), i1 - i0, qcard.data(), nq, EC.data());
-                }
-                if (rc != LASH_OK) my_fail = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
             }
             if (my_fail.empty() && !skip) {
-                // rows of the block are formatted by host threads (the reference's par_iter over reference sketches,
-                // utils.rs:146,248,342), then written in file order
-                auto do_row = [&](uint32_t i) {
-                    std::string &text = row_text[i - i0];
-                    char buf[64];
-                    bool first = true;
-                    const size_t row = (size_t)(i - i0) * nq;
-                    std::vector<double> dist(nq);
-                    uint64_t bad_pair = 0;
-                    const uint32_t ri = rorder[i];
-                    const std::string &rname = rnames[ri];
-                    const uint32_t my_pos = !same_files ? 0 : opt.file_order ? i : qpos.at(rname);
-                    const int drc = lash_dist_rows(algo_id, prec, k, opt.model, opt.fp32 ? 1 : 0, 1, nq, &rcard[ri], qcard.data(),
-                                                   ull ? nullptr : C.data() + row, (hll || ull) ? nullptr : N.data() + row,
-                                                   (hll || ull) ? U.data() + row : nullptr, bias, gpu_ec ? EC.data() + row : nullptr,
-                                                   dist.data(), &bad_pair);
-                    if (drc == LASH_ERANGE) { row_fail[i - i0] = "union of " + rname + " and " + qnames[bad_pair] + bias_msg; return; }
-                    if (drc != LASH_OK) { row_fail[i - i0] = lash_strerror(drc); return; }
-                    for (uint32_t jj = 0; jj < qorder.size(); ++jj) {
-                        if (same_files && jj > my_pos) continue;                                      // utils.rs:158-160
-                        const uint32_t j = qorder[jj];
-                        const double d = qnames[j] == rname ? 0.0 : dist[j];                          // main.rs:452-453
-                        // "{:.6}" (main.rs:456,461): std::to_chars is correctly rounded like printf("%.6f") and several times faster
-                        buf[0] = '\t';
-                        char *end = std::to_chars(buf + 1, buf + sizeof buf - 2, d, std::chars_format::fixed, 6).ptr;
-                        if (!opt.matrix) {
-                            text += rname; text += '\t'; text += qnames[j];
-                            *end++ = '\n';
-                        } else if (first) { text += '\n'; text += rname; }
-                        text.append(buf, end);
-                        first = false;
-                    }
-                };
-                const uint32_t nthreads = (uint32_t)std::max(1, std::min<int>(fmt_threads, (int)(i1 - i0)));
-                std::atomic<uint32_t> next{i0};
-                std::vector<std::thread> pool;
-                auto work = [&]() { for (uint32_t i = next.fetch_add(1); i < i1; i = next.fetch_add(1)) do_row(i); };
-                for (uint32_t t = 1; t < nthreads; ++t) pool.emplace_back(work);
-                work();
-                for (auto &t : pool) t.join();
-                for (const std::string &f : row_fail) if (!f.empty() && my_fail.empty()) my_fail = f;
+                BlockTables bt;
+                bt.c_or_zero = C; bt.n_counts = N; bt.sum_or_union = U; bt.hmh_ec = have_ec ? EC : nullptr; bt.ld = n_cols;
+                my_fail = dist_block_rows(algo_id, prec, k, opt.model, opt.fp32, bias, i0, i1, same_files, nq, rcard.data(), qcard.data(), bt, row_name,
+                                          col_name, col_tab, row_id.data(), col_id.data(), opt.matrix, fmt_threads, row_text);
             }
             // in block order, whatever order the devices finish in
             std::unique_lock<std::mutex> lk(wmu);
@@ -308,6 +312,7 @@ std::string run_dist(const DistOptions &opt)
             lk.unlock();
             wcv.notify_all();
         }
+        lash_host_free_pinned(C); lash_host_free_pinned(N); lash_host_free_pinned(U); lash_host_free_pinned(EC);
         if (ctx) lash_ctx_destroy(ctx);
     };
     {

@@ -6,6 +6,12 @@
 #include <string>
 #include <vector>
 
+#include <unistd.h>
+
+#include <atomic>
+#include <thread>
+
+#include "dist_format.hpp"
 #include "fastx.hpp"
 #include "inflate_fast.hpp"
 #include "json_out.hpp"
@@ -190,6 +196,58 @@ char *lash_host_zstd_read(const char *path, uint8_t **out, uint64_t *n)
     *out = (uint8_t *)malloc(v.size() + 1);
     if (!v.empty()) memcpy(*out, v.data(), v.size());
     return nullptr;
+}
+
+// dist_format.hpp for callers outside C++ (lash_amd/allpairs.py): names and cardinalities are handed over once; every block of
+// reference rows then goes from the GPU's pair tables to text on `threads` host threads and is written to `fd` in row order.
+struct lash_host_formatter {
+    std::vector<std::string> row_names, col_names, col_tab;
+    std::vector<double> row_card, col_card;
+    std::vector<uint32_t> row_id, col_id;
+    std::string err;
+};
+
+// rows and columns in printing order (a pair of equal names prints 0, main.rs:452-453)
+lash_host_formatter *lash_host_formatter_create(const char *const *row_names, const double *row_card, uint32_t n_rows,
+                                                const char *const *col_names, const double *col_card, uint32_t n_cols)
+{
+    lash_host_formatter *f = new lash_host_formatter();
+    for (uint32_t i = 0; i < n_rows; ++i) f->row_names.emplace_back(row_names[i]);
+    for (uint32_t i = 0; i < n_cols; ++i) f->col_names.emplace_back(col_names[i]);
+    f->row_card.assign(row_card, row_card + n_rows);
+    f->col_card.assign(col_card, col_card + n_cols);
+    name_ids(f->row_names, f->col_names, f->row_id, f->col_id);
+    f->col_tab = tabbed_names(f->col_names);
+    return f;
+}
+
+void lash_host_formatter_free(lash_host_formatter *f) { delete f; }
+const char *lash_host_formatter_error(const lash_host_formatter *f) { return f ? f->err.c_str() : ""; }
+
+// rows [i0, i1) from their pair tables (row-major, pitch ld; see lash_dist_rows for which a sketch type uses) to `fd`.
+// Returns the bytes written, or -1 (lash_host_formatter_error says why).
+int64_t lash_host_formatter_block(lash_host_formatter *f, int algo, int p, int k, int model, int fp32, const void *hll_bias, uint32_t i0, uint32_t i1,
+                                  int triangle, const uint32_t *c_or_zero, const uint32_t *n_counts, const double *sum_or_union, const double *hmh_ec,
+                                  uint64_t ld, int matrix, int threads, int fd)
+{
+    if (!f || i0 > i1 || i1 > f->row_names.size()) return -1;
+    BlockTables t;
+    t.c_or_zero = c_or_zero; t.n_counts = n_counts; t.sum_or_union = sum_or_union; t.hmh_ec = hmh_ec; t.ld = ld;
+    std::vector<std::string> text;
+    f->err = dist_block_rows(algo, p, k, model, fp32 != 0, hll_bias, i0, i1, triangle != 0, (uint32_t)f->col_names.size(), f->row_card.data(),
+                             f->col_card.data(), t, f->row_names, f->col_names, f->col_tab, f->row_id.data(), f->col_id.data(), matrix != 0, threads, text);
+    if (!f->err.empty()) return -1;
+    int64_t total = 0;
+    for (const std::string &s : text) {
+        size_t at = 0;
+        while (at < s.size()) {
+            const ssize_t w = write(fd, s.data() + at, s.size() - at);
+            if (w < 0) { f->err = "write failed"; return -1; }
+            at += (size_t)w;
+        }
+        total += (int64_t)s.size();
+    }
+    return total;
 }
 
 }  // extern "C"

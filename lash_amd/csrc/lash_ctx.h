@@ -110,6 +110,12 @@ struct lash_sketch_set {
     DevBuf lohi, bm;
     uint32_t lo = 0xFFFFFFFFu, hi = 0, bm_lo = 0, bm_band = 0;
     bool have_range = false, have_bm = false;
+    // per-member cardinalities (lash_sketch_set_cardinalities keeps them); HyperMinHash: the members at or below 2^19 distinct
+    // k-mers ("small": hyperminhash walks 65 536 cells for a pair of them) and their cell-probability vectors [n_small][65536] f64
+    std::vector<double> card;
+    std::vector<uint32_t> small_idx;
+    DevBuf ec_vec;
+    bool have_ec_vec = false;
 };
 
 int lash_set_build_planes(lash_ctx *ctx, lash_sketch_set *s, bool want_T);   // sketch_set.hip

@@ -215,13 +215,13 @@ void lash_sketch_set_free(lash_ctx *ctx, lash_sketch_set *s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&s->images, &s->S, &s->T, &s->nzcount, &s->lohi, &s->bm}) release(*b);
+    for (DevBuf *b : {&s->images, &s->S, &s->T, &s->nzcount, &s->lohi, &s->bm, &s->ec_vec}) release(*b);
     delete s;
 }
 
 uint32_t lash_sketch_set_size(const lash_sketch_set *s) { return s ? s->n : 0; }
 
-int lash_sketch_set_cardinalities(lash_ctx *ctx, const lash_sketch_set *s, int ull_estimator, const lash_hll_bias *tables, double *out_card,
+int lash_sketch_set_cardinalities(lash_ctx *ctx, lash_sketch_set *s, int ull_estimator, const lash_hll_bias *tables, double *out_card,
                                   uint32_t *bad_index)
 {
     if (!ctx || !s || (s->n && !out_card)) return LASH_EINVAL;
@@ -254,6 +254,14 @@ int lash_sketch_set_cardinalities(lash_ctx *ctx, const lash_sketch_set *s, int u
             out_card[i] = ull_estimator == LASH_ULL_ML ? lash::ull::ml(hh, s->p) : lash::ull::fgra(hh, s->p);
         }
     }
+    s->card.assign(out_card, out_card + s->n);
+    s->small_idx.clear();
+    s->have_ec_vec = false;
+    if (s->algo == LASH_HMH) {
+        double dummy;
+        for (uint32_t i = 0; i < s->n; ++i)
+            if (!hmh_ec_closed_form(out_card[i], out_card[i], &dummy)) s->small_idx.push_back(i);
+    }
     return LASH_OK;
 }
 
@@ -265,10 +273,27 @@ int lash_sketch_set_prepare(lash_ctx *ctx, lash_sketch_set *ref, lash_sketch_set
     int rc;
     if (ref->n == 0 || qry->n == 0) return LASH_OK;
     if (ref->algo == LASH_HMH) {
+        // expected collisions of small pairs (lash_sketch_set_hmh_expected_collisions): the query side's cell vectors, once, when
+        // both sides have small members and the vectors fit a third of the free memory (else they are made per block)
+        if (!ref->small_idx.empty() && !qry->small_idx.empty() && !qry->have_ec_vec) {
+            size_t free_b = 0, total_b = 0;
+            const size_t need = qry->small_idx.size() * (size_t)65536 * 8;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 3) {
+                std::vector<double> cards(qry->small_idx.size());
+                for (size_t j = 0; j < cards.size(); ++j) cards[j] = qry->card[qry->small_idx[j]];
+                if ((rc = reserve(ctx, qry->ec_vec, need))) return rc;
+                if ((rc = reserve(ctx, ctx->ec_card, cards.size() * 8))) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->ec_card.ptr, cards.data(), cards.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, launch_collision_vectors(static_cast<const double *>(ctx->ec_card.ptr), (uint32_t)cards.size(),
+                                                     static_cast<double *>(qry->ec_vec.ptr), ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                qry->have_ec_vec = true;
+            }
+        }
         static const bool words_kernel = getenv("LASH_HMH_PAIRS_WORDS") != nullptr;      // A/B knob: the u16-pair kernel on the images
         if (words_kernel) return LASH_OK;
+        if ((rc = lash_set_build_planes(ctx, ref, true))) return rc;                     // (both layouts in one pass when ref == qry)
         if ((rc = lash_set_build_planes(ctx, qry, false))) return rc;
-        if ((rc = lash_set_build_planes(ctx, ref, true))) return rc;
     } else if (ref->algo == LASH_HLL && ref->p >= 10) {
         static const bool byte_kernel_only = getenv("LASH_HLL_PAIRS_BYTEWISE") != nullptr;
         if (byte_kernel_only) return LASH_OK;
@@ -290,7 +315,6 @@ int lash_sketch_set_pair_block_device(lash_ctx *ctx, const lash_sketch_set *ref,
                                       double *d_sum_or_union)
 {
     if (!ctx || !ref || !qry || ref->algo != qry->algo || ref->p != qry->p || r0 > r1 || r1 > ref->n || n_cols > qry->n) return LASH_EINVAL;
-    if (triangle && ref != qry) return LASH_EINVAL;
     if (ref->device != ctx->device || qry->device != ctx->device) return LASH_EINVAL;
     const uint32_t nr = r1 - r0;
     if (nr == 0 || n_cols == 0) return LASH_OK;
@@ -350,6 +374,56 @@ int lash_sketch_set_pair_block(lash_ctx *ctx, const lash_sketch_set *ref, uint32
         HIPCHK(ctx, hipMemcpyAsync(out_sum_or_union, d_u, np * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LASH_OK;
+}
+
+int lash_sketch_set_hmh_expected_collisions(lash_ctx *ctx, const lash_sketch_set *ref, uint32_t r0, uint32_t r1, const lash_sketch_set *qry,
+                                            uint32_t n_cols, double *out_ec, uint64_t *n_small_pairs)
+{
+    if (n_small_pairs) *n_small_pairs = 0;
+    if (!ctx || !ref || !qry || ref->algo != LASH_HMH || qry->algo != LASH_HMH || r0 > r1 || r1 > ref->n || n_cols > qry->n) return LASH_EINVAL;
+    if (ref->card.size() != ref->n || qry->card.size() != qry->n) return LASH_EINVAL;          // lash_sketch_set_cardinalities first
+    // the block's small rows, the small columns below n_cols (small_idx ascends)
+    const auto rb = std::lower_bound(ref->small_idx.begin(), ref->small_idx.end(), r0), re = std::lower_bound(rb, ref->small_idx.end(), r1);
+    const uint32_t nrs = (uint32_t)(re - rb);
+    const uint32_t nqs = (uint32_t)(std::lower_bound(qry->small_idx.begin(), qry->small_idx.end(), n_cols) - qry->small_idx.begin());
+    if (nrs == 0 || nqs == 0) return LASH_OK;
+    if (!out_ec) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    constexpr size_t VEC = 65536 * sizeof(double);
+    int rc;
+    std::vector<double> cards(nrs), x;
+    for (uint32_t i = 0; i < nrs; ++i) cards[i] = ref->card[rb[i]];
+    if ((rc = reserve(ctx, ctx->ec_ref, (size_t)nrs * VEC))) return rc;
+    if ((rc = reserve(ctx, ctx->ec_card, (size_t)(nrs + 4096) * 8))) return rc;
+    double *d_card = static_cast<double *>(ctx->ec_card.ptr);
+    HIPCHK(ctx, hipMemcpyAsync(d_card, cards.data(), (size_t)nrs * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, launch_collision_vectors(d_card, nrs, static_cast<double *>(ctx->ec_ref.ptr), ctx->stream));
+    // the query vectors: the set's (prepare), or made here 4 096 at a time when they did not fit
+    const uint32_t q_step = qry->have_ec_vec ? nqs : 4096u;
+    std::vector<double> qc;
+    for (uint32_t q0 = 0; q0 < nqs; q0 += q_step) {
+        const uint32_t nq = std::min(q_step, nqs - q0);
+        const double *d_B = static_cast<const double *>(qry->ec_vec.ptr);
+        if (!qry->have_ec_vec) {
+            qc.resize(nq);
+            for (uint32_t j = 0; j < nq; ++j) qc[j] = qry->card[qry->small_idx[q0 + j]];
+            if ((rc = reserve(ctx, ctx->ec_qry, (size_t)nq * VEC))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(d_card + nrs, qc.data(), (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, launch_collision_vectors(d_card + nrs, nq, static_cast<double *>(ctx->ec_qry.ptr), ctx->stream));
+            d_B = static_cast<const double *>(ctx->ec_qry.ptr);
+        }
+        if ((rc = reserve(ctx, ctx->ec_x, (size_t)nrs * nq * 8))) return rc;
+        HIPCHK(ctx, launch_collision_gemm(static_cast<const double *>(ctx->ec_ref.ptr), nrs, d_B, nq, static_cast<double *>(ctx->ec_x.ptr), ctx->stream));
+        x.resize((size_t)nrs * nq);
+        HIPCHK(ctx, hipMemcpyAsync(x.data(), ctx->ec_x.ptr, x.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < nrs; ++i) {
+            double *row = out_ec + (size_t)(rb[i] - r0) * n_cols;
+            for (uint32_t j = 0; j < nq; ++j) row[qry->small_idx[q0 + j]] = hmh_ec_from_cell_sum(x[(size_t)i * nq + j]);
+        }
+    }
+    if (n_small_pairs) *n_small_pairs = (uint64_t)nrs * nqs;
     return LASH_OK;
 }
 

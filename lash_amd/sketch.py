@@ -486,6 +486,17 @@ class SketchSet:
     def prepare(self, qry=None):
         self._ctx._check(self._lib.lash_sketch_set_prepare(self._ctx._h, self._h, (qry or self)._h))
 
+    def hmh_expected_collisions(self, r0, r1, qry=None, n_cols=None):
+        """hyperminhash's expected collisions of the block's SMALL pairs (both sketches <= 2^19 distinct k-mers) as a float64
+        [r1 - r0, n_cols] array for lash_dist_rows' hmh_ec (other entries are not read), or None when the block has none.
+        cardinalities() must have run on both sets."""
+        q = qry or self
+        nc = q.n if n_cols is None else int(n_cols)
+        out = np.empty((int(r1) - int(r0), nc), dtype=np.float64)
+        cnt = C.c_uint64()
+        self._ctx._check(self._lib.lash_sketch_set_hmh_expected_collisions(self._ctx._h, self._h, int(r0), int(r1), q._h, nc, out.ctypes.data, C.byref(cnt)))
+        return out if cnt.value else None
+
     def pair_block(self, r0, r1, qry=None, n_cols=None, triangle=False, estimator="fgra", out=None):
         """statistics of rows [r0, r1) against columns [0, n_cols) of `qry` (default: this set) as the dict lash_dist_rows takes.
         `out`: optional dict of preallocated (e.g. pinned) flat arrays 'c', 'n' (uint32), 'u' (float64) of >= (r1-r0)*n_cols."""

@@ -333,3 +333,50 @@ def test_lash_dist_cli_ull(tmp_path, matrix, model, p, est):
     # a bad estimator name is refused like the reference's panic (utils.rs:216)
     r = subprocess.run([H.CLI, "dist", "-q", "ul", "-r", "ul", "-e", "median"], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode != 0 and "fgra or ml" in r.stderr
+
+
+@pytest.mark.parametrize("algo,p", [("hmh", 0), ("ull", 10)])
+def test_lash_dist_with_repeated_names(tmp_path, algo, p):
+    """A list file that names a genome several times gives a names JSON with repeats; the reference's maps keep ONE entry per name
+    (the last sketch, utils.rs:111-127).  `lash dist` used to size its cardinality tables by the map and index them by file
+    position: a 400-entry list with 3 distinct names overran the heap.  Same-files and reference-vs-query, map order
+    and --file-order."""
+    gs = [O.synth_genome(90 + i, 120_000) for i in range(3)]
+    paths = []
+    for i, g in enumerate(gs):
+        q = tmp_path / ("r%d.fa" % i)
+        q.write_bytes(b">g\n" + g.tobytes() + b"\n")
+        paths.append(str(q))
+    many = [paths[i % 3] for i in range(400)]
+    (tmp_path / "many.txt").write_text("\n".join(many) + "\n")
+    (tmp_path / "three.txt").write_text("\n".join(paths) + "\n")
+    (tmp_path / "dup.txt").write_text("\n".join([paths[0], paths[0], paths[1]]) + "\n")
+    env = dict(os.environ)
+    pflag = ["-p", str(p)] if algo != "hmh" else []
+    for pre, lst in (("many", "many.txt"), ("three", "three.txt"), ("dup", "dup.txt")):
+        r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / lst), "-o", pre, "-k", "16", "-a", algo] + pflag, cwd=tmp_path, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+
+    def run(q, r_, *extra):
+        out = "d_%s_%s%s.txt" % (q, r_, "_fo" if extra else "")
+        r = subprocess.run([H.CLI, "dist", "-q", q, "-r", r_, "-o", out, "-t", "3"] + list(extra), cwd=tmp_path, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return [tuple(ln.split("\t")) for ln in (tmp_path / out).read_text().strip().split("\n")[1:]]
+    base = {frozenset((a, b)): d for a, b, d in run("three", "three")}          # the three genomes without repeats
+    assert len(base) == 6
+    # 400 names, 3 distinct: the triangle of a 3-entry map
+    rows = run("many", "many")
+    assert len(rows) == 6 and {frozenset((a, b)): d for a, b, d in rows} == base
+    order = R.hashbrown_name_order(many)
+    assert len(order) == 3
+    assert [(a, b) for a, b, _ in rows] == [(many[order[i]], many[order[j]]) for i in range(3) for j in range(i + 1)]
+    # reference-vs-query with repeats on both sides: 3 x 2 map entries
+    rows = run("dup", "many")
+    assert len(rows) == 6 and all(base[frozenset((a, b))] == d for a, b, d in rows)
+    rows = run("many", "dup")
+    assert len(rows) == 6 and all(base[frozenset((a, b))] == d for a, b, d in rows)
+    # --file-order keeps every listed entry: 3 rows (triangle 1 + 2 + 3), the repeated name against itself prints 0
+    rows = run("dup", "dup", "--file-order")
+    assert [(a, b) for a, b, _ in rows] == [(paths[0], paths[0]), (paths[0], paths[0]), (paths[0], paths[0]), (paths[1], paths[0]), (paths[1], paths[0]),
+                                            (paths[1], paths[1])]
+    assert [d for _, _, d in rows[:3]] == ["0.000000"] * 3 and rows[3][2] == rows[4][2] == base[frozenset((paths[0], paths[1]))]

@@ -454,3 +454,36 @@ def test_name_order_with_odd_names():
     got = H.name_order(names)
     assert got == R.hashbrown_name_order(names)
     assert sorted(got) == list(range(len(names)))
+
+
+def test_block_formatter_equals_the_python_restatement(tmp_path):
+    """host/dist_format.cpp (what `lash dist` and lash_amd.allpairs print rows with) against the pure-Python twin: list and matrix
+    form, the triangle, "same name prints 0" (also for a name listed twice), 1 / 0 / NaN fast paths, several threads; the
+    distances themselves come from lash_dist_rows on both sides (hmh statistics made with numpy)."""
+    import lash_amd
+    from lash_amd.allpairs import _Formatter, format_rows
+    rng = np.random.default_rng(17)
+    n, k = 23, 16
+    names = ["g%d.fa" % i for i in range(n)]
+    names[7] = names[3]                                            # listed twice
+    names[11] = "dir with space/é.fa"
+    card = rng.uniform(6e5, 5e6, n)
+    c = rng.integers(0, 9000, size=(n, n)).astype(np.uint32)
+    c[2, :] = 0                                                    # C == 0 -> similarity 0 -> distance exactly 1
+    c[5, 4] = 16384
+    nn = np.full((n, n), 16384, np.uint32)
+    want = lash_amd.dist_rows("hmh", 0, k, 1, card, card, c_or_zero=c, n_counts=nn)
+    for matrix in (False, True):
+        f = _Formatter(names, card)
+        path = tmp_path / ("m%d.txt" % matrix)
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        total = 0
+        for b0, b1 in ((0, 1), (1, 9), (9, n)):                    # pair tables of a block: rows [b0, b1) x columns [0, b1)
+            st = dict(c_or_zero=np.ascontiguousarray(c[b0:b1, :b1]), n_counts=np.ascontiguousarray(nn[b0:b1, :b1]))
+            total += f.block(lash_amd.HMH, 0, k, 1, False, None, b0, b1, st, b1, matrix, 3, fd)
+        os.close(fd)
+        f.close()
+        got = open(path, "rb").read().decode()
+        assert len(got.encode()) == total
+        assert got == format_rows(names, 0, want, matrix=matrix)
+    assert "1.000000" in got and "0.000000" in got

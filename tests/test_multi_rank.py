@@ -164,8 +164,8 @@ def _allpairs_worker(rank, world, port, algo, p, k, q):
         aid = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}[algo]
         imgs = [O.sketch_genomes(aid, k, p, 42, g, np.array([0, len(g)], np.uint64), np.array([0, 1], np.uint64))[0] for g in gs[a:b]]
         local = torch.from_numpy(np.stack(imgs)) if imgs else torch.zeros((0, O.image_bytes(aid, p)), dtype=torch.uint8)
-        r0, r1, block = all_vs_all(algo, p, k, local, [e - s for s, e in blocks], pair_stats=_numpy_pair_stats, estimator="fgra")
-        q.put((rank, r0, r1, block))
+        bands = all_vs_all(algo, p, k, local, [e - s for s, e in blocks], pair_stats=_numpy_pair_stats, estimator="fgra")
+        q.put((rank, bands))
     finally:
         dist.destroy_process_group()
 
@@ -190,9 +190,13 @@ def test_all_vs_all_rows_over_ranks_equal_single_process(world, algo, p, k):
     for pr in procs:
         pr.join(120)
         assert pr.exitcode == 0
-    got.sort()
-    assert got[0][1] == 0 and got[-1][2] == n and all(a[2] == b[1] for a, b in zip(got[:-1], got[1:]))   # rows partition [0, N)
-    full = np.concatenate([g[3] for g in got])
+    # rank r owns bands r and 2W-1-r of 2W equal bands (the printed triangle is then balanced): together they partition [0, N)
+    from lash_amd.allpairs import row_bands
+    for r, bands in got:
+        assert [(b0, b1) for b0, b1, _ in bands] == row_bands(n, r, world)
+    got = sorted(b for _, bands in got for b in bands)
+    assert got[0][0] == 0 and got[-1][1] == n and all(a[1] == b[0] for a, b in zip(got[:-1], got[1:]))
+    full = np.concatenate([g[2] for g in got])
     assert full.shape == (n, n) and np.array_equal(full, want)
     if algo == "hmh":                                            # and the numbers are the reference's formula (pure-Python restatement)
         import pyref as R
