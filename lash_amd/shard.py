@@ -62,3 +62,27 @@ def merge_partial_images(local_images, merge_into, group=None):
     for r in range(1, world):
         merge_into(acc, out[r * n:(r + 1) * n])
     return acc
+
+
+def effective_cores():
+    """host cores this process may really use: the minimum of the logical CPUs, the affinity mask and the cgroup CPU quota
+    (the GPU boxes report 256 logical CPUs and a 16-CPU quota)"""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)

@@ -214,3 +214,106 @@ def test_config4_full_100gbp(env):
         assert np.array_equal(O.merge_images(O.ULL, p, full, want), full), w0
     print("configs[4] full size: %d reads, %.3e k-mers; device time pack %.1f + sketch %.1f + finalize %.1f ms over %d calls"
           % (n_reads, ta["kmers"], ta["pack_ms"], ta["sketch_ms"], ta["finalize_ms"], ta["calls"]))
+
+
+def test_config3_full_100k_genomes_all_vs_all(env, tmp_path):
+    """BASELINE configs[3] at its stated TOTAL size on ONE GPU — 100 000 x 5 Mbp, hmh k=16, then the 100 000 x 100 000 all-vs-all
+    (5.00005e9 printed pairs) through lash_amd.allpairs at world_size 1 (the 8-GPU run shards exactly this 8 ways and adds the
+    all-gather; RCCL with >= 2 ranks is NOT exercised here).  Sketching runs in 8 chunks of 12 500 genomes (62.5 GB of ASCII
+    resident per chunk), the images accumulate to 3.28 GB; the text goes to os.devnull.  Checked:
+      * census: every chunk counts genomes x (L - k + 1) k-mers; three genomes equal the oracle bit for bit;
+      * the stream prints exactly N (N + 1) / 2 rows (byte count of the fixed-width rows);
+      * pair statistics: a block's diagonal has C = N = 16 384 (a full sketch against itself), a sampled off-diagonal block is
+        symmetric (rows A x columns B == (rows B x columns A) transposed) and equals numpy on its first entries;
+      * a 2 000-genome sub-collection through lash_amd.allpairs (real files) == `lash dist --file-order` on the same sketches, byte
+        for byte (LASH_FULLSIZE=0 shrinks N to 8 000 and the sub-collection to 500)."""
+    import subprocess
+    import time
+    import torch.distributed as dist
+    import host_lib as H
+    from lash_amd.allpairs import all_vs_all_stream
+    ctx, torch, lash_amd = env
+    dev = torch.device("cuda", 0)
+    N, chunk, sub = (100_000, 12_500, 2_000) if FULL else (8_000, 1_000, 500)
+    free, _ = torch.cuda.mem_get_info()
+    if free < chunk * L + N * 40_000 * 4 + 24 * 2**30:
+        pytest.skip("needs %.0f GB of free HBM" % ((chunk * L + N * 40_000 * 4 + 24 * 2**30) / 1e9))
+    k, ib = 16, lash_amd.image_bytes("hmh")
+    img = torch.zeros((N, ib), dtype=torch.uint8, device=dev)
+    d_seq = torch.empty(chunk * L, dtype=torch.uint8, device=dev)
+    rec_off = np.arange(chunk + 1, dtype=np.uint64) * np.uint64(L)
+    goff = np.arange(chunk + 1, dtype=np.uint64)
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+    t0 = time.perf_counter()
+    sketch_ms = 0.0
+    for c in range(N // chunk):
+        ctx.synth_genomes_device(c * chunk, chunk, L, d_seq)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        ctx.enable_timing(True)
+        ctx.sketch_batch_device("hmh", k, 0, 42, d_seq, d_rec, chunk, goff, rec_off, img[c * chunk:(c + 1) * chunk].reshape(-1))
+        t = ctx.timing()
+        ctx.enable_timing(False)
+        assert t["kmers"] == chunk * (L - k + 1) and t["bases_last"] == chunk * L, c
+        sketch_ms += t["pack_ms"] + t["sketch_ms"] + t["finalize_ms"]
+    t_sketch = time.perf_counter() - t0
+    for g in (0, N // 2 + 7, N - 1):
+        want = O.sketch_genomes(O.HMH, k, 0, 42, O.synth_genome(g, L), np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
+        assert np.array_equal(img[g].cpu().numpy(), want), g
+    del d_seq
+    torch.cuda.empty_cache()
+
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        names = ["g%06d.fa" % i for i in range(N)]
+        stats = {}
+        t0 = time.perf_counter()
+        parts = all_vs_all_stream("hmh", 0, k, img, [N], names, os.devnull, ctx=ctx, stats=stats)
+        t_all = time.perf_counter() - t0
+        line = 2 * len(names[0]) + 2 + 8 + 1                                     # "ref\tqry\t0.123456\n"
+        assert sum(b for _, _, b in parts) == N * (N + 1) // 2 * line
+        assert stats["printed_pairs"] == N * (N + 1) // 2
+        # the small sub-collection with real files against the C++ command line on the same sketches
+        idx = torch.arange(0, N, N // sub, device=dev)[:sub]
+        sub_img = img[idx].contiguous()
+        sub_names = [names[int(i)] for i in idx.cpu()]
+        out = str(tmp_path / "sub.tsv")
+        bands = all_vs_all_stream("hmh", 0, k, sub_img, [sub], sub_names, out, ctx=ctx)
+        body = b"".join(open(pth, "rb").read() for _, pth, _ in sorted(bands))
+        H.zstd_write(str(tmp_path / "sub_sketches.bin"), sub_img.cpu().numpy().tobytes())
+        (tmp_path / "sub_files.json").write_text(H.json_array(sub_names))
+        H.write_parameters(str(tmp_path / "sub"), "hmh", k, 0, 42)
+        r = subprocess.run([H.CLI, "dist", "-q", "sub", "-r", "sub", "-o", "cli.tsv", "--file-order", "-t", "8"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert (tmp_path / "cli.tsv").read_bytes() == b"Reference\tQuery\tDistance\n" + body
+    finally:
+        if own_pg:
+            dist.destroy_process_group()
+    # pair statistics at full size, straight from the resident set
+    s = ctx.sketch_set("hmh", 0, img)
+    s.prepare()
+    r0 = N - 777
+    tri = s.pair_block(r0, r0 + 300, n_cols=r0 + 300, triangle=True)
+    for i in range(300):
+        assert tri["c_or_zero"][i, r0 + i] == 16384 and tri["n_counts"][i, r0 + i] == 16384
+    a0, b0 = N // 2 + 1000, 123
+    ab = s.pair_block(a0, a0 + 200, n_cols=b0 + 600)["c_or_zero"][:, b0:b0 + 600]
+    ba = s.pair_block(b0, b0 + 600, n_cols=a0 + 200)["c_or_zero"][:, a0:a0 + 200]
+    assert np.array_equal(ab, ba.T)
+    x = img[a0:a0 + 2].cpu().numpy().view(np.uint16)
+    y = img[b0:b0 + 3].cpu().numpy().view(np.uint16)
+    for i in range(2):
+        for j in range(3):
+            assert ab[i, j] == int(((x[i] == y[j]) & (x[i] != 0)).sum())
+    s.free()
+    print("configs[3] total size on one GPU: %d genomes sketched in %.2f s wall (%.1f ms of device stages); all-vs-all %.1f s: gather %.2f, "
+          "cardinalities + operands %.2f, pair blocks incl. copy back %.2f, host rows (lash_dist_rows + text, %d threads) %.2f; %.3e printed pairs"
+          % (N, t_sketch, sketch_ms, t_all, stats["gather_s"], stats["prepare_s"], stats["pair_blocks_s"], stats["threads"], stats["host_rows_s"],
+             stats["printed_pairs"]))
