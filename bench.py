@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""bench.py — k-mers/s sketched on MI355X, BASELINE.json's metric on its configs[1] workload.
+"""bench.py — k-mers/s sketched on MI355X, BASELINE.json's metric.
 
 One step = one pass of the hot path (pack -> sketch -> finalize, i.e. the body of the reference's
 files.par_iter().map(...) at utils.rs:450-509) over one batch of synthetic genomes whose ASCII records are already
-resident in HBM; the images `S::save` would write stay in HBM.  Default workload: 1 000 synthetic 5 Mbp genomes per
-GPU, -a hmh -k 16, seed 42 (SURVEY.md §8(d) generator).  Genomes shard across ranks with no data-path collective
-(weak scaling: every rank sketches its own 1 000 genomes).
+resident in HBM; the images `S::save` would write stay in HBM.  Default workload: 12 500 synthetic 5 Mbp genomes per
+GPU (62.5 GB resident; BASELINE configs[3]'s per-GPU share, and the north-star's ">= 10 000 genomes"), -a hmh -k 16,
+seed 42 (SURVEY.md §8(d) generator); `--genomes 1000` is configs[1].  Genomes shard across ranks with no data-path
+collective (weak scaling: every rank sketches its own 12 500 genomes).
 
     python bench.py                       # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -171,13 +172,16 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True)
     committed round-2 figure.  insts_per_kmer comes from the committed SQ_INSTS_VALU counter pass (profiles/valu.json)."""
     import re
     import subprocess
-    floor, src = None, None
+    floor, src, clock_ghz = None, None, None
     exe = os.path.join(ROOT, "tools", "ubench_hash")
     line = {"hmh": r"\+ ds_max_u32", "hll": "hll p14 k21 stream", "ull": "ull p12 k16 stream"}[algo]
     if run_ubench and os.path.exists(exe):
         try:
             out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
             m = re.search(line + r".*\(([0-9.e+]+) k-mers/s chip-wide\)", out)
+            mc = re.search(line + r".*clock ([0-9.]+) GHz", out)
+            if mc:
+                clock_ghz = float(mc.group(1))
             if m:
                 floor, src = float(m.group(1)), ("tools/ubench_hash run in this process' job (%s instruction stream from registers%s)"
                                                   % (line.replace("\\", "").replace("+ ds_max_u32", "hmh k=16"),
@@ -196,35 +200,57 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True)
         except Exception:
             pass
     rate = kmers_per_launch / (sketch_ms * 1e-3) if sketch_ms > 0 else 0.0
+    # the absolute figure beside the self-referential one: wave-instructions issued per second against the chip's issue peak
+    # (256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles: MI355X_MICROARCH.md, Execution model) at the clock the
+    # ubench run measured in this job (else the 2.4 GHz maximum).  insts_per_kmer is a per-LANE count: SQ_INSTS_VALU / (k-mers / 64).
+    absolute = None
+    if per:
+        wave_instr_per_s = rate * per / 64.0
+        peak_issue = 256 * 4 * (clock_ghz or 2.4) * 1e9 / 2.0
+        absolute = {"wave_instr_per_s": wave_instr_per_s, "peak_wave_instr_per_s": peak_issue, "frac": wave_instr_per_s / peak_issue,
+                    "clock_ghz": clock_ghz or 2.4, "clock_source": "tools/ubench_hash (s_memtime / s_memrealtime) in this job" if clock_ghz else "datasheet maximum",
+                    "note": "the remainder is 4-cycle instructions (multiplies, alignbit, 3-operand VOP3) issued at half rate, not idle slots"}
     return {"bound": "valu-issue", "achieved": rate, "peak": floor, "unit": "k-mers/s", "frac": (rate / floor) if floor else None,
-            "insts_per_kmer": per, "insts_source": vsrc, "peak_source": src,
-            "note": "peak = measured ceiling of this instruction stream with no memory traffic, not a datasheet number"}
+            "insts_per_kmer": per, "insts_source": (vsrc + " — from the committed counter pass, not measured in this run") if vsrc else None,
+            "peak_source": src, "absolute_issue": absolute,
+            "note": "peak = measured ceiling of this instruction stream with no memory traffic (self-referential: it prices the kernel's own "
+                    "instruction mix); absolute_issue = issued wave-instructions against the chip's datasheet issue rate"}
 
 
 def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L, G, d_seq, d_rec, goff, rec_off, d_img, ib):
     """BASELINE configs[3] in the shape one node allows: every rank sketches its G genomes (shard), ONE collective — the
-    all-gather of the finished images over RCCL — then rank r owns reference rows [r*N/W, (r+1)*N/W) against all N sketches
-    (pair kernel on its GPU).  A step is timed by HIP-synchronised wall clock like the sketch bench; the O(pairs) host
-    arithmetic of the estimators (lash_dist_rows) is timed beside it on a bounded sample of the rows."""
+    all-gather of the finished images over RCCL — then every rank holds all N sketches as a resident set (lash_sketch_set:
+    operands of the pair kernels built once per step) and computes the pair statistics of its two bands of the lower triangle
+    (rows handed out so that every rank owns the same number of printed pairs, lash_amd.allpairs.row_bands), tiles above the
+    diagonal skipped.  A step is timed by HIP-synchronised wall clock like the sketch bench; the O(pairs) host arithmetic and
+    text (liblash_host.so) are timed beside it on a bounded sample of this rank's rows."""
     import numpy as np
     import lash_amd
-    from lash_amd.allpairs import cardinalities, row_block
+    from lash_amd.allpairs import row_bands
     N = G * world
     every = torch.empty((N, ib), dtype=torch.uint8, device=dev)
-    r0, r1 = row_block(N, rank, world)
-    nr = r1 - r0
-    if algo == "hmh":
-        outs = (torch.empty((nr, N), dtype=torch.int32, device=dev), torch.empty((nr, N), dtype=torch.int32, device=dev))
-    elif algo == "hll":
-        outs = (torch.empty((nr, N), dtype=torch.int32, device=dev), torch.empty((nr, N), dtype=torch.float64, device=dev))
-    else:
-        outs = (torch.empty((nr, N), dtype=torch.float64, device=dev),)
+    bands = row_bands(N, rank, world)
+    cap = 1 << 27                                          # pair-table entries per call
+    blocks = []
+    for b_lo, b_hi in bands:
+        b0 = b_lo
+        while b0 < b_hi:
+            b1 = min(b_hi, b0 + max(1, cap // (b0 + 1)))
+            while b1 > b0 + 1 and (b1 - b0) * b1 > cap:
+                b1 -= 1
+            blocks.append((b0, b1))
+            b0 = b1
+    big = max((b1 - b0) * b1 for b0, b1 in blocks)
+    o_c = torch.empty(big, dtype=torch.int32, device=dev)
+    o_n = torch.empty(big, dtype=torch.int32, device=dev)
+    o_u = torch.empty(big, dtype=torch.float64, device=dev)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     # one explicit stream for everything: the library's kernels, the collective (RCCL orders itself against the current stream)
     # and the events — torch's default stream is the NULL stream, which lash_ctx_set_stream takes as "use your own"
     side = torch.cuda.Stream(device=dev)
     ctx.set_stream(side)
     torch.cuda.set_stream(side)
+    lib = lash_amd.load()
 
     def step(timed=False):
         if timed:
@@ -238,66 +264,68 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
             every.view(-1).copy_(d_img)
         if timed:
             ev[2].record()
-        ref = every[r0:r1]
-        if algo == "hmh":
-            ctx.hmh_pair_counts_device(ref, nr, every, N, outs[0], outs[1])
-        elif algo == "hll":
-            ctx.hll_pair_union_stats_device(p, ref, nr, every, N, outs[0], outs[1])
-        else:
-            ctx.ull_pair_union_estimates_device(p, "fgra", ref, nr, every, N, outs[0])
+        s = ctx.sketch_set(algo, p, every)
+        s.prepare()
+        for b0, b1 in blocks:
+            ctx._check(lib.lash_sketch_set_pair_block_device(ctx._h, s._h, b0, b1, s._h, b1, 1, 0, o_c.data_ptr(), o_n.data_ptr(), o_u.data_ptr()))
         if timed:
             ev[3].record()
+        return s
 
-    for _ in range(3 + args.warmup):
-        step()
+    for _ in range(2 + args.warmup):
+        step().free()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step().free()                                     # (free synchronizes the stream)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    step(timed=True)
+    s = step(timed=True)
     torch.cuda.synchronize()
-    stage = {"sketch": ev[0].elapsed_time(ev[1]), "gather": ev[1].elapsed_time(ev[2]), "pairs": ev[2].elapsed_time(ev[3])}
+    stage = {"sketch": ev[0].elapsed_time(ev[1]), "gather": ev[1].elapsed_time(ev[2]), "set + pairs": ev[2].elapsed_time(ev[3])}
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # host arithmetic on a bounded sample of this rank's rows
-    host = every.cpu().numpy()
+    # host side on a bounded sample of this rank's rows: cardinalities (GPU histograms + host finish) and rows -> text
     t1 = time.perf_counter()
-    card = cardinalities(algo, p, host[: min(N, 2000)])
-    card_s_per_sketch = (time.perf_counter() - t1) / min(N, 2000)
-    rows = min(nr, 64)
-    st = {}
-    if algo == "hmh":
-        st = dict(c_or_zero=outs[0][:rows].cpu().numpy().view(np.uint32), n_counts=outs[1][:rows].cpu().numpy().view(np.uint32))
-    elif algo == "hll":
-        st = dict(c_or_zero=outs[0][:rows].cpu().numpy().view(np.uint32), sum_or_union=outs[1][:rows].cpu().numpy())
-    else:
-        st = dict(sum_or_union=outs[0][:rows].cpu().numpy())
-    full_card = np.resize(card, N)
+    card = s.cardinalities()
+    card_s = time.perf_counter() - t1
+    from lash_amd.allpairs import _Formatter
+    from lash_amd.shard import effective_cores
+    names = ["g%06d.fa" % i for i in range(N)]
+    fmt = _Formatter(names, card)
+    b0 = blocks[-1][0]
+    b1 = min(blocks[-1][1], b0 + 64)
+    st = s.pair_block(b0, b1, n_cols=b1, triangle=True)
+    threads = max(1, 2 * effective_cores() // world)
+    fd = os.open(os.devnull, os.O_WRONLY)
     t1 = time.perf_counter()
-    d = lash_amd.dist_rows(algo, p, k, 1, full_card[:rows], full_card, **st)
-    host_pairs_per_s = rows * N / (time.perf_counter() - t1)
+    fmt.block(lash_amd.ALGOS[algo], p, k, 1, False, None, b0, b1, st, b1, False, threads, fd)
+    host_pairs_per_s = sum(range(b0 + 1, b1 + 1)) / (time.perf_counter() - t1)
+    os.close(fd)
+    fmt.close()
+    s.free()
     if rank == 0:
         kmers = G * (L - k + 1) * world * args.steps
-        pairs = N * N * args.steps                       # all ranks' row blocks together: the full N x N matrix per step
+        pairs = N * (N + 1) // 2 * args.steps             # all ranks' bands together: the printed triangle per step
         print(json.dumps({
             "metric": "k-mers/s sketched + all-vs-all (%s, k=%d)" % (algo, k), "value": kmers / elapsed, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[3] shape: %d synthetic %d-bp genomes per GPU sketched (-a %s -k %d), images all-gathered over "
-                                   "RCCL (%d x %d B), every rank computes %d of the %d reference rows against all %d sketches"
-                                   % (G, L, algo, k, N, ib, nr, N, N), "genomes_per_gpu": G, "genome_length": L, "algo": algo, "k": k, "p": p},
-            "pairs_per_s": pairs / elapsed, "stage_ms_rank0": stage,
-            "host_arithmetic": {"cardinality_s_per_sketch": card_s_per_sketch, "dist_rows_pairs_per_s_one_thread": host_pairs_per_s,
-                                "note": "O(sketches) + O(pairs) estimator arithmetic (lash_dist_rows), outside the timed step; mean distance of the sample %.4f" % float(d.mean())},
+                                   "RCCL (%d x %d B), every rank holds them as a resident set and computes its two bands of the lower triangle "
+                                   "(%d of %d rows, equal printed pairs per rank)"
+                                   % (G, L, algo, k, N, ib, sum(b - a for a, b in bands), N), "genomes_per_gpu": G, "genome_length": L, "algo": algo, "k": k, "p": p},
+            "printed_pairs_per_s": pairs / elapsed, "stage_ms_rank0": stage,
+            "host_side": {"cardinalities_s_all_sketches": card_s, "rows_to_text_pairs_per_s_this_rank": host_pairs_per_s, "threads": threads,
+                          "note": "lash_dist_rows + row text in C++ (liblash_host.so), outside the timed step: a full run's wall time is "
+                                  "bounded by this, not by the GPU (profiles/r03/config3_full_one_gpu.log)"},
             "roofline": None, "cpu_baseline": None}))
 
 
@@ -306,7 +334,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--genomes", type=int, default=1000, help="genomes per GPU (weak scaling)")
+    ap.add_argument("--genomes", type=int, default=12500, help="genomes per GPU (weak scaling).  12 500 x 5 Mbp = 62.5 GB of ASCII resident per GPU: "
+                    "the north-star configuration (>= 10 000 genomes), and --gpus 8 is then exactly BASELINE configs[3]'s 100 000; "
+                    "configs[1] is --genomes 1000")
     ap.add_argument("--length", type=int, default=5_000_000)
     ap.add_argument("--algo", default="hmh")
     ap.add_argument("-k", type=int, default=16)
@@ -504,6 +534,7 @@ def main():
                        "algo": algo, "k": k, "p": p, "sharding": "genomes across ranks"},
             "roofline": {"bound": "hbm", "kernel": "sketch_kernel<DIRECT>" if direct else "sketch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed (not collected in this run)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sketch_ms,
                          "input": "ASCII records (1 B/base)" if direct else "packed 2-bit words (0.25 B/base)",
                          "note": "integer-ALU/LDS-atomic bound kernel: see DESIGN.md 'Roofline'"},

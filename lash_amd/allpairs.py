@@ -146,36 +146,53 @@ def all_vs_all_stream(algo, p, k, local_images, counts, names, out_prefix, *, ct
     threads = threads or max(1, 2 * effective_cores() // max(1, world))   # (a little oversubscription hides the ordered writes)
     fmt = _Formatter(names, card)
     cap = max(max_block_pairs, n)
-    # the block's pair tables land in page-locked memory (the copy back runs at the link rate); the owners stay alive with `pins`
-    pins = {"c": PinnedArray(cap * 4, np.uint32) if a != _lib.ULL else None, "n": PinnedArray(cap * 4, np.uint32) if a == _lib.HMH else None,
-            "u": PinnedArray(cap * 8, np.float64) if a != _lib.HMH else None}
-    pin = {k_: v.array for k_, v in pins.items() if v is not None}
-    parts, t_gpu, t_host, pairs = [], 0.0, 0.0, 0
+    # the block's pair tables land in page-locked memory (the copy back runs at the link rate).  Two slots: a helper thread has the
+    # GPU compute block b+1 while this one turns block b into text (the C calls release the interpreter lock)
+    from concurrent.futures import ThreadPoolExecutor
+    pins = [{"c": PinnedArray(cap * 4, np.uint32) if a != _lib.ULL else None, "n": PinnedArray(cap * 4, np.uint32) if a == _lib.HMH else None,
+             "u": PinnedArray(cap * 8, np.float64) if a != _lib.HMH else None} for _ in range(2)]
+    pin = [{k_: v.array for k_, v in ps.items() if v is not None} for ps in pins]
     nb = 2 * world
+    blocks = []                                                  # (band, b0, b1): rows [b0, b1) x columns [0, b1), <= cap pair-table entries
     for band in (rank, nb - 1 - rank):
         b_lo, b_hi = row_block(n, band, nb)
-        path = os.devnull if out_prefix == os.devnull else "%s.band%d" % (out_prefix, band)     # (os.devnull: a timing / census run)
-        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-        written = 0
         b0 = b_lo
         while b0 < b_hi:
             b1 = min(b_hi, b0 + max(1, cap // max(b0 + 1, 1)))
             while b1 > b0 + 1 and (b1 - b0) * b1 > cap:
                 b1 -= 1
-            tg = time.perf_counter()
-            st = s.pair_block(b0, b1, n_cols=b1, triangle=True, estimator=estimator, out=pin)
-            if a == _lib.HMH:
-                ec = s.hmh_expected_collisions(b0, b1, n_cols=b1)
-                if ec is not None:
-                    st["hmh_ec"] = ec
+            blocks.append((band, b0, b1))
+            b0 = b1
+    gpu_s = [0.0]
+
+    def gpu_block(i):
+        _, b0, b1 = blocks[i]
+        tg = time.perf_counter()
+        st = s.pair_block(b0, b1, n_cols=b1, triangle=True, estimator=estimator, out=pin[i & 1])
+        if a == _lib.HMH:
+            ec = s.hmh_expected_collisions(b0, b1, n_cols=b1)
+            if ec is not None:
+                st["hmh_ec"] = ec
+        gpu_s[0] += time.perf_counter() - tg
+        return st
+    parts, t_host, pairs = [], 0.0, 0
+    fds = {}
+    for band in (rank, nb - 1 - rank):
+        path = os.devnull if out_prefix == os.devnull else "%s.band%d" % (out_prefix, band)     # (os.devnull: a timing / census run)
+        fds[band] = [path, os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644), 0]
+    with ThreadPoolExecutor(1) as ex:
+        fut = ex.submit(gpu_block, 0) if blocks else None
+        for i, (band, b0, b1) in enumerate(blocks):
+            st = fut.result()
+            fut = ex.submit(gpu_block, i + 1) if i + 1 < len(blocks) else None
             th = time.perf_counter()
-            written += fmt.block(a, p, k, model, fp32, hll_bias, b0, b1, st, b1, matrix, threads, fd)
-            t_gpu += th - tg
+            fds[band][2] += fmt.block(a, p, k, model, fp32, hll_bias, b0, b1, st, b1, matrix, threads, fds[band][1])
             t_host += time.perf_counter() - th
             pairs += sum(range(b0 + 1, b1 + 1))
-            b0 = b1
+    for band, (path, fd, written) in fds.items():
         os.close(fd)
         parts.append((band, path, written))
+    t_gpu = gpu_s[0]
     fmt.close()
     s.free()
     del pin, pins
