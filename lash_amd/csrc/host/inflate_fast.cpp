@@ -252,7 +252,7 @@ int InflateStream::decode_block(const uint8_t *in, size_t in_n, size_t &ip_ref, 
         uint32_t e = ll[bb & ((1u << LL_ROOT) - 1u)];
         if (e & E_SUB) e = ll[(e >> 16) + ((bb >> LL_ROOT) & ((1u << ((e >> 8) & 15u)) - 1u))];
         unsigned n = e & 0xFFu;
-        if (!FAST && n > bc) { ret = (e & E_BAD) ? BAD_DATA : TRUNCATED; break; }
+        if (!FAST && n > bc) { ret = TRUNCATED; break; }      // (the zero padding past the end may look up anything, E_BAD included)
         if (e & (E_LIT | E_EOB | E_BAD)) {
             if (e & E_BAD) { ret = BAD_DATA; break; }
             bb >>= n; bc -= n;
@@ -269,7 +269,7 @@ int InflateStream::decode_block(const uint8_t *in, size_t in_n, size_t &ip_ref, 
         e = dt[bb & ((1u << D_ROOT) - 1u)];
         if (e & E_SUB) e = dt[(e >> 16) + ((bb >> D_ROOT) & ((1u << ((e >> 8) & 15u)) - 1u))];
         n = e & 0xFFu;
-        if (!FAST && n > bc) { ret = (e & E_BAD) ? BAD_DATA : TRUNCATED; break; }
+        if (!FAST && n > bc) { ret = TRUNCATED; break; }
         if (e & E_BAD) { ret = BAD_DATA; break; }
         saved = bb;
         bb >>= n; bc -= n;
@@ -596,10 +596,17 @@ long WindowedInflate::read(const uint8_t *in, size_t in_n, size_t &in_pos, uint8
 {
     if (!buf_) { *err = "out of memory"; return -1; }
     size_t got = 0;
+    const uint32_t crc_in = crc_;
+    const uint64_t total_in = total_;
     while (got < n) {
         if (rd_ < op_) {
+            // crc() / total() cover exactly the bytes HANDED OUT: a caller that gives up on this decoder mid-member (pgzip.cpp:
+            // zlib takes the member over) can check the replacement's prefix against them
             const size_t take = n - got < op_ - rd_ ? n - got : op_ - rd_;
+            if (test_flip_ >= 0 && (uint64_t)test_flip_ >= total_ && (uint64_t)test_flip_ < total_ + take) buf_[rd_ + ((uint64_t)test_flip_ - total_)] ^= 0x20;
             memcpy(dst + got, buf_ + rd_, take);
+            crc_ = crc32_fast(crc_, buf_ + rd_, take);
+            total_ += take;
             rd_ += take;
             got += take;
             continue;
@@ -609,12 +616,14 @@ long WindowedInflate::read(const uint8_t *in, size_t in_n, size_t &in_pos, uint8
             memmove(buf_, buf_ + op_ - 32768, 32768);
             op_ = rd_ = 32768;
         }
-        const size_t before = op_;
         const InflateStream::Status st = z_.run(in, in_n, in_pos, buf_, op_, cap_);
-        crc_ = crc32_fast(crc_, buf_ + before, op_ - before);
-        total_ += op_ - before;
         if (st == InflateStream::DONE) done_ = true;
-        else if (st != InflateStream::OUTPUT_FULL) { *err = st == InflateStream::TRUNCATED ? "truncated gzip stream" : "corrupt deflate data"; return -1; }
+        else if (st != InflateStream::OUTPUT_FULL) {
+            *err = st == InflateStream::TRUNCATED ? "truncated gzip stream" : "corrupt deflate data";
+            crc_ = crc_in;                                                // the caller discards this call's bytes
+            total_ = total_in;
+            return -1;
+        }
     }
     return (long)got;
 }

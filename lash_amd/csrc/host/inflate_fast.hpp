@@ -53,7 +53,7 @@ private:
 uint32_t crc32_fast(uint32_t crc, const uint8_t *p, size_t n);
 
 // Every member of the gzip file image src[0..n): header (RFC 1952, all optional fields), deflate stream, CRC-32 and length
-// check; the inflated bytes are appended to out.  Returns "" or what is wrong.  `one_member`: stop after the first member and
+// check; the inflated bytes are appended to out.  Returns nullptr on success, else a static string saying what is wrong.  `one_member`: stop after the first member and
 // report where it ended through *consumed.
 struct ByteSink {                      // contiguous growable output (realloc; the decoder only keeps offsets)
     uint8_t *p = nullptr;
@@ -74,7 +74,9 @@ size_t gzip_header_length(const uint8_t *p, size_t avail);
 
 // One gzip member's deflate body read sequentially with bounded memory (a single-member file of any size): 32 KiB of
 // history + `chunk` bytes, refilled as the caller drains it.  The caller positions in_pos after the member header and, when
-// done() turns true, finds it at the member's 8-byte trailer, which it checks against crc() / total().
+// done() turns true, finds it at the member's 8-byte trailer, which it checks against crc() / total().  crc() / total() always
+// cover exactly the bytes read() has handed out so far.  TRUNCATED is terminal: `in` must be the complete stream (the callers
+// pass the whole mmap'd file); the decoder consumes bits before it reports it and cannot be resumed.
 class WindowedInflate {
 public:
     explicit WindowedInflate(size_t chunk = 1u << 20);
@@ -87,6 +89,7 @@ public:
     bool done() const { return done_ && rd_ == op_; }
     uint32_t crc() const { return crc_; }
     uint64_t total() const { return total_; }
+    void test_flip_output_byte(long at) { test_flip_ = at; }   // tests: a decoder defect — output byte `at` of every member comes out wrong
 private:
     InflateStream z_;
     uint8_t *buf_;
@@ -94,6 +97,7 @@ private:
     bool done_ = false;
     uint32_t crc_ = 0;
     uint64_t total_ = 0;
+    long test_flip_ = -1;
 };
 
 }  // namespace lashhost

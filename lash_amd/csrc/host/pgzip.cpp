@@ -107,6 +107,8 @@ struct ParallelGzip::Impl {
     uint64_t delivered = 0, z_skip = 0;
     const bool no_fast = getenv("LASH_NO_FAST_INFLATE") != nullptr;
     const long test_fail_after = getenv("LASH_TEST_FAST_INFLATE_FAIL_AFTER") ? atol(getenv("LASH_TEST_FAST_INFLATE_FAIL_AFTER")) : -1;
+    const long test_flip_at = getenv("LASH_TEST_FAST_INFLATE_FLIP_AT") ? atol(getenv("LASH_TEST_FAST_INFLATE_FLIP_AT")) : -1;   // corrupt that output byte
+    uint32_t skip_crc = 0, skip_crc_want = 0;
     // speculative side
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
@@ -299,6 +301,10 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
                 I.z_open = true;
                 I.in_pos = I.pos;
                 I.z_skip = I.delivered;
+                // what went out already came from the fast decoder UNVERIFIED (its CRC is only checked at the member's end):
+                // zlib's version of those bytes must have the same CRC, or the caller holds wrong bytes — an error, not a fallback
+                I.skip_crc_want = I.fast.crc();
+                I.skip_crc = 0;
             }
             continue;
         }
@@ -317,8 +323,14 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
             const uInt before = I.z.avail_out;
             const int rc = inflate(&I.z, Z_NO_FLUSH);
             if (rc != Z_OK && rc != Z_STREAM_END) { err = "Invalid input file: corrupt gzip stream"; return -1; }
-            if (skipping) I.z_skip -= before - I.z.avail_out;
-            else done += before - I.z.avail_out;
+            if (skipping) {
+                I.skip_crc = crc32_fast(I.skip_crc, scratch, before - I.z.avail_out);
+                I.z_skip -= before - I.z.avail_out;
+                if (I.z_skip == 0 && I.skip_crc != I.skip_crc_want) {
+                    err = "Invalid input file: the fast inflate path and zlib disagree on bytes already handed out (decoder defect or memory corruption)";
+                    return -1;
+                }
+            } else done += before - I.z.avail_out;
             if (rc == Z_STREAM_END) {
                 if (I.z_skip) { err = "Invalid input file: corrupt gzip stream"; return -1; }   // (shorter than what the fast decoder produced)
                 const uint64_t end = I.in_pos - I.z.avail_in;    // the member ended here
@@ -348,6 +360,7 @@ long ParallelGzip::read(uint8_t *dst, size_t n, std::string &err)
         const size_t hl = I.no_fast ? 0 : gzip_header_length(I.map + I.pos, I.size - I.pos);
         if (hl) {
             I.fast.begin();
+            I.fast.test_flip_output_byte(I.test_flip_at);
             I.fast_ip = I.pos + hl;
             I.fast_open = true;
             continue;

@@ -395,6 +395,19 @@ def test_gzip_reader_padding_fallback_and_zlib_only(tmp_path):
                 {"LASH_TEST_FAST_INFLATE_FAIL_AFTER": "5000000", "LASH_PGZIP_MEMBER_CAP": "1000000"}, {"LASH_NO_FAST_INFLATE": "1"}):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=os.path.dirname(here), **env))
         assert r.returncode == 0 and "same" in r.stdout, (env, r.stderr[-2000:])
+    # (iv) a DEFECT in the fast decoder (simulated: one wrong output byte).  The sequential path hands bytes out before the
+    # member's CRC is known; when zlib then takes the member over it re-makes those bytes, and their CRC must equal that of what
+    # went out — a silent skip would leave the wrong byte with the caller.  The read must FAIL, not return other bytes.
+    code2 = ("import sys; sys.path.insert(0, %r); import host_lib as H\n"
+             "try:\n"
+             "    d, p, s = H.pgzip_read(%r + '/single.gz', 1, 1 << 16)\n"
+             "    print('returned', d == open(%r, 'rb').read())\n"
+             "except ValueError as e:\n"
+             "    print('refused:', e)\n" % (here, str(tmp_path), str(tmp_path / "want.bin")))
+    for flip in ("12345", "6000000"):
+        r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONPATH=os.path.dirname(here), LASH_TEST_FAST_INFLATE_FLIP_AT=flip))
+        assert r.returncode == 0 and "refused:" in r.stdout and "disagree" in r.stdout, (flip, r.stdout, r.stderr[-2000:])
 
 
 def test_threaded_fastq_check_equals_the_sequential_one():
