@@ -81,7 +81,14 @@ typedef struct {
     char    hmh_header[8];    /* U2  ""       */
     char    hll_header[8];    /* U3  "azspl"  */
     char    ull_header[8];    /* U4  "l"      */
-} lash_layout;                /* 32 bytes */
+    uint8_t fastq_skip_bad;   /* U6  what lash's record loop sees after a MALFORMED FASTQ record.  The loop is
+                                     `while let Some(res) = reader.next() { if let Ok(rec) = res {..} }` (utils.rs:457-458): it
+                                     keeps calling next() after an Err.  0: needletail's iterator is finished by the error — the
+                                     records before it stand, nothing after it is seen.  1: the iterator goes on — the malformed
+                                     record is dropped, reading resumes at the next line that starts with '@' and whose line
+                                     after next starts with '+'.  tools/ref_probe carries two such files                  0 */
+    uint8_t reserved[7];      /*     zero */
+} lash_layout;                /* 40 bytes */
 
 /* Sums over every sketch call since lash_ctx_enable_timing(ctx, 1) (HIP events on the ctx stream). */
 typedef struct {
@@ -126,7 +133,7 @@ size_t      lash_sketch_image_bytes(int algo, int p);      /* bytes S::save writ
 void        lash_layout_default(lash_layout *out);
 int         lash_layout_check(const lash_layout *lay);     /* LASH_OK or LASH_EINVAL */
 /* "key=value,..." on top of the default: codes=ACGT (the four letters in code order) kmer=msb|lsb hmh_x=high|low
- * hmh_reg=le|be hll_bucket=low|high hmh_hdr= hll_hdr=azspl ull_hdr=l.  NULL / "" = the default. */
+ * hmh_reg=le|be hll_bucket=low|high hmh_hdr= hll_hdr=azspl ull_hdr=l fastq_err=stop|skip.  NULL / "" = the default. */
 int         lash_layout_parse(const char *spec, lash_layout *out);
 size_t      lash_layout_header_bytes(const lash_layout *lay, int algo);
 size_t      lash_layout_image_bytes(const lash_layout *lay, int algo, int p);   /* lay NULL = default; 0 if invalid */
@@ -204,6 +211,12 @@ uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32
  * contiguous) with a well-formed stand-in that contributes no base.  Host only. */
 uint64_t lash_fastq_valid_prefix(const uint8_t *buf, uint64_t n);
 void     lash_fastq_neutralise_tail(uint8_t *tail, uint64_t n);
+/* Both in one, for either setting of layout.fastq_skip_bad: overwrites, in place, every byte needletail's iterator would not
+ * turn into a record — skip_bad 0: what follows the first malformed record (lash_fastq_neutralise_tail); skip_bad 1: each
+ * malformed stretch up to the next plausible record start ('@' + 'x'..., which makes it part of that record's header line), the
+ * last one as a tail — so that the device parse of the buffer yields exactly the reference's records.  File offsets stay as
+ * they are.  Returns the number of bytes overwritten (0: a well-formed file).  Host only. */
+uint64_t lash_fastq_sanitize(uint8_t *buf, uint64_t n, int skip_bad);
 
 /* Two-stage form for callers that keep genomes resident in HBM as 2-bit (0.28 B/base incl. break bitmap):
  * pack once, sketch many times (other k / algo / seed).  The pack stage performs filter_out_n + KSeq::new

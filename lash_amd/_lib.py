@@ -24,7 +24,8 @@ class Layout(C.Structure):
     """lash_layout: the reference's crate-internal rules as data."""
     _fields_ = [("base_code", C.c_uint8 * 4), ("kmer_lsb_first", C.c_uint8), ("hmh_x_low", C.c_uint8),
                 ("hmh_reg_be", C.c_uint8), ("hll_bucket_high", C.c_uint8),
-                ("hmh_header", C.c_char * 8), ("hll_header", C.c_char * 8), ("ull_header", C.c_char * 8)]
+                ("hmh_header", C.c_char * 8), ("hll_header", C.c_char * 8), ("ull_header", C.c_char * 8),
+                ("fastq_skip_bad", C.c_uint8), ("reserved", C.c_uint8 * 7)]
 
 
 class Timing(C.Structure):
@@ -70,6 +71,7 @@ PROTOTYPES = {
     "lash_ctx_hll_inexact_sums": (_u32, [_vp, _vp, _u32]),
     "lash_fastq_valid_prefix": (_u64, [_vp, _u64]),
     "lash_fastq_neutralise_tail": (None, [_vp, _u64]),
+    "lash_fastq_sanitize": (_u64, [_vp, _u64, _int]),
     "lash_pack_device": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u32, C.POINTER(_vp)]),
     "lash_sketch_packed_device": (_int, [_vp, _PP, _vp, _vp]),
     "lash_packed_free": (None, [_vp, _vp]),

@@ -31,7 +31,7 @@ std::string layout_from_option(const std::string &spec, lash_layout &out)
     const char *env = getenv("LASH_LAYOUT");
     const std::string text = !spec.empty() ? spec : (env ? env : "");
     if (lash_layout_parse(text.c_str(), &out) != LASH_OK)
-        return "bad layout '" + text + "' (codes=ACGT,kmer=msb|lsb,hmh_x=high|low,hmh_reg=le|be,hll_bucket=low|high,"
+        return "bad layout '" + text + "' (codes=ACGT,kmer=msb|lsb,hmh_x=high|low,hmh_reg=le|be,hll_bucket=low|high,fastq_err=stop|skip,"
                "hmh_hdr=,hll_hdr=azspl,ull_hdr=l)";
     return "";
 }
@@ -385,8 +385,14 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
         if (!eof && cut == 0) { result = "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path; break; }
         bool stop_here = false;
         if (fmt == LASH_FMT_FASTQ) {                      // the chunk starts and ends at record boundaries: validate it whole
-            const uint64_t ok = fastq_valid_prefix_mt(b, cut, threads);
-            if (ok < cut) { cut = (size_t)ok; stop_here = true; }   // needletail stops at the malformed record (utils.rs:457)
+            lash_layout lay;
+            (void)lash_ctx_get_layout(ctx, &lay);
+            if (lay.fastq_skip_bad) {
+                (void)lash_fastq_sanitize(b, cut, 1);       // layout switch U6: malformed records are dropped, the reading goes on
+            } else {
+                const uint64_t ok = fastq_valid_prefix_mt(b, cut, threads);
+                if (ok < cut) { cut = (size_t)ok; stop_here = true; }   // needletail stops at the malformed record (utils.rs:457)
+            }
         }
         t_check += since(t0);
         // what follows the cut moves to the front of the other buffer — once the sketching side has let go of it
@@ -617,8 +623,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                             if (f == LASH_FMT_FASTQ) {
                                 // needletail's iterator ends at the first malformed record and lash keeps what came before
                                 // (utils.rs:457): validate here, in the reader thread, and blank out what it would never yield
-                                const uint64_t ok = lash_fastq_valid_prefix(dst, s.size);
-                                if (ok < s.size) lash_fastq_neutralise_tail(dst + ok, s.size - ok);
+                                (void)lash_fastq_sanitize(dst, s.size, opt.layout.fastq_skip_bad);
                             }
                         }
                     }

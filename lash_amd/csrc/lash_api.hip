@@ -462,6 +462,7 @@ int lash_layout_parse(const char *spec, lash_layout *out)
         else if (key == "hmh_hdr") ok = hdr(lay.hmh_header);
         else if (key == "hll_hdr") ok = hdr(lay.hll_header);
         else if (key == "ull_hdr") ok = hdr(lay.ull_header);
+        else if (key == "fastq_err") ok = two("stop", "skip", lay.fastq_skip_bad);
         else ok = false;
         if (!ok) return LASH_EINVAL;
     }
@@ -862,7 +863,9 @@ uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t ca
 // '>', line ends stripped.  FASTQ: '@' header, sequence line, '+' line, quality line of the same length; iteration STOPS at
 // the first record that breaks this (the records before it stand).  Returns the offset at which the iteration stopped
 // (n when the whole buffer parsed); seq / rec_off may be NULL (validation only).
-static size_t parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> *seq, std::vector<uint64_t> *rec_off)
+// `bad` (FASTQ, may be NULL): the byte ranges [first, second) that are not part of any record the iteration yields.
+static size_t parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> *seq, std::vector<uint64_t> *rec_off, bool skip_bad = false,
+                                 std::vector<std::pair<size_t, size_t>> *bad = nullptr)
 {
     auto line_end = [&](size_t p) { const void *q = memchr(d + p, '\n', n - p); return q ? (size_t)((const uint8_t *)q - d) : n; };
     size_t i = 0;
@@ -881,25 +884,45 @@ static size_t parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t
         return n;
     }
     while (i < n) {
-        if (d[i] != '@') break;
-        const size_t e = line_end(i);
-        if (e >= n) break;
-        const size_t s = e + 1, se = line_end(s);
-        if (se >= n) break;
-        const size_t pl = se + 1;
-        if (pl >= n || d[pl] != '+') break;
-        const size_t pe = line_end(pl);
-        if (pe >= n) break;
-        const size_t ql = pe + 1, qe = line_end(ql);
-        size_t sl = se - s, qn = qe - ql;
-        while (sl && d[s + sl - 1] == '\r') --sl;
-        while (qn && d[ql + qn - 1] == '\r') --qn;
-        if (sl != qn) break;
-        if (seq) seq->insert(seq->end(), d + s, d + s + sl);
-        if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
-        i = qe < n ? qe + 1 : n;
+        const size_t rec = i;
+        bool ok = false;
+        do {
+            if (d[i] != '@') break;
+            const size_t e = line_end(i);
+            if (e >= n) break;
+            const size_t s = e + 1, se = line_end(s);
+            if (se >= n) break;
+            const size_t pl = se + 1;
+            if (pl >= n || d[pl] != '+') break;
+            const size_t pe = line_end(pl);
+            if (pe >= n) break;
+            const size_t ql = pe + 1, qe = line_end(ql);
+            size_t sl = se - s, qn = qe - ql;
+            while (sl && d[s + sl - 1] == '\r') --sl;
+            while (qn && d[ql + qn - 1] == '\r') --qn;
+            if (sl != qn) break;
+            if (seq) seq->insert(seq->end(), d + s, d + s + sl);
+            if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
+            i = qe < n ? qe + 1 : n;
+            ok = true;
+        } while (false);
+        if (ok) continue;
+        if (!skip_bad) { if (bad) bad->emplace_back(rec, n); return rec; }      // the iterator is finished by the error
+        // layout.fastq_skip_bad: resume at the next plausible record start after `rec`
+        size_t c = line_end(rec), resume = n;
+        while (c < n) {
+            const size_t ls = c + 1;
+            if (ls >= n) break;
+            if (d[ls] == '@') {
+                const size_t l1 = line_end(ls), l2 = l1 < n ? line_end(l1 + 1) : n;
+                if (l2 < n && l2 + 1 < n && d[l2 + 1] == '+') { resume = ls; break; }
+            }
+            c = line_end(ls);
+        }
+        if (bad) bad->emplace_back(rec, resume);
+        i = resume;
     }
-    return i;
+    return n;
 }
 
 uint64_t lash_fastq_valid_prefix(const uint8_t *buf, uint64_t n)
@@ -907,6 +930,23 @@ uint64_t lash_fastq_valid_prefix(const uint8_t *buf, uint64_t n)
     if (!buf || n == 0) return 0;
     if (buf[0] != '@') return 0;
     return (uint64_t)parse_fastx_strict(buf, (size_t)n, nullptr, nullptr);
+}
+
+uint64_t lash_fastq_sanitize(uint8_t *buf, uint64_t n, int skip_bad)
+{
+    if (!buf || n == 0 || buf[0] != '@') return 0;
+    std::vector<std::pair<size_t, size_t>> bad;
+    parse_fastx_strict(buf, (size_t)n, nullptr, nullptr, skip_bad != 0, &bad);
+    uint64_t changed = 0;
+    for (const auto &b : bad) {
+        if (b.second >= n) lash_fastq_neutralise_tail(buf + b.first, n - b.first);
+        else {                                                     // becomes the head of the next record's header line
+            buf[b.first] = '@';
+            for (size_t i = b.first + 1; i < b.second; ++i) buf[i] = 'x';
+        }
+        changed += b.second - b.first;
+    }
+    return changed;
 }
 
 void lash_fastq_neutralise_tail(uint8_t *tail, uint64_t n)
@@ -965,7 +1005,7 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     for (uint32_t g : bad) {                                       // exact reference semantics for the malformed ones
         std::vector<uint8_t> seq;
         std::vector<uint64_t> rec_off(1, 0);
-        parse_fastx_strict(raw + file_off[g], (size_t)(file_off[g + 1] - file_off[g]), &seq, &rec_off);
+        parse_fastx_strict(raw + file_off[g], (size_t)(file_off[g + 1] - file_off[g]), &seq, &rec_off, ctx->layout.fastq_skip_bad != 0);
         const uint64_t goff[2] = {0, (uint64_t)rec_off.size() - 1};
         const uint8_t dummy = 0;
         rc = lash_sketch_batch(ctx, prm, seq.empty() ? &dummy : seq.data(), rec_off.data(), rec_off.size() - 1, goff, 1, out_images + (size_t)g * ib);

@@ -58,7 +58,7 @@ struct HostStage {
     bool pending = false;
 };
 
-const lash_layout kDefaultLayout = {{0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l"};
+const lash_layout kDefaultLayout = {{0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l", 0, {0, 0, 0, 0, 0, 0, 0}};
 
 }  // namespace lashi
 using namespace lashi;

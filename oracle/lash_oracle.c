@@ -103,7 +103,7 @@ uint64_t lash_or_mask_bits(uint64_t v, int k)
 /* ------------------------------------------------------------------------------------------
  * The layout: every unverified crate-internal choice as data (lash_oracle.h)
  * ---------------------------------------------------------------------------------------- */
-static const lash_or_layout DEFAULT_LAYOUT = { {0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l" };
+static const lash_or_layout DEFAULT_LAYOUT = { {0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l", 0, {0} };
 static inline const lash_or_layout *lay_of(const lash_or_params *prm) { return prm->layout ? prm->layout : &DEFAULT_LAYOUT; }
 
 void lash_or_layout_default(lash_or_layout *out) { *out = DEFAULT_LAYOUT; }
@@ -631,23 +631,44 @@ static int sketch_file_with(const lash_or_params *prm, const uint8_t *buf, uint6
             sketch_record(&rc, joined ? joined : buf, n);
         }
     } else {
+        const int skip_bad = lay_of(prm)->fastq_skip_bad;            /* switch U6: what follows a malformed record */
         while (p < end) {
-            if (*p != '@') break;                                    /* malformed: iteration ends */
-            const uint8_t *e = line_end(p, end);
-            if (e >= end) break;
-            const uint8_t *sq = e + 1, *se = line_end(sq, end);
-            if (se >= end) break;
-            const uint8_t *pl = se + 1;
-            if (pl >= end || *pl != '+') break;
-            const uint8_t *pe = line_end(pl, end);
-            if (pe >= end) break;
-            const uint8_t *ql = pe + 1, *qe = line_end(ql, end);
-            size_t sl = (size_t)(se - sq), qn = (size_t)(qe - ql);
-            while (sl && sq[sl - 1] == '\r') sl--;
-            while (qn && ql[qn - 1] == '\r') qn--;
-            if (sl != qn) break;                                     /* sequence and quality lengths differ */
-            sketch_record(&rc, sq, sl);
-            p = qe < end ? qe + 1 : end;
+            const uint8_t *rec = p;
+            int ok = 0;
+            do {
+                if (*p != '@') break;                                /* malformed */
+                const uint8_t *e = line_end(p, end);
+                if (e >= end) break;
+                const uint8_t *sq = e + 1, *se = line_end(sq, end);
+                if (se >= end) break;
+                const uint8_t *pl = se + 1;
+                if (pl >= end || *pl != '+') break;
+                const uint8_t *pe = line_end(pl, end);
+                if (pe >= end) break;
+                const uint8_t *ql = pe + 1, *qe = line_end(ql, end);
+                size_t sl = (size_t)(se - sq), qn = (size_t)(qe - ql);
+                while (sl && sq[sl - 1] == '\r') sl--;
+                while (qn && ql[qn - 1] == '\r') qn--;
+                if (sl != qn) break;                                 /* sequence and quality lengths differ */
+                sketch_record(&rc, sq, sl);
+                p = qe < end ? qe + 1 : end;
+                ok = 1;
+            } while (0);
+            if (ok) continue;
+            if (!skip_bad) break;                                    /* the iterator is finished by the error */
+            /* resume at the next plausible record start after `rec`: a line that starts with '@' whose line after next starts with '+' */
+            const uint8_t *c = line_end(rec, end);
+            p = end;
+            while (c < end) {
+                const uint8_t *ls = c + 1;                           /* a line start */
+                if (ls >= end) break;
+                if (*ls == '@') {
+                    const uint8_t *l1 = line_end(ls, end);
+                    const uint8_t *l2 = l1 < end ? line_end(l1 + 1, end) : end;
+                    if (l2 < end && l2 + 1 < end && l2[1] == '+') { p = ls; break; }
+                }
+                c = line_end(ls, end);
+            }
         }
     }
     free(joined);

@@ -47,7 +47,14 @@ typedef struct {
     char    hmh_header[8];    /* U2: ""        */
     char    hll_header[8];    /* U3: "azspl"   (bincode of alpha, zero, sum, p, Box<[u8]> length prefix)  */
     char    ull_header[8];    /* U4: "l"       (bincode Vec<u8> length prefix)                            */
-} lash_or_layout;             /* 32 bytes */
+    uint8_t fastq_skip_bad;   /* U6: what lash's record loop sees after a malformed FASTQ record.  The loop is
+                                 `while let Some(res) = reader.next() { if let Ok(rec) = res {..} }` (utils.rs:457-458): it KEEPS CALLING
+                                 next() after an Err.  0 = needletail's iterator is finished by the error (next() -> None): the
+                                 records before it stand, nothing after it is seen.  1 = the iterator goes on: the malformed
+                                 record is dropped and reading resumes at the next line that starts with '@' and whose
+                                 line after next starts with '+'                                              default 0 */
+    uint8_t reserved[7];      /* zero */
+} lash_or_layout;             /* 40 bytes */
 
 void   lash_or_layout_default(lash_or_layout *out);
 /* 0 if usable: base_code a permutation of 0..3, header templates made of known field codes */

@@ -14,22 +14,23 @@ _SO = os.environ.get("LASH_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "liblas
 
 
 class Layout(C.Structure):
-    """lash_or_layout == the product's lash_layout (32 bytes): SURVEY App. D's unknowns U1-U5 as data."""
+    """lash_or_layout == the product's lash_layout (40 bytes): SURVEY App. D's unknowns U1-U6 as data."""
     _fields_ = [("base_code", C.c_uint8 * 4), ("kmer_lsb_first", C.c_uint8), ("hmh_x_low", C.c_uint8),
                 ("hmh_reg_be", C.c_uint8), ("hll_bucket_high", C.c_uint8),
-                ("hmh_header", C.c_char * 8), ("hll_header", C.c_char * 8), ("ull_header", C.c_char * 8)]
+                ("hmh_header", C.c_char * 8), ("hll_header", C.c_char * 8), ("ull_header", C.c_char * 8),
+                ("fastq_skip_bad", C.c_uint8), ("reserved", C.c_uint8 * 7)]
 
     def spec(self):
         """the text form lash_layout_parse() takes"""
         order = "".join("ACGT"[list(self.base_code).index(c)] for c in range(4))
-        return ("codes=%s,kmer=%s,hmh_x=%s,hmh_reg=%s,hll_bucket=%s,hmh_hdr=%s,hll_hdr=%s,ull_hdr=%s"
+        return ("codes=%s,kmer=%s,hmh_x=%s,hmh_reg=%s,hll_bucket=%s,hmh_hdr=%s,hll_hdr=%s,ull_hdr=%s,fastq_err=%s"
                 % (order, "lsb" if self.kmer_lsb_first else "msb", "low" if self.hmh_x_low else "high",
                    "be" if self.hmh_reg_be else "le", "high" if self.hll_bucket_high else "low",
-                   self.hmh_header.decode(), self.hll_header.decode(), self.ull_header.decode()))
+                   self.hmh_header.decode(), self.hll_header.decode(), self.ull_header.decode(), "skip" if self.fastq_skip_bad else "stop"))
 
 
 def make_layout(codes="ACGT", kmer="msb", hmh_x="high", hmh_reg="le", hll_bucket="low", hmh_hdr="", hll_hdr="azspl",
-                ull_hdr="l"):
+                ull_hdr="l", fastq_err="stop"):
     """codes: the four letters in code order (code 0 first), e.g. "ACGT" (kmerutils hypothesis) or "ACTG"."""
     lay = Layout()
     for code, letter in enumerate(codes):
@@ -39,6 +40,7 @@ def make_layout(codes="ACGT", kmer="msb", hmh_x="high", hmh_reg="le", hll_bucket
     lay.hmh_reg_be = int(hmh_reg == "be")
     lay.hll_bucket_high = int(hll_bucket == "high")
     lay.hmh_header, lay.hll_header, lay.ull_header = hmh_hdr.encode(), hll_hdr.encode(), ull_hdr.encode()
+    lay.fastq_skip_bad = int(fastq_err == "skip")
     return lay
 
 

@@ -50,9 +50,9 @@ def test_layout_host_entries():
     """lash_layout (SURVEY App. D's unknowns as data): default, parse, sizes — host only."""
     import oracle_lib as O
     d = lash_amd.parse_layout(None)
-    assert bytes(d) == bytes(O.default_layout())                      # the product's and the oracle's structs are the same 32 bytes
-    assert C.sizeof(_lib.Layout) == 32 == C.sizeof(O.Layout)
-    spec = "codes=ACTG,kmer=lsb,hmh_x=low,hmh_reg=be,hll_bucket=high,hmh_hdr=l,hll_hdr=pzsal,ull_hdr=pL"
+    assert bytes(d) == bytes(O.default_layout())                      # the product's and the oracle's structs are the same 40 bytes
+    assert C.sizeof(_lib.Layout) == 40 == C.sizeof(O.Layout)
+    spec = "codes=ACTG,kmer=lsb,hmh_x=low,hmh_reg=be,hll_bucket=high,hmh_hdr=l,hll_hdr=pzsal,ull_hdr=pL,fastq_err=skip"
     lay = lash_amd.parse_layout(spec)
     assert bytes(lay) == bytes(O.parse_layout(spec))
     assert lash_amd.image_bytes("hmh", 0, lay) == 8 + 32768 == O.image_bytes(O.HMH, 0, O.parse_layout(spec))

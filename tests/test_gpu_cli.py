@@ -148,3 +148,22 @@ def test_cli_stops_at_malformed_fastq_records_like_needletail(tmp_path):
         for i, name in enumerate(files):
             assert blob[i * ib:(i + 1) * ib] == want[i].tobytes(), (algo, name)
         assert blob[ib:2 * ib] != blob[:ib]                      # the truncation is real: not the same sketch as the clean file
+        # the other hypothesis of SURVEY App. D's U6 (needletail's iterator goes on after an error): --layout fastq_err=skip drops
+        # the malformed record and resumes at the next record — batch path, streamed path and the library's host-buffer entry
+        out2 = str(tmp_path / ("skip_" + algo))
+        r = subprocess.run([H.CLI, "sketch", "-f", str(tmp_path / "l.txt"), "-o", out2, "-a", algo, "-k", str(k), "-p", str(p), "--stream-mb", "2",
+                            "--batch-mb", "1", "-t", "3", "--layout", "fastq_err=skip"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        blob2 = H.zstd_read(out2 + "_sketches.bin")
+        lay = O.make_layout(fastq_err="skip")
+        want2 = O.sketch_files(ALGO[algo], k, p if algo != "hmh" else 0, 42, list(files.values()), threads=4, layout=lay)
+        for i, name in enumerate(files):
+            assert blob2[i * ib:(i + 1) * ib] == want2[i].tobytes(), (algo, name, "skip")
+        assert blob2[ib:2 * ib] != blob[ib:2 * ib]
+    import lash_amd
+    with lash_amd.Context(0) as ctx:
+        ctx.set_layout("fastq_err=skip")
+        got = ctx.sketch_files_raw("hmh", 16, 0, 42, [files["no_plus.fq"], files["ok.fq"], files["blank_line.fq"]])
+        want = O.sketch_files(O.HMH, 16, 0, 42, [files["no_plus.fq"], files["ok.fq"], files["blank_line.fq"]], layout=O.make_layout(fastq_err="skip"))
+        assert np.array_equal(got, want)
+        assert ctx.format_errors() == [0, 2]

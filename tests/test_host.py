@@ -500,3 +500,72 @@ def test_block_formatter_equals_the_python_restatement(tmp_path):
         assert len(got.encode()) == total
         assert got == format_rows(names, 0, want, matrix=matrix)
     assert "1.000000" in got and "0.000000" in got
+
+
+def _fastq_records_after_errors(data, skip_bad):
+    """independent restatement of the two hypotheses of layout.fastq_skip_bad, line-list based: every piece of
+    data.split(b"\n") but the last is a newline-terminated line"""
+    lines = data.split(b"\n")
+    L = len(lines)
+    recs, i = [], 0
+
+    def record_at(i):
+        if not lines[i].startswith(b"@") or i + 3 > L - 1:         # header, sequence and '+' lines must be terminated
+            return None
+        if not lines[i + 2].startswith(b"+"):
+            return None
+        s, q = lines[i + 1].rstrip(b"\r"), lines[i + 3].rstrip(b"\r")
+        return s if len(s) == len(q) else None
+    while i < L and not (i == L - 1 and lines[i] == b""):          # (the empty piece after a final newline is the end of the data)
+        s = record_at(i)
+        if s is not None:
+            recs.append(s)
+            i += 4
+            continue
+        if not skip_bad:
+            break
+        j = i + 1
+        while j < L and not (lines[j].startswith(b"@") and j + 2 <= L - 1 and lines[j + 2].startswith(b"+")):
+            j += 1
+        i = j
+    return recs
+
+
+def test_fastq_error_switch_stop_or_skip():
+    """layout.fastq_skip_bad (U6): utils.rs:457-458 keeps calling next() after an Err, so what lash sees after a malformed FASTQ
+    record depends on needletail's iterator.  Both hypotheses — the iterator is finished (default) / the bad record is dropped and
+    reading resumes at the next plausible record start — in the oracle and in lash_fastq_sanitize, against an independent
+    restatement; the sanitized buffer parses to exactly the same records with EITHER rule (what the device parse needs)."""
+    import ctypes as C
+    import lash_amd
+    import oracle_lib as O
+    lib = lash_amd.load()
+    rng = np.random.default_rng(23)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=40 + 3 * i)) for i in range(12)]
+    rec = lambda i, q=None, plus=b"+": b"@r%d\n%s\n%s\n%s\n" % (i, seqs[i], plus, (b"I" * len(seqs[i])) if q is None else q)
+    files = {
+        "bad_plus_in_the_middle": rec(0) + rec(1) + rec(2) + rec(3, plus=b"-") + rec(4) + rec(5),
+        "short_quality_in_the_middle": rec(0) + rec(1) + rec(6, q=b"III") + rec(7) + rec(8),
+        "two_bad_stretches_and_a_bad_tail": rec(0) + b"garbage line\n" + rec(1) + rec(2, q=b"I") + rec(3) + b"@trunc\nACGT\n+\n",
+        "bad_first_record": rec(9, plus=b"x") + rec(10) + rec(11),
+        "well_formed": rec(0) + rec(1),
+    }
+    for name, data in files.items():
+        for skip in (0, 1):
+            want_recs = _fastq_records_after_errors(data, bool(skip))
+            seq = np.frombuffer(b"".join(want_recs), np.uint8)
+            off = np.concatenate([[0], np.cumsum([len(r) for r in want_recs])]).astype(np.uint64)
+            want = O.sketch_genomes(O.HMH, 16, 0, 42, seq, off, np.array([0, len(want_recs)], np.uint64))[0]
+            lay = O.make_layout(fastq_err="skip" if skip else "stop")
+            got = O.sketch_files(O.HMH, 16, 0, 42, [data], layout=lay)[0]
+            assert np.array_equal(got, want), (name, skip)
+            buf = np.frombuffer(data, np.uint8).copy()
+            changed = int(lib.lash_fastq_sanitize(buf.ctypes.data, len(data), skip))
+            fixed = buf.tobytes()
+            assert (changed == 0) == (name == "well_formed") and len(fixed) == len(data)
+            for skip2 in (0, 1):                                  # now well-formed: both rules read the same records
+                assert np.array_equal(O.sketch_files(O.HMH, 16, 0, 42, [fixed], layout=O.make_layout(fastq_err="skip" if skip2 else "stop"))[0], want), (name, skip, skip2)
+    # the two rules differ exactly where records follow the error
+    a = _fastq_records_after_errors(files["bad_plus_in_the_middle"], False)
+    b = _fastq_records_after_errors(files["bad_plus_in_the_middle"], True)
+    assert a == seqs[:3] and b == seqs[:3] + seqs[4:6]

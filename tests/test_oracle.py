@@ -198,7 +198,7 @@ def test_layout_alternatives_match_pyref(li, algo, k, p):
 
 def test_default_layout_is_the_survey_hypothesis():
     d = O.default_layout()
-    assert d.spec() == "codes=ACGT,kmer=msb,hmh_x=high,hmh_reg=le,hll_bucket=low,hmh_hdr=,hll_hdr=azspl,ull_hdr=l"
+    assert d.spec() == "codes=ACGT,kmer=msb,hmh_x=high,hmh_reg=le,hll_bucket=low,hmh_hdr=,hll_hdr=azspl,ull_hdr=l,fastq_err=stop"
     assert O.header_bytes(O.HMH) == 0 and O.header_bytes(O.HLL) == 33 and O.header_bytes(O.ULL) == 8
     bad = O.make_layout()
     bad.base_code[0] = 1                                    # A and C share a code: not a permutation

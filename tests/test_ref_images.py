@@ -145,6 +145,28 @@ def test_reference_map_order_equals_name_order():
         assert sorted(tuple(r.split("\t")[:2]) for r in rows) == sorted((names[order[a]], names[order[b]]) for a in range(len(order)) for b in range(a + 1))
 
 
+@needs_ref
+def test_reference_after_a_malformed_fastq_record():
+    """layout.fastq_skip_bad: `while let Some(res) = reader.next() { if let Ok(rec) = res {..} }`
+    (utils.rs:457-458) keeps calling next() after an Err; the kit's two FASTQ files have good records on both sides of one
+    malformed record.  The real images say which hypothesis holds; the default must be the one."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "ref_probe"))
+    from make_inputs import ERROR_INPUTS, error_files
+    m = _manifest()
+    if "errors" not in m:
+        pytest.skip("this kit run predates the error probe")
+    assert not m["errors"].get("failed"), "the real lash did not finish on a malformed FASTQ: " + m["errors"].get("log_tail", "")
+    files = [error_files()[n] for n in ERROR_INPUTS]
+    raw = open(os.path.join(REF, m["errors"]["images"]), "rb").read()
+    ref = np.frombuffer(raw, np.uint8).reshape(len(files), -1)
+    stop = O.sketch_files(O.HMH, 16, 0, 42, files)
+    skip = O.sketch_files(O.HMH, 16, 0, 42, files, layout=O.make_layout(fastq_err="skip"))
+    assert not np.array_equal(stop, skip)
+    if np.array_equal(ref, skip):
+        pytest.fail("needletail's iterator goes on after an error: set fastq_err=skip as the default (kDefaultLayout / DEFAULT_LAYOUT)")
+    assert np.array_equal(ref, stop), "neither hypothesis of layout.fastq_skip_bad reproduces the real images" + _hint()
+
+
 def test_probe_kit_selftest():
     """The kit's search and report work: oracle-made images under a non-default layout are fitted back to a layout that
     reproduces them (tools/ref_probe/selftest.py).  Says nothing about lash itself."""

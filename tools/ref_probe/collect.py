@@ -29,7 +29,7 @@ def sorted_rows(path):
 
 def main(work, out):
     sys.path.insert(0, HERE)
-    from make_inputs import INPUTS, ORDER_NAMES
+    from make_inputs import ERROR_INPUTS, INPUTS, ORDER_NAMES
     cases = []
     for line in open(os.path.join(HERE, "cases.tsv")):
         if line.startswith("#") or not line.strip():
@@ -67,6 +67,20 @@ def main(work, out):
             if os.path.exists(os.path.join(od, src)):
                 shutil.copy(os.path.join(od, src), os.path.join(out, src.replace(".raw", ".txt")))
                 manifest["order"][key] = src.replace(".raw", ".txt")
+    # the error probe: the images of the two FASTQ files with a malformed record in the middle (hmh k=16 seed 42), or the fact
+    # that the real lash did not get that far
+    ed = os.path.join(work, "errors")
+    if os.path.isdir(ed):
+        binf = os.path.join(ed, "errors_sketches.bin")
+        if os.path.exists(binf):
+            raw = zstd_decompress(binf)
+            with open(os.path.join(out, "errors.bin"), "wb") as f:
+                f.write(raw)
+            manifest["errors"] = {"inputs": ERROR_INPUTS, "images": "errors.bin", "sha256": hashlib.sha256(raw).hexdigest(),
+                                  "algo": "hmh", "k": 16, "seed": 42}
+        else:
+            log = open(os.path.join(ed, "sketch.log")).read()[-2000:] if os.path.exists(os.path.join(ed, "sketch.log")) else ""
+            manifest["errors"] = {"inputs": ERROR_INPUTS, "failed": True, "log_tail": log}
     with open(os.path.join(out, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     print("wrote %d cases to %s" % (len(cases), out))

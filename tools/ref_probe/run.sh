@@ -44,6 +44,11 @@ d=$WORK/order; rm -rf "$d"; mkdir -p "$d"; cp "$WORK"/in_order/* "$d"/
   "$LASH_BIN" dist -q order -r order --dm -t 1 -o order.dm.raw > dist.log 2>&1
   "$LASH_BIN" dist -q order -r order -t 1 -o order.rows.raw >> dist.log 2>&1
 ) || echo "map-order probe failed" >&2
+# error probe: what does lash sketch AFTER a malformed FASTQ record? (utils.rs:457-458 keeps calling next(); pins layout.fastq_skip_bad)
+d=$WORK/errors; rm -rf "$d"; mkdir -p "$d"; cp "$WORK"/in_errors/* "$d"/
+( cd "$d"
+  "$LASH_BIN" sketch -f list.txt -o errors -a hmh -k 16 -t 1 > sketch.log 2>&1
+) || echo "error probe failed (a panic on malformed FASTQ would itself be the answer: see $d/sketch.log)" >&2
 python3 "$HERE/collect.py" "$WORK" "$OUT"
 ( cd "$HERE/kmer_probe" && cargo +nightly run --release > "$OUT/kmer_probe.txt" 2> "$WORK/kmer_probe.err" ) || echo "kmer_probe did not build/run (optional)" >&2
 python3 "$HERE/fit_layout.py" "$OUT"
