@@ -1,0 +1,25 @@
+"""A smoke tier of every randomized runner (tests/fuzz_gpu*.py) inside the `-m gpu` suite, fixed seeds, a few seconds each, so
+that a regression the fuzzers would find turns the driver's GPU test record red.  The long runs stay by hand
+(tools/gpu_round.sh, tools/gpu_longfuzz.sh)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.mark.parametrize("script,iters,seed,ok", [
+    ("fuzz_gpu.py", 150, 5, "fuzz ok"),                 # record / direct / pack-first routes vs the oracle
+    ("fuzz_gpu_raw.py", 150, 9, "raw fuzz ok"),         # device-side FASTA / FASTQ parse, malformed records injected
+    ("fuzz_gpu_cli.py", 20, 11, "cli fuzz ok"),         # `lash sketch` end to end (gz / plain, batch sizes, threads)
+    ("fuzz_gpu_stream.py", 12, 7, "stream fuzz ok"),    # large-file streaming: chunk cuts, N runs over the cut
+    ("fuzz_gpu_dist.py", 12, 13, "dist fuzz ok"),       # `lash dist` vs the pure-Python estimators, all three sketch types
+])
+def test_fuzz_runner_smoke(script, iters, seed, ok):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE)
+    r = subprocess.run([sys.executable, os.path.join(HERE, script), str(iters), str(seed)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and ok in r.stdout, (script, r.stdout[-1500:], r.stderr[-3000:])
