@@ -146,6 +146,7 @@ int pack_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 {
     uint32_t *tbc = static_cast<uint32_t *>(pk->tile_begin_c.ptr);
     HIPCHK(ctx, launch_dirty_tile_scan(pk->pm.tile_begin, pk->d_dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
+    if (pk->any_multi) HIPCHK(ctx, launch_zero_dirty_brk(pk->d_descs, pk->d_dirty, pk->n_genomes, static_cast<uint32_t *>(pk->brk.ptr), stream));
     if (!ctx->probe_host) {
         HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->probe_host), 64, hipHostMallocDefault));
         ctx->probe_host[0] = 0;
@@ -240,11 +241,14 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             mpk->pa.nvalid = pk->d_nvalid;
             mpk->pm.tile_begin = pk->d_tile_begin;
             const size_t lb_bytes = reinterpret_cast<uint8_t *>(pk->d_dirty) - static_cast<uint8_t *>(pk->lookback.ptr);
-            HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (size_t)(3 * (size_t)n_genomes + 2) * 4, ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (size_t)(4 * (size_t)n_genomes + 2) * 4, ctx->stream));
             if (pk->any_multi) {
-                HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, ctx->stream));
-                HIPCHK(ctx, hipMemsetAsync(pk->brk_bytes.ptr, 0, pk->total_brk * 4, ctx->stream));
-                HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, static_cast<uint32_t *>(pk->brk_bytes.ptr),
+                // record starts in BYTE positions: genomes whose records are all equally long (read sets) get theirs computed in
+                // the sketch kernel, the others a bitmap every word of which brk_bytes_kernel writes (no memset).  The
+                // packed-position bitmap of the fallback is cleared only for the genomes that take it (pack_dirty)
+                uint32_t *nonuni = pk->d_dirty + 3 * (size_t)n_genomes + 1;
+                HIPCHK(ctx, launch_rec_uniform(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, ctx->stream));
+                HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, static_cast<uint32_t *>(pk->brk_bytes.ptr),
                                              ctx->stream));
             }
         }
@@ -295,6 +299,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.seq = pk->d_seq;
         sa.brk_bytes = static_cast<const uint32_t *>(pk->brk_bytes.ptr);
         sa.dirty = pk->d_dirty;
+        sa.rec_off = pk->d_rec_off;
+        sa.nonuniform = pk->d_dirty + 3 * (size_t)n_genomes + 1;
         sa.nslow = pk->d_dirty + n_genomes + 1;
         sa.ndel = sa.nslow + n_genomes;
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true));     // ASCII in, exact while nothing is deleted

@@ -30,6 +30,9 @@ struct SketchArgs {
                                   // deleted bytes); [n_genomes] = how many.  Non-direct launches with dirty != NULL run only these
     uint32_t         *nslow;      // [n_genomes] wave-tiles of the direct pass that met deleted bytes (budget: sketch_kernels.hip)
     uint32_t         *ndel;       // [n_genomes] bytes the direct pass deleted in place (surviving bases = nvalid - ndel while !dirty)
+    const uint64_t   *rec_off;    // direct mode: the caller's record offsets (uniform-length genomes derive their record starts from them)
+    const uint32_t   *nonuniform; // direct mode: [n_genomes], 0 = all records of the genome have the same length (rec_uniform_kernel):
+                                  // its record starts are the multiples of that length, no bitmap is made or read for it
     uint32_t         *hll_corner; // NULL or [n_genomes], see FinalizeArgs (genomes whose one work item writes the image itself)
     uint64_t          bitflip;    // xxh3 seed-folded constant (64- or 128-bit variant by algo)
     LayoutDev         lay;
@@ -56,9 +59,15 @@ struct SketchPlan {
 SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
                          bool direct = false);
-// record starts of multi-record format-0 genomes -> args.brk_bytes (zeroed before the launch)
-hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec,
+// nonuniform[g] (zeroed before the launch) != 0 <=> the records of multi-record genome g differ in length
+hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, uint32_t *nonuniform,
+                              hipStream_t stream);
+// record starts of the multi-record format-0 genomes whose records differ in length -> args.brk_bytes; every word of such a
+// genome's bitmap is written (no memset needed), genomes with nonuniform[g] == 0 are left alone
+hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, const uint32_t *nonuniform,
                             uint32_t *brk_bytes, hipStream_t stream);
+// zero the packed-position break bitmap of the genomes the direct pass flagged dirty (the pack kernel ORs into it)
+hipError_t launch_zero_dirty_brk(const GenomeDesc *genomes, const uint32_t *dirty, uint32_t n_genomes, uint32_t *brk, hipStream_t stream);
 
 struct FinalizeArgs {
     const uint8_t  *partials;

@@ -205,6 +205,22 @@ __device__ __forceinline__ uint64_t kmer_valid_mask(uint32_t b0, uint32_t b1, ui
     return kvm & ~lo;
 }
 
+// Equal-length records (rec_uniform_kernel): record starts are the multiples of RL, the genome's first record excepted.
+// Bit i of the result: position pos + i starts a record, i < n_bits <= 96.
+struct Brk96 { uint32_t b0, b1, b2; };
+__device__ __forceinline__ Brk96 uniform_breaks(uint32_t pos, uint32_t RL, uint32_t n_bits)
+{
+    const uint32_t m = pos % RL;
+    uint32_t o = m ? RL - m : 0u;                       // the first record start at or after pos
+    if (pos == 0u && o == 0u) o = RL;                   // (a genome's first record is no barrier)
+    Brk96 b{0u, 0u, 0u};
+    for (; o < n_bits; o += RL) {
+        const uint32_t bit = 1u << (o & 31u);
+        if (o < 32u) b.b0 |= bit; else if (o < 64u) b.b1 |= bit; else b.b2 |= bit;
+    }
+    return b;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // one packed word = 16 k-mer start positions, fully unrolled: 16 independent instruction streams per lane
 // ------------------------------------------------------------------------------------------------------------
@@ -451,7 +467,7 @@ __device__ __forceinline__ uint64_t window_or(uint64_t lo, uint32_t hi32, int n)
 // is hashed iff that start is in J (the others are whole windows the fast path has done).  Returns how many it added.
 template <int ALGO, bool XLOW, class Regs>
 __device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *gseq, uint64_t L, uint64_t pos0, uint64_t J,
-                                               uint64_t starts, const uint32_t *bk, int k, uint64_t bitflip, int p,
+                                               uint64_t starts, const uint32_t *bk, uint32_t RL, int k, uint64_t bitflip, int p,
                                                uint32_t cmask, const CodeTabs ct, uint32_t *dirty)
 {
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -477,7 +493,8 @@ __device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *g
         const uint32_t codes = ascii16_to_word(q, bad, ct);      // byte j -> bits 31-2j..30-2j
         uint32_t ok = ~inv16(q) & ((1u << nb) - 1u);
         uint32_t brk = 0;
-        if (bk) {
+        if (RL) brk = uniform_breaks((uint32_t)pos, RL, 16u).b0;          // equal-length records: starts are multiples of RL
+        else if (bk) {
             const uint64_t two = ((uint64_t)bk[(pos >> 5) + 1] << 32) | bk[pos >> 5];
             brk = (uint32_t)(two >> (pos & 31)) & 0xFFFFu;
         }
@@ -557,7 +574,14 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     // A genome with a single record has no interior record boundary: its lanes read three always-zero words (one
     // L1-resident line) instead of streaming 1/8 B per base of break bitmap from HBM.  No branch, no second loop.
     const bool multi_rec = gd.format != 0u || gd.rec_end - gd.rec_begin > 1;
-    const uint32_t *__restrict__ bk = multi_rec ? (DIRECT ? a.brk_bytes : a.brk) + gd.brk_off : a.zero_words;
+    // direct mode, all records of the genome equally long (a FASTQ read set; rec_uniform_kernel): record starts are the multiples
+    // of RL — computed per lane and tile instead of read from a bitmap that then need not exist
+    uint32_t RL = 0;
+    if constexpr (DIRECT) {
+        if (multi_rec && gd.format == 0u && a.nonuniform[it.genome] == 0u) RL = (uint32_t)(a.rec_off[gd.rec_begin + 1] - a.rec_off[gd.rec_begin]);
+    }
+    const bool use_bitmap = multi_rec && RL == 0u;
+    const uint32_t *__restrict__ bk = use_bitmap ? (DIRECT ? a.brk_bytes : a.brk) + gd.brk_off : a.zero_words;
     const uint8_t *__restrict__ gseq = DIRECT ? a.seq + gd.byte_off : nullptr;
     uint32_t *const dirty = DIRECT ? a.dirty + it.genome : nullptr;
     KParams kp;
@@ -600,7 +624,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             t.c4 = w[w0 + 4];                                             // look-ahead (same or next cache line)
             t.c5 = (KMODE == KM_GT16) ? w[w0 + 5] : 0u;
         }
-        const uint32_t bi = multi_rec ? w0 >> 1 : 0u;                     // (w0 * 16) / 32
+        const uint32_t bi = use_bitmap ? w0 >> 1 : 0u;                    // (w0 * 16) / 32
         t.b0 = bk[bi]; t.b1 = bk[bi + 1]; t.b2 = bk[bi + 2];
     };
     TileRegs nxt;
@@ -643,7 +667,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     if constexpr (KMODE == KM_GT16) c5 = t.w[5];
                     bad |= t.bad;
                 }
-                kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
+                if (RL) { const Brk96 ub = uniform_breaks((uint32_t)pos0, RL, 96u); kv = kmer_valid_mask(ub.b0, ub.b1, ub.b2, pos0, nk, k); }
+                else kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
             }
             if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull) {
                 // bytes outside the alphabet in this wave's tile: handled in place while the genome stays within its
@@ -677,7 +702,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 }
                 if (nd && part == 0u) atomicAdd(a.ndel + it.genome, nd);         // (the passes of a partitioned table see the same bytes)
                 if (junc)                                                      // (here, not after the hashing: nothing of it stays live)
-                    my_kmers += junction_walk<ALGO, XLOW, Regs>(regs, gseq, L, pos0, junc, jstarts, multi_rec ? bk : nullptr, k, kp.bitflip, p,
+                    my_kmers += junction_walk<ALGO, XLOW, Regs>(regs, gseq, L, pos0, junc, jstarts, use_bitmap ? bk : nullptr, RL, k, kp.bitflip, p,
                                                                 cmask, ctabs, dirty);
             }
         } else if (active) {
@@ -1008,51 +1033,108 @@ hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_
     return direct ? launch_algo<true, false>(plan, args, n_items, stream) : launch_algo<false, false>(plan, args, n_items, stream);
 }
 
-// one thread per record: the first byte of every record but a genome's first is a k-mer barrier (utils.rs:457-464).
-// Record offsets ascend, so the records whose bits share a 32-bit word are consecutive: the first of them ("head": the
-// record before it lands in another word) gathers the bits of its followers and writes the word with ONE plain store —
-// no atomics (20 M fire-and-forget atomicOr for a 3 Gbp read set took 0.29 ms, 8 % of the step).
-__global__ void __launch_bounds__(256) brk_bytes_kernel(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes,
-                                                        uint32_t *brk_bytes)
+// Are all records of a genome the same length (a FASTQ read set)?  Then record starts are the multiples of that length and the
+// sketch kernel derives them arithmetically: no bitmap to make (brk_bytes_kernel: 6 % of a reads-shaped step), to clear or to read
+// (0.125 B per base).  One thread per record compares its length with the genome's first record's.
+__global__ void __launch_bounds__(256) rec_uniform_kernel(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes,
+                                                          uint32_t *nonuniform)
 {
     for (uint32_t g = blockIdx.y; g < n_genomes; g += gridDim.y) {
         const GenomeDesc gd = genomes[g];
         if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
+        const uint64_t len0 = rec_off[gd.rec_begin + 1] - rec_off[gd.rec_begin];
+        if (len0 == 0 || len0 > 0xFFFFFFFFull) { if (blockIdx.x == 0 && threadIdx.x == 0) nonuniform[g] = 1u; continue; }
+        bool differs = false;
+        for (uint64_t r = gd.rec_begin + 1 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < gd.rec_end; r += (uint64_t)gridDim.x * blockDim.x)
+            differs = differs || rec_off[r + 1] - rec_off[r] != len0;
+        if (differs) nonuniform[g] = 1u;                                 // (same value from every writer)
+    }
+}
+
+// one thread per record: the first byte of every record but a genome's first is a k-mer barrier (utils.rs:457-464).
+// Record offsets ascend, so the records whose bits share a 32-bit word are consecutive: the first of them ("head": the
+// record before it lands in another word) gathers the bits of its followers, writes the word with ONE plain store and zeroes
+// the words up to the next head's — every word of the genome's bitmap is written exactly once: no atomics (20 M atomicOr for a
+// 3 Gbp read set took 0.29 ms, 8 % of the step), no memset.
+__global__ void __launch_bounds__(256) brk_bytes_kernel(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes,
+                                                        const uint32_t *nonuniform, uint32_t *brk_bytes)
+{
+    for (uint32_t g = blockIdx.y; g < n_genomes; g += gridDim.y) {
+        const GenomeDesc gd = genomes[g];
+        if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
+        if (nonuniform && nonuniform[g] == 0u) continue;                  // equal-length records: nobody reads this genome's bitmap
+        const uint64_t n_words = (gd.byte_len + 1 + 31) / 32 + 4;        // (+3 words of look-ahead in kmer_valid_mask)
+        uint32_t *bm = brk_bytes + gd.brk_off;
+        // in-genome record starts: positions < byte_len (empty records at the genome's end start at byte_len: no barrier)
+        auto pos_of = [&](uint64_t r) { return rec_off[r] - gd.byte_off; };
         for (uint64_t r = gd.rec_begin + 1 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < gd.rec_end;
              r += (uint64_t)gridDim.x * blockDim.x) {
-            const uint64_t pos = rec_off[r] - gd.byte_off;
-            if (pos >= gd.byte_len) continue;                           // (empty records at the genome's end)
-            const uint64_t word = pos >> 5;
-            uint32_t bits = 1u << (pos & 31);
-            if (r > gd.rec_begin + 1 && ((rec_off[r - 1] - gd.byte_off) >> 5) == word) {
-                // a follower.  Heads look at most 32 records ahead (runs of empty records can put any number of starts into
-                // one word); a follower beyond that reach — and then its head too — falls back to the atomic.
-                if (r >= gd.rec_begin + 33 && ((rec_off[r - 32] - gd.byte_off) >> 5) == word) atomicOr(brk_bytes + gd.brk_off + word, bits);
+            const uint64_t pos = pos_of(r);
+            if (pos >= gd.byte_len) {                                     // nothing to mark; the first such record finishes the bitmap
+                if (r == gd.rec_begin + 1 || pos_of(r - 1) < gd.byte_len) {
+                    const uint64_t from = r == gd.rec_begin + 1 ? 0 : (pos_of(r - 1) >> 5) + 1;
+                    for (uint64_t w = from; w < n_words; ++w) bm[w] = 0u;
+                }
                 continue;
             }
-            const uint64_t q_end = gd.rec_end < r + 32 ? gd.rec_end : r + 32;
-            uint64_t q = r + 1;
-            for (; q < q_end; ++q) {
-                const uint64_t pq = rec_off[q] - gd.byte_off;
-                if ((pq >> 5) != word || pq >= gd.byte_len) break;
+            const uint64_t word = pos >> 5;
+            if (r > gd.rec_begin + 1 && (pos_of(r - 1) >> 5) == word) continue;      // a follower
+            if (r == gd.rec_begin + 1) for (uint64_t w = 0; w < word; ++w) bm[w] = 0u; // before the first record start
+            uint32_t bits = 1u << (pos & 31);
+            uint64_t q = r + 1, next_word = n_words;
+            for (; q < gd.rec_end; ++q) {
+                const uint64_t pq = pos_of(q);
+                if (pq >= gd.byte_len) break;
+                if ((pq >> 5) != word) { next_word = pq >> 5; break; }
                 bits |= 1u << (pq & 31);
             }
-            const bool reach_exceeded = q == r + 32 && q < gd.rec_end && ((rec_off[q] - gd.byte_off) >> 5) == word;
-            if (reach_exceeded) atomicOr(brk_bytes + gd.brk_off + word, bits);
-            else brk_bytes[gd.brk_off + word] = bits;
+            bm[word] = bits;
+            for (uint64_t w = word + 1; w < next_word; ++w) bm[w] = 0u;
         }
     }
 }
 
-hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec,
-                            uint32_t *brk_bytes, hipStream_t stream)
+// the packed-position bitmap of the genomes the direct pass gave up on (pack_lookback_kernel ORs record starts into it)
+__global__ void __launch_bounds__(256) zero_dirty_brk_kernel(const GenomeDesc *genomes, const uint32_t *dirty, uint32_t n_genomes, uint32_t *brk)
 {
-    if (n_genomes == 0) return hipSuccess;
+    for (uint32_t g = blockIdx.y; g < n_genomes; g += gridDim.y) {
+        if (dirty[g] == 0u) continue;
+        const GenomeDesc gd = genomes[g];
+        if (gd.format == 0u && gd.rec_end - gd.rec_begin <= 1) continue;
+        const uint64_t n_words = (gd.byte_len + 1 + 31) / 32 + 4;
+        for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) brk[gd.brk_off + w] = 0u;
+    }
+}
+
+static dim3 per_record_grid(uint32_t n_genomes, uint64_t n_rec)
+{
     // x: enough 256-thread blocks per genome for ~4 records per thread (a read set is one genome with millions of records)
     const uint64_t per_genome = n_rec / n_genomes + 1;
     const uint32_t gx = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(8, per_genome / 1024 + 1));
-    hipLaunchKernelGGL(brk_bytes_kernel, dim3(gx, n_genomes < 65535u ? n_genomes : 65535u), dim3(256), 0, stream, genomes,
-                       rec_off, n_genomes, brk_bytes);
+    return dim3(gx, n_genomes < 65535u ? n_genomes : 65535u);
+}
+
+hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, uint32_t *nonuniform,
+                              hipStream_t stream)
+{
+    if (n_genomes == 0) return hipSuccess;
+    hipLaunchKernelGGL(rec_uniform_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform);
+    return hipGetLastError();
+}
+
+hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, const uint32_t *nonuniform,
+                            uint32_t *brk_bytes, hipStream_t stream)
+{
+    if (n_genomes == 0) return hipSuccess;
+    hipLaunchKernelGGL(brk_bytes_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform, brk_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_dirty_brk(const GenomeDesc *genomes, const uint32_t *dirty, uint32_t n_genomes, uint32_t *brk, hipStream_t stream)
+{
+    if (n_genomes == 0) return hipSuccess;
+    const uint32_t gy = std::min(n_genomes, 512u), gx = std::max(8u, std::min(1024u, 4096u / gy));
+    hipLaunchKernelGGL(zero_dirty_brk_kernel, dim3(gx, gy), dim3(256), 0, stream, genomes, dirty, n_genomes, brk);
     return hipGetLastError();
 }
 
