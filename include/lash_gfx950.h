@@ -46,6 +46,12 @@ extern "C" {
 #define LASH_F_HMH_X_LOW   1u  /* SURVEY App. D switch U1: take x (bucket, lz) from the LOW 64 bits of xxh3_128
                                   (per call; OR-ed with the context layout's hmh_x_low) */
 #define LASH_F_ACCUMULATE  2u  /* out_images already hold sketches of the same algo/p: union the new ones in */
+#define LASH_F_AMINO       8u  /* the amino-acid branch of sketch_files (utils.rs:511-563; `aa`, which main.rs:198 hard-wires to false and
+                                  whose --aa flag is commented out at main.rs:97-104): records are upper-cased, records whose RAW
+                                  length is below k skipped, every byte outside the 20 residue letters deleted (filter_out_a,
+                                  utils.rs:43-55), 5-bit codes, k 1..=12 (utils.rs:554 panics above), no reverse complement,
+                                  mask_aa_bits (utils.rs:66-76), add_kmer as for nucleotides.  lash_sketch_batch[_async/_device] and
+                                  lash_sketch_files_raw (host parse); the packed / raw-device entries return LASH_EINVAL */
 #define LASH_F_NO_DIRECT   4u  /* lash_sketch_batch[_device]: always pack first.  By default the sketch kernel first reads
                                   the record bytes itself, which is exact while a genome holds only upper-case ACGT
                                   (filter_out_n, utils.rs:33-41, deletes nothing); genomes where it meets anything else
@@ -87,7 +93,9 @@ typedef struct {
                                      records before it stand, nothing after it is seen.  1: the iterator goes on — the malformed
                                      record is dropped, reading resumes at the next line that starts with '@' and whose line
                                      after next starts with '+'.  tools/ref_probe carries two such files                  0 */
-    uint8_t reserved[7];      /*     zero */
+    uint8_t aa_code_zero_based; /* U7 amino-acid sketches (LASH_F_AMINO): kmerutils' 5-bit residue codes over "ACDEFGHIKLMNPQRSTVWY" in
+                                     that order — 0: A = 1 ... Y = 20, 1: A = 0 ... Y = 19                                  0 */
+    uint8_t reserved[6];      /*     zero */
 } lash_layout;                /* 40 bytes */
 
 /* Sums over every sketch call since lash_ctx_enable_timing(ctx, 1) (HIP events on the ctx stream). */
@@ -133,7 +141,7 @@ size_t      lash_sketch_image_bytes(int algo, int p);      /* bytes S::save writ
 void        lash_layout_default(lash_layout *out);
 int         lash_layout_check(const lash_layout *lay);     /* LASH_OK or LASH_EINVAL */
 /* "key=value,..." on top of the default: codes=ACGT (the four letters in code order) kmer=msb|lsb hmh_x=high|low
- * hmh_reg=le|be hll_bucket=low|high hmh_hdr= hll_hdr=azspl ull_hdr=l fastq_err=stop|skip.  NULL / "" = the default. */
+ * hmh_reg=le|be hll_bucket=low|high hmh_hdr= hll_hdr=azspl ull_hdr=l fastq_err=stop|skip aa_codes=one|zero.  NULL / "" = the default. */
 int         lash_layout_parse(const char *spec, lash_layout *out);
 size_t      lash_layout_header_bytes(const lash_layout *lay, int algo);
 size_t      lash_layout_image_bytes(const lash_layout *lay, int algo, int p);   /* lay NULL = default; 0 if invalid */

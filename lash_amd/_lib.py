@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx95
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE, EFORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 HMH, HLL, ULL = 0, 1, 2
-F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT = 1, 2, 4
+F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT, F_AMINO = 1, 2, 4, 8
 FMT_FASTA, FMT_FASTQ = 1, 2
 ABI_VERSION = 3
 
@@ -25,7 +25,7 @@ class Layout(C.Structure):
     _fields_ = [("base_code", C.c_uint8 * 4), ("kmer_lsb_first", C.c_uint8), ("hmh_x_low", C.c_uint8),
                 ("hmh_reg_be", C.c_uint8), ("hll_bucket_high", C.c_uint8),
                 ("hmh_header", C.c_char * 8), ("hll_header", C.c_char * 8), ("ull_header", C.c_char * 8),
-                ("fastq_skip_bad", C.c_uint8), ("reserved", C.c_uint8 * 7)]
+                ("fastq_skip_bad", C.c_uint8), ("aa_code_zero_based", C.c_uint8), ("reserved", C.c_uint8 * 6)]
 
 
 class Timing(C.Structure):

@@ -46,6 +46,7 @@ void usage()
             "  -a, --algorithm <algorithm>  HyperMinHash (hmh), UltraLogLog (ull), or HyperLogLog (hll) [default: hmh]\n"
             "  -p, --precision <precision>  Specifiy precision, for ull and hll only. [default: 10]\n"
             "  -s, --seed <seed>            Random seed [default: 42]\n"
+            "      --aa                     Amino acid sketching (k 1-12); the reference carries this flag commented out\n"
             "      --gpus <n> | --device <d> | --devices <d,d,...>  GPUs to use, one worker each [default: device 0]\n"
             "dist options:\n"
             "  -q, --query <prefix>  -r, --reference <prefix>  -o, --output_file <name> [default: dist]\n"
@@ -98,7 +99,7 @@ int cmd_sketch(int argc, char **argv)
     std::string err;
     const std::map<std::string, std::string> alias = {{"f", "file"}, {"o", "output"}, {"k", "kmer"}, {"t", "threads"},
                                                       {"a", "algorithm"}, {"p", "precision"}, {"s", "seed"}};
-    if (!parse(argc, argv, 2, alias, {"hmh-x-low"}, a, err)) { fprintf(stderr, "error: %s\n", err.c_str()); return 2; }
+    if (!parse(argc, argv, 2, alias, {"hmh-x-low", "aa"}, a, err)) { fprintf(stderr, "error: %s\n", err.c_str()); return 2; }
     if (!a.kv.count("file")) { fprintf(stderr, "error: the following required arguments were not provided:\n  --file <file>\n"); return 2; }
     SketchOptions opt;
     const std::string output = a.kv.count("output") ? a.kv["output"] : "sketch";
@@ -118,13 +119,15 @@ int cmd_sketch(int argc, char **argv)
     else if (alg == "ull") opt.algo = LASH_ULL;
     else { fprintf(stderr, "Algorithm must be either hmh, ull, or hll\n"); return 101; }      // main.rs:245 panic
     if (k < 1 || k > 32) { fprintf(stderr, "k-mer length must be 1-32\n"); return 101; }       // utils.rs:501 panic
+    const bool amino = a.flags.count("aa") != 0;                                               // main.rs:97-104 (commented out there)
+    if (amino && k > 12) { fprintf(stderr, "k-mer length for amino acid must be 1\xe2\x80\x93" "12\n"); return 101; }   // utils.rs:554 panic
     opt.k = (int)k;
     opt.precision = (int)p;
     opt.seed = seed;
     opt.threads = (int)std::max<uint64_t>(1, threads);
     opt.batch_bytes = std::max<uint64_t>(1, batch_mb) << 20;
     opt.stream_bytes = std::max<uint64_t>(1, stream_mb) << 20;
-    opt.flags = a.flags.count("hmh-x-low") ? LASH_F_HMH_X_LOW : 0;
+    opt.flags = (a.flags.count("hmh-x-low") ? LASH_F_HMH_X_LOW : 0) | (amino ? LASH_F_AMINO : 0);
     err = layout_from_option(a.kv.count("layout") ? a.kv["layout"] : "", opt.layout);
     if (!err.empty()) { fprintf(stderr, "error: %s\n", err.c_str()); return 2; }
     if (a.kv.count("devices")) {                              // explicit worker list, e.g. 0,1,2,3 (repeats allowed: 0,0 = two workers on GPU 0)
@@ -147,7 +150,7 @@ int cmd_sketch(int argc, char **argv)
     SketchStats st;
     err = sketch_files(opt, files, output, &st);
     if (!err.empty()) { fprintf(stderr, "Error: %s\n", err.c_str()); return 1; }
-    err = write_parameters_json(output, alg, opt.k, opt.precision, opt.seed);
+    err = write_parameters_json(output, alg, opt.k, opt.precision, opt.seed, amino);
     if (!err.empty()) { fprintf(stderr, "Error: %s\n", err.c_str()); return 1; }
     fprintf(stderr, "sketched %llu files (%.3f GB of FASTA/FASTQ text) in %.2f s on %zu GPU(s), %llu batches\n",
             (unsigned long long)st.files, st.bytes / 1e9, st.seconds, opt.devices.size(), (unsigned long long)st.batches);

@@ -53,13 +53,13 @@ std::string read_list_file(const std::string &path, std::vector<std::string> &fi
 }
 
 std::string write_parameters_json(const std::string &output_name, const std::string &algorithm, int k, int precision,
-                                  uint64_t seed)
+                                  uint64_t seed, bool amino)
 {
     std::map<std::string, std::string> kv;
     kv["k"] = std::to_string(k);
     kv["algorithm"] = algorithm;
     kv["seed"] = std::to_string(seed);
-    kv["molecule"] = "nucleotide";                                        // aa is hard-wired false (main.rs:198)
+    kv["molecule"] = amino ? "amino_acid" : "nucleotide";                 // main.rs:248-252 (the reference hard-wires aa = false, main.rs:198)
     if (algorithm == "ull" || algorithm == "hll") kv["precision"] = std::to_string(precision);
     std::ofstream out(output_name + "_parameters.json", std::ios::binary);
     if (!out) return "cannot create " + output_name + "_parameters.json";
@@ -382,6 +382,7 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
         t0 = now();
         std::vector<uint8_t> carry;
         size_t cut = eof ? have : find_cut(b, have, fmt, carry);
+        if ((prm0.flags & LASH_F_AMINO) && !carry.empty()) { result = "a protein record larger than a --stream-mb chunk: " + path; break; }
         if (!eof && cut == 0) { result = "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path; break; }
         bool stop_here = false;
         if (fmt == LASH_FMT_FASTQ) {                      // the chunk starts and ends at record boundaries: validate it whole

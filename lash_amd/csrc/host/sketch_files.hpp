@@ -26,7 +26,7 @@ struct SketchOptions {
     uint64_t batch_bytes = 1ull << 26;   // file bytes per GPU batch (page-locking a buffer costs ~0.18 s per GB)
     uint64_t stream_bytes = 1ull << 30;  // files larger than this (compressed: > 1/3 of it on disk) are streamed in chunks
                                          // of this size with on-device accumulation (BASELINE configs[4]); < 4 GiB
-    uint32_t flags = 0;              // LASH_F_HMH_X_LOW
+    uint32_t flags = 0;              // LASH_F_HMH_X_LOW, LASH_F_AMINO (--aa)
     lash_layout layout;              // set by layout_from_option(); every context gets it
     SketchOptions() { lash_layout_default(&layout); }
 };
@@ -45,7 +45,7 @@ std::string read_list_file(const std::string &path, std::vector<std::string> &fi
 
 // main.rs:248-276
 std::string write_parameters_json(const std::string &output_name, const std::string &algorithm, int k, int precision,
-                                  uint64_t seed);
+                                  uint64_t seed, bool amino = false);
 
 // where a streamed chunk ends (0 = no boundary found) and the bytes the next chunk must start with (tests)
 size_t stream_find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry);

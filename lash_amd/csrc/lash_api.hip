@@ -356,6 +356,115 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     return LASH_OK;
 }
 
+// The amino-acid branch (LASH_F_AMINO; utils.rs:511-563): no pack stage — a lane of aa_sketch_kernel reads a record's bytes itself.
+// Work items are ranges of a genome's records; partials and finalize as for nucleotides.
+int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
+              const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes, uint8_t *d_out_images)
+{
+    int rc;
+    if ((rc = timing_begin(ctx))) return rc;
+    EvSet *ev = ctx->cur_ev;
+    const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
+    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false);
+    const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
+    std::vector<GenomeDesc> descs(n_genomes, GenomeDesc{});
+    std::vector<WorkItem> items;
+    std::vector<uint32_t> item_begin(n_genomes + 1, 0);
+    uint32_t max_slices = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        if (genome_rec_off[g + 1] < genome_rec_off[g] || genome_rec_off[g + 1] > n_rec) return LASH_EINVAL;
+        GenomeDesc &d = descs[g];
+        d.byte_off = genome_byte_off[g];
+        d.byte_len = genome_byte_off[g + 1] - genome_byte_off[g];
+        d.rec_begin = genome_rec_off[g];
+        d.rec_end = genome_rec_off[g + 1];
+        item_begin[g] = (uint32_t)items.size();
+        const uint64_t nr = d.rec_end - d.rec_begin;
+        if (nr > 0xFFFFFFFFull) return LASH_ELIMIT;
+        uint32_t s = 0;
+        for (uint64_t r0 = 0; r0 < nr; r0 += AA_RECORDS_PER_ITEM, ++s)
+            for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)
+                items.push_back(WorkItem{g, (uint32_t)r0, (uint32_t)std::min<uint64_t>(nr, r0 + AA_RECORDS_PER_ITEM), (s & 0x7FFFu) | (part << 16)});
+        max_slices = std::max(max_slices, s);
+    }
+    item_begin[n_genomes] = (uint32_t)items.size();
+    const uint32_t n_items = (uint32_t)items.size();
+    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + 1) * plan.partial_stride))) return rc;
+    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
+    if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
+    std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0}, {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0},
+                                {descs.data(), descs.size() * sizeof(GenomeDesc), 0}};
+    const size_t total = layout_sections(sec);
+    if ((rc = reserve(ctx, ctx->items, total + 256))) return rc;
+    if ((rc = upload_sections(ctx, ctx->items.ptr, sec, total, ctx->stream))) return rc;
+    uint8_t *tb = static_cast<uint8_t *>(ctx->items.ptr);
+    if (!ctx->counter_zeroed) {
+        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));
+        ctx->counter_zeroed = true;
+    }
+    if (!plan.use_lds && n_items) HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n_items * plan.nreg32 * 4, ctx->stream));
+    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
+    SketchArgs sa{};
+    sa.seq = d_seq;
+    sa.rec_off = d_rec_off;
+    sa.genomes = reinterpret_cast<const GenomeDesc *>(tb + sec[2].off);
+    sa.items = reinterpret_cast<const WorkItem *>(tb + sec[0].off);
+    sa.partials = static_cast<uint8_t *>(ctx->partials.ptr);
+    sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
+    sa.item_kmers = static_cast<uint32_t *>(ctx->item_kmers.ptr);
+    sa.images = d_out_images;
+    sa.image_bytes = image_bytes;
+    const double alpha = hll_alpha(prm->p);
+    memcpy(&sa.alpha_bits, &alpha, 8);
+    sa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
+    sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
+    sa.lay = layout_dev(ctx->layout, prm->algo);
+    sa.partial_stride = plan.partial_stride;
+    sa.nreg32 = plan.nreg32 >> plan.parts_log2;
+    sa.k = prm->k;
+    sa.p = prm->p;
+    ctx->hll_flags_n = 0;
+    if (prm->algo == LASH_HLL) {
+        if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
+        sa.hll_corner = static_cast<uint32_t *>(ctx->hll_flags.ptr);
+        ctx->hll_flags_n = n_genomes;
+    }
+    HIPCHK(ctx, launch_sketch_aa(plan, sa, n_items, ctx->stream));
+    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
+    FinalizeArgs fa{};
+    fa.partials = static_cast<const uint8_t *>(ctx->partials.ptr);
+    fa.items = sa.items;
+    fa.genome_item_begin = reinterpret_cast<const uint32_t *>(tb + sec[1].off);
+    fa.nvalid = nullptr;                                           // every item is live
+    fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
+    fa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
+    fa.images = d_out_images;
+    fa.partial_stride = plan.partial_stride;
+    fa.partial_base_off = 0;
+    fa.image_bytes = image_bytes;
+    memcpy(&fa.alpha_bits, &alpha, 8);
+    fa.algo = prm->algo;
+    fa.p = prm->p;
+    fa.k = prm->k;
+    fa.accumulate = sa.accumulate;
+    fa.parts_log2 = plan.parts_log2;
+    fa.lay = sa.lay;
+    fa.src_images = 0;
+    fa.hll_corner = sa.hll_corner;
+    fa.group = 0;
+    if (max_slices > 32u && n_genomes <= 65535u)
+        for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
+    HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
+    HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
+    if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
+    ctx->cur_ev = nullptr;
+    ctx->last.sketch_launches += n_items ? 1 : 0;
+    ctx->last.sketch_workgroups = n_items;
+    return LASH_OK;
+}
+
 }  // namespace
 
 // ===============================================================================================================
@@ -401,6 +510,7 @@ int lash_params_check(const lash_params *prm)
 {
     if (!prm) return LASH_EINVAL;
     if (prm->k < 1 || prm->k > 32) return LASH_EINVAL;                    // utils.rs:500-502
+    if ((prm->flags & LASH_F_AMINO) && prm->k > 12) return LASH_EINVAL;   // utils.rs:554: "k-mer length for amino acid must be 1-12"
     switch (prm->algo) {
     case LASH_HMH: return LASH_OK;                                        // precision ignored, main.rs:212-213
     case LASH_HLL: return (prm->p >= 4 && prm->p <= 16) ? LASH_OK : LASH_EINVAL;
@@ -469,6 +579,7 @@ int lash_layout_parse(const char *spec, lash_layout *out)
         else if (key == "hll_hdr") ok = hdr(lay.hll_header);
         else if (key == "ull_hdr") ok = hdr(lay.ull_header);
         else if (key == "fastq_err") ok = two("stop", "skip", lay.fastq_skip_bad);
+        else if (key == "aa_codes") ok = two("one", "zero", lay.aa_code_zero_based);
         else ok = false;
         if (!ok) return LASH_EINVAL;
     }
@@ -705,6 +816,7 @@ int lash_sketch_packed_device(lash_ctx *ctx, const lash_params *prm, const lash_
     if (!ctx || !pk || (pk->n_genomes && !d_out_images)) return LASH_EINVAL;
     int rc = lash_params_check(prm);
     if (rc) return rc;
+    if (prm->flags & LASH_F_AMINO) return LASH_EINVAL;                   // packed genomes are 2-bit nucleotides
     (void)hipSetDevice(ctx->device);
     if ((rc = timing_begin(ctx))) return rc;
     ctx->last_packed.clear();
@@ -723,6 +835,7 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     ctx->last_packed.clear();
     ctx->last.calls += 1;
     if (n_genomes == 0) return LASH_OK;
+    if (prm->flags & LASH_F_AMINO) return sketch_aa(ctx, prm, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, n_genomes, d_out_images);
 
     // One packed batch, one stream.  Packing chunk c+1 on a second stream while chunk c is sketched was measured and
     // rejected (DESIGN.md "Rejected"): the pack workgroups' LDS fragments the CU's 160 KiB so that only one 64 KiB
@@ -819,6 +932,7 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
     if (!ctx || (n_files && (!d_out_images || !file_off || !file_fmt))) return LASH_EINVAL;
     int rc = lash_params_check(prm);
     if (rc) return rc;
+    if (prm->flags & LASH_F_AMINO) return LASH_EINVAL;                   // the device-side parse feeds the nucleotide pack stage only
     (void)hipSetDevice(ctx->device);
     if (ctx->raw_files_pending) {                                // flags of an earlier raw call nobody has looked at yet
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -978,6 +1092,20 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     (void)hipSetDevice(ctx->device);
     const uint64_t bytes = file_off[n_files];
     if (bytes && !raw) return LASH_EINVAL;
+    if (prm->flags & LASH_F_AMINO) {
+        // protein FASTA / FASTQ: parsed here on the host with needletail's record rules, sketched by the record entry
+        std::vector<uint8_t> seq;
+        std::vector<uint64_t> rec_off(1, 0), goff(1, 0);
+        for (uint32_t g = 0; g < n_files; ++g) {
+            const uint8_t *f = raw + file_off[g];
+            const size_t n = (size_t)(file_off[g + 1] - file_off[g]);
+            if (n == 0 || (f[0] != '>' && f[0] != '@')) return LASH_EINVAL;
+            parse_fastx_strict(f, n, &seq, &rec_off, ctx->layout.fastq_skip_bad != 0);
+            goff.push_back(rec_off.size() - 1);
+        }
+        const uint8_t dummy = 0;
+        return lash_sketch_batch(ctx, prm, seq.empty() ? &dummy : seq.data(), rec_off.data(), rec_off.size() - 1, goff.data(), n_files, out_images);
+    }
     const size_t ib = image_bytes(ctx->layout, prm->algo, prm->p), img_bytes = (size_t)n_files * ib;
     if ((rc = reserve(ctx, ctx->st_seq, bytes + 64))) return rc;
     if ((rc = reserve(ctx, ctx->st_img, img_bytes + 64))) return rc;

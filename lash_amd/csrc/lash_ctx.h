@@ -58,7 +58,7 @@ struct HostStage {
     bool pending = false;
 };
 
-const lash_layout kDefaultLayout = {{0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l", 0, {0, 0, 0, 0, 0, 0, 0}};
+const lash_layout kDefaultLayout = {{0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l", 0, 0, {0, 0, 0, 0, 0, 0}};
 
 }  // namespace lashi
 using namespace lashi;
@@ -344,6 +344,7 @@ LayoutDev layout_dev(const lash_layout &lay, int algo)
     d.hmh_reg_be = lay.hmh_reg_be;
     d.kmer_lsb_first = lay.kmer_lsb_first;
     d.hll_bucket_high = lay.hll_bucket_high;
+    d.aa_code_base = lay.aa_code_zero_based ? 0u : 1u;
     return d;
 }
 

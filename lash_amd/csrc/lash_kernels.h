@@ -59,6 +59,10 @@ struct SketchPlan {
 SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
                          bool direct = false);
+// amino-acid sketches (LASH_F_AMINO; utils.rs:511-563): work items are RECORD ranges of a genome (WorkItem::word_begin / word_end =
+// record indices relative to the genome's first), a lane walks one record at a time; args.seq / args.rec_off = the caller's bytes
+hipError_t launch_sketch_aa(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream);
+constexpr uint32_t AA_RECORDS_PER_ITEM = 4096;
 // nonuniform[g] (zeroed before the launch) != 0 <=> the records of multi-record genome g differ in length
 hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, uint32_t *nonuniform,
                               hipStream_t stream);

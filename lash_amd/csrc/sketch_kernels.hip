@@ -521,6 +521,91 @@ __device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *g
     return added;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// end of a work item, shared by the nucleotide and the amino-acid kernel: k-mer census, then the registers leave LDS
+// ------------------------------------------------------------------------------------------------------------
+template <int ALGO, int REGS, class Regs>
+__device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem &it, const Regs &regs, uint32_t *census, uint32_t part,
+                                            uint32_t my_kmers, int p)
+{
+    constexpr bool USE_LDS = REGS != REGS_GLOBAL;
+    // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one store per item
+    Regs::lds_wait();
+    for (int off = 32; off > 0; off >>= 1) my_kmers += __shfl_down(my_kmers, off, 64);
+    if ((threadIdx.x & 63) == 0) census[threadIdx.x >> 6] = my_kmers;
+    if constexpr (!USE_LDS) __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long tot = 0;
+        for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) tot += census[i];
+        a.item_kmers[blockIdx.x] = part == 0u ? (uint32_t)tot : 0u;   // < 2^32 per slice; summed by finalize_kernel (the
+                                                                      // passes of one slice count the same k-mers: once)
+    }
+
+    // flush in image register format (u16 LE for HMH, u8 for HLL / ULL): into this item's partial sketch, or — when the
+    // item is the only one of its genome (ITEM_SOLE: many small genomes) — straight into the genome's image, header
+    // included, so that neither a partial nor a finalize pass is needed for it
+    const bool sole = (it.slice & ITEM_SOLE) != 0u;
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)blockIdx.x * a.partial_stride);
+    uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
+    const uint32_t HDR = a.lay.hdr_bytes, reg_be = ALGO == 0 ? a.lay.hmh_reg_be : 0u;
+    uint32_t *hist = census + 16;                                          // 72 words after the census (HLL header)
+    if constexpr (ALGO == 1) {
+        if (sole) {
+            if (threadIdx.x < 72) hist[threadIdx.x] = 0;
+            __syncthreads();
+        }
+    }
+    auto put = [&](uint32_t i, uint32_t v) {
+        if (!sole) { out[i] = v; return; }
+        uint8_t *dst = img + HDR + 4ull * i;
+        if (a.accumulate) v = merge_word<ALGO>(hmh_img_order(load_u32_any(dst), reg_be), v);
+        store_u32_any(dst, hmh_img_order(v, reg_be));
+        if constexpr (ALGO == 1) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t rho = (v >> (8 * b)) & 0xFFu;
+                atomicAdd(&hist[rho < 71u ? rho : 71u], 1u);
+            }
+        }
+    };
+    if constexpr (ALGO == 0) {
+        for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
+            put(i, regs.get(2 * i) | (regs.get(2 * i + 1) << 16));
+        if (sole && threadIdx.x == 0 && HDR) write_header(img, a.lay.hdr_tpl, a.alpha_bits, HMH_M, 0, 0.0, HMH_P);
+    } else if constexpr (ALGO == 1) {
+        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
+        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
+        for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
+            put(i, regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24));
+        if (sole) {
+            __syncthreads();
+            if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
+        }
+    } else {
+        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
+        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
+        for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t lo = regs.get(8 * i + 2 * b), hi = regs.get(8 * i + 2 * b + 1);
+                uint32_t r = 0;
+                if (lo | hi) {
+                    // hash4j pack(): r = 4 * (index of leading one) + the two bits below it
+                    const uint64_t x = ((uint64_t)hi << 32) | lo;
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(x);
+                    const uint32_t below = top >= 2 ? (uint32_t)(x >> (top - 2)) & 3u : (uint32_t)(x << (2 - top)) & 3u;
+                    r = (top << 2) | below;
+                }
+                o |= r << (8 * b);
+            }
+            put(i, o);
+        }
+        if (sole && threadIdx.x == 0) write_header(img, a.lay.hdr_tpl, a.alpha_bits, 1ull << p, 0, 0.0, p);   // switch U4
+    }
+}
+
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT = false>
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
@@ -748,80 +833,102 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         }
     }
 
-    // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one store per item
-    Regs::lds_wait();
-    for (int off = 32; off > 0; off >>= 1) my_kmers += __shfl_down(my_kmers, off, 64);
-    if ((threadIdx.x & 63) == 0) census[threadIdx.x >> 6] = my_kmers;
-    if constexpr (!USE_LDS) __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long tot = 0;
-        for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) tot += census[i];
-        a.item_kmers[blockIdx.x] = part == 0u ? (uint32_t)tot : 0u;   // < 2^32 per slice; summed by finalize_kernel (the
-                                                                      // passes of one slice count the same k-mers: once)
-    }
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p);
+}
 
-    // flush in image register format (u16 LE for HMH, u8 for HLL / ULL): into this item's partial sketch, or — when the
-    // item is the only one of its genome (ITEM_SOLE: many small genomes) — straight into the genome's image, header
-    // included, so that neither a partial nor a finalize pass is needed for it
-    const bool sole = (it.slice & ITEM_SOLE) != 0u;
-    uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)blockIdx.x * a.partial_stride);
-    uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
-    const uint32_t HDR = a.lay.hdr_bytes, reg_be = ALGO == 0 ? a.lay.hmh_reg_be : 0u;
-    uint32_t *hist = census + 16;                                          // 72 words after the census (HLL header)
-    if constexpr (ALGO == 1) {
-        if (sole) {
-            if (threadIdx.x < 72) hist[threadIdx.x] = 0;
-            __syncthreads();
+// ------------------------------------------------------------------------------------------------------------
+// amino-acid sketches: the `aa` branch of sketch_files (/root/reference/src/utils.rs:511-563), unreachable in the reference
+// (main.rs:198 hard-wires aa = false).  Per record: upper-case (:521), skip when the RAW length is below k (:523-525), delete every
+// byte outside the 20 residue letters (filter_out_a, utils.rs:43-55), 5 bits per residue in the order "ACDEFGHIKLMNPQRSTVWY"
+// (kmerutils aautils [UNPINNED]: layout.aa_code_zero_based), k-mer = the last k residues, first one most significant,
+// mask_aa_bits (utils.rs:66-76), add_kmer as for nucleotides (utils.rs:395-434).  Proteins are short and many: a LANE walks one
+// record with a rolling register, a workgroup takes a range of a genome's records and shares one sketch in LDS.
+// ------------------------------------------------------------------------------------------------------------
+template <int ALGO, bool XLOW, int REGS>
+__global__ void __launch_bounds__(256) aa_sketch_kernel(SketchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
+    const WorkItem it = a.items[blockIdx.x];
+    const GenomeDesc gd = a.genomes[it.genome];
+    const int k = a.k, p = a.p;
+    constexpr bool USE_LDS = REGS != REGS_GLOBAL;
+    using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type;
+    Regs regs;
+    uint32_t *census;
+    const uint32_t part = it.slice >> 16;
+    if constexpr (USE_LDS) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
+        regs.base = lds_regs;
+        if constexpr (REGS == REGS_LDS_PARTS) {
+            regs.local_mask = a.nreg32 - 1u;
+            regs.part_shift = 31u - (uint32_t)__builtin_clz(a.nreg32);
+            regs.part = part;
         }
-    }
-    auto put = [&](uint32_t i, uint32_t v) {
-        if (!sole) { out[i] = v; return; }
-        uint8_t *dst = img + HDR + 4ull * i;
-        if (a.accumulate) v = merge_word<ALGO>(hmh_img_order(load_u32_any(dst), reg_be), v);
-        store_u32_any(dst, hmh_img_order(v, reg_be));
-        if constexpr (ALGO == 1) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t rho = (v >> (8 * b)) & 0xFFu;
-                atomicAdd(&hist[rho < 71u ? rho : 71u], 1u);
-            }
-        }
-    };
-    if constexpr (ALGO == 0) {
-        for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
-            put(i, regs.get(2 * i) | (regs.get(2 * i + 1) << 16));
-        if (sole && threadIdx.x == 0 && HDR) write_header(img, a.lay.hdr_tpl, a.alpha_bits, HMH_M, 0, 0.0, HMH_P);
-    } else if constexpr (ALGO == 1) {
-        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
-        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
-        for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
-            put(i, regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24));
-        if (sole) {
-            __syncthreads();
-            if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
-        }
+        census = lds_regs + a.nreg32;
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
     } else {
-        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
-        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
-        for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
-            uint32_t o = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t lo = regs.get(8 * i + 2 * b), hi = regs.get(8 * i + 2 * b + 1);
-                uint32_t r = 0;
-                if (lo | hi) {
-                    // hash4j pack(): r = 4 * (index of leading one) + the two bits below it
-                    const uint64_t x = ((uint64_t)hi << 32) | lo;
-                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(x);
-                    const uint32_t below = top >= 2 ? (uint32_t)(x >> (top - 2)) & 3u : (uint32_t)(x << (2 - top)) & 3u;
-                    r = (top << 2) | below;
-                }
-                o |= r << (8 * b);
+        regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;
+        census = lds_regs;
+    }
+    __syncthreads();
+    const uint64_t kmask = (1ull << (5 * k)) - 1ull;                          // mask_aa_bits, k <= 12
+    constexpr uint32_t LETTERS = 0x016FBDFDu;                                  // bit i: 'A' + i is one of ACDEFGHIKLMNPQRSTVWY
+    const uint32_t base = a.lay.aa_code_base;
+    uint32_t my_kmers = 0;
+    for (uint64_t r = gd.rec_begin + it.word_begin + threadIdx.x; r < gd.rec_begin + it.word_end; r += blockDim.x) {
+        const uint64_t b0 = a.rec_off[r], b1 = a.rec_off[r + 1];
+        if (b1 - b0 < (uint64_t)k) continue;                                   // utils.rs:523-525: the raw length
+        uint64_t v = 0;
+        uint32_t have = 0;
+        auto residue = [&](uint32_t c) {
+            c &= ~(((c - 0x61u) < 26u) ? 0x20u : 0u);                          // to_ascii_uppercase
+            const uint32_t idx = c - 0x41u;
+            if (idx >= 26u || !((LETTERS >> idx) & 1u)) return;                // filter_out_a
+            const uint32_t code = (uint32_t)__builtin_popcount(LETTERS & ((1u << idx) - 1u)) + base;
+            v = (v << 5) | code;
+            if (++have >= (uint32_t)k) {
+                const uint64_t m = v & kmask;
+                (void)add_kmer<ALGO, XLOW, false, false>(regs, (uint32_t)m, (uint32_t)(m >> 32), 0xFFFFFFFFu, a.bitflip, p);
+                ++my_kmers;
             }
-            put(i, o);
+        };
+        uint64_t i = b0;
+        for (; i + 16 <= b1; i += 16) {
+            const uint4 q = load16_any(a.seq + i);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) residue((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
         }
-        if (sole && threadIdx.x == 0) write_header(img, a.lay.hdr_tpl, a.alpha_bits, 1ull << p, 0, 0.0, p);   // switch U4
+        for (; i < b1; ++i) residue(a.seq[i]);
+    }
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p);
+}
+
+template <int ALGO, bool XLOW>
+static hipError_t launch_aa_regs(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
+{
+    auto go = [&](auto kern) {
+        if (plan.lds_bytes > 48u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(n), dim3(256), plan.lds_bytes, s, args);
+        return hipGetLastError();
+    };
+    if (plan.use_lds && plan.parts_log2) return go(aa_sketch_kernel<ALGO, XLOW, REGS_LDS_PARTS>);
+    if (plan.use_lds) return go(aa_sketch_kernel<ALGO, XLOW, REGS_LDS>);
+    return go(aa_sketch_kernel<ALGO, XLOW, REGS_GLOBAL>);
+}
+
+hipError_t launch_sketch_aa(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
+{
+    if (n_items == 0) return hipSuccess;
+    switch (plan.algo) {
+    case 0: return plan.x_low ? launch_aa_regs<0, true>(plan, args, n_items, stream) : launch_aa_regs<0, false>(plan, args, n_items, stream);
+    case 1: return launch_aa_regs<1, false>(plan, args, n_items, stream);
+    case 2: return launch_aa_regs<2, false>(plan, args, n_items, stream);
+    default: return hipErrorInvalidValue;
     }
 }
 

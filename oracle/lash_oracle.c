@@ -103,7 +103,7 @@ uint64_t lash_or_mask_bits(uint64_t v, int k)
 /* ------------------------------------------------------------------------------------------
  * The layout: every unverified crate-internal choice as data (lash_oracle.h)
  * ---------------------------------------------------------------------------------------- */
-static const lash_or_layout DEFAULT_LAYOUT = { {0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l", 0, {0} };
+static const lash_or_layout DEFAULT_LAYOUT = { {0, 1, 2, 3}, 0, 0, 0, 0, "", "azspl", "l", 0, 0, {0} };
 static inline const lash_or_layout *lay_of(const lash_or_params *prm) { return prm->layout ? prm->layout : &DEFAULT_LAYOUT; }
 
 void lash_or_layout_default(lash_or_layout *out) { *out = DEFAULT_LAYOUT; }
@@ -446,6 +446,44 @@ static void scratch_free(scratch_t *sc) { free(sc->filt); free(sc->packed); mems
 static int sketch_genome_with(const lash_or_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
                               uint8_t *image, scratch_t *sc);
 
+/* ------------------------------------------------------------------------------------------
+ * The amino-acid branch (utils.rs:511-563; unreachable in the reference: main.rs:198 hard-wires aa = false, the --aa flag is
+ * commented out at main.rs:97-104).  Per record: seq().to_ascii_uppercase() (:521); records whose RAW length is below k are
+ * skipped (:523-525, BEFORE the filter, unlike the nucleotide branch); filter_out_a keeps the 20 residue letters
+ * (utils.rs:43-55); kmerutils' SequenceAA / KmerAA32bit (k <= 6) / KmerAA64bit (k <= 12) [UNPINNED: 5 bits per residue,
+ * codes per layout.aa_code_zero_based, k-mer built by shift-left-and-OR so the first residue is most significant, no
+ * k-mer when fewer than k residues survive]; mask_aa_bits (utils.rs:66-76); add_kmer as for nucleotides.
+ * ---------------------------------------------------------------------------------------- */
+static int aa_code(const lash_or_layout *lay, uint8_t c)           /* -1: deleted by filter_out_a */
+{
+    static const char letters[] = "ACDEFGHIKLMNPQRSTVWY";
+    const char *at = c ? strchr(letters, (int)c) : NULL;
+    if (!at) return -1;
+    return (int)(at - letters) + (lay->aa_code_zero_based ? 0 : 1);
+}
+static uint64_t mask_aa_bits(uint64_t v, int k)                    /* utils.rs:66-76 */
+{
+    const unsigned b = 5u * (unsigned)k;
+    if (b == 0) return 0;
+    if (b >= 64) return v;
+    return v & ((1ull << b) - 1ull);
+}
+static void sketch_record_aa(const lash_or_params *prm, const lash_or_layout *lay, const uint8_t *rec, size_t n, kmer_sink sink, void *ctx)
+{
+    const int k = prm->k;
+    if (n < (size_t)k) return;                                      /* utils.rs:523-525: the RAW length */
+    uint64_t v = 0;
+    size_t have = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t c = rec[i];
+        if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);            /* to_ascii_uppercase */
+        const int code = aa_code(lay, c);
+        if (code < 0) continue;                                     /* filter_out_a */
+        v = (v << 5) | (uint64_t)code;                              /* (bits above 5k fall to mask_aa_bits; k <= 12: 60 bits) */
+        if (++have >= (size_t)k) sink(ctx, mask_aa_bits(v, k));
+    }
+}
+
 int lash_or_sketch_genome(const lash_or_params *prm, const uint8_t *seq,
                           const uint64_t *rec_off, uint64_t n_rec, uint8_t *image)
 {
@@ -462,9 +500,11 @@ static int sketch_genome_with(const lash_or_params *prm, const uint8_t *seq, con
     sketch_t s;
     sketch_new(&s, prm);                                         /* utils.rs:454 */
     kmer_sink sink = prm->algo == LASH_OR_HMH ? hmh_add_kmer : prm->algo == LASH_OR_HLL ? hll_add_kmer : ull_add_kmer;
+    if (prm->amino && prm->k > 12) { sketch_free(&s); return -1; }   /* utils.rs:554: panic, k must be 1-12 */
     for (uint64_t r = 0; r < n_rec; r++) {                       /* utils.rs:457 */
         const uint8_t *rec = seq + rec_off[r];
         size_t n = (size_t)(rec_off[r + 1] - rec_off[r]);
+        if (prm->amino) { sketch_record_aa(prm, s.lay, rec, n, sink, &s); continue; }
         scratch_reserve(sc, n);
         size_t m = lash_or_filter_out_n(rec, n, sc->filt);        /* utils.rs:459 */
         if (m >= (size_t)prm->k) {                               /* utils.rs:460-462 */
@@ -587,6 +627,7 @@ typedef struct { const lash_or_params *prm; sketch_t *s; scratch_t *sc; kmer_sin
 
 static void sketch_record(rec_ctx *rc, const uint8_t *rec, size_t n)
 {
+    if (rc->prm->amino) { sketch_record_aa(rc->prm, rc->s->lay, rec, n, rc->sink, rc->s); return; }
     scratch_reserve(rc->sc, n);
     size_t m = lash_or_filter_out_n(rec, n, rc->sc->filt);          /* utils.rs:459 */
     if (m < (size_t)rc->prm->k) return;                             /* utils.rs:460-462 */
@@ -607,7 +648,7 @@ static const uint8_t *line_end(const uint8_t *p, const uint8_t *end)
 
 static int sketch_file_with(const lash_or_params *prm, const uint8_t *buf, uint64_t len, uint8_t *image, scratch_t *sc)
 {
-    if (check_params(prm->algo, prm->k, prm->p) || lash_or_layout_check(lay_of(prm))) return -1;
+    if (check_params(prm->algo, prm->k, prm->p) || lash_or_layout_check(lay_of(prm)) || (prm->amino && prm->k > 12)) return -1;
     if (len == 0 || (buf[0] != '>' && buf[0] != '@')) return -2;    /* parse_fastx_file(..).expect("Invalid input file") */
     sketch_t s;
     sketch_new(&s, prm);

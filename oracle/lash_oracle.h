@@ -53,7 +53,9 @@ typedef struct {
                                  records before it stand, nothing after it is seen.  1 = the iterator goes on: the malformed
                                  record is dropped and reading resumes at the next line that starts with '@' and whose
                                  line after next starts with '+'                                              default 0 */
-    uint8_t reserved[7];      /* zero */
+    uint8_t aa_code_zero_based; /* U7 (amino-acid sketches, utils.rs:511-563): kmerutils' 5-bit residue codes over "ACDEFGHIKLMNPQRSTVWY"
+                                 in that order — 0: A = 1 ... Y = 20 (the crate's match table as recalled), 1: A = 0 ... Y = 19   default 0 */
+    uint8_t reserved[6];      /* zero */
 } lash_or_layout;             /* 40 bytes */
 
 void   lash_or_layout_default(lash_or_layout *out);
@@ -68,6 +70,10 @@ typedef struct {
     uint64_t seed;       /* -s, default 42            (main.rs:88-95)                */
     int hmh_x_is_low;    /* switch U1: 0 => x = high64(xxh3_128), y = low64; OR-ed with layout->hmh_x_low */
     const lash_or_layout *layout;   /* NULL = lash_or_layout_default() */
+    int amino;           /* != 0: the amino-acid branch of sketch_files (utils.rs:511-563; `aa`, hard-wired false at main.rs:198):
+                            records are upper-cased, shorter-than-k RAW records skipped, every byte outside the 20 residue
+                            letters deleted (filter_out_a, utils.rs:43-55), 5-bit codes, k <= 12, no reverse complement,
+                            mask_aa_bits (utils.rs:66-76)                                                   */
 } lash_or_params;
 
 /* XXH3 short-input closed forms (utils.rs:412,428 and inside hyperminhash for :397). */

@@ -18,19 +18,20 @@ class Layout(C.Structure):
     _fields_ = [("base_code", C.c_uint8 * 4), ("kmer_lsb_first", C.c_uint8), ("hmh_x_low", C.c_uint8),
                 ("hmh_reg_be", C.c_uint8), ("hll_bucket_high", C.c_uint8),
                 ("hmh_header", C.c_char * 8), ("hll_header", C.c_char * 8), ("ull_header", C.c_char * 8),
-                ("fastq_skip_bad", C.c_uint8), ("reserved", C.c_uint8 * 7)]
+                ("fastq_skip_bad", C.c_uint8), ("aa_code_zero_based", C.c_uint8), ("reserved", C.c_uint8 * 6)]
 
     def spec(self):
         """the text form lash_layout_parse() takes"""
         order = "".join("ACGT"[list(self.base_code).index(c)] for c in range(4))
-        return ("codes=%s,kmer=%s,hmh_x=%s,hmh_reg=%s,hll_bucket=%s,hmh_hdr=%s,hll_hdr=%s,ull_hdr=%s,fastq_err=%s"
+        return ("codes=%s,kmer=%s,hmh_x=%s,hmh_reg=%s,hll_bucket=%s,hmh_hdr=%s,hll_hdr=%s,ull_hdr=%s,fastq_err=%s%s"
                 % (order, "lsb" if self.kmer_lsb_first else "msb", "low" if self.hmh_x_low else "high",
                    "be" if self.hmh_reg_be else "le", "high" if self.hll_bucket_high else "low",
-                   self.hmh_header.decode(), self.hll_header.decode(), self.ull_header.decode(), "skip" if self.fastq_skip_bad else "stop"))
+                   self.hmh_header.decode(), self.hll_header.decode(), self.ull_header.decode(), "skip" if self.fastq_skip_bad else "stop",
+                   ",aa_codes=zero" if self.aa_code_zero_based else ""))
 
 
 def make_layout(codes="ACGT", kmer="msb", hmh_x="high", hmh_reg="le", hll_bucket="low", hmh_hdr="", hll_hdr="azspl",
-                ull_hdr="l", fastq_err="stop"):
+                ull_hdr="l", fastq_err="stop", aa_codes="one"):
     """codes: the four letters in code order (code 0 first), e.g. "ACGT" (kmerutils hypothesis) or "ACTG"."""
     lay = Layout()
     for code, letter in enumerate(codes):
@@ -41,6 +42,7 @@ def make_layout(codes="ACGT", kmer="msb", hmh_x="high", hmh_reg="le", hll_bucket
     lay.hll_bucket_high = int(hll_bucket == "high")
     lay.hmh_header, lay.hll_header, lay.ull_header = hmh_hdr.encode(), hll_hdr.encode(), ull_hdr.encode()
     lay.fastq_skip_bad = int(fastq_err == "skip")
+    lay.aa_code_zero_based = int(aa_codes == "zero")
     return lay
 
 
@@ -54,7 +56,7 @@ def parse_layout(spec):
 
 class Params(C.Structure):
     _fields_ = [("algo", C.c_int), ("k", C.c_int), ("p", C.c_int), ("seed", C.c_uint64), ("hmh_x_is_low", C.c_int),
-                ("layout", C.POINTER(Layout))]
+                ("layout", C.POINTER(Layout)), ("amino", C.c_int)]
 
 
 def build():
@@ -147,17 +149,17 @@ def default_layout():
     return lay
 
 
-def _params(algo, k, p, seed, hmh_x_is_low, layout):
-    return Params(algo, k, p, seed, hmh_x_is_low, C.pointer(layout) if layout is not None else None)
+def _params(algo, k, p, seed, hmh_x_is_low, layout, amino=False):
+    return Params(algo, k, p, seed, hmh_x_is_low, C.pointer(layout) if layout is not None else None, 1 if amino else 0)
 
 
-def sketch_files(algo, k, p, seed, files_bytes, threads=1, hmh_x_is_low=0, layout=None) -> np.ndarray:
+def sketch_files(algo, k, p, seed, files_bytes, threads=1, hmh_x_is_low=0, layout=None, amino=False) -> np.ndarray:
     """files_bytes: list of uncompressed FASTA/FASTQ file contents -> images[n_files, image_bytes]
     (the oracle's own needletail-like parse + the per-file closure, utils.rs:452-508)."""
     n = len(files_bytes)
     bufs = (C.c_char_p * max(n, 1))(*files_bytes)
     lens = (C.c_uint64 * max(n, 1))(*[len(f) for f in files_bytes])
-    prm = _params(algo, k, p, seed, hmh_x_is_low, layout)
+    prm = _params(algo, k, p, seed, hmh_x_is_low, layout, amino)
     images = np.zeros((n, image_bytes(algo, p, layout)), dtype=np.uint8)
     rc = lib.lash_or_sketch_file_buffers(C.byref(prm), bufs, lens, n, images.ctypes.data, threads)
     if rc != 0:
@@ -166,7 +168,7 @@ def sketch_files(algo, k, p, seed, files_bytes, threads=1, hmh_x_is_low=0, layou
 
 
 def sketch_genomes(algo, k, p, seed, seq: np.ndarray, rec_off: np.ndarray, genome_rec_off: np.ndarray,
-                   threads=1, hmh_x_is_low=0, layout=None) -> np.ndarray:
+                   threads=1, hmh_x_is_low=0, layout=None, amino=False) -> np.ndarray:
     """Returns images[n_genomes, image_bytes] (uint8)."""
     seq = np.ascontiguousarray(seq, dtype=np.uint8)
     if seq.size == 0:
@@ -174,7 +176,7 @@ def sketch_genomes(algo, k, p, seed, seq: np.ndarray, rec_off: np.ndarray, genom
     rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
     genome_rec_off = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
     n_g = len(genome_rec_off) - 1
-    prm = _params(algo, k, p, seed, hmh_x_is_low, layout)
+    prm = _params(algo, k, p, seed, hmh_x_is_low, layout, amino)
     ib = image_bytes(algo, p, layout)
     images = np.zeros((n_g, ib), dtype=np.uint8)
     rc = lib.lash_or_sketch_genomes(C.byref(prm), seq.ctypes.data, rec_off.ctypes.data, genome_rec_off.ctypes.data,

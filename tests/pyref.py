@@ -159,6 +159,34 @@ def ull_sketch(records, k, p, seed, lay=DEFAULT):
     return lay.header("ull", p, 1 << p) + bytes(st)
 
 
+def sketch_from_masked_kmers(algo, p, seed, values, lay=DEFAULT):
+    """the three add_kmer rules (utils.rs:395-434) on a list of masked k-mer values, however they were made (tests/test_amino.py)"""
+    class _L(list):
+        pass
+    if algo == "hmh":
+        regs = [0] * 16384
+        for km in values:
+            lo, hi = xxh3_128_4b(km & 0xFFFFFFFF, seed)
+            x, y = (lo, hi) if lay.x_low else (hi, lo)
+            reg = ((clz64(((x << 14) & M64) ^ 0x3FFF) + 1) << 10) | (y & 0x3FF)
+            if regs[x >> 50] < reg:
+                regs[x >> 50] = reg
+        return lay.header("hmh", 14, 16384) + b"".join(struct.pack(">H" if lay.reg_be else "<H", r) for r in regs)
+    if algo == "hll":
+        m = [0] * (1 << p)
+        for km in values:
+            x = xxh3_64_8b(km, seed)
+            j, w = (x >> (64 - p), x & ((1 << (64 - p)) - 1)) if lay.bucket_high else (x & ((1 << p) - 1), x >> p)
+            m[j] = max(m[j], (64 - p) - w.bit_length() + 1)
+        return lay.header("hll", p, 1 << p, sum(1 for r in m if r == 0), sum(2.0 ** (-r) for r in m)) + bytes(m)
+    st = [0] * (1 << p)
+    for km in values:
+        h = xxh3_64_8b(km, seed)
+        t = (~((~h & M64) << p)) & M64
+        st[h >> (64 - p)] = ull_pack(ull_unpack(st[h >> (64 - p)]) | (1 << (clz64(t) + p - 1)))
+    return lay.header("ull", p, 1 << p) + bytes(st)
+
+
 # ---- dist side: hyperminhash similarity as published by axiomhq/hyperminhash (the crate hyperminhash 0.1.4 ports it)
 # and the Mash-style distance of main.rs:415-423.  [PARITY UNPINNED like every crate-internal rule.]
 import math
