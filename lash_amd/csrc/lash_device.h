@@ -107,15 +107,26 @@ __device__ __forceinline__ void xxh3_128_4b_hmh_fast(uint32_t w, uint64_t bitfli
     xh = __umulhi(h0, m0) + h0 * m1 + h1 * m0;
 }
 
-// XXH3-64 of the 8 little-endian bytes of {v_hi,v_lo} (XXH3_len_4to8_64b, len = 8 -> XXH3_rrmxmx)
-__device__ __forceinline__ uint64_t xxh3_64_8b(uint32_t v_lo, uint32_t v_hi, uint64_t bitflip)
+// XXH3-64 of the 8 little-endian bytes of {v_hi,v_lo} (XXH3_len_4to8_64b, len = 8 -> XXH3_rrmxmx), up to but NOT including the
+// final `h ^= h >> 28`
+__device__ __forceinline__ uint64_t xxh3_64_8b_pre(uint32_t v_lo, uint32_t v_hi, uint64_t bitflip)
 {
     // input64 = input2 + (input1 << 32): the two halves trade places
-    uint64_t h = (((uint64_t)v_lo << 32) | v_hi) ^ bitflip;
-    h ^= ((h << 49) | (h >> 15)) ^ ((h << 24) | (h >> 40));
+    const uint32_t lo = v_hi ^ (uint32_t)bitflip, hi = v_lo ^ (uint32_t)(bitflip >> 32);
+    // h ^= rotl(h, 49) ^ rotl(h, 24) in 32-bit halves: rotl 49 = rotr 15, rotl 24 = halves swapped + rotr 8; every half of a rotated
+    // value is one v_alignbit, the three-way xor one v_bitop3 — 6 instructions; as 64-bit shifts hipcc needs 10, two of them
+    // v_lshrrev_b64 / v_lshlrev_b64 at 5.9 cycles
+    const uint32_t nlo = __builtin_amdgcn_bitop3_b32(lo, alignbit(hi, lo, 15), alignbit(lo, hi, 8), 0x96);
+    const uint32_t nhi = __builtin_amdgcn_bitop3_b32(hi, alignbit(lo, hi, 15), alignbit(hi, lo, 8), 0x96);
+    uint64_t h = ((uint64_t)nhi << 32) | nlo;
     h *= XXH_PRIME_MX2;
     h ^= (h >> 35) + 8;
     h *= XXH_PRIME_MX2;
+    return h;
+}
+__device__ __forceinline__ uint64_t xxh3_64_8b(uint32_t v_lo, uint32_t v_hi, uint64_t bitflip)
+{
+    const uint64_t h = xxh3_64_8b_pre(v_lo, v_hi, bitflip);
     return h ^ (h >> 28);
 }
 

@@ -129,9 +129,20 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
     } else if constexpr (ALGO == 1) {
         // utils.rs:411-413: push_hash64(xxh3_64(masked.to_le_bytes(), seed)): bucket = low p bits,
         // rho = 1 + leading zeros of the remaining 64-p bits = clz64(h | (2^p - 1)) + 1
+        const uint32_t pm = (1u << p) - 1u;
+        if constexpr (FAST && !HLL_HIGH) {
+            // the hash's last step is h ^= h >> 28, which cannot move the leading one of the high word: the rank comes from the
+            // high word BEFORE it, and the bucket needs only the low p bits of the low word after it
+            const uint64_t g = xxh3_64_8b_pre(c_lo, c_hi, bitflip);
+            const uint32_t gh = (uint32_t)(g >> 32), gl = (uint32_t)g;
+            const uint32_t j = (gl ^ alignbit(gh, gl, 28)) & pm;
+            uint32_t rho = ffbh_u32(gh) + 1u;                                   // gh == 0 -> 0 (an under-estimate; re-run by the caller)
+            if constexpr (MASKED) rho &= vm;
+            regs.umax(j, rho);
+            return gh;
+        }
         const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
         const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
-        const uint32_t pm = (1u << p) - 1u;
         if constexpr (HLL_HIGH) {
             // layout.hll_bucket_high (SURVEY App. D, U3 alternative; ALT kernels, exact form only): bucket = top p bits,
             // rho = 1 + leading zeros of the lower 64-p bits = clz64((h << p) | 2^(p-1)) + 1
@@ -152,10 +163,20 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
     } else {
         // utils.rs:427-429: UltraLogLog::add(h): idx = top p bits, bit (nlz + p - 1) of the register's prefix
         // bitmap; sequential pack(unpack(old) | bit) == pack(OR of all bits), so OR now, pack later
-        const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
-        const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
-        const uint32_t idx = hh >> (32 - p);                                 // p <= 26 < 32
-        const uint32_t th = alignbit(hh, hl, 32 - p);                        // high word of ~(~h << p), p >= 3
+        uint32_t hh, hl, idx, th;
+        if constexpr (FAST) {
+            // without materialising the hash's last step h' = g ^ (g >> 28): bits [63-p, 32-p] of h' are those bits of g xor the
+            // same bits of g >> 28, i.e. of the high word shifted right by 28 - p (p <= 26); the index sits above the xorshift's reach
+            const uint64_t g = xxh3_64_8b_pre(c_lo, c_hi, bitflip);
+            hh = (uint32_t)(g >> 32); hl = (uint32_t)g;
+            idx = hh >> (32 - p);
+            th = alignbit(hh, hl, 32 - p) ^ (hh >> (28 - p));
+        } else {
+            const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
+            hh = (uint32_t)(h >> 32); hl = (uint32_t)h;
+            idx = hh >> (32 - p);                                            // p <= 26 < 32
+            th = alignbit(hh, hl, 32 - p);                                   // high word of ~(~h << p), p >= 3
+        }
         uint32_t bit, one;
         if constexpr (FAST) {
             bit = ffbh_u32(th) + (uint32_t)p - 1u;                           // valid when th != 0

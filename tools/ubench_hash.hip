@@ -40,13 +40,13 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
                 const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0, rh = r ? alignbit(r2, r1, 2 * r) : r1;
                 const uint64_t r64 = (((uint64_t)rh << 32) | rl) & ((1ull << 42) - 1ull);
                 const uint64_t cn = f64 < r64 ? f64 : r64;
-                const uint64_t hh64 = xxh3_64_8b((uint32_t)cn, (uint32_t)(cn >> 32), bitflip);
+                const uint64_t hh64 = xxh3_64_8b_pre((uint32_t)cn, (uint32_t)(cn >> 32), bitflip);   // (the kernel's fast form: add_kmer<1, FAST>)
                 const uint32_t hh = (uint32_t)(hh64 >> 32), hl = (uint32_t)hh64;
-                asm volatile("ds_max_u32 %0, %1" ::"v"((hl & 16383u) << 2), "v"(ffbh_u32(hh) + 1u) : "memory");
+                asm volatile("ds_max_u32 %0, %1" ::"v"(((hl ^ alignbit(hh, hl, 28)) & 16383u) << 2), "v"(ffbh_u32(hh) + 1u) : "memory");
             } else if constexpr (MODE == 5) {     // ull p=12 k=16 (configs[4]): xxh3_64 + rule + ds_or
-                const uint64_t hh64 = xxh3_64_8b(can, 0u, bitflip);
+                const uint64_t hh64 = xxh3_64_8b_pre(can, 0u, bitflip);                             // (add_kmer<2, FAST>)
                 const uint32_t hh = (uint32_t)(hh64 >> 32), hl = (uint32_t)hh64;
-                const uint32_t th = alignbit(hh, hl, 32 - 12);
+                const uint32_t th = alignbit(hh, hl, 32 - 12) ^ (hh >> (28 - 12));
                 const uint32_t bit = ffbh_u32(th) + 11u;
                 asm volatile("ds_or_b32 %0, %1" ::"v"(((hh >> 20) * 2u + ((bit >> 5) & 1u)) << 2), "v"((th < 1u ? th : 1u) << (bit & 31u)) : "memory");
             } else {                              // the sketch kernel's own fast path (add_kmer<HMH, x = high half, FAST>):
