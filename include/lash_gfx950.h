@@ -190,14 +190,15 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
                                  const uint8_t *file_fmt, uint32_t n_files, uint8_t *d_out_images);
 /* Malformed FASTQ.  needletail's iterator ends with an error at a record that is not header / sequence / '+' / quality and
  * lash keeps the records before it (`while let Some(Ok(..))`, utils.rs:457).  The device parse counts lines modulo 4 and
- * cannot stop mid-file, but it CHECKS: a line in phase 0 must start with '@', one in phase 2 with '+'.  Files that fail:
+ * cannot stop mid-file, but it CHECKS needletail's rules in full: a line in phase 0 must start with '@', one in phase 2 with
+ * '+' (pack_kernels.hip); a quality line must be as long as its sequence line, CR stripped, and the file must end on a whole
+ * record (fastq_check.hip, round 3 — a second scan over newline positions).  Files that fail:
  *   lash_sketch_files_raw         (bytes on the host) re-does each such file through a host parse that stops at the first
- *                                 malformed record and lash_sketch_batch — exact reference semantics, returns LASH_OK;
+ *                                 malformed record (or drops it: layout.fastq_skip_bad) and lash_sketch_batch — exact reference
+ *                                 semantics, returns LASH_OK;
  *   lash_sketch_files_raw_device  (bytes only in HBM) leaves their images unreliable; the next lash_ctx_synchronize() returns
- *                                 LASH_EFORMAT.
- * Not detected ON THE DEVICE: a quality line whose LENGTH differs from its sequence line's (needletail's other FASTQ
- * error).  The 4-line structure is intact then, nothing is mis-phased, and such a file is sketched to its end where the
- * reference stops — unless the caller validates first with lash_fastq_valid_prefix (below), as the `lash` CLI does.
+ *                                 LASH_EFORMAT.  The flagged set equals the set of files lash_fastq_valid_prefix(buf, n) < n
+ *                                 (tests/test_gpu_rawfiles.py holds them side by side).
  * Either way the indices of those files (of the last raw call) are available here: returns how many, copies up to `cap`.
  * The first byte of a file must be '>' or '@' (parse_fastx_file fails otherwise, utils.rs:453): LASH_EINVAL from both. */
 uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap);
@@ -211,8 +212,8 @@ uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t ca
  * the genomes of the LAST HyperLogLog sketch call that are in that corner (indices into that call's genomes; returns how many,
  * writes at most `cap`).  tests/test_gpu_hll_corner.py holds k-mers that reach it. */
 uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32_t cap);
-/* Host-side twin for callers that want needletail's FASTQ rules in full before the bytes go to the device (the `lash` CLI
- * does this in its reader threads, ~4 GB/s per thread): the length of the longest prefix of `buf` that is a sequence of
+/* Host-side twin of the device checks (what the library itself runs on a flagged file; the `lash` CLI no longer pre-validates —
+ * it hands the bytes over and reads lash_ctx_format_errors): the length of the longest prefix of `buf` that is a sequence of
  * well-formed records — '@' header, sequence, '+' line, quality of EQUAL length (CR stripped); the last record may lack its
  * final newline.  == n for a well-formed file, 0 if the first byte is not '@'.  What follows the prefix is what needletail's
  * iterator never yields; lash_fastq_neutralise_tail overwrites such a tail (inside a batch buffer whose file offsets must stay

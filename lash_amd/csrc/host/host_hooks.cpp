@@ -125,7 +125,6 @@ char *lash_host_gunzip_windowed(const uint8_t *src, uint64_t n, uint64_t window,
     return nullptr;
 }
 
-uint64_t lash_host_fastq_valid_prefix_mt(const uint8_t *b, uint64_t n, int threads) { return stream_fastq_valid_prefix_mt(b, n, threads); }
 
 // pgzip.hpp: inflates a (multi-member) gzip file with `threads` inflate threads, reading in `read_size` pieces.  Returns NULL and
 // the malloc'd bytes on success, else the error text; counts[0] / counts[1] = members served by workers / sequentially.

@@ -237,48 +237,7 @@ size_t find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry
     return 0;                                             // no FASTQ record boundary in the second half
 }
 
-// lash_fastq_valid_prefix over a chunk of hundreds of MiB on several threads.  Well-formedness composes: if a piece is valid
-// through its very end, validating the next piece from there is exactly what the sequential scan would do next.  So the
-// chunk (which starts at a record) is split at guessed record starts ('@' opening a line whose second next line opens with
-// '+'), the pieces are checked concurrently, and only if one of them stops short — a malformed record, or a guess that was no
-// record start — the scan is redone sequentially from that piece's start.  The result equals the one-thread result always;
-// the guess only decides how often the slow path runs (never, on real data).  ~4-8 GB/s per thread: on one thread this was
-// the serial bottleneck of a streamed FASTQ.gz once the members inflated in parallel.
-uint64_t fastq_valid_prefix_mt(const uint8_t *b, uint64_t n, int threads)
-{
-    if (threads <= 1 || n < (32u << 20)) return lash_fastq_valid_prefix(b, n);
-    auto line_end = [&](uint64_t p) { const void *e = memchr(b + p, '\n', n - p); return e ? (uint64_t)((const uint8_t *)e - b) : n; };
-    std::vector<uint64_t> start{0};
-    for (int t = 1; t < threads; ++t) {
-        uint64_t q = n / (uint64_t)threads * (uint64_t)t;
-        const uint64_t stop = std::min<uint64_t>(n, q + (16u << 20));
-        uint64_t found = 0;
-        for (; q < stop; ++q) {
-            if (b[q] != '@' || b[q - 1] != '\n') continue;
-            const uint64_t e1 = line_end(q);
-            if (e1 >= n) break;
-            const uint64_t e2 = line_end(e1 + 1);
-            if (e2 + 1 >= n) break;
-            if (b[e2 + 1] == '+') { found = q; break; }
-        }
-        if (found > start.back()) start.push_back(found);
-    }
-    start.push_back(n);
-    const size_t pieces = start.size() - 1;
-    if (pieces < 2) return lash_fastq_valid_prefix(b, n);
-    std::vector<uint64_t> ok(pieces, 0);
-    std::vector<std::thread> pool;
-    for (size_t i = 1; i < pieces; ++i)
-        pool.emplace_back([&, i] { ok[i] = lash_fastq_valid_prefix(b + start[i], start[i + 1] - start[i]); });
-    ok[0] = lash_fastq_valid_prefix(b, start[1]);
-    for (auto &t : pool) t.join();
-    for (size_t i = 0; i < pieces; ++i)
-        if (ok[i] < start[i + 1] - start[i]) return start[i] + lash_fastq_valid_prefix(b + start[i], n - start[i]);
-    return n;
-}
-
-// One file too large for a batch: chunks of it are sketched into the same image with LASH_F_ACCUMULATE.
-// Two pinned chunk buffers: this thread fills and checks chunk n+1 (inflate wait + copy out of the members + FASTQ check)
+// Two pinned chunk buffers: this thread fills chunk n+1 (inflate wait + copy out of the members + finding the cut)
 // while a second thread has the library sketch chunk n (H2D copy + kernels; the only user of `ctx` meanwhile).
 std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::string &path, uint64_t chunk_bytes,
                             PinnedBuf &buf0, PinnedBuf &buf1, uint8_t *image, uint64_t &bytes_seen, int threads)
@@ -296,6 +255,9 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
     std::condition_variable cv;
     std::deque<Job> jobs;
     bool busy[2] = {false, false}, no_more = false, halt = false, corner_noted = false;
+    lash_layout lay0;
+    (void)lash_ctx_get_layout(ctx, &lay0);
+    const bool skip_bad = lay0.fastq_skip_bad != 0;           // layout switch U6: malformed records are dropped, the reading goes on
     std::string gpu_err;
     uint64_t calls = 0;
     double t_gpu = 0;
@@ -333,7 +295,7 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
                         }
                         // a malformed FASTQ record ends needletail's iteration (utils.rs:457): the library kept this chunk's
                         // records before it; nothing after it belongs to the sketch
-                        if (lash_ctx_format_errors(ctx, nullptr, 0) != 0) stop = true;
+                        if (lash_ctx_format_errors(ctx, nullptr, 0) != 0 && !skip_bad) stop = true;
                     }
                     t_gpu += since(t0);
                 }
@@ -384,17 +346,10 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
         size_t cut = eof ? have : find_cut(b, have, fmt, carry);
         if ((prm0.flags & LASH_F_AMINO) && !carry.empty()) { result = "a protein record larger than a --stream-mb chunk: " + path; break; }
         if (!eof && cut == 0) { result = "cannot find a record boundary inside a " + std::to_string(chunk_bytes >> 20) + " MiB chunk of " + path; break; }
-        bool stop_here = false;
-        if (fmt == LASH_FMT_FASTQ) {                      // the chunk starts and ends at record boundaries: validate it whole
-            lash_layout lay;
-            (void)lash_ctx_get_layout(ctx, &lay);
-            if (lay.fastq_skip_bad) {
-                (void)lash_fastq_sanitize(b, cut, 1);       // layout switch U6: malformed records are dropped, the reading goes on
-            } else {
-                const uint64_t ok = fastq_valid_prefix_mt(b, cut, threads);
-                if (ok < cut) { cut = (size_t)ok; stop_here = true; }   // needletail stops at the malformed record (utils.rs:457)
-            }
-        }
+        // FASTQ: the chunk starts and ends at record boundaries and goes to the library as it is.  Malformed records — line
+        // structure AND quality-line lengths — are found on the device (pack_kernels.hip, fastq_check.hip); the library then
+        // re-does the chunk with needletail's rule and reports it (round 3: no host pass over every byte any more).
+        const bool stop_here = false;
         t_check += since(t0);
         // what follows the cut moves to the front of the other buffer — once the sketching side has let go of it
         t0 = now();
@@ -433,7 +388,6 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
 
 // test hook (host_hooks.cpp): the chunk-cut rule of the large-file streamer
 size_t stream_find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry) { return find_cut(b, n, fmt, carry); }
-uint64_t stream_fastq_valid_prefix_mt(const uint8_t *b, uint64_t n, int threads) { return fastq_valid_prefix_mt(b, n, threads); }
 
 std::string sketch_files(const SketchOptions &opt, const std::vector<std::string> &files, const std::string &output_name,
                          SketchStats *stats)
@@ -621,11 +575,8 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                             const int f = sniff_format(dst, s.size);
                             if (!f) e = "Invalid input file: neither FASTA ('>') nor FASTQ ('@'): " + files[i];
                             b->fmt[i - b->f0] = (uint8_t)(f ? f : LASH_FMT_FASTA);
-                            if (f == LASH_FMT_FASTQ) {
-                                // needletail's iterator ends at the first malformed record and lash keeps what came before
-                                // (utils.rs:457): validate here, in the reader thread, and blank out what it would never yield
-                                (void)lash_fastq_sanitize(dst, s.size, opt.layout.fastq_skip_bad);
-                            }
+                            // (malformed FASTQ records: found on the device, the file is then re-done by the library with
+                            // needletail's rule — utils.rs:457 — or, under layout fastq_err=skip, without the bad records)
                         }
                     }
                     if (!e.empty()) { std::lock_guard<std::mutex> lk(b->emu); if (b->err.empty()) b->err = e; }

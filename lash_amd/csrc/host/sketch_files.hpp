@@ -49,6 +49,5 @@ std::string write_parameters_json(const std::string &output_name, const std::str
 
 // where a streamed chunk ends (0 = no boundary found) and the bytes the next chunk must start with (tests)
 size_t stream_find_cut(const uint8_t *b, size_t n, int fmt, std::vector<uint8_t> &carry);
-uint64_t stream_fastq_valid_prefix_mt(const uint8_t *b, uint64_t n, int threads);   // test hook: the streamer's threaded FASTQ check
 
 }  // namespace lashhost

@@ -134,6 +134,28 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
         pk->pa = pa; pk->v2 = v2; pk->pm = pm;
     } else {
         HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, formats != nullptr, stream));
+        if (formats) {
+            // FASTQ files: quality-line lengths and how the file ends, into the same flags (fastq_check.hip)
+            std::vector<FqFile> fq;
+            uint64_t blocks = 0;
+            const uint64_t bb = fastq_check_block_bytes();
+            for (uint32_t g = 0; g < n_genomes; ++g) {
+                if (formats[g] != LASH_FMT_FASTQ || descs[g].byte_len == 0) continue;
+                const uint64_t nb = (descs[g].byte_len + bb - 1) / bb;
+                fq.push_back(FqFile{descs[g].byte_off, descs[g].byte_len, (uint32_t)blocks, (uint32_t)nb, g, 0u});
+                blocks += nb;
+            }
+            if (blocks > 0x7FFFFFFFull) return LASH_ELIMIT;
+            if (!fq.empty()) {
+                std::vector<Section> sec = {{fq.data(), fq.size() * sizeof(FqFile), 0}};
+                const size_t total = layout_sections(sec), tab = total;
+                if ((rc = reserve(ctx, pk->fq, tab + fastq_check_scratch_words((uint32_t)fq.size(), (uint32_t)blocks) * 4))) return rc;
+                if ((rc = upload_sections(ctx, pk->fq.ptr, sec, total, stream))) return rc;
+                uint8_t *fb = static_cast<uint8_t *>(pk->fq.ptr);
+                HIPCHK(ctx, launch_fastq_check(d_seq, reinterpret_cast<const FqFile *>(fb + sec[0].off), (uint32_t)fq.size(), (uint32_t)blocks,
+                                               reinterpret_cast<uint32_t *>(fb + tab), pa.file_err, stream));
+            }
+        }
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[1], stream));
     TRACE("pack: done");
@@ -638,7 +660,7 @@ void lash_ctx_destroy(lash_ctx *ctx)
         release(*b);
     {
         lash_packed &sc = ctx->scratch;
-        for (DevBuf *b : {&sc.words, &sc.brk, &sc.tables, &sc.tiles, &sc.lookback, &sc.tile_begin_c, &sc.brk_bytes})
+        for (DevBuf *b : {&sc.words, &sc.brk, &sc.tables, &sc.tiles, &sc.lookback, &sc.tile_begin_c, &sc.brk_bytes, &sc.fq})
             release(*b);
     }
     for (lash_sketch_set *ps : {&ctx->pl_ref, &ctx->pl_qry})
@@ -801,7 +823,7 @@ void lash_packed_free(lash_ctx *ctx, lash_packed *pk)
         for (auto it = ctx->last_packed.begin(); it != ctx->last_packed.end();)
             it = (*it == pk) ? ctx->last_packed.erase(it) : it + 1;
     }
-    for (DevBuf *b : {&pk->words, &pk->brk, &pk->tables, &pk->tiles, &pk->lookback, &pk->tile_begin_c, &pk->brk_bytes})
+    for (DevBuf *b : {&pk->words, &pk->brk, &pk->tables, &pk->tiles, &pk->lookback, &pk->tile_begin_c, &pk->brk_bytes, &pk->fq})
         release(*b);
     delete pk;
 }

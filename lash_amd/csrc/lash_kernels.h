@@ -71,6 +71,20 @@ hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off
 hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, const uint32_t *nonuniform,
                             uint32_t *brk_bytes, hipStream_t stream);
 // zero the packed-position break bitmap of the genomes the direct pass flagged dirty (the pack kernel ORs into it)
+// fastq_check.hip: the FASTQ rule the pack kernel's line-structure check cannot see — a quality line as long as its sequence
+// line, a file that ends on a whole record (needletail's Err; /root/reference/src/utils.rs:453-459 stops there).
+struct FqFile {
+    uint64_t off;        // first byte of the file in the raw buffer
+    uint64_t len;        // bytes (< 4 GiB)
+    uint32_t block0;     // index of the file's first 4 KiB block among all FASTQ blocks of the call
+    uint32_t n_blocks;
+    uint32_t index;      // which file_err word to set
+    uint32_t pad;
+};
+hipError_t launch_fastq_check(const uint8_t *d_raw, const FqFile *d_files, uint32_t n_files, uint32_t n_blocks, uint32_t *d_scratch,
+                              uint32_t *d_file_err, hipStream_t stream);
+size_t fastq_check_scratch_words(uint32_t n_files, uint32_t n_blocks);
+uint32_t fastq_check_block_bytes();
 hipError_t launch_zero_dirty_brk(const GenomeDesc *genomes, const uint32_t *dirty, uint32_t n_genomes, uint32_t *brk, hipStream_t stream);
 
 struct FinalizeArgs {

@@ -51,7 +51,7 @@ def fasta_file(rng):
     return data
 
 
-def fastq_file(rng, length_errors=False):
+def fastq_file(rng, length_errors=True):
     nl = rng.choice([b"\n", b"\n", b"\r\n"])
     out = []
     for r in range(rng.randint(0, 400)):
@@ -67,11 +67,8 @@ def fastq_file(rng, length_errors=False):
             out[i] = out[i].replace(nl + b"+", nl + b"-", 1)   # the '+' line does not start with '+'
         elif kind < 0.8 or not length_errors:
             out[i] = b"r" + out[i][1:]                      # header without '@'
-        else:                                               # quality one character short: only the CLI (host validation) stops there
-            out[i] = out[i][:-len(nl) - 1] + nl if len(out[i]) > len(nl) + 1 else out[i]
-        # (a quality line whose LENGTH differs from its sequence line's — needletail's other FASTQ error — keeps the 4-line
-        # structure intact; the device parse does not detect it and sketches the file to its end: documented divergence,
-        # tests/test_gpu_rawfiles.py)
+        else:                                               # quality one character short: needletail's other FASTQ error; the
+            out[i] = out[i][:-len(nl) - 1] + nl if len(out[i]) > len(nl) + 1 else out[i]   # 4-line structure stays intact (fastq_check.hip)
     data = b"".join(out)
     if rng.random() < 0.3 and data.endswith(nl) and out and len(s):
         data = data[:-len(nl)]                              # no newline after the last quality line (if it is not empty:

@@ -41,8 +41,6 @@ def _load():
                                               C.POINTER(C.c_uint64)]
     lib.lash_host_crc32.restype = C.c_uint32
     lib.lash_host_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_uint64]
-    lib.lash_host_fastq_valid_prefix_mt.restype = C.c_uint64
-    lib.lash_host_fastq_valid_prefix_mt.argtypes = [C.c_char_p, C.c_uint64, C.c_int]
     lib.lash_host_xxh3_64.restype = C.c_uint64
     lib.lash_host_xxh3_64.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64]
     lib.lash_host_name_order.restype = C.c_uint64
@@ -166,8 +164,3 @@ def gunzip_windowed(data: bytes, window=4096, piece=1000):
 
 def crc32(data: bytes, crc=0) -> int:
     return int(lib.lash_host_crc32(crc, data, len(data)))
-
-
-def fastq_valid_prefix_mt(data: bytes, threads: int) -> int:
-    """the large-file streamer's threaded form of lash_fastq_valid_prefix (must equal it)"""
-    return int(lib.lash_host_fastq_valid_prefix_mt(data, len(data), threads))

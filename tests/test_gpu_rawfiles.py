@@ -172,14 +172,114 @@ def test_malformed_fastq_is_detected_on_the_device_and_redone_exactly(ctx):
         if i not in ctx.format_errors():
             assert np.array_equal(img[i], want[i]), n              # the well-formed ones are right
     ctx.synchronize()                                              # the error was consumed
-    # DOCUMENTED DIVERGENCE: a quality line whose length differs from its sequence line's is needletail's other FASTQ error
-    # (the reference stops there).  The 4-line structure is intact, nothing is mis-phased, and the device parse — which checks
-    # line starts, not line lengths — sketches the file to its end: the image equals that of the repaired file.
+    # a quality line whose length differs from its sequence line's is needletail's other FASTQ error (the reference stops there).
+    # The 4-line structure is intact, so the line-start check above cannot see it; fastq_check.hip compares the line lengths on
+    # the device (round 3) and the file is re-done exactly like the others.
     short_q = _fastq(reads[:10]) + b"@x\n" + reads[10] + b"\n+\n" + b"I" * (len(reads[10]) - 1) + b"\n" + _fastq(reads[11:])
-    repaired = _fastq(reads[:10]) + b"@x\n" + reads[10] + b"\n+\n" + b"I" * len(reads[10]) + b"\n" + _fastq(reads[11:])
-    got = ctx.sketch_files_raw("hmh", 16, 0, 42, [short_q])
-    assert ctx.format_errors() == []
-    assert np.array_equal(got, O.sketch_files(O.HMH, 16, 0, 42, [repaired]))
-    assert not np.array_equal(got, O.sketch_files(O.HMH, 16, 0, 42, [short_q]))     # the oracle (needletail's rule) stops at record 10
+    got = ctx.sketch_files_raw("hmh", 16, 0, 42, [good, short_q])
+    assert ctx.format_errors() == [1]
+    assert np.array_equal(got, O.sketch_files(O.HMH, 16, 0, 42, [good, short_q]))     # the oracle (needletail's rule) stops at record 10
+    assert not np.array_equal(got[1], O.sketch_files(O.HMH, 16, 0, 42, [_fastq(reads)])[0])
     with pytest.raises(lash_amd.LashError):                        # first byte rule (parse_fastx_file fails, utils.rs:453)
         ctx.sketch_files_raw("hmh", 16, 0, 42, [b"\n" + good])
+
+
+def _device_flags(ctx, files):
+    """lash_sketch_files_raw_device on FASTQ files -> the set of flagged file indices"""
+    import ctypes as C
+    import lash_amd
+    import torch
+    from lash_amd import _lib
+    d_raw = torch.from_numpy(np.frombuffer(b"".join(files) + b"\0" * 64, np.uint8).copy()).cuda()
+    off = np.cumsum([0] + [len(f) for f in files]).astype(np.uint64)
+    fmt = np.full(len(files), 2, np.uint8)
+    d_img = torch.zeros(len(files) * lash_amd.image_bytes("hmh"), dtype=torch.uint8, device="cuda")
+    prm = _lib.Params(0, 16, 0, 0, 42)
+    rc = _lib.load().lash_sketch_files_raw_device(ctx._h, C.byref(prm), d_raw.data_ptr(), off.ctypes.data, fmt.ctypes.data, len(files), d_img.data_ptr())
+    assert rc == 0
+    try:
+        ctx.synchronize()
+    except lash_amd.LashError as e:
+        assert e.code == _lib.EFORMAT
+    return set(ctx.format_errors()), d_img.cpu().numpy().reshape(len(files), -1)
+
+
+def _host_says_bad(f):
+    from lash_amd import _lib
+    buf = np.frombuffer(f, np.uint8)
+    return int(_lib.load().lash_fastq_valid_prefix(buf.ctypes.data, len(f))) < len(f)
+
+
+def test_fastq_quality_length_check_on_the_device_is_exact(ctx):
+    """the device-buffer entry flags EXACTLY the files needletail's rule (the host parse, lash_fastq_valid_prefix)
+    stops in — quality lines of a different length anywhere in the file, lines that span several 4 KiB blocks of the check,
+    CRLF, a last record without its final newline, a file cut inside a record — and no well-formed file."""
+    rng = random.Random(77)
+
+    def read(n):
+        return "".join(rng.choice("ACGT") for _ in range(n)).encode()
+
+    def rec(i, s, q=None, nl=b"\n"):
+        return b"@r%d" % i + nl + s + nl + b"+" + nl + (b"I" * len(s) if q is None else q) + nl
+
+    short = [read(rng.randint(20, 300)) for _ in range(300)]
+    longr = [read(rng.choice([4000, 4096, 4097, 9000, 20000, 70000])) for _ in range(12)]
+    ok_short = b"".join(rec(i, s) for i, s in enumerate(short))
+    ok_long = b"".join(rec(i, s) for i, s in enumerate(longr))
+    files = {
+        "ok short": ok_short,
+        "ok long": ok_long,
+        "ok crlf": b"".join(rec(i, s, nl=b"\r\n") for i, s in enumerate(short)),
+        "ok no final newline": ok_short[:-1],
+        "ok long no final newline": ok_long[:-1],
+        "ok empty read": rec(0, b"") + rec(1, short[1]) + rec(2, b""),
+        "ok one record": rec(0, short[0]),
+        "ok empty last quality, no newline": rec(0, short[0]) + b"@e\n\n+\n",       # the host parse takes it (no base in it anyway)
+        "ok cr only in quality": rec(0, b"ACGT", b"IIII\r") + rec(1, b"ACGT\r", b"IIII"),
+        "bad short quality": b"".join(rec(i, s, b"I" * (len(s) - 1) if i == 150 else None) for i, s in enumerate(short)),
+        "bad long quality (last record)": b"".join(rec(i, s, b"I" * (len(s) + 1) if i == 299 else None) for i, s in enumerate(short)),
+        "bad first record": b"".join(rec(i, s, b"" if i == 0 else None) for i, s in enumerate(short)),
+        "bad long read, quality one short": b"".join(rec(i, s, b"I" * (len(s) - 1) if i == 7 else None) for i, s in enumerate(longr)),
+        "bad long read, quality a block longer": b"".join(rec(i, s, b"I" * (len(s) + 4096) if i == 3 else None) for i, s in enumerate(longr)),
+        "bad last quality short, no newline": ok_short[:-2],
+        "bad cut after plus line": ok_short + b"@x\nACGT\n+\n",
+        "bad cut after sequence": ok_short + b"@x\nACGT\n",
+        "bad cut in header": ok_short + b"@x",
+        "bad crlf quality short": b"".join(rec(i, s, b"I" * (len(s) - 1) if i == 20 else None, nl=b"\r\n") for i, s in enumerate(short)),
+        "bad swapped lengths": rec(0, b"ACGTACGT", b"IIII") + rec(1, b"ACGT", b"IIIIIIII"),
+    }
+    names = list(files)
+    data = [files[n] for n in names]
+    want_bad = {i for i, f in enumerate(data) if _host_says_bad(f)}
+    assert {names[i] for i in want_bad} == {n for n in names if n.startswith("bad")}        # the host rule itself, as a sanity check
+    flagged, img = _device_flags(ctx, data)
+    assert {names[i] for i in flagged} == {names[i] for i in want_bad}
+    want = O.sketch_files(O.HMH, 16, 0, 42, data, threads=4)
+    for i in range(len(data)):
+        if i not in flagged:
+            assert np.array_equal(img[i], want[i]), names[i]
+    # and the host-buffer entry re-does the flagged ones exactly
+    got = ctx.sketch_files_raw("hmh", 16, 0, 42, data)
+    assert np.array_equal(got, want)
+    # randomized: files of random records, one random defect (or none) each
+    for it in range(30):
+        data = []
+        for _ in range(rng.randint(1, 8)):
+            nl = rng.choice([b"\n", b"\r\n"])
+            recs = []
+            for i in range(rng.randint(1, 120)):
+                s = read(rng.choice([0, 1, 50, 150, rng.randint(1, 600), rng.choice([4090, 5000, 13000])]))
+                recs.append([b"@r%d" % i, s, b"+", bytes(rng.choice(b"I@+ACGT#") for _ in range(len(s)))])
+            if rng.random() < 0.5:
+                r = rng.choice(recs)
+                d = rng.choice([-1, 1, 2, -len(r[1]) // 2, 4096])
+                r[3] = r[3][:len(r[3]) + d] if d < 0 else r[3] + b"I" * d
+            f = b"".join(nl.join(r) + nl for r in recs)
+            if rng.random() < 0.3:
+                f = f[:-len(nl)]
+            if rng.random() < 0.15:
+                f = f[:rng.randint(1, len(f))]
+            data.append(f)
+        want_bad = {i for i, f in enumerate(data) if _host_says_bad(f)}
+        flagged, img = _device_flags(ctx, data)
+        assert flagged == want_bad, (it, sorted(flagged), sorted(want_bad))

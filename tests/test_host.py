@@ -410,53 +410,6 @@ def test_gzip_reader_padding_fallback_and_zlib_only(tmp_path):
         assert r.returncode == 0 and "refused:" in r.stdout and "disagree" in r.stdout, (flip, r.stdout, r.stderr[-2000:])
 
 
-def test_threaded_fastq_check_equals_the_sequential_one():
-    """The streamer validates a chunk on several threads (sketch_files.cpp: fastq_valid_prefix_mt): split at guessed record
-    starts, pieces checked concurrently, sequential redo from the first piece that stops short.  It must return exactly what
-    lash_fastq_valid_prefix returns — also when the guess is wrong ('@' opening a quality line two lines above a sequence line
-    that opens with '+': both legal for needletail) and when a record really is malformed, anywhere."""
-    import lash_amd
-    rng = np.random.default_rng(33)
-
-    def seq_prefix(b):
-        return int(lash_amd.load().lash_fastq_valid_prefix(b, len(b)))
-
-    def reads(n, trap=False):
-        out = []
-        for i in range(n):
-            L = int(rng.integers(50, 200))
-            s = bytes(np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, size=L)])
-            q = bytes(rng.integers(33, 74, size=L, dtype=np.uint8))
-            if trap and i % 3 == 0:
-                q = b"@" + q[1:]                                  # quality line that opens like a header ...
-            if trap and i % 3 == 1:
-                s = b"+" + s[1:]                                  # ... followed (after the next header) by a sequence line opening with '+'
-            out.append(b"@r%d\n" % i + s + b"\n+\n" + q + b"\n")
-        return out
-
-    n_reads = 220_000                                              # ~70 MB: above the 32 MiB threshold of the threaded form
-    for trap in (False, True):
-        recs = reads(n_reads, trap)
-        good = b"".join(recs)
-        assert len(good) > (40 << 20)
-        for threads in (2, 5, 16):
-            assert H.fastq_valid_prefix_mt(good, threads) == seq_prefix(good) == len(good)
-        # one malformed record at various depths: quality one byte short, a missing '+', a blank line
-        for where in (0, 1, n_reads // 7, n_reads // 2, n_reads - 2, n_reads - 1):
-            for kind in range(3):
-                r = recs[where]
-                h, s, p, q = r.split(b"\n")[:4]
-                bad = [h + b"\n" + s + b"\n+\n" + q[:-1] + b"\n", h + b"\n" + s + b"\n" + q + b"\n", h + b"\n" + s + b"\n\n+\n" + q + b"\n"][kind]
-                data = b"".join(recs[:where]) + bad + b"".join(recs[where + 1:])
-                want = seq_prefix(data)
-                assert want <= sum(len(x) for x in recs[:where]) + len(bad)
-                for threads in (3, 8):
-                    assert H.fastq_valid_prefix_mt(data, threads) == want, (trap, where, kind, threads)
-    # the last record without its final newline, and a buffer below the threshold
-    assert H.fastq_valid_prefix_mt(good[:-1], 4) == seq_prefix(good[:-1]) == len(good) - 1
-    assert H.fastq_valid_prefix_mt(good[:1000], 4) == seq_prefix(good[:1000])
-
-
 def test_name_order_with_odd_names():
     """names of every XXH3 length class (0 .. > 240 bytes once the 0xFF terminator is added), non-ASCII paths, one-letter and
     empty names: the two restatements agree and every name appears once"""
