@@ -199,7 +199,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
-    const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(plan.lds_bytes, 1u)) : 4u;   // 64 KiB + census -> 2
+    const uint32_t lds_wg = plan.lds_bytes + (pk->direct ? sketch_direct_stage_bytes(plan) : 0u);            // direct: + the waves' staging areas
+    const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(lds_wg, 1u)) : 4u;   // 64 KiB + census -> 2
     const uint64_t slots = (uint64_t)ctx->cu_count * std::min(wg_per_cu, 2048u / plan.threads);
     uint64_t total_words = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) total_words += (pk->byte_len[g] + 15) / 16;

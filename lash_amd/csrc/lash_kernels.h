@@ -37,6 +37,7 @@ struct SketchArgs {
     uint64_t          bitflip;    // xxh3 seed-folded constant (64- or 128-bit variant by algo)
     LayoutDev         lay;
     uint32_t          partial_stride;
+    uint32_t          stage_off;  // direct mode: LDS byte offset of the waves' staging areas (dense_tile), after registers + census
     uint32_t          nreg32;     // u32 words of register state (HMH 16384, HLL 2^p, ULL 2*2^p)
     int               k;
     int               p;
@@ -57,6 +58,8 @@ struct SketchPlan {
 
 // small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)
 SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false);
+// direct launches: bytes of LDS the waves' staging areas take on top of plan.lds_bytes (they start at plan.lds_bytes)
+uint32_t sketch_direct_stage_bytes(const SketchPlan &plan);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
                          bool direct = false);
 // amino-acid sketches (LASH_F_AMINO; utils.rs:511-563): work items are RECORD ranges of a genome (WorkItem::word_begin / word_end =

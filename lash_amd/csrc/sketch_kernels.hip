@@ -542,6 +542,314 @@ __device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *g
     return added;
 }
 
+// ---- direct mode, dense dirt in place ----------------------------------------------------------------------
+// A wave-tile (64 lanes x 64 bytes) with many deleted bytes — a soft-masked block, the flank of an assembly gap — is not worth
+// per-lane junction walks, and lanes that own deleted bytes would idle through the hashing.  The wave COMPACTS the tile instead:
+// every lane classifies its 64 bytes, a wave prefix sum gives each lane's offset among the survivors, the survivors go to a
+// wave-private LDS staging area as the same 2-bit stream the pack stage would have written to HBM (plus the record-break bits
+// moved to compacted positions), followed by the next k-1 surviving bases after the tile (found by the whole wave, 1 KiB per
+// step, however long the deleted run is, up to DENSE_SCAN_MAX).  Then the lanes share the survivors EVENLY — ceil(words / 64)
+// packed words each, 1..4 — and hash them with the same process_word as the clean path: a half-deleted tile costs half a tile.
+// The k-mers of a tile are those whose FIRST base is one of the tile's surviving bytes (filter_out_n joins across deleted
+// bytes, utils.rs:33-41; records still separate, utils.rs:457-464), so tiles stay independent: no carry, no look-back.
+constexpr uint32_t DENSE_STAGE_CODE_WORDS = 264;      // 4096 + 31 + 16 bases at 16 per word, rounded up; reads reach word 4*63+5
+constexpr uint32_t DENSE_STAGE_BRK_WORDS = 136;       // the same positions, one bit each; reads reach word 2*63+3 (+1)
+constexpr uint32_t DENSE_STAGE_WORDS = DENSE_STAGE_CODE_WORDS + DENSE_STAGE_BRK_WORDS;   // 1600 bytes per wave
+constexpr uint32_t DENSE_SCAN_MAX = 4u << 20;         // bytes of look-ahead scan before the genome is left to the pack stage
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
+{
+    // Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows
+    // 2, 3 (row_bcast:15 / :31): six DPP adds, no LDS round trips (a __shfl_up is a ds_bpermute)
+    uint32_t incl = v;
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    return incl - v;
+}
+
+// 16 bytes -> 2-bit codes (byte j in bits 31-2j..30-2j; garbage where deleted) and which bytes are NOT one of A C G T (bit j)
+__device__ __forceinline__ uint32_t classify16(const uint4 q, const CodeTabs ct, uint32_t &inv)
+{
+    auto four = [&](uint32_t x, uint32_t &iv) {
+        const uint32_t key = x & 0x07070707u;
+        const uint32_t z = x ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, key);     // zero byte <=> the letter its low bits stand for
+        const uint32_t nz = ((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z;
+        iv = ((((nz >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+        return (__builtin_amdgcn_perm(ct.hi, ct.lo, key) * 0x40100401u) >> 24;
+    };
+    uint32_t i0, i1, i2, i3;
+    const uint32_t c = (four(q.x, i0) << 24) | (four(q.y, i1) << 16) | (four(q.z, i2) << 8) | four(q.w, i3);
+    inv = i0 | (i1 << 4) | (i2 << 8) | (i3 << 12);
+    return c;
+}
+// certainly no A C G T among the 16 bytes?  Those four letters have bits 5 and 3 clear; lower-case letters have bit 5 set, 'N' bit 3:
+// if every byte has one of the two, nothing survives.  (A cheap sufficient test for the long runs; "false" means "look closer".)
+__device__ __forceinline__ uint32_t hopeless_bits(const uint4 q)
+{
+    return (q.x | (q.x << 2)) & (q.y | (q.y << 2)) & (q.z | (q.z << 2)) & (q.w | (q.w << 2));
+}
+__device__ __forceinline__ bool hopeless16(const uint4 q) { return (hopeless_bits(q) & 0x20202020u) == 0x20202020u; }
+
+// 16 classified bytes -> their survivors, first in bits 31:30 (`codes`: byte j in bits 31-2j..30-2j; `m`: bit j = byte j survives)
+__device__ __forceinline__ uint32_t compact16(uint32_t codes, uint32_t m, uint32_t recv, uint32_t &cb)
+{
+    // recv: bit j = the survivor at byte j opens a record (compacted alongside into cb, LSB first)
+    if (m == 0xFFFFu) { cb = recv; return codes; }
+    uint32_t bits = 0, cnt = 0;
+    cb = 0;
+    while (m) {
+        const uint32_t j = (uint32_t)__builtin_ctz(m);
+        m &= m - 1;
+        bits |= ((codes >> (30 - 2 * j)) & 3u) << (30 - 2 * cnt);
+        cb |= ((recv >> j) & 1u) << cnt;
+        ++cnt;
+    }
+    return bits;
+}
+
+// `n` compacted bases (`bits`, first in 31:30) and their break bits to stream position s of the wave's staging area (LDS byte address)
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void lds_or(uint32_t byte_addr, uint32_t v) { asm volatile("ds_or_b32 %0, %1" ::"v"(byte_addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void stage_put(uint32_t stage_b, uint32_t s, uint32_t bits, uint32_t cb, uint32_t n, bool breaks)
+{
+    if (n == 0) return;
+    const uint32_t w = s >> 4, sh = 2u * (s & 15u);
+    lds_or(stage_b + 4u * w, bits >> sh);
+    if (sh && (s & 15u) + n > 16u) lds_or(stage_b + 4u * w + 4u, bits << (32u - sh));
+    if (breaks && cb) {
+        const uint32_t bm = stage_b + 4u * DENSE_STAGE_CODE_WORDS;
+        const uint32_t bw = s >> 5, bs = s & 31u;
+        lds_or(bm + 4u * bw, cb << bs);
+        if (bs && bs + n > 32u) lds_or(bm + 4u * bw + 4u, cb >> (32u - bs));
+    }
+}
+
+template <int ALGO, int KMODE, bool XLOW, class Regs>
+__device__ __noinline__ uint32_t dense_tile(const Regs regs, const KParams kp, const uint8_t *gseq, uint64_t L, uint64_t P0, uint64_t E,
+                                            const uint32_t *bk, uint32_t RL, int k, uint32_t cmask, const CodeTabs ct, uint32_t stage_b,
+                                            uint32_t *dirty, uint32_t *ndel, bool have_raw, uint4 q0, uint4 q1, uint4 q2, uint4 q3)
+{
+    // have_raw (per lane): q0..q3 are the lane's 64 bytes, still in registers from the tile load
+    const uint32_t lane = threadIdx.x & 63u;
+    // the KiB after the tile, asked for now: its round trip runs under the classification and the staging
+    const bool la_fast = E + 1024 <= L;                                           // uniform
+    uint4 la0 = make_uint4(0, 0, 0, 0);
+    if (la_fast) la0 = load16_any(gseq + E + 16ull * lane);
+    lds_u32 *const stage = (lds_u32 *)(uintptr_t)stage_b;                                    // this wave's staging area (LDS byte address)
+    const bool breaks = bk != nullptr || RL != 0u;
+    // ---- 1. the lane's own 64 bytes: codes, survivors, record starts ----
+    const uint64_t o = P0 + 64ull * lane;
+    const uint32_t own = o >= E ? 0u : (E - o >= 64 ? 64u : (uint32_t)(E - o));
+    uint4 q[4] = {q0, q1, q2, q3};
+    if (have_raw) {
+    } else if (o + 64 <= L) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = load16_any(gseq + o + 16 * c);
+    } else {
+        uint32_t d[16];
+        for (int i = 0; i < 16; ++i) d[i] = 0x4E4E4E4Eu;                         // 'N': beyond the genome nothing survives
+        for (uint32_t i = 0; i < 64 && o + i < L; ++i) d[i >> 2] = (d[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)gseq[o + i] << (8 * (i & 3)));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = make_uint4(d[4 * c], d[4 * c + 1], d[4 * c + 2], d[4 * c + 3]);
+    }
+    uint32_t codes[4], vm[4];
+    const uint64_t ownmask = own >= 64 ? ~0ull : ((1ull << own) - 1ull);
+    uint64_t v64 = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        uint32_t iv;
+        codes[c] = classify16(q[c], ct, iv);
+        vm[c] = ~iv & 0xFFFFu & (uint32_t)(ownmask >> (16 * c));
+        v64 |= (uint64_t)vm[c] << (16 * c);
+    }
+    const uint32_t n_mine = (uint32_t)__builtin_popcountll(v64);
+    uint32_t T;
+    const uint32_t off = wave_excl_scan(n_mine, T);
+    if (ndel) {
+        // the census of deleted bytes (lash_timing::bases_last): the owned region, and the genome's last < k bytes when they start
+        // beyond this tile — no k-mer starts there, so no wave will look at them
+        uint32_t nd = own - n_mine;
+        for (int d = 32; d > 0; d >>= 1) nd += __shfl_xor(nd, d, 64);
+        if (lane == 0) {
+            if (E < L && L - E < (uint64_t)k)
+                for (uint64_t i = E; i < L; ++i) { const uint32_t c = gseq[i]; nd += !(c == 0x41u || c == 0x43u || c == 0x47u || c == 0x54u); }
+            if (nd) atomicAdd(ndel, nd);
+        }
+    }
+    if (T == 0u) return 0u;
+    // record starts land on the first survivor at or after them: a carry through the deleted bytes (~v + starts), lanes chained
+    uint64_t recv = 0;
+    bool pend_tile = false;                                                       // a record starts after the tile's last survivor
+    if (breaks) {
+        uint64_t rb = 0;
+        if (own) {
+            if (RL) { const Brk96 ub = uniform_breaks((uint32_t)o, RL, 64u); rb = (uint64_t)ub.b0 | ((uint64_t)ub.b1 << 32); }
+            else rb = (uint64_t)bk[o >> 5] | ((uint64_t)bk[(o >> 5) + 1] << 32);
+            rb &= ownmask;
+        }
+        const uint64_t nv = ~v64 & ownmask;                                       // owned and deleted
+        // carry out of the lane: a start after its last survivor (own < 64: positions at or above `own` absorb nothing and
+        // propagate, like deleted ones)
+        const uint64_t fill = nv | ~ownmask;
+        const uint64_t rbd = rb & fill;                                           // starts AT a survivor need no carry (OR-ed in below)
+        const bool gen = fill + rbd < rbd;                                        // carry out with no carry in
+        const uint64_t G = __builtin_amdgcn_ballot_w64(gen), Z = __builtin_amdgcn_ballot_w64(n_mine == 0u);
+        const uint64_t below = (1ull << lane) - 1ull;
+        const uint64_t nz = ~Z & below;
+        const uint64_t from = nz ? ~((1ull << (63 - __builtin_clzll(nz))) - 1ull) : ~0ull;   // lanes hs .. lane-1
+        const bool pend_in = (G & below & from) != 0ull;
+        recv = ((fill + rbd + (pend_in ? 1ull : 0ull)) | rb) & v64;
+        const uint64_t nzall = ~Z;                                                // T > 0: some lane has survivors
+        const int hs = 63 - __builtin_clzll(nzall);
+        pend_tile = (G >> hs) != 0ull;
+    }
+    // ---- 2. staging: zero, own survivors, look-ahead ----
+    {
+        lds_u32 *z = stage + 4u * lane;
+        z[0] = 0; z[1] = 0; z[2] = 0; z[3] = 0;
+        if (lane < (DENSE_STAGE_WORDS - 256u) / 4u) { z[256] = 0; z[257] = 0; z[258] = 0; z[259] = 0; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        uint32_t s = off;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t cb;
+            const uint32_t bits = compact16(codes[c], vm[c], (uint32_t)(recv >> (16 * c)) & 0xFFFFu, cb);
+            const uint32_t n = (uint32_t)__builtin_popcount(vm[c]);
+            stage_put(stage_b, s, bits, cb, n, breaks);
+            s += n;
+        }
+    }
+    uint32_t A = 0;                                                               // surviving bases found after the tile
+    if (E < L && !pend_tile && k > 1) {
+        const uint32_t want = (uint32_t)k - 1u;
+        uint64_t base = E;
+        for (;;) {
+            if (base - E >= DENSE_SCAN_MAX) {                                    // a very long gap: the pack stage takes the genome
+                if (lane == 0) atomicOr(dirty, 1u);
+                return 0u;
+            }
+            const uint64_t at = base + 16ull * lane;
+            uint4 x;
+            if (base == E && la_fast) x = la0;
+            else if (at + 16 <= L) x = load16_any(gseq + at);
+            else {
+                uint32_t d[4] = {0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu, 0x4E4E4E4Eu};
+                for (uint32_t i = 0; i < 16 && at + i < L; ++i) d[i >> 2] = (d[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)gseq[at + i] << (8 * (i & 3)));
+                x = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            uint32_t iv;
+            const uint32_t cw = classify16(x, ct, iv);
+            uint32_t m = ~iv & 0xFFFFu;
+            bool stop = base + 1024 >= L;
+            uint32_t rb = 0;
+            if (breaks && at < L) {
+                if (RL) rb = uniform_breaks((uint32_t)at, RL, 16u).b0;
+                else rb = (bk[at >> 5] >> (at & 31u)) & 0xFFFFu;                  // `at` is a multiple of 16 (E < L: E is one of 64)
+            }
+            const uint64_t Bm = __builtin_amdgcn_ballot_w64(rb != 0u);
+            if (Bm) {                                                             // the next record: nothing from its start on
+                const uint32_t fb = (uint32_t)__builtin_ctzll(Bm);
+                if (lane > fb) m = 0;
+                else if (lane == fb) m &= (1u << __builtin_ctz(rb)) - 1u;
+                stop = true;
+            }
+            const uint32_t n = (uint32_t)__builtin_popcount(m);
+            uint32_t tot;
+            const uint32_t at_s = A + wave_excl_scan(n, tot);
+            if (n && at_s < want) {
+                uint32_t cb;
+                const uint32_t bits = compact16(cw, m, 0u, cb);
+                stage_put(stage_b, T + at_s, bits, 0u, n, false);
+            }
+            A += tot;
+            if (A >= want || stop) break;
+            base += 1024;
+            if (tot != 0u) continue;
+            // a whole KiB deleted: a long run (soft-masked block, assembly gap).  Skip ahead 8 KiB per round trip to the first KiB
+            // that holds a survivor or a record start; the loop above takes it from there.
+            for (;;) {
+                if (base + 8192 + 16 > L || base - E >= DENSE_SCAN_MAX) break;    // near the genome's end: KiB by KiB (above)
+                uint4 y[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) y[j] = load16_any(gseq + base + 1024ull * j + 16ull * lane);
+                uint32_t first = 8;
+#pragma unroll
+                for (int j = 7; j >= 0; --j) {
+                    bool hit = !hopeless16(y[j]);
+                    if (breaks) {
+                        const uint64_t aj = base + 1024ull * j + 16ull * lane;
+                        hit = hit || (RL ? uniform_breaks((uint32_t)aj, RL, 16u).b0 != 0u : ((bk[aj >> 5] >> (aj & 31u)) & 0xFFFFu) != 0u);
+                    }
+                    if (__builtin_amdgcn_ballot_w64(hit) != 0ull) first = (uint32_t)j;
+                }
+                base += 1024ull * first;
+                if (first < 8u) break;
+            }
+        }
+        if (A > want) A = want;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- 3. the survivors, shared evenly, through the clean path's hashing ----
+    const uint32_t S = T + A;
+    const uint32_t nk = S >= (uint32_t)k ? (T < S - (uint32_t)k + 1u ? T : S - (uint32_t)k + 1u) : 0u;   // k-mers that start in the tile
+    if (nk == 0u) return 0u;
+    const uint32_t wpl = ((nk + 15u) / 16u + 63u) / 64u;                          // packed words per lane: 1..4
+    const uint32_t fw = wpl * lane, pos0 = 16u * fw;
+    const bool active = pos0 < nk;
+    const uint32_t junk = (threadIdx.x + 1u) * 0x9E3779B1u;
+    uint32_t c0 = junk, c1 = ~junk, c2 = junk, c3 = ~junk, c4 = junk, c5 = ~junk;
+    uint64_t kv = 0;
+    if (active) {
+        c0 = stage[fw]; c1 = stage[fw + 1]; c2 = stage[fw + 2]; c3 = stage[fw + 3]; c4 = stage[fw + 4]; c5 = stage[fw + 5];
+        uint32_t b0 = 0, b1 = 0, b2 = 0;
+        if (breaks) {
+            const lds_u32 *bm = stage + DENSE_STAGE_CODE_WORDS + (pos0 >> 5);
+            const uint32_t sh = pos0 & 31u;                                       // 0 or 16
+            const uint32_t w0 = bm[0], w1 = bm[1], w2 = bm[2], w3 = bm[3];
+            b0 = sh ? (w0 >> 16) | (w1 << 16) : w0;
+            b1 = sh ? (w1 >> 16) | (w2 << 16) : w1;
+            b2 = sh ? (w2 >> 16) | (w3 << 16) : w2;
+        }
+        kv = kmer_valid_mask(b0, b1, b2, pos0, nk, k);
+        if (wpl < 4u) kv &= (1ull << (16u * wpl)) - 1ull;
+    }
+    const uint32_t added = (uint32_t)__builtin_popcountll(kv);
+    const uint64_t full = wpl < 4u ? (1ull << (16u * wpl)) - 1ull : ~0ull;
+    const bool all_valid = __builtin_amdgcn_ballot_w64(kv != full) == 0ull;
+    uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
+#pragma unroll 1
+    for (uint32_t wi = 0; wi < wpl; ++wi) {
+        uint32_t z;
+        if (all_valid) {
+            z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
+        } else {
+            uint32_t kvw = (uint32_t)kv;
+            asm volatile("" : "+v"(kvw));
+            z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+        }
+        constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+        if (z <= Z_REDO) {
+            uint32_t kvw = (uint32_t)kv;
+            asm volatile("" : "+v"(kvw));
+            (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+        }
+        c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = 0;
+        r0 = r1;
+        if constexpr (KMODE == KM_GT16) { r1 = r2; r2 = rcword(c2, cmask); } else { r1 = rcword(c1, cmask); }
+        kv >>= 16;
+    }
+    return added;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // end of a work item, shared by the nucleotide and the amino-acid kernel: k-mer census, then the registers leave LDS
 // ------------------------------------------------------------------------------------------------------------
@@ -701,6 +1009,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
     uint32_t my_kmers = 0;
+    uint32_t tiles_dense = 0;                                               // direct mode, per wave: how many of its tiles needed dense_tile
 
     // One tile = blockDim.x * 4 words.  The next tile's words and break bits are loaded into registers before the
     // current tile is hashed (about 10k cycles of VALU work per tile cover the HBM latency).
@@ -777,34 +1086,71 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 else kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
             }
             if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull) {
-                // bytes outside the alphabet in this wave's tile: handled in place while the genome stays within its
-                // budget of such wave-tiles (sparse dirt), else the whole genome goes to the pack stage (dense dirt)
+                // bytes outside the alphabet in this wave's tile.  Sparse dirt (an IUPAC code, an N in a read): the lanes that own
+                // junction k-mers walk them, below.  Dense dirt — more than a quarter of the 4 KiB deleted, a junction k-mer whose
+                // bases lie beyond its lane's 96 bytes (the flank of a gap or of a soft-masked block), or a genome past its budget
+                // of walked wave-tiles: the wave compacts the tile in LDS and hashes the survivors (dense_tile).
+                const bool raw_ok = active && direct_fast(w0);                 // cur.q .. cur.a3 are this lane's own 64 bytes
+                {
+                    // the inside of a soft-masked block or of a gap: every active lane sees nothing but lower case / N -> nothing to do
+                    const bool gone = raw_ok && (hopeless_bits(cur.q) & hopeless_bits(cur.a1) & hopeless_bits(cur.a2) & hopeless_bits(cur.a3) &
+                                                 0x20202020u) == 0x20202020u;
+                    const uint64_t act = __builtin_amdgcn_ballot_w64(active);
+                    if (__builtin_amdgcn_ballot_w64(gone) == act) {
+                        // (raw_ok lanes own exactly their 64 bytes: the genome's tail is at least 32 bytes away)
+                        if ((threadIdx.x & 63) == 0 && part == 0u) atomicAdd(a.ndel + it.genome, 64u * (uint32_t)__builtin_popcountll(act));
+                        continue;
+                    }
+                }
                 uint32_t over = 0;
                 if ((threadIdx.x & 63) == 0) over = atomicAdd(a.nslow + it.genome, 1u) >= 32u + (uint32_t)(gd.byte_len >> 16);
-                if (__builtin_amdgcn_readfirstlane((int)over) != 0) {
-                    if ((threadIdx.x & 63) == 0) atomicOr(dirty, 1u);
-                    break;
-                }
+                // a quarter of the lanes met deleted bytes: dense without looking closer
+                bool dense = __builtin_amdgcn_readfirstlane((int)over) != 0 || __builtin_popcountll(__builtin_amdgcn_ballot_w64(bad != 0u)) >= 16;
                 uint32_t nd = 0;
                 uint64_t junc = 0, jstarts = 0;
-                if (active && bad != 0u) {
-                    const InvMask im = lane_inv_mask(gseq, pos0, L);
-                    const uint64_t W = window_or(im.lo, im.hi, k);            // windows that hold a deleted byte
-                    const uint64_t in_gen = L - pos0 >= 64 ? ~0ull : ((1ull << (L - pos0)) - 1ull);
-                    junc = ~im.lo & W & in_gen;                                // surviving first base, broken window
-                    jstarts = junc ? (~im.lo & in_gen & ~((1ull << __builtin_ctzll(junc)) - 1ull)) : 0ull;
-                    kv &= ~W;
-                    // deleted bytes this lane accounts for: its own 64, and the genome's last <= k-1 bytes when no lane starts there
-                    const uint64_t own = pos0 + 64 >= nk ? L - pos0 : 64;
-                    nd = (uint32_t)__builtin_popcountll(im.lo & in_gen) +
-                         (own > 64 ? (uint32_t)__builtin_popcount(im.hi & ((own >= 96 ? 0u : (1u << (own - 64))) - 1u)) : 0u);
+                if (!dense) {
+                    bool far = false;
+                    if (active && bad != 0u) {
+                        const InvMask im = lane_inv_mask(gseq, pos0, L);
+                        const uint64_t W = window_or(im.lo, im.hi, k);            // windows that hold a deleted byte
+                        const uint64_t in_gen = L - pos0 >= 64 ? ~0ull : ((1ull << (L - pos0)) - 1ull);
+                        junc = ~im.lo & W & in_gen;                                // surviving first base, broken window
+                        jstarts = junc ? (~im.lo & in_gen & ~((1ull << __builtin_ctzll(junc)) - 1ull)) : 0ull;
+                        kv &= ~W;
+                        // deleted bytes this lane accounts for: its own 64, and the genome's last <= k-1 bytes when no lane starts there
+                        const uint64_t own = pos0 + 64 >= nk ? L - pos0 : 64;
+                        nd = (uint32_t)__builtin_popcountll(im.lo & in_gen) +
+                             (own > 64 ? (uint32_t)__builtin_popcount(im.hi & ((own >= 96 ? 0u : (1u << (own - 64))) - 1u)) : 0u);
+                        if (junc) {
+                            // the last junction start needs k-1 survivors after it; are they among the lane's 96 bytes?
+                            const uint32_t bl = 63u - (uint32_t)__builtin_clzll(junc);
+                            const uint64_t in_gen_hi = L - pos0 >= 96 ? 0xFFFFFFFFull : (L - pos0 > 64 ? ((1ull << (L - pos0 - 64)) - 1ull) : 0ull);
+                            const uint64_t after = bl == 63u ? 0ull : (~im.lo & in_gen) >> (bl + 1u);
+                            far = (uint32_t)__builtin_popcountll(after) + (uint32_t)__builtin_popcountll(~(uint64_t)im.hi & in_gen_hi) < (uint32_t)k - 1u &&
+                                  pos0 + 96 < L;                               // (the genome's end cuts the walk short anyway)
+                        }
+                    }
+                    uint32_t wave_nd = nd;
+                    for (int o = 32; o > 0; o >>= 1) wave_nd += __shfl_xor(wave_nd, o, 64);
+                    dense = wave_nd > 1024u || __builtin_amdgcn_ballot_w64(far) != 0ull;
                 }
-                // more than a quarter of this wave's 4 KiB deleted: dense dirt (soft-masked block, long gap) -> pack stage, now
-                uint32_t wave_nd = nd;
-                for (int o = 32; o > 0; o >>= 1) wave_nd += __shfl_xor(wave_nd, o, 64);
-                if (wave_nd > 1024u) {
-                    if ((threadIdx.x & 63) == 0) atomicOr(dirty, 1u);
-                    break;
+                if (dense) {
+                    // Finely fragmented dirt (a repeat-masked assembly: a lower-case stretch every few hundred bases) makes nearly every
+                    // wave-tile a compaction; the pack stage does that at HBM speed and feeds the lean packed kernel, which is faster
+                    // from about three dense tiles in four (tools/dirty_rate.py: 5.9 vs 4.5 ms per 5 Gbp with 500-byte blocks).  The
+                    // wave's own tiles are a sample of the genome: past that ratio it hands the genome over.
+                    tiles_dense = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiles_dense) + 1u;
+                    const uint32_t tiles_seen = (tile - it.word_begin) / step + 1u;
+                    if (tiles_dense >= 6u && tiles_dense * 4u > tiles_seen * 3u && (threadIdx.x & 63) == 0)
+                        atomicOr(dirty, 1u);                                   // (seen by every wave of the genome at its next tile load)
+                    const uint64_t P0 = 16ull * (tile + (threadIdx.x & ~63u) * SKETCH_WORDS_PER_THREAD);
+                    uint64_t E = P0 + 4096 < 16ull * it.word_end ? P0 + 4096 : 16ull * it.word_end;
+                    E = E < L ? E : L;
+                    const uint32_t stage_b = a.stage_off + (threadIdx.x >> 6) * (DENSE_STAGE_WORDS * 4u);
+                    my_kmers += dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
+                                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
+                                                                   part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3);
+                    continue;
                 }
                 if (nd && part == 0u) atomicAdd(a.ndel + it.genome, nd);         // (the passes of a partitioned table see the same bytes)
                 if (junc)                                                      // (here, not after the hashing: nothing of it stays live)
@@ -1105,16 +1451,20 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
     return s;
 }
 
+uint32_t sketch_direct_stage_bytes(const SketchPlan &plan) { return (plan.threads / 64u) * DENSE_STAGE_WORDS * 4u; }
+
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
     auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT>;
-    if (plan.lds_bytes > 48u * 1024u) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+    SketchArgs a = args;
+    a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile)
+    const uint32_t lds = plan.lds_bytes + (DIRECT ? sketch_direct_stage_bytes(plan) : 0u);
+    if (lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(n_items), dim3(plan.threads), plan.lds_bytes, stream, args);
+    hipLaunchKernelGGL(kern, dim3(n_items), dim3(plan.threads), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -119,13 +119,14 @@ def test_direct_pass_backs_off_while_batches_are_dirty():
     batches keep turning out dirty, probing again every 8th call.  Results never change."""
     import lash_amd
     c = lash_amd.Context(0)
-    # dense dirt (every 97th byte lower-case: far over the in-place budget), so the direct pass gives these genomes up
+    # finely fragmented dirt (every 97th byte lower-case: every wave-tile would be a compaction), so the direct pass hands these
+    # genomes to the pack stage (sketch_kernels.hip: three dense wave-tiles in four)
     dirty = []
     for i in range(6):
-        g = O.synth_genome(40 + i, 200_000).copy()
+        g = O.synth_genome(40 + i, 1_000_000).copy()
         g[::97] |= 0x20
         dirty.append([g.tobytes()])
-    clean = [[O.synth_genome(50 + i, 200_000).tobytes()] for i in range(6)]
+    clean = [[O.synth_genome(50 + i, 1_000_000).tobytes()] for i in range(6)]
     sd, od, gd = lash_amd.records_to_arrays(dirty)
     sc, oc, gc = lash_amd.records_to_arrays(clean)
     want_d = oracle_images("hmh", 16, 0, 42, sd, od, gd)
