@@ -202,10 +202,10 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
 // which k-mer start positions of a lane's 64 are real k-mers of the reference's iterator?
 // position i is valid iff i + k <= L (genome end) and no record begins in (i, i+k-1].
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t kmer_valid_mask(uint32_t b0, uint32_t b1, uint32_t b2, uint64_t pos0, uint64_t nk, int k)
+__device__ __forceinline__ uint64_t kmer_valid_mask(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t pos0, uint32_t nk, int k)
 {
-    // b0..b2: break bits of positions pos0 .. pos0+95
-    const uint64_t lim = nk - pos0;                       // caller guarantees pos0 < nk
+    // b0..b2: break bits of positions pos0 .. pos0+95 (a genome has fewer than 2^32 - 64 bases)
+    const uint32_t lim = nk - pos0;                       // caller guarantees pos0 < nk
     const uint64_t kvm = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
     if ((b0 | b1 | b2) == 0u || k == 1) return kvm;
     // S(i) = OR_{d=1..k-1} B(i+d) by doubling on the 96-bit window
@@ -949,6 +949,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
     const int k = a.k, p = a.p;
     const uint64_t nk = L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0;     // k-mer start positions of the genome
+    // (a genome is shorter than 2^32 - 64 bytes: the per-tile tests are done on 32-bit word counts — one scalar register each
+    // instead of a pair and a 64-bit compare; the loop is short of scalar registers)
+    const uint32_t nk_words = (uint32_t)((nk + 15) >> 4);                // word w holds a k-mer start <=> w < nk_words
+    const uint32_t fast_words = L >= 96 ? (uint32_t)((L - 96) >> 4) + 1u : 0u;   // all 96 bytes from word w on are inside <=> w < fast_words
     if ((uint64_t)it.word_begin * 16 >= nk) {                             // slice beyond the surviving bases
         // the only work item of a genome too short for a single k-mer still owes the (empty) image; when the call
         // unions into existing images there is nothing to add
@@ -1018,13 +1022,13 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint32_t step = blockDim.x * SKETCH_WORDS_PER_THREAD;
     auto tile_active = [&](uint32_t tile) {
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
-        return tile < it.word_end && w0 < it.word_end && (uint64_t)w0 * 16 < nk;
+        return tile < it.word_end && w0 < it.word_end && w0 < nk_words;
     };
     // Loads are unconditional (inactive lanes and the prefetch past the last tile read a clamped, in-bounds
     // address): a predicated load sits in an exec-masked block and hipcc then waits for it at the block's end,
     // which would expose the HBM latency once per tile.
     const uint32_t w_last = it.word_end - SKETCH_WORDS_PER_THREAD;        // slices are >= 4 words, multiples of 4
-    auto direct_fast = [&](uint32_t w0) { return (uint64_t)w0 * 16 + 96 <= L; };   // all 96 bytes inside the genome
+    auto direct_fast = [&](uint32_t w0) { return w0 < fast_words; };              // all 96 bytes inside the genome
     auto tile_load = [&](uint32_t tile, TileRegs &t) {
         uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
         w0 = w0 < w_last ? w0 : w_last;
@@ -1069,10 +1073,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         uint64_t kv = 0;
         if constexpr (DIRECT) {
             // another workgroup (or an earlier tile) met a byte outside ACGT: this genome goes to the fallback path
-            if (__builtin_amdgcn_readfirstlane((int)cur.dflag) != 0) break;
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane((int)cur.dflag) != 0, 0)) break;
             uint32_t bad = 0;
             if (active) {
-                if (direct_fast(w0)) {
+                if (__builtin_expect(direct_fast(w0), 1)) {
                     c0 = ascii16_to_word(cur.q, bad, ctabs); c1 = ascii16_to_word(cur.a1, bad, ctabs); c2 = ascii16_to_word(cur.a2, bad, ctabs);
                     c3 = ascii16_to_word(cur.a3, bad, ctabs); c4 = ascii16_to_word(cur.la, bad, ctabs);
                     if constexpr (KMODE == KM_GT16) c5 = ascii16_to_word(cur.lb, bad, ctabs);
@@ -1082,10 +1086,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     if constexpr (KMODE == KM_GT16) c5 = t.w[5];
                     bad |= t.bad;
                 }
-                if (RL) { const Brk96 ub = uniform_breaks((uint32_t)pos0, RL, 96u); kv = kmer_valid_mask(ub.b0, ub.b1, ub.b2, pos0, nk, k); }
-                else kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
+                if (RL) { const Brk96 ub = uniform_breaks((uint32_t)pos0, RL, 96u); kv = kmer_valid_mask(ub.b0, ub.b1, ub.b2, (uint32_t)pos0, (uint32_t)nk, k); }
+                else kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, (uint32_t)pos0, (uint32_t)nk, k);
             }
-            if (__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) {      // (unlikely: keeps its spills out of the clean path)
                 // bytes outside the alphabet in this wave's tile.  Sparse dirt (an IUPAC code, an N in a read): the lanes that own
                 // junction k-mers walk them, below.  Dense dirt — more than a quarter of the 4 KiB deleted, a junction k-mer whose
                 // bases lie beyond its lane's 96 bytes (the flank of a gap or of a soft-masked block), or a genome past its budget
@@ -1150,6 +1154,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     my_kmers += dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
                                                                    (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
                                                                    part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3);
+                    // the prefetched tile is asked for again rather than kept alive across the call (24 registers that the clean
+                    // path would otherwise spill on every tile)
+                    tile_load(tile + step, nxt);
                     continue;
                 }
                 if (nd && part == 0u) atomicAdd(a.ndel + it.genome, nd);         // (the passes of a partitioned table see the same bytes)
@@ -1159,7 +1166,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             }
         } else if (active) {
             c0 = cur.q.x; c1 = cur.q.y; c2 = cur.q.z; c3 = cur.q.w; c4 = cur.c4; c5 = cur.c5;
-            kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, pos0, nk, k);
+            kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, (uint32_t)pos0, (uint32_t)nk, k);
         }
         my_kmers += (uint32_t)__builtin_popcountll(kv);
         // wave-uniform: every lane of this wave has 64 real k-mers -> no per-k-mer masking at all
