@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/profile_collect.py gpurun_out/<tag> [profiles/r02] — file the rocprofv3 summaries of tools/r02_profiles.sh under
-profiles/r02/<name>/ and recompute, per workload, what bench.py's roofline fields quote:
+"""tools/profile_collect.py gpurun_out/<tag> [profiles/rNN] — file the rocprofv3 summaries of tools/rNN_profiles.sh under
+profiles/rNN/<name>/ and recompute, per workload, what bench.py's roofline fields quote:
   profiles/traffic.json   HBM bytes per launch of the dominant kernel = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes; the x2 is
                           the gfx950 correction of MI355X_MICROARCH.md's HBM section, re-checked by the calibration run)
   profiles/valu.json      SQ_INSTS_VALU per k-mer of the dominant kernel + the measured issue ceiling (tools/ubench_hash)
@@ -34,6 +34,7 @@ def main():
     src = sys.argv[1]
     dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02"
     os.makedirs(dst, exist_ok=True)
+    rnd = int(re.search(r"r(\d+)", os.path.basename(dst.rstrip("/"))).group(1))
     traffic_path, valu_path = "profiles/traffic.json", "profiles/valu.json"
     traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
     valu = json.load(open(valu_path)) if os.path.exists(valu_path) else {}
@@ -89,25 +90,25 @@ def main():
         key = "%s%s_k%d_p%d_g%d_l%d" % ("direct_" if direct else "", cfg["algo"], cfg["k"], cfg["p"], cfg["genomes_per_gpu"], cfg["genome_length"])
         if hbm is not None and cfg.get("dirty", "none") == "none":
             traffic[key] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
-                            "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1; calibrated in the same session (profiles/r02/hbm_calibration.txt)",
-                            "source": "profiles/r02/%s/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes)" % name,
-                            "kernel": short, "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "round": 2}
+                            "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1; calibrated in the same session (%s/hbm_calibration.txt)" % dst,
+                            "source": "%s/%s/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes)" % (dst, name),
+                            "kernel": short, "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "round": rnd}
         vkey = "%s%s_k%d" % ("direct_" if direct else "", cfg["algo"], cfg["k"])
         if insts is not None and cfg.get("dirty", "none") == "none":
-            if cfg["genomes_per_gpu"] != 10000 or vkey not in valu:
+            if cfg["genomes_per_gpu"] not in (10000, 12500) or vkey not in valu or valu[vkey].get("round", 0) < rnd:
                 valu[vkey] = {"valu_insts_per_kmer": insts / (kmers / 64.0),
                               "note": "SQ_INSTS_VALU counts wave-instructions: per k-mer = SQ_INSTS_VALU / (k-mers / 64)",
-                              "source": "profiles/r02/%s/pmc_summary.txt" % name, "round": 2}
+                              "source": "%s/%s/pmc_summary.txt" % (dst, name), "round": rnd}
                 if (cfg["algo"], cfg["k"]) in floors:
                     valu[vkey]["issue_floor_kmers_per_s"] = floors[(cfg["algo"], cfg["k"])]
-                    valu[vkey]["floor_source"] = "profiles/r02/ubench_hash.txt (tools/ubench_hash, same session)"
+                    valu[vkey]["floor_source"] = "%s/ubench_hash.txt (tools/ubench_hash, same session)" % dst
         alg = roof["algorithmic_bytes_per_launch"]
         rows.append((name, short, dom_calls, dom_ms, roof["avg_launch_ms"], alg, alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK if dom_ms else None,
                      hbm, insts / (kmers / 64.0) if insts else None, j["value"]))
     json.dump(traffic, open(traffic_path, "w"), indent=1)
     json.dump(valu, open(valu_path, "w"), indent=1)
     with open(os.path.join(dst, "SUMMARY.md"), "w") as f:
-        f.write("# profiles/r02 — rocprofv3 summaries per workload (tools/r02_profiles.sh, one MI355X)\n\n"
+        f.write("# %s — rocprofv3 summaries per workload (tools/r%02d_profiles.sh, one MI355X)\n\n" % (dst, rnd) +
                 "| workload | dominant kernel | launches | avg ms (rocprofv3) | avg ms (HIP events, unprofiled run) | algorithmic bytes | frac of 8 TB/s | HBM bytes (PMC) | VALU wave-instr per 64 k-mers | k-mers/s |\n|---|---|---|---|---|---|---|---|---|---|\n")
         for r in rows:
             f.write("| %s | `%s` | %s | %s | %.3f | %.4g | %s | %s | %s | %.3e |\n" % (
