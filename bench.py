@@ -516,7 +516,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 key = "%s%s_k%d_p%d_g%d_l%d" % ("direct_" if direct else "", algo, k, p, G, L)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch") if args.dirty == "none" else None   # (the counter passes are of the clean workload)
             except Exception:
                 traffic = None
         out = {
