@@ -853,6 +853,14 @@ __device__ __noinline__ uint32_t dense_tile(const Regs regs, const KParams kp, c
 // ------------------------------------------------------------------------------------------------------------
 // end of a work item, shared by the nucleotide and the amino-acid kernel: k-mer census, then the registers leave LDS
 // ------------------------------------------------------------------------------------------------------------
+// sum of v over the wave's lanes, the same value in every lane's hands (six DPP adds + a readlane; cf. wave_excl_scan)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    uint32_t total;
+    (void)wave_excl_scan(v, total);
+    return total;
+}
+
 template <int ALGO, int REGS, class Regs>
 __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem &it, const Regs &regs, uint32_t *census, uint32_t part,
                                             uint32_t my_kmers, int p)
@@ -860,8 +868,7 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one store per item
     Regs::lds_wait();
-    for (int off = 32; off > 0; off >>= 1) my_kmers += __shfl_down(my_kmers, off, 64);
-    if ((threadIdx.x & 63) == 0) census[threadIdx.x >> 6] = my_kmers;
+    if ((threadIdx.x & 63) == 0) census[threadIdx.x >> 6] = my_kmers;          // my_kmers: the WAVE's count (wave-uniform)
     if constexpr (!USE_LDS) __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1151,26 +1158,31 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     uint64_t E = P0 + 4096 < 16ull * it.word_end ? P0 + 4096 : 16ull * it.word_end;
                     E = E < L ? E : L;
                     const uint32_t stage_b = a.stage_off + (threadIdx.x >> 6) * (DENSE_STAGE_WORDS * 4u);
-                    my_kmers += dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
-                                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
-                                                                   part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3);
+                    my_kmers += wave_sum(dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
+                                                                            (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
+                                                                            part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3));
                     // the prefetched tile is asked for again rather than kept alive across the call (24 registers that the clean
                     // path would otherwise spill on every tile)
                     tile_load(tile + step, nxt);
                     continue;
                 }
                 if (nd && part == 0u) atomicAdd(a.ndel + it.genome, nd);         // (the passes of a partitioned table see the same bytes)
+                uint32_t walked = 0;
                 if (junc)                                                      // (here, not after the hashing: nothing of it stays live)
-                    my_kmers += junction_walk<ALGO, XLOW, Regs>(regs, gseq, L, pos0, junc, jstarts, use_bitmap ? bk : nullptr, RL, k, kp.bitflip, p,
-                                                                cmask, ctabs, dirty);
+                    walked = junction_walk<ALGO, XLOW, Regs>(regs, gseq, L, pos0, junc, jstarts, use_bitmap ? bk : nullptr, RL, k, kp.bitflip, p,
+                                                             cmask, ctabs, dirty);
+                my_kmers += wave_sum(walked);
             }
         } else if (active) {
             c0 = cur.q.x; c1 = cur.q.y; c2 = cur.q.z; c3 = cur.q.w; c4 = cur.c4; c5 = cur.c5;
             kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, (uint32_t)pos0, (uint32_t)nk, k);
         }
-        my_kmers += (uint32_t)__builtin_popcountll(kv);
         // wave-uniform: every lane of this wave has 64 real k-mers -> no per-k-mer masking at all
         const bool all_valid = __builtin_amdgcn_ballot_w64(kv != ~0ull) == 0ull;
+        // the k-mer census is kept per WAVE in a scalar register (a vector register less across the hashing: the k > 16 kernels sit
+        // at their 128-register cap and spilled this one on every tile): 4 096 for a full tile, a wave sum otherwise
+        if (all_valid) my_kmers += 4096u;
+        else my_kmers += wave_sum((uint32_t)__builtin_popcountll(kv));
 
         uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
 #pragma unroll 1
@@ -1276,7 +1288,7 @@ __global__ void __launch_bounds__(256) aa_sketch_kernel(SketchArgs a)
         }
         for (; i < b1; ++i) residue(a.seq[i]);
     }
-    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p);
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, wave_sum(my_kmers), p);
 }
 
 template <int ALGO, bool XLOW>
