@@ -179,6 +179,9 @@ template <class T>
 T compute_distance(T frac, int k, int model)
 {
     const T kk = (T)k;
+    // frac == 0 (no similarity left after the collision correction: nearly every pair of an all-vs-all): both models give exactly 1 —
+    // -ln(0) / k = +inf -> min(.., 1) = 1;  1 - 0^(1/k) = 1 — without the libm call (glibc's pow(0, y) alone is 45 ns)
+    if (frac == (T)0) return (T)1;
     if (model == 1) { const T d = -std::log(frac) / kk; return d < (T)1 ? d : (T)1; }      // (-frac.ln() / k).min(1)
     return (T)1 - std::pow(frac, (T)1 / kk);
 }

@@ -63,11 +63,15 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     tile_begin[n_genomes] = (uint32_t)n_tiles;
     TRACE("pack: tables built");
     int rc;
-    if ((rc = reserve(ctx, pk->words, pk->total_words * 4))) return rc;
-    if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
-    if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
-    const size_t lb_bytes = (((size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512) + 15) & ~(size_t)15;
-    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(4 * (size_t)n_genomes + 2) * 4))) return rc;
+    // direct mode packs nothing (round 3: the genomes the direct pass gives up are redone from their ASCII bytes by
+    // stream_sketch_kernel), so there is no 2-bit stream, no tile table and no look-back state to make room for
+    if (!direct) {
+        if ((rc = reserve(ctx, pk->words, pk->total_words * 4))) return rc;
+        if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
+        if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
+    }
+    const size_t lb_bytes = direct ? 0 : (((size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512) + 15) & ~(size_t)15;
+    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(5 * (size_t)n_genomes + 2) * 4))) return rc;
     pk->d_dirty = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(pk->lookback.ptr) + lb_bytes);
     if (direct && (rc = reserve(ctx, pk->tile_begin_c, (size_t)(n_genomes + 2) * 4))) return rc;
     if (n_genomes == 0) return LASH_OK;
@@ -96,7 +100,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
         pk->d_nvalid = reinterpret_cast<uint64_t *>(tb + sec[2].off);
         TRACE("pack: tables uploaded");
         if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
-        HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (formats ? (size_t)(4 * (size_t)n_genomes + 2) * 4 : 0), stream));
+        HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (formats ? (size_t)(5 * (size_t)n_genomes + 2) * 4 : 0), stream));
         TRACE("pack: memsets queued");
     } else {
         // direct mode: tables go up together with the work items (sketch_from), the pack launch follows the direct pass
@@ -129,10 +133,8 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pm.tiles = static_cast<TileInfo *>(pk->tiles.ptr);
     pm.n_tiles = (uint32_t)n_tiles;
     pm.n_genomes = n_genomes;
-    pk->error_flag = v2.error_flag;
-    if (direct) {                                             // launched by pack_dirty() after the direct sketch pass
-        pk->pa = pa; pk->v2 = v2; pk->pm = pm;
-    } else {
+    pk->error_flag = direct ? nullptr : v2.error_flag;        // (direct mode launches no pack kernel)
+    if (!direct) {
         HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, formats != nullptr, stream));
         if (formats) {
             // FASTQ files: quality-line lengths and how the file ends, into the same flags (fastq_check.hip)
@@ -162,13 +164,12 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     return LASH_OK;
 }
 
-// direct mode, second half: pack exactly the genomes whose dirty flag the direct sketch pass set.  Which ones is
-// decided on the device (scan of the flagged genomes' tile counts), so the host queues this without waiting.
-int pack_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
+// direct mode, feedback: how much of the batch (in 16 KiB tiles) lies in genomes the direct pass gave up — counted on the device,
+// copied to a pinned word without waiting; lash_sketch_batch_device looks at it before its next call (dirty_frac).
+int probe_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 {
     uint32_t *tbc = static_cast<uint32_t *>(pk->tile_begin_c.ptr);
-    HIPCHK(ctx, launch_dirty_tile_scan(pk->pm.tile_begin, pk->d_dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
-    if (pk->any_multi) HIPCHK(ctx, launch_zero_dirty_brk(pk->d_descs, pk->d_dirty, pk->n_genomes, static_cast<uint32_t *>(pk->brk.ptr), stream));
+    HIPCHK(ctx, launch_dirty_tile_scan(pk->d_tile_begin, pk->d_dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
     if (!ctx->probe_host) {
         HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->probe_host), 64, hipHostMallocDefault));
         ctx->probe_host[0] = 0;
@@ -178,13 +179,8 @@ int pack_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
         HIPCHK(ctx, hipMemcpyAsync(ctx->probe_host, tbc + pk->n_genomes + 1, 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(ctx, hipEventRecord(ctx->probe_ev, stream));
         ctx->probe_pending = true;
-        ctx->probe_tiles = pk->pm.n_tiles;
+        ctx->probe_tiles = pk->h_tile_begin.empty() ? 0 : pk->h_tile_begin.back();
     }
-    PackV2Args v2 = pk->v2;
-    PackMapArgs pm = pk->pm;
-    pm.tile_begin = tbc;
-    pm.n_tiles_dev = v2.n_tiles_dev = tbc + pk->n_genomes + 1;
-    HIPCHK(ctx, launch_pack_v2(pk->pa, v2, pm, (uint32_t)ctx->cu_count, false, stream));
     return LASH_OK;
 }
 
@@ -260,11 +256,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             mpk->d_descs = reinterpret_cast<GenomeDesc *>(tb + sec[2].off);
             mpk->d_tile_begin = reinterpret_cast<uint32_t *>(tb + sec[3].off);
             mpk->d_nvalid = reinterpret_cast<uint64_t *>(tb + sec[4].off);
-            mpk->pa.genomes = mpk->pm.genomes = pk->d_descs;
-            mpk->pa.nvalid = pk->d_nvalid;
-            mpk->pm.tile_begin = pk->d_tile_begin;
-            const size_t lb_bytes = reinterpret_cast<uint8_t *>(pk->d_dirty) - static_cast<uint8_t *>(pk->lookback.ptr);
-            HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (size_t)(4 * (size_t)n_genomes + 2) * 4, ctx->stream));
+            // flags and counters of the direct pass: dirty [n+1] | nslow [n] | ndel [n] | nonuniform [n] +1 | ndel2 [n]
+            HIPCHK(ctx, hipMemsetAsync(pk->d_dirty, 0, (size_t)(5 * (size_t)n_genomes + 2) * 4, ctx->stream));
             if (pk->any_multi) {
                 // record starts in BYTE positions: genomes whose records are all equally long (read sets) get theirs computed in
                 // the sketch kernel, the others a bitmap every word of which brk_bytes_kernel writes (no memset).  The
@@ -326,11 +319,17 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.nonuniform = pk->d_dirty + 3 * (size_t)n_genomes + 1;
         sa.nslow = pk->d_dirty + n_genomes + 1;
         sa.ndel = sa.nslow + n_genomes;
-        HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true));     // ASCII in, exact while nothing is deleted
-        if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
-        if ((rc = pack_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
-        HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, false));    // the flagged genomes, from their 2-bit form
-        ctx->last.direct_launches += n_items ? 1 : 0;
+        sa.ndel2 = pk->d_dirty + 4 * (size_t)n_genomes + 2;
+        if (!pk->stream_first) {
+            HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
+            if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
+            if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
+            ctx->last.direct_launches += n_items ? 1 : 0;
+        } else {
+            // recent batches were full of finely fragmented dirt: every genome goes straight to the compacting kernel
+            HIPCHK(ctx, hipMemsetAsync(pk->d_dirty, 0x01, (size_t)n_genomes * 4, ctx->stream));
+        }
+        HIPCHK(ctx, launch_sketch_stream(plan, sa, n_items, ctx->stream));    // the flagged genomes, compacted on the fly
     } else {
         HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream));
     }
@@ -785,12 +784,12 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
         std::vector<uint64_t> nv(pk->n_genomes);
         HIPCHK(ctx, hipMemcpy(nv.data(), pk->d_nvalid, nv.size() * 8, hipMemcpyDeviceToHost));
         for (uint64_t v : nv) t.bases_last += v;
-        if (pk->direct) {                                          // bytes the direct pass deleted in place (genomes it kept)
-            const uint32_t n = pk->n_genomes;
-            std::vector<uint32_t> fl(3 * (size_t)n + 1);
+        if (pk->direct) {                                          // bytes deleted: by the direct pass in the genomes it kept, by
+            const uint32_t n = pk->n_genomes;                      // the compacting kernel in the ones it took over
+            std::vector<uint32_t> fl(5 * (size_t)n + 2);
             HIPCHK(ctx, hipMemcpy(fl.data(), pk->d_dirty, fl.size() * 4, hipMemcpyDeviceToHost));
             for (uint32_t g = 0; g < n; ++g)
-                if (!fl[g]) t.bases_last -= fl[2 * (size_t)n + 1 + g];
+                t.bases_last -= fl[g] ? fl[4 * (size_t)n + 2 + g] : fl[2 * (size_t)n + 1 + g];
         }
     }
     *out = t;
@@ -876,10 +875,13 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
     }
     // (the alternative k-mer / bucket rules of a non-default layout exist for packed input only)
     bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct && !layout_alt(ctx->layout, prm->algo);
+    bool stream_first = false;
     if (direct && ctx->dirty_frac > 0.2f) {
-        if (++ctx->direct_skipped < 8) direct = false;          // pack first; try again every 8th call
+        if (++ctx->direct_skipped < 8) stream_first = true;     // skip the optimistic pass; try it again every 8th call
         else ctx->direct_skipped = 0;
     }
+    static const bool env_stream_first = getenv("LASH_STREAM_FIRST") != nullptr;     // A/B knob for tools/ (like LASH_NO_DIRECT)
+    ctx->scratch.stream_first = (stream_first || env_stream_first) && direct;
     rc = pack_into(ctx, &ctx->scratch, ctx->stream, ev, d_seq, d_seq + genome_byte_off[n_genomes], d_rec_off, n_rec,
                    genome_rec_off, genome_byte_off, n_genomes, nullptr, direct);
     if (rc) return rc;

@@ -80,6 +80,7 @@ struct lash_packed {
     const uint8_t *d_seq = nullptr;
     uint32_t *d_dirty = nullptr;         // inside `lookback` (zeroed by the same memset): [n+1] dirty flags, then [n] slow
                                          // wave-tile counts and [n] in-place deleted-byte counts of the direct pass
+    bool stream_first = false;       // direct mode: skip the optimistic pass, every genome goes to stream_sketch_kernel
     DevBuf tile_begin_c, brk_bytes, fq;                       // fq: FASTQ file table + scratch of fastq_check.hip
     std::vector<GenomeDesc> h_descs;     // host copies, uploaded together with the work items
     std::vector<uint32_t> h_tile_begin;

@@ -30,6 +30,7 @@ struct SketchArgs {
                                   // deleted bytes); [n_genomes] = how many.  Non-direct launches with dirty != NULL run only these
     uint32_t         *nslow;      // [n_genomes] wave-tiles of the direct pass that met deleted bytes (budget: sketch_kernels.hip)
     uint32_t         *ndel;       // [n_genomes] bytes the direct pass deleted in place (surviving bases = nvalid - ndel while !dirty)
+    uint32_t         *ndel2;      // [n_genomes] bytes stream_sketch_kernel deleted in the genomes it took over (zeroed)
     const uint64_t   *rec_off;    // direct mode: the caller's record offsets (uniform-length genomes derive their record starts from them)
     const uint32_t   *nonuniform; // direct mode: [n_genomes], 0 = all records of the genome have the same length (rec_uniform_kernel):
                                   // its record starts are the multiples of that length, no bitmap is made or read for it
@@ -58,6 +59,8 @@ struct SketchPlan {
 
 // small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)
 SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false);
+// the genomes flagged in args.dirty, again from their ASCII bytes, compacted through an LDS ring per wave (stream_sketch_kernel)
+hipError_t launch_sketch_stream(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream);
 // direct launches: bytes of LDS the waves' staging areas take on top of plan.lds_bytes (they start at plan.lds_bytes)
 uint32_t sketch_direct_stage_bytes(const SketchPlan &plan);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,

@@ -1152,7 +1152,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     // wave's own tiles are a sample of the genome: past that ratio it hands the genome over.
                     tiles_dense = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiles_dense) + 1u;
                     const uint32_t tiles_seen = (tile - it.word_begin) / step + 1u;
-                    if (tiles_dense >= 6u && tiles_dense * 4u > tiles_seen * 3u && (threadIdx.x & 63) == 0)
+                    if (tiles_dense >= 4u && tiles_dense * 8u > tiles_seen && (threadIdx.x & 63) == 0)
                         atomicOr(dirty, 1u);                                   // (seen by every wave of the genome at its next tile load)
                     const uint64_t P0 = 16ull * (tile + (threadIdx.x & ~63u) * SKETCH_WORDS_PER_THREAD);
                     uint64_t E = P0 + 4096 < 16ull * it.word_end ? P0 + 4096 : 16ull * it.word_end;
@@ -1220,6 +1220,322 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
 
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// stream_sketch_kernel — the genomes the direct pass gave up (dense_tile's fallback ratio, a gap beyond DENSE_SCAN_MAX), still
+// from their ASCII bytes and in ONE pass: no 2-bit round trip through HBM, no second kernel.
+//
+// Same work items as the direct pass.  Each wave takes a CONTIGUOUS part of the item's bytes and walks it 2 KiB at a time:
+// classify (32 bytes per lane), DPP prefix sum, survivors appended to a wave-private ring in LDS (the staging area of
+// dense_tile: 260 words of 2-bit codes + 130 words of record-start bits) — and whenever the ring holds 2 048 bases plus the k-1
+// that follow them, a batch of 2 048 k-mer starts is hashed: two packed words per lane, every lane busy, the clean path's
+// process_word.  Because a wave reads its bytes in order there is nothing to look ahead for or to round up: the k-mers of a
+// wave are those whose first base is a surviving byte of its part, so after its last byte it keeps reading until k-1 more
+// bases have survived (or the record / genome ends), then hashes what is left under a mask.
+// ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t RING_W = 260, RING_BW = 130;          // code words / record-start words (4 160 bases); both fit DENSE_STAGE_WORDS
+constexpr uint32_t STREAM_CHUNK = 2048, STREAM_BATCH = 2048;
+static_assert(RING_W <= DENSE_STAGE_CODE_WORDS && RING_BW <= DENSE_STAGE_BRK_WORDS, "the ring lives in dense_tile's staging area");
+
+template <int ALGO, int KMODE, bool XLOW, int REGS>
+__global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
+    const WorkItem it = a.items[blockIdx.x];
+    if (a.dirty[it.genome] == 0u) return;                                  // only the genomes the direct pass gave up
+    const GenomeDesc gd = a.genomes[it.genome];
+    const uint64_t L = gd.byte_len;
+    const int k = a.k, p = a.p;
+    const uint64_t nkg = L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0;
+    if ((uint64_t)it.word_begin * 16 >= nkg) {                            // (as in sketch_kernel: the item holds no k-mer start)
+        if ((it.slice & ITEM_SOLE) && !a.accumulate) {
+            uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
+            for (uint64_t i = threadIdx.x; i < a.image_bytes; i += blockDim.x) img[i] = 0;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint64_t n_regs = ALGO == 0 ? HMH_M : (1ull << p);
+                write_header(img, a.lay.hdr_tpl, a.alpha_bits, n_regs, n_regs, (double)n_regs, ALGO == 0 ? HMH_P : p);
+            }
+        }
+        return;
+    }
+    constexpr bool USE_LDS = REGS != REGS_GLOBAL;
+    using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type;
+    Regs regs;
+    uint32_t *census;
+    const uint32_t part = it.slice >> 16;
+    if constexpr (USE_LDS) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
+        regs.base = lds_regs;
+        if constexpr (REGS == REGS_LDS_PARTS) {
+            regs.local_mask = a.nreg32 - 1u;
+            regs.part_shift = 31u - (uint32_t)__builtin_clz(a.nreg32);
+            regs.part = part;
+        }
+        census = lds_regs + a.nreg32;
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
+    } else {
+        regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;
+        census = lds_regs;
+    }
+    const bool multi_rec = gd.rec_end - gd.rec_begin > 1;
+    uint32_t RL = 0;
+    if (multi_rec && a.nonuniform[it.genome] == 0u) RL = (uint32_t)(a.rec_off[gd.rec_begin + 1] - a.rec_off[gd.rec_begin]);
+    const uint32_t *__restrict__ bk = (multi_rec && RL == 0u) ? a.brk_bytes + gd.brk_off : nullptr;
+    const bool breaks = bk != nullptr || RL != 0u;
+    const uint8_t *__restrict__ gseq = a.seq + gd.byte_off;
+    KParams kp;
+    kp.bitflip = a.bitflip;
+    kp.p = p;
+    kp.sh_lt = 32u - 2u * (uint32_t)k;
+    kp.mask_lt = (KMODE == KM_LT16) ? ((1u << (2 * k)) - 1u) : 0xFFFFFFFFu;
+    kp.sh_gt = 64u - 2u * (uint32_t)k;
+    kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    kp.lsb_xor = 0ull;
+    const uint32_t cmask = a.lay.comp_mask;
+    const CodeTabs ct{a.lay.code_lo, a.lay.code_hi};
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t stage_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.stage_off + wave * (DENSE_STAGE_WORDS * 4u)));
+    const uint32_t brk_b = stage_b + 4u * DENSE_STAGE_CODE_WORDS;
+    lds_u32 *const ring = (lds_u32 *)(uintptr_t)stage_b;
+    lds_u32 *const bring = (lds_u32 *)(uintptr_t)brk_b;
+    for (uint32_t i = lane; i < DENSE_STAGE_WORDS; i += 64u) ring[i] = 0;
+    __syncthreads();                                                       // the register table and every ring are clear
+
+    // this wave's part of the item: [ws, we) in genome bytes, 2 KiB-aligned relative to the item's first byte
+    const uint64_t B0 = 16ull * it.word_begin, B1 = 16ull * it.word_end < L ? 16ull * it.word_end : L;
+    const uint64_t span = (((B1 - B0 + n_waves - 1) / n_waves) + STREAM_CHUNK - 1) & ~(uint64_t)(STREAM_CHUNK - 1);
+    const uint64_t ws = B0 + (uint64_t)wave * span, we = ws + span < B1 ? ws + span : B1;
+    uint32_t my_kmers = 0;
+    if (ws < B1) {
+        const uint32_t want = (uint32_t)k - 1u;                            // bases a k-mer needs after its first
+        uint32_t head_w = 0, have = 0, own_left = 0, la_have = 0, own_seen = 0;   // wave-uniform ring state (bases after head; ...)
+        bool pend = false, stop = false;
+        // one batch of `nstarts` k-mer starts (<= 2 048) from the ring's head; the ring must hold nstarts + k - 1 bases (or end there)
+        auto hash_batch = [&](uint32_t nstarts) {
+            const uint32_t pos0 = 32u * lane;
+            const bool active = pos0 < nstarts;
+            const uint32_t junk = (threadIdx.x + 1u) * 0x9E3779B1u;
+            uint32_t c0 = junk, c1 = ~junk, c2 = junk, c3 = ~junk;
+            uint32_t kvw = 0;
+            auto rw = [&](uint32_t j) { uint32_t w = head_w + 2u * lane + j; w = w >= RING_W ? w - RING_W : w; return w; };
+            const uint32_t w0 = rw(0), w1 = rw(1);
+            if (active) {
+                c0 = ring[w0]; c1 = ring[w1]; c2 = ring[rw(2)]; c3 = ring[rw(3)];
+                uint32_t b0 = 0, b1 = 0;
+                if (breaks) {
+                    uint32_t bw = (head_w >> 1) + lane; bw = bw >= RING_BW ? bw - RING_BW : bw;
+                    const uint32_t bw1 = bw + 1u == RING_BW ? 0u : bw + 1u;
+                    b0 = bring[bw]; b1 = bring[bw1];
+                }
+                kvw = (uint32_t)kmer_valid_mask(b0, b1, 0u, pos0, nstarts, k);
+            }
+            const bool all_valid = __builtin_amdgcn_ballot_w64(kvw != 0xFFFFFFFFu) == 0ull;
+            my_kmers += all_valid ? 2048u : wave_sum((uint32_t)__builtin_popcount(kvw));
+            // the batch's words are free again (appends OR into zeroed words); the two after it belong to the next batch
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            ring[w0] = 0; ring[w1] = 0;
+            if (breaks) { uint32_t bw = (head_w >> 1) + lane; bw = bw >= RING_BW ? bw - RING_BW : bw; bring[bw] = 0; }
+            uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
+#pragma unroll 1
+            for (int wi = 0; wi < 2; ++wi) {
+                uint32_t z;
+                if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
+                else {
+                    uint32_t m = kvw;
+                    asm volatile("" : "+v"(m));
+                    z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, m);
+                }
+                constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+                if (z <= Z_REDO) {
+                    uint32_t m = kvw;
+                    asm volatile("" : "+v"(m));
+                    (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, m);
+                }
+                c0 = c1; c1 = c2; c2 = c3; c3 = 0;
+                r0 = r1;
+                if constexpr (KMODE == KM_GT16) { r1 = r2; r2 = rcword(c2, cmask); } else { r1 = rcword(c1, cmask); }
+                kvw >>= 16;
+            }
+            head_w += STREAM_BATCH / 16u;
+            head_w = head_w >= RING_W ? head_w - RING_W : head_w;
+        };
+        // the chunk's bytes, 32 per lane, asked for one chunk ahead (lanes whose 32 bytes are not all inside the genome read a
+        // dummy line and fetch their bytes one by one when their turn comes)
+        auto chunk_load = [&](uint64_t cp, uint4 &x0, uint4 &x1) {
+            const uint64_t ca = cp + 32ull * lane;
+            const uint8_t *src = ca + 32 <= L ? gseq + ca : a.safe;
+            x0 = load16_any(src); x1 = load16_any(src + 16);
+        };
+        uint4 n0, n1;
+        chunk_load(ws, n0, n1);
+        for (uint64_t pos = ws; pos < L && !stop; pos += STREAM_CHUNK) {
+            if (pos >= we && (own_left == 0u || la_have >= want)) break;    // nothing owned waits for more bases
+            const uint64_t at = pos + 32ull * lane;
+            uint4 q0 = n0, q1 = n1;
+            chunk_load(pos + STREAM_CHUNK, n0, n1);
+            if (at + 32 > L) {
+                uint32_t d[8];
+                for (int i = 0; i < 8; ++i) d[i] = 0x4E4E4E4Eu;                  // 'N': beyond the genome nothing survives
+                for (uint32_t i = 0; i < 32 && at + i < L; ++i) d[i >> 2] = (d[i >> 2] & ~(0xFFu << (8 * (i & 3)))) | ((uint32_t)gseq[at + i] << (8 * (i & 3)));
+                q0 = make_uint4(d[0], d[1], d[2], d[3]); q1 = make_uint4(d[4], d[5], d[6], d[7]);
+            }
+            // ---- classification in three steps: is anything deleted at all? (most chunks of most genomes: no) — is anything left?
+            //      (the inside of a masked block: no) — else which bytes ----
+            uint32_t bad = 0;
+            const uint32_t cw0 = ascii16_to_word(q0, bad, ct), cw1 = ascii16_to_word(q1, bad, ct);
+            const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we && !breaks;
+            uint32_t T, own_t;
+            if (chunk_clean) {
+                // 2 048 survivors, all owned, no record starts: lane i's 32 bases go to ring position have + 32 i, one shift for all
+                const uint32_t rel = have + 32u * lane, sh = 2u * (rel & 15u);
+                uint32_t w = head_w + (rel >> 4); w = w >= RING_W ? w - RING_W : w;
+                const uint32_t w1 = w + 1u == RING_W ? 0u : w + 1u, w2 = w1 + 1u == RING_W ? 0u : w1 + 1u;
+                if (sh) {
+                    lds_or(stage_b + 4u * w, cw0 >> sh);
+                    lds_or(stage_b + 4u * w1, (cw0 << (32u - sh)) | (cw1 >> sh));
+                    lds_or(stage_b + 4u * w2, cw1 << (32u - sh));
+                } else {
+                    lds_or(stage_b + 4u * w, cw0);
+                    lds_or(stage_b + 4u * w1, cw1);
+                }
+                T = STREAM_CHUNK; own_t = STREAM_CHUNK;
+            } else {
+            uint32_t v;
+            if (__builtin_amdgcn_ballot_w64((hopeless_bits(q0) & hopeless_bits(q1) & 0x20202020u) != 0x20202020u) == 0ull) v = 0u;
+            else v = ~(inv16(q0) | (inv16(q1) << 16));                         // bit j: byte j survives (bytes past L are 'N')
+            const uint32_t own_n = at >= we ? 0u : (we - at >= 32 ? 32u : (uint32_t)(we - at));
+            const uint32_t ownmask = own_n >= 32u ? 0xFFFFFFFFu : ((1u << own_n) - 1u);
+            // ---- record starts land on the first survivor at or after them (cf. dense_tile); one that lands BEYOND the part ends it ----
+            uint32_t recv = 0;
+            if (breaks) {
+                uint32_t rb = 0;
+                if (at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
+                const uint32_t fill = ~v, rbd = rb & fill;
+                const bool gen = fill + rbd < rbd;
+                const uint64_t G = __builtin_amdgcn_ballot_w64(gen), Z = __builtin_amdgcn_ballot_w64(v == 0u);
+                const uint64_t below = (1ull << lane) - 1ull, nz = ~Z & below;
+                const uint64_t from = nz ? ~((1ull << (63 - __builtin_clzll(nz))) - 1ull) : ~0ull;
+                const bool pend_in = (G & below & from) != 0ull || (nz == 0ull && pend);
+                recv = ((fill + rbd + (pend_in ? 1u : 0u)) | rb) & v;
+                const uint64_t nzall = ~Z;
+                pend = nzall ? (G >> (63 - __builtin_clzll(nzall))) != 0ull : (pend || G != 0ull);
+                const uint32_t cut = recv & ~ownmask;                             // the next record opens here, past this wave's part
+                const uint64_t Cm = __builtin_amdgcn_ballot_w64(cut != 0u);
+                if (Cm) {
+                    const uint32_t fl = (uint32_t)__builtin_ctzll(Cm);
+                    if (lane > fl) v &= ownmask;
+                    else if (lane == fl) v &= ownmask | ((1u << __builtin_ctz(cut)) - 1u);
+                    stop = true;
+                }
+            }
+            const uint32_t n_all = (uint32_t)__builtin_popcount(v);
+            const uint32_t off = wave_excl_scan(n_all, T);
+            if (T == 0u) continue;                                             // nothing survives in this chunk
+            own_t = pos + STREAM_CHUNK <= we ? T : (pos >= we ? 0u : wave_sum((uint32_t)__builtin_popcount(v & ownmask)));
+            // ---- append: two 16-byte groups per lane at ring position have + off ----
+            {
+                uint32_t rel = have + off;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t m = (v >> (16 * c)) & 0xFFFFu;
+                    uint32_t cb;
+                    const uint32_t bits = compact16(c ? cw1 : cw0, m, (recv >> (16 * c)) & 0xFFFFu, cb);
+                    const uint32_t n = (uint32_t)__builtin_popcount(m);
+                    if (n) {
+                        uint32_t w = head_w + (rel >> 4); w = w >= RING_W ? w - RING_W : w;
+                        const uint32_t wn = w + 1u == RING_W ? 0u : w + 1u, sh = 2u * (rel & 15u);
+                        lds_or(stage_b + 4u * w, bits >> sh);
+                        if (sh && (rel & 15u) + n > 16u) lds_or(stage_b + 4u * wn, bits << (32u - sh));
+                        if (breaks && cb) {
+                            uint32_t bw = (head_w >> 1) + (rel >> 5); bw = bw >= RING_BW ? bw - RING_BW : bw;
+                            const uint32_t bwn = bw + 1u == RING_BW ? 0u : bw + 1u, bs = rel & 31u;
+                            lds_or(brk_b + 4u * bw, cb << bs);
+                            if (bs && bs + n > 32u) lds_or(brk_b + 4u * bwn, cb >> (32u - bs));
+                        }
+                    }
+                    rel += n;
+                }
+            }
+            }
+            have += T; own_left += own_t; own_seen += own_t; la_have += T - own_t;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            while (have >= STREAM_BATCH + want && own_left > 0u) {
+                const uint32_t ns = own_left < STREAM_BATCH ? own_left : STREAM_BATCH;
+                hash_batch(ns);
+                have -= STREAM_BATCH; own_left -= ns;
+                if (ns < STREAM_BATCH) break;                                  // (the owned starts are done; what is left in the ring is look-ahead)
+            }
+        }
+        // ---- what is left: starts that have their k-1 followers, in batches, the rest of the ring behind them ----
+        while (own_left > 0u) {
+            const uint32_t room = have >= (uint32_t)k ? have - want : 0u;      // starts whose whole window is in the ring
+            uint32_t ns = own_left < STREAM_BATCH ? own_left : STREAM_BATCH;
+            ns = ns < room ? ns : room;
+            if (ns == 0u) break;
+            hash_batch(ns);
+            have = have > STREAM_BATCH ? have - STREAM_BATCH : 0u;
+            own_left -= ns;
+            if (ns < STREAM_BATCH) break;
+        }
+        // surviving bases of this wave's part (lash_timing::bases_last)
+        if (lane == 0 && part == 0u && a.ndel2) atomicAdd(a.ndel2 + it.genome, (uint32_t)(we - ws) - own_seen);
+    }
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p);
+}
+
+template <int ALGO, int KMODE, bool XLOW, int REGS>
+static hipError_t launch_stream_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
+{
+    auto kern = stream_sketch_kernel<ALGO, KMODE, XLOW, REGS>;
+    SketchArgs a = args;
+    a.stage_off = plan.lds_bytes;
+    const uint32_t lds = plan.lds_bytes + sketch_direct_stage_bytes(plan);
+    if (lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_items), dim3(plan.threads), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int ALGO, bool XLOW>
+static hipError_t launch_stream_kmode(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
+{
+    const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
+    if constexpr (ALGO != 0) {
+        if (plan.use_lds && plan.parts_log2) {
+            if (km == KM_16) return launch_stream_one<ALGO, KM_16, XLOW, REGS_LDS_PARTS>(plan, args, n, s);
+            if (km == KM_LT16) return launch_stream_one<ALGO, KM_LT16, XLOW, REGS_LDS_PARTS>(plan, args, n, s);
+            return launch_stream_one<ALGO, KM_GT16, XLOW, REGS_LDS_PARTS>(plan, args, n, s);
+        }
+    }
+    if (plan.use_lds) {
+        if (km == KM_16) return launch_stream_one<ALGO, KM_16, XLOW, REGS_LDS>(plan, args, n, s);
+        if (km == KM_LT16) return launch_stream_one<ALGO, KM_LT16, XLOW, REGS_LDS>(plan, args, n, s);
+        return launch_stream_one<ALGO, KM_GT16, XLOW, REGS_LDS>(plan, args, n, s);
+    }
+    if constexpr (ALGO == 2) {
+        if (km == KM_16) return launch_stream_one<ALGO, KM_16, XLOW, REGS_GLOBAL>(plan, args, n, s);
+        if (km == KM_LT16) return launch_stream_one<ALGO, KM_LT16, XLOW, REGS_GLOBAL>(plan, args, n, s);
+        return launch_stream_one<ALGO, KM_GT16, XLOW, REGS_GLOBAL>(plan, args, n, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_sketch_stream(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
+{
+    if (n_items == 0) return hipSuccess;
+    if (plan.alt) return hipErrorInvalidValue;
+    switch (plan.algo) {
+    case 0: return plan.x_low ? launch_stream_kmode<0, true>(plan, args, n_items, stream) : launch_stream_kmode<0, false>(plan, args, n_items, stream);
+    case 1: return launch_stream_kmode<1, false>(plan, args, n_items, stream);
+    case 2: return launch_stream_kmode<2, false>(plan, args, n_items, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

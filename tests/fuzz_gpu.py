@@ -25,8 +25,20 @@ def random_genome(rng):
                         rng.choice([63, 64, 65, 95, 96, 97, 2047, 2048, 2049, 4096, 16384, 16385, 32768]),
                         rng.choice([262_144, 262_145, rng.randint(300_000, 2_500_000)]) if rng.random() < 0.3 else 1000])   # several slices
         s = bytearray(O.synth_genome(rng.randint(0, 10**6), max(L, 1)).tobytes()[:L])
-        if kind < 0.45:
+        if kind < 0.3:
             pass                                            # clean
+        elif kind < 0.45 and L:
+            # block dirt: soft-masked stretches and gaps of 50 bytes .. 200 kb (whole wave-tiles deleted, tiles that end inside a
+            # run, runs that span slices and records) — what the in-kernel compaction (dense_tile) exists for
+            pos = rng.randrange(L)
+            while pos < L:
+                run = min(rng.choice([50, 300, 1000, 4096, 5000, 12_000, 40_000, 200_000]), L - pos)
+                fill = rng.choice([b"N", b"n", None])
+                if fill is None:
+                    s[pos:pos + run] = bytes(s[pos:pos + run]).lower()
+                else:
+                    s[pos:pos + run] = fill * run
+                pos += run + rng.choice([1, 5, 15, 16, 31, 64, 700, 4096, 9000, 60_000])
         elif kind < 0.7 and L:
             for _ in range(rng.randint(1, 3)):              # sparse dirt
                 i = rng.randrange(L)
