@@ -52,11 +52,11 @@ extern "C" {
                                   utils.rs:43-55), 5-bit codes, k 1..=12 (utils.rs:554 panics above), no reverse complement,
                                   mask_aa_bits (utils.rs:66-76), add_kmer as for nucleotides.  lash_sketch_batch[_async/_device] and
                                   lash_sketch_files_raw (host parse); the packed / raw-device entries return LASH_EINVAL */
-#define LASH_F_NO_DIRECT   4u  /* lash_sketch_batch[_device]: always pack first.  By default the sketch kernel first reads
-                                  the record bytes itself, which is exact while a genome holds only upper-case ACGT
-                                  (filter_out_n, utils.rs:33-41, deletes nothing); genomes where it meets anything else
-                                  are re-done through the pack stage in the same call.  Same images either way: set this
-                                  for batches known to be full of N / lower case, to skip the attempt */
+#define LASH_F_NO_DIRECT   4u  /* lash_sketch_batch[_device]: pack first (ASCII -> 2-bit stream in HBM -> sketch), the route raw
+                                  FASTA / FASTQ bytes always take.  By default the sketch kernels read the record bytes
+                                  themselves and apply filter_out_n (utils.rs:33-41) on the fly: clean stretches as they are,
+                                  deleted bytes by junction walks / in-LDS compaction, soft-masked genomes by a compacting
+                                  kernel.  Same images either way; the flag exists for A/B runs */
 
 typedef struct lash_ctx lash_ctx;        /* one per (host thread, GPU): stream, workspace, scratch */
 typedef struct lash_packed lash_packed;  /* device-resident 2-bit genomes produced by lash_pack_* */
@@ -103,7 +103,7 @@ typedef struct {
     float    pack_ms;           /* ASCII -> 2-bit + record-break bitmap (incl. the small table uploads); calls
                                    that took the direct route spend nothing here: their dirty-genome pack is
                                    queued behind the direct pass and counted in sketch_ms */
-    float    sketch_ms;         /* k-mer / xxh3 / register-update kernels (direct pass + dirty-genome fallback) */
+    float    sketch_ms;         /* k-mer / xxh3 / register-update kernels (direct pass + the compacting kernel for handed-over genomes) */
     float    finalize_ms;       /* partial-sketch reduction + byte images                                  */
     uint32_t calls;             /* sketch calls summed                                                     */
     uint32_t sketch_launches;   /* launches of the sketch kernel summed                                    */
