@@ -58,6 +58,10 @@ extern "C" {
                                   deleted bytes by junction walks / in-LDS compaction, soft-masked genomes by a compacting
                                   kernel.  Same images either way; the flag exists for A/B runs */
 
+#define LASH_F_STREAM_ONLY 16u /* lash_sketch_batch[_device]: skip the optimistic pass, every genome goes through the compacting
+                                  kernel (stream_sketch_kernel) — what the context does by itself while batches keep turning out
+                                  soft-masked.  Same images; for A/B runs and tests */
+
 typedef struct lash_ctx lash_ctx;        /* one per (host thread, GPU): stream, workspace, scratch */
 typedef struct lash_packed lash_packed;  /* device-resident 2-bit genomes produced by lash_pack_* */
 

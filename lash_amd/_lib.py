@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx95
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE, EFORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 HMH, HLL, ULL = 0, 1, 2
-F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT, F_AMINO = 1, 2, 4, 8
+F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT, F_AMINO, F_STREAM_ONLY = 1, 2, 4, 8, 16
 FMT_FASTA, FMT_FASTQ = 1, 2
 ABI_VERSION = 3
 

@@ -881,7 +881,7 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
         else ctx->direct_skipped = 0;
     }
     static const bool env_stream_first = getenv("LASH_STREAM_FIRST") != nullptr;     // A/B knob for tools/ (like LASH_NO_DIRECT)
-    ctx->scratch.stream_first = (stream_first || env_stream_first) && direct;
+    ctx->scratch.stream_first = (stream_first || env_stream_first || (prm->flags & LASH_F_STREAM_ONLY)) && direct;
     rc = pack_into(ctx, &ctx->scratch, ctx->stream, ev, d_seq, d_seq + genome_byte_off[n_genomes], d_rec_off, n_rec,
                    genome_rec_off, genome_byte_off, n_genomes, nullptr, direct);
     if (rc) return rc;

@@ -1434,7 +1434,36 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             }
             const uint32_t n_all = (uint32_t)__builtin_popcount(v);
             const uint32_t off = wave_excl_scan(n_all, T);
-            if (T == 0u) continue;                                             // nothing survives in this chunk
+            if (T == 0u) {                                                     // nothing survives in this chunk
+                if (pos >= we && !stop) {
+                    // past the wave's part, inside a long run of deleted bytes (a gap, a masked block): 8 KiB per round trip to
+                    // the first chunk that may hold a survivor or a record start — the workgroup's slot waits for this wave
+                    uint64_t np = pos + STREAM_CHUNK;
+                    for (;;) {
+                        if (np + 4 * STREAM_CHUNK + 32 > L) break;              // near the genome's end: chunk by chunk
+                        uint4 y[8];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            y[2 * j] = load16_any(gseq + np + (uint64_t)j * STREAM_CHUNK + 32ull * lane);
+                            y[2 * j + 1] = load16_any(gseq + np + (uint64_t)j * STREAM_CHUNK + 32ull * lane + 16);
+                        }
+                        uint32_t first = 4;
+#pragma unroll
+                        for (int j = 3; j >= 0; --j) {
+                            bool hit = (hopeless_bits(y[2 * j]) & hopeless_bits(y[2 * j + 1]) & 0x20202020u) != 0x20202020u;
+                            if (breaks) {
+                                const uint64_t aj = np + (uint64_t)j * STREAM_CHUNK + 32ull * lane;
+                                hit = hit || (RL ? uniform_breaks((uint32_t)aj, RL, 32u).b0 != 0u : bk[aj >> 5] != 0u);
+                            }
+                            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) first = (uint32_t)j;
+                        }
+                        np += (uint64_t)first * STREAM_CHUNK;
+                        if (first < 4u) break;
+                    }
+                    if (np != pos + STREAM_CHUNK) { pos = np - STREAM_CHUNK; chunk_load(np, n0, n1); }
+                }
+                continue;
+            }
             own_t = pos + STREAM_CHUNK <= we ? T : (pos >= we ? 0u : wave_sum((uint32_t)__builtin_popcount(v & ownmask)));
             // ---- append: two 16-byte groups per lane at ring position have + off ----
             {

@@ -61,7 +61,7 @@ def main():
         k = rng.choice([rng.randint(1, 32), 16, 21, 31, 32])
         p = 0 if an == "hmh" else rng.choice([rng.randint(4, 16)] if an == "hll" else [rng.randint(3, 20), rng.randint(3, 14)])
         seed = rng.choice([0, 42, rng.getrandbits(64)])
-        flags = rng.choice([0, 0, lash_amd.F_NO_DIRECT]) | (lash_amd.F_HMH_X_LOW if an == "hmh" and rng.random() < 0.2 else 0)
+        flags = rng.choice([0, 0, lash_amd.F_NO_DIRECT, lash_amd.F_STREAM_ONLY]) | (lash_amd.F_HMH_X_LOW if an == "hmh" and rng.random() < 0.2 else 0)
         gs = [random_genome(rng) for _ in range(rng.randint(1, 12))]
         seq, off, goff = lash_amd.records_to_arrays(gs)
         mode = rng.choice(["host", "host", "accumulate", "device", "packed"])
@@ -85,8 +85,8 @@ def main():
                 ctx.sketch_batch_device(an, k, p, seed, d_seq, d_off, len(off) - 1, goff, gbo, d_img, flags=flags)
             else:
                 pk = ctx.pack_device(d_seq, d_off, len(off) - 1, goff, gbo)
-                ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=flags & ~lash_amd.F_NO_DIRECT)
-                ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=(flags & ~lash_amd.F_NO_DIRECT) | lash_amd.F_ACCUMULATE)   # idempotent
+                ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=flags & ~(lash_amd.F_NO_DIRECT | lash_amd.F_STREAM_ONLY))
+                ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=(flags & ~(lash_amd.F_NO_DIRECT | lash_amd.F_STREAM_ONLY)) | lash_amd.F_ACCUMULATE)   # idempotent
             ctx.synchronize()
             got = d_img.cpu().numpy().reshape(len(gs), -1)
             if mode == "packed":

@@ -257,8 +257,8 @@ def test_sparse_dirt_is_handled_in_place(an, k, p):
 
 
 def test_long_runs_and_dense_dirt_still_fall_back(ctx):
-    """A run of deleted bytes longer than the junction walk's reach, and a genome with far more dirty wave-tiles than the
-    in-place budget, are given up by the direct pass and re-done through the pack stage in the same call."""
+    """A long gap (compacted in place by its wave: dense_tile) and a genome with soft-masked confetti all over (handed to
+    stream_sketch_kernel in the same call): images, census and surviving-base count as the oracle's."""
     import lash_amd
     a = bytearray(O.synth_genome(1300, 400_000).tobytes())
     a[200_000:230_000] = b"N" * 30_000                                  # one long gap
@@ -276,3 +276,52 @@ def test_long_runs_and_dense_dirt_still_fall_back(ctx):
         same(got, oracle_images(an, k, p, 42, seq, off, goff), "fallback " + an)
         assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
         assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g in gs for r in g)
+
+
+def _soft_masked_genomes(rng):
+    """records with lower-case / N stretches of 50 bytes .. 300 kb at random places: whole wave-tiles deleted, tiles and wave parts that
+    end inside a run, runs across record and slice boundaries, a gap longer than the stream kernel's 8 KiB skip"""
+    gs = []
+    for n_rec in (1, 1, 3, 17):
+        recs = []
+        for _ in range(n_rec):
+            L = rng.choice([5_000, 70_000, 400_000, 1_500_000]) if n_rec < 17 else rng.randint(0, 30_000)
+            s = bytearray(O.synth_genome(rng.randint(0, 10**6), max(L, 1)).tobytes()[:L])
+            pos = rng.randrange(max(L, 1))
+            while pos < L:
+                run = min(rng.choice([50, 300, 2_000, 4_096, 10_000, 45_000, 300_000]), L - pos)
+                if rng.random() < 0.5:
+                    s[pos:pos + run] = bytes(s[pos:pos + run]).lower()
+                else:
+                    s[pos:pos + run] = b"N" * run
+                pos += run + rng.choice([1, 15, 16, 31, 33, 500, 2_048, 10_000, 100_000])
+            recs.append(bytes(s))
+        gs.append(recs)
+    return gs
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 5, 0), ("hmh", 32, 0), ("hll", 21, 14), ("hll", 16, 16), ("ull", 16, 12), ("ull", 27, 17)])
+def test_stream_kernel_alone_equals_the_oracle(an, k, p):
+    """LASH_F_STREAM_ONLY: every genome through stream_sketch_kernel (what the context does by itself while batches keep turning
+    out soft-masked) — clean, sparsely dirty, soft-masked, multi-record, every short length; census and surviving bases too."""
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    rng = random.Random(zlib.crc32(repr(("stream", an, k, p)).encode()))
+    corpora = [_soft_masked_genomes(rng), _sparse_dirt_genomes(rng, k),
+               [clean_records(rng, 1, 100_000, 600_000), clean_records(rng, 40, 0, 9_000), [b"ACGT" * 7, b"", b"N" * 5000, b"acgt" * 3000]],
+               [[O.synth_genome(9000 + L, max(L, 1)).tobytes()[:L]] for L in list(range(0, 70)) + [2047, 2048, 2049, 4095, 4096, 4097, 16383, 16385]]]
+    for gs in corpora:
+        seq, off, goff = lash_amd.records_to_arrays(gs)
+        want = oracle_images(an, k, p, 42, seq, off, goff)
+        ctx.enable_timing(True)
+        got = ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_STREAM_ONLY)
+        tm = ctx.timing()
+        ctx.enable_timing(False)
+        assert tm["direct_launches"] == 0
+        same(got, want, "stream only %s k=%d" % (an, k))
+        assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+        assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g in gs for r in g)
+        # and through the default route (direct pass, in-place compaction, hand-over) and the pack-first one
+        same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), want, "default route")
+        same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, "pack first")
+    ctx.close()
