@@ -87,9 +87,6 @@ struct lash_packed {
     std::vector<uint64_t> h_nvalid;
     const uint64_t *d_rec_off = nullptr;
     uint64_t n_rec = 0;
-    PackArgs pa{};
-    PackV2Args v2{};
-    PackMapArgs pm{};
     bool owned_by_ctx = false;           // the scratch instance reused by lash_sketch_batch_device
 };
 

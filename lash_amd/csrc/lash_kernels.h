@@ -26,8 +26,8 @@ struct SketchArgs {
     const uint8_t    *seq;        // the caller's record bytes
     const uint32_t   *brk_bytes;  // record-break bitmap in BYTE positions (== base positions while nothing is deleted)
     const uint8_t    *safe;       // >= 128 readable bytes: load target of lanes that are not on the fast path
-    uint32_t         *dirty;      // [n_genomes + 1] per genome: the direct pass gave this genome up (dense dirt or a long run of
-                                  // deleted bytes); [n_genomes] = how many.  Non-direct launches with dirty != NULL run only these
+    uint32_t         *dirty;      // [n_genomes + 1] per genome: the direct pass hands this genome to stream_sketch_kernel (much dense
+                                  // dirt, or a gap beyond its look-ahead scan); the stream launch runs only these
     uint32_t         *nslow;      // [n_genomes] wave-tiles of the direct pass that met deleted bytes (budget: sketch_kernels.hip)
     uint32_t         *ndel;       // [n_genomes] bytes the direct pass deleted in place (surviving bases = nvalid - ndel while !dirty)
     uint32_t         *ndel2;      // [n_genomes] bytes stream_sketch_kernel deleted in the genomes it took over (zeroed)
@@ -76,7 +76,6 @@ hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off
 // genome's bitmap is written (no memset needed), genomes with nonuniform[g] == 0 are left alone
 hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, const uint32_t *nonuniform,
                             uint32_t *brk_bytes, hipStream_t stream);
-// zero the packed-position break bitmap of the genomes the direct pass flagged dirty (the pack kernel ORs into it)
 // fastq_check.hip: the FASTQ rule the pack kernel's line-structure check cannot see — a quality line as long as its sequence
 // line, a file that ends on a whole record (needletail's Err; /root/reference/src/utils.rs:453-459 stops there).
 struct FqFile {
@@ -91,7 +90,6 @@ hipError_t launch_fastq_check(const uint8_t *d_raw, const FqFile *d_files, uint3
                               uint32_t *d_file_err, hipStream_t stream);
 size_t fastq_check_scratch_words(uint32_t n_files, uint32_t n_blocks);
 uint32_t fastq_check_block_bytes();
-hipError_t launch_zero_dirty_brk(const GenomeDesc *genomes, const uint32_t *dirty, uint32_t n_genomes, uint32_t *brk, hipStream_t stream);
 
 struct FinalizeArgs {
     const uint8_t  *partials;

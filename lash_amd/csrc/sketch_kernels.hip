@@ -952,7 +952,6 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     const WorkItem it = a.items[blockIdx.x];
     const GenomeDesc gd = a.genomes[it.genome];
-    if constexpr (!DIRECT) { if (a.dirty && a.dirty[it.genome] == 0u) return; }   // fallback launch: dirty genomes only
     const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
     const int k = a.k, p = a.p;
     const uint64_t nk = L >= (uint64_t)k ? L - (uint64_t)k + 1 : 0;     // k-mer start positions of the genome
@@ -1936,18 +1935,6 @@ __global__ void __launch_bounds__(256) brk_bytes_kernel(const GenomeDesc *genome
     }
 }
 
-// the packed-position bitmap of the genomes the direct pass gave up on (pack_lookback_kernel ORs record starts into it)
-__global__ void __launch_bounds__(256) zero_dirty_brk_kernel(const GenomeDesc *genomes, const uint32_t *dirty, uint32_t n_genomes, uint32_t *brk)
-{
-    for (uint32_t g = blockIdx.y; g < n_genomes; g += gridDim.y) {
-        if (dirty[g] == 0u) continue;
-        const GenomeDesc gd = genomes[g];
-        if (gd.format == 0u && gd.rec_end - gd.rec_begin <= 1) continue;
-        const uint64_t n_words = (gd.byte_len + 1 + 31) / 32 + 4;
-        for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) brk[gd.brk_off + w] = 0u;
-    }
-}
-
 static dim3 per_record_grid(uint32_t n_genomes, uint64_t n_rec)
 {
     // x: enough 256-thread blocks per genome for ~4 records per thread (a read set is one genome with millions of records)
@@ -1969,14 +1956,6 @@ hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, 
 {
     if (n_genomes == 0) return hipSuccess;
     hipLaunchKernelGGL(brk_bytes_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform, brk_bytes);
-    return hipGetLastError();
-}
-
-hipError_t launch_zero_dirty_brk(const GenomeDesc *genomes, const uint32_t *dirty, uint32_t n_genomes, uint32_t *brk, hipStream_t stream)
-{
-    if (n_genomes == 0) return hipSuccess;
-    const uint32_t gy = std::min(n_genomes, 512u), gx = std::max(8u, std::min(1024u, 4096u / gy));
-    hipLaunchKernelGGL(zero_dirty_brk_kernel, dim3(gx, gy), dim3(256), 0, stream, genomes, dirty, n_genomes, brk);
     return hipGetLastError();
 }
 
