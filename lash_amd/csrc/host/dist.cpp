@@ -261,6 +261,7 @@ std::string run_dist(const DistOptions &opt)
         uint32_t *C = nullptr, *N = nullptr;
         double *U = nullptr, *EC = nullptr;
         size_t cap = 0, ec_cap = 0;
+        RowText row_text;                                        // the block's text; its memory is reused from block to block
         auto grow = [&](size_t np) {
             if (np <= cap) return true;
             lash_host_free_pinned(C); lash_host_free_pinned(N); lash_host_free_pinned(U);
@@ -276,10 +277,10 @@ std::string run_dist(const DistOptions &opt)
             if (blk >= n_blocks) break;
             const uint32_t i0 = block_begin[blk], i1 = block_begin[blk + 1];
             const uint32_t n_cols = same_files ? std::min(i1, nq) : nq;     // the triangle: no row of the block prints beyond its own column
-            std::vector<std::string> row_text(i1 - i0);
             bool skip;
             { std::lock_guard<std::mutex> lk(wmu); skip = !fail.empty(); }
             bool have_ec = false;
+            row_text.off.clear(); row_text.len.clear();
             if (my_fail.empty() && !skip) {
                 const size_t np = (size_t)(i1 - i0) * n_cols;
                 if (!grow(np)) my_fail = "out of page-locked host memory";
@@ -301,13 +302,14 @@ std::string run_dist(const DistOptions &opt)
                 bt.c_or_zero = C; bt.n_counts = N; bt.sum_or_union = U; bt.hmh_ec = have_ec ? EC : nullptr; bt.ld = n_cols;
                 my_fail = dist_block_rows(algo_id, prec, k, opt.model, opt.fp32, bias, i0, i1, same_files, nq, rcard.data(), qcard.data(), bt, row_name,
                                           col_name, col_tab, row_id.data(), col_id.data(), opt.matrix, fmt_threads, row_text);
+                if (!my_fail.empty()) row_text.len.clear();
             }
             // in block order, whatever order the devices finish in
             std::unique_lock<std::mutex> lk(wmu);
             wcv.wait(lk, [&] { return next_to_write == blk; });
             if (!my_fail.empty() && fail.empty()) fail = my_fail;
             if (fail.empty())
-                for (const std::string &t : row_text) fwrite(t.data(), 1, t.size(), out);
+                for (size_t r = 0; r < row_text.rows(); ++r) fwrite(row_text.data(r), 1, row_text.size(r), out);
             ++next_to_write;
             lk.unlock();
             wcv.notify_all();

@@ -32,16 +32,20 @@ void name_ids(const std::vector<std::string> &row_name, const std::vector<std::s
     for (size_t j = 0; j < col_name.size(); ++j) col_id[j] = id_of(col_name[j]);
 }
 
-void append_row(std::string &out, const std::string &rname, const std::vector<std::string> &qtab, uint32_t n_print, const double *dist,
-                uint32_t row_id, const uint32_t *col_id, bool matrix)
+size_t row_text_bound(const std::string &rname, const std::vector<std::string> &qtab, uint32_t n_print, bool matrix)
 {
-    if (n_print == 0) return;                                                    // (a row with no column prints nothing, main.rs:443)
-    // "{:.6}" (main.rs:456,461): std::to_chars(fixed, 6) is correctly rounded like Rust's formatter, several times faster than printf
+    if (matrix) return 1 + rname.size() + (size_t)n_print * 28;
     size_t qbytes = 0;
-    if (!matrix) for (uint32_t c = 0; c < n_print; ++c) qbytes += qtab[c].size();
-    const size_t at0 = out.size();
-    out.resize(at0 + (matrix ? 1 + rname.size() + (size_t)n_print * 28 : (size_t)n_print * (rname.size() + 28) + qbytes));
-    char *p = &out[at0];
+    for (uint32_t c = 0; c < n_print; ++c) qbytes += qtab[c].size();
+    return (size_t)n_print * (rname.size() + 28) + qbytes;
+}
+
+size_t format_row(char *dst, const std::string &rname, const std::vector<std::string> &qtab, uint32_t n_print, const double *dist, uint32_t row_id,
+                  const uint32_t *col_id, bool matrix)
+{
+    if (n_print == 0) return 0;                                                  // (a row with no column prints nothing, main.rs:443)
+    // "{:.6}" (main.rs:456,461): std::to_chars(fixed, 6) is correctly rounded like Rust's formatter, several times faster than printf
+    char *p = dst;
     if (matrix) { *p++ = '\n'; memcpy(p, rname.data(), rname.size()); p += rname.size(); }
     for (uint32_t c = 0; c < n_print; ++c) {
         const double d = col_id[c] == row_id ? 0.0 : dist[c];
@@ -56,20 +60,43 @@ void append_row(std::string &out, const std::string &rname, const std::vector<st
         else p = std::to_chars(p, p + 26, d, std::chars_format::fixed, 6).ptr;
         if (!matrix) *p++ = '\n';
     }
-    out.resize((size_t)(p - out.data()));
+    return (size_t)(p - dst);
+}
+
+void append_row(std::string &out, const std::string &rname, const std::vector<std::string> &qtab, uint32_t n_print, const double *dist,
+                uint32_t row_id, const uint32_t *col_id, bool matrix)
+{
+    if (n_print == 0) return;
+    const size_t at0 = out.size();
+    out.resize(at0 + row_text_bound(rname, qtab, n_print, matrix));
+    out.resize(at0 + format_row(&out[at0], rname, qtab, n_print, dist, row_id, col_id, matrix));
 }
 
 std::string dist_block_rows(int algo, int p, int k, int model, bool fp32, const void *hll_bias, uint32_t i0, uint32_t i1, bool triangle,
                             uint32_t n_cols_total, const double *row_card, const double *col_card, const BlockTables &t,
                             const std::vector<std::string> &row_name, const std::vector<std::string> &col_name,
                             const std::vector<std::string> &col_tab, const uint32_t *row_id, const uint32_t *col_id, bool matrix, int threads,
-                            std::vector<std::string> &row_text)
+                            RowText &text)
 {
     static const char *bias_msg = ": cardinality estimate <= 5 * 2^p needs the HLL++ bias tables of streaming_algorithms, which are "
                                   "not built in (pass --hll-bias <file from tools/ref_probe/extract_hll_bias.py>, or sketch with a smaller -p)";
     const bool hll = algo == LASH_HLL, ull = algo == LASH_ULL;
-    row_text.assign(i1 - i0, std::string());
-    std::vector<std::string> row_fail(i1 - i0);
+    const uint32_t n_rows = i1 - i0;
+    // slots: row r at off[r], room for its upper bound (list form: the column names' bytes come from a running sum)
+    text.off.assign(n_rows, 0);
+    text.len.assign(n_rows, 0);
+    {
+        std::vector<size_t> qsum;                                                 // qsum[c] = bytes of col_tab[0 .. c)
+        if (!matrix) { qsum.resize((size_t)n_cols_total + 1, 0); for (uint32_t c = 0; c < n_cols_total; ++c) qsum[c + 1] = qsum[c] + col_tab[c].size(); }
+        size_t at = 0;
+        for (uint32_t r = 0; r < n_rows; ++r) {
+            const uint32_t i = i0 + r, n_print = triangle ? std::min(i + 1, n_cols_total) : n_cols_total;
+            text.off[r] = at;
+            at += matrix ? 1 + row_name[i].size() + (size_t)n_print * 28 : (size_t)n_print * (row_name[i].size() + 28) + qsum[n_print];
+        }
+        if (text.buf.size() < at) text.buf.resize(at + at / 8);
+    }
+    std::vector<std::string> row_fail(n_rows);
     auto do_row = [&](uint32_t i, std::vector<double> &dist) {
         const size_t row = (size_t)(i - i0) * t.ld;
         const uint32_t n_print = triangle ? std::min(i + 1, n_cols_total) : n_cols_total;                  // utils.rs:158-160
@@ -80,9 +107,9 @@ std::string dist_block_rows(int algo, int p, int k, int model, bool fp32, const 
                                        static_cast<const lash_hll_bias *>(hll_bias), t.hmh_ec ? t.hmh_ec + row : nullptr, dist.data(), &bad_pair);
         if (drc == LASH_ERANGE) { row_fail[i - i0] = "union of " + row_name[i] + " and " + col_name[bad_pair] + bias_msg; return; }
         if (drc != LASH_OK) { row_fail[i - i0] = lash_strerror(drc); return; }
-        append_row(row_text[i - i0], row_name[i], col_tab, n_print, dist.data(), row_id[i], col_id, matrix);
+        text.len[i - i0] = format_row(text.buf.data() + text.off[i - i0], row_name[i], col_tab, n_print, dist.data(), row_id[i], col_id, matrix);
     };
-    const uint32_t nthreads = (uint32_t)std::max(1, std::min<int>(threads, (int)(i1 - i0)));
+    const uint32_t nthreads = (uint32_t)std::max(1, std::min<int>(threads, (int)n_rows));
     std::atomic<uint32_t> next{i0};
     std::vector<std::thread> pool;
     auto work = [&]() { std::vector<double> dist; for (uint32_t i = next.fetch_add(1); i < i1; i = next.fetch_add(1)) do_row(i, dist); };

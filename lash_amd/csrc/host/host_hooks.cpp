@@ -204,6 +204,7 @@ struct lash_host_formatter {
     std::vector<double> row_card, col_card;
     std::vector<uint32_t> row_id, col_id;
     std::string err;
+    lashhost::RowText text;              // the last block's text (memory kept from block to block)
 };
 
 // rows and columns in printing order (a pair of equal names prints 0, main.rs:452-453)
@@ -232,19 +233,19 @@ int64_t lash_host_formatter_block(lash_host_formatter *f, int algo, int p, int k
     if (!f || i0 > i1 || i1 > f->row_names.size()) return -1;
     BlockTables t;
     t.c_or_zero = c_or_zero; t.n_counts = n_counts; t.sum_or_union = sum_or_union; t.hmh_ec = hmh_ec; t.ld = ld;
-    std::vector<std::string> text;
+    RowText &text = f->text;                                                     // (one caller at a time: lash_amd/allpairs.py formats blocks in order)
     f->err = dist_block_rows(algo, p, k, model, fp32 != 0, hll_bias, i0, i1, triangle != 0, (uint32_t)f->col_names.size(), f->row_card.data(),
                              f->col_card.data(), t, f->row_names, f->col_names, f->col_tab, f->row_id.data(), f->col_id.data(), matrix != 0, threads, text);
     if (!f->err.empty()) return -1;
     int64_t total = 0;
-    for (const std::string &s : text) {
+    for (size_t r = 0; r < text.rows(); ++r) {
         size_t at = 0;
-        while (at < s.size()) {
-            const ssize_t w = write(fd, s.data() + at, s.size() - at);
+        while (at < text.size(r)) {
+            const ssize_t w = write(fd, text.data(r) + at, text.size(r) - at);
             if (w < 0) { f->err = "write failed"; return -1; }
             at += (size_t)w;
         }
-        total += (int64_t)s.size();
+        total += (int64_t)text.size(r);
     }
     return total;
 }
