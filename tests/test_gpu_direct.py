@@ -325,3 +325,26 @@ def test_stream_kernel_alone_equals_the_oracle(an, k, p):
         same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), want, "default route")
         same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, "pack first")
     ctx.close()
+
+
+def test_a_gap_longer_than_the_look_ahead_scan(ctx):
+    """An assembly gap of 5 MB (centromere-sized): the wave of the direct pass that reaches it gives up after scanning 4 MiB
+    (DENSE_SCAN_MAX) and hands the genome over; the stream kernel skips the gap 8 KiB per round trip.  The k-mers that span the
+    gap are the ones filter_out_n's joined flanks give."""
+    import lash_amd
+    g = bytearray(O.synth_genome(4242, 9_000_000).tobytes())
+    g[2_000_123:7_100_456] = b"N" * (7_100_456 - 2_000_123)
+    h = bytearray(O.synth_genome(4243, 6_000_000).tobytes())
+    h[100:5_600_000] = bytes(h[100:5_600_000]).lower()                   # a soft-masked genome with a clean tail
+    gs = [[bytes(g)], [bytes(h)], [O.synth_genome(4244, 300_000).tobytes()]]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    for an, k, p in (("hmh", 16, 0), ("ull", 31, 12)):
+        want = oracle_images(an, k, p, 42, seq, off, goff)
+        ctx.enable_timing(True)
+        got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+        tm = ctx.timing()
+        ctx.enable_timing(False)
+        same(got, want, "long gap " + an)
+        assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g_ in gs for r in g_)
+        assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g_ in gs for r in g_)
+        same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_STREAM_ONLY), want, "long gap, stream only " + an)
