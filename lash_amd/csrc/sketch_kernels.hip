@@ -395,8 +395,9 @@ __device__ __forceinline__ uint32_t hmh_img_order(uint32_t v, uint32_t be) { ret
 // ---- direct mode: 2-bit words straight from ASCII ------------------------------------------------------------
 // While a genome holds nothing but upper-case ACGT, filter_out_n (utils.rs:33-41) deletes nothing, base i IS byte i,
 // and the pack stage's scan has nothing to compute: the sketch kernel can read the caller's bytes itself and save
-// the 2-bit round trip through HBM.  Codes are kmerutils' 2-bit alphabet A,C,G,T -> 0,1,2,3; a byte
-// outside the alphabet flags the genome dirty and it is re-done by the pack + sketch path (lash_api.hip).
+// the 2-bit round trip through HBM.  Codes are kmerutils' 2-bit alphabet A,C,G,T -> 0,1,2,3; bytes
+// outside the alphabet are deleted on the fly (junction walks, dense_tile below), and a genome with many of them is
+// handed to stream_sketch_kernel in the same call (lash_api.hip) — since round 3 nothing here goes through the pack stage.
 __device__ __forceinline__ uint4 load16_any(const uint8_t *p)    // any alignment (gfx950 global loads take it)
 {
     uint4 v;
@@ -450,9 +451,9 @@ __device__ __noinline__ TailWords ascii96_tail(const uint8_t *gseq, uint64_t o, 
 // every window that holds a deleted byte masked out); otherwise it is b plus the next k-1 SURVIVING bytes, wherever they
 // are — a "junction" k-mer.  Junction k-mers are few (at most k-1 per run of deleted bytes) and belong to the lane that
 // owns b; that lane walks forward from its first junction start, skipping deleted bytes, and hashes them one by one.
-// One assembly gap or a sprinkle of IUPAC codes therefore costs a few microseconds of one lane instead of sending
-// the genome through the pack stage after a wasted direct pass; dense dirt (soft-masked assemblies) and runs longer
-// than WALK_MAX still take the fallback, decided per genome by a budget of slow wave-tiles.
+// A sprinkle of IUPAC codes or an N in a read therefore costs a few microseconds of one lane.  Tiles where that would not be
+// cheap — much of the tile deleted, a junction k-mer whose bases lie beyond its lane's 96 bytes, a genome past its budget of
+// walked tiles — are compacted by their wave instead (dense_tile, below); WALK_MAX is a safety net behind those tests.
 constexpr uint32_t WALK_MAX = 4096;          // bytes a junction walk may read past its lane's 64 positions
 
 __device__ __forceinline__ uint32_t inv4(uint32_t x)            // bit j: byte j is not one of A C G T
@@ -1162,10 +1163,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     dense = wave_nd > 1024u || __builtin_amdgcn_ballot_w64(far) != 0ull;
                 }
                 if (dense) {
-                    // Finely fragmented dirt (a repeat-masked assembly: a lower-case stretch every few hundred bases) makes nearly every
-                    // wave-tile a compaction; the pack stage does that at HBM speed and feeds the lean packed kernel, which is faster
-                    // from about three dense tiles in four (tools/dirty_rate.py: 5.9 vs 4.5 ms per 5 Gbp with 500-byte blocks).  The
-                    // wave's own tiles are a sample of the genome: past that ratio it hands the genome over.
+                    // A genome that needs this often (a soft-masked assembly) is better off in stream_sketch_kernel, which compacts as it
+                    // reads and is faster on anything but clean input (tools/dirty_rate.py, DESIGN.md 4.0: 10 kb blocks 4.05 ms in place
+                    // vs 3.03 ms streamed per 5 Gbp).  The wave's own tiles are a sample of the genome: from one dense tile in eight
+                    // (and at least four) it hands the genome over; the occasional gap stays here and costs no second pass.
                     tiles_dense = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiles_dense) + 1u;
                     const uint32_t tiles_seen = (tile - it.word_begin) / step + 1u;
                     if (tiles_dense >= 4u && tiles_dense * 8u > tiles_seen && (threadIdx.x & 63) == 0)
