@@ -1404,7 +1404,11 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             //      (the inside of a masked block: no) — else which bytes ----
             uint32_t bad = 0;
             const uint32_t cw0 = ascii16_to_word(q0, bad, ct), cw1 = ascii16_to_word(q1, bad, ct);
-            const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we && !breaks;
+            // record starts among the lane's 32 positions (multi-record genomes: contigs, reads)
+            uint32_t rb = 0;
+            if (breaks && at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
+            const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we &&
+                                     (!breaks || (!pend && __builtin_amdgcn_ballot_w64(rb != 0u) == 0ull));
             uint32_t T, own_t;
             if (chunk_clean) {
                 // 2 048 survivors, all owned, no record starts: lane i's 32 bases go to ring position have + 32 i, one shift for all
@@ -1429,8 +1433,6 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             // ---- record starts land on the first survivor at or after them (cf. dense_tile); one that lands BEYOND the part ends it ----
             uint32_t recv = 0;
             if (breaks) {
-                uint32_t rb = 0;
-                if (at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
                 const uint32_t fill = ~v, rbd = rb & fill;
                 const bool gen = fill + rbd < rbd;
                 const uint64_t G = __builtin_amdgcn_ballot_w64(gen), Z = __builtin_amdgcn_ballot_w64(v == 0u);
