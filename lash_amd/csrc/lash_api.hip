@@ -249,6 +249,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         DevBuf &dst = pk->direct ? mpk->tables : ctx->items;
         if ((rc = reserve(ctx, dst, total + 256))) return rc;
         if ((rc = upload_sections(ctx, dst.ptr, sec, total, ctx->stream))) return rc;
+        if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));            // the sketch stage: record-start bitmaps included
         uint8_t *tb = static_cast<uint8_t *>(dst.ptr);
         d_items = reinterpret_cast<const WorkItem *>(tb + sec[0].off);
         d_item_begin = reinterpret_cast<const uint32_t *>(tb + sec[1].off);
@@ -265,7 +266,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
                 uint32_t *nonuni = pk->d_dirty + 3 * (size_t)n_genomes + 1;
                 HIPCHK(ctx, launch_rec_uniform(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, ctx->stream));
                 HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, static_cast<uint32_t *>(pk->brk_bytes.ptr),
-                                             ctx->stream));
+                                             pk->n_rec != 0 && total_bytes / pk->n_rec >= 1024u, ctx->stream));
             }
         }
     }
@@ -277,7 +278,6 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     if (!plan.use_lds && n_items)
         HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n_items * plan.nreg32 * 4, ctx->stream));
 
-    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
     TRACE("sketch: items uploaded");
 
     SketchArgs sa{};

@@ -1955,6 +1955,35 @@ __global__ void __launch_bounds__(256) brk_bytes_kernel(const GenomeDesc *genome
     }
 }
 
+// The same bitmap for genomes of FEW LONG records (a draft assembly: tens of contigs of 100 kb): the head-record form above would
+// have each of 50 threads zero-fill 12 KiB on its own (3.3 ms per 1 000 genomes — more than sketching them); here every thread
+// zeroes its share of the words and the few record starts are OR-ed in afterwards (0.2 ms).
+__global__ void __launch_bounds__(256) brk_zero_kernel(const GenomeDesc *genomes, uint32_t n_genomes, const uint32_t *nonuniform, uint32_t *brk_bytes)
+{
+    for (uint32_t g = blockIdx.y; g < n_genomes; g += gridDim.y) {
+        const GenomeDesc gd = genomes[g];
+        if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
+        if (nonuniform && nonuniform[g] == 0u) continue;
+        const uint64_t n_words = (gd.byte_len + 1 + 31) / 32 + 4;
+        uint32_t *bm = brk_bytes + gd.brk_off;
+        for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) bm[w] = 0u;
+    }
+}
+__global__ void __launch_bounds__(256) brk_set_kernel(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes,
+                                                      const uint32_t *nonuniform, uint32_t *brk_bytes)
+{
+    for (uint32_t g = blockIdx.y; g < n_genomes; g += gridDim.y) {
+        const GenomeDesc gd = genomes[g];
+        if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
+        if (nonuniform && nonuniform[g] == 0u) continue;
+        uint32_t *bm = brk_bytes + gd.brk_off;
+        for (uint64_t r = gd.rec_begin + 1 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < gd.rec_end; r += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t pos = rec_off[r] - gd.byte_off;
+            if (pos < gd.byte_len) atomicOr(bm + (pos >> 5), 1u << (pos & 31));
+        }
+    }
+}
+
 static dim3 per_record_grid(uint32_t n_genomes, uint64_t n_rec)
 {
     // x: enough 256-thread blocks per genome for ~4 records per thread (a read set is one genome with millions of records)
@@ -1972,9 +2001,15 @@ hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off
 }
 
 hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, const uint32_t *nonuniform,
-                            uint32_t *brk_bytes, hipStream_t stream)
+                            uint32_t *brk_bytes, bool long_records, hipStream_t stream)
 {
     if (n_genomes == 0) return hipSuccess;
+    if (long_records) {
+        const uint32_t gy = std::min(n_genomes, 1024u), gx = std::max(4u, std::min(256u, 8192u / gy));
+        hipLaunchKernelGGL(brk_zero_kernel, dim3(gx, gy), dim3(256), 0, stream, genomes, n_genomes, nonuniform, brk_bytes);
+        hipLaunchKernelGGL(brk_set_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform, brk_bytes);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(brk_bytes_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform, brk_bytes);
     return hipGetLastError();
 }
