@@ -206,6 +206,21 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // sketch time is flat from 2x to 24x the slots (4.87-4.91 ms on the default bench), the finalize time grows with it
     uint64_t target = total_words / (slots * slice_factor) + 1;
     target = std::max(target, min_slice);
+    {
+        // When some genome is cut anyway (so partials and the finalize pass exist whatever the slicing), items of at most 1 MiB: a
+        // large batch would otherwise get multi-megabyte items, and the few genomes handed to stream_sketch_kernel — one or two
+        // items each — would run on a fraction of the chip (2 000 mixed genomes: that launch 1.6 ms -> 0.5 ms).
+        static const uint64_t cap = getenv("LASH_ITEM_CAP_WORDS") ? std::max(1024, atoi(getenv("LASH_ITEM_CAP_WORDS"))) : 65536;
+        // (only for batches of unequal genomes: a batch of equal ones keeps its few large items — when those are soft-masked they all
+        // are, every item is busy in both launches, and smaller items only add ramp-up: -3 % on bench.py --dirty lower)
+        bool any_cut = false;
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint32_t g = 0; g < n_genomes; ++g) {
+            any_cut = any_cut || (((pk->byte_len[g] + 15) / 16 + 3) & ~3ull) > target;
+            lo = std::min<uint64_t>(lo, pk->byte_len[g]); hi = std::max<uint64_t>(hi, pk->byte_len[g]);
+        }
+        if (any_cut && hi > lo + lo / 4) target = std::max(min_slice, std::min(target, cap));
+    }
     std::vector<WorkItem> items;
     uint32_t max_slices = 0;                                       // most slices any genome is cut into
     bool all_sole = plan.parts_log2 == 0 && plan.use_lds && n_genomes > 0;   // every genome has exactly one work item
@@ -227,6 +242,26 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     }
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
+    // Launch order: longest items first when their sizes differ (a collection of 0.6 .. 12 Mbp genomes lost 11 % to the tail of a
+    // launch in genome order: the hardware hands workgroups out in index order, and a 3.6 MB item that starts last runs alone).
+    // A bucket sort on the size's leading bits: O(items), stable inside a bucket (neighbouring items still share cache lines).
+    std::vector<uint32_t> order;
+    {
+        uint32_t lo = ~0u, hi = 0;
+        for (const WorkItem &w : items) { const uint32_t n = w.word_end - w.word_begin; lo = std::min(lo, n); hi = std::max(hi, n); }
+        if (n_items > slots && hi > lo + lo / 4) {
+            auto bucket = [&](uint32_t n) {                             // 8 buckets per octave, larger sizes first
+                const uint32_t e = 31u - (uint32_t)__builtin_clz(n | 1u);
+                const uint32_t m = e >= 3 ? (n >> (e - 3)) & 7u : 0u;
+                return 255u - (e * 8u + m);
+            };
+            uint32_t count[257] = {0};
+            for (const WorkItem &w : items) ++count[bucket(w.word_end - w.word_begin) + 1];
+            for (int b = 0; b < 256; ++b) count[b + 1] += count[b];
+            order.resize(n_items);
+            for (uint32_t i = 0; i < n_items; ++i) order[count[bucket(items[i].word_end - items[i].word_begin)]++] = i;
+        }
+    }
     TRACE("sketch: planned");
 
     int rc;
@@ -235,7 +270,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
     if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
     const WorkItem *d_items;
-    const uint32_t *d_item_begin;
+    const uint32_t *d_item_begin, *d_item_order = nullptr;
     {
         std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0},
                                     {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0}};
@@ -245,6 +280,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             sec.push_back({pk->h_tile_begin.data(), pk->h_tile_begin.size() * 4, 0});
             sec.push_back({pk->h_nvalid.data(), pk->h_nvalid.size() * 8, 0});
         }
+        const size_t order_sec = sec.size();
+        if (!order.empty()) sec.push_back({order.data(), order.size() * 4, 0});
         const size_t total = layout_sections(sec);
         DevBuf &dst = pk->direct ? mpk->tables : ctx->items;
         if ((rc = reserve(ctx, dst, total + 256))) return rc;
@@ -253,6 +290,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         uint8_t *tb = static_cast<uint8_t *>(dst.ptr);
         d_items = reinterpret_cast<const WorkItem *>(tb + sec[0].off);
         d_item_begin = reinterpret_cast<const uint32_t *>(tb + sec[1].off);
+        d_item_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(tb + sec[order_sec].off);
         if (pk->direct) {
             mpk->d_descs = reinterpret_cast<GenomeDesc *>(tb + sec[2].off);
             mpk->d_tile_begin = reinterpret_cast<uint32_t *>(tb + sec[3].off);
@@ -287,6 +325,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     sa.genomes = pk->d_descs;
     sa.nvalid = pk->d_nvalid;
     sa.items = d_items;
+    sa.item_order = d_item_order;
     sa.partials = static_cast<uint8_t *>(ctx->partials.ptr);
     sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
     sa.item_kmers = static_cast<uint32_t *>(ctx->item_kmers.ptr);
@@ -321,6 +360,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.ndel = sa.nslow + n_genomes;
         sa.ndel2 = pk->d_dirty + 4 * (size_t)n_genomes + 2;
         if (!pk->stream_first) {
+            if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));       // direct_ms: this one launch
             HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
             if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
             if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
@@ -770,7 +810,7 @@ int lash_ctx_get_timing(lash_ctx *ctx, lash_timing *out)
         if (s.pack) { HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[0], s.e[1])); t.pack_ms += ms; }
         HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[2], s.e[3])); t.sketch_ms += ms;
         HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[3], s.e[4])); t.finalize_ms += ms;
-        if (s.direct) { HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[2], s.e[5])); t.direct_ms += ms; }
+        if (s.direct) { HIPCHK(ctx, hipEventElapsedTime(&ms, s.e[6], s.e[5])); t.direct_ms += ms; }
     }
     t.kmers = 0;
     t.bases_last = 0;

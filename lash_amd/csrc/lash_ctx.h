@@ -27,8 +27,8 @@ struct DevBuf {
 };
 
 struct EvSet {
-    hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pack start/end; sketch start/end;
-    bool pack = false, done = false, direct = false;                            // finalize end; end of the direct pass
+    hipEvent_t e[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // pack start/end; sketch stage start/end;
+    bool pack = false, done = false, direct = false;                            // finalize end; end [5] and start [6] of the direct kernel
 };
 
 // LASH_TRACE_HOST=1: host-side microsecond marks of one call on stderr (tools/, DESIGN.md "Host cost of a call").

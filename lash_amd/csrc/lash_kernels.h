@@ -15,6 +15,7 @@ struct SketchArgs {
     const GenomeDesc *genomes;
     const uint64_t   *nvalid;     // surviving bases per genome
     const WorkItem   *items;
+    const uint32_t   *item_order; // NULL, or a permutation of the item indices: workgroup b takes item item_order[b] (longest first)
     uint8_t          *partials;   // [n_items][partial_stride] partial sketches in image register format
     uint32_t         *gregs;      // [n_items][nreg32] zeroed u32 words, only for the global-register variant
     uint32_t         *item_kmers; // [n_items] valid k-mers of each work item (summed per genome by finalize_kernel)

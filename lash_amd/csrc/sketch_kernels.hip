@@ -881,8 +881,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 template <int ALGO, int REGS, class Regs>
 __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem &it, const Regs &regs, uint32_t *census, uint32_t part,
-                                            uint32_t my_kmers, int p)
+                                            uint32_t my_kmers, int p, uint32_t item)
 {
+    // `item`: the work item's index (its slot in partials / item_kmers / gregs) — blockIdx.x unless the launch is ordered (a.item_order)
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     // valid k-mer census (tests compare it with the oracle's iterator count): wave reduce, LDS, one store per item
     Regs::lds_wait();
@@ -892,7 +893,7 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
     if (threadIdx.x == 0) {
         unsigned long long tot = 0;
         for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) tot += census[i];
-        a.item_kmers[blockIdx.x] = part == 0u ? (uint32_t)tot : 0u;   // < 2^32 per slice; summed by finalize_kernel (the
+        a.item_kmers[item] = part == 0u ? (uint32_t)tot : 0u;   // < 2^32 per slice; summed by finalize_kernel (the
                                                                       // passes of one slice count the same k-mers: once)
     }
 
@@ -900,7 +901,7 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
     // item is the only one of its genome (ITEM_SOLE: many small genomes) — straight into the genome's image, header
     // included, so that neither a partial nor a finalize pass is needed for it
     const bool sole = (it.slice & ITEM_SOLE) != 0u;
-    uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)blockIdx.x * a.partial_stride);
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)item * a.partial_stride);
     uint8_t *img = a.images + (uint64_t)it.genome * a.image_bytes;
     const uint32_t HDR = a.lay.hdr_bytes, reg_be = ALGO == 0 ? a.lay.hmh_reg_be : 0u;
     uint32_t *hist = census + 16;                                          // 72 words after the census (HLL header)
@@ -968,7 +969,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     // bucket offset goes straight into the ds_max / ds_or address
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
 
-    const WorkItem it = a.items[blockIdx.x];
+    // work items are handed out longest first when their sizes differ (a.item_order: the host's permutation), so that the last
+    // workgroups to start are the short ones: a mixed collection lost 11 % to its tail in launch order = genome order
+    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x;
+    const WorkItem it = a.items[item];
     const GenomeDesc gd = a.genomes[it.genome];
     const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
     const int k = a.k, p = a.p;
@@ -1008,7 +1012,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         }
         census = lds_regs + a.nreg32;
     } else {
-        regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;           // zeroed by the host (hipMemsetAsync)
+        regs.base = a.gregs + (uint64_t)item * a.nreg32;           // zeroed by the host (hipMemsetAsync)
         census = lds_regs;
     }
 
@@ -1236,7 +1240,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         }
     }
 
-    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p);
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1259,7 +1263,8 @@ template <int ALGO, int KMODE, bool XLOW, int REGS>
 __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
-    const WorkItem it = a.items[blockIdx.x];
+    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x;
+    const WorkItem it = a.items[item];
     if (a.dirty[it.genome] == 0u) return;                                  // only the genomes the direct pass gave up
     const GenomeDesc gd = a.genomes[it.genome];
     const uint64_t L = gd.byte_len;
@@ -1294,7 +1299,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
         census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
     } else {
-        regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;
+        regs.base = a.gregs + (uint64_t)item * a.nreg32;
         census = lds_regs;
     }
     const bool multi_rec = gd.rec_end - gd.rec_begin > 1;
@@ -1532,7 +1537,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
         // surviving bases of this wave's part (lash_timing::bases_last)
         if (lane == 0 && part == 0u && a.ndel2) atomicAdd(a.ndel2 + it.genome, (uint32_t)(we - ws) - own_seen);
     }
-    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p);
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
 }
 
 template <int ALGO, int KMODE, bool XLOW, int REGS>
@@ -1652,7 +1657,7 @@ __global__ void __launch_bounds__(256) aa_sketch_kernel(SketchArgs a)
         }
         for (; i < b1; ++i) residue(a.seq[i]);
     }
-    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, wave_sum(my_kmers), p);
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, wave_sum(my_kmers), p, blockIdx.x);
 }
 
 template <int ALGO, bool XLOW>
