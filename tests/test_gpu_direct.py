@@ -348,3 +348,37 @@ def test_a_gap_longer_than_the_look_ahead_scan(ctx):
         assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g_ in gs for r in g_)
         assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g_ in gs for r in g_)
         same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_STREAM_ONLY), want, "long gap, stream only " + an)
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("ull", 21, 12)])
+def test_many_unequal_genomes_are_handed_out_longest_first(an, k, p):
+    """More work items than workgroup slots and sizes that differ: the library orders the launch longest first (item_order) and
+    the kernels index partials, censuses and images through that permutation.  700 genomes of 20 kb .. 600 kb, a few of them
+    soft-masked (handed to the stream kernel under the same order), some in several records."""
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    rng = random.Random(zlib.crc32(repr(("order", an, k, p)).encode()))
+    gs = []
+    for i in range(700):
+        L = int(20_000 * (30 ** rng.random()))
+        s = bytearray(O.synth_genome(7000 + i, L).tobytes())
+        if i % 37 == 5:
+            for b in range(0, L, 3000):
+                s[b:b + 700] = bytes(s[b:b + 700]).lower()
+        if i % 11 == 3:
+            cuts = sorted(rng.sample(range(1, L), 3))
+            gs.append([bytes(s[a:b]) for a, b in zip([0] + cuts, cuts + [L])])
+        else:
+            gs.append([bytes(s)])
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    want = oracle_images(an, k, p, 42, seq, off, goff)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    same(got, want, "unequal genomes " + an)
+    assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
+    assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g in gs for r in g)
+    same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_STREAM_ONLY), want, "unequal genomes, stream only " + an)
+    same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, "unequal genomes, pack first " + an)
+    ctx.close()
