@@ -36,7 +36,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
         d.rec_begin = formats ? 0 : genome_rec_off[g];
         d.rec_end = formats ? 0 : genome_rec_off[g + 1];
         d.format = formats ? formats[g] : 0u;
-        d.pad = 0;
+        d.handover = 1;
         d.word_off = wo;
         d.brk_off = bo;
         pk->byte_len[g] = d.byte_len;
@@ -242,6 +242,13 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     }
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
+    if (pk->direct) {
+        // how many waves must judge a genome too dirty before it is handed over: one for a genome of a few items, 1 in 32 for a 3 Gbp
+        // read set cut into thousands (where SOME wave always meets four reads with an N among its first tiles)
+        lash_packed *mpk = const_cast<lash_packed *>(pk);
+        for (uint32_t g = 0; g < n_genomes; ++g)
+            mpk->h_descs[g].handover = std::max<uint32_t>(1u, (item_begin[g + 1] - item_begin[g]) * (plan.threads / 64u) / 32u);
+    }
     // Launch order: longest items first when their sizes differ (a collection of 0.6 .. 12 Mbp genomes lost 11 % to the tail of a
     // launch in genome order: the hardware hands workgroups out in index order, and a 3.6 MB item that starts last runs alone).
     // A bucket sort on the size's leading bits: O(items), stable inside a bucket (neighbouring items still share cache lines).

@@ -21,7 +21,8 @@ struct GenomeDesc {
     uint64_t rec_begin;   // records [rec_begin, rec_end) of rec_off[]  (format 0 only)
     uint64_t rec_end;
     uint32_t format;      // 0 = record sequences + rec_off table; 1 = raw FASTA file bytes; 2 = raw FASTQ file bytes
-    uint32_t pad;
+    uint32_t handover;   // direct mode: waves of this genome that must find it too dirty before it is handed to stream_sketch_kernel
+                         // (about 1 in 32 of the waves that work on it, at least 1; set when the work items are planned)
 };
 
 // One workgroup of the sketch kernel = one slice of one genome.

@@ -29,7 +29,7 @@ struct SketchArgs {
     const uint8_t    *safe;       // >= 128 readable bytes: load target of lanes that are not on the fast path
     uint32_t         *dirty;      // [n_genomes + 1] per genome: the direct pass hands this genome to stream_sketch_kernel (much dense
                                   // dirt, or a gap beyond its look-ahead scan); the stream launch runs only these
-    uint32_t         *nslow;      // [n_genomes] wave-tiles of the direct pass that met deleted bytes (budget: sketch_kernels.hip)
+    uint32_t         *nslow;      // [n_genomes] waves that found their part of the genome too dirty for the direct pass (hand-over at GenomeDesc::handover)
     uint32_t         *ndel;       // [n_genomes] bytes the direct pass deleted in place (surviving bases = nvalid - ndel while !dirty)
     uint32_t         *ndel2;      // [n_genomes] bytes stream_sketch_kernel deleted in the genomes it took over (zeroed)
     const uint64_t   *rec_off;    // direct mode: the caller's record offsets (uniform-length genomes derive their record starts from them)

@@ -1041,7 +1041,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
     uint32_t my_kmers = 0;
-    uint32_t tiles_dense = 0;                                               // direct mode, per wave: how many of its tiles needed dense_tile
+    uint32_t tiles_dense = 0;                                               // direct mode, per wave: how many of its tiles held deleted bytes
+    bool judged = false;                                                    // ... and whether it has already voted to hand the genome over
 
     // One tile = blockDim.x * 4 words.  The next tile's words and break bits are loaded into registers before the
     // current tile is hashed (about 10k cycles of VALU work per tile cover the HBM latency).
@@ -1134,11 +1135,23 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                         continue;
                     }
                 }
-                uint32_t over = 0;
-                if ((threadIdx.x & 63) == 0) over = atomicAdd(a.nslow + it.genome, 1u) >= 32u + (uint32_t)(gd.byte_len >> 16);
+                // A genome whose tiles need this often — walked or compacted: a soft-masked assembly, a read set with an N in every
+                // hundredth read — is better off in stream_sketch_kernel, which filters as it reads (tools/dirty_rate.py).
+                // The wave's own tiles are a sample of the genome: from one dirty tile in eight (and at least four) it hands the
+                // genome over; the occasional gap or IUPAC code stays here and costs no second pass.  (Until round 3 a per-genome
+                // counter in memory held a budget of walked tiles: one returning atomic per dirty tile on ONE address, which for a
+                // single 3 Gbp read set with 20 000 Ns serialised in the L2 and cost more than the walks — 2.9 -> 4.4 ms.)
+                tiles_dense = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiles_dense) + 1u;
+                if (tiles_dense >= 4u && tiles_dense * 8u > (tile - it.word_begin) / step + 1u && !judged) {
+                    // this wave's verdict, once; the genome goes when enough of its waves agree (GenomeDesc::handover: one for a
+                    // genome of a few items, 1 in 32 for a read set of thousands — there SOME wave always meets four dirty tiles early)
+                    judged = true;
+                    if ((threadIdx.x & 63) == 0 && atomicAdd(a.nslow + it.genome, 1u) + 1u >= gd.handover)
+                        atomicOr(dirty, 1u);                                   // (seen by every wave of the genome at its next tile load)
+                }
                 // a quarter of the lanes met deleted bytes: dense without looking closer
-                bool dense = __builtin_amdgcn_readfirstlane((int)over) != 0 || __builtin_popcountll(__builtin_amdgcn_ballot_w64(bad != 0u)) >= 16;
-                uint32_t nd = 0;
+                bool dense = __builtin_popcountll(__builtin_amdgcn_ballot_w64(bad != 0u)) >= 16;
+                uint32_t nd = 0, wave_nd = 0;
                 uint64_t junc = 0, jstarts = 0;
                 if (!dense) {
                     bool far = false;
@@ -1162,19 +1175,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                                   pos0 + 96 < L;                               // (the genome's end cuts the walk short anyway)
                         }
                     }
-                    uint32_t wave_nd = nd;
-                    for (int o = 32; o > 0; o >>= 1) wave_nd += __shfl_xor(wave_nd, o, 64);
+                    wave_nd = wave_sum(nd);
                     dense = wave_nd > 1024u || __builtin_amdgcn_ballot_w64(far) != 0ull;
                 }
                 if (dense) {
-                    // A genome that needs this often (a soft-masked assembly) is better off in stream_sketch_kernel, which compacts as it
-                    // reads and is faster on anything but clean input (tools/dirty_rate.py, DESIGN.md 4.0: 10 kb blocks 4.05 ms in place
-                    // vs 3.03 ms streamed per 5 Gbp).  The wave's own tiles are a sample of the genome: from one dense tile in eight
-                    // (and at least four) it hands the genome over; the occasional gap stays here and costs no second pass.
-                    tiles_dense = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiles_dense) + 1u;
-                    const uint32_t tiles_seen = (tile - it.word_begin) / step + 1u;
-                    if (tiles_dense >= 4u && tiles_dense * 8u > tiles_seen && (threadIdx.x & 63) == 0)
-                        atomicOr(dirty, 1u);                                   // (seen by every wave of the genome at its next tile load)
                     const uint64_t P0 = 16ull * (tile + (threadIdx.x & ~63u) * SKETCH_WORDS_PER_THREAD);
                     uint64_t E = P0 + 4096 < 16ull * it.word_end ? P0 + 4096 : 16ull * it.word_end;
                     E = E < L ? E : L;
@@ -1187,7 +1191,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     tile_load(tile + step, nxt);
                     continue;
                 }
-                if (nd && part == 0u) atomicAdd(a.ndel + it.genome, nd);         // (the passes of a partitioned table see the same bytes)
+                if (wave_nd && part == 0u && (threadIdx.x & 63) == 0) atomicAdd(a.ndel + it.genome, wave_nd);   // (one per wave; the passes of a partitioned table see the same bytes)
                 uint32_t walked = 0;
                 if (junc)                                                      // (here, not after the hashing: nothing of it stays live)
                     walked = junction_walk<ALGO, XLOW, Regs>(regs, gseq, L, pos0, junc, jstarts, use_bitmap ? bk : nullptr, RL, k, kp.bitflip, p,

@@ -19,6 +19,10 @@ for name, lens in (("equal 150 bp", np.full(N, 150, np.int64)), ("100..150 bp", 
     ctx = lash_amd.Context(0)
     d_seq = torch.empty(L, dtype=torch.uint8, device=dev)
     ctx.synth_genomes_device(900000, 1, L, d_seq)
+    if os.environ.get("N_FRAC"):                               # an N in that fraction of the reads (what real FASTQ has)
+        idx = torch.from_numpy(rng.choice(N, size=int(N * float(os.environ["N_FRAC"])), replace=False).astype(np.int64)).to(dev)
+        at = torch.from_numpy(off[:-1].astype(np.int64)).to(dev)[idx] + 37
+        d_seq[at] = ord("N")
     d_rec = torch.from_numpy(off.astype(np.int64)).to(dev)
     d_img = torch.zeros(lash_amd.image_bytes("ull", 12), dtype=torch.uint8, device=dev)
     goff = np.array([0, N], dtype=np.uint64)
@@ -32,6 +36,6 @@ for name, lens in (("equal 150 bp", np.full(N, 150, np.int64)), ("100..150 bp", 
     ctx.synchronize()
     t = ctx.timing()
     ms = (t["sketch_ms"] + t["finalize_ms"] + t["pack_ms"]) / 10
-    print("%-14s %d reads, %.2f GB: %.3f ms per step -> %.4g k-mers/s (%.4g B/s)" % (name, N, L / 1e9, ms, t["kmers"] / 10 / (ms * 1e-3), L / (ms * 1e-3)), flush=True)
+    print("%-14s %d reads, %.2f GB: %.3f ms per step -> %.4g k-mers/s (%.4g B/s), direct launches %d of 10" % (name, N, L / 1e9, ms, t["kmers"] / 10 / (ms * 1e-3), L / (ms * 1e-3), t["direct_launches"]), flush=True)
     ctx.close()
     del d_seq, d_rec
