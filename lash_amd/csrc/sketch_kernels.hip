@@ -1416,11 +1416,12 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             // record starts among the lane's 32 positions (multi-record genomes: contigs, reads)
             uint32_t rb = 0;
             if (breaks && at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
-            const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we &&
-                                     (!breaks || (!pend && __builtin_amdgcn_ballot_w64(rb != 0u) == 0ull));
+            // nothing deleted in an owned chunk (and no record start waiting for a survivor): every base goes to the ring as it is,
+            // and a record start stays on its own base
+            const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we && !pend;
             uint32_t T, own_t;
             if (chunk_clean) {
-                // 2 048 survivors, all owned, no record starts: lane i's 32 bases go to ring position have + 32 i, one shift for all
+                // 2 048 survivors, all owned: lane i's 32 bases go to ring position have + 32 i, one shift for all
                 const uint32_t rel = have + 32u * lane, sh = 2u * (rel & 15u);
                 uint32_t w = head_w + (rel >> 4); w = w >= RING_W ? w - RING_W : w;
                 const uint32_t w1 = w + 1u == RING_W ? 0u : w + 1u, w2 = w1 + 1u == RING_W ? 0u : w1 + 1u;
@@ -1431,6 +1432,12 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
                 } else {
                     lds_or(stage_b + 4u * w, cw0);
                     lds_or(stage_b + 4u * w1, cw1);
+                }
+                if (breaks && __builtin_amdgcn_ballot_w64(rb != 0u) != 0ull && rb) {   // (reads: a dozen record starts per chunk)
+                    uint32_t bw = (head_w >> 1) + (rel >> 5); bw = bw >= RING_BW ? bw - RING_BW : bw;
+                    const uint32_t bwn = bw + 1u == RING_BW ? 0u : bw + 1u, bs = rel & 31u;
+                    lds_or(brk_b + 4u * bw, rb << bs);
+                    if (bs) lds_or(brk_b + 4u * bwn, rb >> (32u - bs));
                 }
                 T = STREAM_CHUNK; own_t = STREAM_CHUNK;
             } else {
