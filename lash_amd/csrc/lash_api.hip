@@ -311,7 +311,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
                 uint32_t *nonuni = pk->d_dirty + 3 * (size_t)n_genomes + 1;
                 HIPCHK(ctx, launch_rec_uniform(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, ctx->stream));
                 HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, static_cast<uint32_t *>(pk->brk_bytes.ptr),
-                                             pk->n_rec != 0 && total_bytes / pk->n_rec >= 1024u, ctx->stream));
+                                             ctx->stream));
             }
         }
     }

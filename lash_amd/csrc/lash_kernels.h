@@ -75,10 +75,10 @@ hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off
                               hipStream_t stream);
 // record starts of the multi-record format-0 genomes whose records differ in length -> args.brk_bytes; every word of such a
 // genome's bitmap is written (no memset needed), genomes with nonuniform[g] == 0 are left alone
-// long_records: the batch's records average a KiB or more (assemblies of contigs, not read sets): zero the bitmaps with every
-// thread and OR the few record starts in, instead of one thread per record writing its stretch of words
+// (genomes whose records average a KiB or more — assemblies of contigs — have their bitmaps zeroed by every thread and the few record
+// starts OR-ed in; read sets are written from their head records: decided per genome on the device)
 hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, const uint32_t *nonuniform,
-                            uint32_t *brk_bytes, bool long_records, hipStream_t stream);
+                            uint32_t *brk_bytes, hipStream_t stream);
 // fastq_check.hip: the FASTQ rule the pack kernel's line-structure check cannot see — a quality line as long as its sequence
 // line, a file that ends on a whole record (needletail's Err; /root/reference/src/utils.rs:453-459 stops there).
 struct FqFile {

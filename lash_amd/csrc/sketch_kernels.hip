@@ -1928,6 +1928,10 @@ __global__ void __launch_bounds__(256) rec_uniform_kernel(const GenomeDesc *geno
     }
 }
 
+// which of the two bitmap writers takes a genome: long records (a draft assembly: contigs of a KiB and more on average) are zeroed by
+// every thread and have their few starts OR-ed in; short ones (a read set) are written word by word from their "head" records
+__device__ __forceinline__ bool long_records(const GenomeDesc &gd) { return gd.byte_len / (gd.rec_end - gd.rec_begin) >= 1024u; }
+
 // one thread per record: the first byte of every record but a genome's first is a k-mer barrier (utils.rs:457-464).
 // Record offsets ascend, so the records whose bits share a 32-bit word are consecutive: the first of them ("head": the
 // record before it lands in another word) gathers the bits of its followers, writes the word with ONE plain store and zeroes
@@ -1940,6 +1944,7 @@ __global__ void __launch_bounds__(256) brk_bytes_kernel(const GenomeDesc *genome
         const GenomeDesc gd = genomes[g];
         if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
         if (nonuniform && nonuniform[g] == 0u) continue;                  // equal-length records: nobody reads this genome's bitmap
+        if (long_records(gd)) continue;                                   // brk_zero_kernel + brk_set_kernel
         const uint64_t n_words = (gd.byte_len + 1 + 31) / 32 + 4;        // (+3 words of look-ahead in kmer_valid_mask)
         uint32_t *bm = brk_bytes + gd.brk_off;
         // in-genome record starts: positions < byte_len (empty records at the genome's end start at byte_len: no barrier)
@@ -1980,6 +1985,7 @@ __global__ void __launch_bounds__(256) brk_zero_kernel(const GenomeDesc *genomes
         const GenomeDesc gd = genomes[g];
         if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
         if (nonuniform && nonuniform[g] == 0u) continue;
+        if (!long_records(gd)) continue;
         const uint64_t n_words = (gd.byte_len + 1 + 31) / 32 + 4;
         uint32_t *bm = brk_bytes + gd.brk_off;
         for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) bm[w] = 0u;
@@ -1992,6 +1998,7 @@ __global__ void __launch_bounds__(256) brk_set_kernel(const GenomeDesc *genomes,
         const GenomeDesc gd = genomes[g];
         if (gd.format != 0u || gd.rec_end - gd.rec_begin <= 1) continue;
         if (nonuniform && nonuniform[g] == 0u) continue;
+        if (!long_records(gd)) continue;
         uint32_t *bm = brk_bytes + gd.brk_off;
         for (uint64_t r = gd.rec_begin + 1 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < gd.rec_end; r += (uint64_t)gridDim.x * blockDim.x) {
             const uint64_t pos = rec_off[r] - gd.byte_off;
@@ -2017,15 +2024,13 @@ hipError_t launch_rec_uniform(const GenomeDesc *genomes, const uint64_t *rec_off
 }
 
 hipError_t launch_brk_bytes(const GenomeDesc *genomes, const uint64_t *rec_off, uint32_t n_genomes, uint64_t n_rec, const uint32_t *nonuniform,
-                            uint32_t *brk_bytes, bool long_records, hipStream_t stream)
+                            uint32_t *brk_bytes, hipStream_t stream)
 {
     if (n_genomes == 0) return hipSuccess;
-    if (long_records) {
-        const uint32_t gy = std::min(n_genomes, 1024u), gx = std::max(4u, std::min(256u, 8192u / gy));
-        hipLaunchKernelGGL(brk_zero_kernel, dim3(gx, gy), dim3(256), 0, stream, genomes, n_genomes, nonuniform, brk_bytes);
-        hipLaunchKernelGGL(brk_set_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform, brk_bytes);
-        return hipGetLastError();
-    }
+    // every genome is taken by exactly one of the two forms (long_records()); a batch may hold both kinds
+    const uint32_t gy = std::min(n_genomes, 1024u), gx = std::max(4u, std::min(256u, 8192u / gy));
+    hipLaunchKernelGGL(brk_zero_kernel, dim3(gx, gy), dim3(256), 0, stream, genomes, n_genomes, nonuniform, brk_bytes);
+    hipLaunchKernelGGL(brk_set_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform, brk_bytes);
     hipLaunchKernelGGL(brk_bytes_kernel, per_record_grid(n_genomes, n_rec), dim3(256), 0, stream, genomes, rec_off, n_genomes, nonuniform, brk_bytes);
     return hipGetLastError();
 }
