@@ -452,8 +452,8 @@ __device__ __noinline__ TailWords ascii96_tail(const uint8_t *gseq, uint64_t o, 
 // are — a "junction" k-mer.  Junction k-mers are few (at most k-1 per run of deleted bytes) and belong to the lane that
 // owns b; that lane walks forward from its first junction start, skipping deleted bytes, and hashes them one by one.
 // A sprinkle of IUPAC codes or an N in a read therefore costs a few microseconds of one lane.  Tiles where that would not be
-// cheap — much of the tile deleted, a junction k-mer whose bases lie beyond its lane's 96 bytes, a genome past its budget of
-// walked tiles — are compacted by their wave instead (dense_tile, below); WALK_MAX is a safety net behind those tests.
+// cheap — much of the tile deleted, a junction k-mer whose bases lie beyond its lane's 96 bytes — are compacted by their wave
+// instead (dense_tile, below); WALK_MAX is a safety net behind those tests.
 constexpr uint32_t WALK_MAX = 4096;          // bytes a junction walk may read past its lane's 64 positions
 
 __device__ __forceinline__ uint32_t inv4(uint32_t x)            // bit j: byte j is not one of A C G T
@@ -1120,9 +1120,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             }
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) {      // (unlikely: keeps its spills out of the clean path)
                 // bytes outside the alphabet in this wave's tile.  Sparse dirt (an IUPAC code, an N in a read): the lanes that own
-                // junction k-mers walk them, below.  Dense dirt — more than a quarter of the 4 KiB deleted, a junction k-mer whose
-                // bases lie beyond its lane's 96 bytes (the flank of a gap or of a soft-masked block), or a genome past its budget
-                // of walked wave-tiles: the wave compacts the tile in LDS and hashes the survivors (dense_tile).
+                // junction k-mers walk them, below.  Dense dirt — more than a quarter of the 4 KiB deleted, or a junction k-mer whose
+                // bases lie beyond its lane's 96 bytes (the flank of a gap or of a soft-masked block): the wave compacts the tile in
+                // LDS and hashes the survivors (dense_tile).
                 const bool raw_ok = active && direct_fast(w0);                 // cur.q .. cur.a3 are this lane's own 64 bytes
                 {
                     // the inside of a soft-masked block or of a gap: every active lane sees nothing but lower case / N -> nothing to do
