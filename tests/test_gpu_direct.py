@@ -382,3 +382,28 @@ def test_many_unequal_genomes_are_handed_out_longest_first(an, k, p):
     same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_STREAM_ONLY), want, "unequal genomes, stream only " + an)
     same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, "unequal genomes, pack first " + an)
     ctx.close()
+
+
+@pytest.mark.parametrize("frac", [0.002, 0.05])
+def test_a_read_set_with_ns_is_voted_on_by_its_waves(ctx, frac):
+    """One 30 Mbp genome of 150-bp reads, an N in `frac` of them: hundreds of work items, so the hand-over needs 1 in 32 of the
+    genome's waves to agree (GenomeDesc::handover) — a few unlucky waves at 0.2 % do not send it away, at 5 % they all vote.
+    Either way the images, the census and the surviving bases are the oracle's."""
+    import lash_amd
+    rng = np.random.default_rng(int(frac * 1e4))
+    n, rl = 200_000, 150
+    s = np.frombuffer(O.synth_genome(5151, n * rl).tobytes(), np.uint8).copy()
+    hit = rng.choice(n, size=int(n * frac), replace=False)
+    s[hit * rl + rng.integers(0, rl, size=len(hit))] = ord("N")
+    seq = s
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(rl))
+    goff = np.array([0, n], dtype=np.uint64)
+    for an, k, p in (("ull", 16, 12), ("hmh", 21, 0)):
+        want = oracle_images(an, k, p, 42, seq, off, goff)
+        ctx.enable_timing(True)
+        got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+        tm = ctx.timing()
+        ctx.enable_timing(False)
+        same(got, want, "reads with N %s %g" % (an, frac))
+        assert tm["kmers"] == (n - len(hit)) * (rl - k + 1) + len(hit) * (rl - 1 - k + 1)      # (the N is deleted, its flanks are joined)
+        assert tm["bases_last"] == n * rl - len(hit)
