@@ -226,19 +226,49 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     bool all_sole = plan.parts_log2 == 0 && plan.use_lds && n_genomes > 0;   // every genome has exactly one work item
     std::vector<uint32_t> item_begin(n_genomes + 1, 0);
     items.reserve(n_genomes * 2);
+    auto slicing = [&](uint32_t g, uint64_t &nw, uint64_t &ns, uint64_t &per) {
+        nw = ((pk->byte_len[g] + 15) / 16 + 3) & ~3ull;
+        ns = nw ? (nw + target - 1) / target : 0;
+        per = nw ? (((nw + ns - 1) / ns) + 3) & ~3ull : 0;
+    };
+    // The tail of a launch: equal items run in lockstep rounds of `slots`, and the last round is as long as a full one however
+    // few items it holds (600 x 5 Mbp in 2 400 items = 4.7 rounds took the time of 5; 12 500 whole genomes 24.4 -> 25).  The last
+    // round's worth of slices is therefore cut into quarters: the launch ends on a quarter-round boundary instead.  Index order is
+    // launch order, so the small items are the ones handed out last.
+    static const uint32_t tail_split = getenv("LASH_TAIL_SPLIT") ? (uint32_t)std::max(1, atoi(getenv("LASH_TAIL_SPLIT"))) : 4u;
+    const uint64_t tail_min = min_slice / 8;                        // 32 kb of sequence: 15 us of a workgroup's time
+    uint64_t n_coarse = 0, fine_from = ~0ull;
+    uint64_t c_lo = ~0ull, c_hi = 0;                               // smallest and largest slice
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        uint64_t nw, ns, per;
+        slicing(g, nw, ns, per);
+        if (!nw) continue;
+        const uint64_t cnt = (nw + per - 1) / per, last = nw - (cnt - 1) * per;
+        n_coarse += cnt;
+        c_lo = std::min(c_lo, last); c_hi = std::max(c_hi, cnt > 1 ? per : last);
+    }
+    const bool unequal = c_hi > c_lo + c_lo / 4;                   // then the launch goes longest first (below) and ends on its small items anyway
+    // (two or three rounds' worth in quarters, or halves / eighths: the same within noise)
+    if (plan.use_lds && tail_split > 1 && n_coarse > slots && !unequal) fine_from = n_coarse - slots;
+    uint64_t ci = 0;                                               // coarse slice counter over the batch
     for (uint32_t g = 0; g < n_genomes; ++g) {
         item_begin[g] = (uint32_t)items.size();
-        const uint64_t nw = ((pk->byte_len[g] + 15) / 16 + 3) & ~3ull;
+        uint64_t nw, ns, per;
+        slicing(g, nw, ns, per);
         if (nw == 0) { all_sole = false; continue; }               // no work item at all: finalize writes the empty image
-        const uint64_t ns = (nw + target - 1) / target;
-        const uint64_t per = (((nw + ns - 1) / ns) + 3) & ~3ull;
         uint32_t s = 0;
-        max_slices = std::max<uint32_t>(max_slices, (uint32_t)((nw + per - 1) / per));
-        if (ns != 1) all_sole = false;
-        for (uint64_t b = 0; b < nw; b += per, ++s)
-            for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)                   // slice index | pass << 16
-                items.push_back(WorkItem{g, (uint32_t)b, (uint32_t)std::min(nw, b + per),
-                                         (s & 0x7FFFu) | (part << 16) | ((ns == 1 && plan.parts_log2 == 0 && plan.use_lds) ? ITEM_SOLE : 0u)});
+        const bool whole = ns == 1 && plan.parts_log2 == 0 && plan.use_lds;
+        for (uint64_t b = 0; b < nw; b += per, ++ci) {
+            const uint64_t e = std::min(nw, b + per);
+            uint64_t sub = e - b;                                  // this slice as one item, or as tail_split smaller ones
+            if (ci >= fine_from && (e - b) / tail_split >= tail_min) sub = ((((e - b) + tail_split - 1) / tail_split) + 3) & ~3ull;
+            const bool sole = whole && sub == e - b;
+            for (uint64_t bb = b; bb < e; bb += sub, ++s)
+                for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)               // slice index | pass << 16
+                    items.push_back(WorkItem{g, (uint32_t)bb, (uint32_t)std::min(e, bb + sub), (s & 0x7FFFu) | (part << 16) | (sole ? ITEM_SOLE : 0u)});
+        }
+        max_slices = std::max<uint32_t>(max_slices, s);
+        if (s != 1) all_sole = false;
     }
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
@@ -254,9 +284,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // A bucket sort on the size's leading bits: O(items), stable inside a bucket (neighbouring items still share cache lines).
     std::vector<uint32_t> order;
     {
-        uint32_t lo = ~0u, hi = 0;
-        for (const WorkItem &w : items) { const uint32_t n = w.word_end - w.word_begin; lo = std::min(lo, n); hi = std::max(hi, n); }
-        if (n_items > slots && hi > lo + lo / 4) {
+        if (n_items > slots && unequal) {
             auto bucket = [&](uint32_t n) {                             // 8 buckets per octave, larger sizes first
                 const uint32_t e = 31u - (uint32_t)__builtin_clz(n | 1u);
                 const uint32_t m = e >= 3 ? (n >> (e - 3)) & 7u : 0u;
@@ -407,7 +435,9 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // one finalize workgroup walks all of a genome's partials: fine for a handful of slices, 20 ms for the 4 096 slices of
     // a metagenome-sized input (BASELINE configs[4]) -> fold groups of 32 slices first (until <= 16 heads remain)
     fa.group = 0;
-    if (max_slices > 32u && n_genomes <= 65535u)
+    // (from 9 slices on: finalize_kernel's walk is serial — a dependent load per slice and word — and the tail quarters give a
+    // genome up to 16: 300 x 5 Mbp, finalize stage 0.27 -> 0.15 ms)
+    if (max_slices > 8u && n_genomes <= 65535u)
         for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
     if (all_sole) {
         HIPCHK(ctx, launch_census(fa, n_genomes, ctx->stream));            // every image was written by its one work item
@@ -523,7 +553,9 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     fa.src_images = 0;
     fa.hll_corner = sa.hll_corner;
     fa.group = 0;
-    if (max_slices > 32u && n_genomes <= 65535u)
+    // (from 9 slices on: finalize_kernel's walk is serial — a dependent load per slice and word — and the tail quarters give a
+    // genome up to 16: 300 x 5 Mbp, finalize stage 0.27 -> 0.15 ms)
+    if (max_slices > 8u && n_genomes <= 65535u)
         for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
     HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
     HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));

@@ -3,6 +3,7 @@
 lash_sketch_batch[_device] first lets the sketch kernel read the record bytes itself — exact while a genome holds only
 upper-case ACGT, because filter_out_n (utils.rs:33-41) then deletes nothing — and re-does, in the same call, every genome
 in which it met another byte through the pack stage.  Both routes must give the oracle's images, whatever the mix."""
+import os
 import random
 import zlib
 
@@ -407,3 +408,42 @@ def test_a_read_set_with_ns_is_voted_on_by_its_waves(ctx, frac):
         same(got, want, "reads with N %s %g" % (an, frac))
         assert tm["kmers"] == (n - len(hit)) * (rl - k + 1) + len(hit) * (rl - 1 - k + 1)      # (the N is deleted, its flanks are joined)
         assert tm["bases_last"] == n * rl - len(hit)
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("ull", 21, 12), ("hll", 21, 16)])
+def test_the_last_round_of_equal_items_is_cut_into_quarters(an, k, p):
+    """More equal work items than workgroup slots: the last round's worth of them is cut into quarters (lash_api.hip, "the tail of
+    a launch").  220 genomes of 1.06 Mbp are 1 100 slices of 13 252 words; with 512 slots (hmh on a 256-CU part) the first 588 stay
+    whole and the other 512 become four work items each — genomes with 5, 8..17 and 20 partials in one launch, which also takes
+    the finalize stage through its grouped fold.  Some genomes in records, one soft-masked; the oracle checks a sample from both ends and
+    the middle, the census all of it.  hll p = 16 runs two bucket-space passes per slice on top."""
+    import lash_amd
+    ctx = lash_amd.Context(0)
+    n, L = 220, 1_060_000
+    gs = []
+    for i in range(n):
+        s = O.synth_genome(9000 + i, L).tobytes()
+        if i % 53 == 1:
+            gs.append([s[:300_001], s[300_001:300_050], s[300_050:]])
+        elif i == 120:
+            b = bytearray(s)
+            for at in range(0, L, 5000):
+                b[at:at + 900] = bytes(b[at:at + 900]).lower()
+            gs.append([bytes(b)])
+        else:
+            gs.append([s])
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    ctx.enable_timing(True)
+    got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+    tm = ctx.timing()
+    ctx.enable_timing(False)
+    assert tm["kmers"] == sum(max(0, len(O.filter_out_n(r)) - k + 1) for g in gs for r in g)
+    import torch
+    if (an == "hmh" and torch.cuda.get_device_properties(0).multi_processor_count == 256 and "LASH_TAIL_SPLIT" not in os.environ
+            and "LASH_SLICE_FACTOR" not in os.environ):
+        assert tm["sketch_workgroups"] == (1100 - 512) + 512 * 4                 # (64 KiB of LDS sketch: two workgroups per CU)
+    assert tm["sketch_workgroups"] > 1100
+    sample = [0, 1, 2, 14, 15, 16, 54, 107, 116, 117, 118, 119, 120, 121, 160, n - 2, n - 1]
+    sseq, soff, sgoff = lash_amd.records_to_arrays([gs[i] for i in sample])
+    same(got[sample], oracle_images(an, k, p, 42, sseq, soff, sgoff), "tail quarters " + an)
+    ctx.close()
