@@ -32,7 +32,7 @@ class Timing(C.Structure):
     _fields_ = [("pack_ms", C.c_float), ("sketch_ms", C.c_float), ("finalize_ms", C.c_float), ("calls", C.c_uint32),
                 ("sketch_launches", C.c_uint32), ("sketch_workgroups", C.c_uint32), ("direct_launches", C.c_uint32),
                 ("kmers", C.c_uint64), ("bases_last", C.c_uint64), ("packed_bytes", C.c_uint64),
-                ("direct_ms", C.c_float), ("reserved", C.c_float)]
+                ("direct_ms", C.c_float), ("defer_launches", C.c_uint32)]
 
 
 _vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int

@@ -297,6 +297,14 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             for (uint32_t i = 0; i < n_items; ++i) order[count[bucket(items[i].word_end - items[i].word_begin)]++] = i;
         }
     }
+    // HyperMinHash with deferred signatures (process_word_defer) pays off when a work item's table fills up early in the item, i.e.
+    // when items are long: the share of k-mers that can still change their bucket is 2.8 % at 5 Mbp per item, 10 % at 1 Mbp
+    SketchPlan plan_d = plan;
+    {
+        static const int64_t defer_min = getenv("LASH_DEFER_MIN") ? atoll(getenv("LASH_DEFER_MIN")) : 2000000;   // bases per work item; < 0: never
+        plan_d.defer = pk->direct && prm->algo == LASH_HMH && !x_low && !plan.alt && plan.use_lds && plan.parts_log2 == 0 && n_items > 0 &&
+                       defer_min >= 0 && total_words * 16 / n_items >= (uint64_t)defer_min;
+    }
     TRACE("sketch: planned");
 
     int rc;
@@ -396,10 +404,11 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.ndel2 = pk->d_dirty + 4 * (size_t)n_genomes + 2;
         if (!pk->stream_first) {
             if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));       // direct_ms: this one launch
-            HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
+            HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
             if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
             if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
             ctx->last.direct_launches += n_items ? 1 : 0;
+            ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
         } else {
             // recent batches were full of finely fragmented dirt: every genome goes straight to the compacting kernel
             HIPCHK(ctx, hipMemsetAsync(pk->d_dirty, 0x01, (size_t)n_genomes * 4, ctx->stream));

@@ -107,6 +107,20 @@ __device__ __forceinline__ void xxh3_128_4b_hmh_fast(uint32_t w, uint64_t bitfli
     xh = __umulhi(h0, m0) + h0 * m1 + h1 * m0;
 }
 
+// ... and only the half that decides bucket and rank (the signature half — a third of the instructions — is left to the few
+// k-mers whose rank can still win their bucket: process_word_defer)
+__device__ __forceinline__ uint32_t xxh3_128_4b_hmh_rank(uint32_t w, uint64_t bitflip)
+{
+    uint64_t l, h;
+    xxh3_mul128(w ^ (uint32_t)bitflip, w ^ (uint32_t)(bitflip >> 32), l, h);
+    asm("" : "+v"(l));                                   // (opaque: with nothing else using l, hipcc folds the doubling into the multiply chain — 8 instructions for one)
+    asm("v_lshl_add_u64 %0, %1, 1, %0" : "+v"(h) : "v"(l));   // h += l << 1
+    h ^= h >> 37;
+    constexpr uint32_t m0 = (uint32_t)XXH_PRIME_MX1, m1 = (uint32_t)(XXH_PRIME_MX1 >> 32);
+    const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+    return __umulhi(h0, m0) + h0 * m1 + h1 * m0;
+}
+
 // XXH3-64 of the 8 little-endian bytes of {v_hi,v_lo} (XXH3_len_4to8_64b, len = 8 -> XXH3_rrmxmx), up to but NOT including the
 // final `h ^= h >> 28`
 __device__ __forceinline__ uint64_t xxh3_64_8b_pre(uint32_t v_lo, uint32_t v_hi, uint64_t bitflip)

@@ -56,6 +56,7 @@ struct SketchPlan {
     uint32_t parts_log2;          // > 0: the bucket space is covered in 2^parts_log2 passes, nreg32 / lds_bytes are per pass
     uint32_t partial_bytes;       // bytes of one partial sketch (register array only)
     uint32_t partial_stride;      // rounded up to 16
+    bool     defer = false;       // direct HyperMinHash launch with deferred signatures (the caller sets it for batches of large work items)
 };
 
 // small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)

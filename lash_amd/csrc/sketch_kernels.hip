@@ -311,6 +311,92 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// HyperMinHash with the signature deferred.  A k-mer changes its bucket only if its rank is at least the bucket's current one —
+// one k-mer in 25 of a 5 Mbp genome — and the rank needs only the x half of the hash.  The filter computes that half, reads the
+// bucket's register back (a stale value is a smaller one: the test only gets more permissive) and appends the k-mers that pass to a
+// wave-private list in LDS (the wave's dense_tile staging area; 320 entries: 63 left over + 4 k-mers x 64 lanes between two
+// checks); whenever 64 are waiting, the wave runs the full update on them, one per lane, every lane busy.  max() is commutative
+// and idempotent: order and repetition do not matter.  The list is drained from its end, so it never wraps or moves.
+//   rank test: x18 = the 18 rank bits below the bucket; lz_new >= lz_cur  <=>  x18 <= 0x7FFFF >> lz_cur   (lz_cur 0 = empty: all pass;
+//   lz_cur >= 19 — more zeros than the 18 bits show — x18 must be 0, and the full update decides; 32 and up pass everything)
+// ------------------------------------------------------------------------------------------------------------
+struct SigQueue { uint32_t base_b, pos_b; };                // wave-uniform LDS byte addresses: the list, its first free slot
+constexpr uint32_t SIGQ_CAP = 320;                          // the word after them takes the stores of the lanes that did not pass
+
+__device__ __forceinline__ uint32_t lds_load(uint32_t byte_addr) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr; }
+__device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr = v; }
+
+template <class Regs>
+__device__ __forceinline__ void sigq_drain64(const Regs &regs, uint64_t bitflip, int p, SigQueue &q, uint32_t lane)
+{
+    q.pos_b -= 256u;
+    const uint32_t c = lds_load(q.pos_b + lane * 4u);
+    const uint32_t t = add_kmer<0, false, false, true>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
+    if (__builtin_amdgcn_ballot_w64(t < 0x4000u) != 0ull) (void)add_kmer<0, false, false, false>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
+}
+template <class Regs>
+__device__ __forceinline__ void sigq_drain_all(const Regs &regs, uint64_t bitflip, int p, SigQueue &q, uint32_t lane)
+{
+    q.pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.pos_b);
+    while (q.pos_b >= q.base_b + 256u) sigq_drain64(regs, bitflip, p, q, lane);
+    const uint32_t n = (q.pos_b - q.base_b) >> 2;
+    if (n) {
+        const uint32_t c = lds_load(q.base_b + (lane < n ? lane : 0u) * 4u);
+        (void)add_kmer<0, false, true, false>(regs, c, 0u, lane < n ? 0xFFFFFFFFu : 0u, bitflip, p);
+        q.pos_b = q.base_b;
+    }
+}
+
+template <int KMODE, bool MASKED, class Regs>
+__device__ __forceinline__ void process_word_defer(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1, uint32_t c2,
+                                                   uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw, SigQueue &q, uint32_t lane)
+{
+    const uint32_t base_b = q.base_b;
+    uint32_t pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.pos_b);
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) {
+        // four k-mers as one straight line: four rank halves, four registers read back, four tests, four stores (the lanes that
+        // did not pass store to a dummy word) — no branch before the list is appended to: with a branch per k-mer the scheduler had
+        // one hash chain at a time, 16 % slower than not deferring at all
+        uint32_t can[4], x18[4], cur[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = g + j;
+            if constexpr (KMODE == KM_GT16) {
+                const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
+                const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
+                const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
+                const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
+                const uint32_t rh = r ? alignbit(r2, r1, 2 * r) : r1;
+                const uint64_t rc = (((uint64_t)rh << 32) | rl) & kp.mask_gt;
+                can[j] = (uint32_t)(fwd < rc ? fwd : rc);
+            } else {
+                uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
+                uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
+                if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
+                can[j] = fwd < rc ? fwd : rc;
+            }
+            const uint32_t xh = xxh3_128_4b_hmh_rank(can[j], kp.bitflip);
+            cur[j] = lds_load((xh >> 16) & 0xFFFCu);                                              // the register table starts at LDS address 0
+            x18[j] = xh & 0x3FFFFu;
+            if constexpr (MASKED) x18[j] |= ~(uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1);   // not a k-mer: never passes
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pass = x18[j] <= (0x7FFFFu >> ((cur[j] >> 10) & 31u));
+            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+            // (the running position stays in a scalar register and enters as the one scalar operand of the address's shift-add: as
+            // the count operand of v_mbcnt it would be a second scalar beside the mask and cost a v_mov per k-mer)
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (pass) lds_store(at * 4u + pos_b, can[j]);
+            pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos_b + 4u * (uint32_t)__builtin_popcountll(m)));
+        }
+        while (pos_b >= base_b + 256u) { q.pos_b = pos_b; sigq_drain64(regs, kp.bitflip, kp.p, q, lane); pos_b = q.pos_b; }
+    }
+    q.pos_b = pos_b;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------------------
 #ifndef LASH_SKETCH_WAVES_PER_EU
@@ -961,10 +1047,11 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
     }
 }
 
-template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT = false>
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT = false, bool DEFER = false>
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
     static_assert(!(ALT && DIRECT), "the alternative k-mer / bucket rules run on packed input only");
+    static_assert(!DEFER || (ALGO == 0 && !XLOW && REGS == REGS_LDS && DIRECT && !ALT), "deferred signatures: HyperMinHash, x = high half, direct mode");
     // dynamic LDS: [nreg32 register words][16 words of per-wave census]; registers start at LDS offset 0 so the
     // bucket offset goes straight into the ds_max / ds_or address
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
@@ -1041,6 +1128,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
     uint32_t my_kmers = 0;
+    SigQueue sigq;                                                          // DEFER: lives in the wave's staging area
+    sigq.base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.stage_off + (threadIdx.x >> 6) * (DENSE_STAGE_WORDS * 4u)));
+    sigq.pos_b = sigq.base_b;
+    const uint32_t lane = threadIdx.x & 63u;
     uint32_t tiles_dense = 0;                                               // direct mode, per wave: how many of its tiles held deleted bytes
     bool judged = false;                                                    // ... and whether it has already voted to hand the genome over
 
@@ -1183,6 +1274,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     uint64_t E = P0 + 4096 < 16ull * it.word_end ? P0 + 4096 : 16ull * it.word_end;
                     E = E < L ? E : L;
                     const uint32_t stage_b = a.stage_off + (threadIdx.x >> 6) * (DENSE_STAGE_WORDS * 4u);
+                    if constexpr (DEFER) sigq_drain_all(regs, kp.bitflip, p, sigq, lane);     // (the staging area is about to be used)
                     my_kmers += wave_sum(dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
                                                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
                                                                             part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3));
@@ -1219,6 +1311,14 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 if (a.lay.hll_bucket_high) (void)process_word<ALGO, KMODE, XLOW, true, false, Regs, true, ALGO == 1>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
                 else (void)process_word<ALGO, KMODE, XLOW, true, false, Regs, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
                 z = 0xFFFFFFFFu;
+            } else if constexpr (DEFER) {
+                z = 0xFFFFFFFFu;                                               // (nothing to re-run: the full update does that itself)
+                if (all_valid) process_word_defer<KMODE, false>(regs, kp, c0, c1, c2, r0, r1, r2, 0u, sigq, lane);
+                else {
+                    uint32_t kvw = (uint32_t)kv;
+                    asm volatile("" : "+v"(kvw));
+                    process_word_defer<KMODE, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw, sigq, lane);
+                }
             } else if (all_valid) {
                 z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
             } else {
@@ -1244,6 +1344,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         }
     }
 
+    if constexpr (DEFER) sigq_drain_all(regs, kp.bitflip, p, sigq, lane);
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
 }
 
@@ -1856,6 +1957,9 @@ template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
     auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT>;
+    if constexpr (ALGO == 0 && !XLOW && REGS == REGS_LDS && DIRECT && !ALT) {
+        if (plan.defer) kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT, true>;
+    }
     SketchArgs a = args;
     a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile)
     const uint32_t lds = plan.lds_bytes + (DIRECT ? sketch_direct_stage_bytes(plan) : 0u);

@@ -58,6 +58,8 @@ def main():
     for it in range(iters):
         rng = random.Random(seed0 * 100003 + it)
         an = rng.choice(["hmh", "hll", "ull"])
+        if os.environ.get("FUZZ_ALGO"):                     # e.g. FUZZ_ALGO=hmh LASH_DEFER_MIN=0: every direct launch defers its signatures
+            an = os.environ["FUZZ_ALGO"]
         k = rng.choice([rng.randint(1, 32), 16, 21, 31, 32])
         p = 0 if an == "hmh" else rng.choice([rng.randint(4, 16)] if an == "hll" else [rng.randint(3, 20), rng.randint(3, 14)])
         seed = rng.choice([0, 42, rng.getrandbits(64)])

@@ -56,6 +56,9 @@ def test_baseline_config_properties(env, algo, k, p, G):
     algo_id = lash_amd.ALGOS[algo]
     d_seq, img, t = _sketch_synth(ctx, torch, lash_amd, 0, G, algo, k, p)
     assert t["kmers"] == G * (L - k + 1) and t["bases_last"] == G * L
+    if FULL and "LASH_DEFER_MIN" not in os.environ:
+        # work items of 2.5 Mbp and more: the HyperMinHash launch defers its signatures (process_word_defer), the others never do
+        assert t["defer_launches"] == (1 if algo == "hmh" else 0), t
     # oracle spot checks
     for g in (0, G // 3, G - 1):
         want = O.sketch_genomes(algo_id, k, p, 42, O.synth_genome(g, L), np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]

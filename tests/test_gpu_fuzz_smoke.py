@@ -23,3 +23,13 @@ def test_fuzz_runner_smoke(script, iters, seed, ok):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE)
     r = subprocess.run([sys.executable, os.path.join(HERE, script), str(iters), str(seed)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and ok in r.stdout, (script, r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_fuzz_with_deferred_signatures_everywhere():
+    """HyperMinHash batches of long work items run sketch_kernel<..., DEFER> (signature half of the hash only for the k-mers whose
+    rank can still win their bucket; lash_api.hip: from 2 Mbp per work item).  LASH_DEFER_MIN=0 sends EVERY direct HyperMinHash
+    launch of the runner down that kernel — tiny genomes, read sets, dirt, slices — against the oracle as usual.  (The full-size
+    tests take the route by themselves.)"""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE, LASH_DEFER_MIN="0", FUZZ_ALGO="hmh")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_gpu.py"), "150", "21"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
