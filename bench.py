@@ -175,6 +175,8 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
     floor, src, clock_ghz = None, None, None
     exe = os.path.join(ROOT, "tools", "ubench_hash")
     line = {"hmh": r"\+ ds_max_u32", "hll": "hll p14 k21 stream", "ull": "ull p12 k16 stream"}[algo]
+    if defer:
+        line = "defer: hmh k16 stream"                   # sketch_kernel<DIRECT, DEFER>'s own stream: rank half, read back, test, append, drain
     if run_ubench and os.path.exists(exe):
         try:
             out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
@@ -201,12 +203,9 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
             pass
     defer_note = None
     if defer:
-        # the launch deferred the signature half of the hash (sketch_kernel<..., DEFER>): its instruction stream is shorter than the
-        # one tools/ubench_hash runs, so that ceiling does not bound it and no fraction of it is claimed
-        defer_note = ("this launch ran sketch_kernel<DIRECT, DEFER> (signature half of xxh3_128 only for k-mers whose rank can still win their "
-                      "bucket): the ubench ceiling below prices the FULL per-k-mer stream (%s k-mers/s) and does not bound this kernel"
-                      % ("%.3g" % floor if floor else "n/a"))
-        floor = None
+        defer_note = ("this launch ran sketch_kernel<DIRECT, DEFER> (signature half of xxh3_128 only for the k-mers whose rank can still win "
+                      "their bucket): the ceiling is that kernel's own stream in tools/ubench_hash ('defer: hmh k16 stream'), the table "
+                      "filling as in a 5 Mbp work item")
     rate = kmers_per_launch / (sketch_ms * 1e-3) if sketch_ms > 0 else 0.0
     # the absolute figure beside the self-referential one: wave-instructions issued per second against the chip's issue peak
     # (256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles: MI355X_MICROARCH.md, Execution model) at the clock the

@@ -299,9 +299,11 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     }
     // HyperMinHash with deferred signatures (process_word_defer) pays off when a work item's table fills up early in the item, i.e.
     // when items are long: the share of k-mers that can still change their bucket is 2.8 % at 5 Mbp per item, 10 % at 1 Mbp
+    // (profiles/r03/defer/ab.txt: -12 % of the kernel's time at 5 Mbp per item, -5.5 % at 1 Mbp, -3 % at 1.25 Mbp slices, +3 % at
+    // 0.73 Mbp, +17 % at 0.26 Mbp)
     SketchPlan plan_d = plan;
     {
-        static const int64_t defer_min = getenv("LASH_DEFER_MIN") ? atoll(getenv("LASH_DEFER_MIN")) : 2000000;   // bases per work item; < 0: never
+        static const int64_t defer_min = getenv("LASH_DEFER_MIN") ? atoll(getenv("LASH_DEFER_MIN")) : 1000000;   // bases per work item; < 0: never
         plan_d.defer = pk->direct && prm->algo == LASH_HMH && !x_low && !plan.alt && plan.use_lds && plan.parts_log2 == 0 && n_items > 0 &&
                        defer_min >= 0 && total_words * 16 / n_items >= (uint64_t)defer_min;
     }

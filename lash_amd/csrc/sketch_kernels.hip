@@ -321,7 +321,12 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
 //   lz_cur >= 19 — more zeros than the 18 bits show — x18 must be 0, and the full update decides; 32 and up pass everything)
 // ------------------------------------------------------------------------------------------------------------
 struct SigQueue { uint32_t base_b, pos_b; };                // wave-uniform LDS byte addresses: the list, its first free slot
-constexpr uint32_t SIGQ_CAP = 320;                          // the word after them takes the stores of the lanes that did not pass
+constexpr uint32_t SIGQ_CAP = 320;
+#ifndef LASH_SIGQ_GROUP
+#define LASH_SIGQ_GROUP 4
+#endif
+constexpr int SIGQ_GROUP = LASH_SIGQ_GROUP;               // k-mers between two "64 waiting?" checks: 63 + SIGQ_GROUP * 64 <= SIGQ_CAP
+                          // the word after them takes the stores of the lanes that did not pass
 
 __device__ __forceinline__ uint32_t lds_load(uint32_t byte_addr) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr; }
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr = v; }
@@ -354,13 +359,13 @@ __device__ __forceinline__ void process_word_defer(const Regs &regs, const KPara
     const uint32_t base_b = q.base_b;
     uint32_t pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.pos_b);
 #pragma unroll
-    for (int g = 0; g < 16; g += 4) {
+    for (int g = 0; g < 16; g += SIGQ_GROUP) {
         // four k-mers as one straight line: four rank halves, four registers read back, four tests, four stores (the lanes that
         // did not pass store to a dummy word) — no branch before the list is appended to: with a branch per k-mer the scheduler had
         // one hash chain at a time, 16 % slower than not deferring at all
-        uint32_t can[4], x18[4], cur[4];
+        uint32_t can[SIGQ_GROUP], x18[SIGQ_GROUP], cur[SIGQ_GROUP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SIGQ_GROUP; ++j) {
             const int r = g + j;
             if constexpr (KMODE == KM_GT16) {
                 const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
@@ -377,21 +382,33 @@ __device__ __forceinline__ void process_word_defer(const Regs &regs, const KPara
                 can[j] = fwd < rc ? fwd : rc;
             }
             const uint32_t xh = xxh3_128_4b_hmh_rank(can[j], kp.bitflip);
+#ifdef LASH_ABL_DEFER_NO_READ
+            cur[j] = (xh >> 16) & 0xFFFCu;
+#else
             cur[j] = lds_load((xh >> 16) & 0xFFFCu);                                              // the register table starts at LDS address 0
+#endif
             x18[j] = xh & 0x3FFFFu;
             if constexpr (MASKED) x18[j] |= ~(uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1);   // not a k-mer: never passes
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SIGQ_GROUP; ++j) {
             const bool pass = x18[j] <= (0x7FFFFu >> ((cur[j] >> 10) & 31u));
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
             // (the running position stays in a scalar register and enters as the one scalar operand of the address's shift-add: as
             // the count operand of v_mbcnt it would be a second scalar beside the mask and cost a v_mov per k-mer)
             const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#ifdef LASH_ABL_DEFER_NO_APPEND   // timing-only diagnostic builds (tools/variants.sh): results are wrong by construction
+            asm volatile("" ::"v"(at), "v"(can[j]));
+#else
             if (pass) lds_store(at * 4u + pos_b, can[j]);
             pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos_b + 4u * (uint32_t)__builtin_popcountll(m)));
+#endif
         }
+#ifdef LASH_ABL_DEFER_NO_DRAIN
+        while (pos_b >= base_b + 256u) pos_b -= 256u;
+#else
         while (pos_b >= base_b + 256u) { q.pos_b = pos_b; sigq_drain64(regs, kp.bitflip, kp.p, q, lane); pos_b = q.pos_b; }
+#endif
     }
     q.pos_b = pos_b;
 }
@@ -1138,7 +1155,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     // One tile = blockDim.x * 4 words.  The next tile's words and break bits are loaded into registers before the
     // current tile is hashed (about 10k cycles of VALU work per tile cover the HBM latency).
     // direct mode keeps the raw bytes in registers until they are hashed: 4 x 16 own bytes + 1 (2) look-ahead chunks
-    struct TileRegs { uint4 q; uint4 a1, a2, a3, la, lb; uint32_t c4, c5, b0, b1, b2, dflag; };
+    struct TileRegs { uint4 q; uint4 a1, a2, a3, la, lb; uint4 b; uint32_t c4, c5, dflag; };
     const uint32_t step = blockDim.x * SKETCH_WORDS_PER_THREAD;
     auto tile_active = [&](uint32_t tile) {
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
@@ -1164,7 +1181,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             t.c5 = (KMODE == KM_GT16) ? w[w0 + 5] : 0u;
         }
         const uint32_t bi = use_bitmap ? w0 >> 1 : 0u;                    // (w0 * 16) / 32
-        t.b0 = bk[bi]; t.b1 = bk[bi + 1]; t.b2 = bk[bi + 2];
+        // three words are needed; FOUR are loaded: a dwordx3 lands in three consecutive registers that are not the ones the loop carries,
+        // hipcc then copies two of them — and waits for every load of the prefetch just issued to do so, at the top of each tile
+        // (every genome's bitmap, and the zero words, have the fourth word: lash_api.hip, bo += ... + 4)
+        t.b = load16_any(reinterpret_cast<const uint8_t *>(bk + bi));
     };
     TileRegs nxt;
     tile_load(it.word_begin, nxt);
@@ -1181,11 +1201,16 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         const uint64_t pos0 = (uint64_t)w0 * 16;
         const bool active = tile_active(tile);
         const TileRegs cur = nxt;
-        tile_load(tile + step, nxt);
+        asm volatile("" ::"v"(cur.b.w));                                // (keeps the bitmap load four words wide: see tile_load)
+        // The next tile's loads are issued AFTER this tile's bytes have been converted (and its dirt, if any, dealt with), right
+        // before the hashing — not here.  Issued here, hipcc's wait for this tile's registers at the conversion is a vmcnt(0) that
+        // also waits for the loads just issued (the counter is in order, and the loop's other paths make it give up counting): the
+        // prefetch never overlapped anything, from round 1 on ("prefetch on/off is neutral").  Converted first, the only loads
+        // outstanding at that wait are a whole tile of hashing old; and the raw bytes of two tiles are never live together.
         // A wave with no lane inside the slice has nothing to hash (a 10 kbp genome fills 2.5 of a workgroup's 8 waves).
         // Letting it run the masked body is worse than wasted issue slots: its lanes would all hash the same all-zero
         // words and hit ONE LDS address with 64-way serialized atomics (46 us per small genome instead of ~10).
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) continue;
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) { tile_load(tile + step, nxt); continue; }
 
         // inactive lanes of an active wave: distinct garbage words (their updates are masked to no-ops), for the same reason
         const uint32_t junk = (threadIdx.x + 1u) * 0x9E3779B1u;
@@ -1207,7 +1232,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     bad |= t.bad;
                 }
                 if (RL) kv = uniform_valid_mask((uint32_t)pos0, RL, (uint32_t)nk, k);
-                else kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, (uint32_t)pos0, (uint32_t)nk, k);
+                else kv = kmer_valid_mask(cur.b.x, cur.b.y, cur.b.z, (uint32_t)pos0, (uint32_t)nk, k);
             }
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) {      // (unlikely: keeps its spills out of the clean path)
                 // bytes outside the alphabet in this wave's tile.  Sparse dirt (an IUPAC code, an N in a read): the lanes that own
@@ -1223,6 +1248,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     if (__builtin_amdgcn_ballot_w64(gone) == act) {
                         // (raw_ok lanes own exactly their 64 bytes: the genome's tail is at least 32 bytes away)
                         if ((threadIdx.x & 63) == 0 && part == 0u) atomicAdd(a.ndel + it.genome, 64u * (uint32_t)__builtin_popcountll(act));
+                        tile_load(tile + step, nxt);
                         continue;
                     }
                 }
@@ -1278,8 +1304,6 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     my_kmers += wave_sum(dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
                                                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
                                                                             part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3));
-                    // the prefetched tile is asked for again rather than kept alive across the call (24 registers that the clean
-                    // path would otherwise spill on every tile)
                     tile_load(tile + step, nxt);
                     continue;
                 }
@@ -1292,8 +1316,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             }
         } else if (active) {
             c0 = cur.q.x; c1 = cur.q.y; c2 = cur.q.z; c3 = cur.q.w; c4 = cur.c4; c5 = cur.c5;
-            kv = kmer_valid_mask(cur.b0, cur.b1, cur.b2, (uint32_t)pos0, (uint32_t)nk, k);
+            kv = kmer_valid_mask(cur.b.x, cur.b.y, cur.b.z, (uint32_t)pos0, (uint32_t)nk, k);
         }
+        tile_load(tile + step, nxt);                                    // (see the top of the loop)
         // wave-uniform: every lane of this wave has 64 real k-mers -> no per-k-mer masking at all
         const bool all_valid = __builtin_amdgcn_ballot_w64(kv != ~0ull) == 0ull;
         // the k-mer census is kept per WAVE in a scalar register (a vector register less across the hashing: the k > 16 kernels sit

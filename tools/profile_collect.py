@@ -43,7 +43,8 @@ def main():
     if os.path.exists(ub):
         shutil.copy(ub, os.path.join(dst, "ubench_hash.txt"))
         txt = open(ub).read()
-        for key, pat in ((("hmh", 16), r"\+ ds_max_u32"), (("hll", 21), "hll p14 k21 stream"), (("ull", 16), "ull p12 k16 stream")):
+        for key, pat in ((("hmh", 16), r"\+ ds_max_u32"), (("hll", 21), "hll p14 k21 stream"), (("ull", 16), "ull p12 k16 stream"),
+                         (("hmh", 16, "defer"), "defer: hmh k16 stream")):
             m = re.search(pat + r".*\(([0-9.e+]+) k-mers/s chip-wide\)", txt)
             if m:
                 floors[key] = float(m.group(1))
@@ -79,6 +80,8 @@ def main():
                     dom, dom_ms, dom_calls = r["Name"], float(r["AverageNs"]) / 1e6, int(r["Calls"])
         short = dom.split("(")[0].replace("void ", "") if dom else None
         c = pmc.get(short, {}) if short else {}
+        if short and not c:                             # (pmc_summary.py prints the first 50 characters of a kernel's name)
+            c = next((v for kname, v in pmc.items() if len(kname) >= 40 and short.startswith(kname)), {})
         fetch, write, insts = c.get("FETCH_SIZE"), c.get("WRITE_SIZE"), c.get("SQ_INSTS_VALU")
         hbm = int(2 * fetch * 1024 + write * 1024) if fetch is not None and write is not None else None
         kmers = cfg["genomes_per_gpu"] * (cfg["genome_length"] - cfg["k"] + 1) if cfg.get("records_per_gpu", 0) == cfg["genomes_per_gpu"] \
@@ -93,14 +96,16 @@ def main():
                             "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1; calibrated in the same session (%s/hbm_calibration.txt)" % dst,
                             "source": "%s/%s/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes)" % (dst, name),
                             "kernel": short, "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "round": rnd}
-        vkey = "%s%s_k%d" % ("direct_" if direct else "", cfg["algo"], cfg["k"])
+        defer = "DEFER" in roof["kernel"]               # HyperMinHash with deferred signatures: a stream, a count and a ceiling of its own
+        vkey = "%s%s_k%d%s" % ("direct_" if direct else "", cfg["algo"], cfg["k"], "_defer" if defer else "")
         if insts is not None and cfg.get("dirty", "none") == "none":
             if cfg["genomes_per_gpu"] not in (10000, 12500) or vkey not in valu or valu[vkey].get("round", 0) < rnd:
                 valu[vkey] = {"valu_insts_per_kmer": insts / (kmers / 64.0),
                               "note": "SQ_INSTS_VALU counts wave-instructions: per k-mer = SQ_INSTS_VALU / (k-mers / 64)",
                               "source": "%s/%s/pmc_summary.txt" % (dst, name), "round": rnd}
-                if (cfg["algo"], cfg["k"]) in floors:
-                    valu[vkey]["issue_floor_kmers_per_s"] = floors[(cfg["algo"], cfg["k"])]
+                fkey = (cfg["algo"], cfg["k"], "defer") if defer else (cfg["algo"], cfg["k"])
+                if fkey in floors:
+                    valu[vkey]["issue_floor_kmers_per_s"] = floors[fkey]
                     valu[vkey]["floor_source"] = "%s/ubench_hash.txt (tools/ubench_hash, same session)" % dst
         alg = roof["algorithmic_bytes_per_launch"]
         rows.append((name, short, dom_calls, dom_ms, roof["avg_launch_ms"], alg, alg / (dom_ms * 1e-3) / 1e9 / HBM_PEAK if dom_ms else None,

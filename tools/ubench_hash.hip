@@ -49,6 +49,8 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
                 const uint32_t th = alignbit(hh, hl, 32 - 12) ^ (hh >> (28 - 12));
                 const uint32_t bit = ffbh_u32(th) + 11u;
                 asm volatile("ds_or_b32 %0, %1" ::"v"(((hh >> 20) * 2u + ((bit >> 5) & 1u)) << 2), "v"((th < 1u ? th : 1u) << (bit & 31u)) : "memory");
+            } else if constexpr (MODE == 6) {     // deferred signatures, step 1: the rank half of the hash alone
+                acc ^= xxh3_128_4b_hmh_rank(can, bitflip);
             } else {                              // the sketch kernel's own fast path (add_kmer<HMH, x = high half, FAST>):
                 uint32_t xh, sig;                 // only the bits the register rule reads, + the rule (+ the LDS atomic, MODE 3)
                 xxh3_128_4b_hmh_fast(can, bitflip, xh, sig);
@@ -71,21 +73,90 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
     }
 }
 
+// The deferring kernel's stream (sketch_kernels.hip, process_word_defer) in the same harness: groups of four k-mers — rank half,
+// register read back, test — STAGE 0; + append to the wave's list — STAGE 1; + the full update of 64 waiting k-mers — STAGE 2 (all
+// of it).  The table fills as in a real work item (iters * 16 * 512 k-mers into 16 384 buckets per workgroup).
+__device__ __forceinline__ uint32_t ub_lds_load(uint32_t b) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b; }
+__device__ __forceinline__ void ub_lds_store(uint32_t b, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b = v; }
+template <int STAGE>
+__global__ void __launch_bounds__(1024) defer_bench(unsigned long long *cycles, uint32_t *sink, int iters, uint64_t bitflip)
+{
+    extern __shared__ uint32_t lds[];
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    uint32_t c0 = threadIdx.x * 2654435761u + blockIdx.x, c1 = c0 ^ 0x9E3779B9u;
+    uint32_t acc = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536u + (threadIdx.x >> 6) * 1600u));
+    uint32_t pos_b = base_b;
+    unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+        const uint32_t r0 = rcword(c0), r1 = rcword(c1);
+#pragma unroll
+        for (int g = 0; g < 16; g += 4) {
+            uint32_t can[4], x18[4], cur[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = g + j;
+                const uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
+                const uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
+                can[j] = fwd < rc ? fwd : rc;
+                const uint32_t xh = xxh3_128_4b_hmh_rank(can[j], bitflip);
+                cur[j] = ub_lds_load((xh >> 16) & 0xFFFCu);
+                x18[j] = xh & 0x3FFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool pass = x18[j] <= (0x7FFFFu >> ((cur[j] >> 10) & 31u));
+                if constexpr (STAGE == 0) { acc += pass; continue; }
+                const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pass) ub_lds_store(at * 4u + pos_b, can[j]);
+                pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos_b + 4u * (uint32_t)__builtin_popcountll(m)));
+            }
+            if constexpr (STAGE >= 1) {
+                while (pos_b >= base_b + 256u) {
+                    pos_b -= 256u;
+                    if constexpr (STAGE == 2) {
+                        const uint32_t c = ub_lds_load(pos_b + lane * 4u);
+                        uint32_t xh, sig;
+                        xxh3_128_4b_hmh_fast(c, bitflip, xh, sig);
+                        const uint32_t t18 = (xh << 14) | 0x3FFFu;
+                        asm volatile("ds_max_u32 %0, %1" ::"v"((xh >> 18) << 2), "v"(((ffbh_u32(t18) << 10) | sig) + 0x400u) : "memory");
+                    }
+                }
+            }
+        }
+        c0 = c1; c1 = c1 * 1664525u + 1013904223u + acc;
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (acc == 0x12345) sink[0] = acc + lds[threadIdx.x];
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned slot = (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) & 8191u;
+        cycles[slot] = t1 - t0;
+        cycles[65536 + slot] = rt1 - rt0;
+    }
+}
+
 // Steady state: 20 rounds of 512-thread workgroups per CU (64 KiB of LDS each -> 2 resident per CU = 4 waves per
 // SIMD, as in the sketch kernel), wall time from HIP events; the clock comes from s_memtime / s_memrealtime.
 // (Per-wave in-kernel timing divided by the nominal waves per SIMD under-states the cost: waves are resident for
 // only ~2/3 of a single-round launch.)
+typedef void (*bench_kernel)(unsigned long long *, uint32_t *, int, uint64_t);
+void run_kernel(bench_kernel kern, const char *name, int iters, unsigned long long *d_cyc, uint32_t *d_sink, unsigned lds_bytes = 65536);
 template <int MODE>
-void run(const char *name, int iters, unsigned long long *d_cyc, uint32_t *d_sink)
+void run(const char *name, int iters, unsigned long long *d_cyc, uint32_t *d_sink) { run_kernel(hash_bench<MODE>, name, iters, d_cyc, d_sink); }
+void run_kernel(bench_kernel kern, const char *name, int iters, unsigned long long *d_cyc, uint32_t *d_sink, unsigned lds_bytes)
 {
     const int threads = 512, blocks = 256 * 2 * 10;
-    auto kern = hash_bench<MODE>;
-    CHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    CHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 65536, 0, d_cyc, d_sink, iters / 4, 0xeef023344dc994d6ull);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, 0, d_cyc, d_sink, iters / 4, 0xeef023344dc994d6ull);
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 65536, 0, d_cyc, d_sink, iters, 0xeef023344dc994d6ull);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, 0, d_cyc, d_sink, iters, 0xeef023344dc994d6ull);
     CHK(hipEventRecord(e1));
     CHK(hipDeviceSynchronize());
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
@@ -111,5 +182,11 @@ int main()
     run<3>("+ ds_max_u32", 200, d_cyc, d_sink);
     run<4>("hll p14 k21 stream", 200, d_cyc, d_sink);
     run<5>("ull p12 k16 stream", 200, d_cyc, d_sink);
+    // deferred signatures (HyperMinHash, long work items): 600 iterations = 300 k-mers per bucket, a 5 Mbp work item's load
+    run<6>("hmh rank half only", 200, d_cyc, d_sink);
+    run_kernel(defer_bench<0>, "defer: + read + test", 600, d_cyc, d_sink, 65536 + 12800);
+    run_kernel(defer_bench<1>, "defer: + append", 600, d_cyc, d_sink, 65536 + 12800);
+    run_kernel(defer_bench<2>, "defer: hmh k16 stream", 600, d_cyc, d_sink, 65536 + 12800);
+    run<3>("+ ds_max_u32 (600)", 600, d_cyc, d_sink);
     return 0;
 }

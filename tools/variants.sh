@@ -7,7 +7,7 @@ mkdir -p build/variants
 while [ $# -ge 2 ]; do
   NAME=$1; FLAGS=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function $FLAGS \
-     -o build/variants/liblash_$NAME.so lash_amd/csrc/lash_api.hip lash_amd/csrc/sketch_kernels.hip lash_amd/csrc/pack_kernels.hip lash_amd/csrc/dist_kernels.hip &
+     -o build/variants/liblash_$NAME.so lash_amd/csrc/*.hip &
 done
 wait
 ls -la build/variants
