@@ -117,7 +117,7 @@ typedef struct {
     uint64_t bases_last;        /* bases that survived filter_out_n in the last call                       */
     uint64_t packed_bytes;      /* 2-bit words + break bitmap read by the sketch kernel, summed            */
     float    direct_ms;         /* the part of sketch_ms spent in the direct (ASCII-reading) sketch kernel */
-    uint32_t defer_launches;    /* of direct_launches: HyperMinHash with deferred signatures (batches of long work items) */
+    uint32_t defer_launches;    /* of sketch_launches: HyperMinHash with deferred signatures (batches of long work items)  */
 } lash_timing;
 
 /* ---- library / context ---------------------------------------------------------------------------------- */

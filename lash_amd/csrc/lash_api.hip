@@ -195,7 +195,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
-    const uint32_t lds_wg = plan.lds_bytes + (pk->direct ? sketch_direct_stage_bytes(plan) : 0u);            // direct: + the waves' staging areas
+    const bool defer_eligible = prm->algo == LASH_HMH && !x_low && !plan.alt && plan.use_lds && plan.parts_log2 == 0;   // (see plan_d below)
+    const uint32_t lds_wg = plan.lds_bytes + ((pk->direct || defer_eligible) ? sketch_direct_stage_bytes(plan) : 0u);   // + the waves' staging areas / lists
     const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(lds_wg, 1u)) : 4u;   // 64 KiB + census -> 2
     const uint64_t slots = (uint64_t)ctx->cu_count * std::min(wg_per_cu, 2048u / plan.threads);
     uint64_t total_words = 0;
@@ -205,7 +206,6 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     static const uint64_t slice_factor_env = getenv("LASH_SLICE_FACTOR") ? std::max(1, atoi(getenv("LASH_SLICE_FACTOR"))) : 0;
     // HyperMinHash launches that may defer their signatures (below) like long items — a slice starts with an empty table — and the
     // quartered tail (below) has taken over what the many small slices were for: 2x the slots there (1 000 x 5 Mbp: 4.39 -> 4.33 ms)
-    const bool defer_eligible = pk->direct && prm->algo == LASH_HMH && !x_low && !plan.alt && plan.use_lds && plan.parts_log2 == 0;
     const uint64_t slice_factor = slice_factor_env ? slice_factor_env : (defer_eligible ? 2 : 4);   // tuning knob: the
     // sketch time is flat from 2x to 24x the slots (4.87-4.91 ms on the default bench), the finalize time grows with it
     uint64_t target = total_words / (slots * slice_factor) + 1;
@@ -421,7 +421,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         }
         HIPCHK(ctx, launch_sketch_stream(plan, sa, n_items, ctx->stream));    // the flagged genomes, compacted on the fly
     } else {
-        HIPCHK(ctx, launch_sketch(plan, sa, n_items, ctx->stream));
+        HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream));
+        ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
     }
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
     TRACE("sketch: launched");

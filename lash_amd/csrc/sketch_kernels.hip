@@ -1068,7 +1068,7 @@ template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT = fals
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
     static_assert(!(ALT && DIRECT), "the alternative k-mer / bucket rules run on packed input only");
-    static_assert(!DEFER || (ALGO == 0 && !XLOW && REGS == REGS_LDS && DIRECT && !ALT), "deferred signatures: HyperMinHash, x = high half, direct mode");
+    static_assert(!DEFER || (ALGO == 0 && !XLOW && REGS == REGS_LDS && !ALT), "deferred signatures: HyperMinHash, x = high half, one LDS table");
     // dynamic LDS: [nreg32 register words][16 words of per-wave census]; registers start at LDS offset 0 so the
     // bucket offset goes straight into the ds_max / ds_or address
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
@@ -1982,12 +1982,13 @@ template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
     auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT>;
-    if constexpr (ALGO == 0 && !XLOW && REGS == REGS_LDS && DIRECT && !ALT) {
-        if (plan.defer) kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT, true>;
+    bool defer = false;
+    if constexpr (ALGO == 0 && !XLOW && REGS == REGS_LDS && !ALT) {
+        if (plan.defer) { kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT, true>; defer = true; }
     }
     SketchArgs a = args;
-    a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile)
-    const uint32_t lds = plan.lds_bytes + (DIRECT ? sketch_direct_stage_bytes(plan) : 0u);
+    a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile);
+    const uint32_t lds = plan.lds_bytes + ((DIRECT || defer) ? sketch_direct_stage_bytes(plan) : 0u);   // deferring launches keep their lists there
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
