@@ -321,12 +321,12 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
 //   lz_cur >= 19 — more zeros than the 18 bits show — x18 must be 0, and the full update decides; 32 and up pass everything)
 // ------------------------------------------------------------------------------------------------------------
 struct SigQueue { uint32_t base_b, pos_b; };                // wave-uniform LDS byte addresses: the list, its first free slot
-constexpr uint32_t SIGQ_CAP = 320;
+constexpr uint32_t SIGQ_CAP = 320;                          // entries; the list sits at the start of the wave's staging area
 #ifndef LASH_SIGQ_GROUP
-#define LASH_SIGQ_GROUP 4
+#define LASH_SIGQ_GROUP 4                                   // (tools/variants.sh: groups of two measured 3 % slower)
 #endif
-constexpr int SIGQ_GROUP = LASH_SIGQ_GROUP;               // k-mers between two "64 waiting?" checks: 63 + SIGQ_GROUP * 64 <= SIGQ_CAP
-                          // the word after them takes the stores of the lanes that did not pass
+constexpr int SIGQ_GROUP = LASH_SIGQ_GROUP;                 // k-mers between two "64 waiting?" checks
+static_assert(63 + SIGQ_GROUP * 64 <= (int)SIGQ_CAP && 16 % SIGQ_GROUP == 0, "the list must hold what can arrive between two checks");
 
 __device__ __forceinline__ uint32_t lds_load(uint32_t byte_addr) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr; }
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr = v; }
@@ -676,6 +676,7 @@ __device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *g
 constexpr uint32_t DENSE_STAGE_CODE_WORDS = 264;      // 4096 + 31 + 16 bases at 16 per word, rounded up; reads reach word 4*63+5
 constexpr uint32_t DENSE_STAGE_BRK_WORDS = 136;       // the same positions, one bit each; reads reach word 2*63+3 (+1)
 constexpr uint32_t DENSE_STAGE_WORDS = DENSE_STAGE_CODE_WORDS + DENSE_STAGE_BRK_WORDS;   // 1600 bytes per wave
+static_assert(SIGQ_CAP <= DENSE_STAGE_WORDS, "process_word_defer's list lives in the wave's staging area");
 constexpr uint32_t DENSE_SCAN_MAX = 4u << 20;         // bytes of look-ahead scan before the genome is left to the pack stage
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
