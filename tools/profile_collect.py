@@ -99,7 +99,10 @@ def main():
         defer = "DEFER" in roof["kernel"]               # HyperMinHash with deferred signatures: a stream, a count and a ceiling of its own
         vkey = "%s%s_k%d%s" % ("direct_" if direct else "", cfg["algo"], cfg["k"], "_defer" if defer else "")
         if insts is not None and cfg.get("dirty", "none") == "none":
-            if cfg["genomes_per_gpu"] not in (10000, 12500) or vkey not in valu or valu[vkey].get("round", 0) < rnd:
+            # one entry per kernel: the deferring kernel's from the default workload (whole genomes: what bench.py runs by default), the
+            # others' from the 1 000-genome / read-set runs unless only a large run exists
+            if (cfg["genomes_per_gpu"] == 12500 or vkey not in valu) if defer else \
+               (cfg["genomes_per_gpu"] not in (10000, 12500) or vkey not in valu or valu[vkey].get("round", 0) < rnd):
                 valu[vkey] = {"valu_insts_per_kmer": insts / (kmers / 64.0),
                               "note": "SQ_INSTS_VALU counts wave-instructions: per k-mer = SQ_INSTS_VALU / (k-mers / 64)",
                               "source": "%s/%s/pmc_summary.txt" % (dst, name), "round": rnd}
