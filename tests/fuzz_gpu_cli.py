@@ -55,6 +55,8 @@ def main():
             lst = os.path.join(td, "l.txt")
             open(lst, "w").write("\n".join(paths) + "\n")
             algo = rng.choice(["hmh", "hll", "ull"])
+            if os.environ.get("FUZZ_ALGO"):
+                algo = os.environ["FUZZ_ALGO"]
             k = rng.choice([rng.randint(1, 32), 16, 21])
             p = rng.randint(4, 14)
             extra = rng.choice([[], ["--batch-mb", "1"], ["--batch-mb", "1", "--devices", "0,0"], ["--devices", "0,0,0"], ["-t", "2"]])

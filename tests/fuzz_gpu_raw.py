@@ -83,6 +83,8 @@ def main():
         for it in range(iters):
             rng = random.Random(seed0 * 7919 + it)
             an = rng.choice(["hmh", "hll", "ull"])
+            if os.environ.get("FUZZ_ALGO"):
+                an = os.environ["FUZZ_ALGO"]
             k = rng.choice([rng.randint(1, 32), 16, 21])
             p = 0 if an == "hmh" else rng.randint(4, 14)
             files = [fasta_file(rng) if rng.random() < 0.6 else fastq_file(rng) for _ in range(rng.randint(1, 6))]
