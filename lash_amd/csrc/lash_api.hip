@@ -453,7 +453,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.group = 0;
     // (from 9 slices on: finalize_kernel's walk is serial — a dependent load per slice and word — and the tail quarters give a
     // genome up to 16: 300 x 5 Mbp, finalize stage 0.27 -> 0.15 ms)
-    if (max_slices > 8u && n_genomes <= 65535u)
+    // (the fold's grid spans every genome of the batch: with many thousands of genomes and ONE long one, wait for the 33rd slice as before)
+    if (max_slices > (n_genomes <= 4096u ? 8u : 32u) && n_genomes <= 65535u)
         for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
     if (all_sole) {
         HIPCHK(ctx, launch_census(fa, n_genomes, ctx->stream));            // every image was written by its one work item
