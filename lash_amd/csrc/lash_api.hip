@@ -214,7 +214,10 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         // When some genome is cut anyway (so partials and the finalize pass exist whatever the slicing), items of at most 1 MiB: a
         // large batch would otherwise get multi-megabyte items, and the few genomes handed to stream_sketch_kernel — one or two
         // items each — would run on a fraction of the chip (2 000 mixed genomes: that launch 1.6 ms -> 0.5 ms).
-        static const uint64_t cap = getenv("LASH_ITEM_CAP_WORDS") ? std::max(1024, atoi(getenv("LASH_ITEM_CAP_WORDS"))) : 65536;
+        // (2 MiB where the launch may defer signatures: that kernel wants long items — the same collection 7.83 -> 7.50 ms, while the
+        // HyperLogLog kernel loses with the larger items, 8.09 -> 8.49 ms)
+        static const uint64_t cap_env = getenv("LASH_ITEM_CAP_WORDS") ? std::max(1024, atoi(getenv("LASH_ITEM_CAP_WORDS"))) : 0;
+        const uint64_t cap = cap_env ? cap_env : (defer_eligible ? 131072 : 65536);
         // (only for batches of unequal genomes: a batch of equal ones keeps its few large items — when those are soft-masked they all
         // are, every item is busy in both launches, and smaller items only add ramp-up: -3 % on bench.py --dirty lower)
         bool any_cut = false;
