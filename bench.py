@@ -9,6 +9,7 @@ seed 42 (SURVEY.md §8(d) generator); `--genomes 1000` is configs[1].  Genomes s
 collective (weak scaling: every rank sketches its own 12 500 genomes).
 
     python bench.py                       # 1 GPU
+    python bench.py --gpus N              # N > 1 without a rendezvous in the environment: starts the line below as a child process
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -336,6 +337,28 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
             "roofline": None, "cpu_baseline": None}))
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks ourselves — one process per
+    GPU under torch.distributed.run, the command line the driver would have used — as a CHILD process, relay its output and
+    return its exit code.  This process has not imported torch and never touches the GPU (no exec from a GPU-initialised
+    process: the ranks are children of the launcher, which is a child of this).  The reference's counterpart is
+    `files.par_iter()` (utils.rs:450-452): one task per shard, results in shard order."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode          # stdout / stderr are inherited: rank 0's ONE JSON line passes through
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,6 +387,9 @@ def main():
     ap.add_argument("--no-ubench", action="store_true", help="do not run tools/ubench_hash for the VALU ceiling (profiler runs: "
                     "rocprofv3 follows child processes); the committed profiles/valu.json figure is quoted instead")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     import torch

@@ -14,15 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_dry_run_on_one_gpu():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, LASH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--genomes", "40"],
-                       cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+def _check_line(r):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                       # rank 0 only
@@ -33,3 +25,27 @@ def test_two_ranks_dry_run_on_one_gpu():
     kmers = 2 * 40 * (5_000_000 - 16 + 1) * 3                    # both ranks' genomes, every step
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 * 3 / kmers - 1) < 1e-6
     assert j["roofline"]["frac"] > 0 and j["roofline_valu"]["bound"] == "valu-issue"
+
+
+def test_two_ranks_dry_run_on_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, LASH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--genomes", "40"],
+                       cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    _check_line(r)
+
+
+def test_plain_command_line_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it, the way the driver runs --gpus 1) starts its ranks
+    itself as a child process and prints exactly one JSON line with n_gpus = 2."""
+    env = dict(os.environ, LASH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--genomes", "40"],
+                       cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    _check_line(r)
