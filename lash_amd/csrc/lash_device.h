@@ -32,6 +32,17 @@ __device__ __forceinline__ uint32_t ffbh_u32(uint32_t x)
     asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// min of two 64-bit values as {hi, lo} words.  hipcc's form is v_cmp_lt_u64 -> vcc + two VOP2 v_cndmask_b32 ... vcc, and on gfx950
+// a VOP2 v_cndmask_b32 reading vcc holds the SIMD for 17-23 cycles (tools/ubench_isa: 12.7 cycles per instruction for the triple,
+// 4.5 with the lane mask in a scalar pair and the VOP3 encoding of the select): a third of the k > 16 window's cost.
+__device__ __forceinline__ void min_u64(uint32_t a_lo, uint32_t a_hi, uint32_t b_lo, uint32_t b_hi, uint32_t &lo, uint32_t &hi)
+{
+    uint64_t m;                                                           // lanes where a < b (a scalar pair, not vcc)
+    const uint64_t a = ((uint64_t)a_hi << 32) | a_lo, b = ((uint64_t)b_hi << 32) | b_lo;
+    asm("v_cmp_lt_u64_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(b_lo), "v"(a_lo), "s"(m));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(b_hi), "v"(a_hi), "s"(m));
+}
 __device__ __forceinline__ uint32_t pm_of(int p) { return (1u << p) - 1u; }
 
 __device__ __forceinline__ uint32_t clz64_nz(uint32_t hi, uint32_t lo)
@@ -41,6 +52,22 @@ __device__ __forceinline__ uint32_t clz64_nz(uint32_t hi, uint32_t lo)
     uint32_t cl = lo ? (uint32_t)__builtin_clz(lo) + 32u : 64u;
     return ch < cl ? ch : cl;
 }
+
+// The seed-folded xxh3 constant as the two 32-bit words the hash xors into its input.  Which register file they sit in decides
+// what that xor costs: gfx950 issues `v_xor_b32 v,v` (and literal / inline forms) in 2.6 cycles per wave and SIMD, `v_xor_b32 s,v`
+// in 4.4 (tools/ubench_isa, profiles/r04/isa_cost/): the hot kernels keep the words in vector registers (vector()), code that
+// runs once per junction or per drained k-mer takes them as they come (scalar()).
+struct BitFlip {
+    uint32_t lo, hi;
+    static __device__ __forceinline__ BitFlip scalar(uint64_t b) { return BitFlip{(uint32_t)b, (uint32_t)(b >> 32)}; }
+    static __device__ __forceinline__ BitFlip vector(uint64_t b)
+    {
+        BitFlip f;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(f.lo) : "s"((uint32_t)b));     // (opaque: hipcc would fold a plain copy back into the scalar operand)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(f.hi) : "s"((uint32_t)(b >> 32)));
+        return f;
+    }
+};
 
 // 64 x 64 -> 128 multiply of {a1,a0} by the XXH3 constant PRIME64_1 + (len << 2), len = 4.
 // Four v_mad_u64_u32; the third one adds the full 64-bit partial sum and its carry-out (VCC) is folded into the
@@ -63,10 +90,10 @@ __device__ __forceinline__ void xxh3_mul128(uint32_t a0, uint32_t a1, uint64_t &
 }
 
 // XXH3-128 of the 4 little-endian bytes of w (XXH3_len_4to8_128b, len = 4), seed folded into `bitflip`.
-__device__ __forceinline__ void xxh3_128_4b(uint32_t w, uint64_t bitflip, uint64_t &lo, uint64_t &hi)
+__device__ __forceinline__ void xxh3_128_4b(uint32_t w, BitFlip bitflip, uint64_t &lo, uint64_t &hi)
 {
     uint64_t l, h;
-    xxh3_mul128(w ^ (uint32_t)bitflip, w ^ (uint32_t)(bitflip >> 32), l, h);
+    xxh3_mul128(w ^ bitflip.lo, w ^ bitflip.hi, l, h);
     h += l << 1;
     l ^= h >> 3;
     l ^= l >> 35;
@@ -83,10 +110,10 @@ __device__ __forceinline__ void xxh3_128_4b(uint32_t w, uint64_t bitflip, uint64
 //   xh    = bits 63:32 of the high half (bucket = xh >> 18, rank field = xh & 0x3FFFF)
 //   sig10 = bits 9:0 of the low half
 // Skips the low word of the last multiply and the final xorshift of the high half (they only feed bits 31:0 of x).
-__device__ __forceinline__ void xxh3_128_4b_hmh_fast(uint32_t w, uint64_t bitflip, uint32_t &xh, uint32_t &sig10)
+__device__ __forceinline__ void xxh3_128_4b_hmh_fast(uint32_t w, BitFlip bitflip, uint32_t &xh, uint32_t &sig10)
 {
     uint64_t l, h;
-    xxh3_mul128(w ^ (uint32_t)bitflip, w ^ (uint32_t)(bitflip >> 32), l, h);
+    xxh3_mul128(w ^ bitflip.lo, w ^ bitflip.hi, l, h);
     h += l << 1;
     l ^= h >> 3;
     l ^= l >> 35;
@@ -109,10 +136,10 @@ __device__ __forceinline__ void xxh3_128_4b_hmh_fast(uint32_t w, uint64_t bitfli
 
 // ... and only the half that decides bucket and rank (the signature half — a third of the instructions — is left to the few
 // k-mers whose rank can still win their bucket: process_word_defer)
-__device__ __forceinline__ uint32_t xxh3_128_4b_hmh_rank(uint32_t w, uint64_t bitflip)
+__device__ __forceinline__ uint32_t xxh3_128_4b_hmh_rank(uint32_t w, BitFlip bitflip)
 {
     uint64_t l, h;
-    xxh3_mul128(w ^ (uint32_t)bitflip, w ^ (uint32_t)(bitflip >> 32), l, h);
+    xxh3_mul128(w ^ bitflip.lo, w ^ bitflip.hi, l, h);
     asm("" : "+v"(l));                                   // (opaque: with nothing else using l, hipcc folds the doubling into the multiply chain — 8 instructions for one)
     asm("v_lshl_add_u64 %0, %1, 1, %0" : "+v"(h) : "v"(l));   // h += l << 1
     h ^= h >> 37;
@@ -123,10 +150,10 @@ __device__ __forceinline__ uint32_t xxh3_128_4b_hmh_rank(uint32_t w, uint64_t bi
 
 // XXH3-64 of the 8 little-endian bytes of {v_hi,v_lo} (XXH3_len_4to8_64b, len = 8 -> XXH3_rrmxmx), up to but NOT including the
 // final `h ^= h >> 28`
-__device__ __forceinline__ uint64_t xxh3_64_8b_pre(uint32_t v_lo, uint32_t v_hi, uint64_t bitflip)
+__device__ __forceinline__ uint64_t xxh3_64_8b_pre(uint32_t v_lo, uint32_t v_hi, BitFlip bitflip)
 {
     // input64 = input2 + (input1 << 32): the two halves trade places
-    const uint32_t lo = v_hi ^ (uint32_t)bitflip, hi = v_lo ^ (uint32_t)(bitflip >> 32);
+    const uint32_t lo = v_hi ^ bitflip.lo, hi = v_lo ^ bitflip.hi;
     // h ^= rotl(h, 49) ^ rotl(h, 24) in 32-bit halves: rotl 49 = rotr 15, rotl 24 = halves swapped + rotr 8; every half of a rotated
     // value is one v_alignbit, the three-way xor one v_bitop3 — 6 instructions; as 64-bit shifts hipcc needs 10, two of them
     // v_lshrrev_b64 / v_lshlrev_b64 at 5.9 cycles
@@ -138,7 +165,7 @@ __device__ __forceinline__ uint64_t xxh3_64_8b_pre(uint32_t v_lo, uint32_t v_hi,
     h *= XXH_PRIME_MX2;
     return h;
 }
-__device__ __forceinline__ uint64_t xxh3_64_8b(uint32_t v_lo, uint32_t v_hi, uint64_t bitflip)
+__device__ __forceinline__ uint64_t xxh3_64_8b(uint32_t v_lo, uint32_t v_hi, BitFlip bitflip)
 {
     const uint64_t h = xxh3_64_8b_pre(v_lo, v_hi, bitflip);
     return h ^ (h >> 28);

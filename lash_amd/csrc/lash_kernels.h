@@ -40,6 +40,8 @@ struct SketchArgs {
     LayoutDev         lay;
     uint32_t          partial_stride;
     uint32_t          stage_off;  // direct mode: LDS byte offset of the waves' staging areas (dense_tile), after registers + census
+    uint32_t          stage_stride; // bytes of one wave's staging area (dense_tile's 1 600, or the lanes' stacks of a deferring launch if larger)
+    uint32_t          sigq_depth; // deferring launches: words of one lane's stack (odd: the lanes' slots fall into distinct banks)
     uint32_t          nreg32;     // u32 words of register state (HMH 16384, HLL 2^p, ULL 2*2^p)
     int               k;
     int               p;
@@ -57,6 +59,7 @@ struct SketchPlan {
     uint32_t partial_bytes;       // bytes of one partial sketch (register array only)
     uint32_t partial_stride;      // rounded up to 16
     bool     defer = false;       // direct HyperMinHash launch with deferred signatures (the caller sets it for batches of large work items)
+    uint32_t sigq_depth = 7;      // ... and the depth of its lanes' stacks (process_word_defer)
 };
 
 // small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)

@@ -32,31 +32,47 @@ enum { KM_16 = 0, KM_LT16 = 1, KM_GT16 = 2 };
 
 // ------------------------------------------------------------------------------------------------------------
 // register spaces: LDS (the normal case) or global memory (2^p too large for 160 KiB of LDS)
+//
+// What a table word holds WHILE a work item is hashed is chosen for the update's instruction count — one VALU instruction is
+// ~4.2 cycles of a SIMD whatever it does (tools/ubench_isa, profiles/r04/isa_cost) — and turned into the register of the image
+// by the flush (finish_item), once per item:
+//   HyperMinHash   raw = (lz - 1) << 10 | sig  under a SIGNED maximum, -1 = empty  (the rule's "+ 0x400" moves to the flush)
+//   HyperLogLog    raw = rho - 1               under a SIGNED maximum, -1 = empty  (v_ffbh's "nothing found" IS the no-op)
+//   UltraLogLog    a 64-bit bitmap of the nlz values seen (bit n: some k-mer had nlz = n); hash4j's prefix is that << (p - 1).
+//                  nlz < 32 whenever the fast form applies, so the fast form always hits the pair's first word
+//   HyperMinHash, deferring launches (LdsThrRegs): the rank as a THRESHOLD, see there
 // ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t RANK_EMPTY = 0xFFFFFFFFu;                   // HyperMinHash / HyperLogLog table word of an empty register
+
 struct LdsRegs {
     uint32_t *base;
     // The register table starts at LDS address 0 (the kernel has no static __shared__; checked at kernel entry), so the
     // word index goes straight into the DS address.  Through a pointer hipcc adds the table's link-time base (0) with a
     // v_add_u32 per k-mer; the update itself is fire-and-forget, nothing in the hashing loop reads the table back, and
     // lds_wait() drains the counter before the flush reads it.
+    static constexpr bool THR = false;
 #ifdef LASH_ABL_NO_ATOMIC   // timing-only diagnostic build (tools/variants.sh): results are wrong by construction
-    __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const { asm volatile("" ::"v"(i), "v"(v)); }
-    __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const { asm volatile("" ::"v"(i), "v"(v)); }
+    __device__ __forceinline__ void smax(uint32_t i, uint32_t v) const { asm volatile("" ::"v"(i), "v"(v)); }
+    __device__ __forceinline__ void bor_b(uint32_t b, uint32_t v) const { asm volatile("" ::"v"(b), "v"(v)); }
 #else
-    __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const
-    { asm volatile("ds_max_u32 %0, %1" ::"v"(i << 2), "v"(v) : "memory"); }
-    __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const
-    { asm volatile("ds_or_b32 %0, %1" ::"v"(i << 2), "v"(v) : "memory"); }
+    __device__ __forceinline__ void smax(uint32_t i, uint32_t v) const
+    { asm volatile("ds_max_i32 %0, %1" ::"v"(i << 2), "v"(v) : "memory"); }
+    __device__ __forceinline__ void bor_b(uint32_t byte_addr, uint32_t v) const
+    { asm volatile("ds_or_b32 %0, %1" ::"v"(byte_addr), "v"(v) : "memory"); }
 #endif
+    // UltraLogLog: OR `v` into word `w` (0 / 1) of register idx's bitmap pair; hh = the hash's high word (idx = its top p bits)
+    __device__ __forceinline__ void bor_first(uint32_t hh, int p, uint32_t v) const { bor_b((hh >> (29 - p)) & ~7u, v); }
+    __device__ __forceinline__ void bor_pair(uint32_t idx, uint32_t w, uint32_t v) const { bor_b((idx << 3) | (w << 2), v); }
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i]; }
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
-struct GlobalRegs {
+struct GlobalRegs {                                            // (UltraLogLog p >= 19 only: a zeroed slab per work item)
     uint32_t *base;
-    __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const
-    { if (v) (void)__hip_atomic_fetch_max(base + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const
-    { if (v) (void)__hip_atomic_fetch_or(base + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static constexpr bool THR = false;
+    __device__ __forceinline__ void smax(uint32_t, uint32_t) const {}
+    __device__ __forceinline__ void bor_pair(uint32_t idx, uint32_t w, uint32_t v) const
+    { if (v) (void)__hip_atomic_fetch_or(base + 2u * idx + w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void bor_first(uint32_t hh, int p, uint32_t v) const { bor_pair(hh >> (32 - p), 0u, v); }
     __device__ __forceinline__ uint32_t get(uint32_t i) const
     { return __hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     static __device__ __forceinline__ void lds_wait() {}
@@ -64,7 +80,7 @@ struct GlobalRegs {
 
 // A register table larger than 128 KiB of LDS but no more than 16 times that (HLL p=16; ULL p=15..18) is covered in
 // 2..16 PASSES over the slice: each pass (its own work item) owns one contiguous 1/2^lp of the bucket space in a 128 KiB
-// LDS table and drops the updates of the other buckets (value 0: max / OR no-ops).  Hashing every k-mer 2^lp times
+// LDS table and drops the updates of the other buckets (no-op values).  Hashing every k-mer 2^lp times
 // still beats per-k-mer global atomics (HLL p=16: 2.7e10 -> 3e11 k-mers/s).  Indices are register-word indices of the
 // FULL table; the part is their top lp bits.
 struct LdsPartRegs {
@@ -72,18 +88,52 @@ struct LdsPartRegs {
     uint32_t local_mask;      // (words per part) - 1
     uint32_t part_shift;      // log2(words per part)
     uint32_t part;
-    __device__ __forceinline__ void umax(uint32_t i, uint32_t v) const
-    { asm volatile("ds_max_u32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : 0u) : "memory"); }
-    __device__ __forceinline__ void bor(uint32_t i, uint32_t v) const
-    { asm volatile("ds_or_b32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : 0u) : "memory"); }
+    static constexpr bool THR = false;
+    __device__ __forceinline__ void smax(uint32_t i, uint32_t v) const
+    { asm volatile("ds_max_i32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : RANK_EMPTY) : "memory"); }
+    __device__ __forceinline__ void bor_pair(uint32_t idx, uint32_t w, uint32_t v) const
+    {
+        const uint32_t i = 2u * idx + w;
+        asm volatile("ds_or_b32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : 0u) : "memory");
+    }
+    __device__ __forceinline__ void bor_first(uint32_t hh, int p, uint32_t v) const { bor_pair(hh >> (32 - p), 0u, v); }
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i]; }       // i: local word index
+    static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+};
+
+// HyperMinHash, launches that defer signatures (process_word_defer).  The filter asks one question per k-mer — can its rank still
+// win its bucket? — so the table word answers it with ONE compare: the rank is stored as the largest value of the hash's rank bits
+// that still passes,
+//     bits 31:16   thr = 0xFFFF >> min(lz - 1, 16)        (x16, the 16 rank bits below the bucket, passes <=> x16 <= thr)
+//     bits 15:0    0xFFFE - ((lz - 1 - min(lz - 1, 16)) << 10 | sig)
+// under an UNSIGNED MINIMUM, 0xFFFFFFFF = empty (passes everything; every real word is smaller).  A smaller word is a larger
+// (lz, sig) in the reference's order (utils.rs:395-398 -> hyperminhash add_hash), so ds_min_u32 is its max; beyond 16 leading
+// zeros the threshold is 0 (x16 must be 0) and the full update decides.  get() turns the word back into lz << 10 | sig.
+struct LdsThrRegs {
+    uint32_t *base;
+    static constexpr bool THR = true;
+    static __device__ __forceinline__ uint32_t encode(uint32_t lzm1, uint32_t sig)
+    {
+        const uint32_t m = lzm1 < 16u ? lzm1 : 16u;
+        return ((0xFFFFu >> m) << 16) | (0xFFFEu - (((lzm1 - m) << 10) | sig));
+    }
+    __device__ __forceinline__ void push_rank(uint32_t bucket, uint32_t lzm1, uint32_t sig, uint32_t vm) const
+    { asm volatile("ds_min_u32 %0, %1" ::"v"(bucket << 2), "v"(encode(lzm1, sig) | ~vm) : "memory"); }
+    __device__ __forceinline__ uint32_t get(uint32_t i) const                 // -> the table word LdsRegs would hold
+    {
+        const uint32_t w = base[i];
+        if (w == 0xFFFFFFFFu) return RANK_EMPTY;
+        const uint32_t thr = w >> 16, t = 0xFFFEu - (w & 0xFFFFu);
+        const uint32_t m = thr ? (uint32_t)__builtin_clz(thr) - 16u : 16u;
+        return ((m + (t >> 10)) << 10) | (t & 0x3FFu);
+    }
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
 
 enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_LDS_PARTS = 2 };
 
 // ------------------------------------------------------------------------------------------------------------
-// the three add_kmer rules.  `vm` is 0 or ~0: invalid k-mers degrade to max(x,0) / OR 0.
+// the three add_kmer rules.  `vm` is 0 or ~0: invalid k-mers degrade to no-ops (max with "empty", OR 0).
 //
 // FAST: every rule needs a 64-bit count-leading-zeros whose answer is < 32 unless the top word `t` of the
 // counted value is 0 (probability 2^-32 per k-mer).  The fast form counts in the top word only
@@ -92,7 +142,7 @@ enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_LDS_PARTS = 2 };
 // ------------------------------------------------------------------------------------------------------------
 template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs, bool HLL_HIGH = false>
 __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, uint32_t c_hi, uint32_t vm,
-                                             uint64_t bitflip, int p)
+                                             BitFlip bitflip, int p)
 {
     if constexpr (ALGO == 0) {
         // utils.rs:395-398: Sketch::add_bytes_with_seed(&(masked as u32).to_le_bytes(), seed)
@@ -103,9 +153,13 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             uint32_t xh, sig;
             xxh3_128_4b_hmh_fast(c_lo, bitflip, xh, sig);
             const uint32_t t18 = (xh << 14) | 0x3FFFu;
-            uint32_t reg = ((ffbh_u32(t18) << 10) | sig) + 0x400u;
-            if constexpr (MASKED) reg &= vm;
-            regs.umax(xh >> 18, reg);
+            if constexpr (Regs::THR) {
+                regs.push_rank(xh >> 18, ffbh_u32(t18), sig, MASKED ? vm : 0xFFFFFFFFu);
+            } else {
+                uint32_t raw = (ffbh_u32(t18) << 10) | sig;
+                if constexpr (MASKED) raw |= ~vm;
+                regs.smax(xh >> 18, raw);
+            }
             return t18;                                  // < 0x4000 <=> all 18 rank bits were zero
         } else {
             uint64_t lo, hi;
@@ -114,21 +168,26 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x;
             const uint32_t bucket = xh >> 18;                                // x >> 50
             const uint32_t th = alignbit(xh, xl, 18);                        // high word of (x << 14) ^ 0x3FFF
-            uint32_t lzm1;                                                   // lz - 1; FAST with th == 0: 0xFFFFFFFF, so
-            if constexpr (FAST) {                                            // reg wraps to sig alone (an under-estimate)
+            uint32_t lzm1;                                                   // lz - 1; FAST with th == 0: 0xFFFFFFFF, a raw word
+            if constexpr (FAST) {                                            // below "empty" (an under-estimate: nothing happens)
                 lzm1 = ffbh_u32(th);
             } else {
                 const uint32_t tl = (xl << 14) | 0x3FFFu;                    // low word, never 0
-                lzm1 = clz64_nz(th, tl);
+                lzm1 = clz64_nz(th, tl);                                     // lz = lzm1 + 1 = 1..=51
             }
-            uint32_t reg = ((lzm1 << 10) | ((uint32_t)y & 0x3FFu)) + 0x400u; // (lz << 10) | sig, lz = 1..=51
-            if constexpr (MASKED) reg &= vm;
-            regs.umax(bucket, reg);
+            if constexpr (Regs::THR) {
+                static_assert(!FAST || !Regs::THR, "deferring launches use the 18-bit fast form or the exact one");
+                regs.push_rank(bucket, lzm1, (uint32_t)y & 0x3FFu, MASKED ? vm : 0xFFFFFFFFu);
+            } else {
+                uint32_t raw = (lzm1 << 10) | ((uint32_t)y & 0x3FFu);        // flush: + 0x400 = (lz << 10) | sig
+                if constexpr (MASKED) raw |= ~vm;
+                regs.smax(bucket, raw);
+            }
             return th;
         }
     } else if constexpr (ALGO == 1) {
         // utils.rs:411-413: push_hash64(xxh3_64(masked.to_le_bytes(), seed)): bucket = low p bits,
-        // rho = 1 + leading zeros of the remaining 64-p bits = clz64(h | (2^p - 1)) + 1
+        // rho = 1 + leading zeros of the remaining 64-p bits = clz64(h | (2^p - 1)) + 1; the table holds rho - 1
         const uint32_t pm = (1u << p) - 1u;
         if constexpr (FAST && !HLL_HIGH) {
             // the hash's last step is h ^= h >> 28, which cannot move the leading one of the high word: the rank comes from the
@@ -136,9 +195,9 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             const uint64_t g = xxh3_64_8b_pre(c_lo, c_hi, bitflip);
             const uint32_t gh = (uint32_t)(g >> 32), gl = (uint32_t)g;
             const uint32_t j = (gl ^ alignbit(gh, gl, 28)) & pm;
-            uint32_t rho = ffbh_u32(gh) + 1u;                                   // gh == 0 -> 0 (an under-estimate; re-run by the caller)
-            if constexpr (MASKED) rho &= vm;
-            regs.umax(j, rho);
+            uint32_t raw = ffbh_u32(gh);                                        // gh == 0 -> "empty" (nothing happens; re-run by the caller)
+            if constexpr (MASKED) raw |= ~vm;
+            regs.smax(j, raw);
             return gh;
         }
         const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
@@ -148,53 +207,46 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             // rho = 1 + leading zeros of the lower 64-p bits = clz64((h << p) | 2^(p-1)) + 1
             static_assert(!FAST || !HLL_HIGH, "the alternative bucket rule has no fast form");
             const uint32_t jh = hh >> (32 - p);
-            uint32_t rho = clz64_nz(alignbit(hh, hl, 32 - p), (hl << p) | (1u << (p - 1))) + 1u;
-            if constexpr (MASKED) rho &= vm;
-            regs.umax(jh, rho);
+            uint32_t raw = clz64_nz(alignbit(hh, hl, 32 - p), (hl << p) | (1u << (p - 1)));
+            if constexpr (MASKED) raw |= ~vm;
+            regs.smax(jh, raw);
             return 1u;
         }
         const uint32_t j = hl & pm;
-        uint32_t rho;
-        if constexpr (FAST) rho = ffbh_u32(hh) + 1u;                         // hh == 0 -> 0 (an under-estimate)
-        else rho = clz64_nz(hh, hl | pm) + 1u;
-        if constexpr (MASKED) rho &= vm;
-        regs.umax(j, rho);
+        uint32_t raw;
+        if constexpr (FAST) raw = ffbh_u32(hh);                              // hh == 0 -> "empty"
+        else raw = clz64_nz(hh, hl | pm);
+        if constexpr (MASKED) raw |= ~vm;
+        regs.smax(j, raw);
         return hh;
     } else {
-        // utils.rs:427-429: UltraLogLog::add(h): idx = top p bits, bit (nlz + p - 1) of the register's prefix
-        // bitmap; sequential pack(unpack(old) | bit) == pack(OR of all bits), so OR now, pack later
-        uint32_t hh, hl, idx, th;
+        // utils.rs:427-429: UltraLogLog::add(h): idx = top p bits, nlz = leading zeros of the 64-p bits below; hash4j sets bit
+        // (nlz + p - 1) of the register's prefix and packs; sequential pack(unpack(old) | bit) == pack(OR of all bits)
+        // (SURVEY §7.3), so: OR the nlz values into a bitmap now, shift by p - 1 and pack at the flush
+        uint32_t hh, hl, th;
         if constexpr (FAST) {
             // without materialising the hash's last step h' = g ^ (g >> 28): bits [63-p, 32-p] of h' are those bits of g xor the
             // same bits of g >> 28, i.e. of the high word shifted right by 28 - p (p <= 26); the index sits above the xorshift's reach
             const uint64_t g = xxh3_64_8b_pre(c_lo, c_hi, bitflip);
             hh = (uint32_t)(g >> 32); hl = (uint32_t)g;
-            idx = hh >> (32 - p);
             th = alignbit(hh, hl, 32 - p) ^ (hh >> (28 - p));
+            // th != 0 -> nlz = v_ffbh(th) < 32: always the pair's first word; th == 0 -> push nothing (re-run by the caller)
+            uint32_t one;
+            if constexpr (MASKED) asm("v_min3_u32 %0, %1, 1, %2" : "=v"(one) : "v"(th), "v"(vm));   // th == 0 or an invalid k-mer: nothing
+            else one = th < 1u ? th : 1u;
+            regs.bor_first(hh, p, one << (ffbh_u32(th) & 31u));
+            return th;
         } else {
             const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
             hh = (uint32_t)(h >> 32); hl = (uint32_t)h;
-            idx = hh >> (32 - p);                                            // p <= 26 < 32
             th = alignbit(hh, hl, 32 - p);                                   // high word of ~(~h << p), p >= 3
-        }
-        uint32_t bit, one;
-        if constexpr (FAST) {
-            bit = ffbh_u32(th) + (uint32_t)p - 1u;                           // valid when th != 0
-            if constexpr (MASKED) {                                           // th == 0 or an invalid k-mer (vm == 0) -> push nothing:
-                asm("v_min3_u32 %0, %1, 1, %2" : "=v"(one) : "v"(th), "v"(vm));   // one instruction for both conditions
-                regs.bor(idx * 2u + ((bit >> 5) & 1u), one << (bit & 31u));
-                return th;
-            }
-            one = th < 1u ? th : 1u;                                          // th == 0 -> push nothing
-        } else {
             const uint32_t tl = (hl << p) | pm_of(p);
-            bit = clz64_nz(th, tl) + (uint32_t)p - 1u;                       // nlz 0..=64-p -> bit p-1..=63
-            one = 1u;
+            const uint32_t nlz = clz64_nz(th, tl);                           // 0..=64-p
+            uint32_t val = 1u << (nlz & 31u);
+            if constexpr (MASKED) val &= vm;
+            regs.bor_pair(hh >> (32 - p), nlz >> 5, val);
+            return th;
         }
-        uint32_t val = one << (bit & 31u);
-        if constexpr (MASKED) val &= vm;
-        regs.bor(idx * 2u + ((bit >> 5) & 1u), val);
-        return th;
     }
 }
 
@@ -263,13 +315,21 @@ __device__ __forceinline__ uint64_t uniform_valid_mask(uint32_t pos0, uint32_t R
 // one packed word = 16 k-mer start positions, fully unrolled: 16 independent instruction streams per lane
 // ------------------------------------------------------------------------------------------------------------
 struct KParams {
-    uint64_t bitflip;
+    BitFlip bitflip;
     uint64_t mask_gt;      // KM_GT16: low 2k bits
     uint64_t lsb_xor;      // ALT: 0, or (layout.kmer_lsb_first) the complement mask on the low 2k bits
-    uint32_t sh_lt;        // KM_LT16: 32 - 2k
-    uint32_t mask_lt;      // KM_LT16: low 2k bits
+    uint32_t sh_lt;        // KM_LT16: 32 - 2k            (these two and mask_hi sit in VECTOR registers in the hot kernels: a VOP2
+    uint32_t mask_lt;      // KM_LT16: low 2k bits          with a scalar source issues in 4.4 cycles, with two vector sources in 2.6-2.9)
+    uint32_t mask_hi;      // KM_GT16: bits 63:32 of mask_gt (its low word is all ones: 2k > 32)
     uint32_t sh_gt;        // KM_GT16: 64 - 2k
     int p;
+    // per-kernel constants of VOP2 instructions as vector registers (see BitFlip, lash_device.h)
+    __device__ __forceinline__ void to_vector_registers()
+    {
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sh_lt) : "s"(sh_lt));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(mask_lt) : "s"(mask_lt));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(mask_hi) : "s"(mask_hi));
+    }
 };
 
 // ALT (layout.kmer_lsb_first / hll_bucket_high; SURVEY App. D alternatives of U5 / U3): with the first base of a k-mer in
@@ -290,13 +350,11 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
             const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
             const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
             const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
-            const uint32_t rh = r ? alignbit(r2, r1, 2 * r) : r1;
-            uint64_t rc = (((uint64_t)rh << 32) | rl) & kp.mask_gt;
+            const uint32_t rh = (r ? alignbit(r2, r1, 2 * r) : r1) & kp.mask_hi;     // (the mask's low word is all ones)
+            uint64_t rc = ((uint64_t)rh << 32) | rl;
             uint64_t km = fwd;
             if constexpr (ALT) { km = rc ^ kp.lsb_xor; rc = fwd ^ kp.lsb_xor; }   // lsb_xor == 0 (msb-first): min(rc, fwd), the same
-            const uint64_t can = km < rc ? km : rc;                              // km.min(rc), utils.rs:494
-            can_lo = (uint32_t)can;
-            can_hi = (uint32_t)(can >> 32);
+            min_u64((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)rc, (uint32_t)(rc >> 32), can_lo, can_hi);   // km.min(rc), utils.rs:494
         } else {
             uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
             uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
@@ -312,58 +370,67 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
 
 // ------------------------------------------------------------------------------------------------------------
 // HyperMinHash with the signature deferred.  A k-mer changes its bucket only if its rank is at least the bucket's current one —
-// one k-mer in 25 of a 5 Mbp genome — and the rank needs only the x half of the hash.  The filter computes that half, reads the
-// bucket's register back (a stale value is a smaller one: the test only gets more permissive) and appends the k-mers that pass to a
-// wave-private list in LDS (the wave's dense_tile staging area; 320 entries: 63 left over + 4 k-mers x 64 lanes between two
-// checks); whenever 64 are waiting, the wave runs the full update on them, one per lane, every lane busy.  max() is commutative
-// and idempotent: order and repetition do not matter.  The list is drained from its end, so it never wraps or moves.
-//   rank test: x18 = the 18 rank bits below the bucket; lz_new >= lz_cur  <=>  x18 <= 0x7FFFF >> lz_cur   (lz_cur 0 = empty: all pass;
-//   lz_cur >= 19 — more zeros than the 18 bits show — x18 must be 0, and the full update decides; 32 and up pass everything)
+// one k-mer in 35 of a 5 Mbp genome — and the rank needs only the x half of the hash.  The filter computes that half, reads the
+// bucket's word back (LdsThrRegs: the word IS the threshold; a stale value is a larger one, the test only gets more permissive),
+// and the k-mers that pass wait for the full update in LDS.
+//
+// Round 4: every LANE keeps its own little stack (depth a.sigq_depth, an odd number of words: the lanes' slots then fall into
+// distinct banks).  Appending is three vector instructions and no scalar one:
+//     ds_write_b32 ptr, k-mer          every lane, no exec mask: a k-mer that does not pass is overwritten by the next
+//     v_cmp_le_u32_sdwa vcc, x16.WORD_0, word.WORD_1     (x16 = the 16 rank bits below the bucket)
+//     v_cndmask_b32 inc, 0, 4, vcc ; v_add_u32 ptr, ptr, inc
+// Round 3 compacted the passing lanes into one wave-wide list instead (ballot, two v_mbcnt, address, exec save / restore, scalar
+// position arithmetic, a readfirstlane per word): 9 vector + 6 scalar instructions per k-mer for test and append, now 5 + 0.
+// The price is the drain: when some lane could not take another group of k-mers, every lane that has one pops ONE and runs the
+// full update — two thirds of the lanes on average at depth 7 (the compacted list ran them 64 at a time), nearly all at the depth
+// a 1024-thread workgroup has room for.  max() is commutative and idempotent: order and repetition do not matter.
 // ------------------------------------------------------------------------------------------------------------
-struct SigQueue { uint32_t base_b, pos_b; };                // wave-uniform LDS byte addresses: the list, its first free slot
-constexpr uint32_t SIGQ_CAP = 320;                          // entries; the list sits at the start of the wave's staging area
+struct SigQueue {
+    uint32_t ptr;        // per lane: LDS byte address of its next free slot
+    uint32_t lane_b;     // per lane: LDS byte address of its first slot
+    uint32_t lim;        // per lane: lane_b + 4 * (depth - SIGQ_GROUP); beyond it the lane cannot take another group
+};
 #ifndef LASH_SIGQ_GROUP
 #define LASH_SIGQ_GROUP 4                                   // (tools/variants.sh: groups of two measured 3 % slower)
 #endif
-constexpr int SIGQ_GROUP = LASH_SIGQ_GROUP;                 // k-mers between two "64 waiting?" checks
-static_assert(63 + SIGQ_GROUP * 64 <= (int)SIGQ_CAP && 16 % SIGQ_GROUP == 0, "the list must hold what can arrive between two checks");
+constexpr int SIGQ_GROUP = LASH_SIGQ_GROUP;                 // k-mers between two "is a lane full?" checks
+constexpr uint32_t SIGQ_MIN_DEPTH = 7;                      // 512-thread workgroups, two per CU: 64 x 7 words = 1 792 bytes per wave
+static_assert(16 % SIGQ_GROUP == 0 && SIGQ_GROUP < (int)SIGQ_MIN_DEPTH, "a lane must hold a whole group of k-mers");
 
 __device__ __forceinline__ uint32_t lds_load(uint32_t byte_addr) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr; }
 __device__ __forceinline__ void lds_store(uint32_t byte_addr, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr = v; }
 
-template <class Regs>
-__device__ __forceinline__ void sigq_drain64(const Regs &regs, uint64_t bitflip, int p, SigQueue &q, uint32_t lane)
+__device__ __forceinline__ void sigq_init(SigQueue &q, uint32_t wave_base_b, uint32_t depth, uint32_t lane)
 {
-    q.pos_b -= 256u;
-    const uint32_t c = lds_load(q.pos_b + lane * 4u);
-    const uint32_t t = add_kmer<0, false, false, true>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
-    if (__builtin_amdgcn_ballot_w64(t < 0x4000u) != 0ull) (void)add_kmer<0, false, false, false>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
+    q.lane_b = wave_base_b + lane * depth * 4u;
+    q.ptr = q.lane_b;
+    q.lim = q.lane_b + 4u * (depth - (uint32_t)SIGQ_GROUP);
 }
-template <class Regs>
-__device__ __forceinline__ void sigq_drain_all(const Regs &regs, uint64_t bitflip, int p, SigQueue &q, uint32_t lane)
+// every lane that has a k-mer waiting pops one and runs the full update on it; ALL: until every stack is empty (end of the
+// item, or the staging area is needed), else until every lane can take another group
+template <bool ALL, class Regs>
+__device__ __forceinline__ void sigq_drain(const Regs &regs, BitFlip bitflip, int p, SigQueue &q)
 {
-    q.pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.pos_b);
-    while (q.pos_b >= q.base_b + 256u) sigq_drain64(regs, bitflip, p, q, lane);
-    const uint32_t n = (q.pos_b - q.base_b) >> 2;
-    if (n) {
-        const uint32_t c = lds_load(q.base_b + (lane < n ? lane : 0u) * 4u);
-        (void)add_kmer<0, false, true, false>(regs, c, 0u, lane < n ? 0xFFFFFFFFu : 0u, bitflip, p);
-        q.pos_b = q.base_b;
-    }
+    do {
+        if (q.ptr != q.lane_b) {
+            q.ptr -= 4u;
+            const uint32_t c = lds_load(q.ptr);
+            const uint32_t t = add_kmer<0, false, false, true>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
+            if (t < 0x4000u) (void)add_kmer<0, false, false, false>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
+        }
+    } while (__builtin_amdgcn_ballot_w64(ALL ? q.ptr != q.lane_b : q.ptr > q.lim) != 0ull);
 }
 
 template <int KMODE, bool MASKED, class Regs>
 __device__ __forceinline__ void process_word_defer(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1, uint32_t c2,
-                                                   uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw, SigQueue &q, uint32_t lane)
+                                                   uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw, SigQueue &q)
 {
-    const uint32_t base_b = q.base_b;
-    uint32_t pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)q.pos_b);
+    static_assert(Regs::THR, "the filter reads thresholds");
 #pragma unroll
     for (int g = 0; g < 16; g += SIGQ_GROUP) {
-        // four k-mers as one straight line: four rank halves, four registers read back, four tests, four stores (the lanes that
-        // did not pass store to a dummy word) — no branch before the list is appended to: with a branch per k-mer the scheduler had
-        // one hash chain at a time, 16 % slower than not deferring at all
-        uint32_t can[SIGQ_GROUP], x18[SIGQ_GROUP], cur[SIGQ_GROUP];
+        // four k-mers as one straight line: four rank halves, four words read back, then four appends — no branch in between: with
+        // a branch per k-mer the scheduler had one hash chain at a time, 16 % slower than not deferring at all
+        uint32_t can[SIGQ_GROUP], x16[SIGQ_GROUP], cur[SIGQ_GROUP];
 #pragma unroll
         for (int j = 0; j < SIGQ_GROUP; ++j) {
             const int r = g + j;
@@ -372,9 +439,9 @@ __device__ __forceinline__ void process_word_defer(const Regs &regs, const KPara
                 const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
                 const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
                 const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
-                const uint32_t rh = r ? alignbit(r2, r1, 2 * r) : r1;
-                const uint64_t rc = (((uint64_t)rh << 32) | rl) & kp.mask_gt;
-                can[j] = (uint32_t)(fwd < rc ? fwd : rc);
+                const uint32_t rh = (r ? alignbit(r2, r1, 2 * r) : r1) & kp.mask_hi;
+                uint32_t can_hi;
+                min_u64((uint32_t)fwd, (uint32_t)(fwd >> 32), rl, rh, can[j], can_hi);
             } else {
                 uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
                 uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
@@ -387,30 +454,27 @@ __device__ __forceinline__ void process_word_defer(const Regs &regs, const KPara
 #else
             cur[j] = lds_load((xh >> 16) & 0xFFFCu);                                              // the register table starts at LDS address 0
 #endif
-            x18[j] = xh & 0x3FFFFu;
-            if constexpr (MASKED) x18[j] |= ~(uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1);   // not a k-mer: never passes
+            x16[j] = xh >> 2;                                                                     // bits 15:0 = the 16 rank bits below the bucket
         }
 #pragma unroll
         for (int j = 0; j < SIGQ_GROUP; ++j) {
-            const bool pass = x18[j] <= (0x7FFFFu >> ((cur[j] >> 10) & 31u));
-            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
-            // (the running position stays in a scalar register and enters as the one scalar operand of the address's shift-add: as
-            // the count operand of v_mbcnt it would be a second scalar beside the mask and cost a v_mov per k-mer)
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 #ifdef LASH_ABL_DEFER_NO_APPEND   // timing-only diagnostic builds (tools/variants.sh): results are wrong by construction
-            asm volatile("" ::"v"(at), "v"(can[j]));
+            asm volatile("" ::"v"(x16[j]), "v"(cur[j]), "v"(can[j]));
 #else
-            if (pass) lds_store(at * 4u + pos_b, can[j]);
-            pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos_b + 4u * (uint32_t)__builtin_popcountll(m)));
+            lds_store(q.ptr, can[j]);
+            uint32_t inc;
+            asm("v_cmp_le_u32_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:WORD_1\n\tv_cndmask_b32_e64 %0, 0, 4, vcc"
+                : "=v"(inc) : "v"(x16[j]), "v"(cur[j]) : "vcc");
+            if constexpr (MASKED) inc &= (uint32_t)__builtin_amdgcn_sbfe((int)kvw, g + j, 1);       // not a k-mer: never stays
+            q.ptr += inc;
 #endif
         }
-#ifdef LASH_ABL_DEFER_NO_DRAIN
-        while (pos_b >= base_b + 256u) pos_b -= 256u;
+#ifndef LASH_ABL_DEFER_NO_DRAIN
+        if (__builtin_amdgcn_ballot_w64(q.ptr > q.lim) != 0ull) sigq_drain<false>(regs, kp.bitflip, kp.p, q);
 #else
-        while (pos_b >= base_b + 256u) { q.pos_b = pos_b; sigq_drain64(regs, kp.bitflip, kp.p, q, lane); pos_b = q.pos_b; }
+        q.ptr = q.ptr > q.lim ? q.lane_b : q.ptr;
 #endif
     }
-    q.pos_b = pos_b;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -609,7 +673,7 @@ __device__ __forceinline__ uint64_t window_or(uint64_t lo, uint32_t hi32, int n)
 // is hashed iff that start is in J (the others are whole windows the fast path has done).  Returns how many it added.
 template <int ALGO, bool XLOW, class Regs>
 __device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *gseq, uint64_t L, uint64_t pos0, uint64_t J,
-                                               uint64_t starts, const uint32_t *bk, uint32_t RL, int k, uint64_t bitflip, int p,
+                                               uint64_t starts, const uint32_t *bk, uint32_t RL, int k, BitFlip bitflip, int p,
                                                uint32_t cmask, const CodeTabs ct, uint32_t *dirty)
 {
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -676,7 +740,6 @@ __device__ __noinline__ uint32_t junction_walk(const Regs regs, const uint8_t *g
 constexpr uint32_t DENSE_STAGE_CODE_WORDS = 264;      // 4096 + 31 + 16 bases at 16 per word, rounded up; reads reach word 4*63+5
 constexpr uint32_t DENSE_STAGE_BRK_WORDS = 136;       // the same positions, one bit each; reads reach word 2*63+3 (+1)
 constexpr uint32_t DENSE_STAGE_WORDS = DENSE_STAGE_CODE_WORDS + DENSE_STAGE_BRK_WORDS;   // 1600 bytes per wave
-static_assert(SIGQ_CAP <= DENSE_STAGE_WORDS, "process_word_defer's list lives in the wave's staging area");
 constexpr uint32_t DENSE_SCAN_MAX = 4u << 20;         // bytes of look-ahead scan before the genome is left to the pack stage
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
@@ -1028,15 +1091,18 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
             }
         }
     };
+    // table words -> registers of the image (see "register spaces" at the top of the file)
+    auto hmh_reg = [](uint32_t raw) { return (int32_t)raw < 0 ? 0u : raw + 0x400u; };       // (lz - 1) << 10 | sig, -1 = empty -> lz << 10 | sig, 0
+    auto hll_reg = [](uint32_t raw) { return raw + 1u; };                                     // rho - 1, -1 = empty -> rho, 0
     if constexpr (ALGO == 0) {
         for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
-            put(i, regs.get(2 * i) | (regs.get(2 * i + 1) << 16));
+            put(i, hmh_reg(regs.get(2 * i)) | (hmh_reg(regs.get(2 * i + 1)) << 16));
         if (sole && threadIdx.x == 0 && HDR) write_header(img, a.lay.hdr_tpl, a.alpha_bits, HMH_M, 0, 0.0, HMH_P);
     } else if constexpr (ALGO == 1) {
         const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
         if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
         for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
-            put(i, regs.get(4 * i) | (regs.get(4 * i + 1) << 8) | (regs.get(4 * i + 2) << 16) | (regs.get(4 * i + 3) << 24));
+            put(i, hll_reg(regs.get(4 * i)) | (hll_reg(regs.get(4 * i + 1)) << 8) | (hll_reg(regs.get(4 * i + 2)) << 16) | (hll_reg(regs.get(4 * i + 3)) << 24));
         if (sole) {
             __syncthreads();
             if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
@@ -1051,8 +1117,9 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
                 const uint32_t lo = regs.get(8 * i + 2 * b), hi = regs.get(8 * i + 2 * b + 1);
                 uint32_t r = 0;
                 if (lo | hi) {
-                    // hash4j pack(): r = 4 * (index of leading one) + the two bits below it
-                    const uint64_t x = ((uint64_t)hi << 32) | lo;
+                    // the nlz values seen -> hash4j's prefix (bit nlz + p - 1; nlz <= 64 - p); pack(): r = 4 * (index of the
+                    // leading one) + the two bits below it
+                    const uint64_t x = (((uint64_t)hi << 32) | lo) << (p - 1);
                     const uint32_t top = 63u - (uint32_t)__builtin_clzll(x);
                     const uint32_t below = top >= 2 ? (uint32_t)(x >> (top - 2)) & 3u : (uint32_t)(x << (2 - top)) & 3u;
                     r = (top << 2) | below;
@@ -1102,8 +1169,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
 
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
-    using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
-                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type;
+    using Regs = typename std::conditional<DEFER, LdsThrRegs, typename std::conditional<REGS == REGS_LDS, LdsRegs,
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type>::type;
     Regs regs;
     uint32_t *census;
     const uint32_t part = it.slice >> 16;                                  // REGS_LDS_PARTS: which 1/2^lp of the buckets
@@ -1136,20 +1203,21 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint8_t *__restrict__ gseq = DIRECT ? a.seq + gd.byte_off : nullptr;
     uint32_t *const dirty = DIRECT ? a.dirty + it.genome : nullptr;
     KParams kp;
-    kp.bitflip = a.bitflip;
+    kp.bitflip = BitFlip::vector(a.bitflip);
     kp.p = p;
     kp.sh_lt = 32u - 2u * (uint32_t)k;
     kp.mask_lt = (KMODE == KM_LT16) ? ((1u << (2 * k)) - 1u) : 0xFFFFFFFFu;
     kp.sh_gt = 64u - 2u * (uint32_t)k;
     kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    kp.mask_hi = (uint32_t)(kp.mask_gt >> 32);
+    if constexpr (!ALT) kp.to_vector_registers();
     kp.lsb_xor = (ALT && a.lay.kmer_lsb_first) ? ((((uint64_t)a.lay.comp_mask << 32) | a.lay.comp_mask) & kp.mask_gt) : 0ull;
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
     uint32_t my_kmers = 0;
-    SigQueue sigq;                                                          // DEFER: lives in the wave's staging area
-    sigq.base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.stage_off + (threadIdx.x >> 6) * (DENSE_STAGE_WORDS * 4u)));
-    sigq.pos_b = sigq.base_b;
     const uint32_t lane = threadIdx.x & 63u;
+    SigQueue sigq;                                                          // DEFER: the lanes' stacks live in the wave's staging area
+    sigq_init(sigq, (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.stage_off + (threadIdx.x >> 6) * a.stage_stride)), a.sigq_depth, lane);
     uint32_t tiles_dense = 0;                                               // direct mode, per wave: how many of its tiles held deleted bytes
     bool judged = false;                                                    // ... and whether it has already voted to hand the genome over
 
@@ -1192,7 +1260,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     // the table is cleared while the first tile's loads are in flight; a raw barrier, because __syncthreads() would also
     // drain vmcnt and with it those loads
     if constexpr (USE_LDS) {
-        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
@@ -1300,8 +1368,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     const uint64_t P0 = 16ull * (tile + (threadIdx.x & ~63u) * SKETCH_WORDS_PER_THREAD);
                     uint64_t E = P0 + 4096 < 16ull * it.word_end ? P0 + 4096 : 16ull * it.word_end;
                     E = E < L ? E : L;
-                    const uint32_t stage_b = a.stage_off + (threadIdx.x >> 6) * (DENSE_STAGE_WORDS * 4u);
-                    if constexpr (DEFER) sigq_drain_all(regs, kp.bitflip, p, sigq, lane);     // (the staging area is about to be used)
+                    const uint32_t stage_b = a.stage_off + (threadIdx.x >> 6) * a.stage_stride;
+                    if constexpr (DEFER) sigq_drain<true>(regs, kp.bitflip, p, sigq);           // (the staging area is about to be used)
                     my_kmers += wave_sum(dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
                                                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
                                                                             part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3));
@@ -1339,11 +1407,11 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 z = 0xFFFFFFFFu;
             } else if constexpr (DEFER) {
                 z = 0xFFFFFFFFu;                                               // (nothing to re-run: the full update does that itself)
-                if (all_valid) process_word_defer<KMODE, false>(regs, kp, c0, c1, c2, r0, r1, r2, 0u, sigq, lane);
+                if (all_valid) process_word_defer<KMODE, false>(regs, kp, c0, c1, c2, r0, r1, r2, 0u, sigq);
                 else {
                     uint32_t kvw = (uint32_t)kv;
                     asm volatile("" : "+v"(kvw));
-                    process_word_defer<KMODE, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw, sigq, lane);
+                    process_word_defer<KMODE, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw, sigq);
                 }
             } else if (all_valid) {
                 z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
@@ -1370,7 +1438,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         }
     }
 
-    if constexpr (DEFER) sigq_drain_all(regs, kp.bitflip, p, sigq, lane);
+    if constexpr (DEFER) sigq_drain<true>(regs, kp.bitflip, p, sigq);
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
 }
 
@@ -1428,7 +1496,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             regs.part = part;
         }
         census = lds_regs + a.nreg32;
-        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else {
         regs.base = a.gregs + (uint64_t)item * a.nreg32;
         census = lds_regs;
@@ -1440,12 +1508,14 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
     const bool breaks = bk != nullptr || RL != 0u;
     const uint8_t *__restrict__ gseq = a.seq + gd.byte_off;
     KParams kp;
-    kp.bitflip = a.bitflip;
+    kp.bitflip = BitFlip::vector(a.bitflip);
     kp.p = p;
     kp.sh_lt = 32u - 2u * (uint32_t)k;
     kp.mask_lt = (KMODE == KM_LT16) ? ((1u << (2 * k)) - 1u) : 0xFFFFFFFFu;
     kp.sh_gt = 64u - 2u * (uint32_t)k;
     kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    kp.mask_hi = (uint32_t)(kp.mask_gt >> 32);
+    kp.to_vector_registers();
     kp.lsb_xor = 0ull;
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ct{a.lay.code_lo, a.lay.code_hi};
@@ -1759,7 +1829,7 @@ __global__ void __launch_bounds__(256) aa_sketch_kernel(SketchArgs a)
             regs.part = part;
         }
         census = lds_regs + a.nreg32;
-        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = 0;
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else {
         regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;
         census = lds_regs;
@@ -1782,7 +1852,7 @@ __global__ void __launch_bounds__(256) aa_sketch_kernel(SketchArgs a)
             v = (v << 5) | code;
             if (++have >= (uint32_t)k) {
                 const uint64_t m = v & kmask;
-                (void)add_kmer<ALGO, XLOW, false, false>(regs, (uint32_t)m, (uint32_t)(m >> 32), 0xFFFFFFFFu, a.bitflip, p);
+                (void)add_kmer<ALGO, XLOW, false, false>(regs, (uint32_t)m, (uint32_t)(m >> 32), 0xFFFFFFFFu, BitFlip::scalar(a.bitflip), p);
                 ++my_kmers;
             }
         };
@@ -1977,7 +2047,13 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
     return s;
 }
 
-uint32_t sketch_direct_stage_bytes(const SketchPlan &plan) { return (plan.threads / 64u) * DENSE_STAGE_WORDS * 4u; }
+// per wave: dense_tile's staging area (direct mode) and / or the lanes' stacks of a deferring launch (they share it)
+static uint32_t stage_stride_bytes(const SketchPlan &plan, bool direct, bool defer)
+{
+    const uint32_t stage = direct ? DENSE_STAGE_WORDS * 4u : 0u, stacks = defer ? 64u * plan.sigq_depth * 4u : 0u;
+    return std::max(stage, stacks);
+}
+uint32_t sketch_direct_stage_bytes(const SketchPlan &plan) { return (plan.threads / 64u) * stage_stride_bytes(plan, true, true); }
 
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
@@ -1989,7 +2065,9 @@ static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uin
     }
     SketchArgs a = args;
     a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile);
-    const uint32_t lds = plan.lds_bytes + ((DIRECT || defer) ? sketch_direct_stage_bytes(plan) : 0u);   // deferring launches keep their lists there
+    a.stage_stride = stage_stride_bytes(plan, DIRECT, defer);              // deferring launches keep their lanes' stacks there
+    a.sigq_depth = plan.sigq_depth;
+    const uint32_t lds = plan.lds_bytes + (plan.threads / 64u) * a.stage_stride;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -10,8 +10,9 @@ using namespace lash;
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 template <int MODE>
-__global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, uint32_t *sink, int iters, uint64_t bitflip)
+__global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, uint32_t *sink, int iters, uint64_t bitflip64)
 {
+    const BitFlip bitflip = BitFlip::vector(bitflip64);
     extern __shared__ uint32_t lds[];
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0;
     __syncthreads();
@@ -79,8 +80,9 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
 __device__ __forceinline__ uint32_t ub_lds_load(uint32_t b) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b; }
 __device__ __forceinline__ void ub_lds_store(uint32_t b, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b = v; }
 template <int STAGE>
-__global__ void __launch_bounds__(1024) defer_bench(unsigned long long *cycles, uint32_t *sink, int iters, uint64_t bitflip)
+__global__ void __launch_bounds__(1024) defer_bench(unsigned long long *cycles, uint32_t *sink, int iters, uint64_t bitflip64)
 {
+    const BitFlip bitflip = BitFlip::vector(bitflip64);
     extern __shared__ uint32_t lds[];
     for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0;
     __syncthreads();
