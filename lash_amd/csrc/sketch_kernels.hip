@@ -332,11 +332,40 @@ struct KParams {
     }
 };
 
+// The canonical k-mer of start position r (0..15) of a word for 16 < k <= 32: the window's value, right-aligned, against the
+// mirrored window of the reverse-complemented stream (utils.rs:493-494).  K = 0: k at run time — two funnel shifts per stream,
+// one 64-bit shift, one mask.  K = k at compile time (21: BASELINE configs[2], the reference's usual HyperLogLog setting): every
+// half is a field at a known place — one v_bfe_u32 while it lies inside one stream word, one v_alignbit for the low words —
+// 4.4 instead of 6 instructions per k-mer in front of the 64-bit minimum.
+template <int K>
+__device__ __forceinline__ void canon_gt16(int r, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t r0, uint32_t r1, uint32_t r2, const KParams &kp,
+                                           uint32_t &can_lo, uint32_t &can_hi)
+{
+    uint32_t f_lo, f_hi, q_lo, q_hi;
+    if constexpr (K == 0) {
+        const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
+        const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
+        const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
+        f_lo = (uint32_t)fwd; f_hi = (uint32_t)(fwd >> 32);
+        q_lo = r ? alignbit(r1, r0, 2 * r) : r0;
+        q_hi = (r ? alignbit(r2, r1, 2 * r) : r1) & kp.mask_hi;                // (the mask's low word is all ones)
+    } else {
+        static_assert(K > 16 && K < 32, "compile-time k of the 64-bit window");
+        constexpr int D = 2 * K - 32;                                          // bits of the k-mer above its low word
+        const int s = 2 * r + D;                                               // stream bit where its low word starts
+        f_lo = s < 32 ? alignbit(c0, c1, 32 - s) : s == 32 ? c1 : alignbit(c1, c2, 64 - s);
+        f_hi = s <= 32 ? (uint32_t)__builtin_amdgcn_ubfe(c0, 32 - s, D) : alignbit(c0, c1, 32 - 2 * r) >> (32 - D);
+        q_lo = r ? alignbit(r1, r0, 2 * r) : r0;
+        q_hi = s <= 32 ? (uint32_t)__builtin_amdgcn_ubfe(r1, 2 * r, D) : alignbit(r2, r1, 2 * r) & ((1u << D) - 1u);
+    }
+    min_u64(f_lo, f_hi, q_lo, q_hi, can_lo, can_hi);                           // km.min(rc), utils.rs:494
+}
+
 // ALT (layout.kmer_lsb_first / hll_bucket_high; SURVEY App. D alternatives of U5 / U3): with the first base of a k-mer in
 // its LEAST significant bits the iterator's value is the group-reversed window, and
 //     groups_reversed(fwd) = rc ^ cm,   its reverse complement = fwd ^ cm      (cm = complement mask on 2k bits),
 // because rc = groups_reversed(fwd ^ cm) and cm reads the same in both directions.  Two extra XORs per k-mer, exact forms only.
-template <int ALGO, int KMODE, bool XLOW, bool MASKED, bool FAST, class Regs, bool ALT = false, bool HLL_HIGH = false>
+template <int ALGO, int KMODE, bool XLOW, bool MASKED, bool FAST, class Regs, bool ALT = false, bool HLL_HIGH = false, int K = 0>
 __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1,
                                                  uint32_t c2, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw)
 {
@@ -345,16 +374,17 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
     for (int r = 0; r < 16; ++r) {
         const uint32_t vm = MASKED ? (uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1) : 0xFFFFFFFFu;   // 0 or ~0
         uint32_t can_lo, can_hi = 0;
-        if constexpr (KMODE == KM_GT16) {
+        if constexpr (KMODE == KM_GT16 && !ALT) {
+            canon_gt16<K>(r, c0, c1, c2, r0, r1, r2, kp, can_lo, can_hi);
+        } else if constexpr (KMODE == KM_GT16) {
             const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
             const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
             const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
             const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
             const uint32_t rh = (r ? alignbit(r2, r1, 2 * r) : r1) & kp.mask_hi;     // (the mask's low word is all ones)
-            uint64_t rc = ((uint64_t)rh << 32) | rl;
-            uint64_t km = fwd;
-            if constexpr (ALT) { km = rc ^ kp.lsb_xor; rc = fwd ^ kp.lsb_xor; }   // lsb_xor == 0 (msb-first): min(rc, fwd), the same
-            min_u64((uint32_t)km, (uint32_t)(km >> 32), (uint32_t)rc, (uint32_t)(rc >> 32), can_lo, can_hi);   // km.min(rc), utils.rs:494
+            const uint64_t rc = ((uint64_t)rh << 32) | rl;
+            // first base least significant: the iterator's value is the group-reversed window (see above); lsb_xor == 0: min(rc, fwd)
+            min_u64((uint32_t)(rc ^ kp.lsb_xor), (uint32_t)((rc ^ kp.lsb_xor) >> 32), (uint32_t)(fwd ^ kp.lsb_xor), (uint32_t)((fwd ^ kp.lsb_xor) >> 32), can_lo, can_hi);
         } else {
             uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
             uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
@@ -421,7 +451,7 @@ __device__ __forceinline__ void sigq_drain(const Regs &regs, BitFlip bitflip, in
     } while (__builtin_amdgcn_ballot_w64(ALL ? q.ptr != q.lane_b : q.ptr > q.lim) != 0ull);
 }
 
-template <int KMODE, bool MASKED, class Regs>
+template <int KMODE, bool MASKED, class Regs, int K = 0>
 __device__ __forceinline__ void process_word_defer(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1, uint32_t c2,
                                                    uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw, SigQueue &q)
 {
@@ -435,13 +465,8 @@ __device__ __forceinline__ void process_word_defer(const Regs &regs, const KPara
         for (int j = 0; j < SIGQ_GROUP; ++j) {
             const int r = g + j;
             if constexpr (KMODE == KM_GT16) {
-                const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
-                const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
-                const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
-                const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
-                const uint32_t rh = (r ? alignbit(r2, r1, 2 * r) : r1) & kp.mask_hi;
                 uint32_t can_hi;
-                min_u64((uint32_t)fwd, (uint32_t)(fwd >> 32), rl, rh, can[j], can_hi);
+                canon_gt16<K>(r, c0, c1, c2, r0, r1, r2, kp, can[j], can_hi);
             } else {
                 uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
                 uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
@@ -572,20 +597,23 @@ __device__ __forceinline__ uint4 load16_any(const uint8_t *p)    // any alignmen
     return v;
 }
 struct CodeTabs { uint32_t lo, hi; };   // LayoutDev::code_lo / code_hi (defaults 0x01000000 / 0x02000003: A,C,G,T = 0,1,2,3)
-__device__ __forceinline__ uint32_t ascii4_to_2bit(uint32_t x, uint32_t &bad, const CodeTabs ct)
+__device__ __forceinline__ uint32_t ascii4_gather(uint32_t x, uint32_t &bad, const CodeTabs ct)
 {
     // The low 3 bits tell the four letters apart (A 1, C 3, T 4, G 7), so they index two 8-entry byte tables held in
     // v_perm operands: the letter that key stands for (0xFF for the keys no letter has: never equal to x, whose low
     // bits ARE the key) and its 2-bit code (the context layout's base codes: kernel arguments, same instruction count).
     const uint32_t key = x & 0x07070707u;
-    bad |= x ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, key);        // entries 7..4 | 3..0
+    bad = __builtin_amdgcn_bitop3_b32(bad, x, __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, key), 0xF6);   // bad | (x ^ letters); tables: entries 7..4 | 3..0
     const uint32_t code = __builtin_amdgcn_perm(ct.hi, ct.lo, key);
-    return (code * 0x40100401u) >> 24;                                       // b0<<6 | b1<<4 | b2<<2 | b3 (no carries)
+    return code * 0x40100401u;                                               // bits 31:24 = b0<<6 | b1<<4 | b2<<2 | b3 (no carries); the rest is junk
 }
+__device__ __forceinline__ uint32_t ascii4_to_2bit(uint32_t x, uint32_t &bad, const CodeTabs ct) { return ascii4_gather(x, bad, ct) >> 24; }
 __device__ __forceinline__ uint32_t ascii16_to_word(const uint4 q, uint32_t &bad, const CodeTabs ct)
 {
-    return (ascii4_to_2bit(q.x, bad, ct) << 24) | (ascii4_to_2bit(q.y, bad, ct) << 16) | (ascii4_to_2bit(q.z, bad, ct) << 8) |
-           ascii4_to_2bit(q.w, bad, ct);
+    // the four products' top bytes, first chunk most significant: three byte permutes (hipcc's shift / mask / or form: six)
+    const uint32_t r0 = ascii4_gather(q.x, bad, ct), r1 = ascii4_gather(q.y, bad, ct), r2 = ascii4_gather(q.z, bad, ct), r3 = ascii4_gather(q.w, bad, ct);
+    const uint32_t t01 = __builtin_amdgcn_perm(r0, r1, 0x07030303u), t23 = __builtin_amdgcn_perm(r2, r3, 0x03030703u);
+    return __builtin_amdgcn_perm(t01, t23, 0x07060100u);
 }
 // tail lanes (the last <= 2 lanes of a genome, whose 96 bytes are not all inside it): bytes at or past L read as 'A' (their
 // k-mers are masked).  All 96 byte loads are unconditional on a clamped index, so they are issued together: one memory
@@ -1214,6 +1242,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     kp.lsb_xor = (ALT && a.lay.kmer_lsb_first) ? ((((uint64_t)a.lay.comp_mask << 32) | a.lay.comp_mask) & kp.mask_gt) : 0ull;
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
+    constexpr bool K21 = KMODE == KM_GT16 && DIRECT && !ALT && !DEFER && REGS == REGS_LDS;   // kernels with a k = 21 body of their own
     uint32_t my_kmers = 0;
     const uint32_t lane = threadIdx.x & 63u;
     SigQueue sigq;                                                          // DEFER: the lanes' stacks live in the wave's staging area
@@ -1412,6 +1441,14 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     uint32_t kvw = (uint32_t)kv;
                     asm volatile("" : "+v"(kvw));
                     process_word_defer<KMODE, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw, sigq);
+                }
+            } else if (K21 && k == 21) {
+                // k = 21 (BASELINE configs[2]; the fields of the 64-bit window at compile-time places: canon_gt16<21>)
+                if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true, Regs, false, false, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
+                else {
+                    uint32_t kvw = (uint32_t)kv;
+                    asm volatile("" : "+v"(kvw));
+                    z = process_word<ALGO, KMODE, XLOW, true, true, Regs, false, false, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
                 }
             } else if (all_valid) {
                 z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
@@ -2037,6 +2074,10 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
     if (const char *e = getenv("LASH_SKETCH_THREADS")) {                    // tuning knob (tools/)
         const int t = atoi(e);
         if (t >= 64 && t <= 1024 && t % 64 == 0) s.threads = (uint32_t)t;
+    }
+    if (const char *e = getenv("LASH_SIGQ_DEPTH")) {                        // tuning knob: words of a lane's stack in deferring launches
+        const int d = atoi(e) | 1;
+        if (d >= (int)SIGQ_MIN_DEPTH && d <= 63) s.sigq_depth = (uint32_t)d;
     }
     if (!s.use_lds) s.lds_bytes = 0;
     // Small tables (hll p<=13, ull p<=12) would let 4 workgroups = 8 waves/SIMD share a CU; the kernel is VALU-issue
