@@ -204,9 +204,15 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     const uint64_t step = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
     const uint64_t min_slice = step * 8;                           // amortise the LDS clear + flush
     static const uint64_t slice_factor_env = getenv("LASH_SLICE_FACTOR") ? std::max(1, atoi(getenv("LASH_SLICE_FACTOR"))) : 0;
-    // HyperMinHash launches that may defer their signatures (below) like long items — a slice starts with an empty table — and the
-    // quartered tail (below) has taken over what the many small slices were for: 2x the slots there (1 000 x 5 Mbp: 4.39 -> 4.33 ms)
-    const uint64_t slice_factor = slice_factor_env ? slice_factor_env : (defer_eligible ? 2 : 4);   // tuning knob: the
+    uint64_t len_lo = ~0ull, len_hi = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) { len_lo = std::min<uint64_t>(len_lo, pk->byte_len[g]); len_hi = std::max<uint64_t>(len_hi, pk->byte_len[g]); }
+    const bool equal_genomes = n_genomes > 0 && len_hi <= len_lo + len_lo / 4;
+    // HyperMinHash launches that may defer their signatures (below) like long items — a slice starts with an empty table, and the share
+    // of k-mers that pass the filter is 2.8 % over a whole 5 Mbp genome, 7.7 % over a third of one — and the split tail (below) has
+    // taken over what the many small slices were for: 2x the slots there (1 000 x 5 Mbp: 4.39 -> 4.33 ms, round 3), and for batches of
+    // EQUAL genomes 1x: BASELINE configs[1], 1 000 x 5 Mbp, runs whole genomes in two rounds instead of thirds in six (4.12 -> 3.95 ms,
+    // profiles/r04/cfg1_slicing.txt; a collection of unequal genomes loses a third with that: it needs the item cap below)
+    const uint64_t slice_factor = slice_factor_env ? slice_factor_env : (defer_eligible ? (equal_genomes ? 1 : 2) : 4);   // tuning knob: the
     // sketch time is flat from 2x to 24x the slots (4.87-4.91 ms on the default bench), the finalize time grows with it
     uint64_t target = total_words / (slots * slice_factor) + 1;
     target = std::max(target, min_slice);
@@ -242,7 +248,9 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // few items it holds (600 x 5 Mbp in 2 400 items = 4.7 rounds took the time of 5; 12 500 whole genomes 24.4 -> 25).  The last
     // round's worth of slices is therefore cut into quarters: the launch ends on a quarter-round boundary instead.  Index order is
     // launch order, so the small items are the ones handed out last.
-    static const uint32_t tail_split = getenv("LASH_TAIL_SPLIT") ? (uint32_t)std::max(1, atoi(getenv("LASH_TAIL_SPLIT"))) : 4u;
+    static const uint32_t tail_split_env = getenv("LASH_TAIL_SPLIT") ? (uint32_t)std::max(1, atoi(getenv("LASH_TAIL_SPLIT"))) : 0u;
+    // (halves where whole genomes may defer signatures: a quarter of a genome fills its table four times over)
+    const uint32_t tail_split = tail_split_env ? tail_split_env : (defer_eligible && equal_genomes ? 2u : 4u);
     const uint64_t tail_min = min_slice / 8;                        // 32 kb of sequence: 15 us of a workgroup's time
     uint64_t n_coarse = 0, fine_from = ~0ull;
     uint64_t c_lo = ~0ull, c_hi = 0;                               // smallest and largest slice

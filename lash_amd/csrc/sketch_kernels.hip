@@ -119,6 +119,10 @@ struct LdsThrRegs {
     }
     __device__ __forceinline__ void push_rank(uint32_t bucket, uint32_t lzm1, uint32_t sig, uint32_t vm) const
     { asm volatile("ds_min_u32 %0, %1" ::"v"(bucket << 2), "v"(encode(lzm1, sig) | ~vm) : "memory"); }
+    // lzm1 <= 18 (the 18-bit fast form): exact up to 16, 17 and 18 go in as 16 — an under-estimate, and the caller re-runs those
+    // (THR_REDO) — which makes the word three instructions
+    __device__ __forceinline__ void push_rank_fast(uint32_t bucket, uint32_t lzm1, uint32_t sig, uint32_t vm) const
+    { asm volatile("ds_min_u32 %0, %1" ::"v"(bucket << 2), "v"((((0xFFFF0000u >> lzm1) & 0xFFFF0000u) | (0xFFFEu - sig)) | ~vm) : "memory"); }
     __device__ __forceinline__ uint32_t get(uint32_t i) const                 // -> the table word LdsRegs would hold
     {
         const uint32_t w = base[i];
@@ -154,13 +158,13 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             xxh3_128_4b_hmh_fast(c_lo, bitflip, xh, sig);
             const uint32_t t18 = (xh << 14) | 0x3FFFu;
             if constexpr (Regs::THR) {
-                regs.push_rank(xh >> 18, ffbh_u32(t18), sig, MASKED ? vm : 0xFFFFFFFFu);
+                regs.push_rank_fast(xh >> 18, ffbh_u32(t18), sig, MASKED ? vm : 0xFFFFFFFFu);
             } else {
                 uint32_t raw = (ffbh_u32(t18) << 10) | sig;
                 if constexpr (MASKED) raw |= ~vm;
                 regs.smax(xh >> 18, raw);
             }
-            return t18;                                  // < 0x4000 <=> all 18 rank bits were zero
+            return t18;                                  // < 0x4000 <=> all 18 rank bits were zero (LdsThrRegs: < 0x8000, 17 of them)
         } else {
             uint64_t lo, hi;
             xxh3_128_4b(c_lo, bitflip, lo, hi);
@@ -446,7 +450,7 @@ __device__ __forceinline__ void sigq_drain(const Regs &regs, BitFlip bitflip, in
             q.ptr -= 4u;
             const uint32_t c = lds_load(q.ptr);
             const uint32_t t = add_kmer<0, false, false, true>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
-            if (t < 0x4000u) (void)add_kmer<0, false, false, false>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
+            if (t < 0x8000u) (void)add_kmer<0, false, false, false>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);   // rank 17 and up: exact form
         }
     } while (__builtin_amdgcn_ballot_w64(ALL ? q.ptr != q.lane_b : q.ptr > q.lim) != 0ull);
 }
@@ -1049,7 +1053,7 @@ __device__ __noinline__ uint32_t dense_tile(const Regs regs, const KParams kp, c
             asm volatile("" : "+v"(kvw));
             z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
         }
-        constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+        constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? (Regs::THR ? 0x7FFFu : 0x3FFFu) : 0u;
         if (z <= Z_REDO) {
             uint32_t kvw = (uint32_t)kv;
             asm volatile("" : "+v"(kvw));
@@ -1461,7 +1465,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             }
             // FAST forms return a word whose smallness flags "rank not decided by the bits looked at": exact re-run
             // (HMH/x-high looks at 18 bits -> 2^-18 per k-mer; the others at 32 bits -> 2^-32)
-            constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+            constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? (Regs::THR ? 0x7FFFu : 0x3FFFu) : 0u;
             if (z <= Z_REDO) {
                 uint32_t kvw = (uint32_t)kv;
                 asm volatile("" : "+v"(kvw));
@@ -1609,7 +1613,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
                     asm volatile("" : "+v"(m));
                     z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, m);
                 }
-                constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+                constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? (Regs::THR ? 0x7FFFu : 0x3FFFu) : 0u;
                 if (z <= Z_REDO) {
                     uint32_t m = kvw;
                     asm volatile("" : "+v"(m));
