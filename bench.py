@@ -121,11 +121,18 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
             done += genomes
         return done * (L - k + 1) / el
 
-    cands = sorted({eff, max(1, eff // 2), min(prov["affinity"], 2 * eff), min(prov["affinity"], 4 * eff)}, reverse=True)
+    # threads = the effective core count (the scan over 0.5x..4x of it bought 9 % on a 16-CPU cgroup and took longer
+    # than the GPU phase of the whole run); LASH_BENCH_CPU_SCAN=1 brings the scan back
+    cands = [eff]
+    if os.environ.get("LASH_BENCH_CPU_SCAN"):
+        cands = sorted({eff, max(1, eff // 2), min(prov["affinity"], 2 * eff), min(prov["affinity"], 4 * eff)}, reverse=True)
     scan = {}
-    for T in cands:
-        scan[T] = run(T, min(n, max(2 * T, 8)))
-    best = max(scan, key=scan.get)
+    if len(cands) > 1:
+        for T in cands:
+            scan[T] = run(T, min(n, max(2 * T, 8)))
+        best = max(scan, key=scan.get)
+    else:
+        best = eff
     done, elapsed = 0, 0.0
     while elapsed < target_s:
         t0 = time.perf_counter()
@@ -142,7 +149,7 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
         txt = np.concatenate([full, np.full((full.shape[0], 1), 10, np.uint8)], axis=1).reshape(-1)
         files.append(b">g%d\n" % g + txt.tobytes() + body[(L // 80) * 80:].tobytes() + b"\n")
     pdone, pelapsed = 0, 0.0
-    while pelapsed < max(3.0, target_s / 3):                 # long enough that a cgroup CPU quota cannot be out-run by a burst
+    while pelapsed < max(1.0, target_s / 3):                 # long enough that a cgroup CPU quota cannot be out-run by a burst
         t0 = time.perf_counter()
         O.sketch_files(algo_id, k, p, seed, files, threads=best)
         pelapsed += time.perf_counter() - t0
@@ -156,8 +163,9 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
     return {"value": kmers / elapsed, "unit": "k-mers/s", "cores": best, "kind": "port",
             "sample": "%d synthetic %d-bp genomes, %s k=%d, in-memory sequences (no FASTA parse), %.1f s of CPU work; "
                       "oracle/lash_oracle.c (%s), one task per genome over %d threads (effective cores %d: %d logical, affinity %d, "
-                      "cgroup %s; scan over %s threads)"
-                      % (done, L, algo, k, elapsed, flags, best, eff, prov["logical_cpus"], prov["affinity"], prov["cgroup"], sorted(scan)),
+                      "cgroup %s%s)"
+                      % (done, L, algo, k, elapsed, flags, best, eff, prov["logical_cpus"], prov["affinity"], prov["cgroup"],
+                         ("; scan over %s threads" % sorted(scan)) if scan else ""),
             "parse_inclusive_value": parse_rate,
             "parse_inclusive_sample": "%d passes over %d of those genomes as 80-column FASTA text in memory (%.1f s): needletail-like parse + "
                                       "filter + 2-bit copy + k-mers + sketch per file (utils.rs:452-508), %d threads"
@@ -208,6 +216,26 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
                       "their bucket): the ceiling is that kernel's own stream in tools/ubench_hash ('defer: hmh k16 stream'), the table "
                       "filling as in a 5 Mbp work item")
     rate = kmers_per_launch / (sketch_ms * 1e-3) if sketch_ms > 0 else 0.0
+    # The instruction-mix-weighted ceiling: tools/isa_audit.sh prices the launched kernel's hot blocks from the
+    # compiler's listing with the per-class issue costs tools/ubench_isa measured on the GPU (profiles/r04/isa_cost/costs.json):
+    # sum over classes of count x cost = VALU issue cycles per wave-k-mer; the chip has CUs x 4 SIMDs of them per cycle.
+    mix = None
+    audit = {("hmh", True): "hmh_k16_defer", ("hll", False): "hll_p14_k21", ("ull", False): "ull_p12_k16_reads"}.get((algo, bool(defer)))
+    apath = os.path.join(ROOT, "profiles", "r04", "isa_cost", "%s.json" % audit) if audit else None
+    if direct and apath and os.path.exists(apath) and (algo, k) in (("hmh", 16), ("hll", 21), ("ull", 16)):
+        try:
+            aj = json.load(open(apath))
+            ghz = clock_ghz or 2.4
+            ceil_rate = 256 * 4 * ghz * 1e9 / aj["cycles_per_kmer"] * 64.0
+            mix = {"value": ceil_rate, "unit": "k-mers/s", "frac": rate / ceil_rate if ceil_rate else None,
+                   "cycles_per_wave_kmer": aj["cycles_per_kmer"], "valu_per_kmer_in_listing": aj["valu_per_kmer"], "clock_ghz": ghz,
+                   "clock_source": "tools/ubench_hash (s_memtime / s_memrealtime) in this job" if clock_ghz else "datasheet maximum",
+                   "sections": [{"name": x["name"], "valu_per_kmer": x["valu_per_kmer"], "cycles_per_kmer": x["cycles_per_kmer"]} for x in aj["sections"]],
+                   "source": "profiles/r04/isa_cost/%s.txt (tools/isa_audit.sh: hot blocks of %s from hipcc's listing x the issue costs of "
+                             "profiles/r04/isa_cost/costs.json, measured by tools/ubench_isa at 4 waves per SIMD); per-word and per-tile bookkeeping "
+                             "outside the priced blocks is not in the sum" % (audit, aj["kernel"].replace("void lash::", "").split("(")[0])}
+        except Exception:
+            mix = None
     # the absolute figure beside the self-referential one: wave-instructions issued per second against the chip's issue peak
     # (256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles: MI355X_MICROARCH.md, Execution model) at the clock the
     # ubench run measured in this job (else the 2.4 GHz maximum).  insts_per_kmer is a per-LANE count: SQ_INSTS_VALU / (k-mers / 64).
@@ -219,10 +247,12 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
                     "clock_ghz": clock_ghz or 2.4, "clock_source": "tools/ubench_hash (s_memtime / s_memrealtime) in this job" if clock_ghz else "datasheet maximum",
                     "note": "the remainder is 4-cycle instructions (multiplies, alignbit, 3-operand VOP3) issued at half rate, not idle slots"}
     return {"bound": "valu-issue", "achieved": rate, "peak": floor, "unit": "k-mers/s", "frac": (rate / floor) if floor else None,
-            "insts_per_kmer": per, "insts_source": (vsrc + " — from the committed counter pass, not measured in this run") if vsrc else None,
+            "mix_ceiling": mix, "insts_per_kmer": per, "insts_source": (vsrc + " — from the committed counter pass, not measured in this run") if vsrc else None,
             "peak_source": src, "absolute_issue": absolute, "deferred_signatures": defer_note,
-            "note": "peak = measured ceiling of this instruction stream with no memory traffic (self-referential: it prices the kernel's own "
-                    "instruction mix); absolute_issue = issued wave-instructions against the chip's datasheet issue rate"}
+            "note": "mix_ceiling = chip issue slots / (sum over instruction classes of count x measured issue cost) for the launched kernel "
+                    "variant; peak / frac = the same stream run from registers by tools/ubench_hash (self-referential, kept as the secondary "
+                    "figure); absolute_issue = issued wave-instructions against one per 2 cycles (no VALU mix reaches that: "
+                    "profiles/r04/isa_cost/ubench_isa_w4.txt)"}
 
 
 def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L, G, d_seq, d_rec, goff, rec_off, d_img, ib):
@@ -381,7 +411,8 @@ def main():
     ap.add_argument("--dirty", choices=["none", "nrun", "lower"], default="none",
                     help="nrun: one 100-byte run of N per genome; lower: every other 10 kb block lower-case (soft-masked "
                          "assembly: filter_out_n deletes those bytes, utils.rs:33-41)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU work of the cpu_baseline leg (the oracle on the host cores); the leg also "
+                    "sketches 2 x cores genomes once to warm up and the same genomes as FASTA text for >= 1 s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-ubench", action="store_true", help="do not run tools/ubench_hash for the VALU ceiling (profiler runs: "

@@ -1848,8 +1848,15 @@ hipError_t launch_sketch_stream(const SketchPlan &plan, const SketchArgs &args, 
 // mask_aa_bits (utils.rs:66-76), add_kmer as for nucleotides (utils.rs:395-434).  Proteins are short and many: a LANE walks one
 // record with a rolling register, a workgroup takes a range of a genome's records and shares one sketch in LDS.
 // ------------------------------------------------------------------------------------------------------------
+// Round 4.  The first version gave every lane a stride of records and walked each record in a loop of its own: the lanes of a wave
+// then run in lockstep per RECORD, and a wave is as slow as its longest protein (50..2000 residues: 52 % of the lanes busy on
+// average, tools/aa_rate.py), with a tail where the lanes' totals differ.  Now a lane is a little state machine in ONE loop — 16
+// bytes of its record per trip, or the fetch of its next record — and records are handed out by a counter in LDS (one returning
+// atomic per record), so every lane is busy until the item runs out.  Residue codes come from a 256-byte table in LDS (upper-casing,
+// the 20-letter filter and the code in one ds_read_u8), deleted bytes and the bytes past a record's end simply do not advance the
+// window (no branch), and the register rules run in their 32-bit fast forms with the exact form for the lanes that ask for it.
 template <int ALGO, bool XLOW, int REGS>
-__global__ void __launch_bounds__(256) aa_sketch_kernel(SketchArgs a)
+__global__ void __launch_bounds__(1024) aa_sketch_kernel(SketchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
     const WorkItem it = a.items[blockIdx.x];
@@ -1875,36 +1882,70 @@ __global__ void __launch_bounds__(256) aa_sketch_kernel(SketchArgs a)
         regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;
         census = lds_regs;
     }
-    __syncthreads();
-    const uint64_t kmask = (1ull << (5 * k)) - 1ull;                          // mask_aa_bits, k <= 12
+    // after the census + histogram words (16 + 72): the record counter, then the byte -> code table
+    uint32_t *const next_rec = census + 88;
+    uint8_t *const code_tab = reinterpret_cast<uint8_t *>(census + 92);
     constexpr uint32_t LETTERS = 0x016FBDFDu;                                  // bit i: 'A' + i is one of ACDEFGHIKLMNPQRSTVWY
     const uint32_t base = a.lay.aa_code_base;
+    if (threadIdx.x < 256u) {
+        uint32_t c = threadIdx.x;
+        c &= ~(((c - 0x61u) < 26u) ? 0x20u : 0u);                              // to_ascii_uppercase (utils.rs:43-55)
+        const uint32_t idx = c - 0x41u;
+        const bool letter = idx < 26u && ((LETTERS >> idx) & 1u);              // filter_out_a
+        code_tab[threadIdx.x] = letter ? (uint8_t)((uint32_t)__builtin_popcount(LETTERS & ((1u << idx) - 1u)) + base) : (uint8_t)0xFFu;
+    }
+    if (threadIdx.x == 0) *next_rec = 0u;
+    __syncthreads();
+    const uint64_t kmask = (1ull << (5 * k)) - 1ull;                          // mask_aa_bits, k <= 12
+    const uint32_t kmask_lo = (uint32_t)kmask, kmask_hi = (uint32_t)(kmask >> 32);
+    const BitFlip bitflip = BitFlip::vector(a.bitflip);
+    const uint32_t n_rec = it.word_end - it.word_begin;
+    const uint64_t rec0 = gd.rec_begin + it.word_begin, genome_end = gd.byte_off + gd.byte_len;
     uint32_t my_kmers = 0;
-    for (uint64_t r = gd.rec_begin + it.word_begin + threadIdx.x; r < gd.rec_begin + it.word_end; r += blockDim.x) {
-        const uint64_t b0 = a.rec_off[r], b1 = a.rec_off[r + 1];
-        if (b1 - b0 < (uint64_t)k) continue;                                   // utils.rs:523-525: the raw length
-        uint64_t v = 0;
-        uint32_t have = 0;
-        auto residue = [&](uint32_t c) {
-            c &= ~(((c - 0x61u) < 26u) ? 0x20u : 0u);                          // to_ascii_uppercase
-            const uint32_t idx = c - 0x41u;
-            if (idx >= 26u || !((LETTERS >> idx) & 1u)) return;                // filter_out_a
-            const uint32_t code = (uint32_t)__builtin_popcount(LETTERS & ((1u << idx) - 1u)) + base;
-            v = (v << 5) | code;
-            if (++have >= (uint32_t)k) {
-                const uint64_t m = v & kmask;
-                (void)add_kmer<ALGO, XLOW, false, false>(regs, (uint32_t)m, (uint32_t)(m >> 32), 0xFFFFFFFFu, BitFlip::scalar(a.bitflip), p);
-                ++my_kmers;
+    uint64_t i = 0, b1 = 0;                                                    // this lane's position in its record, the record's end
+    uint32_t v_lo = 0, v_hi = 0, have = 0;
+    bool done = false;
+    for (;;) {
+        if (!done && i >= b1) {                                                // fetch the next record
+            const uint32_t r = __hip_atomic_fetch_add(next_rec, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (r >= n_rec) done = true;
+            else {
+                i = a.rec_off[rec0 + r]; b1 = a.rec_off[rec0 + r + 1];
+                if (b1 - i < (uint64_t)k) i = b1;                              // utils.rs:523-525: the RAW length decides
+                v_lo = v_hi = have = 0;
             }
-        };
-        uint64_t i = b0;
-        for (; i + 16 <= b1; i += 16) {
-            const uint4 q = load16_any(a.seq + i);
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 0; j < 16; ++j) residue((w[j >> 2] >> (8 * (j & 3))) & 0xFFu);
         }
-        for (; i < b1; ++i) residue(a.seq[i]);
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        if (done || i >= b1) continue;
+        const uint32_t n = b1 - i >= 16 ? 16u : (uint32_t)(b1 - i);
+        uint32_t w[4];
+        if (i + 16 <= genome_end) {                                            // (may run into the next record: those bytes are masked)
+            const uint4 q = load16_any(a.seq + i);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        } else {                                                               // the genome's last bytes: never past the caller's buffer
+            w[0] = w[1] = w[2] = w[3] = 0;
+            for (uint32_t j = 0; j < n; ++j) w[j >> 2] |= (uint32_t)a.seq[i + j] << (8 * (j & 3));
+        }
+        i += n;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t code = code_tab[(w[j >> 2] >> (8 * (j & 3))) & 0xFFu];
+            const bool valid = code != 0xFFu && (uint32_t)j < n;               // a deleted byte joins its flanks: the window just does not move
+            if constexpr (ALGO == 0) {
+                v_lo = valid ? (v_lo << 5) | code : v_lo;                      // HyperMinHash hashes (masked as u32): the low word is all it needs
+            } else {
+                const uint32_t nh = alignbit(v_hi, v_lo, 27), nl = (v_lo << 5) | code;
+                v_hi = valid ? nh : v_hi; v_lo = valid ? nl : v_lo;
+            }
+            have += valid ? 1u : 0u;
+            const bool emit = valid && have >= (uint32_t)k;
+            const uint32_t vm = emit ? 0xFFFFFFFFu : 0u;
+            const uint32_t m_lo = v_lo & kmask_lo, m_hi = ALGO == 0 ? 0u : (v_hi & kmask_hi);
+            const uint32_t t = add_kmer<ALGO, XLOW, true, true>(regs, m_lo, m_hi, vm, bitflip, p);
+            constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+            if (t <= Z_REDO) (void)add_kmer<ALGO, XLOW, true, false>(regs, m_lo, m_hi, vm, bitflip, p);   // (rare: the exact form)
+            my_kmers += emit ? 1u : 0u;
+        }
     }
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, wave_sum(my_kmers), p, blockIdx.x);
 }
@@ -1913,11 +1954,12 @@ template <int ALGO, bool XLOW>
 static hipError_t launch_aa_regs(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
 {
     auto go = [&](auto kern) {
-        if (plan.lds_bytes > 48u * 1024u) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+        const uint32_t lds = plan.lds_bytes + 16u + 256u;                       // + the record counter and the byte -> code table
+        if (lds > 48u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(n), dim3(256), plan.lds_bytes, s, args);
+        hipLaunchKernelGGL(kern, dim3(n), dim3(plan.threads), lds, s, args);
         return hipGetLastError();
     };
     if (plan.use_lds && plan.parts_log2) return go(aa_sketch_kernel<ALGO, XLOW, REGS_LDS_PARTS>);

@@ -1,0 +1,27 @@
+#!/bin/bash
+# tools/isa_audit.sh [out_dir] — the issue-cost audit of the three judged sketch kernels: compile
+# sketch_kernels.hip to a listing, price the hot blocks of each kernel with the measured cost table
+# (profiles/r04/isa_cost/costs.json <- tools/ubench_isa on the GPU) and write one text + one JSON file per kernel.
+# The measured figures beside the predictions come from the rocprofv3 passes under profiles/r04/ (cycles = kernel time x clock
+# / wave-k-mers per SIMD; SQ_INSTS_VALU / k-mers x 64).  Runs on the build machine (no GPU needed).
+set -e
+cd "$(dirname "$0")/.."
+OUT=${1:-profiles/r04/isa_cost}; mkdir -p "$OUT"
+S=${LISTING:-/tmp/lash_sketch_kernels.s}
+[ -n "$LISTING" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -S --cuda-device-only -o "$S" lash_amd/csrc/sketch_kernels.hip 2>/dev/null
+M_HMH=${M_HMH:-}; M_HLL=${M_HLL:-}; M_ULL=${M_ULL:-}          # "--measured C --measured-valu V" strings
+# HyperMinHash k = 16, direct, deferring (bench.py's default): the filter's four groups of four k-mers, the drain round
+# (0.028 k-mers pass / 0.64 lanes busy per round = 0.044 rounds per k-mer), the tile's ASCII -> 2-bit conversion
+python3 tools/isa_cost.py "$S" --kernel 'sketch_kernel<0, 0, false, 0, true, false, true>' $M_HMH --json "$OUT/hmh_k16_defer.json" \
+  --section 'filter: window, rank half of xxh3_128, threshold test, append (unmasked)|16|mul==28&bfe_i32==0&ds_write_b32==4' \
+  --section 'drain round: pop + full xxh3_128 + threshold word + ds_min (0.044 rounds per k-mer)|22.7|mul==16&ds_min_u32>=1@first' \
+  --section 'tile: ASCII -> 2-bit words (64 k-mers per lane)|64|perm>=40@first' > "$OUT/hmh_k16_defer.txt"
+# HyperLogLog p = 14, k = 21 (BASELINE configs[2]): the k = 21 word body, the tile's conversion (six chunks)
+python3 tools/isa_cost.py "$S" --kernel 'sketch_kernel<1, 2, false, 0, true, false, false>' $M_HLL --json "$OUT/hll_p14_k21.json" \
+  --section 'word: 16 x (64-bit window k = 21, xxh3_64, rank, ds_max) (unmasked)|16|mul==96&bfe_i32==0&bfe>=16' \
+  --section 'tile: ASCII -> 2-bit words (64 k-mers per lane)|64|perm>=48@first' > "$OUT/hll_p14_k21.txt"
+# UltraLogLog p = 12, k = 16 on reads (configs[4] shape): every tile holds record boundaries -> the masked fast body
+python3 tools/isa_cost.py "$S" --kernel 'sketch_kernel<2, 0, false, 0, true, false, false>' $M_ULL --json "$OUT/ull_p12_k16_reads.json" \
+  --section 'word: 16 x (window, xxh3_64, nlz, ds_or) (masked fast form)|16|mul==96&bfe_i32==16&ffbh==16' \
+  --section 'tile: ASCII -> 2-bit words (64 k-mers per lane)|64|perm>=40@first' > "$OUT/ull_p12_k16_reads.txt"
+for f in "$OUT"/*.txt; do echo "== $f"; tail -n 3 "$f"; done

@@ -18,9 +18,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-VOP2_CHEAP = {"v_xor_b32", "v_and_b32", "v_or_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_lshlrev_b32",
-              "v_ashrrev_i32", "v_min_u32", "v_max_u32", "v_mov_b32", "v_not_b32", "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32",
-              "v_subb_co_u32", "v_cndmask_b32", "v_xnor_b32", "v_min_i32", "v_max_i32"}
+# VOP2 opcodes that tools/ubench_isa measured at double rate with vector / inline / literal sources; v_min / v_max / v_lshlrev /
+# v_cndmask are VOP2 too but run at the full-rate cost and are priced as "vop3"
+VOP2_CHEAP = {"v_xor_b32", "v_and_b32", "v_or_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_mov_b32", "v_not_b32",
+              "v_add_co_u32", "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_xnor_b32"}
 
 
 def operand_kinds(ops):
@@ -143,16 +144,56 @@ def parse_kernels(path):
 
 def block_hist(insts):
     h = collections.Counter()
+    prev = None
     for mn, ops, _ in insts:
-        h[classify(mn, ops)] += 1
+        c = classify(mn, ops)
+        # a v_mov_b32 straight behind a v_mad_u64_u32 rides in the multiply's second pass (ubench_isa "mad + mov alternating")
+        if c.startswith("vop2 v,v") and mn.startswith("v_mov_b32") and prev == "v_mad_u64_u32":
+            c = "v_mov after v_mad_u64_u32"
+        h[c] += 1
+        prev = c
     return h
 
 
-VALU_CLASSES_PREFIX = ("v", )
+def signature(insts):
+    """What tells the blocks of a kernel apart without naming labels (they move with every compile)."""
+    sig = collections.Counter()
+    for mn, ops, _ in insts:
+        b = mn
+        for suf in ("_e32", "_e64", "_sdwa", "_dpp"):
+            if b.endswith(suf):
+                b = b[: -len(suf)]
+        sig["n"] += 1
+        if b in ("v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32"):
+            sig["mul"] += 1
+        if b in ("v_bfe_i32", "v_bfe_u32", "v_perm_b32", "v_ffbh_u32", "v_cmp_lt_u64", "ds_min_u32", "ds_max_i32", "ds_or_b32", "ds_read_b32", "ds_write_b32", "v_alignbit_b32"):
+            sig[b.replace("v_", "").replace("_b32", "").replace("_u32", "").replace("_i32", "_i32") if not b.startswith("ds_") else b] += 1
+    return sig
 
 
 def is_valu(cls):
     return cls.startswith("v") and cls != "vmem"
+
+
+def select(blocks, expr):
+    """expr: 'mul==28&bfe_i32==0' over signature() fields; optional '@first' / '@N' keeps the first (N) matches."""
+    keep = None
+    if "@" in expr:
+        expr, k = expr.split("@")
+        keep = 1 if k == "first" else int(k)
+    out = []
+    for label, insts in blocks:
+        sig = signature(insts)
+        ok = True
+        for term in expr.split("&"):
+            m = re.match(r"^(\w+)(==|>=|<=)(\d+)$", term.strip())
+            if not m:
+                sys.exit("bad selector term: " + term)
+            v, op, n = sig[m.group(1)], m.group(2), int(m.group(3))
+            ok = ok and ((op == "==" and v == n) or (op == ">=" and v >= n) or (op == "<=" and v <= n))
+        if ok:
+            out.append(label)
+    return out[:keep] if keep else out
 
 
 def main():
@@ -160,11 +201,14 @@ def main():
     ap.add_argument("listing")
     ap.add_argument("--kernel", required=True, help="substring of the demangled kernel name")
     ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r04", "isa_cost", "costs.json"))
-    ap.add_argument("--blocks", action="store_true", help="list every basic block with its size and multiply count")
-    ap.add_argument("--hot", default=None, help="comma-separated block labels to price (default: chosen automatically)")
-    ap.add_argument("--kmers-per-block", type=int, default=None)
-    ap.add_argument("--dump", action="store_true", help="print the instructions of the hot blocks with their classes")
+    ap.add_argument("--blocks", action="store_true", help="list every basic block with its signature")
+    ap.add_argument("--section", action="append", default=[], metavar="NAME|KMERS|SELECT",
+                    help="price the blocks SELECT picks as one section that covers KMERS k-mers per lane (a float: 0.044 rounds per k-mer "
+                         "is KMERS = 1 / 0.044); repeatable")
+    ap.add_argument("--dump", action="store_true", help="print the instructions of the selected blocks with their classes")
     ap.add_argument("--measured", type=float, default=None, help="measured cycles per wave-k-mer, printed beside the prediction")
+    ap.add_argument("--measured-valu", type=float, default=None, help="measured SQ_INSTS_VALU per k-mer (per lane)")
+    ap.add_argument("--json", default=None)
     args = ap.parse_args()
     ks = parse_kernels(args.listing)
     match = [n for n in ks if args.kernel in n]
@@ -172,52 +216,50 @@ def main():
         sys.exit("kernel name matches %d functions: %s" % (len(match), match[:8]))
     blocks = ks[match[0]]
     print("kernel:", match[0])
-    info = []
-    for label, insts in blocks:
-        h = block_hist(insts)
-        info.append((label, len(insts), h["v_mad_u64_u32"] + h["v_mul32"], h))
     if args.blocks:
-        for label, n, muls, h in info:
-            if n >= 20:
-                print("%-14s %5d instr  %3d multiplies  valu %4d  bfe_i32 %d" % (label, n, muls, sum(c for k, c in h.items() if is_valu(k)),
-                                                                                    sum(1 for mn, _, _ in dict(blocks)[label] if mn.startswith("v_bfe_i32"))))
-    costs = {}
-    if os.path.exists(args.costs):
-        costs = json.load(open(args.costs))["cycles"]
-    if args.hot:
-        hot = args.hot.split(",")
-    else:
-        # the unmasked per-word bodies: blocks with many multiplies and no v_bfe_i32 (the masked bodies extract 16 mask bits);
-        # blocks of one straight-line word body have equal multiply counts — take the largest group
-        cand = [(label, muls) for label, n, muls, h in info if muls >= 16 and not any(mn.startswith("v_bfe_i32") for mn, _, _ in dict(blocks)[label])]
-        hot = [c[0] for c in cand]
+        for label, insts in blocks:
+            sig = signature(insts)
+            if sig["n"] >= 20:
+                print("%-14s %s" % (label, " ".join("%s=%d" % kv for kv in sorted(sig.items()))))
+    costs = json.load(open(args.costs))["cycles"] if os.path.exists(args.costs) else {}
     bd = dict(blocks)
-    total = collections.Counter()
-    for label in hot:
-        total += block_hist(bd[label])
-    print("hot blocks:", ", ".join("%s(%d)" % (l, len(bd[l])) for l in hot))
-    if args.dump:
-        for label in hot:
-            print("--", label)
-            for mn, ops, raw in bd[label]:
-                print("   %-24s %s" % (classify(mn, ops), raw))
-    nk = args.kmers_per_block
-    if nk is None:
-        nk = 16
-    print("k-mers priced over: %d" % nk)
-    tot_cycles, tot_valu = 0.0, 0
-    print("%-26s %7s %9s %8s %10s" % ("class", "count", "per k-mer", "cycles", "cyc/k-mer"))
-    for cls, cnt in sorted(total.items(), key=lambda kv: -kv[1]):
-        c = costs.get(cls)
-        cyc = cnt * c / nk if c is not None else None
-        if cyc is not None and (is_valu(cls)):
-            tot_cycles += cyc
-        if is_valu(cls):
-            tot_valu += cnt
-        print("%-26s %7d %9.2f %8s %10s" % (cls, cnt, cnt / nk, "%.2f" % c if c is not None else "-", "%.1f" % cyc if cyc is not None else "-"))
-    print("VALU wave-instructions per k-mer: %.2f" % (tot_valu / nk))
-    if costs:
-        print("predicted VALU issue cycles per wave-k-mer: %.1f%s" % (tot_cycles, ("   measured: %.1f  (ratio %.2f)" % (args.measured, tot_cycles / args.measured)) if args.measured else ""))
+    grand_c, grand_v, out_sections = 0.0, 0.0, []
+    for spec in args.section:
+        name, kmers, sel = spec.split("|")
+        kmers = float(kmers)
+        labels = select(blocks, sel)
+        total = collections.Counter()
+        for l in labels:
+            total += block_hist(bd[l])
+        print("\n== %s  [%s -> %d block(s): %s; %.4g k-mers per lane]" % (name, sel, len(labels), ", ".join("%s(%d)" % (l, len(bd[l])) for l in labels), kmers))
+        if args.dump:
+            for l in labels:
+                print("--", l)
+                for mn, ops, raw in bd[l]:
+                    print("   %-28s %s" % (classify(mn, ops), raw))
+        print("%-30s %7s %9s %8s %10s" % ("class", "count", "per k-mer", "cycles", "cyc/k-mer"))
+        sec_c, sec_v = 0.0, 0.0
+        for cls, cnt in sorted(total.items(), key=lambda kv: -kv[1]):
+            c = costs.get(cls)
+            cyc = cnt * c / kmers if (c is not None and is_valu(cls)) else None
+            if is_valu(cls):
+                sec_v += cnt / kmers
+                if cyc is None:
+                    print("   (no cost for class %r)" % cls)
+                else:
+                    sec_c += cyc
+            print("%-30s %7d %9.3f %8s %10s" % (cls, cnt, cnt / kmers, ("%.2f" % c) if (c is not None and is_valu(cls)) else "-", ("%.2f" % cyc) if cyc is not None else "-"))
+        print("%-30s %7s %9.3f %8s %10.2f" % ("section: VALU", "", sec_v, "", sec_c))
+        grand_c += sec_c
+        grand_v += sec_v
+        out_sections.append({"name": name, "select": sel, "blocks": len(labels), "kmers_per_lane": kmers, "valu_per_kmer": sec_v, "cycles_per_kmer": sec_c})
+    if args.section:
+        print("\nVALU wave-instructions per k-mer, sections together: %.2f%s" % (grand_v, ("   measured (SQ_INSTS_VALU): %.2f" % args.measured_valu) if args.measured_valu else ""))
+        print("predicted VALU issue cycles per wave-k-mer: %.1f%s" % (grand_c, ("   measured: %.1f  (predicted / measured %.2f)" % (args.measured, grand_c / args.measured)) if args.measured else ""))
+    if args.json:
+        json.dump({"kernel": match[0], "listing": os.path.basename(args.listing), "costs": os.path.relpath(args.costs, ROOT), "sections": out_sections,
+                   "valu_per_kmer": grand_v, "cycles_per_kmer": grand_c, "measured_cycles_per_kmer": args.measured,
+                   "measured_valu_per_kmer": args.measured_valu}, open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
