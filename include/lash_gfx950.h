@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LASH_ABI_VERSION 3
+#define LASH_ABI_VERSION 4
 
 /* error codes */
 #define LASH_OK       0
@@ -216,6 +216,17 @@ uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t ca
  * the genomes of the LAST HyperLogLog sketch call that are in that corner (indices into that call's genomes; returns how many,
  * writes at most `cap`).  tests/test_gpu_hll_corner.py holds k-mers that reach it. */
 uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32_t cap);
+/* Round 4: the corner is closed for per-genome sketches.  For a flagged genome the library finds the k-mer(s) that put a register
+ * above 53 - p by a binary search over PREFIXES of the genome's records (each probe an ordinary sketch call), takes the incremental
+ * sum up to there from the prefix's own (exact) header, performs that k-mer's `sum -= 2^-old; sum += 2^-new` in IEEE double as
+ * the crate does, and adds the exact net change of the steps that follow: the 8 bytes then equal the oracle's
+ * (tests/test_gpu_hll_corner.py asserts byte equality).  lash_sketch_batch and lash_sketch_files_raw do this themselves before they
+ * return (lash_ctx_hll_inexact_sums() then reports nothing); after lash_sketch_batch_device / _async call this with the same
+ * arguments once the caller may wait: it synchronizes, patches `sum` in d_images and clears the report.  What stays flagged:
+ * calls with LASH_F_ACCUMULATE (the registers already in the image are not the library's to replay — the CLI's streamed chunks
+ * of one huge file) and the raw-bytes device entry.  ~25 small sketch calls per flagged genome, i.e. nothing on average. */
+int lash_hll_replay_sums_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
+                                const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *d_images);
 /* Host-side twin of the device checks (what the library itself runs on a flagged file; the `lash` CLI no longer pre-validates —
  * it hands the bytes over and reads lash_ctx_format_errors): the length of the longest prefix of `buf` that is a sequence of
  * well-formed records — '@' header, sequence, '+' line, quality of EQUAL length (CR stripped); the last record may lack its

@@ -13,7 +13,7 @@ OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE, EFORMAT = 0, -1, -2, -3, -4, -
 HMH, HLL, ULL = 0, 1, 2
 F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT, F_AMINO, F_STREAM_ONLY = 1, 2, 4, 8, 16
 FMT_FASTA, FMT_FASTQ = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Params(C.Structure):
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "lash_sketch_files_raw": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
     "lash_sketch_files_raw_device": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
     "lash_ctx_format_errors": (_u32, [_vp, _vp, _u32]),
+    "lash_hll_replay_sums_device": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),
     "lash_ctx_hll_inexact_sums": (_u32, [_vp, _vp, _u32]),
     "lash_fastq_valid_prefix": (_u64, [_vp, _u64]),
     "lash_fastq_neutralise_tail": (None, [_vp, _u64]),

@@ -404,6 +404,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     sa.k = prm->k;
     sa.p = prm->p;
     ctx->hll_flags_n = 0;
+    ctx->hll_flags_on_host = false;
     if (prm->algo == LASH_HLL) {                                // which genomes end with a register above 53 - p (write_hll_header)
         if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
@@ -552,6 +553,7 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     sa.k = prm->k;
     sa.p = prm->p;
     ctx->hll_flags_n = 0;
+    ctx->hll_flags_on_host = false;
     if (prm->algo == LASH_HLL) {
         if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
         HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
@@ -597,6 +599,135 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
 }  // namespace
 
 // ===============================================================================================================
+
+// ---- HyperLogLog: the incremental `sum` of genomes in the > 53 - p corner, replayed -------------------------------------------
+// streaming_algorithms keeps `sum` per k-mer: sum -= 2^-old; sum += 2^-new (utils.rs:411-413 -> push_hash64).
+// Every such pair is exact in f64 — the terms are multiples of 2^(p-53) and the sum only falls — except where a term BELOW that
+// grid is involved: the k-mer that lifts a register above 53 - p (one in 2^(52-p)), or one that later overwrites such a register.
+// There the result depends on the value `sum` had at that moment, i.e. on the registers of the genome's PREFIX.  So:
+//   * the registers of the final image name the buckets above 53 - p;
+//   * a bucket's value in the sketch of a prefix is monotone in the prefix length: a binary search over cut positions — each probe
+//     one ordinary sketch call on the records cut at that byte — finds the k-mer that did it (prefixes are cut by BYTES, so
+//     deleted bytes, records and k-mer order need no special care: a k-mer belongs to a prefix iff its last base does);
+//   * the sketch of the prefix just before it carries the incremental sum up to there (no sub-grid term yet: its header IS
+//     exact) and the register's old value; the two f64 operations of that k-mer are then done here, on the host, in IEEE double;
+//   * from there to the genome's end (or the next such k-mer) every step is exact, so the net change is the difference of the
+//     on-grid parts of the two register states — one more exact addition.
+// Returns the number of genomes redone; `left` lists those it had to leave (accumulating calls hold registers the replay cannot
+// see).  Synchronous; runs ~25 small sketch calls per flagged genome (one genome in ~10^4 at p = 14).
+static double grid_sum(const uint8_t *regs, size_t m, int p)
+{
+    uint32_t hist[72] = {0};
+    for (size_t i = 0; i < m; ++i) ++hist[regs[i] < 71 ? regs[i] : 71];
+    double s = 0.0;                                                // multiples of 2^(p-53) below 2^p: exact in any order
+    for (int r = 0; r <= 53 - p; ++r) s += (double)hist[r] * ldexp(1.0, -r);
+    return s;
+}
+static int hll_sum_field_offset(const lash_layout &lay)
+{
+    const char *t = header_tpl(lay, LASH_HLL);
+    int at = 0;
+    for (int i = 0; i < 8 && t[i]; ++i) {
+        switch (t[i]) {
+        case 's': return at;
+        case 'a': case 'z': case 'Q': case 'l': at += 8; break;
+        case 'Z': case 'P': case 'L': at += 4; break;
+        case 'p': at += 1; break;
+        default: break;
+        }
+    }
+    return -1;
+}
+
+static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t *d_seq, const uint64_t *d_rec_off, const uint64_t *h_rec_off,
+                           const uint64_t *genome_rec_off, uint8_t *d_images, uint8_t *h_images, const std::vector<uint32_t> &flagged,
+                           std::vector<uint32_t> &left)
+{
+    left.clear();
+    if (flagged.empty()) return LASH_OK;
+    const int p = prm0->p, sum_at = hll_sum_field_offset(ctx->layout);
+    const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p, ib = hdr + m;
+    if (sum_at < 0 || (prm0->flags & (LASH_F_ACCUMULATE | LASH_F_AMINO))) { left = flagged; return LASH_OK; }
+    lash_params prm = *prm0;
+    const lash_timing saved = ctx->last;
+    const bool timing = ctx->timing;
+    ctx->timing = false;
+    int rc = LASH_OK;
+    if ((rc = reserve(ctx, ctx->replay_img, ib + 64))) return rc;
+    std::vector<uint8_t> fin(ib), before(ib), probe(ib);
+    for (uint32_t g : flagged) {
+        const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], nr = r1 - r0;
+        std::vector<uint64_t> rec(nr + 1);
+        if (h_rec_off) memcpy(rec.data(), h_rec_off + r0, (nr + 1) * 8);
+        else HIPCHK(ctx, hipMemcpy(rec.data(), d_rec_off + r0, (nr + 1) * 8, hipMemcpyDeviceToHost));
+        if (h_images) memcpy(fin.data(), h_images + (size_t)g * ib, ib);
+        else HIPCHK(ctx, hipMemcpy(fin.data(), d_images + (size_t)g * ib, ib, hipMemcpyDeviceToHost));
+        if ((rc = reserve(ctx, ctx->replay_rec, (nr + 2) * 8))) break;
+        // the sketch of the genome's records cut at byte `cut` (absolute offset into d_seq) -> out
+        auto prefix = [&](uint64_t cut, std::vector<uint8_t> &out) -> int {
+            size_t i = (size_t)(std::upper_bound(rec.begin(), rec.end(), cut) - rec.begin());   // records [0, i-1) lie wholly before the cut
+            if (i == 0) i = 1;
+            std::vector<uint64_t> pr(rec.begin(), rec.begin() + i);
+            if (pr.back() < cut) pr.push_back(cut);                                             // the record the cut falls into, truncated
+            const uint64_t n = pr.size() - 1, goff[2] = {0, n}, gbo[2] = {pr.front(), pr.back()};
+            HIPCHK(ctx, hipMemcpy(ctx->replay_rec.ptr, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
+            int r = lash_sketch_batch_device(ctx, &prm, d_seq, static_cast<const uint64_t *>(ctx->replay_rec.ptr), n, goff, gbo, 1,
+                                             static_cast<uint8_t *>(ctx->replay_img.ptr));
+            if (r) return r;
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipMemcpy(out.data(), ctx->replay_img.ptr, ib, hipMemcpyDeviceToHost));
+            return LASH_OK;
+        };
+        struct Event { uint64_t cut; uint32_t j; uint8_t neu, old; std::vector<uint8_t> before; };
+        std::vector<Event> events;
+        std::vector<std::pair<uint32_t, uint8_t>> todo;             // (bucket, value above the grid) whose k-mer is to be found
+        for (size_t j = 0; j < m; ++j)
+            if (fin[hdr + j] > 53 - p) todo.push_back({(uint32_t)j, fin[hdr + j]});
+        bool ok = true;
+        while (!todo.empty() && ok) {
+            const auto [j, val] = todo.back();
+            todo.pop_back();
+            uint64_t lo = rec.front(), hi = rec.back();            // prefix(lo) lacks the value, prefix(hi) has it
+            while (hi - lo > 1 && ok) {
+                const uint64_t mid = lo + (hi - lo) / 2;
+                if ((rc = prefix(mid, probe))) { ok = false; break; }
+                if (probe[hdr + j] >= val) hi = mid; else lo = mid;
+            }
+            if (!ok) break;
+            Event e;
+            e.cut = hi; e.j = j; e.neu = val; e.before.resize(ib);
+            if ((rc = prefix(hi - 1, e.before))) { ok = false; break; }
+            e.old = e.before[hdr + j];
+            if (e.old > 53 - p) todo.push_back({j, e.old});         // an earlier k-mer had already put this bucket above the grid
+            events.push_back(std::move(e));
+        }
+        if (!ok) break;
+        std::sort(events.begin(), events.end(), [](const Event &a, const Event &b) { return a.cut < b.cut; });
+        double S;
+        memcpy(&S, events[0].before.data() + sum_at, 8);            // exact up to the first such k-mer
+        double grid_after = 0.0;
+        for (size_t i = 0; i < events.size(); ++i) {
+            const Event &e = events[i];
+            if (i) S += grid_sum(e.before.data() + hdr, m, p) - grid_after;      // exact steps in between: their net change
+            S -= ldexp(1.0, -(int)e.old);                           // the k-mer's own two operations, rounded as the crate's are
+            S += ldexp(1.0, -(int)e.neu);
+            std::vector<uint8_t> after(e.before.begin() + hdr, e.before.end());
+            after[e.j] = e.neu;
+            grid_after = grid_sum(after.data(), m, p);
+        }
+        S += grid_sum(fin.data() + hdr, m, p) - grid_after;
+        if (h_images) memcpy(h_images + (size_t)g * ib + sum_at, &S, 8);
+        if (d_images) HIPCHK(ctx, hipMemcpy(d_images + (size_t)g * ib + sum_at, &S, 8, hipMemcpyHostToDevice));
+    }
+    ctx->last = saved;
+    ctx->timing = timing;
+    if (rc) return rc;
+    ctx->hll_flags_n = 0;
+    ctx->hll_flags_on_host = true;
+    ctx->hll_left = left;
+    return LASH_OK;
+}
+
 extern "C" {
 
 int lash_abi_version(void) { return LASH_ABI_VERSION; }
@@ -1050,12 +1181,45 @@ int lash_sketch_batch_async(lash_ctx *ctx, const lash_params *prm, const uint8_t
     return LASH_OK;
 }
 
+static std::vector<uint32_t> hll_flagged(lash_ctx *ctx)
+{
+    std::vector<uint32_t> idx(lash_ctx_hll_inexact_sums(ctx, nullptr, 0));
+    if (!idx.empty()) lash_ctx_hll_inexact_sums(ctx, idx.data(), (uint32_t)idx.size());
+    return idx;
+}
+
 int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
                       const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images)
 {
-    const int rc = lash_sketch_batch_async(ctx, prm, seq, rec_off, n_rec, genome_rec_off, n_genomes, out_images);
+    int rc = lash_sketch_batch_async(ctx, prm, seq, rec_off, n_rec, genome_rec_off, n_genomes, out_images);
     if (rc) return rc;
-    return lash_ctx_synchronize(ctx);
+    if ((rc = lash_ctx_synchronize(ctx))) return rc;
+    if (prm->algo == LASH_HLL && n_genomes && !(prm->flags & LASH_F_AMINO)) {
+        // genomes with a register above 53 - p: their `sum` as the reference's incremental rule leaves it (hll_replay_sums)
+        const std::vector<uint32_t> flagged = hll_flagged(ctx);
+        if (!flagged.empty()) {
+            const lash_ctx::AsyncSlot &sl = ctx->slot[(ctx->slot_next - 1u) & 1u];           // this call's device copies
+            std::vector<uint32_t> left;
+            rc = hll_replay_sums(ctx, prm, static_cast<const uint8_t *>(sl.seq.ptr), static_cast<const uint64_t *>(sl.rec.ptr), rec_off,
+                                 genome_rec_off, static_cast<uint8_t *>(sl.img.ptr), out_images, flagged, left);
+        }
+    }
+    return rc;
+}
+
+int lash_hll_replay_sums_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
+                                const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *d_images)
+{
+    (void)n_rec;
+    if (!ctx || !prm || !genome_rec_off || (n_genomes && !d_images)) return LASH_EINVAL;
+    if (prm->algo != LASH_HLL) return LASH_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->hll_flags_on_host) return LASH_OK;                     // already done for this call
+    if (ctx->hll_flags_n != n_genomes) return LASH_EINVAL;          // not the arguments of the last HyperLogLog call
+    const std::vector<uint32_t> flagged = hll_flagged(ctx);          // (synchronizes the stream)
+    std::vector<uint32_t> left;
+    if (flagged.empty()) { ctx->hll_flags_on_host = true; ctx->hll_left.clear(); return LASH_OK; }
+    return hll_replay_sums(ctx, prm, d_seq, d_rec_off, nullptr, genome_rec_off, d_images, nullptr, flagged, left);
 }
 
 int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_raw, const uint64_t *file_off,
@@ -1088,6 +1252,10 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
 
 uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32_t cap)
 {
+    if (ctx && ctx->hll_flags_on_host) {                          // a replay has run: what it could not redo
+        for (uint32_t i = 0; i < ctx->hll_left.size() && i < cap && genome_index; ++i) genome_index[i] = ctx->hll_left[i];
+        return (uint32_t)ctx->hll_left.size();
+    }
     if (!ctx || !ctx->hll_flags_n || !ctx->hll_flags.ptr) return 0;
     (void)hipSetDevice(ctx->device);
     std::vector<uint32_t> fl(ctx->hll_flags_n);
@@ -1253,7 +1421,14 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     for (const lash_packed *pk : ctx->last_packed)
         if ((rc = check_pack_flag(ctx, pk))) return rc;
     if ((rc = read_format_errors(ctx))) return rc;
-    const std::vector<uint32_t> bad = ctx->bad_files;
+    std::vector<uint32_t> bad = ctx->bad_files;
+    const size_t n_malformed = bad.size();
+    if (prm->algo == LASH_HLL && !(prm->flags & LASH_F_ACCUMULATE)) {
+        // files with a register above 53 - p go the same way as the malformed ones — host parse, record entry — which replays
+        // their incremental `sum` (hll_replay_sums): one file in ~10^4 at p = 14
+        for (uint32_t g : hll_flagged(ctx))
+            if (std::find(bad.begin(), bad.end(), g) == bad.end()) bad.push_back(g);
+    }
     if (bad.empty()) {
         if (img_bytes) HIPCHK(ctx, hipMemcpy(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost));
         return LASH_OK;
@@ -1277,7 +1452,11 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
         rc = lash_sketch_batch(ctx, prm, seq.empty() ? &dummy : seq.data(), rec_off.data(), rec_off.size() - 1, goff, 1, out_images + (size_t)g * ib);
         if (rc) return rc;
     }
+    bad.resize(n_malformed);
     ctx->bad_files = bad;                                          // still reported (the host may want to stop streaming this file)
+    ctx->hll_flags_n = 0;                                          // (the files in the corner have been redone exactly)
+    ctx->hll_flags_on_host = true;
+    ctx->hll_left.clear();
     return LASH_OK;
 }
 

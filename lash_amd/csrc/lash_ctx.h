@@ -150,6 +150,9 @@ struct lash_ctx {
     std::vector<double> ec_qry_cards;    // the small query cardinalities whose vectors ec_qry holds (reused across row blocks)
     DevBuf hll_flags;                    // [hll_flags_n] per genome of the last HyperLogLog sketch call: a register > 53 - p
     uint32_t hll_flags_n = 0;            // (lash_ctx_hll_inexact_sums)
+    bool hll_flags_on_host = false;      // the list below stands for the flags (hll_replay_sums has dealt with the others)
+    std::vector<uint32_t> hll_left;      // genomes of the last call still in the corner after the replay
+    DevBuf replay_rec, replay_img;       // hll_replay_sums: record offsets and image of a prefix sketch
     std::vector<uint32_t> bad_files;     // lash_ctx_format_errors(): files of the last raw call whose FASTQ structure broke
     uint32_t raw_files_pending = 0;      // files of a lash_sketch_files_raw_device call whose error flags have not been read yet
     // direct-mode feedback: the dirty-tile count of the last direct call comes back through a pinned word, is looked at

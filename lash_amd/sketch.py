@@ -334,6 +334,14 @@ class Context:
         self._lib.lash_ctx_hll_inexact_sums(self._h, idx, n)
         return [int(idx[i]) for i in range(n)]
 
+    def hll_replay_sums_device(self, k, p, seed, d_seq, d_rec_off, n_rec, genome_rec_off, d_images, flags=0):
+        """After sketch_batch_device("hll", ...) with the same arguments: the genomes hll_inexact_sums() lists get the `sum` the
+        reference's incremental rule leaves (include/lash_gfx950.h: lash_hll_replay_sums_device); synchronizes."""
+        prm = self._params("hll", k, p, seed, flags)
+        goff = np.ascontiguousarray(genome_rec_off, dtype=np.uint64)
+        self._check(self._lib.lash_hll_replay_sums_device(self._h, C.byref(prm), _ptr(d_seq), _ptr(d_rec_off), int(n_rec),
+                                                          goff.ctypes.data_as(C.c_void_p), len(goff) - 1, _ptr(d_images)))
+
     def sketch_batch_device(self, algo, k, p, seed, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, d_out,
                             flags=0):
         """Device-resident records in, device images out; asynchronous on the context's stream."""

@@ -7,9 +7,11 @@ gets there turns up once per 2^(52-p) hashes; tools/find_hll_corner.py found the
 (seed 42, k = 21; profiles/r02/hll_corner_kmers.txt).  What is asserted here:
   * the oracle (which restates the incremental rule) agrees these k-mers have rank 38..40;
   * registers, `zero` and every byte outside `sum` are identical between the HIP path and the oracle, on every route;
-  * the HIP path's `sum` is the correctly rounded exact sum, the genome is reported, clean genomes are not;
+  * the kernels' `sum` is the correctly rounded exact sum, the genome is reported, clean genomes are not;
   * the divergence is real (a case where the oracle's incremental value differs is pinned) and bounded by the sub-grid
-    terms themselves: < 2^(p-52) absolute, ~1e-14 relative."""
+    terms themselves: < 2^(p-52) absolute, ~1e-14 relative;
+  * round 4: the REPLAY (lash_hll_replay_sums_device; built into lash_sketch_batch and lash_sketch_files_raw) turns the 8 bytes into
+    the oracle's — whole images byte-identical in the corner too; only accumulating calls stay flagged."""
 import struct
 from fractions import Fraction
 
@@ -47,7 +49,11 @@ def test_corner_kmers_reach_the_stated_rank_in_the_oracle():
 @pytest.mark.parametrize("p", [14, 16])
 @pytest.mark.parametrize("where", ["first", "middle"])
 @pytest.mark.parametrize("size", [30_000, 3_000_000])          # one work item writes the image / slices + finalize
-def test_corner_genomes_match_the_oracle_outside_sum_and_are_reported(p, where, size):
+def test_corner_genomes_are_detected_and_their_sum_is_replayed(p, where, size):
+    """Round 4: byte equality with the oracle IN the corner.  The device entry alone writes the correctly rounded
+    exact sum and reports the genomes (as before); lash_hll_replay_sums_device then gives those genomes the reference's incremental
+    value; the host entry lash_sketch_batch does both before it returns."""
+    import torch
     import lash_amd
     kms = [km for km, rho in CORNER.items() if rho > 53 - p]
     assert kms
@@ -62,10 +68,15 @@ def test_corner_genomes_match_the_oracle_outside_sum_and_are_reported(p, where, 
     recs = [[g.tobytes()] for g in genomes]
     seq, off, goff = lash_amd.records_to_arrays(recs)
     want = np.stack([_oracle(p, g) for g in genomes])
+    ib = want.shape[1]
     with lash_amd.Context(0) as ctx:
+        d_seq, d_off = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        gbo = off[goff.astype(np.int64)]
         for flags in (0, lash_amd.F_NO_DIRECT):
-            got = ctx.sketch_batch("hll", 21, p, 42, seq, off, goff, flags=flags)
+            d_img = torch.zeros(len(genomes) * ib, dtype=torch.uint8, device="cuda")
+            ctx.sketch_batch_device("hll", 21, p, 42, d_seq, d_off, len(off) - 1, goff, gbo, d_img, flags=flags)
             assert ctx.hll_inexact_sums() == corner_idx
+            got = d_img.cpu().numpy().reshape(len(genomes), ib)
             assert np.array_equal(got[:, :16], want[:, :16]) and np.array_equal(got[:, 24:], want[:, 24:])   # all but `sum`
             for i in range(len(genomes)):
                 gs = struct.unpack("<d", got[i, 16:24].tobytes())[0]
@@ -75,6 +86,19 @@ def test_corner_genomes_match_the_oracle_outside_sum_and_are_reported(p, where, 
                     assert gs == ws                                                             # outside the corner: bit-identical
                 else:
                     assert abs(gs - ws) <= 2.0 ** -(52 - p)              # at most the few terms that sit below the 2^(p-53) grid
+            ctx.hll_replay_sums_device(21, p, 42, d_seq, d_off, len(off) - 1, goff, d_img, flags=flags)
+            assert ctx.hll_inexact_sums() == []
+            assert np.array_equal(d_img.cpu().numpy().reshape(len(genomes), ib), want), "replayed sums != the oracle's incremental sums"
+            # the host entry does it by itself
+            got = ctx.sketch_batch("hll", 21, p, 42, seq, off, goff, flags=flags)
+            assert ctx.hll_inexact_sums() == [] and np.array_equal(got, want)
+        # an accumulating call cannot be replayed (the registers already in the image are not this call's): still reported
+        half = [[g.tobytes()[:len(g) // 2], g.tobytes()[len(g) // 2:]] for g in genomes]
+        s1, o1, g1 = lash_amd.records_to_arrays([[h[0]] for h in half])
+        s2, o2, g2 = lash_amd.records_to_arrays([[h[1]] for h in half])
+        acc = ctx.sketch_batch("hll", 21, p, 42, s1, o1, g1)
+        acc = ctx.sketch_batch("hll", 21, p, 42, s2, o2, g2, flags=lash_amd.F_ACCUMULATE, out=acc)
+        assert set(ctx.hll_inexact_sums()) <= set(corner_idx)
         # a call without such genomes reports nothing
         s2, o2, g2 = lash_amd.records_to_arrays([[genomes[-1].tobytes()]])
         ctx.sketch_batch("hll", 21, p, 42, s2, o2, g2)
@@ -83,35 +107,64 @@ def test_corner_genomes_match_the_oracle_outside_sum_and_are_reported(p, where, 
         assert ctx.hll_inexact_sums() == []
 
 
-def test_the_divergence_is_real():
+def test_replay_with_records_deleted_bytes_and_two_corner_kmers():
+    """The replay cuts prefixes by BYTES: records, deleted bytes (N, lower case) and several corner k-mers in one genome — two in
+    different buckets, and the same one twice — need nothing special."""
+    import lash_amd
+    p = 14
+    kms = [np.frombuffer(km.encode(), np.uint8) for km, rho in CORNER.items() if rho > 53 - p]
+    a, b, c = O.synth_genome(960, 400_000), O.synth_genome(961, 250_000), O.synth_genome(962, 120_000)
+    b = b.copy(); b[1000:1300] = ord("N"); b[50_000:50_400] |= 0x20
+    recs = [[a[:100_000].tobytes() + kms[0].tobytes() + a[100_000:].tobytes(), b"ACGT", b.tobytes()[:200_000] + kms[1].tobytes() + b"NN" + b.tobytes()[200_000:],
+             c.tobytes() + kms[0].tobytes()],
+            [O.synth_genome(963, 50_000).tobytes()]]
+    seq, off, goff = lash_amd.records_to_arrays(recs)
+    want = O.sketch_genomes(O.HLL, 21, p, 42, seq, off, goff)
+    with lash_amd.Context(0) as ctx:
+        got = ctx.sketch_batch("hll", 21, p, 42, seq, off, goff)
+        assert ctx.hll_inexact_sums() == []
+    assert np.array_equal(got, want)
+
+
+def test_the_divergence_is_real_and_the_replay_closes_it():
     """p = 14, the rank-40 k-mer first: the reference's first update is 16383 + 2^-40, a tie that rounds to even and drops the
-    term; 300 kbp later the sum is ~650 and 2^-40 is representable, so the exact sum (what the HIP path writes) has it."""
+    term; 300 kbp later the sum is ~650 and 2^-40 is representable, so the exact sum (what the kernels write) has it — and the
+    replayed value does not, like the reference's."""
+    import torch
     import lash_amd
     g = np.concatenate([np.frombuffer(b"CTGAGTGTGTCAGGCGTCATT", np.uint8), O.synth_genome(5, 300_000)])
     want = _oracle(14, g)
     seq, off, goff = lash_amd.records_to_arrays([[g.tobytes()]])
     with lash_amd.Context(0) as ctx:
-        got = ctx.sketch_batch("hll", 21, 14, 42, seq, off, goff)
+        d_seq, d_off = torch.from_numpy(seq).cuda(), torch.from_numpy(off.astype(np.int64)).cuda()
+        d_img = torch.zeros(len(want), dtype=torch.uint8, device="cuda")
+        ctx.sketch_batch_device("hll", 21, 14, 42, d_seq, d_off, 1, goff, off[goff.astype(np.int64)], d_img)
         assert ctx.hll_inexact_sums() == [0]
-    gs = struct.unpack("<d", got[0, 16:24].tobytes())[0]
-    ws = struct.unpack("<d", want[16:24].tobytes())[0]
-    assert gs == _exact_sum(got[0, 33:]) and gs - ws == 2.0 ** -40
-    assert np.array_equal(got[0, 24:], want[24:]) and np.array_equal(got[0, :16], want[:16])
+        got = d_img.cpu().numpy()
+        gs = struct.unpack("<d", got[16:24].tobytes())[0]
+        ws = struct.unpack("<d", want[16:24].tobytes())[0]
+        assert gs == _exact_sum(got[33:]) and gs - ws == 2.0 ** -40
+        assert np.array_equal(got[24:], want[24:]) and np.array_equal(got[:16], want[:16])
+        ctx.hll_replay_sums_device(21, 14, 42, d_seq, d_off, 1, goff, d_img)
+        assert np.array_equal(d_img.cpu().numpy(), want)
 
 
-def test_cli_notes_the_corner(tmp_path):
+def test_cli_replays_whole_files_and_notes_streamed_ones(tmp_path):
     import os
     import subprocess
     import host_lib as H
-    g = np.concatenate([np.frombuffer(b"CTGAGTGTGTCAGGCGTCATT", np.uint8), O.synth_genome(5, 300_000)])
-    (tmp_path / "c.fa").write_bytes(b">c\n" + g.tobytes() + b"\n")
+    g = np.concatenate([np.frombuffer(b"CTGAGTGTGTCAGGCGTCATT", np.uint8), O.synth_genome(5, 3_000_000)])
+    (tmp_path / "c.fa").write_bytes(b">c\n" + b"\n".join(g.tobytes()[i:i + 80] for i in range(0, len(g), 80)) + b"\n")
     (tmp_path / "d.fa").write_bytes(b">d\n" + O.synth_genome(6, 100_000).tobytes() + b"\n")
     (tmp_path / "l.txt").write_text("d.fa\nc.fa\n")
-    for extra in ([], ["--stream-mb", "0"]):
+    for extra in ([], ["--stream-mb", "1"]):
         r = subprocess.run([H.CLI, "sketch", "-f", "l.txt", "-o", "h", "-a", "hll", "-p", "14", "-k", "21"] + extra, cwd=tmp_path, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         notes = [ln for ln in r.stderr.splitlines() if ln.startswith("note:")]
-        assert len(notes) == 1 and "c.fa" in notes[0] and "53 - p" in notes[0], r.stderr
         imgs = np.frombuffer(H.zstd_read(str(tmp_path / "h_sketches.bin")), np.uint8).reshape(2, -1)
         assert np.array_equal(imgs[0], _oracle(14, O.synth_genome(6, 100_000)))
-        assert np.array_equal(imgs[1, 24:], _oracle(14, g)[24:])
+        if not extra:                                  # files sketched whole: the corner file's sum is replayed, nothing to note
+            assert notes == [] and np.array_equal(imgs[1], _oracle(14, g)), r.stderr
+        else:                                          # c.fa streamed in 1 MiB chunks with on-device accumulation: detected, reported, not replayed
+            assert len(notes) == 1 and "c.fa" in notes[0] and "53 - p" in notes[0], r.stderr
+            assert np.array_equal(imgs[1, 24:], _oracle(14, g)[24:])

@@ -12,11 +12,17 @@ import numpy as np
 RL = 150
 
 
-def member(args):
-    idx, n_reads = args
+def member_bases(idx, n_reads):
+    """The reads of member idx as one uint8 array of n_reads * RL bases (deterministic in idx)."""
     rng = np.random.default_rng(20260128 + idx)
     bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=n_reads * RL, dtype=np.uint8)]
     bases[rng.integers(0, n_reads * RL, size=n_reads * RL // 5000)] = ord("N")
+    return bases
+
+
+def member(args):
+    idx, n_reads = args
+    bases = member_bases(idx, n_reads)
     hdr = 15                                                     # "@m0000r0000000\n"
     rec = hdr + (RL + 1) + 2 + (RL + 1)
     out = np.empty((n_reads, rec), np.uint8)
