@@ -184,6 +184,112 @@ int probe_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
     return LASH_OK;
 }
 
+// ---- binned launches (SketchPlan::bins; sketch_kernels.hip "BinRegs") ---------------------------------------------------------
+// Register tables beyond 128 KiB of LDS: the sketch kernels hash every k-mer once and append a 4-byte entry to the list of its bin,
+// bins_apply_kernel builds each bin's registers in LDS and leaves ONE partial per genome ("virtual item" n_items + g) for the
+// ordinary finalize stage.  Lists, counters and fallback tables are sized per genome GROUP (a few GiB at a time; the stream orders
+// the groups, so the buffers are reused), from an upper bound of the entries each genome's work items push.
+struct BinsRun {
+    std::vector<uint32_t> group_end;                  // genome index at which each group ends
+    std::vector<BinGenome> table;                     // per genome: list offset inside its group's buffer, list capacity
+    const BinGenome *d_table = nullptr;
+    uint32_t *d_cnt = nullptr, *d_spill = nullptr;    // [max group][bins], [max group]
+    WorkItem *d_vitems = nullptr;                     // one virtual item per genome
+    uint32_t *d_vbegin = nullptr;                     // 0, 1, ..., n_genomes
+    uint32_t slab_words = 0, max_group = 0;
+    bool fits = true;
+};
+static uint32_t bins_chunk_entries(const SketchPlan &plan)
+{
+    const uint32_t m_row = std::max(1u, 1024u >> (plan.bins_log2 + plan.bin_sub_shift));
+    return ((m_row + 2u) * 8u + 3u) & ~3u;                            // about eight flushes of a row
+}
+static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector<uint64_t> &entries_of_genome, const std::vector<uint32_t> &waves_of_genome,
+                        uint32_t n_genomes, BinsRun &br)
+{
+    const uint32_t B = 1u << plan.bins_log2;
+    br.slab_words = plan.nreg32;                                     // HLL: 2^p words, ULL: 2 * 2^p
+    static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+    br.table.resize(n_genomes);
+    uint64_t bytes = 0, off = 0, group_max_bytes = 0;
+    uint32_t in_group = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+        // a row's entries leave padded to a multiple of four: (m + 1.5) / m on average for rows of m entries per flush
+        const uint64_t m_row = std::max<uint64_t>(1, 1024u >> (plan.bins_log2 + plan.bin_sub_shift));
+        uint64_t mean = entries_of_genome[g] / B * (2 * m_row + 4) / (2 * m_row);
+        uint64_t sq = 1; while (sq * sq < mean) ++sq;
+        const uint64_t cap = (mean + mean / 8 + 8 * sq + 1024 + 63) & ~63ull;
+        if (cap > 0xFFFFFFFFull) { br.fits = false; return LASH_OK; }
+        const uint64_t mine = B * cap * 4 + (uint64_t)br.slab_words * 4;
+        if (mine > budget) { br.fits = false; return LASH_OK; }     // one genome beyond the budget: the caller takes the global-table path
+        if (in_group && (bytes + mine > budget || in_group == 65535u)) {
+            br.group_end.push_back(g);
+            br.max_group = std::max(br.max_group, in_group);
+            bytes = 0; off = 0; in_group = 0;
+        }
+        br.table[g] = BinGenome{off, (uint32_t)cap, 0u};
+        off += B * cap;
+        bytes += mine;
+        group_max_bytes = std::max(group_max_bytes, off * 4);
+        ++in_group;
+    }
+    br.group_end.push_back(n_genomes);
+    br.max_group = std::max(br.max_group, in_group);
+    int rc;
+    if ((rc = reserve(ctx, ctx->bins_lists, group_max_bytes + 256))) return rc;
+    if ((rc = reserve(ctx, ctx->bins_slab, (size_t)br.max_group * br.slab_words * 4 + 256))) return rc;
+    std::vector<WorkItem> vitems(n_genomes);
+    std::vector<uint32_t> vbegin(n_genomes + 1);
+    for (uint32_t g = 0; g < n_genomes; ++g) { vitems[g] = WorkItem{g, 0u, 4u, 0u}; vbegin[g] = g; }
+    vbegin[n_genomes] = n_genomes;
+    std::vector<Section> sec = {{br.table.data(), br.table.size() * sizeof(BinGenome), 0}, {vitems.data(), vitems.size() * sizeof(WorkItem), 0},
+                                {vbegin.data(), vbegin.size() * 4, 0}};
+    const size_t tabs = layout_sections(sec), cnt_bytes = ((size_t)br.max_group * B * 4 + 255) & ~(size_t)255, spill_bytes = ((size_t)br.max_group * 4 + 255) & ~(size_t)255;
+    if ((rc = reserve(ctx, ctx->bins_meta, tabs + cnt_bytes + spill_bytes + 256))) return rc;
+    if ((rc = upload_sections(ctx, ctx->bins_meta.ptr, sec, tabs, ctx->stream))) return rc;
+    uint8_t *mb = static_cast<uint8_t *>(ctx->bins_meta.ptr);
+    br.d_table = reinterpret_cast<const BinGenome *>(mb + sec[0].off);
+    br.d_vitems = reinterpret_cast<WorkItem *>(mb + sec[1].off);
+    br.d_vbegin = reinterpret_cast<uint32_t *>(mb + sec[2].off);
+    br.d_cnt = reinterpret_cast<uint32_t *>(mb + tabs);
+    br.d_spill = reinterpret_cast<uint32_t *>(mb + tabs + cnt_bytes);
+    return LASH_OK;
+}
+// the launches of one call, group by group: launch(sa, first item, items) queues the sketch kernels of an item range
+template <class Launch>
+static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *prm, SketchArgs sa, const BinsRun &br, const std::vector<uint32_t> &item_begin,
+                    uint32_t n_items, const uint32_t *d_item_begin, Launch launch)
+{
+    const uint32_t B = 1u << plan.bins_log2;
+    sa.bin_lists = static_cast<uint32_t *>(ctx->bins_lists.ptr);
+    sa.bin_cnt = br.d_cnt;
+    sa.bin_slab = static_cast<uint32_t *>(ctx->bins_slab.ptr);
+    sa.bin_spill = br.d_spill;
+    sa.bins = B; sa.bin_shift = plan.bin_shift; sa.bin_S = plan.bin_S; sa.bin_sub_shift = plan.bin_sub_shift; sa.bin_slab_words = br.slab_words;
+    sa.bin_chunk = bins_chunk_entries(plan);
+    sa.item_order = nullptr;
+    uint32_t g0 = 0;
+    for (uint32_t g1 : br.group_end) {
+        const uint32_t ng = g1 - g0;
+        HIPCHK(ctx, hipMemsetAsync(br.d_cnt, 0, (size_t)ng * B * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(br.d_spill, 0, (size_t)ng * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->bins_slab.ptr, prm->algo == LASH_ULL ? 0x00 : 0xFF, (size_t)ng * br.slab_words * 4, ctx->stream));
+        sa.bin_genomes = br.d_table + g0;
+        sa.bin_genome0 = g0;
+        sa.item_base = item_begin[g0];
+        int rc = launch(sa, item_begin[g0], item_begin[g1] - item_begin[g0]);
+        if (rc) return rc;
+        BinApplyArgs ba{};
+        ba.lists = sa.bin_lists; ba.cnt = br.d_cnt; ba.slab = sa.bin_slab; ba.spill = br.d_spill; ba.genomes = sa.bin_genomes;
+        ba.partials = sa.partials; ba.item_kmers = sa.item_kmers; ba.genome_item_begin = d_item_begin;
+        ba.partial_stride = sa.partial_stride; ba.virt0 = n_items + g0; ba.genome0 = g0;
+        ba.bins = B; ba.bin_shift = plan.bin_shift; ba.slab_words = br.slab_words; ba.algo = prm->algo; ba.p = prm->p;
+        HIPCHK(ctx, launch_bins_apply(ba, ng, ctx->stream));
+        g0 = g1;
+    }
+    return LASH_OK;
+}
+
 int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, EvSet *ev)
 {
     const uint32_t n_genomes = pk->n_genomes;
@@ -191,7 +297,16 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     for (uint32_t g = 0; g < n_genomes; ++g) total_bytes += pk->byte_len[g];
     const bool small_items = n_genomes > 0 && total_bytes / n_genomes < 100000u;
     const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
-    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo));
+    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo));
+    if (plan.bins) {
+        // a binned launch keeps ~4.6 bytes per input byte of one genome group in HBM: a single genome beyond the budget (a multi-Gbp
+        // input in one call, which the CLI would have streamed in chunks) takes the table-in-global-memory path instead
+        static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+        uint64_t big = 0;
+        for (uint32_t g = 0; g < n_genomes; ++g) big = std::max<uint64_t>(big, pk->byte_len[g]);
+        if (big * 5 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget)
+            plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo), false);
+    }
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
@@ -236,7 +351,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     }
     std::vector<WorkItem> items;
     uint32_t max_slices = 0;                                       // most slices any genome is cut into
-    bool all_sole = plan.parts_log2 == 0 && plan.use_lds && n_genomes > 0;   // every genome has exactly one work item
+    bool all_sole = plan.parts_log2 == 0 && plan.use_lds && !plan.bins && n_genomes > 0;   // every genome has exactly one work item
     std::vector<uint32_t> item_begin(n_genomes + 1, 0);
     items.reserve(n_genomes * 2);
     auto slicing = [&](uint32_t g, uint64_t &nw, uint64_t &ns, uint64_t &per) {
@@ -272,7 +387,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         slicing(g, nw, ns, per);
         if (nw == 0) { all_sole = false; continue; }               // no work item at all: finalize writes the empty image
         uint32_t s = 0;
-        const bool whole = ns == 1 && plan.parts_log2 == 0 && plan.use_lds;
+        const bool whole = ns == 1 && plan.parts_log2 == 0 && plan.use_lds && !plan.bins;
         for (uint64_t b = 0; b < nw; b += per, ++ci) {
             const uint64_t e = std::min(nw, b + per);
             uint64_t sub = e - b;                                  // this slice as one item, or as tail_split smaller ones
@@ -299,7 +414,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // A bucket sort on the size's leading bits: O(items), stable inside a bucket (neighbouring items still share cache lines).
     std::vector<uint32_t> order;
     {
-        if (n_items > slots && unequal) {
+        if (n_items > slots && unequal && !plan.bins) {                 // (binned launches run genome group by genome group, in order)
             auto bucket = [&](uint32_t n) {                             // 8 buckets per octave, larger sizes first
                 const uint32_t e = 31u - (uint32_t)__builtin_clz(n | 1u);
                 const uint32_t m = e >= 3 ? (n >> (e - 3)) & 7u : 0u;
@@ -325,9 +440,25 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     TRACE("sketch: planned");
 
     int rc;
-    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + 1) * plan.partial_stride))) return rc;
-    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + 1) * 4))) return rc;
+    const size_t n_virtual = plan.bins ? n_genomes : 0;               // binned launches: one partial per genome behind the items'
+    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + n_virtual + 1) * plan.partial_stride))) return rc;
+    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + n_virtual + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
+    BinsRun bins_run_state;
+    if (plan.bins) {
+        // entries a genome's work items push: 16 per lane and word for every tile a wave takes part in (masked positions and the
+        // idle lanes of a busy wave included); what dirt adds on top (junction walks, a second pass by the compacting kernel) goes to
+        // the genome's fallback table if its lists run full
+        std::vector<uint64_t> entries(n_genomes, 0);
+        const uint64_t tile_words = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
+        std::vector<uint32_t> waves(n_genomes, 0);
+        for (const WorkItem &w : items) {
+            entries[w.genome] += ((w.word_end - w.word_begin + tile_words - 1) / tile_words) * tile_words * 16;
+            waves[w.genome] += (pk->direct ? 2u : 1u) * (plan.threads / 64u);                 // (a genome handed to the compacting kernel is worked on twice)
+        }
+        if ((rc = bins_prepare(ctx, plan, entries, waves, n_genomes, bins_run_state))) return rc;
+        if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
+    }
     if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
     const WorkItem *d_items;
     const uint32_t *d_item_begin, *d_item_order = nullptr;
@@ -420,18 +551,38 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.nslow = pk->d_dirty + n_genomes + 1;
         sa.ndel = sa.nslow + n_genomes;
         sa.ndel2 = pk->d_dirty + 4 * (size_t)n_genomes + 2;
-        if (!pk->stream_first) {
-            if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));       // direct_ms: this one launch
-            HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
-            if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
-            if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
-            ctx->last.direct_launches += n_items ? 1 : 0;
-            ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
-        } else {
-            // recent batches were full of finely fragmented dirt: every genome goes straight to the compacting kernel
+        if (pk->stream_first)   // recent batches were full of finely fragmented dirt: every genome goes straight to the compacting kernel
             HIPCHK(ctx, hipMemsetAsync(pk->d_dirty, 0x01, (size_t)n_genomes * 4, ctx->stream));
+        if (plan.bins) {
+            if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));
+            rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, d_item_begin, [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int {
+                if (!pk->stream_first) HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream, true));
+                HIPCHK(ctx, launch_sketch_stream(plan, a, cnt, ctx->stream));
+                return LASH_OK;
+            });
+            if (rc) return rc;
+            if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
+            if (!pk->stream_first) {
+                if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
+                ctx->last.direct_launches += n_items ? 1 : 0;
+            }
+        } else {
+            if (!pk->stream_first) {
+                if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));       // direct_ms: this one launch
+                HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
+                if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
+                if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
+                ctx->last.direct_launches += n_items ? 1 : 0;
+                ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
+            }
+            HIPCHK(ctx, launch_sketch_stream(plan, sa, n_items, ctx->stream));    // the flagged genomes, compacted on the fly
         }
-        HIPCHK(ctx, launch_sketch_stream(plan, sa, n_items, ctx->stream));    // the flagged genomes, compacted on the fly
+    } else if (plan.bins) {
+        rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, d_item_begin, [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int {
+            HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream));
+            return LASH_OK;
+        });
+        if (rc) return rc;
     } else {
         HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream));
         ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
@@ -445,6 +596,13 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.genome_item_begin = d_item_begin;
     fa.nvalid = pk->d_nvalid;
     fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
+    if (plan.bins) {                                               // one partial per genome, written by bins_apply_kernel behind the items'
+        fa.partials += (size_t)n_items * plan.partial_stride;
+        fa.item_kmers += n_items;
+        fa.items = bins_run_state.d_vitems;
+        fa.genome_item_begin = bins_run_state.d_vbegin;
+        max_slices = 1;
+    }
     fa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
     fa.images = d_out_images;
     fa.partial_stride = plan.partial_stride;
@@ -493,7 +651,14 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     if ((rc = timing_begin(ctx))) return rc;
     EvSet *ev = ctx->cur_ev;
     const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
-    const SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false);
+    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false);
+    if (plan.bins) {                                                  // (as in sketch_from: one genome beyond the binned launch's budget)
+        static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+        uint64_t big = 0;
+        for (uint32_t g = 0; g < n_genomes; ++g)
+            big = std::max<uint64_t>(big, (genome_byte_off[g + 1] - genome_byte_off[g]) + 32 * (genome_rec_off[g + 1] - genome_rec_off[g]));
+        if (big * 6 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget) plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false, false);
+    }
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
     std::vector<GenomeDesc> descs(n_genomes, GenomeDesc{});
     std::vector<WorkItem> items;
@@ -517,9 +682,24 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     }
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
-    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + 1) * plan.partial_stride))) return rc;
-    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + 1) * 4))) return rc;
+    const size_t n_virtual = plan.bins ? n_genomes : 0;
+    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + n_virtual + 1) * plan.partial_stride))) return rc;
+    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + n_virtual + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
+    BinsRun bins_run_state;
+    if (plan.bins) {
+        // a lane pushes 16 entries per trip of its loop — 16 residues of a record, or the fetch of the next one — and the idle lanes of a
+        // busy wave push along: residues + 32 per record, and a quarter on top
+        std::vector<uint64_t> entries(n_genomes);
+        for (uint32_t g = 0; g < n_genomes; ++g) {
+            const uint64_t e = descs[g].byte_len + 32 * (descs[g].rec_end - descs[g].rec_begin);
+            entries[g] = e + e / 4 + (uint64_t)plan.threads * 256;
+        }
+        std::vector<uint32_t> waves(n_genomes);
+        for (uint32_t g = 0; g < n_genomes; ++g) waves[g] = (item_begin[g + 1] - item_begin[g]) * (plan.threads / 64u);
+        if ((rc = bins_prepare(ctx, plan, entries, waves, n_genomes, bins_run_state))) return rc;
+        if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
+    }
     if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
     std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0}, {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0},
                                 {descs.data(), descs.size() * sizeof(GenomeDesc), 0}};
@@ -560,7 +740,13 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
         sa.hll_corner = static_cast<uint32_t *>(ctx->hll_flags.ptr);
         ctx->hll_flags_n = n_genomes;
     }
-    HIPCHK(ctx, launch_sketch_aa(plan, sa, n_items, ctx->stream));
+    if (plan.bins) {
+        rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, reinterpret_cast<const uint32_t *>(tb + sec[1].off),
+                      [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int { HIPCHK(ctx, launch_sketch_aa(plan, a, cnt, ctx->stream)); return LASH_OK; });
+        if (rc) return rc;
+    } else {
+        HIPCHK(ctx, launch_sketch_aa(plan, sa, n_items, ctx->stream));
+    }
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
     FinalizeArgs fa{};
     fa.partials = static_cast<const uint8_t *>(ctx->partials.ptr);
@@ -568,6 +754,13 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     fa.genome_item_begin = reinterpret_cast<const uint32_t *>(tb + sec[1].off);
     fa.nvalid = nullptr;                                           // every item is live
     fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
+    if (plan.bins) {
+        fa.partials += (size_t)n_items * plan.partial_stride;
+        fa.item_kmers += n_items;
+        fa.items = bins_run_state.d_vitems;
+        fa.genome_item_begin = bins_run_state.d_vbegin;
+        max_slices = 1;
+    }
     fa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
     fa.images = d_out_images;
     fa.partial_stride = plan.partial_stride;

@@ -135,6 +135,7 @@ struct lash_ctx {
     unsigned ring_next = 0;
     std::vector<const lash_packed *> last_packed;   // what the last sketch call consumed (for bases_last / error flags)
     DevBuf items, item_begin, item_kmers, partials, gregs, counter;   // items: [work items | item_begin] of a sketch call
+    DevBuf bins_lists, bins_meta, bins_slab;   // binned launches (SketchPlan::bins): entry lists, tables + counters, fallback tables of one genome group
     bool counter_zeroed = false;
     DevBuf st_seq, st_rec, st_img;       // staging for the synchronous host-buffer entries (files_raw, merge, pair statistics)
     // lash_sketch_batch[_async]: two staging slots and two copy streams, so that the H2D copy of batch n+1 and the D2H copy of

@@ -8,6 +8,7 @@
 namespace lash {
 
 // ---- sketch stage ----------------------------------------------------------------------------------------
+struct BinGenome { uint64_t list_off; uint32_t cap; uint32_t pad; };   // binned launches: this genome's lists, bin b = lists + list_off + b * cap
 struct SketchArgs {
     const uint32_t   *words;      // packed 2-bit bases
     const uint32_t   *brk;        // record-break bitmap
@@ -45,6 +46,17 @@ struct SketchArgs {
     uint32_t          nreg32;     // u32 words of register state (HMH 16384, HLL 2^p, ULL 2*2^p)
     int               k;
     int               p;
+    uint32_t          item_base;  // launches over a range of the items: workgroup b takes item item_base + b (item_order == NULL)
+    // binned launches (SketchPlan::bins; sketch_kernels.hip "BinRegs"): the sketch kernels append entries, bins_apply_kernel builds registers
+    uint32_t         *bin_lists;  // every (genome of the group, bin) list, BinGenome::list_off apart
+    uint32_t         *bin_cnt;    // [genomes of the group][bins] fill counters, zeroed
+    uint32_t         *bin_slab;   // [genomes of the group][bin_slab_words] full-size fallback tables (zero / 0xFF-filled)
+    uint32_t         *bin_spill;  // [genomes of the group] set when a genome's fallback table holds something
+    const BinGenome  *bin_genomes;   // [genomes of the group]
+    uint32_t          bins, bin_shift, bin_S, bin_sub_shift, bin_chunk;
+    uint32_t          bin_lds_off, bin_wave_bytes;   // LDS: the waves' counter + staging areas
+    uint32_t          bin_slab_words;
+    uint32_t          bin_genome0;                  // first genome of the group
 };
 
 struct SketchPlan {
@@ -60,10 +72,28 @@ struct SketchPlan {
     uint32_t partial_stride;      // rounded up to 16
     bool     defer = false;       // direct HyperMinHash launch with deferred signatures (the caller sets it for batches of large work items)
     uint32_t sigq_depth = 7;      // ... and the depth of its lanes' stacks (process_word_defer)
+    // register tables beyond 128 KiB of LDS (HLL p = 16, ULL p = 15 .. 22): hash once, scatter entries into 2^bins_log2 bins per genome,
+    // one LDS pass per bin (BinRegs / bins_apply_kernel).  use_lds stays true (no per-item global table), lds_bytes holds no table.
+    bool     bins = false;
+    uint32_t bins_log2 = 0, bin_shift = 0, bin_S = 0, bin_sub_shift = 0;
 };
+// per wave: bytes of LDS a binned launch needs for its bin counters and staging rows
+uint32_t sketch_bin_wave_bytes(const SketchPlan &plan);
+struct BinApplyArgs {
+    const uint32_t *lists, *cnt, *slab, *spill;
+    const BinGenome *genomes;
+    uint8_t  *partials;           // the group's genomes' "virtual" partials: genome gi of the group at partials + (virt0 + gi) * partial_stride
+    uint32_t *item_kmers;         // ... and its k-mer count at item_kmers[virt0 + gi] = the sum over its real items
+    const uint32_t *genome_item_begin;   // real items of genome g: [genome_item_begin[g], genome_item_begin[g + 1])
+    uint64_t  partial_stride;
+    uint32_t  virt0, genome0;
+    uint32_t  bins, bin_shift, slab_words;
+    int       algo, p;
+};
+hipError_t launch_bins_apply(const BinApplyArgs &args, uint32_t n_group_genomes, hipStream_t stream);
 
 // small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false);
+SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false, bool allow_bins = true);
 // the genomes flagged in args.dirty, again from their ASCII bytes, compacted through an LDS ring per wave (stream_sketch_kernel)
 hipError_t launch_sketch_stream(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream);
 // direct launches: bytes of LDS the waves' staging areas take on top of plan.lds_bytes (they start at plan.lds_bytes)

@@ -46,6 +46,7 @@ constexpr uint32_t RANK_EMPTY = 0xFFFFFFFFu;                   // HyperMinHash /
 
 struct LdsRegs {
     uint32_t *base;
+    static constexpr bool BINS = false;
     // The register table starts at LDS address 0 (the kernel has no static __shared__; checked at kernel entry), so the
     // word index goes straight into the DS address.  Through a pointer hipcc adds the table's link-time base (0) with a
     // v_add_u32 per k-mer; the update itself is fire-and-forget, nothing in the hashing loop reads the table back, and
@@ -66,8 +67,9 @@ struct LdsRegs {
     __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i]; }
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
-struct GlobalRegs {                                            // (UltraLogLog p >= 19 only: a zeroed slab per work item)
+struct GlobalRegs {                                            // (UltraLogLog p >= 23 only: a zeroed slab per work item)
     uint32_t *base;
+    static constexpr bool BINS = false;
     static constexpr bool THR = false;
     __device__ __forceinline__ void smax(uint32_t, uint32_t) const {}
     __device__ __forceinline__ void bor_pair(uint32_t idx, uint32_t w, uint32_t v) const
@@ -78,26 +80,127 @@ struct GlobalRegs {                                            // (UltraLogLog p
     static __device__ __forceinline__ void lds_wait() {}
 };
 
-// A register table larger than 128 KiB of LDS but no more than 16 times that (HLL p=16; ULL p=15..18) is covered in
-// 2..16 PASSES over the slice: each pass (its own work item) owns one contiguous 1/2^lp of the bucket space in a 128 KiB
-// LDS table and drops the updates of the other buckets (no-op values).  Hashing every k-mer 2^lp times
-// still beats per-k-mer global atomics (HLL p=16: 2.7e10 -> 3e11 k-mers/s).  Indices are register-word indices of the
-// FULL table; the part is their top lp bits.
-struct LdsPartRegs {
-    uint32_t *base;
-    uint32_t local_mask;      // (words per part) - 1
-    uint32_t part_shift;      // log2(words per part)
-    uint32_t part;
-    static constexpr bool THR = false;
-    __device__ __forceinline__ void smax(uint32_t i, uint32_t v) const
-    { asm volatile("ds_max_i32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : RANK_EMPTY) : "memory"); }
-    __device__ __forceinline__ void bor_pair(uint32_t idx, uint32_t w, uint32_t v) const
+// A register table larger than 128 KiB of LDS (HyperLogLog p = 16; UltraLogLog p = 15 .. 22) is not updated by the sketch kernels
+// at all (round 4; rounds 1-3 hashed every k-mer once per 128 KiB part of the table, 2 .. 16 times, and from p = 19 fell back to
+// one L2 atomic per k-mer: 1.7e10 k-mers/s).  Every k-mer is hashed ONCE and leaves a 4-byte entry, register index << 6 | value
+// (HyperLogLog: rho - 1; UltraLogLog: nlz; 63 = nothing), in the list of its BIN — the genome's registers cut into bins of 2^14
+// (ULL) / 2^15 (HLL) of them, one LDS table's worth.  bins_apply_kernel then reads each list once and builds its bin's registers in
+// LDS.  HBM: 4 bytes written + 4 read per k-mer beside the 1 byte of input; no atomics in the data path.
+//   The scatter is staged per WAVE: push() takes a slot in the wave's LDS area of its bin (returning ds_add on the bin's counter),
+// and after each word of 16 k-mers per lane the wave reserves room in the bins' lists (one returning global atomic per bin holding
+// entries, issued by 64 lanes at once) and copies the staged entries out, a bin at a time, lanes side by side.  Entries that find
+// their staging row or their list full go straight into the genome's full-size table in global memory (the rounds 1-3 path: exact,
+// slow, and only met by genomes whose k-mers pile into few buckets — a satellite repeat); bins_apply_kernel folds that table in
+// when the genome's flag is up.
+struct BinRegs {
+    static constexpr bool THR = false, BINS = true;
+    uint32_t cnt_b, stage_b;      // LDS byte addresses of this wave's row counters [V] and staging rows [V][S]
+    uint32_t S, V, sub_shift;     // slots per row; rows: V = bins << sub_shift (few bins: each has 2^sub_shift rows, a lane uses row
+    uint32_t sub_lane;            //   lane & (2^sub_shift - 1) of its bin — 64 lanes on 2 counters would be 32-way LDS atomic conflicts)
+    uint32_t bin_shift;           // register index >> bin_shift = bin
+    uint32_t cap;                 // entries per list
+    uint32_t *lists, *cnt;        // this genome's lists and their fill counters [bins]
+    uint32_t *slab, *spill;       // this genome's full-size fallback table, and its "look there too" flag
+    int algo;
+    // mode (wave-uniform): 0 = careful — an entry that finds its row full is applied to the fallback table there and then (junction
+    // walks, dense tiles: lanes push one at a time); 1 = the hot loops' form — no branch between the 16 pushes of a word (with one, each
+    // push waits for its own returning LDS atomic: 16 round trips per word): a full row's entries land in the row's spare slot, `ovf`
+    // remembers it, and the caller runs the word again in mode 2; 2 = every entry straight to the fallback table (max / OR are
+    // idempotent: what was staged the first time does no harm)
+    uint32_t mode;
+    mutable uint32_t ovf;
+    // exact, slow: one global atomic.  (Static, everything by value: a member function that is not inlined takes `this`, the struct
+    // then lives in scratch memory and every push reads its fields back from there — 6.7 vector memory reads per k-mer, found with
+    // SQ_INSTS_VMEM_RD)
+    static __device__ __noinline__ void spill_to(uint32_t *slab, uint32_t *spill, int algo, uint32_t e)
     {
-        const uint32_t i = 2u * idx + w;
-        asm volatile("ds_or_b32 %0, %1" ::"v"((i & local_mask) << 2), "v"((i >> part_shift) == part ? v : 0u) : "memory");
+        const uint32_t v = e & 63u, idx = e >> 6;
+        if (v == 63u) return;
+        if (algo == 2) (void)__hip_atomic_fetch_or(slab + 2u * idx + (v >> 5), 1u << (v & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else (void)__hip_atomic_fetch_max(reinterpret_cast<int *>(slab) + idx, (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(spill, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __device__ __forceinline__ void bor_first(uint32_t hh, int p, uint32_t v) const { bor_pair(hh >> (32 - p), 0u, v); }
-    __device__ __forceinline__ uint32_t get(uint32_t i) const { return base[i]; }       // i: local word index
+    __device__ __forceinline__ void spill_entry(uint32_t e) const { spill_to(slab, spill, algo, e); }
+    __device__ __forceinline__ void push(uint32_t idx, uint32_t v) const
+    {
+        const uint32_t row = ((idx >> bin_shift) << sub_shift) | sub_lane, e = (idx << 6) | (v & 63u);
+        if (mode == 2u) { spill_entry(e); return; }
+        const uint32_t rank = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(uintptr_t)(cnt_b + row * 4u), 1u,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (mode == 1u) {
+            ovf = ovf > rank ? ovf : rank;
+            *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(stage_b + (row * (S + 4u) + (rank < S ? rank : S)) * 4u) = e;
+            return;
+        }
+        if (__builtin_expect(rank < S, 1)) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(stage_b + (row * (S + 4u) + rank) * 4u) = e;
+        else spill_entry(e);
+    }
+    // after a word pushed in mode 1: did a row run full?  (wave-uniform answer; clears the mark)
+    __device__ __forceinline__ bool overflowed() const
+    {
+        const bool o = __builtin_amdgcn_ballot_w64(ovf >= S) != 0ull;
+        ovf = 0u;
+        return o;
+    }
+    // staged entries -> the bins' lists: a lane owns a row, reserves room for its entries in the bin's list and copies them out 16 bytes
+    // at a time (rows are padded to four entries with 0xFFFFFFFF = "nothing", so every reservation and every store is 16-byte
+    // aligned: scattered 4-byte stores were what bound the first version).  The rows of one bin sit in neighbouring lanes and share
+    // ONE returning global atomic (a prefix sum over the wave; 32 lanes adding to the same two counters was the other thing that did).
+    // (Reserving chunks ahead — one atomic per ~8 flushes — was tried and lost: more atomics on fewer counters where bins are few,
+    // and the filling of unused tails.)  Every lane of the wave must call it.
+    __device__ __forceinline__ void flush(uint32_t lane) const
+    {
+        auto lds = [](uint32_t b) { return (__attribute__((address_space(3))) uint32_t *)(uintptr_t)b; };
+        for (uint32_t r0 = 0; r0 < V; r0 += 64u) {
+            const uint32_t row = r0 + lane;
+            uint32_t n = 0;
+            if (row < V) {
+                n = *lds(cnt_b + row * 4u);
+                if (n) *lds(cnt_b + row * 4u) = 0u;
+                n = n < S ? n : S;                                         // (what went beyond the row has been spilled / redone)
+            }
+            const uint32_t n4 = (n + 3u) & ~3u, bin = row >> sub_shift;
+            uint32_t base;
+            if (sub_shift == 0u) {
+                base = n4 ? __hip_atomic_fetch_add(cnt + bin, n4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            } else {
+                uint32_t incl = n4;                                        // inclusive prefix sum over the wave's lanes (six DPP adds)
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);
+                const uint32_t sub = (1u << sub_shift) - 1u, gs = lane & ~sub, ge = gs | sub;
+                const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs * 4u), (int)(incl - n4));     // entries of the bins before this one
+                const uint32_t total = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ge * 4u), (int)incl) - before;
+                uint32_t bin_base = 0;
+                if (lane == gs && total) bin_base = __hip_atomic_fetch_add(cnt + bin, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bin_base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs * 4u), (int)bin_base);
+                base = bin_base + (incl - n4) - before;
+            }
+            uint32_t *dst = lists + (uint64_t)bin * cap;
+            const uint32_t src = stage_b + row * (S + 4u) * 4u;
+            for (uint32_t i = 0; i < n4; i += 4u) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 raw = *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(src + i * 4u);    // ds_read_b128
+                uint4 q = make_uint4(raw.x, raw.y, raw.z, raw.w);
+                if (i + 4u > n) {                                          // the padding (the row holds older entries there)
+                    if (i + 1u >= n) q.y = 0xFFFFFFFFu;
+                    if (i + 2u >= n) q.z = 0xFFFFFFFFu;
+                    q.w = 0xFFFFFFFFu;
+                }
+                const uint32_t at = base + i;
+                if (at + 4u <= cap) *reinterpret_cast<uint4 *>(dst + at) = q;
+                else { spill_entry(q.x); spill_entry(q.y); spill_entry(q.z); spill_entry(q.w); }
+            }
+        }
+    }
+    __device__ __forceinline__ void finish(uint32_t lane) const { flush(lane); }
+    __device__ __forceinline__ uint32_t get(uint32_t) const { return 0u; }
+    __device__ __forceinline__ void smax(uint32_t, uint32_t) const {}       // (never instantiated for a launch: HyperMinHash's table fits)
+    __device__ __forceinline__ void bor_first(uint32_t, int, uint32_t) const {}
+    __device__ __forceinline__ void bor_pair(uint32_t, uint32_t, uint32_t) const {}
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
 
@@ -111,7 +214,7 @@ struct LdsPartRegs {
 // zeros the threshold is 0 (x16 must be 0) and the full update decides.  get() turns the word back into lz << 10 | sig.
 struct LdsThrRegs {
     uint32_t *base;
-    static constexpr bool THR = true;
+    static constexpr bool THR = true, BINS = false;
     static __device__ __forceinline__ uint32_t encode(uint32_t lzm1, uint32_t sig)
     {
         const uint32_t m = lzm1 < 16u ? lzm1 : 16u;
@@ -134,7 +237,7 @@ struct LdsThrRegs {
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
 
-enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_LDS_PARTS = 2 };
+enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_BINS = 2 };
 
 // ------------------------------------------------------------------------------------------------------------
 // the three add_kmer rules.  `vm` is 0 or ~0: invalid k-mers degrade to no-ops (max with "empty", OR 0).
@@ -201,7 +304,8 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             const uint32_t j = (gl ^ alignbit(gh, gl, 28)) & pm;
             uint32_t raw = ffbh_u32(gh);                                        // gh == 0 -> "empty" (nothing happens; re-run by the caller)
             if constexpr (MASKED) raw |= ~vm;
-            regs.smax(j, raw);
+            if constexpr (Regs::BINS) regs.push(j, raw);                        // (its low six bits: 63 = nothing)
+            else regs.smax(j, raw);
             return gh;
         }
         const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
@@ -213,7 +317,8 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             const uint32_t jh = hh >> (32 - p);
             uint32_t raw = clz64_nz(alignbit(hh, hl, 32 - p), (hl << p) | (1u << (p - 1)));
             if constexpr (MASKED) raw |= ~vm;
-            regs.smax(jh, raw);
+            if constexpr (Regs::BINS) regs.push(jh, raw);
+            else regs.smax(jh, raw);
             return 1u;
         }
         const uint32_t j = hl & pm;
@@ -221,7 +326,8 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
         if constexpr (FAST) raw = ffbh_u32(hh);                              // hh == 0 -> "empty"
         else raw = clz64_nz(hh, hl | pm);
         if constexpr (MASKED) raw |= ~vm;
-        regs.smax(j, raw);
+        if constexpr (Regs::BINS) regs.push(j, raw);
+        else regs.smax(j, raw);
         return hh;
     } else {
         // utils.rs:427-429: UltraLogLog::add(h): idx = top p bits, nlz = leading zeros of the 64-p bits below; hash4j sets bit
@@ -235,6 +341,12 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             hh = (uint32_t)(g >> 32); hl = (uint32_t)g;
             th = alignbit(hh, hl, 32 - p) ^ (hh >> (28 - p));
             // th != 0 -> nlz = v_ffbh(th) < 32: always the pair's first word; th == 0 -> push nothing (re-run by the caller)
+            if constexpr (Regs::BINS) {
+                uint32_t nlz = ffbh_u32(th);                                     // th == 0 -> all ones -> 63 = nothing
+                if constexpr (MASKED) nlz |= ~vm;
+                regs.push(hh >> (32 - p), nlz);
+                return th;
+            }
             uint32_t one;
             if constexpr (MASKED) asm("v_min3_u32 %0, %1, 1, %2" : "=v"(one) : "v"(th), "v"(vm));   // th == 0 or an invalid k-mer: nothing
             else one = th < 1u ? th : 1u;
@@ -246,6 +358,10 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             th = alignbit(hh, hl, 32 - p);                                   // high word of ~(~h << p), p >= 3
             const uint32_t tl = (hl << p) | pm_of(p);
             const uint32_t nlz = clz64_nz(th, tl);                           // 0..=64-p
+            if constexpr (Regs::BINS) {
+                regs.push(hh >> (32 - p), MASKED ? (nlz | ~vm) : nlz);
+                return th;
+            }
             uint32_t val = 1u << (nlz & 31u);
             if constexpr (MASKED) val &= vm;
             regs.bor_pair(hh >> (32 - p), nlz >> 5, val);
@@ -1078,6 +1194,32 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return total;
 }
 
+// this wave's BinRegs for the genome of a work item (REGS_BINS launches): counters cleared, nothing staged
+template <int ALGO>
+__device__ __forceinline__ BinRegs bin_regs_of(const SketchArgs &a, uint32_t genome)
+{
+    BinRegs r;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    r.sub_shift = a.bin_sub_shift;
+    r.V = a.bins << r.sub_shift;
+    r.sub_lane = lane & ((1u << r.sub_shift) - 1u);
+    r.cnt_b = a.bin_lds_off + wave * a.bin_wave_bytes;
+    r.stage_b = r.cnt_b + r.V * 4u;
+    r.S = a.bin_S; r.bin_shift = a.bin_shift; r.algo = ALGO;
+    r.mode = 0u; r.ovf = 0u;
+
+    const uint32_t gi = genome - a.bin_genome0;
+    const BinGenome bg = a.bin_genomes[gi];
+    r.cap = bg.cap;
+    r.lists = a.bin_lists + bg.list_off;
+    r.cnt = a.bin_cnt + (uint64_t)gi * a.bins;
+    r.slab = a.bin_slab + (uint64_t)gi * a.bin_slab_words;
+    r.spill = a.bin_spill + gi;
+    for (uint32_t b = lane; b < r.V; b += 64u) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(r.cnt_b + b * 4u) = 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return r;
+}
+
 template <int ALGO, int REGS, class Regs>
 __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem &it, const Regs &regs, uint32_t *census, uint32_t part,
                                             uint32_t my_kmers, int p, uint32_t item)
@@ -1096,6 +1238,10 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
                                                                       // passes of one slice count the same k-mers: once)
     }
 
+    if constexpr (REGS == REGS_BINS) {
+        regs.finish(threadIdx.x & 63u);                                    // what the wave still holds staged; the registers are bins_apply_kernel's job
+        return;
+    }
     // flush in image register format (u16 LE for HMH, u8 for HLL / ULL): into this item's partial sketch, or — when the
     // item is the only one of its genome (ITEM_SOLE: many small genomes) — straight into the genome's image, header
     // included, so that neither a partial nor a finalize pass is needed for it
@@ -1131,8 +1277,7 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
             put(i, hmh_reg(regs.get(2 * i)) | (hmh_reg(regs.get(2 * i + 1)) << 16));
         if (sole && threadIdx.x == 0 && HDR) write_header(img, a.lay.hdr_tpl, a.alpha_bits, HMH_M, 0, 0.0, HMH_P);
     } else if constexpr (ALGO == 1) {
-        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 : (1u << p)) >> 2;     // this pass's registers / 4
-        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
+        const uint32_t nw = (1u << p) >> 2;
         for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
             put(i, hll_reg(regs.get(4 * i)) | (hll_reg(regs.get(4 * i + 1)) << 8) | (hll_reg(regs.get(4 * i + 2)) << 16) | (hll_reg(regs.get(4 * i + 3)) << 24));
         if (sole) {
@@ -1140,8 +1285,7 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
             if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
         }
     } else {
-        const uint32_t nw = (REGS == REGS_LDS_PARTS ? a.nreg32 >> 1 : (1u << p)) >> 2;
-        if constexpr (REGS == REGS_LDS_PARTS) out += part * nw;
+        const uint32_t nw = (1u << p) >> 2;
         for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
             uint32_t o = 0;
 #pragma unroll
@@ -1175,7 +1319,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     // work items are handed out longest first when their sizes differ (a.item_order: the host's permutation), so that the last
     // workgroups to start are the short ones: a mixed collection lost 11 % to its tail in launch order = genome order
-    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x;
+    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x + a.item_base;
     const WorkItem it = a.items[item];
     const GenomeDesc gd = a.genomes[it.genome];
     const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
@@ -1202,18 +1346,16 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<DEFER, LdsThrRegs, typename std::conditional<REGS == REGS_LDS, LdsRegs,
-                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type>::type;
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, BinRegs>::type>::type>::type;
     Regs regs;
     uint32_t *census;
-    const uint32_t part = it.slice >> 16;                                  // REGS_LDS_PARTS: which 1/2^lp of the buckets
-    if constexpr (USE_LDS) {
+    const uint32_t part = 0u;
+    if constexpr (REGS == REGS_BINS) {
+        regs = bin_regs_of<ALGO>(a, it.genome);                            // no table here: entries for bins_apply_kernel
+        census = lds_regs;
+    } else if constexpr (USE_LDS) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
-        if constexpr (REGS == REGS_LDS_PARTS) {
-            regs.local_mask = a.nreg32 - 1u;                               // a.nreg32: words of ONE part (a power of two)
-            regs.part_shift = 31u - (uint32_t)__builtin_clz(a.nreg32);
-            regs.part = part;
-        }
         census = lds_regs + a.nreg32;
     } else {
         regs.base = a.gregs + (uint64_t)item * a.nreg32;           // zeroed by the host (hipMemsetAsync)
@@ -1292,7 +1434,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     tile_load(it.word_begin, nxt);
     // the table is cleared while the first tile's loads are in flight; a raw barrier, because __syncthreads() would also
     // drain vmcnt and with it those loads
-    if constexpr (USE_LDS) {
+    if constexpr (USE_LDS && REGS != REGS_BINS) {
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -1429,6 +1571,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         else my_kmers += wave_sum((uint32_t)__builtin_popcountll(kv));
 
         uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
+        if constexpr (REGS == REGS_BINS) regs.mode = 1u;                   // the word loop pushes without branches (BinRegs::mode)
 #pragma unroll 1
         for (int wi = 0; wi < SKETCH_WORDS_PER_THREAD; ++wi) {
             uint32_t z;
@@ -1471,12 +1614,23 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 asm volatile("" : "+v"(kvw));
                 (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
             }
+            if constexpr (REGS == REGS_BINS) {
+                if (regs.overflowed()) {                                       // a staging row ran full: the word again, straight to the fallback table
+                    regs.mode = 2u;
+                    uint32_t kvw = (uint32_t)kv;
+                    asm volatile("" : "+v"(kvw));
+                    (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+                    regs.mode = 1u;
+                }
+                regs.flush(lane);                                              // this word's 1 024 entries leave the wave's staging rows
+            }
             // rotate the window by one word
             c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = 0;
             r0 = r1;
             if constexpr (KMODE == KM_GT16) { r1 = r2; r2 = rcword(c2, cmask); } else { r1 = rcword(c1, cmask); }
             kv >>= 16;
         }
+        if constexpr (REGS == REGS_BINS) regs.mode = 0u;
     }
 
     if constexpr (DEFER) sigq_drain<true>(regs, kp.bitflip, p, sigq);
@@ -1503,7 +1657,7 @@ template <int ALGO, int KMODE, bool XLOW, int REGS>
 __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
-    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x;
+    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x + a.item_base;
     const WorkItem it = a.items[item];
     if (a.dirty[it.genome] == 0u) return;                                  // only the genomes the direct pass gave up
     const GenomeDesc gd = a.genomes[it.genome];
@@ -1524,18 +1678,16 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
     }
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
-                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type;
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, BinRegs>::type>::type;
     Regs regs;
     uint32_t *census;
-    const uint32_t part = it.slice >> 16;
-    if constexpr (USE_LDS) {
+    const uint32_t part = 0u;
+    if constexpr (REGS == REGS_BINS) {
+        regs = bin_regs_of<ALGO>(a, it.genome);
+        census = lds_regs;
+    } else if constexpr (USE_LDS) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
-        if constexpr (REGS == REGS_LDS_PARTS) {
-            regs.local_mask = a.nreg32 - 1u;
-            regs.part_shift = 31u - (uint32_t)__builtin_clz(a.nreg32);
-            regs.part = part;
-        }
         census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else {
@@ -1619,6 +1771,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
                     asm volatile("" : "+v"(m));
                     (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, m);
                 }
+                if constexpr (REGS == REGS_BINS) regs.flush(lane);
                 c0 = c1; c1 = c2; c2 = c3; c3 = 0;
                 r0 = r1;
                 if constexpr (KMODE == KM_GT16) { r1 = r2; r2 = rcword(c2, cmask); } else { r1 = rcword(c1, cmask); }
@@ -1795,7 +1948,9 @@ static hipError_t launch_stream_one(const SketchPlan &plan, const SketchArgs &ar
     auto kern = stream_sketch_kernel<ALGO, KMODE, XLOW, REGS>;
     SketchArgs a = args;
     a.stage_off = plan.lds_bytes;
-    const uint32_t lds = plan.lds_bytes + sketch_direct_stage_bytes(plan);
+    a.bin_lds_off = plan.lds_bytes + sketch_direct_stage_bytes(plan);
+    a.bin_wave_bytes = sketch_bin_wave_bytes(plan);
+    const uint32_t lds = a.bin_lds_off + (plan.threads / 64u) * a.bin_wave_bytes;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1809,10 +1964,10 @@ static hipError_t launch_stream_kmode(const SketchPlan &plan, const SketchArgs &
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
     if constexpr (ALGO != 0) {
-        if (plan.use_lds && plan.parts_log2) {
-            if (km == KM_16) return launch_stream_one<ALGO, KM_16, XLOW, REGS_LDS_PARTS>(plan, args, n, s);
-            if (km == KM_LT16) return launch_stream_one<ALGO, KM_LT16, XLOW, REGS_LDS_PARTS>(plan, args, n, s);
-            return launch_stream_one<ALGO, KM_GT16, XLOW, REGS_LDS_PARTS>(plan, args, n, s);
+        if (plan.bins) {
+            if (km == KM_16) return launch_stream_one<ALGO, KM_16, XLOW, REGS_BINS>(plan, args, n, s);
+            if (km == KM_LT16) return launch_stream_one<ALGO, KM_LT16, XLOW, REGS_BINS>(plan, args, n, s);
+            return launch_stream_one<ALGO, KM_GT16, XLOW, REGS_BINS>(plan, args, n, s);
         }
     }
     if (plan.use_lds) {
@@ -1859,27 +2014,26 @@ template <int ALGO, bool XLOW, int REGS>
 __global__ void __launch_bounds__(1024) aa_sketch_kernel(SketchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
-    const WorkItem it = a.items[blockIdx.x];
+    const uint32_t item = blockIdx.x + a.item_base;
+    const WorkItem it = a.items[item];
     const GenomeDesc gd = a.genomes[it.genome];
     const int k = a.k, p = a.p;
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
-                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, LdsPartRegs>::type>::type;
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, BinRegs>::type>::type;
     Regs regs;
     uint32_t *census;
-    const uint32_t part = it.slice >> 16;
-    if constexpr (USE_LDS) {
+    const uint32_t part = 0u;
+    if constexpr (REGS == REGS_BINS) {
+        regs = bin_regs_of<ALGO>(a, it.genome);
+        census = lds_regs;
+    } else if constexpr (USE_LDS) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
-        if constexpr (REGS == REGS_LDS_PARTS) {
-            regs.local_mask = a.nreg32 - 1u;
-            regs.part_shift = 31u - (uint32_t)__builtin_clz(a.nreg32);
-            regs.part = part;
-        }
         census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else {
-        regs.base = a.gregs + (uint64_t)blockIdx.x * a.nreg32;
+        regs.base = a.gregs + (uint64_t)item * a.nreg32;
         census = lds_regs;
     }
     // after the census + histogram words (16 + 72): the record counter, then the byte -> code table
@@ -1916,15 +2070,18 @@ __global__ void __launch_bounds__(1024) aa_sketch_kernel(SketchArgs a)
             }
         }
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-        if (done || i >= b1) continue;
-        const uint32_t n = b1 - i >= 16 ? 16u : (uint32_t)(b1 - i);
-        uint32_t w[4];
-        if (i + 16 <= genome_end) {                                            // (may run into the next record: those bytes are masked)
-            const uint4 q = load16_any(a.seq + i);
-            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
-        } else {                                                               // the genome's last bytes: never past the caller's buffer
-            w[0] = w[1] = w[2] = w[3] = 0;
-            for (uint32_t j = 0; j < n; ++j) w[j >> 2] |= (uint32_t)a.seq[i + j] << (8 * (j & 3));
+        // (a lane between records, or out of them, runs the 16 steps below with nothing valid: no divergent skip — the binned
+        // register mode ends every trip with a wave-wide flush)
+        const bool act = !done && i < b1;
+        const uint32_t n = !act ? 0u : (b1 - i >= 16 ? 16u : (uint32_t)(b1 - i));
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (act) {
+            if (i + 16 <= genome_end) {                                        // (may run into the next record: those bytes are masked)
+                const uint4 q = load16_any(a.seq + i);
+                w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+            } else {                                                           // the genome's last bytes: never past the caller's buffer
+                for (uint32_t j = 0; j < n; ++j) w[j >> 2] |= (uint32_t)a.seq[i + j] << (8 * (j & 3));
+            }
         }
         i += n;
 #pragma unroll
@@ -1946,23 +2103,27 @@ __global__ void __launch_bounds__(1024) aa_sketch_kernel(SketchArgs a)
             if (t <= Z_REDO) (void)add_kmer<ALGO, XLOW, true, false>(regs, m_lo, m_hi, vm, bitflip, p);   // (rare: the exact form)
             my_kmers += emit ? 1u : 0u;
         }
+        if constexpr (REGS == REGS_BINS) regs.flush(threadIdx.x & 63u);
     }
-    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, wave_sum(my_kmers), p, blockIdx.x);
+    finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, wave_sum(my_kmers), p, item);
 }
 
 template <int ALGO, bool XLOW>
 static hipError_t launch_aa_regs(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
 {
     auto go = [&](auto kern) {
-        const uint32_t lds = plan.lds_bytes + 16u + 256u;                       // + the record counter and the byte -> code table
+        SketchArgs a = args;
+        a.bin_lds_off = plan.lds_bytes + 16u + 256u;                             // + the record counter and the byte -> code table
+        a.bin_wave_bytes = sketch_bin_wave_bytes(plan);
+        const uint32_t lds = a.bin_lds_off + (plan.threads / 64u) * a.bin_wave_bytes;
         if (lds > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(n), dim3(plan.threads), lds, s, args);
+        hipLaunchKernelGGL(kern, dim3(n), dim3(plan.threads), lds, s, a);
         return hipGetLastError();
     };
-    if (plan.use_lds && plan.parts_log2) return go(aa_sketch_kernel<ALGO, XLOW, REGS_LDS_PARTS>);
+    if (plan.bins) return go(aa_sketch_kernel<ALGO, XLOW, REGS_BINS>);
     if (plan.use_lds) return go(aa_sketch_kernel<ALGO, XLOW, REGS_LDS>);
     return go(aa_sketch_kernel<ALGO, XLOW, REGS_GLOBAL>);
 }
@@ -2094,9 +2255,89 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// bins_apply_kernel — one workgroup per (genome, bin) of a binned launch: the bin's registers are built in LDS from the bin's
+// list (4 bytes per k-mer, read once, coalesced), the genome's fallback table is folded in if anything was spilled there, and the
+// registers leave as image-format bytes into the genome's one partial sketch; finalize_kernel does the rest as for any genome.
+// ------------------------------------------------------------------------------------------------------------
+template <int ALGO>
+__global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    const uint32_t bin = blockIdx.x, gi = blockIdx.y;
+    const uint32_t regs_per_bin = 1u << a.bin_shift, words = ALGO == 2 ? 2u * regs_per_bin : regs_per_bin;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) tab[i] = ALGO == 2 ? 0u : RANK_EMPTY;
+    __syncthreads();
+    const BinGenome bg = a.genomes[gi];
+    const uint32_t *list = a.lists + bg.list_off + (uint64_t)bin * bg.cap;
+    uint32_t n = a.cnt[(uint64_t)gi * a.bins + bin];
+    n = n < bg.cap ? n : bg.cap;
+    auto lds = [](uint32_t byte_addr) { return (__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr; };
+    (void)lds;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t e = list[i], v = e & 63u;
+        if (v == 63u) continue;
+        const uint32_t r = (e >> 6) & (regs_per_bin - 1u);
+        if constexpr (ALGO == 2) atomicOr(&tab[2u * r + (v >> 5)], 1u << (v & 31u));
+        else atomicMax(reinterpret_cast<int *>(tab) + r, (int)v);
+    }
+    __syncthreads();
+    if (a.spill[gi]) {                                                     // entries that found a row or a list full
+        const uint32_t *sl = a.slab + (uint64_t)gi * a.slab_words + (uint64_t)bin * words;
+        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
+            if constexpr (ALGO == 2) tab[i] |= sl[i];
+            else tab[i] = (uint32_t)max((int)tab[i], (int)sl[i]);
+        }
+        __syncthreads();
+    }
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)(a.virt0 + gi) * a.partial_stride) + (uint64_t)bin * (regs_per_bin >> 2);
+    for (uint32_t i = threadIdx.x; i < (regs_per_bin >> 2); i += blockDim.x) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint32_t r;
+            if constexpr (ALGO == 2) {
+                const uint32_t lo = tab[8u * i + 2u * b], hi = tab[8u * i + 2u * b + 1u];
+                r = 0;
+                if (lo | hi) {                                             // as finish_item: nlz bitmap -> hash4j prefix -> pack()
+                    const uint64_t x = (((uint64_t)hi << 32) | lo) << (a.p - 1);
+                    const uint32_t top = 63u - (uint32_t)__builtin_clzll(x);
+                    const uint32_t below = top >= 2 ? (uint32_t)(x >> (top - 2)) & 3u : (uint32_t)(x << (2 - top)) & 3u;
+                    r = (top << 2) | below;
+                }
+            } else {
+                r = tab[4u * i + b] + 1u;                                  // rho - 1, -1 = empty
+            }
+            o |= (r & 0xFFu) << (8 * b);
+        }
+        out[i] = o;
+    }
+    if (bin == 0u && threadIdx.x == 0u) {                                  // the genome's k-mer census: the sum over its work items
+        const uint32_t g = a.genome0 + gi;
+        uint32_t tot = 0;
+        for (uint32_t it = a.genome_item_begin[g]; it < a.genome_item_begin[g + 1]; ++it) tot += a.item_kmers[it];
+        a.item_kmers[a.virt0 + gi] = tot;
+    }
+}
+
+hipError_t launch_bins_apply(const BinApplyArgs &args, uint32_t n_group_genomes, hipStream_t stream)
+{
+    if (n_group_genomes == 0) return hipSuccess;
+    const uint32_t words = (args.algo == 2 ? 2u : 1u) << args.bin_shift, lds = words * 4u;
+    auto go = [&](auto kern) {
+        if (lds > 48u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(args.bins, n_group_genomes), dim3(1024), lds, stream, args);
+        return hipGetLastError();
+    };
+    return args.algo == 2 ? go(bins_apply_kernel<2>) : go(bins_apply_kernel<1>);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items, bool alt)
+SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items, bool alt, bool allow_bins)
 {
     SketchPlan s{};
     s.algo = algo; s.k = k; s.p = p; s.x_low = x_low; s.alt = alt;
@@ -2106,11 +2347,25 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
     s.partial_stride = (s.partial_bytes + 15u) & ~15u;
     s.lds_bytes = s.nreg32 * 4u;
     s.parts_log2 = 0;
-    while ((s.lds_bytes >> s.parts_log2) > 128u * 1024u) ++s.parts_log2;   // bucket-partitioned passes (LdsPartRegs)
-    s.use_lds = s.parts_log2 <= 4u;
-    if (!s.use_lds) s.parts_log2 = 0;
-    s.lds_bytes >>= s.parts_log2;
+    // tables beyond 128 KiB: binned (BinRegs; up to 256 bins of 128 KiB: HLL p = 16, ULL p = 15 .. 22), beyond that a table in global
+    // memory per work item and one atomic per k-mer (ULL p >= 23)
+    uint32_t bl = 0;
+    while ((s.lds_bytes >> bl) > 128u * 1024u) ++bl;
+    static const bool no_bins = getenv("LASH_NO_BINS") != nullptr;         // A/B knob: the global-atomic path for every large table
+    s.bins = bl > 0 && bl <= 8u && !no_bins && allow_bins;
+    s.use_lds = bl == 0 || s.bins;
+    if (s.bins) {
+        s.bins_log2 = bl;
+        s.bin_shift = (algo == 2 ? 14u : 15u);                             // registers per bin: 128 KiB of LDS table in bins_apply_kernel
+        s.bin_sub_shift = bl < 5u ? 5u - bl : 0u;                           // at least 32 staging rows per wave (see BinRegs)
+        const uint32_t mean = 1024u >> (bl + s.bin_sub_shift);              // staged entries per row and word of 16 k-mers per lane
+        uint32_t sq = 1; while (sq * sq < mean) ++sq;
+        s.bin_S = (mean + 4u * sq + 4u + 3u) & ~3u;                         // room for the mean + 4 sigma (rows of 16-byte chunks); more goes to the fallback table
+        s.lds_bytes = 0;                                                    // no table in the sketch kernels
+    }
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU
+    // 64 bins and more: a wave's staging rows take 9 .. 17 KiB — workgroups of four waves, so that two or three of them share a CU
+    if (s.bins && bl >= 6u) s.threads = 256u;
     // Small genomes with a small table (hll p<=13, ull p<=12): a 10 kbp genome fills 2.5 waves, and what limits such a
     // batch is per-workgroup latency (item / descriptor / first tile loads, flush), not issue slots -> 256-thread
     // workgroups, as many per CU as the table allows (100 000 x 10 kbp, hll p=10: 4.4 -> 2.7 ms).  HyperMinHash's 64 KiB
@@ -2126,10 +2381,11 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
         if (d >= (int)SIGQ_MIN_DEPTH && d <= 63) s.sigq_depth = (uint32_t)d;
     }
     if (!s.use_lds) s.lds_bytes = 0;
+    else if (s.bins) {}
     // Small tables (hll p<=13, ull p<=12) would let 4 workgroups = 8 waves/SIMD share a CU; the kernel is VALU-issue
     // bound and the extra waves only add LDS-atomic contention (hll p=13: 7.4e11 vs 8.1e11 k-mers/s).  Asking for 64 KiB
     // keeps it at the two workgroups per CU that the 64 KiB tables get.
-    else if (!many_small && s.threads == 512u && s.lds_bytes < 64u * 1024u) s.lds_bytes = 64u * 1024u;
+    else if (!many_small && !s.bins && s.threads == 512u && s.lds_bytes < 64u * 1024u) s.lds_bytes = 64u * 1024u;
     s.lds_bytes += 64u + 288u;                                             // per-wave census words + HLL header histogram after the registers
     return s;
 }
@@ -2141,6 +2397,7 @@ static uint32_t stage_stride_bytes(const SketchPlan &plan, bool direct, bool def
     return std::max(stage, stacks);
 }
 uint32_t sketch_direct_stage_bytes(const SketchPlan &plan) { return (plan.threads / 64u) * stage_stride_bytes(plan, true, true); }
+uint32_t sketch_bin_wave_bytes(const SketchPlan &plan) { return plan.bins ? ((1u << (plan.bins_log2 + plan.bin_sub_shift)) * (1u + plan.bin_S + 4u)) * 4u : 0u; }
 
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
@@ -2154,7 +2411,9 @@ static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uin
     a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile);
     a.stage_stride = stage_stride_bytes(plan, DIRECT, defer);              // deferring launches keep their lanes' stacks there
     a.sigq_depth = plan.sigq_depth;
-    const uint32_t lds = plan.lds_bytes + (plan.threads / 64u) * a.stage_stride;
+    a.bin_lds_off = plan.lds_bytes + (plan.threads / 64u) * a.stage_stride;
+    a.bin_wave_bytes = sketch_bin_wave_bytes(plan);
+    const uint32_t lds = a.bin_lds_off + (plan.threads / 64u) * a.bin_wave_bytes;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -2168,10 +2427,10 @@ static hipError_t launch_kmode(const SketchPlan &plan, const SketchArgs &args, u
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
     if constexpr (ALGO != 0) {                                  // HMH's table always fits
-        if (plan.use_lds && plan.parts_log2) {
-            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS_PARTS, DIRECT, ALT>(plan, args, n, s);
-            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS_PARTS, DIRECT, ALT>(plan, args, n, s);
-            return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS_PARTS, DIRECT, ALT>(plan, args, n, s);
+        if (plan.bins) {
+            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
+            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
+            return launch_one<ALGO, KM_GT16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
         }
     }
     if (plan.use_lds) {

@@ -153,11 +153,12 @@ def test_short_reads_fastq_like(ctx):
 
 
 @pytest.mark.parametrize("an,k,p", [("hll", 16, 16), ("hll", 25, 16), ("ull", 16, 15), ("ull", 12, 16), ("ull", 21, 17),
-                                    ("ull", 21, 18), ("ull", 9, 19), ("ull", 16, 20), ("ull", 30, 21)])
+                                    ("ull", 21, 18), ("ull", 9, 19), ("ull", 16, 20), ("ull", 30, 21), ("ull", 16, 22), ("ull", 21, 24)])
 def test_register_tables_larger_than_lds(ctx, an, k, p):
-    """2^p registers beyond 128 KiB of LDS: up to 16x that (hll p=16, ull p=15..18) the bucket space is covered in 2..16
-    passes with a 128 KiB LDS table each; larger tables (ull p>=19) live in HBM/L2 and take global atomics.  Multi-record,
-    multi-slice, dirty and empty genomes, through the direct route and the pack-first route."""
+    """2^p registers beyond 128 KiB of LDS.  Round 4: hll p=16 and ull p=15..22 are BINNED — every k-mer hashed once, a 4-byte entry
+    appended to the list of its bin (2^14 / 2^15 registers), one LDS pass per bin (bins_apply_kernel); ull p >= 23 keeps its table in
+    HBM/L2 and takes one global atomic per k-mer.  Multi-record, multi-slice, dirty and empty genomes, through the direct route and the
+    pack-first route."""
     import lash_amd
     g = O.synth_genome(8, 1_300_000)
     gs = [[O.synth_genome(7, 200_000).tobytes()], [b"ACGTNACGT" * 50], [], [g[:700_000].tobytes(), g[700_000:].tobytes()]]
