@@ -75,6 +75,7 @@ struct SketchPlan {
     // register tables beyond 128 KiB of LDS (HLL p = 16, ULL p = 15 .. 22): hash once, scatter entries into 2^bins_log2 bins per genome,
     // one LDS pass per bin (BinRegs / bins_apply_kernel).  use_lds stays true (no per-item global table), lds_bytes holds no table.
     bool     bins = false;
+    bool     bytes = false;       // byte registers in LDS with compare-and-swap updates (LdsByteRegs): hll p = 16, ull p = 15 .. 17
     uint32_t bins_log2 = 0, bin_shift = 0, bin_S = 0, bin_sub_shift = 0;
 };
 // per wave: bytes of LDS a binned launch needs for its bin counters and staging rows

@@ -46,7 +46,7 @@ constexpr uint32_t RANK_EMPTY = 0xFFFFFFFFu;                   // HyperMinHash /
 
 struct LdsRegs {
     uint32_t *base;
-    static constexpr bool BINS = false;
+    static constexpr bool BINS = false, BYTES = false;
     // The register table starts at LDS address 0 (the kernel has no static __shared__; checked at kernel entry), so the
     // word index goes straight into the DS address.  Through a pointer hipcc adds the table's link-time base (0) with a
     // v_add_u32 per k-mer; the update itself is fire-and-forget, nothing in the hashing loop reads the table back, and
@@ -69,7 +69,7 @@ struct LdsRegs {
 };
 struct GlobalRegs {                                            // (UltraLogLog p >= 23 only: a zeroed slab per work item)
     uint32_t *base;
-    static constexpr bool BINS = false;
+    static constexpr bool BINS = false, BYTES = false;
     static constexpr bool THR = false;
     __device__ __forceinline__ void smax(uint32_t, uint32_t) const {}
     __device__ __forceinline__ void bor_pair(uint32_t idx, uint32_t w, uint32_t v) const
@@ -93,7 +93,7 @@ struct GlobalRegs {                                            // (UltraLogLog p
 // slow, and only met by genomes whose k-mers pile into few buckets — a satellite repeat); bins_apply_kernel folds that table in
 // when the genome's flag is up.
 struct BinRegs {
-    static constexpr bool THR = false, BINS = true;
+    static constexpr bool THR = false, BINS = true, BYTES = false;
     uint32_t cnt_b, stage_b;      // LDS byte addresses of this wave's row counters [V] and staging rows [V][S]
     uint32_t S, V, sub_shift;     // slots per row; rows: V = bins << sub_shift (few bins: each has 2^sub_shift rows, a lane uses row
     uint32_t sub_lane;            //   lane & (2^sub_shift - 1) of its bin — 64 lanes on 2 counters would be 32-way LDS atomic conflicts)
@@ -204,6 +204,47 @@ struct BinRegs {
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
 
+// HyperLogLog p = 16 and UltraLogLog p = 15 .. 17 (round 4): the registers as BYTES — 2^p of them, 32 .. 128 KiB of LDS, ONE pass over
+// the genome where rounds 1-3 ran 2 .. 8 bucket-partitioned passes over 32-bit / 64-bit table words (and binning pays only from 8
+// bins on).  LDS has no byte atomics: the update reads the byte and, if the k-mer changes it, runs a compare-and-swap on its word.
+//   HyperLogLog: the byte is rho - 1 as a signed value, -1 = empty (as in the 32-bit tables); a k-mer changes it iff its own is larger.
+//   UltraLogLog: the byte is the register itself; hash4j's add — pack(unpack(r) | 1 << (nlz + p - 1)) — is the merge of r with the
+//   register 4 * (nlz + p - 1) of a sketch that holds only this k-mer (its unpack() is that single bit): ull_merge_fast, lash_device.h.
+struct LdsByteRegs {
+    static constexpr bool THR = false, BINS = false, BYTES = true;
+    int p;
+    static __device__ __forceinline__ uint32_t *word(uint32_t byte_addr) { return (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(byte_addr & ~3u); }
+    __device__ __forceinline__ void hll_max(uint32_t j, uint32_t raw) const        // raw = rho - 1; all ones = nothing
+    {
+        __attribute__((address_space(3))) uint32_t *w = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)(j & ~3u);
+        const uint32_t sh = (j & 3u) * 8u;
+        uint32_t cur = *w;
+        while ((int)raw > (int)(int8_t)(cur >> sh)) {
+            const uint32_t want = (cur & ~(0xFFu << sh)) | ((raw & 0xFFu) << sh);
+            if (__hip_atomic_compare_exchange_strong(w, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        }
+    }
+    __device__ __forceinline__ void ull_add(uint32_t idx, uint32_t nlz) const       // nlz & 63 == 63: nothing
+    {
+        if ((nlz & 63u) == 63u) return;
+        __attribute__((address_space(3))) uint32_t *w = (__attribute__((address_space(3))) uint32_t *)(uintptr_t)(idx & ~3u);
+        const uint32_t sh = (idx & 3u) * 8u, single = 4u * ((nlz & 63u) + (uint32_t)p - 1u);
+        uint32_t cur = *w;
+        for (;;) {
+            const uint32_t r = (cur >> sh) & 0xFFu, nr = ull_merge_fast(r, single);
+            if (nr == r) break;
+            const uint32_t want = (cur & ~(0xFFu << sh)) | (nr << sh);
+            if (__hip_atomic_compare_exchange_strong(w, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        }
+    }
+    __device__ __forceinline__ uint32_t get_word(uint32_t i) const { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(i * 4u); }
+    __device__ __forceinline__ uint32_t get(uint32_t) const { return 0u; }
+    __device__ __forceinline__ void smax(uint32_t, uint32_t) const {}
+    __device__ __forceinline__ void bor_first(uint32_t, int, uint32_t) const {}
+    __device__ __forceinline__ void bor_pair(uint32_t, uint32_t, uint32_t) const {}
+    static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+};
+
 // HyperMinHash, launches that defer signatures (process_word_defer).  The filter asks one question per k-mer — can its rank still
 // win its bucket? — so the table word answers it with ONE compare: the rank is stored as the largest value of the hash's rank bits
 // that still passes,
@@ -214,7 +255,7 @@ struct BinRegs {
 // zeros the threshold is 0 (x16 must be 0) and the full update decides.  get() turns the word back into lz << 10 | sig.
 struct LdsThrRegs {
     uint32_t *base;
-    static constexpr bool THR = true, BINS = false;
+    static constexpr bool THR = true, BINS = false, BYTES = false;
     static __device__ __forceinline__ uint32_t encode(uint32_t lzm1, uint32_t sig)
     {
         const uint32_t m = lzm1 < 16u ? lzm1 : 16u;
@@ -237,7 +278,7 @@ struct LdsThrRegs {
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
 
-enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_BINS = 2 };
+enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_BINS = 2, REGS_BYTES = 3 };
 
 // ------------------------------------------------------------------------------------------------------------
 // the three add_kmer rules.  `vm` is 0 or ~0: invalid k-mers degrade to no-ops (max with "empty", OR 0).
@@ -305,6 +346,7 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             uint32_t raw = ffbh_u32(gh);                                        // gh == 0 -> "empty" (nothing happens; re-run by the caller)
             if constexpr (MASKED) raw |= ~vm;
             if constexpr (Regs::BINS) regs.push(j, raw);                        // (its low six bits: 63 = nothing)
+            else if constexpr (Regs::BYTES) regs.hll_max(j, raw);
             else regs.smax(j, raw);
             return gh;
         }
@@ -318,6 +360,7 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             uint32_t raw = clz64_nz(alignbit(hh, hl, 32 - p), (hl << p) | (1u << (p - 1)));
             if constexpr (MASKED) raw |= ~vm;
             if constexpr (Regs::BINS) regs.push(jh, raw);
+            else if constexpr (Regs::BYTES) regs.hll_max(jh, raw);
             else regs.smax(jh, raw);
             return 1u;
         }
@@ -327,6 +370,7 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
         else raw = clz64_nz(hh, hl | pm);
         if constexpr (MASKED) raw |= ~vm;
         if constexpr (Regs::BINS) regs.push(j, raw);
+        else if constexpr (Regs::BYTES) regs.hll_max(j, raw);
         else regs.smax(j, raw);
         return hh;
     } else {
@@ -341,10 +385,11 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             hh = (uint32_t)(g >> 32); hl = (uint32_t)g;
             th = alignbit(hh, hl, 32 - p) ^ (hh >> (28 - p));
             // th != 0 -> nlz = v_ffbh(th) < 32: always the pair's first word; th == 0 -> push nothing (re-run by the caller)
-            if constexpr (Regs::BINS) {
+            if constexpr (Regs::BINS || Regs::BYTES) {
                 uint32_t nlz = ffbh_u32(th);                                     // th == 0 -> all ones -> 63 = nothing
                 if constexpr (MASKED) nlz |= ~vm;
-                regs.push(hh >> (32 - p), nlz);
+                if constexpr (Regs::BINS) regs.push(hh >> (32 - p), nlz);
+                else regs.ull_add(hh >> (32 - p), nlz);
                 return th;
             }
             uint32_t one;
@@ -360,6 +405,10 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             const uint32_t nlz = clz64_nz(th, tl);                           // 0..=64-p
             if constexpr (Regs::BINS) {
                 regs.push(hh >> (32 - p), MASKED ? (nlz | ~vm) : nlz);
+                return th;
+            }
+            if constexpr (Regs::BYTES) {
+                regs.ull_add(hh >> (32 - p), MASKED ? (nlz | ~vm) : nlz);
                 return th;
             }
             uint32_t val = 1u << (nlz & 31u);
@@ -1272,6 +1321,23 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
     // table words -> registers of the image (see "register spaces" at the top of the file)
     auto hmh_reg = [](uint32_t raw) { return (int32_t)raw < 0 ? 0u : raw + 0x400u; };       // (lz - 1) << 10 | sig, -1 = empty -> lz << 10 | sig, 0
     auto hll_reg = [](uint32_t raw) { return raw + 1u; };                                     // rho - 1, -1 = empty -> rho, 0
+    if constexpr (REGS == REGS_BYTES) {
+        // byte tables: UltraLogLog bytes are the registers; HyperLogLog bytes are rho - 1 (0xFF = empty)
+        for (uint32_t i = threadIdx.x; i < ((1u << p) >> 2); i += blockDim.x) {
+            uint32_t w = regs.get_word(i);
+            if constexpr (ALGO == 1) w = ((w & 0x7F7F7F7Fu) + 0x01010101u) ^ (w & 0x80808080u);      // + 1 in every byte, no carry across (0xFF -> 0)
+            put(i, w);
+        }
+        if constexpr (ALGO == 1) {
+            if (sole) {
+                __syncthreads();
+                if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
+            }
+        } else {
+            if (sole && threadIdx.x == 0) write_header(img, a.lay.hdr_tpl, a.alpha_bits, 1ull << p, 0, 0.0, p);
+        }
+        return;
+    }
     if constexpr (ALGO == 0) {
         for (uint32_t i = threadIdx.x; i < HMH_M / 2; i += blockDim.x)
             put(i, hmh_reg(regs.get(2 * i)) | (hmh_reg(regs.get(2 * i + 1)) << 16));
@@ -1346,13 +1412,18 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<DEFER, LdsThrRegs, typename std::conditional<REGS == REGS_LDS, LdsRegs,
-                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, BinRegs>::type>::type>::type;
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs,
+                                           typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteRegs>::type>::type>::type>::type;
     Regs regs;
     uint32_t *census;
     const uint32_t part = 0u;
     if constexpr (REGS == REGS_BINS) {
         regs = bin_regs_of<ALGO>(a, it.genome);                            // no table here: entries for bins_apply_kernel
         census = lds_regs;
+    } else if constexpr (REGS == REGS_BYTES) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
+        regs.p = p;
+        census = lds_regs + a.nreg32;
     } else if constexpr (USE_LDS) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
@@ -1678,13 +1749,19 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
     }
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
-                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, BinRegs>::type>::type;
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs,
+                                           typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteRegs>::type>::type>::type;
     Regs regs;
     uint32_t *census;
     const uint32_t part = 0u;
     if constexpr (REGS == REGS_BINS) {
         regs = bin_regs_of<ALGO>(a, it.genome);
         census = lds_regs;
+    } else if constexpr (REGS == REGS_BYTES) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
+        regs.p = p;
+        census = lds_regs + a.nreg32;
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else if constexpr (USE_LDS) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
@@ -1964,6 +2041,11 @@ static hipError_t launch_stream_kmode(const SketchPlan &plan, const SketchArgs &
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
     if constexpr (ALGO != 0) {
+        if (plan.bytes) {
+            if (km == KM_16) return launch_stream_one<ALGO, KM_16, XLOW, REGS_BYTES>(plan, args, n, s);
+            if (km == KM_LT16) return launch_stream_one<ALGO, KM_LT16, XLOW, REGS_BYTES>(plan, args, n, s);
+            return launch_stream_one<ALGO, KM_GT16, XLOW, REGS_BYTES>(plan, args, n, s);
+        }
         if (plan.bins) {
             if (km == KM_16) return launch_stream_one<ALGO, KM_16, XLOW, REGS_BINS>(plan, args, n, s);
             if (km == KM_LT16) return launch_stream_one<ALGO, KM_LT16, XLOW, REGS_BINS>(plan, args, n, s);
@@ -2020,13 +2102,19 @@ __global__ void __launch_bounds__(1024) aa_sketch_kernel(SketchArgs a)
     const int k = a.k, p = a.p;
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
-                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs, BinRegs>::type>::type;
+                                           typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs,
+                                           typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteRegs>::type>::type>::type;
     Regs regs;
     uint32_t *census;
     const uint32_t part = 0u;
     if constexpr (REGS == REGS_BINS) {
         regs = bin_regs_of<ALGO>(a, it.genome);
         census = lds_regs;
+    } else if constexpr (REGS == REGS_BYTES) {
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
+        regs.p = p;
+        census = lds_regs + a.nreg32;
+        for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else if constexpr (USE_LDS) {
         if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_regs != 0u) __builtin_trap();
         regs.base = lds_regs;
@@ -2123,6 +2211,7 @@ static hipError_t launch_aa_regs(const SketchPlan &plan, const SketchArgs &args,
         hipLaunchKernelGGL(kern, dim3(n), dim3(plan.threads), lds, s, a);
         return hipGetLastError();
     };
+    if (plan.bytes) return go(aa_sketch_kernel<ALGO, XLOW, REGS_BYTES>);
     if (plan.bins) return go(aa_sketch_kernel<ALGO, XLOW, REGS_BINS>);
     if (plan.use_lds) return go(aa_sketch_kernel<ALGO, XLOW, REGS_LDS>);
     return go(aa_sketch_kernel<ALGO, XLOW, REGS_GLOBAL>);
@@ -2352,6 +2441,10 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
     uint32_t bl = 0;
     while ((s.lds_bytes >> bl) > 128u * 1024u) ++bl;
     static const bool no_bins = getenv("LASH_NO_BINS") != nullptr;         // A/B knob: the global-atomic path for every large table
+    static const bool no_bytes = getenv("LASH_NO_BYTES") != nullptr;       // A/B knob: bins instead of byte tables
+    // up to 128 KiB of BYTE registers (hll p = 16, ull p = 15 .. 17): one pass, compare-and-swap updates (LdsByteRegs); binning pays from 8 bins on
+    s.bytes = bl > 0 && (1u << p) <= 128u * 1024u && algo != 0 && !no_bytes;
+    if (s.bytes) { bl = 0; s.nreg32 = (1u << p) >> 2; s.lds_bytes = s.nreg32 * 4u; }
     s.bins = bl > 0 && bl <= 8u && !no_bins && allow_bins;
     s.use_lds = bl == 0 || s.bins;
     if (s.bins) {
@@ -2427,6 +2520,11 @@ static hipError_t launch_kmode(const SketchPlan &plan, const SketchArgs &args, u
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
     if constexpr (ALGO != 0) {                                  // HMH's table always fits
+        if (plan.bytes) {
+            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_BYTES, DIRECT, ALT>(plan, args, n, s);
+            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_BYTES, DIRECT, ALT>(plan, args, n, s);
+            return launch_one<ALGO, KM_GT16, XLOW, REGS_BYTES, DIRECT, ALT>(plan, args, n, s);
+        }
         if (plan.bins) {
             if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
             if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
