@@ -282,6 +282,7 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
         BinApplyArgs ba{};
         ba.lists = sa.bin_lists; ba.cnt = br.d_cnt; ba.slab = sa.bin_slab; ba.spill = br.d_spill; ba.genomes = sa.bin_genomes;
         ba.partials = sa.partials; ba.item_kmers = sa.item_kmers; ba.genome_item_begin = d_item_begin;
+        ba.items = sa.items; ba.nvalid = sa.nvalid; ba.k = prm->k;
         ba.partial_stride = sa.partial_stride; ba.virt0 = n_items + g0; ba.genome0 = g0;
         ba.bins = B; ba.bin_shift = plan.bin_shift; ba.slab_words = br.slab_words; ba.algo = prm->algo; ba.p = prm->p;
         HIPCHK(ctx, launch_bins_apply(ba, ng, ctx->stream));

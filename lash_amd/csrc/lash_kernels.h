@@ -86,6 +86,9 @@ struct BinApplyArgs {
     uint8_t  *partials;           // the group's genomes' "virtual" partials: genome gi of the group at partials + (virt0 + gi) * partial_stride
     uint32_t *item_kmers;         // ... and its k-mer count at item_kmers[virt0 + gi] = the sum over its real items
     const uint32_t *genome_item_begin;   // real items of genome g: [genome_item_begin[g], genome_item_begin[g + 1])
+    const WorkItem *items;               // ... of which those that begin beyond the genome's surviving bases never ran (as in finalize_kernel)
+    const uint64_t *nvalid;              // NULL: every item ran
+    int       k;
     uint64_t  partial_stride;
     uint32_t  virt0, genome0;
     uint32_t  bins, bin_shift, slab_words;

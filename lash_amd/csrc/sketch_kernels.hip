@@ -2402,8 +2402,11 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
     }
     if (bin == 0u && threadIdx.x == 0u) {                                  // the genome's k-mer census: the sum over its work items
         const uint32_t g = a.genome0 + gi;
+        uint64_t nk = ~0ull;
+        if (a.nvalid) { const uint64_t L = a.nvalid[g]; nk = L >= (uint64_t)a.k ? L - (uint64_t)a.k + 1 : 0; }
         uint32_t tot = 0;
-        for (uint32_t it = a.genome_item_begin[g]; it < a.genome_item_begin[g + 1]; ++it) tot += a.item_kmers[it];
+        for (uint32_t it = a.genome_item_begin[g]; it < a.genome_item_begin[g + 1]; ++it)
+            if ((uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];      // (a slice beyond the surviving bases never ran)
         a.item_kmers[a.virt0 + gi] = tot;
     }
 }
