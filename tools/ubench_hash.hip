@@ -36,30 +36,34 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
                 acc ^= (uint32_t)lo ^ (uint32_t)(hi >> 32) ^ (uint32_t)hi;
             } else if constexpr (MODE == 4) {     // hll p=14 k=21 (BASELINE configs[2]): 64-bit windows + xxh3_64 + rule + ds_max
                 const uint32_t c2 = c1 * 0x9E3779B1u, r2 = rcword(c2);
-                const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0, fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
-                const uint64_t f64 = (((uint64_t)fh << 32) | fl) >> 22;              // 64 - 2k, k = 21
-                const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0, rh = r ? alignbit(r2, r1, 2 * r) : r1;
-                const uint64_t r64 = (((uint64_t)rh << 32) | rl) & ((1ull << 42) - 1ull);
-                const uint64_t cn = f64 < r64 ? f64 : r64;
+                // the kernel's canon_gt16<21>: the window's halves as fields at compile-time places, the minimum through a scalar-pair mask
+                constexpr int D = 10;
+                const int s = 2 * r + D;
+                const uint32_t f_lo = s < 32 ? alignbit(c0, c1, 32 - s) : s == 32 ? c1 : alignbit(c1, c2, 64 - s);
+                const uint32_t f_hi = s <= 32 ? (uint32_t)__builtin_amdgcn_ubfe(c0, 32 - s, D) : alignbit(c0, c1, 32 - 2 * r) >> (32 - D);
+                const uint32_t q_lo = r ? alignbit(r1, r0, 2 * r) : r0;
+                const uint32_t q_hi = s <= 32 ? (uint32_t)__builtin_amdgcn_ubfe(r1, 2 * r, D) : alignbit(r2, r1, 2 * r) & ((1u << D) - 1u);
+                uint32_t cn_lo, cn_hi;
+                min_u64(f_lo, f_hi, q_lo, q_hi, cn_lo, cn_hi);
+                const uint64_t cn = ((uint64_t)cn_hi << 32) | cn_lo;
                 const uint64_t hh64 = xxh3_64_8b_pre((uint32_t)cn, (uint32_t)(cn >> 32), bitflip);   // (the kernel's fast form: add_kmer<1, FAST>)
                 const uint32_t hh = (uint32_t)(hh64 >> 32), hl = (uint32_t)hh64;
-                asm volatile("ds_max_u32 %0, %1" ::"v"(((hl ^ alignbit(hh, hl, 28)) & 16383u) << 2), "v"(ffbh_u32(hh) + 1u) : "memory");
+                asm volatile("ds_max_i32 %0, %1" ::"v"(((hl ^ alignbit(hh, hl, 28)) & 16383u) << 2), "v"(ffbh_u32(hh)) : "memory");   // round 4: rho - 1, signed
             } else if constexpr (MODE == 5) {     // ull p=12 k=16 (configs[4]): xxh3_64 + rule + ds_or
                 const uint64_t hh64 = xxh3_64_8b_pre(can, 0u, bitflip);                             // (add_kmer<2, FAST>)
                 const uint32_t hh = (uint32_t)(hh64 >> 32), hl = (uint32_t)hh64;
                 const uint32_t th = alignbit(hh, hl, 32 - 12) ^ (hh >> (28 - 12));
-                const uint32_t bit = ffbh_u32(th) + 11u;
-                asm volatile("ds_or_b32 %0, %1" ::"v"(((hh >> 20) * 2u + ((bit >> 5) & 1u)) << 2), "v"((th < 1u ? th : 1u) << (bit & 31u)) : "memory");
+                asm volatile("ds_or_b32 %0, %1" ::"v"((hh >> 17) & ~7u), "v"((th < 1u ? th : 1u) << (ffbh_u32(th) & 31u)) : "memory");   // round 4: nlz bitmap, first word
             } else if constexpr (MODE == 6) {     // deferred signatures, step 1: the rank half of the hash alone
                 acc ^= xxh3_128_4b_hmh_rank(can, bitflip);
             } else {                              // the sketch kernel's own fast path (add_kmer<HMH, x = high half, FAST>):
                 uint32_t xh, sig;                 // only the bits the register rule reads, + the rule (+ the LDS atomic, MODE 3)
                 xxh3_128_4b_hmh_fast(can, bitflip, xh, sig);
                 const uint32_t t18 = (xh << 14) | 0x3FFFu;
-                const uint32_t reg = ((ffbh_u32(t18) << 10) | sig) + 0x400u;
+                const uint32_t reg = (ffbh_u32(t18) << 10) | sig;                                  // round 4: (lz - 1) << 10 | sig, signed max
                 const uint32_t bucket = xh >> 18;
                 if constexpr (MODE == 2) acc ^= reg + bucket;
-                else asm volatile("ds_max_u32 %0, %1" ::"v"(bucket << 2), "v"(reg) : "memory");
+                else asm volatile("ds_max_i32 %0, %1" ::"v"(bucket << 2), "v"(reg) : "memory");
             }
         }
         c0 = c1; c1 = c1 * 1664525u + 1013904223u + acc;
@@ -75,29 +79,31 @@ __global__ void __launch_bounds__(1024) hash_bench(unsigned long long *cycles, u
 }
 
 // The deferring kernel's stream (sketch_kernels.hip, process_word_defer) in the same harness: groups of four k-mers — rank half,
-// register read back, test — STAGE 0; + append to the wave's list — STAGE 1; + the full update of 64 waiting k-mers — STAGE 2 (all
+// threshold word read back, test — STAGE 0; + push on the lane's stack — STAGE 1; + the drain rounds (full update, ds_min) — STAGE 2 (all
 // of it).  The table fills as in a real work item (iters * 16 * 512 k-mers into 16 384 buckets per workgroup).
 __device__ __forceinline__ uint32_t ub_lds_load(uint32_t b) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b; }
 __device__ __forceinline__ void ub_lds_store(uint32_t b, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b = v; }
 template <int STAGE>
 __global__ void __launch_bounds__(1024) defer_bench(unsigned long long *cycles, uint32_t *sink, int iters, uint64_t bitflip64)
 {
+    // round 4 (sketch_kernels.hip: LdsThrRegs, SigQueue, process_word_defer): the table word is the threshold, every lane keeps a stack
     const BitFlip bitflip = BitFlip::vector(bitflip64);
     extern __shared__ uint32_t lds[];
-    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0;
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) lds[i] = 0xFFFFFFFFu;
     __syncthreads();
     uint32_t c0 = threadIdx.x * 2654435761u + blockIdx.x, c1 = c0 ^ 0x9E3779B9u;
     uint32_t acc = 0;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t base_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536u + (threadIdx.x >> 6) * 1600u));
-    uint32_t pos_b = base_b;
+    constexpr uint32_t DEPTH = 7;
+    const uint32_t lane_b = 65536u + (threadIdx.x >> 6) * 1792u + lane * DEPTH * 4u, lim = lane_b + 4u * (DEPTH - 4u);
+    uint32_t ptr = lane_b;
     unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
         const uint32_t r0 = rcword(c0), r1 = rcword(c1);
 #pragma unroll
         for (int g = 0; g < 16; g += 4) {
-            uint32_t can[4], x18[4], cur[4];
+            uint32_t can[4], x16[4], cur[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int r = g + j;
@@ -106,27 +112,30 @@ __global__ void __launch_bounds__(1024) defer_bench(unsigned long long *cycles, 
                 can[j] = fwd < rc ? fwd : rc;
                 const uint32_t xh = xxh3_128_4b_hmh_rank(can[j], bitflip);
                 cur[j] = ub_lds_load((xh >> 16) & 0xFFFCu);
-                x18[j] = xh & 0x3FFFFu;
+                x16[j] = xh >> 2;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bool pass = x18[j] <= (0x7FFFFu >> ((cur[j] >> 10) & 31u));
-                if constexpr (STAGE == 0) { acc += pass; continue; }
-                const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (pass) ub_lds_store(at * 4u + pos_b, can[j]);
-                pos_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pos_b + 4u * (uint32_t)__builtin_popcountll(m)));
+                if constexpr (STAGE == 0) { acc += (x16[j] & 0xFFFFu) <= (cur[j] >> 16); continue; }
+                ub_lds_store(ptr, can[j]);
+                uint32_t inc;
+                asm("v_cmp_le_u32_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:WORD_1\n\tv_cndmask_b32_e64 %0, 0, 4, vcc" : "=v"(inc) : "v"(x16[j]), "v"(cur[j]) : "vcc");
+                ptr += inc;
             }
             if constexpr (STAGE >= 1) {
-                while (pos_b >= base_b + 256u) {
-                    pos_b -= 256u;
-                    if constexpr (STAGE == 2) {
-                        const uint32_t c = ub_lds_load(pos_b + lane * 4u);
-                        uint32_t xh, sig;
-                        xxh3_128_4b_hmh_fast(c, bitflip, xh, sig);
-                        const uint32_t t18 = (xh << 14) | 0x3FFFu;
-                        asm volatile("ds_max_u32 %0, %1" ::"v"((xh >> 18) << 2), "v"(((ffbh_u32(t18) << 10) | sig) + 0x400u) : "memory");
-                    }
+                if (__builtin_amdgcn_ballot_w64(ptr > lim) != 0ull) {
+                    do {
+                        if (ptr != lane_b) {
+                            ptr -= 4u;
+                            if constexpr (STAGE == 2) {
+                                const uint32_t c = ub_lds_load(ptr);
+                                uint32_t xh, sig;
+                                xxh3_128_4b_hmh_fast(c, bitflip, xh, sig);
+                                const uint32_t lzm1 = ffbh_u32((xh << 14) | 0x3FFFu);
+                                asm volatile("ds_min_u32 %0, %1" ::"v"((xh >> 18) << 2), "v"(((0xFFFF0000u >> lzm1) & 0xFFFF0000u) | (0xFFFEu - sig)) : "memory");
+                            }
+                        }
+                    } while (__builtin_amdgcn_ballot_w64(ptr > lim) != 0ull);
                 }
             }
         }
@@ -186,9 +195,9 @@ int main()
     run<5>("ull p12 k16 stream", 200, d_cyc, d_sink);
     // deferred signatures (HyperMinHash, long work items): 600 iterations = 300 k-mers per bucket, a 5 Mbp work item's load
     run<6>("hmh rank half only", 200, d_cyc, d_sink);
-    run_kernel(defer_bench<0>, "defer: + read + test", 600, d_cyc, d_sink, 65536 + 12800);
-    run_kernel(defer_bench<1>, "defer: + append", 600, d_cyc, d_sink, 65536 + 12800);
-    run_kernel(defer_bench<2>, "defer: hmh k16 stream", 600, d_cyc, d_sink, 65536 + 12800);
+    run_kernel(defer_bench<0>, "defer: + read + test", 600, d_cyc, d_sink, 65536 + 14336);
+    run_kernel(defer_bench<1>, "defer: + append", 600, d_cyc, d_sink, 65536 + 14336);
+    run_kernel(defer_bench<2>, "defer: hmh k16 stream", 600, d_cyc, d_sink, 65536 + 14336);
     run<3>("+ ds_max_u32 (600)", 600, d_cyc, d_sink);
     return 0;
 }
