@@ -232,8 +232,10 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
                    "clock_source": "tools/ubench_hash (s_memtime / s_memrealtime) in this job" if clock_ghz else "datasheet maximum",
                    "sections": [{"name": x["name"], "valu_per_kmer": x["valu_per_kmer"], "cycles_per_kmer": x["cycles_per_kmer"]} for x in aj["sections"]],
                    "source": "profiles/r04/isa_cost/%s.txt (tools/isa_audit.sh: hot blocks of %s from hipcc's listing x the issue costs of "
-                             "profiles/r04/isa_cost/costs.json, measured by tools/ubench_isa at 4 waves per SIMD); per-word and per-tile bookkeeping "
-                             "outside the priced blocks is not in the sum" % (audit, aj["kernel"].replace("void lash::", "").split("(")[0])}
+                             "profiles/r04/isa_cost/costs.json, measured by tools/ubench_isa at 4 waves per SIMD, x the mixed-stream factor %.3f of "
+                             "profiles/r04/isa_cost/mix_factor.json: tools/ubench_hash's rank-half stream measured / priced the same way); per-word "
+                             "and per-tile bookkeeping outside the priced blocks is not in the sum"
+                             % (audit, aj["kernel"].replace("void lash::", "").split("(")[0], aj.get("mix_factor", 1.0))}
         except Exception:
             mix = None
     # the absolute figure beside the self-referential one: wave-instructions issued per second against the chip's issue peak

@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--measured", type=float, default=None, help="measured cycles per wave-k-mer, printed beside the prediction")
     ap.add_argument("--measured-valu", type=float, default=None, help="measured SQ_INSTS_VALU per k-mer (per lane)")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--mix-factor", default=None, help="JSON {factor: F}: measured / predicted of an independent stream (tools/ubench_hash's rank-half stream "
+                    "priced the same way): instructions of different classes overlap part of their issue, the pure-stream costs add up ~8 %% high")
     args = ap.parse_args()
     ks = parse_kernels(args.listing)
     match = [n for n in ks if args.kernel in n]
@@ -253,12 +255,19 @@ def main():
         grand_c += sec_c
         grand_v += sec_v
         out_sections.append({"name": name, "select": sel, "blocks": len(labels), "kmers_per_lane": kmers, "valu_per_kmer": sec_v, "cycles_per_kmer": sec_c})
+    factor, fsrc = 1.0, None
+    if args.mix_factor and os.path.exists(args.mix_factor):
+        fj = json.load(open(args.mix_factor))
+        factor, fsrc = fj["factor"], fj.get("source")
+    raw_c = grand_c
+    grand_c *= factor
     if args.section:
         print("\nVALU wave-instructions per k-mer, sections together: %.2f%s" % (grand_v, ("   measured (SQ_INSTS_VALU): %.2f" % args.measured_valu) if args.measured_valu else ""))
+        print("sum of count x pure-stream cost: %.1f cycles per wave-k-mer%s" % (raw_c, ("; x mixed-stream factor %.3f (%s)" % (factor, fsrc)) if fsrc else ""))
         print("predicted VALU issue cycles per wave-k-mer: %.1f%s" % (grand_c, ("   measured: %.1f  (predicted / measured %.2f)" % (args.measured, grand_c / args.measured)) if args.measured else ""))
     if args.json:
         json.dump({"kernel": match[0], "listing": os.path.basename(args.listing), "costs": os.path.relpath(args.costs, ROOT), "sections": out_sections,
-                   "valu_per_kmer": grand_v, "cycles_per_kmer": grand_c, "measured_cycles_per_kmer": args.measured,
+                   "valu_per_kmer": grand_v, "cycles_per_kmer": grand_c, "pure_stream_cycles_per_kmer": raw_c, "mix_factor": factor, "measured_cycles_per_kmer": args.measured,
                    "measured_valu_per_kmer": args.measured_valu}, open(args.json, "w"), indent=1)
 
 
