@@ -199,13 +199,7 @@ struct BinsRun {
     uint32_t slab_words = 0, max_group = 0;
     bool fits = true;
 };
-static uint32_t bins_chunk_entries(const SketchPlan &plan)
-{
-    const uint32_t m_row = std::max(1u, 1024u >> (plan.bins_log2 + plan.bin_sub_shift));
-    return ((m_row + 2u) * 8u + 3u) & ~3u;                            // about eight flushes of a row
-}
-static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector<uint64_t> &entries_of_genome, const std::vector<uint32_t> &waves_of_genome,
-                        uint32_t n_genomes, BinsRun &br)
+static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector<uint64_t> &entries_of_genome, uint32_t n_genomes, BinsRun &br)
 {
     const uint32_t B = 1u << plan.bins_log2;
     br.slab_words = plan.nreg32;                                     // HLL: 2^p words, ULL: 2 * 2^p
@@ -266,7 +260,6 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
     sa.bin_slab = static_cast<uint32_t *>(ctx->bins_slab.ptr);
     sa.bin_spill = br.d_spill;
     sa.bins = B; sa.bin_shift = plan.bin_shift; sa.bin_S = plan.bin_S; sa.bin_sub_shift = plan.bin_sub_shift; sa.bin_slab_words = br.slab_words;
-    sa.bin_chunk = bins_chunk_entries(plan);
     sa.item_order = nullptr;
     uint32_t g0 = 0;
     for (uint32_t g1 : br.group_end) {
@@ -452,12 +445,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         // the genome's fallback table if its lists run full
         std::vector<uint64_t> entries(n_genomes, 0);
         const uint64_t tile_words = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
-        std::vector<uint32_t> waves(n_genomes, 0);
-        for (const WorkItem &w : items) {
-            entries[w.genome] += ((w.word_end - w.word_begin + tile_words - 1) / tile_words) * tile_words * 16;
-            waves[w.genome] += (pk->direct ? 2u : 1u) * (plan.threads / 64u);                 // (a genome handed to the compacting kernel is worked on twice)
-        }
-        if ((rc = bins_prepare(ctx, plan, entries, waves, n_genomes, bins_run_state))) return rc;
+        for (const WorkItem &w : items) entries[w.genome] += ((w.word_end - w.word_begin + tile_words - 1) / tile_words) * tile_words * 16;
+        if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
         if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
     }
     if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
@@ -696,9 +685,7 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
             const uint64_t e = descs[g].byte_len + 32 * (descs[g].rec_end - descs[g].rec_begin);
             entries[g] = e + e / 4 + (uint64_t)plan.threads * 256;
         }
-        std::vector<uint32_t> waves(n_genomes);
-        for (uint32_t g = 0; g < n_genomes; ++g) waves[g] = (item_begin[g + 1] - item_begin[g]) * (plan.threads / 64u);
-        if ((rc = bins_prepare(ctx, plan, entries, waves, n_genomes, bins_run_state))) return rc;
+        if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
         if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
     }
     if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;

@@ -53,7 +53,7 @@ struct SketchArgs {
     uint32_t         *bin_slab;   // [genomes of the group][bin_slab_words] full-size fallback tables (zero / 0xFF-filled)
     uint32_t         *bin_spill;  // [genomes of the group] set when a genome's fallback table holds something
     const BinGenome  *bin_genomes;   // [genomes of the group]
-    uint32_t          bins, bin_shift, bin_S, bin_sub_shift, bin_chunk;
+    uint32_t          bins, bin_shift, bin_S, bin_sub_shift;
     uint32_t          bin_lds_off, bin_wave_bytes;   // LDS: the waves' counter + staging areas
     uint32_t          bin_slab_words;
     uint32_t          bin_genome0;                  // first genome of the group
