@@ -284,6 +284,28 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
     return LASH_OK;
 }
 
+// UltraLogLog p >= 23: every work item updates a table of its own in global memory (2^p x 8 bytes: 64 MiB at p = 23, 512 MiB at
+// p = 26).  The items of a call run a chunk at a time so that the tables of one chunk fit a budget (round 4; a table per item of
+// the whole call was 256 GB for 200 genomes at p = 23); launch(sa, items) queues the sketch kernels of an item range.
+template <class Launch>
+static int global_run(lash_ctx *ctx, const SketchPlan &plan, SketchArgs sa, uint32_t n_items, Launch launch)
+{
+    static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+    const uint64_t table = (uint64_t)plan.nreg32 * 4;
+    const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_items ? n_items : 1, budget / table));
+    int rc;
+    if ((rc = reserve(ctx, ctx->gregs, (size_t)per * table + 256))) return rc;
+    sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
+    sa.item_order = nullptr;
+    for (uint32_t i0 = 0; i0 < n_items; i0 += per) {
+        const uint32_t n = std::min(per, n_items - i0);
+        HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n * table, ctx->stream));
+        sa.item_base = i0;
+        if ((rc = launch(sa, n))) return rc;
+    }
+    return LASH_OK;
+}
+
 int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, EvSet *ev)
 {
     const uint32_t n_genomes = pk->n_genomes;
@@ -324,6 +346,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     const uint64_t slice_factor = slice_factor_env ? slice_factor_env : (defer_eligible ? (equal_genomes ? 1 : 2) : 4);   // tuning knob: the
     // sketch time is flat from 2x to 24x the slots (4.87-4.91 ms on the default bench), the finalize time grows with it
     uint64_t target = total_words / (slots * slice_factor) + 1;
+    // a table in global memory per work item (UltraLogLog p >= 23: 64 .. 512 MiB each, zeroed before and read back after): few, long items
+    if (!plan.use_lds) target = total_words / std::max<uint64_t>(1, slots / 4) + 1;
     target = std::max(target, min_slice);
     {
         // When some genome is cut anyway (so partials and the finalize pass exist whatever the slicing), items of at most 1 MiB: a
@@ -408,7 +432,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // A bucket sort on the size's leading bits: O(items), stable inside a bucket (neighbouring items still share cache lines).
     std::vector<uint32_t> order;
     {
-        if (n_items > slots && unequal && !plan.bins) {                 // (binned launches run genome group by genome group, in order)
+        if (n_items > slots && unequal && !plan.bins && plan.use_lds) { // (binned / global-table launches run their items range by range, in order)
             auto bucket = [&](uint32_t n) {                             // 8 buckets per octave, larger sizes first
                 const uint32_t e = 31u - (uint32_t)__builtin_clz(n | 1u);
                 const uint32_t m = e >= 3 ? (n >> (e - 3)) & 7u : 0u;
@@ -449,7 +473,6 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
         if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
     }
-    if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
     const WorkItem *d_items;
     const uint32_t *d_item_begin, *d_item_order = nullptr;
     {
@@ -494,9 +517,6 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
                                                                                  // [128,256) direct mode's safe load target
         ctx->counter_zeroed = true;
     }
-    if (!plan.use_lds && n_items)
-        HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n_items * plan.nreg32 * 4, ctx->stream));
-
     TRACE("sketch: items uploaded");
 
     SketchArgs sa{};
@@ -543,7 +563,20 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         sa.ndel2 = pk->d_dirty + 4 * (size_t)n_genomes + 2;
         if (pk->stream_first)   // recent batches were full of finely fragmented dirt: every genome goes straight to the compacting kernel
             HIPCHK(ctx, hipMemsetAsync(pk->d_dirty, 0x01, (size_t)n_genomes * 4, ctx->stream));
-        if (plan.bins) {
+        if (!plan.use_lds) {
+            if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));
+            rc = global_run(ctx, plan, sa, n_items, [&](const SketchArgs &a, uint32_t cnt) -> int {
+                if (!pk->stream_first) HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream, true));
+                HIPCHK(ctx, launch_sketch_stream(plan, a, cnt, ctx->stream));
+                return LASH_OK;
+            });
+            if (rc) return rc;
+            if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
+            if (!pk->stream_first) {
+                if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
+                ctx->last.direct_launches += n_items ? 1 : 0;
+            }
+        } else if (plan.bins) {
             if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));
             rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, d_item_begin, [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int {
                 if (!pk->stream_first) HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream, true));
@@ -572,6 +605,9 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream));
             return LASH_OK;
         });
+        if (rc) return rc;
+    } else if (!plan.use_lds) {
+        rc = global_run(ctx, plan, sa, n_items, [&](const SketchArgs &a, uint32_t cnt) -> int { HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream)); return LASH_OK; });
         if (rc) return rc;
     } else {
         HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream));
@@ -688,7 +724,6 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
         if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
         if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
     }
-    if (!plan.use_lds && (rc = reserve(ctx, ctx->gregs, (size_t)(n_items + 1) * plan.nreg32 * 4))) return rc;
     std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0}, {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0},
                                 {descs.data(), descs.size() * sizeof(GenomeDesc), 0}};
     const size_t total = layout_sections(sec);
@@ -699,7 +734,6 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
         HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));
         ctx->counter_zeroed = true;
     }
-    if (!plan.use_lds && n_items) HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n_items * plan.nreg32 * 4, ctx->stream));
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
     SketchArgs sa{};
     sa.seq = d_seq;
@@ -731,6 +765,9 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     if (plan.bins) {
         rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, reinterpret_cast<const uint32_t *>(tb + sec[1].off),
                       [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int { HIPCHK(ctx, launch_sketch_aa(plan, a, cnt, ctx->stream)); return LASH_OK; });
+        if (rc) return rc;
+    } else if (!plan.use_lds) {
+        rc = global_run(ctx, plan, sa, n_items, [&](const SketchArgs &a, uint32_t cnt) -> int { HIPCHK(ctx, launch_sketch_aa(plan, a, cnt, ctx->stream)); return LASH_OK; });
         if (rc) return rc;
     } else {
         HIPCHK(ctx, launch_sketch_aa(plan, sa, n_items, ctx->stream));

@@ -1429,7 +1429,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         regs.base = lds_regs;
         census = lds_regs + a.nreg32;
     } else {
-        regs.base = a.gregs + (uint64_t)item * a.nreg32;           // zeroed by the host (hipMemsetAsync)
+        regs.base = a.gregs + (uint64_t)(item - a.item_base) * a.nreg32;   // (tables of the items of this launch: lash_api.hip, global_run)           // zeroed by the host (hipMemsetAsync)
         census = lds_regs;
     }
 
@@ -1768,7 +1768,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
         census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else {
-        regs.base = a.gregs + (uint64_t)item * a.nreg32;
+        regs.base = a.gregs + (uint64_t)(item - a.item_base) * a.nreg32;   // (tables of the items of this launch: lash_api.hip, global_run)
         census = lds_regs;
     }
     const bool multi_rec = gd.rec_end - gd.rec_begin > 1;
@@ -2121,7 +2121,7 @@ __global__ void __launch_bounds__(1024) aa_sketch_kernel(SketchArgs a)
         census = lds_regs + a.nreg32;
         for (uint32_t i = threadIdx.x; i < a.nreg32; i += blockDim.x) lds_regs[i] = ALGO == 2 ? 0u : RANK_EMPTY;
     } else {
-        regs.base = a.gregs + (uint64_t)item * a.nreg32;
+        regs.base = a.gregs + (uint64_t)(item - a.item_base) * a.nreg32;   // (tables of the items of this launch: lash_api.hip, global_run)
         census = lds_regs;
     }
     // after the census + histogram words (16 + 72): the record counter, then the byte -> code table
