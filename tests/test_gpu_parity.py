@@ -171,6 +171,28 @@ def test_register_tables_larger_than_lds(ctx, an, k, p):
     assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, an + " pack-first")
 
 
+@pytest.mark.parametrize("an,k,p", [("ull", 16, 18), ("ull", 21, 20), ("ull", 16, 22), ("hll", 21, 16), ("ull", 12, 16)])
+def test_large_tables_on_repeats_take_the_fallback_paths(ctx, an, k, p):
+    """Binned tables (ull p >= 18) stage entries in per-bin rows and append them to per-bin lists sized for hashed — i.e. spread — k-mers.
+    A satellite-like genome puts millions of identical k-mers into a handful of buckets: rows overflow (the word is re-run straight into
+    the fallback table) and lists overflow (the rest is spilled there, bins_apply_kernel folds it in).  Byte tables (hll p = 16, ull
+    p = 16) see the same input as compare-and-swap contention on few words.  All of it must still be the oracle's image."""
+    import lash_amd
+    rnd = O.synth_genome(77, 400_000).tobytes()
+    unit = b"ACGTTGCATTAGC"
+    gs = [[(unit * 120_000)[:1_500_000]],                                   # one tandem repeat: 13 distinct canonical k-mer phases
+          [rnd[:150_000] + b"A" * 900_000 + rnd[150_000:300_000]],          # a homopolymer run between unique flanks
+          [rnd[:200_000], (b"AC" * 400_000), b"ACGT"],                      # records; a dinucleotide repeat
+          [rnd]]                                                            # an ordinary genome beside them (same group, its own lists)
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
+    ctx.enable_timing(True)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), want, an + " repeats")
+    assert ctx.timing()["kmers"] == sum(len(O.record_kmers(r, k)) for g_ in gs for r in g_)
+    ctx.enable_timing(False)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, an + " repeats, pack-first")
+
+
 def test_parameter_errors_mirror_reference_panics(ctx):
     import lash_amd
     seq, off, goff = lash_amd.records_to_arrays([[b"ACGT" * 10]])
