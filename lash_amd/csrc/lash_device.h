@@ -62,6 +62,9 @@ struct BitFlip {
     static __device__ __forceinline__ BitFlip scalar(uint64_t b) { return BitFlip{(uint32_t)b, (uint32_t)(b >> 32)}; }
     static __device__ __forceinline__ BitFlip vector(uint64_t b)
     {
+#ifdef LASH_SCALAR_CONSTS   // A/B build (tools/variants.sh): the words stay scalar
+        return scalar(b);
+#endif
         BitFlip f;
         asm volatile("v_mov_b32 %0, %1" : "=v"(f.lo) : "s"((uint32_t)b));     // (opaque: hipcc would fold a plain copy back into the scalar operand)
         asm volatile("v_mov_b32 %0, %1" : "=v"(f.hi) : "s"((uint32_t)(b >> 32)));
