@@ -495,7 +495,7 @@ struct KParams {
     // per-kernel constants of VOP2 instructions as vector registers (see BitFlip, lash_device.h)
     __device__ __forceinline__ void to_vector_registers()
     {
-#ifdef LASH_SCALAR_CONSTS
+#ifdef LASH_SCALAR_CONSTS   // A/B build (tools/variants.sh)
         return;
 #endif
         asm volatile("v_mov_b32 %0, %1" : "=v"(sh_lt) : "s"(sh_lt));
@@ -1451,8 +1451,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint8_t *__restrict__ gseq = DIRECT ? a.seq + gd.byte_off : nullptr;
     uint32_t *const dirty = DIRECT ? a.dirty + it.genome : nullptr;
     KParams kp;
-    // (the deferring kernel keeps the words scalar: in its stream the vector form buys nothing and costs two registers it is short of — same-box A/B 9.27 -> 9.20 ms per 2 500 genomes)
-    kp.bitflip = DEFER ? BitFlip::scalar(a.bitflip) : BitFlip::vector(a.bitflip);
+    kp.bitflip = BitFlip::vector(a.bitflip);
     kp.p = p;
     kp.sh_lt = 32u - 2u * (uint32_t)k;
     kp.mask_lt = (KMODE == KM_LT16) ? ((1u << (2 * k)) - 1u) : 0xFFFFFFFFu;
