@@ -448,10 +448,11 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // HyperMinHash with deferred signatures (process_word_defer) pays off when a work item's table fills up early in the item, i.e.
     // when items are long: the share of k-mers that can still change their bucket is 2.8 % at 5 Mbp per item, 10 % at 1 Mbp
     // (profiles/r03/defer/ab.txt: -12 % of the kernel's time at 5 Mbp per item, -5.5 % at 1 Mbp, -3 % at 1.25 Mbp slices, +3 % at
-    // 0.73 Mbp, +17 % at 0.26 Mbp)
+    // 0.73 Mbp, +17 % at 0.26 Mbp; with round 4's threshold words and per-lane stacks, profiles/r04/defer/items.txt: -13.8 % at
+    // 2 Mbp, -6.5 % at 1 Mbp, -2.6 % at 750 kbp, -0.7 % at 600 kbp, +1 % at 500 kbp, +6.5 % at 400 kbp, +19 % at 200 kbp)
     SketchPlan plan_d = plan;
     {
-        static const int64_t defer_min = getenv("LASH_DEFER_MIN") ? atoll(getenv("LASH_DEFER_MIN")) : 1000000;   // bases per work item; < 0: never
+        static const int64_t defer_min = getenv("LASH_DEFER_MIN") ? atoll(getenv("LASH_DEFER_MIN")) : 600000;   // bases per work item; < 0: never
         // (judged on the slices as first cut: the quarters at the launch's tail would pull the mean of a few-round launch under the line)
         plan_d.defer = defer_eligible && n_coarse > 0 && defer_min >= 0 && total_words * 16 / n_coarse >= (uint64_t)defer_min;
     }

@@ -57,7 +57,7 @@ def test_baseline_config_properties(env, algo, k, p, G):
     d_seq, img, t = _sketch_synth(ctx, torch, lash_amd, 0, G, algo, k, p)
     assert t["kmers"] == G * (L - k + 1) and t["bases_last"] == G * L
     if FULL and "LASH_DEFER_MIN" not in os.environ:
-        # work items of 1 Mbp and more (here 1.67 Mbp slices): the HyperMinHash launch defers its signatures (process_word_defer), the others never do
+        # work items of 0.6 Mbp and more (here 1.67 Mbp slices): the HyperMinHash launch defers its signatures (process_word_defer), the others never do
         assert t["defer_launches"] == (1 if algo == "hmh" else 0), t
     # oracle spot checks
     for g in (0, G // 3, G - 1):

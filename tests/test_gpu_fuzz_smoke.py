@@ -27,7 +27,7 @@ def test_fuzz_runner_smoke(script, iters, seed, ok):
 
 def test_fuzz_with_deferred_signatures_everywhere():
     """HyperMinHash batches of long work items run sketch_kernel<..., DEFER> (signature half of the hash only for the k-mers whose
-    rank can still win their bucket; lash_api.hip: from 1 Mbp per work item).  LASH_DEFER_MIN=0 sends EVERY direct HyperMinHash
+    rank can still win their bucket; lash_api.hip: from 0.6 Mbp per work item).  LASH_DEFER_MIN=0 sends EVERY direct HyperMinHash
     launch of the runner down that kernel — tiny genomes, read sets, dirt, slices — against the oracle as usual.  (The full-size
     tests take the route by themselves.)"""
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE, LASH_DEFER_MIN="0", FUZZ_ALGO="hmh")

@@ -8,7 +8,7 @@ for f in "fuzz_gpu.py 300 5" "fuzz_gpu_cli.py 30 11" "fuzz_gpu_stream.py 20 7" "
     set -- $f
     timeout 1500 python3 tests/$1 $2 $3 > $OUT/$1.log 2>&1; echo "$1 rc=$? $(tail -1 $OUT/$1.log)"
 done
-# the same runners with every HyperMinHash launch deferring its signatures (by default only batches of work items >= 1 Mbp do)
+# the same runners with every HyperMinHash launch deferring its signatures (by default only batches of work items >= 0.6 Mbp do)
 for f in "fuzz_gpu.py 300 21" "fuzz_gpu_raw.py 150 22" "fuzz_gpu_cli.py 20 23"; do
     set -- $f
     LASH_DEFER_MIN=0 FUZZ_ALGO=hmh timeout 1500 python3 tests/$1 $2 $3 > $OUT/defer_$1.log 2>&1; echo "LASH_DEFER_MIN=0 $1 rc=$? $(tail -1 $OUT/defer_$1.log)"
