@@ -265,10 +265,19 @@ def main():
         print("\nVALU wave-instructions per k-mer, sections together: %.2f%s" % (grand_v, ("   measured (SQ_INSTS_VALU): %.2f" % args.measured_valu) if args.measured_valu else ""))
         print("sum of count x pure-stream cost: %.1f cycles per wave-k-mer%s" % (raw_c, ("; x mixed-stream factor %.3f (%s)" % (factor, fsrc)) if fsrc else ""))
         print("predicted VALU issue cycles per wave-k-mer: %.1f%s" % (grand_c, ("   measured: %.1f  (predicted / measured %.2f)" % (args.measured, grand_c / args.measured)) if args.measured else ""))
+        if args.measured and args.measured_valu and grand_v > 0 and args.measured_valu > grand_v:
+            # what the kernel issues outside the priced blocks (per word: the window's rotation and the next reverse complement; per tile:
+            # the record-boundary mask, the census, load addresses, scalar spills through v_readlane / v_writelane), at the sections' mean cost
+            extra = args.measured_valu - grand_v
+            with_unlisted = grand_c + extra * grand_c / grand_v
+            print("instructions outside the sections (measured - listed): %.2f per k-mer; at the sections' mean cost (%.2f cycles): predicted %.1f  "
+                  "(predicted / measured %.2f)" % (extra, grand_c / grand_v, with_unlisted, with_unlisted / args.measured))
     if args.json:
         json.dump({"kernel": match[0], "listing": os.path.basename(args.listing), "costs": os.path.relpath(args.costs, ROOT), "sections": out_sections,
                    "valu_per_kmer": grand_v, "cycles_per_kmer": grand_c, "pure_stream_cycles_per_kmer": raw_c, "mix_factor": factor, "measured_cycles_per_kmer": args.measured,
-                   "measured_valu_per_kmer": args.measured_valu}, open(args.json, "w"), indent=1)
+                   "measured_valu_per_kmer": args.measured_valu,
+                   "cycles_per_kmer_with_unlisted": (grand_c + (args.measured_valu - grand_v) * grand_c / grand_v) if (args.measured_valu and grand_v > 0 and args.measured_valu > grand_v) else None},
+                  open(args.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
