@@ -26,6 +26,11 @@
 #include "lash_device.h"
 #include "lash_kernels.h"
 
+// how far the four-word loop of a tile is unrolled (1: one body, the window rotates through register copies)
+#ifndef LASH_WORD_UNROLL
+#define LASH_WORD_UNROLL 1
+#endif
+
 namespace lash {
 
 enum { KM_16 = 0, KM_LT16 = 1, KM_GT16 = 2 };
@@ -1646,7 +1651,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
         uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
         if constexpr (REGS == REGS_BINS) regs.mode = 1u;                   // the word loop pushes without branches (BinRegs::mode)
-#pragma unroll 1
+#pragma unroll LASH_WORD_UNROLL
         for (int wi = 0; wi < SKETCH_WORDS_PER_THREAD; ++wi) {
             uint32_t z;
             if constexpr (ALT) {
