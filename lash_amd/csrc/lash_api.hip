@@ -327,7 +327,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
     const bool defer_eligible = prm->algo == LASH_HMH && !x_low && !plan.alt && plan.use_lds && plan.parts_log2 == 0;   // (see plan_d below)
-    const uint32_t lds_wg = plan.lds_bytes + ((pk->direct || defer_eligible) ? sketch_direct_stage_bytes(plan) : 0u);   // + the waves' staging areas / lists
+    const uint32_t lds_wg = plan.lds_bytes + ((pk->direct || defer_eligible || plan.bytes) ? sketch_direct_stage_bytes(plan) : 0u);   // + the waves' staging areas / lists
     const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(lds_wg, 1u)) : 4u;   // 64 KiB + census -> 2
     const uint64_t slots = (uint64_t)ctx->cu_count * std::min(wg_per_cu, 2048u / plan.threads);
     uint64_t total_words = 0;

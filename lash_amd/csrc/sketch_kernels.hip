@@ -51,7 +51,7 @@ constexpr uint32_t RANK_EMPTY = 0xFFFFFFFFu;                   // HyperMinHash /
 
 struct LdsRegs {
     uint32_t *base;
-    static constexpr bool BINS = false, BYTES = false;
+    static constexpr bool BINS = false, BYTES = false, QUEUED = false;
     // The register table starts at LDS address 0 (the kernel has no static __shared__; checked at kernel entry), so the
     // word index goes straight into the DS address.  Through a pointer hipcc adds the table's link-time base (0) with a
     // v_add_u32 per k-mer; the update itself is fire-and-forget, nothing in the hashing loop reads the table back, and
@@ -74,7 +74,7 @@ struct LdsRegs {
 };
 struct GlobalRegs {                                            // (UltraLogLog p >= 23 only: a zeroed slab per work item)
     uint32_t *base;
-    static constexpr bool BINS = false, BYTES = false;
+    static constexpr bool BINS = false, BYTES = false, QUEUED = false;
     static constexpr bool THR = false;
     __device__ __forceinline__ void smax(uint32_t, uint32_t) const {}
     __device__ __forceinline__ void bor_pair(uint32_t idx, uint32_t w, uint32_t v) const
@@ -98,7 +98,7 @@ struct GlobalRegs {                                            // (UltraLogLog p
 // slow, and only met by genomes whose k-mers pile into few buckets — a satellite repeat); bins_apply_kernel folds that table in
 // when the genome's flag is up.
 struct BinRegs {
-    static constexpr bool THR = false, BINS = true, BYTES = false;
+    static constexpr bool THR = false, BINS = true, BYTES = false, QUEUED = false;
     uint32_t cnt_b, stage_b;      // LDS byte addresses of this wave's row counters [V] and staging rows [V][S]
     uint32_t S, V, sub_shift;     // slots per row; rows: V = bins << sub_shift (few bins: each has 2^sub_shift rows, a lane uses row
     uint32_t sub_lane;            //   lane & (2^sub_shift - 1) of its bin — 64 lanes on 2 counters would be 32-way LDS atomic conflicts)
@@ -216,7 +216,7 @@ struct BinRegs {
 //   UltraLogLog: the byte is the register itself; hash4j's add — pack(unpack(r) | 1 << (nlz + p - 1)) — is the merge of r with the
 //   register 4 * (nlz + p - 1) of a sketch that holds only this k-mer (its unpack() is that single bit): ull_merge_fast, lash_device.h.
 struct LdsByteRegs {
-    static constexpr bool THR = false, BINS = false, BYTES = true;
+    static constexpr bool THR = false, BINS = false, BYTES = true, QUEUED = false;
     int p;
     static __device__ __forceinline__ uint32_t *word(uint32_t byte_addr) { return (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(byte_addr & ~3u); }
     __device__ __forceinline__ void hll_max(uint32_t j, uint32_t raw) const        // raw = rho - 1; all ones = nothing
@@ -250,6 +250,67 @@ struct LdsByteRegs {
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
 
+// The byte tables behind a filter (round 4, second form; sketch_kernel only).  The compare-and-swap update above costs a k-mer its
+// own LDS round trip and its own loop — 47 instructions in a block of their own per k-mer, nothing of the next k-mer's hash issued
+// meanwhile (hll p = 16: 7.1e11 k-mers/s where p = 14's ds_max runs 1.15e12).  But nine k-mers in ten leave their register as it
+// is, and whether one does is a question to the register's byte alone:
+//   HyperLogLog: it changes the byte iff rho - 1 > byte (signed, -1 = empty);
+//   UltraLogLog: with t = byte - 4 * (nlz + p - 1) = 4 * (top - bit) + the two bits below the top:  t < 0 (a new top), t = 4, 5
+//                (one below the top, that bit unset), t = 8, 10 (two below, unset); everything else leaves it alone.
+// So the word loop only ASKS — ds_read_u8, a compare (HLL) / subtract, clamp, table shift (ULL) — and a k-mer that would change
+// its register waits on its lane's stack (the deferring HyperMinHash launches' layout: SigQueue below) as index << 8 | rho - 1 or
+// index << 6 | nlz, appended with an unconditional ds_write and a conditional pointer step.  No branch between the k-mers of a
+// group of four; when some lane cannot take another group, every lane that has an entry pops one and runs the exact update (the
+// compare-and-swap above).  A stale byte (another wave is updating it) only makes the filter more permissive: registers grow
+// monotonically, and what the older value already represents the newer one represents or has dropped below its window.
+//   "Nothing" (a masked position; the fast form's undecided k-mer): HLL's -1 never passes; ULL's nlz = -1 can, as entry value 63,
+// which the update skips.
+template <int ALGO>
+struct LdsByteQRegs : LdsByteRegs {
+    static constexpr bool QUEUED = true;
+    mutable uint32_t qptr;        // per lane: LDS byte address of its next free slot
+    uint32_t q_lane_b, q_lim;     // its first slot; beyond q_lim the lane cannot take another group of four
+    static __device__ __forceinline__ uint32_t ld(uint32_t b) { return *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b; }
+    static __device__ __forceinline__ void st(uint32_t b, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)b = v; }
+    __device__ __forceinline__ void queue_init(uint32_t wave_base_b, uint32_t depth, uint32_t lane)
+    {
+        q_lane_b = wave_base_b + lane * depth * 4u;
+        qptr = q_lane_b;
+        q_lim = q_lane_b + 4u * (depth - 4u);
+    }
+    __device__ __forceinline__ void hll_max(uint32_t j, uint32_t raw) const
+    {
+        const int cur = *(__attribute__((address_space(3))) int8_t *)(uintptr_t)j;                 // ds_read_i8
+        st(qptr, (j << 8) | (raw & 0xFFu));
+        qptr += (int)raw > cur ? 4u : 0u;
+    }
+    __device__ __forceinline__ void ull_add(uint32_t idx, uint32_t nlz) const
+    {
+        const uint32_t r = *(__attribute__((address_space(3))) uint8_t *)(uintptr_t)idx;            // ds_read_u8
+        int ts = (int)(r - ((nlz << 2) + 4u * (uint32_t)p - 5u));                                    // t + 1
+        asm("v_med3_i32 %0, %1, 0, 15" : "=v"(ts) : "v"(ts));                                         // t < 0 -> 0;  t >= 14 -> 15
+        st(qptr, (idx << 6) | (nlz & 63u));
+        qptr += (0x2984u >> ts) & 4u;                                                                  // t + 1 in {0, 5, 6, 9, 11}
+    }
+    // (Two entries per round with their compare-and-swap chains side by side — three LDS round trips for two entries instead of
+    // three each, no branch, idle lanes swapping a slot of their own stack for itself — measured the same or slower: hll p = 16
+    // 5.97 -> 5.91 ms, ull p = 15 / 16 / 17 6.03 -> 6.16, 6.62 -> 6.69, 7.53 -> 7.68.)
+    template <bool ALL>
+    __device__ __forceinline__ void drain() const
+    {
+        do {
+            if (qptr != q_lane_b) {
+                qptr -= 4u;
+                const uint32_t e = ld(qptr);
+                if constexpr (ALGO == 1) LdsByteRegs::hll_max(e >> 8, e & 0xFFu);
+                else LdsByteRegs::ull_add(e >> 6, e & 63u);
+            }
+        } while (__builtin_amdgcn_ballot_w64(ALL ? qptr != q_lane_b : qptr > q_lim) != 0ull);
+    }
+    // after every fourth k-mer of a word
+    __device__ __forceinline__ void check() const { if (__builtin_amdgcn_ballot_w64(qptr > q_lim) != 0ull) drain<false>(); }
+};
+
 // HyperMinHash, launches that defer signatures (process_word_defer).  The filter asks one question per k-mer — can its rank still
 // win its bucket? — so the table word answers it with ONE compare: the rank is stored as the largest value of the hash's rank bits
 // that still passes,
@@ -260,7 +321,7 @@ struct LdsByteRegs {
 // zeros the threshold is 0 (x16 must be 0) and the full update decides.  get() turns the word back into lz << 10 | sig.
 struct LdsThrRegs {
     uint32_t *base;
-    static constexpr bool THR = true, BINS = false, BYTES = false;
+    static constexpr bool THR = true, BINS = false, BYTES = false, QUEUED = false;
     static __device__ __forceinline__ uint32_t encode(uint32_t lzm1, uint32_t sig)
     {
         const uint32_t m = lzm1 < 16u ? lzm1 : 16u;
@@ -571,6 +632,7 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
         }
         const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, HLL_HIGH>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p);
         zacc = zacc < t ? zacc : t;
+        if constexpr (Regs::QUEUED) { if ((r & 3) == 3) regs.check(); }        // (LdsByteQRegs: is some lane's stack full?)
     }
     return zacc;
 }
@@ -1421,7 +1483,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
     using Regs = typename std::conditional<DEFER, LdsThrRegs, typename std::conditional<REGS == REGS_LDS, LdsRegs,
                                            typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs,
-                                           typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteRegs>::type>::type>::type>::type;
+                                           typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteQRegs<ALGO>>::type>::type>::type>::type;
+    // what the slow paths (junction walks, dense tiles) update through: the byte tables' plain compare-and-swap form
+    using SlowRegs = typename std::conditional<REGS == REGS_BYTES, LdsByteRegs, Regs>::type;
     Regs regs;
     uint32_t *census;
     const uint32_t part = 0u;
@@ -1467,11 +1531,13 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     kp.lsb_xor = (ALT && a.lay.kmer_lsb_first) ? ((((uint64_t)a.lay.comp_mask << 32) | a.lay.comp_mask) & kp.mask_gt) : 0ull;
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
-    constexpr bool K21 = KMODE == KM_GT16 && DIRECT && !ALT && !DEFER && REGS == REGS_LDS;   // kernels with a k = 21 body of their own
+    constexpr bool K21 = KMODE == KM_GT16 && DIRECT && !ALT && !DEFER && (REGS == REGS_LDS || REGS == REGS_BYTES);   // kernels with a k = 21 body of their own
     uint32_t my_kmers = 0;
     const uint32_t lane = threadIdx.x & 63u;
     SigQueue sigq;                                                          // DEFER: the lanes' stacks live in the wave's staging area
     sigq_init(sigq, (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.stage_off + (threadIdx.x >> 6) * a.stage_stride)), a.sigq_depth, lane);
+    if constexpr (Regs::QUEUED)                                             // (the byte tables' stacks: same place, same layout)
+        regs.queue_init((uint32_t)__builtin_amdgcn_readfirstlane((int)(a.stage_off + (threadIdx.x >> 6) * a.stage_stride)), a.sigq_depth, lane);
     uint32_t tiles_dense = 0;                                               // direct mode, per wave: how many of its tiles held deleted bytes
     bool judged = false;                                                    // ... and whether it has already voted to hand the genome over
 
@@ -1624,7 +1690,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     E = E < L ? E : L;
                     const uint32_t stage_b = a.stage_off + (threadIdx.x >> 6) * a.stage_stride;
                     if constexpr (DEFER) sigq_drain<true>(regs, kp.bitflip, p, sigq);           // (the staging area is about to be used)
-                    my_kmers += wave_sum(dense_tile<ALGO, KMODE, XLOW, Regs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
+                    if constexpr (Regs::QUEUED) regs.template drain<true>();
+                    my_kmers += wave_sum(dense_tile<ALGO, KMODE, XLOW, SlowRegs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
                                                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
                                                                             part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3));
                     tile_load(tile + step, nxt);
@@ -1633,7 +1700,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 if (wave_nd && part == 0u && (threadIdx.x & 63) == 0) atomicAdd(a.ndel + it.genome, wave_nd);   // (one per wave; the passes of a partitioned table see the same bytes)
                 uint32_t walked = 0;
                 if (junc)                                                      // (here, not after the hashing: nothing of it stays live)
-                    walked = junction_walk<ALGO, XLOW, Regs>(regs, gseq, L, pos0, junc, jstarts, use_bitmap ? bk : nullptr, RL, k, kp.bitflip, p,
+                    walked = junction_walk<ALGO, XLOW, SlowRegs>(regs, gseq, L, pos0, junc, jstarts, use_bitmap ? bk : nullptr, RL, k, kp.bitflip, p,
                                                              cmask, ctabs, dirty);
                 my_kmers += wave_sum(walked);
             }
@@ -1713,6 +1780,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
 
     if constexpr (DEFER) sigq_drain<true>(regs, kp.bitflip, p, sigq);
+    if constexpr (Regs::QUEUED) regs.template drain<true>();
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
 }
 
@@ -2513,7 +2581,7 @@ static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uin
     }
     SketchArgs a = args;
     a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile);
-    a.stage_stride = stage_stride_bytes(plan, DIRECT, defer);              // deferring launches keep their lanes' stacks there
+    a.stage_stride = stage_stride_bytes(plan, DIRECT, defer || REGS == REGS_BYTES);   // deferring launches keep their lanes' stacks there, the byte tables' theirs
     a.sigq_depth = plan.sigq_depth;
     a.bin_lds_off = plan.lds_bytes + (plan.threads / 64u) * a.stage_stride;
     a.bin_wave_bytes = sketch_bin_wave_bytes(plan);

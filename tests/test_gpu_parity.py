@@ -152,12 +152,12 @@ def test_short_reads_fastq_like(ctx):
         assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), oracle_images(ALGO[an], k, p, 42, seq, off, goff), an)
 
 
-@pytest.mark.parametrize("an,k,p", [("hll", 16, 16), ("hll", 25, 16), ("ull", 16, 15), ("ull", 12, 16), ("ull", 21, 17),
+@pytest.mark.parametrize("an,k,p", [("hll", 16, 16), ("hll", 25, 16), ("hll", 21, 16), ("ull", 16, 15), ("ull", 12, 16), ("ull", 21, 17), ("ull", 21, 16), ("ull", 32, 15),
                                     ("ull", 21, 18), ("ull", 9, 19), ("ull", 16, 20), ("ull", 30, 21), ("ull", 16, 22), ("ull", 21, 24)])
 def test_register_tables_larger_than_lds(ctx, an, k, p):
-    """2^p registers beyond 128 KiB of LDS.  Round 4: hll p=16 and ull p=15..22 are BINNED — every k-mer hashed once, a 4-byte entry
-    appended to the list of its bin (2^14 / 2^15 registers), one LDS pass per bin (bins_apply_kernel); ull p >= 23 keeps its table in
-    HBM/L2 and takes one global atomic per k-mer.  Multi-record, multi-slice, dirty and empty genomes, through the direct route and the
+    """2^p registers beyond 128 KiB of LDS as 32-bit words.  Round 4: hll p=16 and ull p=15..17 keep them as BYTES (one pass, updates
+    behind a filter: LdsByteQRegs); ull p=18..22 are BINNED — every k-mer hashed once, a 4-byte entry appended to the list of its bin
+    (2^14 registers), one LDS pass per bin (bins_apply_kernel); ull p >= 23 keeps its table in HBM/L2 and takes one global atomic per k-mer.  Multi-record, multi-slice, dirty and empty genomes, through the direct route and the
     pack-first route."""
     import lash_amd
     g = O.synth_genome(8, 1_300_000)
@@ -169,6 +169,33 @@ def test_register_tables_larger_than_lds(ctx, an, k, p):
     assert ctx.timing()["kmers"] == sum(len(O.record_kmers(r, k)) for g_ in gs for r in g_)
     ctx.enable_timing(False)
     assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, an + " pack-first")
+
+
+@pytest.mark.parametrize("an,k,p", [("hll", 16, 16), ("hll", 21, 16), ("ull", 16, 15), ("ull", 21, 16), ("ull", 11, 17)])
+def test_byte_tables_behind_their_filter_on_reads(ctx, an, k, p):
+    """hll p = 16 / ull p = 15 .. 17 keep their registers as bytes in LDS; the word loop asks each register's byte whether the k-mer would
+    change it and stacks those that would (LdsByteQRegs), the exact compare-and-swap update runs from the stacks.  Reads make every tile
+    a masked one (record boundaries), equal lengths take the computed boundaries, unequal ones the bitmap; an N per few reads walks
+    junctions beside the stacks; enough reads that a lane's stack fills many times over."""
+    import lash_amd
+    rng = random.Random(zlib.crc32(repr((an, k, p)).encode()))
+    body = O.synth_genome(k + p, 2_400_000).tobytes()
+    equal = [body[i:i + 150] for i in range(0, 1_200_000, 150)]
+    ragged, at = [], 1_200_000
+    while at < 2_400_000:
+        n = rng.choice((150, 150, 149, 151, 75, 250, k, k - 1 if k > 1 else 1))
+        r = bytearray(body[at:at + n])
+        if rng.random() < 0.05 and len(r) > 2:
+            r[rng.randrange(len(r))] = ord("N")
+        ragged.append(bytes(r)); at += n
+    gs = [equal, ragged, [body[:300_000]]]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
+    ctx.enable_timing(True)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff), want, an + " reads")
+    assert ctx.timing()["kmers"] == sum(len(O.record_kmers(r, k)) for g_ in gs for r in g_)
+    ctx.enable_timing(False)
+    assert_same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, an + " reads, pack-first")
 
 
 @pytest.mark.parametrize("an,k,p", [("ull", 16, 18), ("ull", 21, 20), ("ull", 16, 22), ("hll", 21, 16), ("ull", 12, 16)])
