@@ -62,6 +62,8 @@ def main():
             an = os.environ["FUZZ_ALGO"]
         k = rng.choice([rng.randint(1, 32), 16, 21, 31, 32])
         p = 0 if an == "hmh" else rng.choice([rng.randint(4, 16)] if an == "hll" else [rng.randint(3, 20), rng.randint(3, 14)])
+        if os.environ.get("FUZZ_P") and an != "hmh":      # e.g. FUZZ_P=15,16,17: the byte tables (hll: p <= 16)
+            p = min(rng.choice([int(x) for x in os.environ["FUZZ_P"].split(",")]), 16 if an == "hll" else 26)
         seed = rng.choice([0, 42, rng.getrandbits(64)])
         flags = rng.choice([0, 0, lash_amd.F_NO_DIRECT, lash_amd.F_STREAM_ONLY]) | (lash_amd.F_HMH_X_LOW if an == "hmh" and rng.random() < 0.2 else 0)
         gs = [random_genome(rng) for _ in range(rng.randint(1, 12))]
