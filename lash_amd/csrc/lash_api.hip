@@ -231,14 +231,18 @@ static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector
     br.max_group = std::max(br.max_group, in_group);
     int rc;
     if ((rc = reserve(ctx, ctx->bins_lists, group_max_bytes + 256))) return rc;
-    if ((rc = reserve(ctx, ctx->bins_slab, (size_t)br.max_group * br.slab_words * 4 + 256))) return rc;
+    {
+        void *before = ctx->bins_slab.ptr;
+        if ((rc = reserve(ctx, ctx->bins_slab, (size_t)br.max_group * br.slab_words * 4 + 256))) return rc;
+        if (ctx->bins_slab.ptr != before) ctx->bins_slab_fill = -1;     // new memory: contents unknown
+    }
     std::vector<WorkItem> vitems(n_genomes);
     std::vector<uint32_t> vbegin(n_genomes + 1);
     for (uint32_t g = 0; g < n_genomes; ++g) { vitems[g] = WorkItem{g, 0u, 4u, 0u}; vbegin[g] = g; }
     vbegin[n_genomes] = n_genomes;
     std::vector<Section> sec = {{br.table.data(), br.table.size() * sizeof(BinGenome), 0}, {vitems.data(), vitems.size() * sizeof(WorkItem), 0},
                                 {vbegin.data(), vbegin.size() * 4, 0}};
-    const size_t tabs = layout_sections(sec), cnt_bytes = ((size_t)br.max_group * B * 4 + 255) & ~(size_t)255, spill_bytes = ((size_t)br.max_group * 4 + 255) & ~(size_t)255;
+    const size_t tabs = layout_sections(sec), cnt_bytes = ((size_t)br.max_group * B * 4 + 255) & ~(size_t)255, spill_bytes = cnt_bytes;   // (one flag per bin)
     if ((rc = reserve(ctx, ctx->bins_meta, tabs + cnt_bytes + spill_bytes + 256))) return rc;
     if ((rc = upload_sections(ctx, ctx->bins_meta.ptr, sec, tabs, ctx->stream))) return rc;
     uint8_t *mb = static_cast<uint8_t *>(ctx->bins_meta.ptr);
@@ -261,12 +265,21 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
     sa.bin_spill = br.d_spill;
     sa.bins = B; sa.bin_shift = plan.bin_shift; sa.bin_S = plan.bin_S; sa.bin_sub_shift = plan.bin_sub_shift; sa.bin_slab_words = br.slab_words;
     sa.item_order = nullptr;
+    // the fallback tables: empty at rest (bins_apply_kernel wipes what it folds in); wiped here only when new, or last left by the other sketch type
+    {
+        const int fill = prm->algo == LASH_ULL ? 0x00 : 0xFF;
+        const size_t need = (size_t)br.max_group * br.slab_words * 4;
+        if (ctx->bins_slab_fill != fill || ctx->bins_slab_clean < need) {
+            HIPCHK(ctx, hipMemsetAsync(ctx->bins_slab.ptr, fill, need, ctx->stream));
+            ctx->bins_slab_clean = need;
+        }
+        ctx->bins_slab_fill = -1;                                      // (until this call's last bins_apply_kernel is queued)
+    }
     uint32_t g0 = 0;
     for (uint32_t g1 : br.group_end) {
         const uint32_t ng = g1 - g0;
         HIPCHK(ctx, hipMemsetAsync(br.d_cnt, 0, (size_t)ng * B * 4, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(br.d_spill, 0, (size_t)ng * 4, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(ctx->bins_slab.ptr, prm->algo == LASH_ULL ? 0x00 : 0xFF, (size_t)ng * br.slab_words * 4, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(br.d_spill, 0, (size_t)ng * B * 4, ctx->stream));
         sa.bin_genomes = br.d_table + g0;
         sa.bin_genome0 = g0;
         sa.item_base = item_begin[g0];
@@ -281,6 +294,7 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
         HIPCHK(ctx, launch_bins_apply(ba, ng, ctx->stream));
         g0 = g1;
     }
+    ctx->bins_slab_fill = prm->algo == LASH_ULL ? 0x00 : 0xFF;
     return LASH_OK;
 }
 

@@ -135,6 +135,7 @@ struct lash_ctx {
     unsigned ring_next = 0;
     std::vector<const lash_packed *> last_packed;   // what the last sketch call consumed (for bases_last / error flags)
     DevBuf items, item_begin, item_kmers, partials, gregs, counter;   // items: [work items | item_begin] of a sketch call
+    int bins_slab_fill = -1; size_t bins_slab_clean = 0;   // the fallback tables rest EMPTY between launches: with which byte (0x00 ull / 0xFF hll; -1: unknown), how far
     DevBuf bins_lists, bins_meta, bins_slab;   // binned launches (SketchPlan::bins): entry lists, tables + counters, fallback tables of one genome group
     bool counter_zeroed = false;
     DevBuf st_seq, st_rec, st_img;       // staging for the synchronous host-buffer entries (files_raw, merge, pair statistics)

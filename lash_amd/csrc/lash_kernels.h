@@ -51,7 +51,7 @@ struct SketchArgs {
     uint32_t         *bin_lists;  // every (genome of the group, bin) list, BinGenome::list_off apart
     uint32_t         *bin_cnt;    // [genomes of the group][bins] fill counters, zeroed
     uint32_t         *bin_slab;   // [genomes of the group][bin_slab_words] full-size fallback tables (zero / 0xFF-filled)
-    uint32_t         *bin_spill;  // [genomes of the group] set when a genome's fallback table holds something
+    uint32_t         *bin_spill;  // [genomes of the group][bins] set when that bin's part of the genome's fallback table holds something
     const BinGenome  *bin_genomes;   // [genomes of the group]
     uint32_t          bins, bin_shift, bin_S, bin_sub_shift;
     uint32_t          bin_lds_off, bin_wave_bytes;   // LDS: the waves' counter + staging areas
@@ -81,7 +81,8 @@ struct SketchPlan {
 // per wave: bytes of LDS a binned launch needs for its bin counters and staging rows
 uint32_t sketch_bin_wave_bytes(const SketchPlan &plan);
 struct BinApplyArgs {
-    const uint32_t *lists, *cnt, *slab, *spill;
+    const uint32_t *lists, *cnt, *spill;
+    uint32_t *slab;                 // (a bin's part is folded in and wiped when its flag is up)
     const BinGenome *genomes;
     uint8_t  *partials;           // the group's genomes' "virtual" partials: genome gi of the group at partials + (virt0 + gi) * partial_stride
     uint32_t *item_kmers;         // ... and its k-mer count at item_kmers[virt0 + gi] = the sum over its real items

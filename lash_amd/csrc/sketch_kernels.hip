@@ -27,6 +27,9 @@
 #include "lash_kernels.h"
 
 // how far the four-word loop of a tile is unrolled (1: one body, the window rotates through register copies)
+#ifndef LASH_BINS_APPLY_LOADS
+#define LASH_BINS_APPLY_LOADS 4         // 16-byte loads a lane of bins_apply_kernel has in flight (8, 16: the same or slower)
+#endif
 #ifndef LASH_WORD_UNROLL
 #define LASH_WORD_UNROLL 1
 #endif
@@ -117,15 +120,16 @@ struct BinRegs {
     // exact, slow: one global atomic.  (Static, everything by value: a member function that is not inlined takes `this`, the struct
     // then lives in scratch memory and every push reads its fields back from there — 6.7 vector memory reads per k-mer, found with
     // SQ_INSTS_VMEM_RD)
-    static __device__ __noinline__ void spill_to(uint32_t *slab, uint32_t *spill, int algo, uint32_t e)
+    // (`spill` holds one flag per BIN of the genome: bins_apply_kernel folds in — and wipes — only the parts of the fallback table that were used)
+    static __device__ __noinline__ void spill_to(uint32_t *slab, uint32_t *spill, int algo, uint32_t bin_shift, uint32_t e)
     {
         const uint32_t v = e & 63u, idx = e >> 6;
         if (v == 63u) return;
         if (algo == 2) (void)__hip_atomic_fetch_or(slab + 2u * idx + (v >> 5), 1u << (v & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else (void)__hip_atomic_fetch_max(reinterpret_cast<int *>(slab) + idx, (int)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(spill, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(spill + (idx >> bin_shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __device__ __forceinline__ void spill_entry(uint32_t e) const { spill_to(slab, spill, algo, e); }
+    __device__ __forceinline__ void spill_entry(uint32_t e) const { spill_to(slab, spill, algo, bin_shift, e); }
     __device__ __forceinline__ void push(uint32_t idx, uint32_t v) const
     {
         const uint32_t row = ((idx >> bin_shift) << sub_shift) | sub_lane, e = (idx << 6) | (v & 63u);
@@ -1333,7 +1337,7 @@ __device__ __forceinline__ BinRegs bin_regs_of(const SketchArgs &a, uint32_t gen
     r.lists = a.bin_lists + bg.list_off;
     r.cnt = a.bin_cnt + (uint64_t)gi * a.bins;
     r.slab = a.bin_slab + (uint64_t)gi * a.bin_slab_words;
-    r.spill = a.bin_spill + gi;
+    r.spill = a.bin_spill + (uint64_t)gi * a.bins;
     for (uint32_t b = lane; b < r.V; b += 64u) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(r.cnt_b + b * 4u) = 0u;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return r;
@@ -2436,21 +2440,37 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
     const uint32_t *list = a.lists + bg.list_off + (uint64_t)bin * bg.cap;
     uint32_t n = a.cnt[(uint64_t)gi * a.bins + bin];
     n = n < bg.cap ? n : bg.cap;
-    auto lds = [](uint32_t byte_addr) { return (__attribute__((address_space(3))) uint32_t *)(uintptr_t)byte_addr; };
-    (void)lds;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t e = list[i], v = e & 63u;
-        if (v == 63u) continue;
-        const uint32_t r = (e >> 6) & (regs_per_bin - 1u);
-        if constexpr (ALGO == 2) atomicOr(&tab[2u * r + (v >> 5)], 1u << (v & 31u));
-        else atomicMax(reinterpret_cast<int *>(tab) + r, (int)v);
+    // 16 x LASH_BINS_APPLY_LOADS bytes per lane and round, all loads issued before the first update, no branch ("nothing" ORs a zero / offers
+    // -1): one entry per round with a `continue` in it ran one global load latency per entry — 76 in a row per lane at p = 20,
+    // 129 us per workgroup, half of a binned launch's time
+    auto apply = [&](uint32_t e) {
+        // ("nothing" — a row's padding, a round's idle lanes — goes to a register of the lane's own: the lanes' zeros on ONE word serialise)
+        const uint32_t v = e & 63u, r = (v == 63u ? threadIdx.x : (e >> 6)) & (regs_per_bin - 1u);
+        if constexpr (ALGO == 2) atomicOr(&tab[2u * r + ((v >> 5) & 1u)], v == 63u ? 0u : 1u << (v & 31u));
+        else atomicMax(reinterpret_cast<int *>(tab) + r, v == 63u ? -1 : (int)v);
+    };
+    const uint4 *l4 = reinterpret_cast<const uint4 *>(list);          // (lists start and reservations are whole 16-byte groups)
+    const uint32_t n4 = n >> 2;
+    constexpr uint32_t Q = LASH_BINS_APPLY_LOADS;
+    for (uint32_t i = threadIdx.x; i < n4; i += Q * blockDim.x) {
+        uint4 q[Q];
+#pragma unroll
+        for (uint32_t b = 0; b < Q; ++b) {
+            const uint32_t at = i + b * blockDim.x;
+            q[b] = at < n4 ? l4[at] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < Q; ++b) { apply(q[b].x); apply(q[b].y); apply(q[b].z); apply(q[b].w); }
     }
+    for (uint32_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) apply(list[i]);
     __syncthreads();
-    if (a.spill[gi]) {                                                     // entries that found a row or a list full
-        const uint32_t *sl = a.slab + (uint64_t)gi * a.slab_words + (uint64_t)bin * words;
+    if (a.spill[(uint64_t)gi * a.bins + bin]) {                           // entries of this bin that found a row or a list full
+        // fold this bin's part of the fallback table in and leave it empty again: the table is wiped once, when it is allocated, not 8 MiB
+        // per genome and call (p = 20; with ONE flag per genome every bin of nearly every genome read its part: some row overflows somewhere)
+        uint32_t *sl = a.slab + (uint64_t)gi * a.slab_words + (uint64_t)bin * words;
         for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
-            if constexpr (ALGO == 2) tab[i] |= sl[i];
-            else tab[i] = (uint32_t)max((int)tab[i], (int)sl[i]);
+            if constexpr (ALGO == 2) { tab[i] |= sl[i]; sl[i] = 0u; }
+            else { tab[i] = (uint32_t)max((int)tab[i], (int)sl[i]); sl[i] = RANK_EMPTY; }
         }
         __syncthreads();
     }

@@ -55,7 +55,10 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     ctx = lash_amd.Context(0)
+    only = int(os.environ["FUZZ_ONLY"]) if os.environ.get("FUZZ_ONLY") else None     # one iteration again, with the differing bytes printed
     for it in range(iters):
+        if only is not None and it != only:
+            continue
         rng = random.Random(seed0 * 100003 + it)
         an = rng.choice(["hmh", "hll", "ull"])
         if os.environ.get("FUZZ_ALGO"):                     # e.g. FUZZ_ALGO=hmh LASH_DEFER_MIN=0: every direct launch defers its signatures
@@ -92,10 +95,15 @@ def main():
                 ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=flags & ~(lash_amd.F_NO_DIRECT | lash_amd.F_STREAM_ONLY))
                 ctx.sketch_packed_device(an, k, p, seed, pk, d_img, flags=(flags & ~(lash_amd.F_NO_DIRECT | lash_amd.F_STREAM_ONLY)) | lash_amd.F_ACCUMULATE)   # idempotent
             ctx.synchronize()
+            # the device entries only FLAG a HyperLogLog genome whose `sum` the incremental rule rounds (a register above 53 - p: one
+            # k-mer in 2^37 at p = 16 — it=187 of seed 44 met one, xxh3_64 = 0x0000000002025fbf); the caller asks for the replay
+            census_before_replay = ctx.timing()["kmers"]
+            if an == "hll" and ctx.hll_inexact_sums():
+                ctx.hll_replay_sums_device(k, p, seed, d_seq, d_off, len(off) - 1, goff, d_img, flags=flags & ~(lash_amd.F_NO_DIRECT | lash_amd.F_STREAM_ONLY))
             got = d_img.cpu().numpy().reshape(len(gs), -1)
             if mode == "packed":
                 pk.free()
-        kmers = ctx.timing()["kmers"]
+        kmers = ctx.timing()["kmers"] if mode in ("host", "accumulate") or len(seq) == 0 else census_before_replay
         ctx.enable_timing(False)
         if mode == "packed":
             kmers //= 2                                      # sketched twice
@@ -104,6 +112,17 @@ def main():
         if not np.array_equal(got, want) or kmers != want_kmers:
             bad = sorted({int(r) for r in np.argwhere(got != want)[:, 0]}) if got.shape == want.shape else "shape"
             print("MISMATCH it=%d mode=%s %s k=%d p=%d seed=%d flags=%d genomes=%s census %d vs %d" % (it, mode, an, k, p, seed, flags, bad, kmers, want_kmers))
+            if only is not None and got.shape == want.shape:
+                d = np.argwhere(got != want)
+                print("  %d bytes differ; first: %s" % (len(d), [(int(g), int(o), int(got[g, o]), int(want[g, o])) for g, o in d[:24]]))
+                print("  genome sizes:", [sum(len(r) for r in g) for g in gs], "records:", [len(g) for g in gs])
+                if an == "hll":
+                    for g in sorted({int(g) for g, _ in d}):
+                        hdr = lash_amd.image_bytes(an, p) - (1 << p)
+                        regs = want[g, hdr:].astype(np.int64)
+                        print("  genome %d: sum got %r want %r (hex %s / %s); registers max %d, histogram of the top: %s; exact sum %r" % (
+                            g, got[g, 16:24].view(np.float64)[0], want[g, 16:24].view(np.float64)[0], got[g, 16:24].tobytes().hex(), want[g, 16:24].tobytes().hex(),
+                            regs.max(), np.bincount(regs)[-6:].tolist(), float(sum(np.ldexp(1.0, -int(r)) * int(c) for r, c in enumerate(np.bincount(regs))))))
             sys.exit(1)
     print("fuzz ok: %d iterations from seed %d" % (iters, seed0))
 

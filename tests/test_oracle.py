@@ -32,6 +32,24 @@ def test_xxh3_golden_vectors():
     assert n == 6 * 512
 
 
+def test_a_rank_39_kmer_met_by_the_fuzzer():
+    """tests/fuzz_gpu.py, seed 44 iteration 187 (round 4): a synthetic genome held the 31-mer 0x13399b149020b766, whose xxh3_64 under
+    seed 42 is 0x0000000002025fbf (python-xxhash, libxxhash 0.8.2, in the build container) — 38 leading zeros, one k-mer in 2^38.  At
+    p = 16 its register gets rank 39 > 53 - p: the HyperLogLog `sum` corner (tests/test_gpu_hll_corner.py) met in the wild."""
+    v, seed = 0x13399b149020b766, 42
+    assert O.xxh3_64_8b(v, seed) == 0x0000000002025fbf == R.xxh3_64_8b(v, seed)
+    try:
+        import xxhash
+        assert xxhash.xxh3_64_intdigest(v.to_bytes(8, "little"), seed=seed) == 0x0000000002025fbf
+    except ImportError:
+        pass
+    km = "".join("ACGT"[(v >> (2 * (30 - i))) & 3] for i in range(31)).encode()
+    assert O.record_kmers(km, 31)[0] == v                         # (its own canonical form)
+    img = O.sketch_genomes(O.HLL, 31, 16, seed, np.frombuffer(km, np.uint8), np.array([0, 31], np.uint64), np.array([0, 1], np.uint64))[0]
+    regs = img[O.image_bytes(O.HLL, 16) - (1 << 16):]
+    assert int(regs.max()) == 39 and int((regs != 0).sum()) == 1 and int(regs.argmax()) == 0x5fbf
+
+
 def test_appendix_b_worked_example():
     seq = b"ACGTTGCATGCATCGATCGGATTACA"
     k16 = O.record_kmers(seq, 16)
