@@ -160,8 +160,14 @@ struct BinRegs {
     __device__ __forceinline__ void flush(uint32_t lane) const
     {
         auto lds = [](uint32_t b) { return (__attribute__((address_space(3))) uint32_t *)(uintptr_t)b; };
-        for (uint32_t r0 = 0; r0 < V; r0 += 64u) {
-            const uint32_t row = r0 + lane;
+        // 64 rows and more (64 bins and more, a row per lane): up to four groups of 64 rows; ALL their reservations are issued before the
+        // first copy waits for one (p = 22, 256 rows: four returning atomics one after the other per word of 16 k-mers were most of its pass)
+        uint32_t n_[4], base_[4];
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) {
+            n_[g] = 0u; base_[g] = 0u;
+            if (g * 64u >= V) continue;
+            const uint32_t row = g * 64u + lane;
             uint32_t n = 0;
             if (row < V) {
                 n = *lds(cnt_b + row * 4u);
@@ -188,6 +194,13 @@ struct BinRegs {
                 bin_base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs * 4u), (int)bin_base);
                 base = bin_base + (incl - n4) - before;
             }
+            n_[g] = n; base_[g] = base;
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < 4u; ++g) {
+            if (g * 64u >= V) continue;
+            const uint32_t row = g * 64u + lane, n = n_[g], base = base_[g];
+            const uint32_t n4 = (n + 3u) & ~3u, bin = row >> sub_shift;
             uint32_t *dst = lists + (uint64_t)bin * cap;
             const uint32_t src = stage_b + row * (S + 4u) * 4u;
             for (uint32_t i = 0; i < n4; i += 4u) {
