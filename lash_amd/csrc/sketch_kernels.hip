@@ -549,14 +549,12 @@ __device__ __forceinline__ Brk96 uniform_breaks(uint32_t pos, uint32_t RL, uint3
 // The same mask for equal-length records, without the bitmap detour: a record start at b (a multiple of RL, b > 0) invalidates the
 // k-1 windows that begin in [b-k+1, b-1].  One modulo and, per record start within reach of the lane's 64 windows (at most one
 // when RL >= 64 + k), two shifts — instead of uniform_breaks' bit loop plus the doubling OR above (90 instructions per lane and tile).
-// (m = pos0 % RL, kept by the caller from tile to tile: the division — a reciprocal that hipcc spilled and reloaded once per tile,
-// waiting for it — is done once per work item)
-__device__ __forceinline__ uint64_t uniform_valid_mask(uint32_t pos0, uint32_t m, uint32_t RL, uint32_t nk, int k)
+__device__ __forceinline__ uint64_t uniform_valid_mask(uint32_t pos0, uint32_t RL, uint32_t nk, int k)
 {
     const uint32_t lim = nk - pos0;                       // caller guarantees pos0 < nk
     const uint64_t kvm = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
     if (k == 1) return kvm;
-    const uint32_t reach = 64u + (uint32_t)k - 1u;
+    const uint32_t m = pos0 % RL, reach = 64u + (uint32_t)k - 1u;
     uint64_t bad = 0;
     for (uint32_t b = RL - m; b < reach; b += RL) {       // (m == 0: the record that starts AT pos0 is no barrier for its own windows)
         const uint32_t lo = b >= (uint32_t)k - 1u ? b - ((uint32_t)k - 1u) : 0u, hi = b - 1u < 63u ? b - 1u : 63u;   // windows lo..hi span the start
@@ -1604,13 +1602,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // equal-length records: the lane's position modulo the record length, stepped from tile to tile (uniform_valid_mask)
-    uint32_t rl_m = 0, rl_delta = 0;
-    if (RL) {
-        rl_m = (uint32_t)((((uint64_t)it.word_begin + threadIdx.x * SKETCH_WORDS_PER_THREAD) * 16) % RL);
-        rl_delta = (uint32_t)(((uint64_t)step * 16) % RL);
-    }
-    for (uint32_t tile = it.word_begin; tile < it.word_end; tile += step, rl_m = rl_m + rl_delta >= RL ? rl_m + rl_delta - RL : rl_m + rl_delta) {
+    for (uint32_t tile = it.word_begin; tile < it.word_end; tile += step) {
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
         const uint64_t pos0 = (uint64_t)w0 * 16;
         const bool active = tile_active(tile);
@@ -1645,7 +1637,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     if constexpr (KMODE == KM_GT16) c5 = t.w[5];
                     bad |= t.bad;
                 }
-                if (RL) kv = uniform_valid_mask((uint32_t)pos0, rl_m, RL, (uint32_t)nk, k);
+                if (RL) kv = uniform_valid_mask((uint32_t)pos0, RL, (uint32_t)nk, k);
                 else kv = kmer_valid_mask(cur.b.x, cur.b.y, cur.b.z, (uint32_t)pos0, (uint32_t)nk, k);
             }
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad != 0u) != 0ull, 0)) {      // (unlikely: keeps its spills out of the clean path)
