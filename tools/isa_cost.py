@@ -218,6 +218,10 @@ def main():
         sys.exit("kernel name matches %d functions: %s" % (len(match), match[:8]))
     blocks = ks[match[0]]
     print("kernel:", match[0])
+    # register spills: a kernel at its register cap that gains two live values starts spilling per tile (seen in round 4 as + 1.7 GB
+    # of HBM writes per launch of the hll k = 21 kernel, time unchanged) — the count to compare from build to build
+    sc = [(label, raw) for label, insts in blocks for mn, ops, raw in insts if mn.startswith("scratch_")]
+    print("scratch instructions in the whole kernel: %d (%d stores) in %d blocks" % (len(sc), sum(r.startswith("scratch_store") for _, r in sc), len({l for l, _ in sc})))
     if args.blocks:
         for label, insts in blocks:
             sig = signature(insts)
@@ -234,6 +238,9 @@ def main():
         for l in labels:
             total += block_hist(bd[l])
         print("\n== %s  [%s -> %d block(s): %s; %.4g k-mers per lane]" % (name, sel, len(labels), ", ".join("%s(%d)" % (l, len(bd[l])) for l in labels), kmers))
+        n_sc = sum(mn.startswith("scratch_") for l in labels for mn, ops, raw in bd[l])
+        if n_sc:
+            print("   (%d scratch instructions inside this section)" % n_sc)
         if args.dump:
             for l in labels:
                 print("--", l)
