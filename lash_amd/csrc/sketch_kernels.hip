@@ -176,6 +176,9 @@ struct BinRegs {
             }
             const uint32_t n4 = (n + 3u) & ~3u, bin = row >> sub_shift;
             uint32_t base;
+#ifdef LASH_ABL_BINS_NO_ATOMIC  // timing-only diagnostic build: every row lands at the start of its list
+            if (true) { base = 0u; (void)bin; } else
+#endif
             if (sub_shift == 0u) {
                 base = n4 ? __hip_atomic_fetch_add(cnt + bin, n4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
             } else {
@@ -213,8 +216,12 @@ struct BinRegs {
                     q.w = 0xFFFFFFFFu;
                 }
                 const uint32_t at = base + i;
+#ifdef LASH_ABL_BINS_NO_STORE   // timing-only diagnostic build (tools/build_variant.sh): results are wrong by construction
+                asm volatile("" ::"v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w), "v"(at));
+#else
                 if (at + 4u <= cap) *reinterpret_cast<uint4 *>(dst + at) = q;
                 else { spill_entry(q.x); spill_entry(q.y); spill_entry(q.z); spill_entry(q.w); }
+#endif
             }
         }
     }
