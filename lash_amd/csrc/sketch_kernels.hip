@@ -1609,6 +1609,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#ifdef LASH_ABL_PROLOGUE_ONLY   // timing-only diagnostic builds (tools/build_variant.sh): results are wrong by construction
+    if (a.k != 99) return;
+#endif
     for (uint32_t tile = it.word_begin; tile < it.word_end; tile += step) {
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
         const uint64_t pos0 = (uint64_t)w0 * 16;
@@ -1805,6 +1808,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     if constexpr (DEFER) sigq_drain<true>(regs, kp.bitflip, p, sigq);
     if constexpr (Regs::QUEUED) regs.template drain<true>();
+#ifdef LASH_ABL_NO_FLUSH
+    if (a.k != 99) return;
+#endif
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
 }
 
