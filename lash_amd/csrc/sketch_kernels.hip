@@ -826,12 +826,82 @@ __device__ __noinline__ void write_header(uint8_t *img, uint64_t tpl, uint64_t a
         }
     }
 }
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)      // every lane in, the total in lane 63 (full exec mask)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+// The header's histogram of an image being written: every register's rho counted in LDS.  One atomic per register put thousands of
+// them on the two or three words of the common ranks (hist[1], hist[2], ...): 4 096 registers of a 10 kbp genome took 7 us, a quarter
+// of its workgroup's time.  Ranks below 8 are tallied per lane in eight 8-bit fields first and leave as one atomic per wave and rank.
+struct HllTally {
+    uint64_t packed = 0;           // eight counts of 8 bits: rho 0 .. 7
+    uint32_t words = 0;            // words tallied since the last flush (4 registers each: 63 words cannot overflow a field)
+    __device__ __forceinline__ void add(uint32_t *hist, uint32_t v)          // v: four registers
+    {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t rho = (v >> (8 * b)) & 0xFFu;
+            if (rho < 8u) packed += 1ull << (8u * rho);
+            else atomicAdd(&hist[rho < 71u ? rho : 71u], 1u);
+        }
+        if (++words == 63u) flush(hist);
+    }
+    __device__ __forceinline__ void flush(uint32_t *hist)                    // (lanes may arrive here at different times: no wave-wide step inside a branch)
+    {
+        if (__builtin_amdgcn_ballot_w64(true) == ~0ull) {                     // the whole wave is here: one atomic per rank
+#pragma unroll
+            for (uint32_t r = 0; r < 8u; ++r) {
+                const uint32_t tot = wave_sum_dpp((uint32_t)(packed >> (8u * r)) & 0xFFu);
+                if ((threadIdx.x & 63u) == 63u && tot) atomicAdd(&hist[r], tot);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t r = 0; r < 8u; ++r) {
+                const uint32_t c = (uint32_t)(packed >> (8u * r)) & 0xFFu;
+                if (c) atomicAdd(&hist[r], c);
+            }
+        }
+        packed = 0; words = 0;
+    }
+};
 // HLL: zero and sum are recomputed from the final registers' histogram.  The reference keeps `sum` incrementally
 // (sum -= 2^-old; sum += 2^-new per k-mer).  While every register is <= 53 - p each of those
 // updates is exact — sum < 2^p after the first one and every term is a multiple of 2^(p-53), so nothing ever needs more
 // than 53 bits — and the incremental value IS sum_j 2^-m[j], which the histogram gives exactly in any order.  A register
 // above 53 - p (one k-mer in 2^(52-p)) brings terms below the grid: the reference's value then depends on the order of
 // its roundings, the one here is the correctly rounded exact sum; `corner` reports the genome (lash_ctx_hll_inexact_sums).
+__device__ __forceinline__ void write_hll_header(uint8_t *img, uint64_t tpl, const uint32_t *hist, uint64_t alpha_bits, int p,
+                                                 uint32_t *corner);
+// The same header by the 64 lanes of a workgroup's FIRST wave (every lane must call it).  One thread walking the 72 ranks — load,
+// branch, convert, multiply, add, each waiting for the last — held its workgroup's slot for ~5 us: 18 % of a 10 kbp genome's time.
+// While no rank lies above 53 - p every term hist[r] * 2^-r is a multiple of 2^-(53-p) and the sum is an integer below 2^54 in those
+// units: lane r shifts its count into place, three 22-bit limbs go through a DPP wave sum each, lane 63 converts — the same double
+// the sequential loop gets, because nothing in either is rounded.  A rank above 53 - p (the `sum` corner): the sequential loop.
+__device__ __forceinline__ void write_hll_header_wave(uint8_t *img, uint64_t tpl, const uint32_t *hist, uint64_t alpha_bits, int p,
+                                                      uint32_t *corner)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const int R = 53 - p;                                                   // 37 .. 49
+    const uint32_t h0 = hist[lane], h1 = lane < 8u ? hist[64u + lane] : 0u;
+    const bool above = ((int)lane > R && h0 != 0u) || h1 != 0u;
+    if (__builtin_amdgcn_ballot_w64(above) != 0ull) {
+        if (lane == 0u) write_hll_header(img, tpl, hist, alpha_bits, p, corner);
+        return;
+    }
+    const uint64_t v = (int)lane <= R ? (uint64_t)h0 << (uint32_t)(R - (int)lane) : 0ull;   // < 2^(p + 53 - p) = 2^53 (+ the others: < 2^54)
+    const uint32_t a = wave_sum_dpp((uint32_t)v & 0x3FFFFFu), b = wave_sum_dpp((uint32_t)(v >> 22) & 0x3FFFFFu), c = wave_sum_dpp((uint32_t)(v >> 44));
+    if (lane == 63u) {
+        const uint64_t S = (uint64_t)a + ((uint64_t)b << 22) + ((uint64_t)c << 44);
+        const double sum = (double)S * __longlong_as_double((long long)(1023 - R) << 52);      // S <= 2^53: exact; the scaling too
+        write_header(img, tpl, alpha_bits, 1ull << p, hist[0], sum, p);
+    }
+}
 __device__ __forceinline__ void write_hll_header(uint8_t *img, uint64_t tpl, const uint32_t *hist, uint64_t alpha_bits, int p,
                                                  uint32_t *corner)
 {
@@ -1399,18 +1469,13 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
             __syncthreads();
         }
     }
+    HllTally tally;
     auto put = [&](uint32_t i, uint32_t v) {
         if (!sole) { out[i] = v; return; }
         uint8_t *dst = img + HDR + 4ull * i;
         if (a.accumulate) v = merge_word<ALGO>(hmh_img_order(load_u32_any(dst), reg_be), v);
         store_u32_any(dst, hmh_img_order(v, reg_be));
-        if constexpr (ALGO == 1) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t rho = (v >> (8 * b)) & 0xFFu;
-                atomicAdd(&hist[rho < 71u ? rho : 71u], 1u);
-            }
-        }
+        if constexpr (ALGO == 1) tally.add(hist, v);
     };
     // table words -> registers of the image (see "register spaces" at the top of the file)
     auto hmh_reg = [](uint32_t raw) { return (int32_t)raw < 0 ? 0u : raw + 0x400u; };       // (lz - 1) << 10 | sig, -1 = empty -> lz << 10 | sig, 0
@@ -1424,8 +1489,9 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
         }
         if constexpr (ALGO == 1) {
             if (sole) {
+                tally.flush(hist);
                 __syncthreads();
-                if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
+                if (threadIdx.x < 64u) write_hll_header_wave(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
             }
         } else {
             if (sole && threadIdx.x == 0) write_header(img, a.lay.hdr_tpl, a.alpha_bits, 1ull << p, 0, 0.0, p);
@@ -1441,8 +1507,9 @@ __device__ __forceinline__ void finish_item(const SketchArgs &a, const WorkItem 
         for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x)
             put(i, hll_reg(regs.get(4 * i)) | (hll_reg(regs.get(4 * i + 1)) << 8) | (hll_reg(regs.get(4 * i + 2)) << 16) | (hll_reg(regs.get(4 * i + 3)) << 24));
         if (sole) {
+            tally.flush(hist);
             __syncthreads();
-            if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
+            if (threadIdx.x < 64u) write_hll_header_wave(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + it.genome : nullptr);
         }
     } else {
         const uint32_t nw = (1u << p) >> 2;
@@ -2424,6 +2491,7 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
     // a genome sketched by a single work item has had its image written by that item (ITEM_SOLE, sketch_kernel)
     if (i1 - i0 == 1u && (a.items[i0].slice & ITEM_SOLE)) return;
 
+    HllTally tally;
     for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
         uint32_t acc = a.accumulate ? hmh_img_order(load_u32_any(img + hdr + 4ull * wi), reg_be) : 0u;
         const uint32_t part = a.parts_log2 ? wi / (nwords >> a.parts_log2) : 0u;   // whose pass wrote this word
@@ -2433,17 +2501,12 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
             acc = merge_word<ALGO>(acc, hmh_img_order(load_u32_any(src + 4ull * wi), src_be));
         }
         store_u32_any(img + hdr + 4ull * wi, hmh_img_order(acc, reg_be));
-        if constexpr (ALGO == 1) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t rho = (acc >> (8 * b)) & 0xFFu;
-                atomicAdd(&hist[rho < 71u ? rho : 71u], 1u);
-            }
-        }
+        if constexpr (ALGO == 1) tally.add(hist, acc);
     }
     if constexpr (ALGO == 1) {
+        tally.flush(hist);
         __syncthreads();
-        if (threadIdx.x == 0) write_hll_header(img, a.lay.hdr_tpl, hist, a.alpha_bits, a.p, a.hll_corner ? a.hll_corner + g : nullptr);
+        if (threadIdx.x < 64u) write_hll_header_wave(img, a.lay.hdr_tpl, hist, a.alpha_bits, a.p, a.hll_corner ? a.hll_corner + g : nullptr);
     } else {
         if (threadIdx.x == 0 && hdr) write_header(img, a.lay.hdr_tpl, a.alpha_bits, ALGO == 0 ? HMH_M : (1ull << a.p), 0, 0.0, ALGO == 0 ? HMH_P : a.p);
     }
