@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define LASH_ABI_VERSION 4
+#define LASH_ABI_VERSION 5
 
 /* error codes */
 #define LASH_OK       0
@@ -61,6 +61,12 @@ extern "C" {
 #define LASH_F_STREAM_ONLY 16u /* lash_sketch_batch[_device]: skip the optimistic pass, every genome goes through the compacting
                                   kernel (stream_sketch_kernel) — what the context does by itself while batches keep turning out
                                   soft-masked.  Same images; for A/B runs and tests */
+
+#define LASH_F_NO_SOLE     32u /* (ABI v5) every sketch entry: do not use the persistent small-genome kernel (sole_kernels.hip), which by
+                                  default takes the genomes of a call that are at most LASH_SOLE_MAX bytes long (environment,
+                                  default 393216; 0 = never) when the sketch's table fits 64 KiB of LDS — a resident workgroup streams
+                                  whole genomes through an LDS ring instead of one workgroup per genome.  Same images; for A/B
+                                  runs and tests */
 
 typedef struct lash_ctx lash_ctx;        /* one per (host thread, GPU): stream, workspace, scratch */
 typedef struct lash_packed lash_packed;  /* device-resident 2-bit genomes produced by lash_pack_* */
@@ -118,6 +124,7 @@ typedef struct {
     uint64_t packed_bytes;      /* 2-bit words + break bitmap read by the sketch kernel, summed            */
     float    direct_ms;         /* the part of sketch_ms spent in the direct (ASCII-reading) sketch kernel */
     uint32_t defer_launches;    /* of sketch_launches: HyperMinHash with deferred signatures (batches of long work items)  */
+    uint32_t sole_launches;     /* (ABI v5) launches of the persistent small-genome kernel summed (sole_kernels.hip)         */
 } lash_timing;
 
 /* ---- library / context ---------------------------------------------------------------------------------- */

@@ -11,9 +11,9 @@ LIB_PATH = os.environ.get("LASH_GFX950_LIB") or os.path.join(PKG, "liblash_gfx95
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ELIMIT, ERANGE, EFORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 HMH, HLL, ULL = 0, 1, 2
-F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT, F_AMINO, F_STREAM_ONLY = 1, 2, 4, 8, 16
+F_HMH_X_LOW, F_ACCUMULATE, F_NO_DIRECT, F_AMINO, F_STREAM_ONLY, F_NO_SOLE = 1, 2, 4, 8, 16, 32
 FMT_FASTA, FMT_FASTQ = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Params(C.Structure):
@@ -32,7 +32,7 @@ class Timing(C.Structure):
     _fields_ = [("pack_ms", C.c_float), ("sketch_ms", C.c_float), ("finalize_ms", C.c_float), ("calls", C.c_uint32),
                 ("sketch_launches", C.c_uint32), ("sketch_workgroups", C.c_uint32), ("direct_launches", C.c_uint32),
                 ("kmers", C.c_uint64), ("bases_last", C.c_uint64), ("packed_bytes", C.c_uint64),
-                ("direct_ms", C.c_float), ("defer_launches", C.c_uint32)]
+                ("direct_ms", C.c_float), ("defer_launches", C.c_uint32), ("sole_launches", C.c_uint32)]
 
 
 _vp, _u64, _u32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int

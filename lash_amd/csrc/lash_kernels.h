@@ -105,6 +105,65 @@ hipError_t launch_sketch_stream(const SketchPlan &plan, const SketchArgs &args, 
 uint32_t sketch_direct_stage_bytes(const SketchPlan &plan);
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream,
                          bool direct = false);
+// ---- whole small genomes on persistent workgroups (sole_kernels.hip, round 5) -------------------------------------------------
+// One sketch per file whatever its size (utils.rs:450-509): a collection of viruses, plasmids, amplicons or contigs is very many
+// genomes of a few kbp.  sketch_kernel gives each a workgroup of its own, whose fixed cost — three dependent loads to find its
+// bytes, a 64-byte-per-lane tile that a 10 kbp genome fills with 2.5 waves, the flush — is 20 us against 1..7 us of hashing.
+// sole_sketch_kernel keeps workgroups resident instead: each takes CHUNKS of consecutive genomes (planned on the host from the
+// genome byte offsets alone: no GenomeDesc, no work items) and streams their bytes through an LDS ring of 2-bit bases — every
+// byte converted once, deleted bytes dropped on the way in (filter_out_n, utils.rs:33-41), record starts as bits beside the
+// bases — from which every lane hashes ONE word (16 k-mer starts) per round; the next round's bytes (the next genome's, when this
+// one ends) are in flight meanwhile, and the image leaves LDS in 16-byte stores.
+struct SoleArgs {
+    // ASCII source (PACKED = false)
+    const uint8_t  *seq;              // the caller's record bytes
+    uint64_t        seq_bytes;        // readable bytes of seq
+    const uint64_t *genome_byte_off;  // [n_genomes + 1] device copy: genome g = bytes [genome_byte_off[g], genome_byte_off[g + 1])
+    const uint32_t *brk_abs;          // NULL (every genome has one record), or bit b set <=> a record starts at byte b of seq (sole_mark_kernel)
+    const uint8_t  *safe;             // >= 16 readable bytes: load target of the lanes whose 16 bytes run past seq
+    uint32_t       *ndel;             // NULL, or [n_genomes]: bytes deleted from each genome sketched here (calls that also run the sliced launch
+                                      // keep their census per genome: lash_timing::bases_last)
+    // packed source (PACKED = true): the pack stage's 2-bit stream, break bitmap, descriptors and surviving-base counts
+    const uint32_t   *words;
+    const uint32_t   *brk;
+    const GenomeDesc *genomes;
+    const uint64_t   *nvalid;
+    // work
+    const uint32_t *chunk_begin;      // [n_chunks + 1] genomes [chunk_begin[c], chunk_begin[c + 1]) form chunk c
+    uint32_t        n_chunks;
+    uint32_t       *ticket;           // zeroed: chunks beyond the first gridDim.x are handed out through it
+    uint64_t        max_len;          // genomes longer than this many bytes (packed: words * 16) belong to the sliced launch
+    // out
+    uint8_t        *images;
+    uint64_t        image_bytes;
+    uint64_t        alpha_bits;       // HLL alpha as f64 bits
+    int             accumulate;
+    uint32_t       *hll_corner;       // NULL or [n_genomes], see FinalizeArgs
+    unsigned long long *wg_counts;    // [gridDim.x][2]: valid k-mers, surviving bases of the genomes this workgroup sketched
+    uint64_t        bitflip;
+    LayoutDev       lay;
+    uint32_t        nreg32;           // table words (HMH 16384, HLL 2^p, ULL 2 * 2^p)
+    int             k, p;
+    // LDS layout (byte offsets; the table starts at 0)
+    uint32_t        hist_off;         // 80 words: HyperLogLog header histogram
+    uint32_t        scan_off;         // 2 x 8 words: the waves' survivor counts of a round (double-buffered)
+    uint32_t        ring_off;         // ring_words words of 2-bit bases
+    uint32_t        brk_off;          // ring_words / 2 words of record-start bits
+    uint32_t        ring_words;       // a power of two, >= 4 * threads
+    uint32_t        lds_words;        // everything, for the initial clear
+};
+struct SolePlan {
+    bool     ok;                      // the sketch type has a table the persistent kernel holds (<= 64 KiB of LDS)
+    uint32_t threads, lds_bytes, wg_per_cu;
+    uint32_t hist_off, scan_off, ring_off, brk_off, ring_words;
+};
+SolePlan make_sole_plan(int algo, int p);
+hipError_t launch_sole(const SolePlan &plan, int algo, int k, bool x_low, bool packed, const SoleArgs &args, uint32_t n_wg, hipStream_t stream);
+// bit b of brk_abs (zeroed, (seq_bytes + 63) / 32 + 2 words) set <=> some record starts at byte b
+hipError_t launch_sole_mark(const uint64_t *rec_off, uint64_t n_rec, uint64_t seq_bytes, uint32_t *brk_abs, hipStream_t stream);
+// wg_counts -> the context's k-mer census (counter[0]) and surviving-base count (counter[1])
+hipError_t launch_sole_census(const unsigned long long *wg_counts, uint32_t n_wg, unsigned long long *counter, unsigned long long *bases, hipStream_t stream);
+
 // amino-acid sketches (LASH_F_AMINO; utils.rs:511-563): work items are RECORD ranges of a genome (WorkItem::word_begin / word_end =
 // record indices relative to the genome's first), a lane walks one record at a time; args.seq / args.rec_off = the caller's bytes
 hipError_t launch_sketch_aa(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream);
@@ -154,6 +213,8 @@ struct FinalizeArgs {
     int             src_images;          // the "partials" are images (lash_merge_images): HMH registers in image byte order
     uint32_t        group;               // 0, or G: launch_reduce_groups() has folded every G consecutive slices (per
                                          // pass) into the first one's partial; only those group heads are read
+    const GenomeDesc *descs;             // NULL, or: genomes of at most skip_max_len bytes are not this launch's (the persistent
+    uint64_t        skip_max_len;        // small-genome kernel writes their images: sole_kernels.hip)
 };
 // Many slices per genome (one metagenome-sized input: thousands of work items, one finalize workgroup): fold every R
 // consecutive slices into the first one's partial, in place, with one workgroup per (genome, pass, group).

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(raw, n), "liblash_gfx950.so does not export %s" % n
         assert n in _lib.PROTOTYPES, "lash_amd/_lib.py has no prototype for %s" % n
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.lash_abi_version() == 4
+    assert lib.lash_abi_version() == 5
 
 
 def test_image_sizes_and_param_checks():
