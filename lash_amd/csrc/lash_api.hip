@@ -332,6 +332,14 @@ uint64_t sole_max_bytes(const lash_ctx *ctx, const lash_params *prm, const SoleP
     return v > 0 ? (uint64_t)v : 0;
 }
 
+// chunks per workgroup: the launch's tail is one chunk long (tools/: LASH_SOLE_CHUNKS)
+uint32_t sole_chunks_per_wg()
+{
+    const char *e = getenv("LASH_SOLE_CHUNKS");
+    const int v = e ? atoi(e) : 24;
+    return (uint32_t)std::max(1, std::min(v, 4096));
+}
+
 // Chunks of consecutive genomes of about equal cost, planned from the genome byte offsets alone: cost = bytes + a fixed part per
 // genome (its flush).  off[g] = first byte (or any monotone position) of genome g, off[n] = the end.
 void sole_chunks(const uint64_t *off, uint32_t n_genomes, uint64_t fixed, uint32_t want, std::vector<uint32_t> &chunk_begin)
@@ -366,8 +374,14 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
     if (n_genomes == 0) return LASH_OK;
     const bool packed = pk != nullptr;
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
-    const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)ctx->cu_count * sp.wg_per_cu, n_genomes);
-    // chunks: eight per workgroup, so that the tail of the launch is an eighth of a workgroup's share
+    const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
+    // as many workgroups as are RESIDENT at a time (the kernel variant's registers, LDS and wave slots taken together): chunks are handed
+    // out to running workgroups, one that started late would only hold its first chunk back
+    uint32_t per_cu = sp.wg_per_cu;
+    HIPCHK(ctx, sole_resident_per_cu(sp, prm->algo, prm->k, x_low, packed, &per_cu));
+    const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)ctx->cu_count * per_cu, n_genomes);
+    // chunks: a couple of dozen per workgroup, so that the tail of the launch is a few percent of a workgroup's share — but none
+    // smaller than ~100 us of a workgroup's time (a chunk starts with a few dependent loads: 3..5 us)
     std::vector<uint32_t> chunk_begin;
     std::vector<uint64_t> off_tmp;
     const uint64_t *off = genome_byte_off;
@@ -377,16 +391,29 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
         for (uint32_t g = 0; g < n_genomes; ++g) off_tmp[g + 1] = off_tmp[g] + pk->byte_len[g];
         off = off_tmp.data();
     }
-    sole_chunks(off, n_genomes, image_bytes / 4 + 256, n_wg * 8u, chunk_begin);
+    {
+        const uint64_t fixed = image_bytes / 4 + 256;
+        const uint64_t total = off[n_genomes] - off[0] + fixed * n_genomes;
+        const uint64_t min_cost = 512ull * sp.threads;                     // 256 KiB for eight waves, 32 KiB for one
+        const uint64_t by_cost = std::max<uint64_t>(n_wg, total / min_cost);
+        sole_chunks(off, n_genomes, fixed, (uint32_t)std::min<uint64_t>((uint64_t)n_wg * sole_chunks_per_wg(), by_cost), chunk_begin);
+    }
     const uint32_t n_chunks = (uint32_t)chunk_begin.size() - 1;
     int rc;
     std::vector<Section> sec = {{chunk_begin.data(), chunk_begin.size() * 4, 0}};
-    if (!packed) sec.push_back({genome_byte_off, ((size_t)n_genomes + 1) * 8, 0});
+    // every genome exactly one record (the usual case: one sequence per file): its byte offsets ARE the record offsets, which are
+    // resident already — no per-genome table goes up at all
+    const bool gbo_is_rec_off = !packed && !any_multi && n_rec == n_genomes && d_rec_off != nullptr;
+    if (!packed && !gbo_is_rec_off) sec.push_back({genome_byte_off, ((size_t)n_genomes + 1) * 8, 0});
     const size_t tabs = layout_sections(sec), counts_bytes = ((size_t)n_wg * 16 + 255) & ~(size_t)255;
     if ((rc = reserve(ctx, ctx->sole_tab, tabs + counts_bytes + 256))) return rc;
     if ((rc = upload_sections(ctx, ctx->sole_tab.ptr, sec, tabs, ctx->stream))) return rc;
     uint8_t *tb = static_cast<uint8_t *>(ctx->sole_tab.ptr);
-    HIPCHK(ctx, hipMemsetAsync(tb + tabs + counts_bytes, 0, 64, ctx->stream));                  // the chunk ticket
+    if (!ctx->sole_state.ptr) {
+        // the chunk ticket: zero at rest (sole_census_kernel, which follows every launch on the stream, puts it back)
+        if ((rc = reserve(ctx, ctx->sole_state, 256))) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->sole_state.ptr, 0, 256, ctx->stream));
+    }
     if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
     if (!ctx->counter_zeroed) {
         HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));
@@ -395,14 +422,14 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
     SoleArgs sa{};
     sa.chunk_begin = reinterpret_cast<const uint32_t *>(tb + sec[0].off);
     sa.n_chunks = n_chunks;
-    sa.ticket = reinterpret_cast<uint32_t *>(tb + tabs + counts_bytes);
+    sa.ticket = static_cast<uint32_t *>(ctx->sole_state.ptr);
     sa.wg_counts = reinterpret_cast<unsigned long long *>(tb + tabs);
     sa.max_len = max_len;
     sa.safe = static_cast<const uint8_t *>(ctx->counter.ptr) + 128;
     if (!packed) {
         sa.seq = d_seq;
         sa.seq_bytes = seq_bytes;
-        sa.genome_byte_off = reinterpret_cast<const uint64_t *>(tb + sec[1].off);
+        sa.genome_byte_off = gbo_is_rec_off ? d_rec_off : reinterpret_cast<const uint64_t *>(tb + sec[1].off);
         sa.ndel = per_genome_ndel;
         if (any_multi) {
             // some genome has more than one record: record starts as bits at absolute byte positions (16 spare bytes: a lane reads
@@ -432,10 +459,9 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
     sa.nreg32 = prm->algo == LASH_HMH ? HMH_M : prm->algo == LASH_HLL ? (1u << prm->p) : (2u << prm->p);
     sa.k = prm->k;
     sa.p = prm->p;
-    const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
     HIPCHK(ctx, launch_sole(sp, prm->algo, prm->k, x_low, packed, sa, n_wg, ctx->stream));
     unsigned long long *ctr = static_cast<unsigned long long *>(ctx->counter.ptr);
-    HIPCHK(ctx, launch_sole_census(sa.wg_counts, n_wg, ctr, ctr + 1, ctx->stream));
+    HIPCHK(ctx, launch_sole_census(sa.wg_counts, n_wg, ctr, ctr + 1, sa.ticket, ctx->stream));
     ctx->last.sole_launches += 1;
     return LASH_OK;
 }
@@ -445,7 +471,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     const uint32_t n_genomes = pk->n_genomes;
     // Genomes of at most sole_max bytes go to the persistent kernel (sole_kernels.hip), the others are cut into work items as ever;
     // blen() is a genome's length as the planning below sees it (0 = not this launch's)
-    const SolePlan sole_plan = make_sole_plan(prm->algo, prm->p);
+    const SolePlan sole_plan = make_sole_plan(prm->algo, prm->p, n_genomes, (uint32_t)ctx->cu_count);
     uint64_t sole_max = sole_max_bytes(ctx, prm, sole_plan);
     if (pk->direct && n_genomes && pk->h_descs[n_genomes - 1].byte_off + pk->h_descs[n_genomes - 1].byte_len < 16) sole_max = 0;   // (the kernel loads 16 bytes at a time, from inside the buffer)
     auto blen = [&](uint32_t g) -> uint64_t { return pk->byte_len[g] <= sole_max && sole_max ? 0 : pk->byte_len[g]; };
@@ -469,9 +495,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         int rc;
         ctx->hll_flags_n = 0;
         ctx->hll_flags_on_host = false;
-        if (prm->algo == LASH_HLL) {
+        if (prm->algo == LASH_HLL) {                                    // (every genome's flag is written by the kernel: nothing to clear)
             if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
-            HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
             ctx->hll_flags_n = n_genomes;
         }
         if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
@@ -1289,6 +1314,7 @@ void lash_ctx_destroy(lash_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     release(ctx->sole_tab);
     release(ctx->sole_brk);
+    release(ctx->sole_state);
     for (DevBuf *b : {&ctx->items, &ctx->item_begin, &ctx->item_kmers, &ctx->partials, &ctx->gregs, &ctx->counter, &ctx->st_seq, &ctx->st_rec,
                       &ctx->st_img, &ctx->hll_flags, &ctx->ec_ref, &ctx->ec_qry, &ctx->ec_x, &ctx->ec_card, &ctx->hll_bm_ref,
                       &ctx->hll_bm_qry, &ctx->hll_lohi})
@@ -1529,7 +1555,7 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
         // Nothing but small genomes (a viral / plasmid / amplicon collection): the persistent kernel takes the whole call, planned
         // from the byte offsets alone — no descriptors, no work items, no pack tables (sole_kernels.hip; VERDICT r4 next #1: the
         // host loops over genomes were 17 ms per 10^6 genomes)
-        const SolePlan sp = make_sole_plan(prm->algo, prm->p);
+        const SolePlan sp = make_sole_plan(prm->algo, prm->p, n_genomes, (uint32_t)ctx->cu_count);
         const uint64_t smax = sole_max_bytes(ctx, prm, sp);
         bool all_small = smax != 0 && genome_byte_off[n_genomes] >= 16, any_multi = false;   // (the kernel loads 16 bytes at a time, from inside the buffer)
         for (uint32_t g = 0; g < n_genomes && all_small; ++g) {
@@ -1540,9 +1566,8 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
         if (all_small) {
             ctx->hll_flags_n = 0;
             ctx->hll_flags_on_host = false;
-            if (prm->algo == LASH_HLL) {
+            if (prm->algo == LASH_HLL) {                                // (every genome's flag is written by the kernel: nothing to clear)
                 if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
-                HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
                 ctx->hll_flags_n = n_genomes;
             }
             if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));

@@ -138,7 +138,7 @@ struct lash_ctx {
     int bins_slab_fill = -1; size_t bins_slab_clean = 0;   // the fallback tables rest EMPTY between launches: with which byte (0x00 ull / 0xFF hll; -1: unknown), how far
     DevBuf bins_lists, bins_meta, bins_slab;   // binned launches (SketchPlan::bins): entry lists, tables + counters, fallback tables of one genome group
     bool counter_zeroed = false;
-    DevBuf sole_tab, sole_brk;           // persistent small-genome launches (sole_kernels.hip): [chunks | genome byte offsets | per-workgroup
+    DevBuf sole_tab, sole_brk, sole_state;           // persistent small-genome launches (sole_kernels.hip): [chunks | genome byte offsets | per-workgroup
                                          // counts | ticket]; record starts as bits at absolute byte positions
     bool last_sole_only = false;         // the last sketch call ran on that kernel alone (lash_timing::bases_last comes from its census)
     DevBuf st_seq, st_rec, st_img;       // staging for the synchronous host-buffer entries (files_raw, merge, pair statistics)

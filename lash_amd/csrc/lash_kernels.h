@@ -157,12 +157,16 @@ struct SolePlan {
     uint32_t threads, lds_bytes, wg_per_cu;
     uint32_t hist_off, scan_off, ring_off, brk_off, ring_words;
 };
-SolePlan make_sole_plan(int algo, int p);
+SolePlan make_sole_plan(int algo, int p, uint32_t n_genomes = 0, uint32_t cu_count = 256);   // n_genomes: of the call, 0 = unknown
 hipError_t launch_sole(const SolePlan &plan, int algo, int k, bool x_low, bool packed, const SoleArgs &args, uint32_t n_wg, hipStream_t stream);
+// workgroups of that launch's kernel variant that one CU holds at a time (hipOccupancyMaxActiveBlocksPerMultiprocessor): the launch is
+// sized to what is resident
+hipError_t sole_resident_per_cu(const SolePlan &plan, int algo, int k, bool x_low, bool packed, uint32_t *out);
 // bit b of brk_abs (zeroed, (seq_bytes + 63) / 32 + 2 words) set <=> some record starts at byte b
 hipError_t launch_sole_mark(const uint64_t *rec_off, uint64_t n_rec, uint64_t seq_bytes, uint32_t *brk_abs, hipStream_t stream);
 // wg_counts -> the context's k-mer census (counter[0]) and surviving-base count (counter[1])
-hipError_t launch_sole_census(const unsigned long long *wg_counts, uint32_t n_wg, unsigned long long *counter, unsigned long long *bases, hipStream_t stream);
+hipError_t launch_sole_census(const unsigned long long *wg_counts, uint32_t n_wg, unsigned long long *counter, unsigned long long *bases, uint32_t *ticket,
+                              hipStream_t stream);                          // (and the chunk ticket back to zero for the next launch)
 
 // amino-acid sketches (LASH_F_AMINO; utils.rs:511-563): work items are RECORD ranges of a genome (WorkItem::word_begin / word_end =
 // record indices relative to the genome's first), a lane walks one record at a time; args.seq / args.rec_off = the caller's bytes

@@ -648,6 +648,34 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
     return zacc;
 }
 
+// A QUARTER of a word: the four k-mer start positions r0 .. r0 + 3 of it, r0 = 0, 4, 8, 12 at RUN time (round 5, sole_kernels.hip).
+// The last words of a small genome are few: handed out a quarter per lane they cost a dependent chain of 4 k-mers instead of 16.
+// Same canonical k-mers, same rule: v_alignbit takes its shift from a register as readily as from an immediate (r = 0 is a select,
+// as in process_word); bit r of kvw says whether position r is a k-mer.
+template <int ALGO, int KMODE, bool XLOW, bool FAST, class Regs>
+__device__ __forceinline__ uint32_t process_quarter(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t r0, uint32_t r1,
+                                                    uint32_t r2, uint32_t kvw, uint32_t rq)
+{
+    uint32_t zacc = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (int)rq + j;
+        const uint32_t vm = (uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1);    // 0 or ~0
+        uint32_t can_lo, can_hi = 0;
+        if constexpr (KMODE == KM_GT16) {
+            canon_gt16<0>(r, c0, c1, c2, r0, r1, r2, kp, can_lo, can_hi);
+        } else {
+            uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
+            uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
+            if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
+            can_lo = fwd < rc ? fwd : rc;
+        }
+        const uint32_t t = add_kmer<ALGO, XLOW, true, FAST, Regs>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p);
+        zacc = zacc < t ? zacc : t;
+    }
+    return zacc;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // HyperMinHash with the signature deferred.  A k-mer changes its bucket only if its rank is at least the bucket's current one —
 // one k-mer in 35 of a 5 Mbp genome — and the rank needs only the x half of the hash.  The filter computes that half, reads the

@@ -113,6 +113,7 @@ __device__ __forceinline__ void sole_flush(const SoleArgs &a, uint32_t g, uint32
         tally.flush(hist);
         wg_barrier(T >> 6);
         if (tid < 64u) {
+            if (tid == 0 && a.hll_corner) a.hll_corner[g] = 0u;            // (set again below if a register lies above 53 - p: same lane)
             write_hll_header_wave(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + g : nullptr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             hist[tid] = 0u;                                   // (for the next genome: its tallies come a barrier later)
@@ -188,37 +189,58 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
     // ---- one pass over ring words [hw, hw + n) (n <= T): lane tid hashes word hw + tid; nk = k-mer starts of the whole genome when the
     //      genome is complete (masks its end), else ~0 ----
     uint32_t zero_w = 0, zero_n = 0, bzero = 0;                            // ring words the previous pass consumed (zeroed by the next one); first break word not yet zeroed
-    auto hash_pass = [&](uint32_t hw, uint32_t n, uint32_t nk, bool breaks) {
+    auto hash_pass = [&](uint32_t hw, uint32_t n, uint32_t nk, bool breaks, bool fine) {
         // words consumed by the previous pass are free again (appends OR into zeroed words); a barrier lies between the two passes.
         // A break word covers TWO code words: it is free once both have been hashed
         if (tid < zero_n) lds_store(ring_b + 4u * ((zero_w + tid) & RM), 0u);
-        if (breaks) {
+        {
             const uint32_t bz_end = (zero_w + zero_n) >> 1;
-            if (bzero + tid < bz_end) lds_store(brk_b + 4u * ((bzero + tid) & BM), 0u);
+            if (breaks && bzero + tid < bz_end) lds_store(brk_b + 4u * ((bzero + tid) & BM), 0u);
             bzero = bz_end > bzero ? bz_end : bzero;
         }
         zero_w = hw; zero_n = n;
-        const bool active = tid < n;
+        // `fine` (the genome's last words): few words are handed out a QUARTER (4 k-mer starts) or a half per lane, so that what is left
+        // after the full passes costs a chain of 4 or 8 k-mers, not 16 — and a 1 kbp genome spreads over 250 lanes instead of 62
+        const uint32_t upl = !fine || 2u * n > T ? 4u : (4u * n > T ? 2u : 1u);                  // quarter units per lane
+        const uint32_t u0 = upl * tid;                                                            // the lane's first unit of the pass
+        const bool active = u0 < 4u * n;
         if (__builtin_amdgcn_ballot_w64(active) == 0ull) return;
-        const uint32_t w = hw + tid, pos0 = 16u * w;
+        const uint32_t w = hw + (u0 >> 2), pos0 = 16u * w;
         const uint32_t junk = (tid + 1u) * 0x9E3779B1u;
         uint32_t c0 = junk, c1 = ~junk, c2 = junk;
         uint32_t kvw = 0;
         if (active) {
             c0 = lds_load(ring_b + 4u * (w & RM)); c1 = lds_load(ring_b + 4u * ((w + 1u) & RM));
             if constexpr (KMODE == KM_GT16) c2 = lds_load(ring_b + 4u * ((w + 2u) & RM));
-            uint32_t b0 = 0, b1 = 0;
-            if (breaks) {
-                const uint32_t bw = w >> 1;
-                const uint32_t x0 = lds_load(brk_b + 4u * (bw & BM)), x1 = lds_load(brk_b + 4u * ((bw + 1u) & BM)), x2 = lds_load(brk_b + 4u * ((bw + 2u) & BM));
-                b0 = (w & 1u) ? (x0 >> 16) | (x1 << 16) : x0;
-                b1 = (w & 1u) ? (x1 >> 16) | (x2 << 16) : x1;
+            kvw = 0xFFFFu;                                                  // a complete word of a genome without record starts: 16 k-mers
+            if (breaks || nk != 0xFFFFFFFFu) {
+                uint32_t b0 = 0, b1 = 0;
+                if (breaks) {
+                    const uint32_t bw = w >> 1;
+                    const uint32_t x0 = lds_load(brk_b + 4u * (bw & BM)), x1 = lds_load(brk_b + 4u * ((bw + 1u) & BM)), x2 = lds_load(brk_b + 4u * ((bw + 2u) & BM));
+                    b0 = (w & 1u) ? (x0 >> 16) | (x1 << 16) : x0;
+                    b1 = (w & 1u) ? (x1 >> 16) | (x2 << 16) : x1;
+                }
+                kvw = (uint32_t)kmer_valid_mask(b0, b1, 0u, pos0, nk, k) & 0xFFFFu;
             }
-            kvw = (uint32_t)kmer_valid_mask(b0, b1, 0u, pos0, nk, k) & 0xFFFFu;
+        }
+        const uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
+        if (upl < 4u) {
+            // ---- quarters ----
+            const uint32_t rq = 4u * (u0 & 3u);
+            kvw &= ((1u << (4u * upl)) - 1u) << rq;                          // the lane's own positions
+            kmers_wave += wave_sum((uint32_t)__builtin_popcount(kvw));
+            for (uint32_t i = 0; i < upl; ++i) {
+                uint32_t m = kvw;
+                asm volatile("" : "+v"(m));
+                const uint32_t z = process_quarter<ALGO, KMODE, XLOW, true>(regs, kp, c0, c1, c2, r0, r1, r2, m, rq + 4u * i);
+                constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+                if (z <= Z_REDO) (void)process_quarter<ALGO, KMODE, XLOW, false>(regs, kp, c0, c1, c2, r0, r1, r2, m, rq + 4u * i);
+            }
+            return;
         }
         const bool all_valid = __builtin_amdgcn_ballot_w64(kvw != 0xFFFFu) == 0ull;
         kmers_wave += all_valid ? 1024u : wave_sum((uint32_t)__builtin_popcount(kvw));
-        const uint32_t r0 = rcword(c0, cmask), r1 = rcword(c1, cmask), r2 = (KMODE == KM_GT16) ? rcword(c2, cmask) : 0u;
         uint32_t z;
         if (K21 && k == 21) {
             if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true, LdsRegs, false, false, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
@@ -264,11 +286,15 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
             const uint32_t lane_off = 16u * tid;
             const uint64_t last16 = a.seq_bytes - 16;
             auto round_load = [&](uint64_t at, uint4 &q, uint32_t &rbw) {
-                const uint64_t base = at < last16 ? at : last16;                             // uniform
-                const uint32_t d = (uint32_t)(at - base), cap = last16 - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(last16 - base);
-                uint32_t vo = lane_off + d;
-                vo = vo < cap ? vo : cap;
-                q = load16_any(a.seq + base + vo);
+                if (__builtin_expect(at + 16ull * T <= a.seq_bytes, 1)) {
+                    q = load16_any(a.seq + at + lane_off);                                   // uniform base + lane offset
+                } else {
+                    const uint64_t base = at < last16 ? at : last16;                         // uniform
+                    const uint32_t d = (uint32_t)(at - base), cap = last16 - base > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(last16 - base);
+                    uint32_t vo = lane_off + d;
+                    vo = vo < cap ? vo : cap;
+                    q = load16_any(a.seq + base + vo);
+                }
                 rbw = 0;
                 if (a.brk_abs) {
                     // 4 bytes of the bitmap at any alignment: bits 8 * (A >> 3) .. + 31 hold the lane's 16 (the bitmap is padded by a round)
@@ -291,6 +317,12 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                 q = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
             };
             const bool breaks = a.brk_abs != nullptr;
+            // The genome whose registers are complete but still in the table.  Its image is written when the NEXT genome is about to hash
+            // its first word, not when its own last word is done: a wave's loads and stores share one counter (vmcnt), so a wave that has
+            // just issued the image's stores and then waits for the next genome's bytes waits for the stores to reach memory — 2 us per
+            // genome with nothing to do.  Flushed late, the stores drain under the next genome's first hash pass.
+            constexpr uint32_t NONE = 0xFFFFFFFFu;
+            uint32_t pending = NONE;
             for (; g < g_end; ++g) {
                 const uint64_t Lb64 = b1 - b0;
                 if (Lb64 <= a.max_len) {
@@ -316,11 +348,12 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                             }
                             uint32_t bad = 0;
                             const uint32_t codes = ascii16_to_word(q, bad, ct);
-                            uint32_t v = 0xFFFFu;
-                            if (!inner) {
-                                const uint32_t rl = rel + lane_off;
-                                const uint32_t own = rl >= Lb ? 0u : (Lb - rl >= 16u ? 16u : Lb - rl);
-                                v = (1u << own) - 1u;
+                            // bytes of the lane's 16 that are the genome's: clamp(Lb - rel - 16 tid, 0, 16) of them (lengths are below 2^31)
+                            uint32_t v;
+                            {
+                                int own = (int)(Lb - rel) - (int)lane_off;
+                                asm("v_med3_i32 %0, %1, 0, 16" : "=v"(own) : "v"(own));
+                                asm("v_bfm_b32 %0, %1, 0" : "=v"(v) : "v"(own));           // (1 << own) - 1
                             }
                             const uint32_t ownmask = v;
                             if (bad) v &= ~inv16(q);
@@ -372,7 +405,6 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                             limit = N >= need ? (N - need) / 16u + 1u : 0u;
                             N += tot;
                             rel += 16u * T;
-                            if (rel >= Lb) continue;                                        // (the last round's words wait for the barrier below)
                         } else if (!whole) {
                             // ---- the genome is in the ring: what is left, under its end's mask ----
                             wg_barrier(nw);
@@ -381,8 +413,13 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                             limit = (nk + 15u) >> 4;
                         }
                         if (H < limit) {
+                            if (pending != NONE) {                                          // the table changes hands
+                                sole_flush<ALGO>(a, pending, a.hist_off, p, T);
+                                pending = NONE;
+                                wg_barrier(nw);
+                            }
                             const uint32_t cnt = limit - H < T ? limit - H : T;
-                            hash_pass(H, cnt, nk, breaks);
+                            hash_pass(H, cnt, nk, breaks, whole);
                             H += cnt;
                             if (whole) zero_n = 0;                                          // (no barrier between the last passes; the rings are wiped below)
                         }
@@ -390,20 +427,23 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                     }
                     bases_wg += N;
                     if (a.ndel && tid == 0) a.ndel[g] = Lb - N;
-                    wg_barrier(nw);
-                    sole_flush<ALGO>(a, g, a.hist_off, p, T);
+                    wg_barrier(nw);                                                         // every wave's k-mers are in the table, every wave is done with the rings
                     // the rings, zero again up to where this genome reached
                     if (Lb) {
                         const uint32_t top = (N >> 4) + 3u < a.ring_words ? (N >> 4) + 3u : a.ring_words;
                         for (uint32_t i = 4u * tid; i < top; i += 4u * T) lds_store4(ring_b + 4u * i, 0u);
                         if (breaks) for (uint32_t i = 4u * tid; i < (top >> 1) + 4u && i < (a.ring_words >> 1); i += 4u * T) lds_store4(brk_b + 4u * i, 0u);
                     }
+                    // (a genome without a single k-mer never touched the table: the one before it is still owed its image)
+                    if (pending != NONE) sole_flush<ALGO>(a, pending, a.hist_off, p, T);
+                    pending = g;
                 }
                 // the next genome begins where this one ends
                 b0 = b1;
                 b1 = sgpr64(p_b);
                 p_b = vload64(a.genome_byte_off, g + 3u <= g_end ? g + 3u : g_end);
             }
+            if (pending != NONE) sole_flush<ALGO>(a, pending, a.hist_off, p, T);            // the chunk's last genome
         }
         // (PACKED: below)
         if constexpr (PACKED) {
@@ -436,7 +476,7 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                         const uint32_t done = N_prev >= need ? (N_prev - need) / 16u + 1u : 0u;
                         if (done > H) {
                             const uint32_t cnt = done - H < T ? done - H : T;
-                            hash_pass(H, cnt, 0xFFFFFFFFu, breaks);
+                            hash_pass(H, cnt, 0xFFFFFFFFu, breaks, false);
                             H += cnt;
                         }
                     }
@@ -446,7 +486,7 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                 zero_n = 0;
                 while (H < nk_words) {
                     const uint32_t cnt = nk_words - H < T ? nk_words - H : T;
-                    hash_pass(H, cnt, nk, breaks);
+                    hash_pass(H, cnt, nk, breaks, true);
                     H += cnt;
                     zero_n = 0;
                 }
@@ -493,8 +533,9 @@ __global__ void __launch_bounds__(256) sole_mark_kernel(const uint64_t *rec_off,
 }
 
 __global__ void __launch_bounds__(256) sole_census_kernel(const unsigned long long *wg_counts, uint32_t n_wg, unsigned long long *counter,
-                                                          unsigned long long *bases)
+                                                          unsigned long long *bases, uint32_t *ticket)
 {
+    if (threadIdx.x == 0) *ticket = 0u;                                     // at rest the chunk ticket is zero: no memset per launch
     // one workgroup: the k-mer census is ADDED to the context's running count, the surviving bases are those of this call
     __shared__ unsigned long long part[2][4];
     unsigned long long km = 0, bs = 0;
@@ -512,7 +553,7 @@ __global__ void __launch_bounds__(256) sole_census_kernel(const unsigned long lo
 // ------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------
-SolePlan make_sole_plan(int algo, int p)
+SolePlan make_sole_plan(int algo, int p, uint32_t n_genomes, uint32_t cu_count)
 {
     SolePlan s{};
     uint32_t table;
@@ -531,13 +572,19 @@ SolePlan make_sole_plan(int algo, int p)
         o.ring_off = (o.scan_off + 20u * 4u + 15u) & ~15u;
         o.brk_off = o.ring_off + o.ring_words * 4u;
         o.lds_bytes = o.brk_off + (o.ring_words / 2u) * 4u + 16u;
-        o.wg_per_cu = std::min(std::min(32u, (160u * 1024u) / o.lds_bytes), 2048u / threads);
+        // (16 waves per CU: the kernels take 64 .. 128 vector registers; sole_resident_per_cu() asks the runtime for the launch itself)
+        o.wg_per_cu = std::min(std::min(32u, (160u * 1024u) / o.lds_bytes), 1024u / threads);
     };
+    // ... as long as every workgroup still gets a few genomes: 2 000 genomes on 4 096 one-wave workgroups would leave half the
+    // chip idle (and each genome to a single wave)
     uint32_t best = 512;
     for (uint32_t t : {64u, 128u, 256u, 512u}) {
         SolePlan o{};
         layout(t, o);
-        if (o.wg_per_cu * (t / 64u) >= 16u) { best = t; break; }
+        if (o.wg_per_cu * (t / 64u) < 16u) continue;
+        if (n_genomes && (uint64_t)o.wg_per_cu * cu_count * 4u > n_genomes && t < 512u) continue;
+        best = t;
+        break;
     }
     if (const char *e = getenv("LASH_SOLE_THREADS")) {                      // tuning knob (tools/)
         const int t = atoi(e);
@@ -548,31 +595,40 @@ SolePlan make_sole_plan(int algo, int p)
     return s;
 }
 
+// n_wg == 0: no launch — *occ receives the workgroups of this variant that are resident on one CU at a time (registers, LDS and wave
+// slots taken together: the persistent launch must not be larger than what is resident, its chunks are handed out to running workgroups)
 template <int ALGO, int KMODE, bool XLOW, bool PACKED>
-static hipError_t launch_sole_one(const SolePlan &plan, const SoleArgs &args, uint32_t n_wg, hipStream_t stream)
+static hipError_t launch_sole_one(const SolePlan &plan, const SoleArgs &args, uint32_t n_wg, hipStream_t stream, uint32_t *occ)
 {
     auto kern = sole_sketch_kernel<ALGO, KMODE, XLOW, PACKED>;
     if (plan.lds_bytes > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
         if (e != hipSuccess) return e;
     }
+    if (occ) {
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(kern), (int)plan.threads, plan.lds_bytes);
+        if (e != hipSuccess) return e;
+        *occ = (uint32_t)std::max(1, n);
+        return hipSuccess;
+    }
     hipLaunchKernelGGL(kern, dim3(n_wg), dim3(plan.threads), plan.lds_bytes, stream, args);
     return hipGetLastError();
 }
 template <int ALGO, bool XLOW, bool PACKED>
-static hipError_t launch_sole_kmode(const SolePlan &plan, int k, const SoleArgs &args, uint32_t n_wg, hipStream_t stream)
+static hipError_t launch_sole_kmode(const SolePlan &plan, int k, const SoleArgs &args, uint32_t n_wg, hipStream_t stream, uint32_t *occ)
 {
-    if (k == 16) return launch_sole_one<ALGO, KM_16, XLOW, PACKED>(plan, args, n_wg, stream);
-    if (k < 16) return launch_sole_one<ALGO, KM_LT16, XLOW, PACKED>(plan, args, n_wg, stream);
-    return launch_sole_one<ALGO, KM_GT16, XLOW, PACKED>(plan, args, n_wg, stream);
+    if (k == 16) return launch_sole_one<ALGO, KM_16, XLOW, PACKED>(plan, args, n_wg, stream, occ);
+    if (k < 16) return launch_sole_one<ALGO, KM_LT16, XLOW, PACKED>(plan, args, n_wg, stream, occ);
+    return launch_sole_one<ALGO, KM_GT16, XLOW, PACKED>(plan, args, n_wg, stream, occ);
 }
 template <bool PACKED>
-static hipError_t launch_sole_algo(const SolePlan &plan, int algo, int k, bool x_low, const SoleArgs &args, uint32_t n_wg, hipStream_t stream)
+static hipError_t launch_sole_algo(const SolePlan &plan, int algo, int k, bool x_low, const SoleArgs &args, uint32_t n_wg, hipStream_t stream, uint32_t *occ)
 {
     switch (algo) {
-    case 0: return x_low ? launch_sole_kmode<0, true, PACKED>(plan, k, args, n_wg, stream) : launch_sole_kmode<0, false, PACKED>(plan, k, args, n_wg, stream);
-    case 1: return launch_sole_kmode<1, false, PACKED>(plan, k, args, n_wg, stream);
-    case 2: return launch_sole_kmode<2, false, PACKED>(plan, k, args, n_wg, stream);
+    case 0: return x_low ? launch_sole_kmode<0, true, PACKED>(plan, k, args, n_wg, stream, occ) : launch_sole_kmode<0, false, PACKED>(plan, k, args, n_wg, stream, occ);
+    case 1: return launch_sole_kmode<1, false, PACKED>(plan, k, args, n_wg, stream, occ);
+    case 2: return launch_sole_kmode<2, false, PACKED>(plan, k, args, n_wg, stream, occ);
     default: return hipErrorInvalidValue;
     }
 }
@@ -582,7 +638,26 @@ hipError_t launch_sole(const SolePlan &plan, int algo, int k, bool x_low, bool p
     SoleArgs a = args;
     a.hist_off = plan.hist_off; a.scan_off = plan.scan_off; a.ring_off = plan.ring_off; a.brk_off = plan.brk_off;
     a.ring_words = plan.ring_words; a.lds_words = plan.lds_bytes / 4u;
-    return packed ? launch_sole_algo<true>(plan, algo, k, x_low, a, n_wg, stream) : launch_sole_algo<false>(plan, algo, k, x_low, a, n_wg, stream);
+    return packed ? launch_sole_algo<true>(plan, algo, k, x_low, a, n_wg, stream, nullptr) : launch_sole_algo<false>(plan, algo, k, x_low, a, n_wg, stream, nullptr);
+}
+
+hipError_t sole_resident_per_cu(const SolePlan &plan, int algo, int k, bool x_low, bool packed, uint32_t *out)
+{
+    if (!plan.ok) return hipErrorInvalidValue;
+    // asked once per kernel variant and workgroup shape
+    struct Entry { uint32_t occ, lds; };
+    static Entry cache[2][3][3][2][9] = {};
+    if (algo < 0 || algo > 2) return hipErrorInvalidValue;
+    Entry &c = cache[packed ? 1 : 0][algo][k == 16 ? 0 : k < 16 ? 1 : 2][x_low ? 1 : 0][plan.threads / 64u];
+    if (!c.occ || c.lds != plan.lds_bytes) {
+        SoleArgs none{};
+        uint32_t occ = 0;
+        hipError_t e = packed ? launch_sole_algo<true>(plan, algo, k, x_low, none, 0, nullptr, &occ) : launch_sole_algo<false>(plan, algo, k, x_low, none, 0, nullptr, &occ);
+        if (e != hipSuccess) return e;
+        c.occ = occ; c.lds = plan.lds_bytes;
+    }
+    *out = c.occ;
+    return hipSuccess;
 }
 
 hipError_t launch_sole_mark(const uint64_t *rec_off, uint64_t n_rec, uint64_t seq_bytes, uint32_t *brk_abs, hipStream_t stream)
@@ -594,9 +669,9 @@ hipError_t launch_sole_mark(const uint64_t *rec_off, uint64_t n_rec, uint64_t se
 }
 
 hipError_t launch_sole_census(const unsigned long long *wg_counts, uint32_t n_wg, unsigned long long *counter, unsigned long long *bases,
-                              hipStream_t stream)
+                              uint32_t *ticket, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sole_census_kernel, dim3(1), dim3(256), 0, stream, wg_counts, n_wg, counter, bases);
+    hipLaunchKernelGGL(sole_census_kernel, dim3(1), dim3(256), 0, stream, wg_counts, n_wg, counter, bases, ticket);
     return hipGetLastError();
 }
 
