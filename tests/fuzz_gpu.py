@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import lash_amd
 import oracle_lib as O
+import fuzz_knobs
 
 ALGO = {"hmh": 0, "hll": 1, "ull": 2}
 
@@ -60,6 +61,7 @@ def main():
         if only is not None and it != only:
             continue
         rng = random.Random(seed0 * 100003 + it)
+        knobs = fuzz_knobs.set_sole(random.Random(seed0 * 1000003 + it))    # which genomes go to the persistent small-genome kernel (FUZZ_SOLE)
         an = rng.choice(["hmh", "hll", "ull"])
         if os.environ.get("FUZZ_ALGO"):                     # e.g. FUZZ_ALGO=hmh LASH_DEFER_MIN=0: every direct launch defers its signatures
             an = os.environ["FUZZ_ALGO"]
@@ -111,7 +113,7 @@ def main():
         want_kmers = sum(len(O.record_kmers(r, k)) for g in gs for r in g)
         if not np.array_equal(got, want) or kmers != want_kmers:
             bad = sorted({int(r) for r in np.argwhere(got != want)[:, 0]}) if got.shape == want.shape else "shape"
-            print("MISMATCH it=%d mode=%s %s k=%d p=%d seed=%d flags=%d genomes=%s census %d vs %d" % (it, mode, an, k, p, seed, flags, bad, kmers, want_kmers))
+            print("MISMATCH [" + knobs + "] it=%d mode=%s %s k=%d p=%d seed=%d flags=%d genomes=%s census %d vs %d" % (it, mode, an, k, p, seed, flags, bad, kmers, want_kmers))
             if only is not None and got.shape == want.shape:
                 d = np.argwhere(got != want)
                 print("  %d bytes differ; first: %s" % (len(d), [(int(g), int(o), int(got[g, o]), int(want[g, o])) for g, o in d[:24]]))

@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import lash_amd
 import host_lib as H
 import oracle_lib as O
+import fuzz_knobs
 from fuzz_gpu_raw import fasta_file, fastq_file
 
 ALGO = {"hmh": 0, "hll": 1, "ull": 2}
@@ -28,6 +29,7 @@ def main():
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         for it in range(iters):
             rng = random.Random(seed0 * 15485863 + it)
+            knobs = fuzz_knobs.set_sole(random.Random(seed0 * 1000003 + it))    # which genomes go to the persistent small-genome kernel (FUZZ_SOLE)
             paths, recs = [], []
             for i in range(rng.randint(1, 40)):
                 data = b""
@@ -71,7 +73,7 @@ def main():
             if blob != want.tobytes():
                 ib = want.shape[1]
                 bad = [i for i in range(len(paths)) if blob[i * ib:(i + 1) * ib] != want[i].tobytes()]
-                print("MISMATCH it=%d %s k=%d p=%d extra=%s files=%s" % (it, algo, k, p, extra, [paths[i] for i in bad][:5]))
+                print("MISMATCH [" + knobs + "] it=%d %s k=%d p=%d extra=%s files=%s" % (it, algo, k, p, extra, [paths[i] for i in bad][:5]))
                 os.system("cp %s /tmp/ 2>/dev/null" % " ".join(paths[i] for i in bad[:3]))
                 sys.exit(1)
             for f in os.listdir(td):

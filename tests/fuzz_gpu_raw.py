@@ -14,6 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import lash_amd
 import host_lib as H
 import oracle_lib as O
+import fuzz_knobs
 
 ALGO = {"hmh": 0, "hll": 1, "ull": 2}
 
@@ -82,6 +83,7 @@ def main():
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         for it in range(iters):
             rng = random.Random(seed0 * 7919 + it)
+            knobs = fuzz_knobs.set_sole(random.Random(seed0 * 1000003 + it))    # which genomes go to the persistent small-genome kernel (FUZZ_SOLE)
             an = rng.choice(["hmh", "hll", "ull"])
             if os.environ.get("FUZZ_ALGO"):
                 an = os.environ["FUZZ_ALGO"]
@@ -102,7 +104,7 @@ def main():
                 bad = sorted({int(r) for r in np.argwhere(got != want)[:, 0]})
                 for b in bad:
                     open("/tmp/fuzz_raw_fail_%d.bin" % b, "wb").write(files[b])
-                print("MISMATCH it=%d %s k=%d p=%d files=%s (saved to /tmp/fuzz_raw_fail_*.bin)" % (it, an, k, p, bad))
+                print("MISMATCH [" + knobs + "] it=%d %s k=%d p=%d files=%s (saved to /tmp/fuzz_raw_fail_*.bin)" % (it, an, k, p, bad))
                 sys.exit(1)
     print("raw fuzz ok: %d iterations from seed %d" % (iters, seed0))
 

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import host_lib as H
 import oracle_lib as O
+import fuzz_knobs
 
 
 def big_fasta(rng):
@@ -52,6 +53,7 @@ def main():
     with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
         for it in range(iters):
             rng = random.Random(seed0 * 104729 + it)
+            knobs = fuzz_knobs.set_sole(random.Random(seed0 * 1000003 + it))    # which genomes go to the persistent small-genome kernel (FUZZ_SOLE)
             paths = []
             for i in range(rng.randint(1, 3)):
                 data = big_fasta(rng) if rng.random() < 0.6 else big_fastq(rng)
@@ -76,7 +78,7 @@ def main():
             if blobs[0] != blobs[1]:
                 for pth in paths:
                     os.system("cp %s /tmp/" % pth)
-                print("MISMATCH it=%d %s k=%d (inputs copied to /tmp)" % (it, algo, k))
+                print("MISMATCH [" + knobs + "] it=%d %s k=%d (inputs copied to /tmp)" % (it, algo, k))
                 sys.exit(1)
             for pth in paths:
                 os.remove(pth)

@@ -1,0 +1,29 @@
+"""Knobs shared by the randomized GPU runners (tests/fuzz_gpu*.py).
+
+FUZZ_SOLE pins which genomes the persistent small-genome kernel (lash_amd/csrc/sole_kernels.hip) takes in every iteration:
+    FUZZ_SOLE=0      never (LASH_SOLE_MAX=0): the sliced kernels only — direct pass, junction walks, dense tiles, stream kernel
+    FUZZ_SOLE=1      the library default (genomes up to 393 216 bytes)
+    FUZZ_SOLE=<n>    genomes up to n bytes (small n: most batches hold both kinds and run both launches)
+unset: drawn per iteration from {0, 2 000, 50 000, default}, and the kernel's workgroup shape (LASH_SOLE_THREADS) from
+{default, 64, 128, 256, 512}.  The library reads both variables on every call; subprocesses (the CLI runners) inherit them."""
+import os
+
+
+def set_sole(rng):
+    pin = os.environ.get("FUZZ_SOLE")
+    if pin is None:
+        choice = rng.choice(["0", "2000", "50000", None, None])
+    elif pin == "1":
+        choice = None
+    else:
+        choice = pin
+    if choice is None:
+        os.environ.pop("LASH_SOLE_MAX", None)
+    else:
+        os.environ["LASH_SOLE_MAX"] = choice
+    t = rng.choice([None, None, "64", "128", "256", "512"])
+    if t is None:
+        os.environ.pop("LASH_SOLE_THREADS", None)
+    else:
+        os.environ["LASH_SOLE_THREADS"] = t
+    return "sole_max=%s threads=%s" % (choice or "default", t or "default")

@@ -30,6 +30,18 @@ def test_fuzz_with_deferred_signatures_everywhere():
     rank can still win their bucket; lash_api.hip: from 0.6 Mbp per work item).  LASH_DEFER_MIN=0 sends EVERY direct HyperMinHash
     launch of the runner down that kernel — tiny genomes, read sets, dirt, slices — against the oracle as usual.  (The full-size
     tests take the route by themselves.)"""
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE, LASH_DEFER_MIN="0", FUZZ_ALGO="hmh")
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE, LASH_DEFER_MIN="0", FUZZ_ALGO="hmh", FUZZ_SOLE="0")
     r = subprocess.run([sys.executable, os.path.join(HERE, "fuzz_gpu.py"), "150", "21"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("script,iters,seed,ok", [("fuzz_gpu.py", 150, 31, "fuzz ok"), ("fuzz_gpu_raw.py", 100, 32, "raw fuzz ok"),
+                                                  ("fuzz_gpu_cli.py", 12, 33, "cli fuzz ok")])
+def test_fuzz_with_the_persistent_kernel_everywhere(script, iters, seed, ok):
+    """Round 5: genomes of at most LASH_SOLE_MAX bytes run on the persistent small-genome kernel (sole_kernels.hip).  By default the
+    runners draw that limit per iteration (tests/fuzz_knobs.py: 0, 2 000, 50 000 or the library's default, and the kernel's workgroup
+    shape); FUZZ_SOLE=1 pins the default, so that nearly every genome of every iteration — clean, dirty, multi-record, accumulated,
+    packed first, raw FASTA / FASTQ bytes, through the CLI — takes the new path, against the oracle as usual."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE, FUZZ_SOLE="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, script), str(iters), str(seed)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and ok in r.stdout, (script, r.stdout[-1500:], r.stderr[-3000:])
