@@ -174,7 +174,7 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
             "thread_scan": {str(T): v for T, v in sorted(scan.items())}}, ok
 
 
-def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True, defer=False):
+def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True, defer=False, p=0, reads=False, sole=False):
     """The binding roofline of the sketch kernel is integer-VALU issue, not HBM.  Its ceiling is
     MEASURED: tools/ubench_hash runs the kernel's per-k-mer instruction stream (window, reverse complement, xxh3_128, register
     rule, LDS atomic) from registers, no HBM, at the kernel's occupancy; run here when the binary is built, else the
@@ -220,7 +220,12 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
     # compiler's listing with the per-class issue costs tools/ubench_isa measured on the GPU (profiles/r04/isa_cost/costs.json):
     # sum over classes of count x cost = VALU issue cycles per wave-k-mer; the chip has CUs x 4 SIMDs of them per cycle.
     mix = None
-    audit = {("hmh", True): "hmh_k16_defer", ("hll", False): "hll_p14_k21", ("ull", False): "ull_p12_k16_reads"}.get((algo, bool(defer)))
+    # each audit prices ONE kernel variant on ONE shape: it applies only to the launch that matches it (ADVICE r4 — the ull audit is of the
+    # p = 12 reads-shaped launch, the hll one of the p = 14 ds_max kernel, none of them of the persistent small-genome kernel)
+    audit = {("hmh", True, 0, False): "hmh_k16_defer", ("hll", False, 14, False): "hll_p14_k21",
+             ("ull", False, 12, True): "ull_p12_k16_reads"}.get((algo, bool(defer), 0 if algo == "hmh" else p, bool(reads)))
+    if sole:
+        audit = None
     apath = os.path.join(ROOT, "profiles", "r04", "isa_cost", "%s.json" % audit) if audit else None
     if direct and apath and os.path.exists(apath) and (algo, k) in (("hmh", 16), ("hll", 21), ("ull", 16)):
         try:
@@ -608,7 +613,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sketch_ms,
                          "input": "ASCII records (1 B/base)" if direct else "packed 2-bit words (0.25 B/base)",
                          "note": "integer-ALU/LDS-atomic bound kernel: see DESIGN.md 'Roofline'"},
-            "roofline_valu": valu_roofline(kmers_step_rank, sketch_ms, direct, algo, k, not args.no_ubench, defer and not dirty_in),
+            "roofline_valu": valu_roofline(kmers_step_rank, sketch_ms, direct, algo, k, not args.no_ubench, defer and not dirty_in, p=p, reads=reads,
+                                           sole=tm.get("sole_launches", 0) > 0),
             "stage_ms_per_step": {"pack": tm["pack_ms"] / max(tm["calls"], 1), "sketch": stage_sketch_ms,
                                   "finalize": tm["finalize_ms"] / max(tm["calls"], 1)},
             "packed_resident_kmers_per_s_this_rank": kmers_step_rank * args.steps / packed_elapsed,   # 2-bit genomes kept in HBM

@@ -189,6 +189,13 @@ int probe_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 // bins_apply_kernel builds each bin's registers in LDS and leaves ONE partial per genome ("virtual item" n_items + g) for the
 // ordinary finalize stage.  Lists, counters and fallback tables are sized per genome GROUP (a few GiB at a time; the stream orders
 // the groups, so the buffers are reused), from an upper bound of the entries each genome's work items push.
+// HBM one group of a binned launch (or one chunk of per-item global tables) may take: LASH_BINS_MB, default 6 GiB; read per call
+uint64_t bins_budget_bytes()
+{
+    const char *e = getenv("LASH_BINS_MB");
+    return (e ? (uint64_t)std::max(64, atoi(e)) : 6144ull) << 20;
+}
+
 struct BinsRun {
     std::vector<uint32_t> group_end;                  // genome index at which each group ends
     std::vector<BinGenome> table;                     // per genome: list offset inside its group's buffer, list capacity
@@ -203,7 +210,7 @@ static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector
 {
     const uint32_t B = 1u << plan.bins_log2;
     br.slab_words = plan.nreg32;                                     // HLL: 2^p words, ULL: 2 * 2^p
-    static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+    const uint64_t budget = bins_budget_bytes();
     br.table.resize(n_genomes);
     uint64_t bytes = 0, off = 0, group_max_bytes = 0;
     uint32_t in_group = 0;
@@ -304,7 +311,7 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
 template <class Launch>
 static int global_run(lash_ctx *ctx, const SketchPlan &plan, SketchArgs sa, uint32_t n_items, Launch launch)
 {
-    static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+    const uint64_t budget = bins_budget_bytes();
     const uint64_t table = (uint64_t)plan.nreg32 * 4;
     const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_items ? n_items : 1, budget / table));
     int rc;
@@ -466,7 +473,7 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
     return LASH_OK;
 }
 
-int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, EvSet *ev)
+int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, EvSet *ev, bool allow_bins = true)
 {
     const uint32_t n_genomes = pk->n_genomes;
     // Genomes of at most sole_max bytes go to the persistent kernel (sole_kernels.hip), the others are cut into work items as ever;
@@ -510,11 +517,11 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     uint64_t total_bytes = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) total_bytes += blen(g);
     const bool small_items = n_genomes > n_sole && total_bytes / (n_genomes - n_sole) < 100000u;
-    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo));
+    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo), allow_bins);
     if (plan.bins) {
         // a binned launch keeps ~4.6 bytes per input byte of one genome group in HBM: a single genome beyond the budget (a multi-Gbp
         // input in one call, which the CLI would have streamed in chunks) takes the table-in-global-memory path instead
-        static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+        const uint64_t budget = bins_budget_bytes();
         uint64_t big = 0;
         for (uint32_t g = 0; g < n_genomes; ++g) big = std::max<uint64_t>(big, pk->byte_len[g]);
         if (big * 5 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget)
@@ -670,7 +677,10 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         const uint64_t tile_words = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
         for (const WorkItem &w : items) entries[w.genome] += ((w.word_end - w.word_begin + tile_words - 1) / tile_words) * tile_words * 16;
         if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
-        if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
+        // a genome whose lists outgrow the budget after all (the estimate above is coarser than bins_prepare's sizing: ADVICE r4): the
+        // call is planned again without bins — a table in global memory per work item, as the comment above promises.  Nothing has
+        // been queued yet.
+        if (!bins_run_state.fits) return sketch_from(ctx, prm, pk, d_out_images, ev, false);
     }
     const WorkItem *d_items;
     const uint32_t *d_item_begin, *d_item_order = nullptr;
@@ -873,15 +883,15 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
 // The amino-acid branch (LASH_F_AMINO; utils.rs:511-563): no pack stage — a lane of aa_sketch_kernel reads a record's bytes itself.
 // Work items are ranges of a genome's records; partials and finalize as for nucleotides.
 int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
-              const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes, uint8_t *d_out_images)
+              const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes, uint8_t *d_out_images, bool allow_bins = true)
 {
     int rc;
-    if ((rc = timing_begin(ctx))) return rc;
+    if (allow_bins && (rc = timing_begin(ctx))) return rc;            // (the second attempt keeps the first one's event set)
     EvSet *ev = ctx->cur_ev;
     const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
-    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false);
+    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false, allow_bins);
     if (plan.bins) {                                                  // (as in sketch_from: one genome beyond the binned launch's budget)
-        static const uint64_t budget = (getenv("LASH_BINS_MB") ? (uint64_t)std::max(64, atoi(getenv("LASH_BINS_MB"))) : 6144ull) << 20;
+        const uint64_t budget = bins_budget_bytes();
         uint64_t big = 0;
         for (uint32_t g = 0; g < n_genomes; ++g)
             big = std::max<uint64_t>(big, (genome_byte_off[g + 1] - genome_byte_off[g]) + 32 * (genome_rec_off[g + 1] - genome_rec_off[g]));
@@ -924,7 +934,8 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
             entries[g] = e + e / 4 + (uint64_t)plan.threads * 256;
         }
         if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
-        if (!bins_run_state.fits) { ctx->err = "binned sketch launch: a genome's lists outgrow the budget (LASH_BINS_MB)"; return LASH_ELIMIT; }
+        if (!bins_run_state.fits)                                    // (as in sketch_from: planned again without bins; nothing has been queued yet)
+            return sketch_aa(ctx, prm, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, n_genomes, d_out_images, false);
     }
     std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0}, {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0},
                                 {descs.data(), descs.size() * sizeof(GenomeDesc), 0}};
@@ -1069,8 +1080,20 @@ static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t
     const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p, ib = hdr + m;
     if (sum_at < 0 || (prm0->flags & (LASH_F_ACCUMULATE | LASH_F_AMINO))) { left = flagged; return LASH_OK; }
     lash_params prm = *prm0;
-    const lash_timing saved = ctx->last;
-    const bool timing = ctx->timing;
+    // the probes are ordinary sketch calls: whatever they leave behind in the context — timing switch and sums, the list of packed
+    // batches the user's call consumed, the direct pass's dirt feedback — is put back on EVERY way out
+    struct Restore {
+        lash_ctx *c;
+        lash_timing last; bool timing; std::vector<const lash_packed *> packed; float dirty_frac; uint32_t direct_skipped; bool sole_only;
+        explicit Restore(lash_ctx *x) : c(x), last(x->last), timing(x->timing), packed(x->last_packed), dirty_frac(x->dirty_frac),
+                                        direct_skipped(x->direct_skipped), sole_only(x->last_sole_only) {}
+        ~Restore()
+        {
+            c->last = last; c->timing = timing; c->last_packed = packed; c->dirty_frac = dirty_frac; c->direct_skipped = direct_skipped;
+            c->last_sole_only = sole_only;
+            c->probe_pending = false;                                 // (a probe's feedback is not the user's batch's)
+        }
+    } restore(ctx);
     ctx->timing = false;
     int rc = LASH_OK;
     if ((rc = reserve(ctx, ctx->replay_img, ib + 64))) return rc;
@@ -1129,8 +1152,9 @@ static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t
         for (size_t i = 0; i < events.size(); ++i) {
             const Event &e = events[i];
             if (i) S += grid_sum(e.before.data() + hdr, m, p) - grid_after;      // exact steps in between: their net change
-            S -= ldexp(1.0, -(int)e.old);                           // the k-mer's own two operations, rounded as the crate's are
-            S += ldexp(1.0, -(int)e.neu);
+            // the k-mer's own update, rounded as the crate's is: ONE operation, sum -= 2^-old - 2^-new (the difference is exact unless
+            // new - old > 53; ADVICE r4: the two-step form differs when the bucket's old value lies above 53 - p as well)
+            S -= ldexp(1.0, -(int)e.old) - ldexp(1.0, -(int)e.neu);
             std::vector<uint8_t> after(e.before.begin() + hdr, e.before.end());
             after[e.j] = e.neu;
             grid_after = grid_sum(after.data(), m, p);
@@ -1139,8 +1163,6 @@ static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t
         if (h_images) memcpy(h_images + (size_t)g * ib + sum_at, &S, 8);
         if (d_images) HIPCHK(ctx, hipMemcpy(d_images + (size_t)g * ib + sum_at, &S, 8, hipMemcpyHostToDevice));
     }
-    ctx->last = saved;
-    ctx->timing = timing;
     if (rc) return rc;
     ctx->hll_flags_n = 0;
     ctx->hll_flags_on_host = true;
@@ -1886,15 +1908,18 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     if ((rc = read_format_errors(ctx))) return rc;
     std::vector<uint32_t> bad = ctx->bad_files;
     const size_t n_malformed = bad.size();
+    // HyperLogLog files with a register above 53 - p, taken NOW: the per-file redo calls below overwrite the device flags
+    std::vector<uint32_t> corner;
+    if (prm->algo == LASH_HLL) corner = hll_flagged(ctx);
     if (prm->algo == LASH_HLL && !(prm->flags & LASH_F_ACCUMULATE)) {
-        // files with a register above 53 - p go the same way as the malformed ones — host parse, record entry — which replays
-        // their incremental `sum` (hll_replay_sums): one file in ~10^4 at p = 14
-        for (uint32_t g : hll_flagged(ctx))
+        // ... go the same way as the malformed ones — host parse, record entry — which replays their incremental `sum`
+        // (hll_replay_sums): one file in ~10^4 at p = 14
+        for (uint32_t g : corner)
             if (std::find(bad.begin(), bad.end(), g) == bad.end()) bad.push_back(g);
     }
     if (bad.empty()) {
         if (img_bytes) HIPCHK(ctx, hipMemcpy(out_images, ctx->st_img.ptr, img_bytes, hipMemcpyDeviceToHost));
-        return LASH_OK;
+        return LASH_OK;                                            // (an accumulating call's corner files stay flagged on the device)
     }
     std::vector<uint8_t> is_bad(n_files, 0);
     for (uint32_t g : bad) is_bad[g] = 1;
@@ -1917,9 +1942,15 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     }
     bad.resize(n_malformed);
     ctx->bad_files = bad;                                          // still reported (the host may want to stop streaming this file)
-    ctx->hll_flags_n = 0;                                          // (the files in the corner have been redone exactly)
+    // Without LASH_F_ACCUMULATE the corner files have been redone exactly: nothing left to report.  An accumulating call redoes only the
+    // malformed files (the registers already in the images are not the library's to replay): its other corner files stay reported
+    // (the redo calls had wiped the device flags, and the list was cleared regardless)
+    ctx->hll_flags_n = 0;
     ctx->hll_flags_on_host = true;
     ctx->hll_left.clear();
+    if (prm->flags & LASH_F_ACCUMULATE)
+        for (uint32_t g : corner)
+            if (std::find(bad.begin(), bad.end(), g) == bad.end()) ctx->hll_left.push_back(g);
     return LASH_OK;
 }
 

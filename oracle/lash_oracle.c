@@ -302,8 +302,12 @@ static void hll_add_kmer(void *ctx, uint64_t masked)
     uint8_t old = s->reg[j];
     uint8_t neu = old > rho ? old : rho;
     s->hll_zero -= (old == 0);
-    s->hll_sum -= pow2_neg(old);
-    s->hll_sum += pow2_neg(neu);
+    /* upstream `push` as recalled (SURVEY App. A.3 is RECALLED-UNVERIFIED either way): ONE update per k-mer,
+     *     self.sum -= f64::from_bits(..old..) - f64::from_bits(..new..);
+     * i.e. the difference of the two powers first (exact unless new - old > 53), then one rounding into `sum`.  Equal to the
+     * two-step form (sum -= 2^-old; sum += 2^-new) whenever 2^-old lies on sum's grid — every update outside the `sum` corner, and in
+     * the corner unless the bucket's OLD value is above 53 - p as well. */
+    s->hll_sum -= pow2_neg(old) - pow2_neg(neu);
     s->reg[j] = neu;
 }
 

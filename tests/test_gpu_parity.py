@@ -431,3 +431,26 @@ def test_runs_of_empty_and_tiny_records_share_break_words(ctx, flags):
         got = ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=flags)
         want = oracle_images(ALGO[an], k, p, 42, seq, off, goff)
         assert_same(got, want, "%s k=%d flags=%d" % (an, k, flags))
+
+
+def test_a_genome_whose_bin_lists_outgrow_the_budget_takes_the_global_table(ctx, monkeypatch):
+    """the pre-check of a binned launch estimated 5 bytes of list per input byte where bins_prepare sizes ~6.75 at
+    ULL p = 22, so a genome in between passed the first, failed the second and the call returned LASH_ELIMIT instead of taking the
+    table-in-global-memory plan.  With LASH_BINS_MB=1024 the window is 147 .. 185 MB at p = 22: a 160 Mbp genome now sketches (planned
+    again without bins) and equals the oracle."""
+    import torch
+    import lash_amd
+    monkeypatch.setenv("LASH_BINS_MB", "1024")
+    L = 160_000_000
+    d_seq = torch.empty(L, dtype=torch.uint8, device="cuda")
+    ctx.synth_genomes_device(77, 1, L, d_seq)
+    rec_off = np.array([0, L], dtype=np.uint64)
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).cuda()
+    goff = np.array([0, 1], dtype=np.uint64)
+    ib = lash_amd.image_bytes("ull", 22)
+    d_img = torch.zeros(ib, dtype=torch.uint8, device="cuda")
+    ctx.sketch_batch_device("ull", 16, 22, 42, d_seq, d_rec, 1, goff, rec_off, d_img)        # raised LASH_ELIMIT before
+    ctx.synchronize()
+    host = O.synth_genome(77, L)
+    want = oracle_images(ALGO["ull"], 16, 22, 42, host, rec_off, goff)
+    assert_same(d_img.cpu().numpy().reshape(1, ib), want, "ull p=22, 160 Mbp, LASH_BINS_MB=1024")
