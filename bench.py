@@ -303,7 +303,12 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
         ctx.sketch_batch_device(algo, k, p, seed, d_seq, d_rec, G, goff, rec_off, d_img)
         if timed:
             ev[1].record()
-        if dist:
+        if dist and dist.get_backend() != "nccl":
+            # LASH_BENCH_BACKEND=gloo, the launch dry run (ranks share devices): the same collective on host tensors
+            mine, gathered = d_img.cpu(), torch.empty(every.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, mine)
+            every.view(-1).copy_(gathered)
+        elif dist:
             dist.all_gather_into_tensor(every.view(-1), d_img)
         else:
             every.view(-1).copy_(d_img)
@@ -362,7 +367,8 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
         print(json.dumps({
             "metric": "k-mers/s sketched + all-vs-all (%s, k=%d)" % (algo, k), "value": kmers / elapsed, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic" if not dist or dist.get_backend() == "nccl" else "synthetic (LAUNCH DRY RUN: ranks share GPUs over gloo, not a scaling measurement)",
             "config": {"workload": "configs[3] shape: %d synthetic %d-bp genomes per GPU sketched (-a %s -k %d), images all-gathered over "
                                    "RCCL (%d x %d B), every rank holds them as a resident set and computes its two bands of the lower triangle "
                                    "(%d of %d rows, equal printed pairs per rank)"
@@ -374,6 +380,19 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
             "roofline": None, "cpu_baseline": None}))
 
 
+def visible_gpus():
+    """GPUs this process' children could use, counted WITHOUT initialising HIP here (the parent of a self-launch must never touch the
+    GPU): a one-shot CHILD asks torch (torch.cuda.device_count() does not initialise HIP on this image, and the child is gone before
+    anything else starts).  The KFD topology is no substitute — a container that is handed one GPU of an 8-GPU node still lists eight
+    nodes with SIMDs there (seen on the round-5 box).  None when the child cannot tell: let the ranks find out."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception:
+        return None
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start the N ranks ourselves — one process per
     GPU under torch.distributed.run, the command line the driver would have used — as a CHILD process, relay its output and
@@ -382,6 +401,14 @@ def self_launch(n):
     `files.par_iter()` (utils.rs:450-452): one task per shard, results in shard order."""
     import socket
     import subprocess
+    # pre-flight (VERDICT r4 next #7): more ranks than GPUs would die inside every torchrun child with a traceback of its own; say it
+    # once, in one line, before anything is started.  (LASH_BENCH_BACKEND=gloo is the launch dry run in which ranks SHARE devices.)
+    have = visible_gpus()
+    if have is not None and n > have and os.environ.get("LASH_BENCH_BACKEND", "nccl") == "nccl":
+        print(json.dumps({"error": "bench.py --gpus %d: this process can see %d GPU%s (torch.cuda.device_count() in a child); nothing was launched"
+                                   % (n, have, "" if have == 1 else "s"), "n_gpus_requested": n, "n_gpus_visible": have}))
+        sys.stdout.flush()
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -545,11 +572,14 @@ def main():
     pk = ctx.pack_device(d_seq, d_rec, n_rec, goff, rec_off)
     ctx.sketch_packed_device(algo, k, p, seed, pk, d_img)
     torch.cuda.synchronize()
+    ctx.enable_timing(True)
     tp0 = time.perf_counter()
     for _ in range(args.steps):
         ctx.sketch_packed_device(algo, k, p, seed, pk, d_img)
     torch.cuda.synchronize()
     packed_elapsed = time.perf_counter() - tp0
+    tm_pk = ctx.timing()                                    # (HIP events on the ctx stream: the packed-input sketch kernel's own time)
+    ctx.enable_timing(False)
     pk.free()
 
     # oracle-free cross-check on every rank: the pack-first route (a different kernel chain) must give the same images
@@ -612,7 +642,14 @@ def main():
                          "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed (not collected in this run)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sketch_ms,
                          "input": "ASCII records (1 B/base)" if direct else "packed 2-bit words (0.25 B/base)",
-                         "note": "integer-ALU/LDS-atomic bound kernel: see DESIGN.md 'Roofline'"},
+                         # the OTHER accounting of SURVEY 8(d) / BASELINE.md (0.2566 B per k-mer at hmh k=16): the same genomes resident as the
+                         # 2-bit stream, sketched by the packed-input kernel in this run — ceil(L/4) + S bytes per genome over that kernel's time
+                         "frac_packed_accounting": (G * algorithmic_bytes_per_genome(L, ib, ascii_input=False) / (tm_pk["sketch_ms"] / max(tm_pk["calls"], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                                   if tm_pk["sketch_ms"] > 0 else None,
+                         "packed_accounting": {"algorithmic_bytes_per_launch": G * algorithmic_bytes_per_genome(L, ib, ascii_input=False),
+                                               "avg_launch_ms": tm_pk["sketch_ms"] / max(tm_pk["calls"], 1), "kernel": "sketch_kernel (packed 2-bit input, lash_sketch_packed_device)"},
+                         "note": "integer-ALU/LDS-atomic bound kernel: see DESIGN.md 'Roofline'.  frac is on the bytes the dominant kernel really reads (ASCII, 1 B per base); "
+                                 "frac_packed_accounting is the north-star's packed-2-bit accounting measured on the packed-input kernel"},
             "roofline_valu": valu_roofline(kmers_step_rank, sketch_ms, direct, algo, k, not args.no_ubench, defer and not dirty_in, p=p, reads=reads,
                                            sole=tm.get("sole_launches", 0) > 0),
             "stage_ms_per_step": {"pack": tm["pack_ms"] / max(tm["calls"], 1), "sketch": stage_sketch_ms,

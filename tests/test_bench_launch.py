@@ -59,3 +59,32 @@ def test_parent_of_a_self_launch_never_loads_torch():
     import json
     argv = json.loads(r.stdout.strip().splitlines()[-1])["argv"]
     assert argv[-6:] == ["--gpus", "2", "--workload", "allpairs", "--steps", "1"] and "--nproc-per-node" in argv
+
+
+def test_more_ranks_than_gpus_is_refused_in_one_line(monkeypatch, capsys):
+    """`bench.py --gpus 8` on a node with fewer GPUs used to die inside every torchrun child with a traceback per
+    rank.  The parent now counts the GPUs without touching HIP (KFD topology, or a one-shot child) and says so once: one JSON line, exit
+    code 2, nothing launched."""
+    import json
+    b = _bench()
+    launched = []
+    monkeypatch.setattr(b, "visible_gpus", lambda: 1)
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: launched.append(a) or subprocess.CompletedProcess(a, 0))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("LASH_BENCH_BACKEND", raising=False)
+    try:
+        b.main()
+        raise AssertionError("main() must exit")
+    except SystemExit as e:
+        assert e.code == 2
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.strip()]
+    assert len(out) == 1 and not launched
+    j = json.loads(out[0])
+    assert j["n_gpus_requested"] == 8 and j["n_gpus_visible"] == 1 and "nothing was launched" in j["error"]
+    # the dry run (ranks share devices over gloo) is not refused
+    monkeypatch.setenv("LASH_BENCH_BACKEND", "gloo")
+    try:
+        b.main()
+    except SystemExit as e:
+        assert e.code == 0 and launched

@@ -49,3 +49,39 @@ def test_plain_command_line_launches_its_own_ranks():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--genomes", "40"],
                        cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
     _check_line(r)
+
+
+def _one_line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_every_workload_rehearses_with_two_ranks():
+    """the first real multi-GPU run must not be lost to a trivial failure, so every workload's multi-rank code path
+    (sharding, barrier, max-over-ranks, and for allpairs the gather of the images and the row bands) runs here with two ranks on one GPU
+    over gloo: exactly one JSON line, n_gpus = 2, marked as a dry run."""
+    env = dict(os.environ, LASH_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "reads", "--algo", "ull", "-p", "12",
+                        "--reads", "2000000"], cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    j = _one_line(r)
+    assert j["n_gpus"] == 2 and "DRY RUN" in j["data"] and j["cpu_baseline"] is None
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 * 2 / (2 * 2_000_000 * (150 - 16 + 1) * 2) - 1) < 1e-6
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "allpairs", "--genomes", "300",
+                        "--length", "200000"], cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    j = _one_line(r)
+    assert j["n_gpus"] == 2 and "DRY RUN" in j["data"] and j["printed_pairs_per_s"] > 0
+    assert set(j["stage_ms_rank0"]) == {"sketch", "gather", "set + pairs"}
+
+
+def test_asking_for_more_gpus_than_the_box_has_fails_in_one_line():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LASH_BENCH_BACKEND"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1"], cwd=ROOT, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 2, r.stdout[-1000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus_requested"] == 8 and "Traceback" not in r.stderr
