@@ -365,9 +365,9 @@ enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_BINS = 2, REGS_BYTES = 3 };
 // (one v_ffbh_u32) and returns `t`; when t == 0 it has pushed a harmless under-estimate (max) or nothing (OR),
 // and the caller re-runs the word with FAST = false — legal because max/OR are idempotent.
 // ------------------------------------------------------------------------------------------------------------
-template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs, bool HLL_HIGH = false>
+template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs, bool HLL_HIGH = false, bool VSH = false>
 __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, uint32_t c_hi, uint32_t vm,
-                                             BitFlip bitflip, int p)
+                                             BitFlip bitflip, int p, uint32_t ull_sh28 = 0, uint32_t ull_sh29 = 0)
 {
     if constexpr (ALGO == 0) {
         // utils.rs:395-398: Sketch::add_bytes_with_seed(&(masked as u32).to_le_bytes(), seed)
@@ -460,7 +460,7 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             // same bits of g >> 28, i.e. of the high word shifted right by 28 - p (p <= 26); the index sits above the xorshift's reach
             const uint64_t g = xxh3_64_8b_pre(c_lo, c_hi, bitflip);
             hh = (uint32_t)(g >> 32); hl = (uint32_t)g;
-            th = alignbit(hh, hl, 32 - p) ^ (hh >> (28 - p));
+            th = alignbit(hh, hl, 32 - p) ^ (hh >> (VSH ? ull_sh28 : (uint32_t)(28 - p)));   // (VSH: the amounts sit in vector registers, KParams)
             // th != 0 -> nlz = v_ffbh(th) < 32: always the pair's first word; th == 0 -> push nothing (re-run by the caller)
             if constexpr (Regs::BINS || Regs::BYTES) {
                 uint32_t nlz = ffbh_u32(th);                                     // th == 0 -> all ones -> 63 = nothing
@@ -472,7 +472,8 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             uint32_t one;
             if constexpr (MASKED) asm("v_min3_u32 %0, %1, 1, %2" : "=v"(one) : "v"(th), "v"(vm));   // th == 0 or an invalid k-mer: nothing
             else one = th < 1u ? th : 1u;
-            regs.bor_first(hh, p, one << (ffbh_u32(th) & 31u));
+            if constexpr (VSH && std::is_same<Regs, LdsRegs>::value) regs.bor_b((hh >> ull_sh29) & ~7u, one << (ffbh_u32(th) & 31u));
+            else regs.bor_first(hh, p, one << (ffbh_u32(th) & 31u));
             return th;
         } else {
             const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
@@ -568,6 +569,8 @@ struct KParams {
     uint32_t mask_lt;      // KM_LT16: low 2k bits          with a scalar source issues in 4.4 cycles, with two vector sources in 2.6-2.9)
     uint32_t mask_hi;      // KM_GT16: bits 63:32 of mask_gt (its low word is all ones: 2k > 32)
     uint32_t sh_gt;        // KM_GT16: 64 - 2k
+    uint32_t ull_sh28 = 0, ull_sh29 = 0;   // UltraLogLog fast form: 28 - p and 29 - p as VECTOR registers (round 5: `v_lshrrev_b32 v, s, v` issues in
+                           // 4.42 cycles, `v, v, v` in 2.75 — two of them per k-mer; 0 = not set, the rule takes p as it comes)
     int p;
     // per-kernel constants of VOP2 instructions as vector registers (see BitFlip, lash_device.h)
     __device__ __forceinline__ void to_vector_registers()
@@ -578,6 +581,11 @@ struct KParams {
         asm volatile("v_mov_b32 %0, %1" : "=v"(sh_lt) : "s"(sh_lt));
         asm volatile("v_mov_b32 %0, %1" : "=v"(mask_lt) : "s"(mask_lt));
         asm volatile("v_mov_b32 %0, %1" : "=v"(mask_hi) : "s"(mask_hi));
+        if (p <= 26) {
+            ull_sh28 = 28u - (uint32_t)p; ull_sh29 = 29u - (uint32_t)p;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ull_sh28) : "s"(ull_sh28));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ull_sh29) : "s"(ull_sh29));
+        }
     }
 };
 
@@ -641,7 +649,7 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
             if constexpr (ALT) { fwd ^= (uint32_t)kp.lsb_xor; rc ^= (uint32_t)kp.lsb_xor; }   // min() is symmetric: no swap needed
             can_lo = fwd < rc ? fwd : rc;                                        // utils.rs:470,482
         }
-        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, HLL_HIGH>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p);
+        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, HLL_HIGH, !ALT>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28, kp.ull_sh29);
         zacc = zacc < t ? zacc : t;
         if constexpr (Regs::QUEUED) { if ((r & 3) == 3) regs.check(); }        // (LdsByteQRegs: is some lane's stack full?)
     }
@@ -670,7 +678,7 @@ __device__ __forceinline__ uint32_t process_quarter(const Regs &regs, const KPar
             if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
             can_lo = fwd < rc ? fwd : rc;
         }
-        const uint32_t t = add_kmer<ALGO, XLOW, true, FAST, Regs>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p);
+        const uint32_t t = add_kmer<ALGO, XLOW, true, FAST, Regs, false, true>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28, kp.ull_sh29);
         zacc = zacc < t ? zacc : t;
     }
     return zacc;

@@ -111,7 +111,16 @@ def parse_kernels(path):
     """-> {demangled name: [(label, [(mnemonic, operands, raw line)])]} for every function in an amdgcn .s listing."""
     lines = open(path, errors="replace").read().splitlines()
     funcs, cur, name = {}, None, None
+    files, loc = {}, None                                   # .file N "dir" "name" / .loc N line col (listings made with -gline-tables-only)
     for ln in lines:
+        m = re.match(r'^\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', ln)
+        if m:
+            files[int(m.group(1))] = os.path.basename(m.group(3) or m.group(2))
+            continue
+        m = re.match(r"^\s*\.loc\s+(\d+)\s+(\d+)", ln)
+        if m:
+            loc = (int(m.group(1)), int(m.group(2)))
+            continue
         m = re.match(r"^(_Z[A-Za-z0-9_]+):", ln)
         if m:
             name = m.group(1)
@@ -134,7 +143,7 @@ def parse_kernels(path):
         mn = parts[0]
         ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
         ops = [o.split()[0] if o.split() else o for o in ops]              # strips modifiers such as 'bitop3:0x96', 'offset:4'
-        cur[-1][1].append((mn, ops, s))
+        cur[-1][1].append((mn, ops, s if loc is None else s + "\t; @%s:%d" % (files.get(loc[0], "?"), loc[1])))
     if not funcs:
         return {}
     names = list(funcs)
@@ -206,6 +215,8 @@ def main():
                     help="price the blocks SELECT picks as one section that covers KMERS k-mers per lane (a float: 0.044 rounds per k-mer "
                          "is KMERS = 1 / 0.044); repeatable")
     ap.add_argument("--dump", action="store_true", help="print the instructions of the selected blocks with their classes")
+    ap.add_argument("--mnemonics", action="store_true", help="per section: the MNEMONIC histogram (count, per k-mer, class, cycles) and, when the listing "
+                    "carries .loc lines (hipcc -gline-tables-only), the source lines the section's VALU instructions come from (VERDICT r4 next #2)")
     ap.add_argument("--measured", type=float, default=None, help="measured cycles per wave-k-mer, printed beside the prediction")
     ap.add_argument("--measured-valu", type=float, default=None, help="measured SQ_INSTS_VALU per k-mer (per lane)")
     ap.add_argument("--json", default=None)
@@ -259,6 +270,29 @@ def main():
                     sec_c += cyc
             print("%-30s %7d %9.3f %8s %10s" % (cls, cnt, cnt / kmers, ("%.2f" % c) if (c is not None and is_valu(cls)) else "-", ("%.2f" % cyc) if cyc is not None else "-"))
         print("%-30s %7s %9.3f %8s %10.2f" % ("section: VALU", "", sec_v, "", sec_c))
+        if args.mnemonics:
+            mh, src = collections.Counter(), collections.Counter()
+            for l in labels:
+                prev = None
+                for mn, ops, raw in bd[l]:
+                    c = classify(mn, ops)
+                    if c.startswith("vop2 v,v") and mn.startswith("v_mov_b32") and prev == "v_mad_u64_u32":
+                        c = "v_mov after v_mad_u64_u32"
+                    prev = c
+                    if not is_valu(c):
+                        continue
+                    mh[(mn, c)] += 1
+                    at = raw.rsplit("; @", 1)
+                    if len(at) == 2:
+                        src[at[1]] += 1
+            print("   mnemonics (VALU only):  %-28s %-28s %6s %9s %9s" % ("mnemonic", "class", "count", "per k-mer", "cyc/k-mer"))
+            for (mn, c), cnt in sorted(mh.items(), key=lambda kv: -kv[1] * (costs.get(kv[0][1]) or 0)):
+                cc = costs.get(c)
+                print("   %22s  %-28s %-28s %6d %9.3f %9s" % ("", mn, c, cnt, cnt / kmers, ("%.2f" % (cnt * cc / kmers)) if cc is not None else "-"))
+            if src:
+                print("   source lines (VALU instructions per k-mer; inlined code is charged to the line it was written on):")
+                for at, cnt in src.most_common(24):
+                    print("   %22s  %-40s %9.3f" % ("", at, cnt / kmers))
         grand_c += sec_c
         grand_v += sec_v
         out_sections.append({"name": name, "select": sel, "blocks": len(labels), "kmers_per_lane": kmers, "valu_per_kmer": sec_v, "cycles_per_kmer": sec_c})
