@@ -380,6 +380,83 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
             "roofline": None, "cpu_baseline": None}))
 
 
+def cli_bench(args):
+    """--workload cli: the drop-in surface itself — `lash sketch -f list -o out` (lash_amd/bin/lash, the C++ host
+    above the C ABI: main.rs:180-279, utils.rs:439-580) from FASTA FILES on tmpfs to `{o}_sketches.bin`, as a child process, timed on
+    the wall clock by this process.  Never the default line: PCIe and the host's file reads are inside the step."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, ROOT)
+    algo, k, p, L, G = args.algo, args.k, args.p if args.algo != "hmh" else 0, args.length, args.genomes
+    assert L % 80 == 0, "--workload cli writes 80-column FASTA: --length must be a multiple of 80"
+    exe = os.path.join(ROOT, "lash_amd", "bin", "lash")
+    d = tempfile.mkdtemp(prefix="lash_bench_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        distinct = min(G, max(1, (6 << 30) // (L + L // 80)))          # at most ~6 GB of tmpfs; further paths are hard links (read in full all the same)
+        # the files are written by a CHILD (the library's own generator on the GPU, SURVEY 8(d)): this process never touches the GPU, it only
+        # starts programs and reads the clock
+        gen = ("import sys, os, numpy as np, torch\nsys.path.insert(0, %r)\nimport lash_amd\n"
+               "ctx = lash_amd.Context(0)\nL, distinct, d = %d, %d, %r\n"
+               "for g0 in range(0, distinct, 100):\n"
+               "    n = min(100, distinct - g0)\n"
+               "    dseq = torch.empty(n * L, dtype=torch.uint8, device='cuda')\n"
+               "    ctx.synth_genomes_device(g0, n, L, dseq)\n"
+               "    torch.cuda.synchronize()\n"
+               "    host = dseq.cpu().numpy().reshape(n, L // 80, 80)\n"
+               "    for i in range(n):\n"
+               "        lines = np.empty((L // 80, 81), dtype=np.uint8)\n"
+               "        lines[:, :80] = host[i]\n"
+               "        lines[:, 80] = 10\n"
+               "        with open(os.path.join(d, 'g%%d.fa' %% (g0 + i)), 'wb') as f:\n"
+               "            f.write(b'>g%%d\\n' %% (g0 + i))\n"
+               "            f.write(lines.tobytes())\n"
+               "ctx.close()\n") % (ROOT, L, distinct, d)
+        r = subprocess.run([sys.executable, "-c", gen], capture_output=True, text=True, timeout=3600)
+        if r.returncode != 0:
+            raise SystemExit("could not write the FASTA files: " + r.stderr[-2000:])
+        names = []
+        for g in range(G):
+            if g >= distinct:
+                os.link(os.path.join(d, "g%d.fa" % (g % distinct)), os.path.join(d, "g%d.fa" % g))
+            names.append(os.path.join(d, "g%d.fa" % g))
+        open(os.path.join(d, "list.txt"), "w").write("\n".join(names) + "\n")
+        text_bytes = G * (L + L // 80 + len(">g0\n"))
+        threads = min(64, max(4, (os.cpu_count() or 8)))
+        cmd = [exe, "sketch", "-f", os.path.join(d, "list.txt"), "-o", os.path.join(d, "out"), "-k", str(k), "-a", algo, "-t", str(threads)]
+        if algo != "hmh":
+            cmd += ["-p", str(p)]
+        walls, inside = [], []
+        for it in range(args.warmup + args.steps):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=3600)
+            w = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise SystemExit("lash sketch failed: " + r.stderr[-2000:])
+            if it >= args.warmup:
+                walls.append(w)
+                for ln in (r.stdout + r.stderr).splitlines():
+                    if ln.startswith("sketched ") and " in " in ln:
+                        inside.append(float(ln.split(" in ")[1].split(" s")[0]))
+        wall = sum(walls) / len(walls)
+        kmers = G * (L - k + 1)
+        print(json.dumps({
+            "metric": "k-mers/s sketched (%s, k=%d) through the `lash sketch` command line" % (algo, k), "value": kmers / wall, "unit": "k-mers/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic FASTA files on tmpfs",
+            "config": {"workload": "`lash sketch` END TO END: %d FASTA files of %d bp (80-column lines, %.2f GB of text; %d distinct, the rest hard links) on tmpfs "
+                                   "-> {o}_sketches.bin + the two JSON files; process start, file reads, PCIe, device parse + pack + sketch, zstd and the write are "
+                                   "all inside the step (a child process per step)" % (G, L, text_bytes / 1e9, distinct),
+                       "genomes": G, "genome_length": L, "algo": algo, "k": k, "p": p, "threads": threads},
+            "text_gb_per_s": text_bytes / wall / 1e9,
+            "inside_sketch_files_s": (sum(inside) / len(inside)) if inside else None,
+            "roofline": None, "cpu_baseline": None,
+            "note": "not a kernel measurement: the step is bound by the host link (PCIe Gen5 x16 carries ~1 B per base) and the file reads; the resident-input "
+                    "line is `python bench.py` without --workload"}))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def visible_gpus():
     """GPUs this process' children could use, counted WITHOUT initialising HIP here (the parent of a self-launch must never touch the
     GPU): a one-shot CHILD asks torch (torch.cuda.device_count() does not initialise HIP on this image, and the child is gone before
@@ -436,7 +513,7 @@ def main():
     ap.add_argument("-k", type=int, default=16)
     ap.add_argument("-p", type=int, default=14)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--workload", choices=["genomes", "reads", "allpairs"], default="genomes",
+    ap.add_argument("--workload", choices=["genomes", "reads", "allpairs", "cli"], default="genomes",
                     help="genomes: --genomes x --length bp, one record each (configs[1]/[2]); reads: ONE sketch of --reads "
                          "150-bp records (configs[4] shape; use with --algo ull -p 12); allpairs: configs[3] shape — every rank "
                          "sketches --genomes genomes, the images are all-gathered (RCCL), every rank computes its block of "
@@ -455,6 +532,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+    if args.workload == "cli":                              # (cli: `lash sketch` from files on tmpfs, one GPU; see cli_bench)
+        assert args.gpus == 1, "--workload cli runs the command line on one GPU (it takes -d for more)"
+        if args.genomes == 12500:
+            args.genomes = 1000                             # configs[1] size unless asked otherwise
+        return cli_bench(args)
 
     import numpy as np
     import torch

@@ -85,3 +85,16 @@ def test_asking_for_more_gpus_than_the_box_has_fails_in_one_line():
     assert r.returncode == 2, r.stdout[-1000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and json.loads(lines[0])["n_gpus_requested"] == 8 and "Traceback" not in r.stderr
+
+
+def test_the_cli_workload_prints_the_same_contract():
+    """`bench.py --workload cli` times `lash sketch` itself — FASTA files on tmpfs in, sketches.bin out, a child
+    process per step — and prints the usual JSON line (never the default line)."""
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LASH_BENCH_BACKEND"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "cli", "--genomes", "60", "--length", "400000", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    j = _one_line(r)
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["unit"] == "k-mers/s" and "END TO END" in j["config"]["workload"]
+    assert abs(j["value"] * j["ms_per_step"] * 1e-3 / (60 * (400000 - 16 + 1)) - 1) < 1e-6 and j["text_gb_per_s"] > 0
