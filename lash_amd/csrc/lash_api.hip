@@ -807,7 +807,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
                 ctx->last.direct_launches += n_items ? 1 : 0;
                 ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
             }
-            HIPCHK(ctx, launch_sketch_stream(plan, sa, n_items, ctx->stream));    // the flagged genomes, compacted on the fly
+            HIPCHK(ctx, launch_sketch_stream(plan_d, sa, n_items, ctx->stream));    // the flagged genomes, compacted on the fly
         }
     } else if (plan.bins) {
         rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, d_item_begin, [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int {

@@ -383,9 +383,15 @@ constexpr uint32_t RING_W = 260, RING_BW = 130;          // code words / record-
 constexpr uint32_t STREAM_CHUNK = 2048, STREAM_BATCH = 2048;
 static_assert(RING_W <= DENSE_STAGE_CODE_WORDS && RING_BW <= DENSE_STAGE_BRK_WORDS, "the ring lives in dense_tile's staging area");
 
-template <int ALGO, int KMODE, bool XLOW, int REGS>
+// DEFER (round 5): HyperMinHash genomes of long work items — a soft-masked assembly is exactly that — run the
+// filter of process_word_defer here too: the rank half of the hash for every k-mer, the signature half only for the few whose rank
+// can still win their bucket (threshold words, per-lane stacks: LdsThrRegs, SigQueue).  The stacks sit BEHIND the waves' rings, and
+// the launch is 1 024 threads (one workgroup per CU, sixteen waves: the waves of this kernel never wait for each other between the
+// first and the last barrier, so one large workgroup loses nothing to two small ones and has room for both areas).
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DEFER = false>
 __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
 {
+    static_assert(!DEFER || (ALGO == 0 && !XLOW && REGS == REGS_LDS), "deferred signatures: HyperMinHash, x = high half, one LDS table");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
     const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x + a.item_base;
     const WorkItem it = a.items[item];
@@ -407,9 +413,9 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
         return;
     }
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
-    using Regs = typename std::conditional<REGS == REGS_LDS, LdsRegs,
+    using Regs = typename std::conditional<DEFER, LdsThrRegs, typename std::conditional<REGS == REGS_LDS, LdsRegs,
                                            typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs,
-                                           typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteRegs>::type>::type>::type;
+                                           typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteRegs>::type>::type>::type>::type;
     Regs regs;
     uint32_t *census;
     const uint32_t part = 0u;
@@ -454,6 +460,9 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
     const uint32_t brk_b = stage_b + 4u * DENSE_STAGE_CODE_WORDS;
     lds_u32 *const ring = (lds_u32 *)(uintptr_t)stage_b;
     lds_u32 *const bring = (lds_u32 *)(uintptr_t)brk_b;
+    SigQueue sigq;                                                          // DEFER: the lanes' stacks, behind every wave's ring
+    sigq_init(sigq, (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.stage_off + n_waves * (DENSE_STAGE_WORDS * 4u) + wave * (64u * a.sigq_depth * 4u))),
+              a.sigq_depth, lane);
     for (uint32_t i = lane; i < DENSE_STAGE_WORDS; i += 64u) ring[i] = 0;
     __syncthreads();                                                       // the register table and every ring are clear
 
@@ -495,7 +504,15 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
 #pragma unroll 1
             for (int wi = 0; wi < 2; ++wi) {
                 uint32_t z;
-                if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
+                if constexpr (DEFER) {
+                    z = 0xFFFFFFFFu;                                           // (nothing to re-run: the full update does that itself)
+                    if (all_valid) process_word_defer<KMODE, false>(regs, kp, c0, c1, c2, r0, r1, r2, 0u, sigq);
+                    else {
+                        uint32_t m = kvw;
+                        asm volatile("" : "+v"(m));
+                        process_word_defer<KMODE, true>(regs, kp, c0, c1, c2, r0, r1, r2, m, sigq);
+                    }
+                } else if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
                 else {
                     uint32_t m = kvw;
                     asm volatile("" : "+v"(m));
@@ -675,6 +692,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
         // surviving bases of this wave's part (lash_timing::bases_last)
         if (lane == 0 && part == 0u && a.ndel2) atomicAdd(a.ndel2 + it.genome, (uint32_t)(we - ws) - own_seen);
     }
+    if constexpr (DEFER) sigq_drain<true>(regs, kp.bitflip, p, sigq);
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
 }
 
@@ -682,16 +700,25 @@ template <int ALGO, int KMODE, bool XLOW, int REGS>
 static hipError_t launch_stream_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
     auto kern = stream_sketch_kernel<ALGO, KMODE, XLOW, REGS>;
+    uint32_t threads = plan.threads, stacks = 0;
     SketchArgs a = args;
+    if constexpr (ALGO == 0 && !XLOW && REGS == REGS_LDS) {
+        if (plan.defer) {                                                  // (see the kernel: 1 024 threads, the lanes' stacks behind the rings)
+            kern = stream_sketch_kernel<ALGO, KMODE, XLOW, REGS, true>;
+            threads = 1024u;
+            stacks = (threads / 64u) * 64u * plan.sigq_depth * 4u;
+        }
+    }
     a.stage_off = plan.lds_bytes;
-    a.bin_lds_off = plan.lds_bytes + sketch_direct_stage_bytes(plan);
+    a.sigq_depth = plan.sigq_depth;
+    a.bin_lds_off = plan.lds_bytes + (threads / 64u) * (DENSE_STAGE_WORDS * 4u) + stacks;
     a.bin_wave_bytes = sketch_bin_wave_bytes(plan);
-    const uint32_t lds = a.bin_lds_off + (plan.threads / 64u) * a.bin_wave_bytes;
+    const uint32_t lds = a.bin_lds_off + (threads / 64u) * a.bin_wave_bytes;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(n_items), dim3(plan.threads), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(n_items), dim3(threads), lds, stream, a);
     return hipGetLastError();
 }
 
