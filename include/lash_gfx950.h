@@ -234,6 +234,16 @@ uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32
  * of one huge file) and the raw-bytes device entry.  ~25 small sketch calls per flagged genome, i.e. nothing on average. */
 int lash_hll_replay_sums_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
                                 const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *d_images);
+/* (ABI v5) The same for ONE FILE STREAMED IN CHUNKS with LASH_F_ACCUMULATE (the CLI's --stream-mb; utils.rs:457-505 reads the file's records
+ * in order into one sketch, so the reference's `sum` is the incremental value over the whole file).  Call after each chunk's
+ * lash_sketch_files_raw: raw / n_bytes / fmt = the chunk as it was handed over, image_before = the file's image before that call,
+ * image_after = after it (host memory, patched in place), carry[2] + *have_carry = state the caller keeps per file (zero-initialised).
+ * While no register is above 53 - p nothing happens.  A chunk that lifts one there is replayed — prefix sketches of the chunk united with
+ * image_before's registers locate the k-mers, their updates are done in IEEE double as the crate does — and from then on every later
+ * chunk's exact net change is added to the carried value: image_after's `sum` equals the reference's after every chunk
+ * (tests/test_gpu_hll_corner.py asserts byte equality for --stream-mb 1). */
+int lash_hll_replay_streamed_chunk(lash_ctx *ctx, const lash_params *prm, const uint8_t *raw, uint64_t n_bytes, int fmt,
+                                   const uint8_t *image_before, uint8_t *image_after, double *carry, int *have_carry);
 /* Host-side twin of the device checks (what the library itself runs on a flagged file; the `lash` CLI no longer pre-validates —
  * it hands the bytes over and reads lash_ctx_format_errors): the length of the longest prefix of `buf` that is a sequence of
  * well-formed records — '@' header, sequence, '+' line, quality of EQUAL length (CR stripped); the last record may lack its

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "lash_sketch_files_raw_device": (_int, [_vp, _PP, _vp, _vp, _vp, _u32, _vp]),
     "lash_ctx_format_errors": (_u32, [_vp, _vp, _u32]),
     "lash_hll_replay_sums_device": (_int, [_vp, _PP, _vp, _vp, _u64, _vp, _u32, _vp]),
+    "lash_hll_replay_streamed_chunk": (_int, [_vp, _PP, _vp, _u64, _int, _vp, _vp, _vp, _vp]),
     "lash_ctx_hll_inexact_sums": (_u32, [_vp, _vp, _u32]),
     "lash_fastq_valid_prefix": (_u64, [_vp, _u64]),
     "lash_fastq_neutralise_tail": (None, [_vp, _u64]),

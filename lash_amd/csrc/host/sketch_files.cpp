@@ -255,6 +255,11 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
     std::condition_variable cv;
     std::deque<Job> jobs;
     bool busy[2] = {false, false}, no_more = false, halt = false, corner_noted = false;
+    // HyperLogLog: the image before each chunk and the carried incremental `sum` (lash_hll_replay_streamed_chunk, round 5: a streamed
+    // file's header then equals the reference's, which reads the whole file into one sketch in order, utils.rs:457-505)
+    std::vector<uint8_t> image_before;
+    double hll_carry[2] = {0.0, 0.0};
+    int hll_have_carry = 0;
     lash_layout lay0;
     (void)lash_ctx_get_layout(ctx, &lay0);
     const bool skip_bad = lay0.fastq_skip_bad != 0;           // layout switch U6: malformed records are dropped, the reading goes on
@@ -284,14 +289,28 @@ std::string stream_big_file(lash_ctx *ctx, const lash_params &prm0, const std::s
                     if (calls) prm.flags |= LASH_F_ACCUMULATE;
                     const uint64_t off[2] = {0, (uint64_t)jb.cut};
                     const uint8_t f = (uint8_t)jb.fmt;
+                    const bool hll_nt = prm.algo == LASH_HLL && !(prm.flags & LASH_F_AMINO);
+                    const size_t ib = hll_nt ? lash_layout_image_bytes(&lay0, LASH_HLL, prm.p) : 0;
+                    if (hll_nt) {
+                        if (calls) image_before.assign(image, image + ib);
+                        else {                                    // the first chunk starts from the empty sketch: every register 0
+                            image_before.assign(ib, 0);
+                        }
+                    }
                     const int rc = lash_sketch_files_raw(ctx, &prm, bufs[jb.b]->p, off, &f, 1, image);
                     if (rc != LASH_OK) e = std::string(lash_strerror(rc)) + " " + lash_ctx_last_error(ctx);
                     else {
                         ++calls;
-                        if (prm.algo == LASH_HLL && !corner_noted && lash_ctx_hll_inexact_sums(ctx, nullptr, 0) != 0) {
-                            corner_noted = true;  // registers only grow: once above 53 - p the final image is, too
-                            fprintf(stderr, "note: %s: a HyperLogLog register exceeds 53 - p; the header's sum field is the exact sum and may differ "
-                                            "from lash's incrementally rounded value in its last bits\n", path.c_str());
+                        if (hll_nt) {
+                            // a register above 53 - p: this chunk's part of the incremental sum is replayed, later chunks carry it on
+                            const int rr = lash_hll_replay_streamed_chunk(ctx, &prm0, bufs[jb.b]->p, (uint64_t)jb.cut, jb.fmt, image_before.data(), image,
+                                                                          hll_carry, &hll_have_carry);
+                            if (rr != LASH_OK && !corner_noted) {
+                                corner_noted = true;
+                                fprintf(stderr, "note: %s: a HyperLogLog register exceeds 53 - p and the replay of the streamed chunk failed (%s); the header's "
+                                                "sum field is the exact sum and may differ from lash's incrementally rounded value in its last bits\n",
+                                        path.c_str(), lash_strerror(rr));
+                            }
                         }
                         // a malformed FASTQ record ends needletail's iteration (utils.rs:457): the library kept this chunk's
                         // records before it; nothing after it belongs to the sketch

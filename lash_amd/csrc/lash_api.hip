@@ -1070,6 +1070,103 @@ static int hll_sum_field_offset(const lash_layout &lay)
     return -1;
 }
 
+// the replay's probes are ordinary sketch calls: whatever they leave behind in the context — timing switch and sums, the list of
+// packed batches the user's call consumed, the direct pass's dirt feedback — is put back on EVERY way out
+struct ReplayRestore {
+    lash_ctx *c;
+    lash_timing last; bool timing; std::vector<const lash_packed *> packed; float dirty_frac; uint32_t direct_skipped; bool sole_only;
+    explicit ReplayRestore(lash_ctx *x) : c(x), last(x->last), timing(x->timing), packed(x->last_packed), dirty_frac(x->dirty_frac),
+                                          direct_skipped(x->direct_skipped), sole_only(x->last_sole_only) {}
+    ~ReplayRestore()
+    {
+        c->last = last; c->timing = timing; c->last_packed = packed; c->dirty_frac = dirty_frac; c->direct_skipped = direct_skipped;
+        c->last_sole_only = sole_only;
+        c->probe_pending = false;                                     // (a probe's feedback is not the user's batch's)
+    }
+};
+
+// One genome (or one streamed chunk of a file) of the replay.  `rec`: its records' absolute offsets into d_seq; `fin`: its image
+// AFTER (header + registers, on the host); `base`: NULL, or the registers the sketch held BEFORE these records (a streamed file's
+// earlier chunks: every prefix sketch is united with them before it is looked at).  (S, G, carry): the incremental sum and the on-grid
+// sum of the registers at the moment S was last brought up to date — carried from chunk to chunk of a streamed file; in: carry == false
+// means "no register has been above 53 - p so far" (S is then the exact sum, taken from the registers).  Out: S is the reference's
+// incremental value after these records, G the on-grid sum of `fin`'s registers, carry = true.
+static int hll_replay_one(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const std::vector<uint64_t> &rec, const uint8_t *fin,
+                          const uint8_t *base, double &S, double &G, bool &carry)
+{
+    const int p = prm->p;
+    const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p, ib = hdr + m;
+    int rc;
+    if ((rc = reserve(ctx, ctx->replay_img, ib + 64))) return rc;
+    if ((rc = reserve(ctx, ctx->replay_rec, (rec.size() + 1) * 8))) return rc;
+    // the registers after the genome's records cut at byte `cut` (absolute offset into d_seq), united with `base` -> out
+    auto prefix = [&](uint64_t cut, std::vector<uint8_t> &out) -> int {
+        size_t i = (size_t)(std::upper_bound(rec.begin(), rec.end(), cut) - rec.begin());   // records [0, i-1) lie wholly before the cut
+        if (i == 0) i = 1;
+        std::vector<uint64_t> pr(rec.begin(), rec.begin() + i);
+        if (pr.back() < cut) pr.push_back(cut);                                             // the record the cut falls into, truncated
+        const uint64_t n = pr.size() - 1, goff[2] = {0, n}, gbo[2] = {pr.front(), pr.back()};
+        HIPCHK(ctx, hipMemcpy(ctx->replay_rec.ptr, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
+        int r = lash_sketch_batch_device(ctx, prm, d_seq, static_cast<const uint64_t *>(ctx->replay_rec.ptr), n, goff, gbo, 1,
+                                         static_cast<uint8_t *>(ctx->replay_img.ptr));
+        if (r) return r;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        out.resize(ib);
+        HIPCHK(ctx, hipMemcpy(out.data(), ctx->replay_img.ptr, ib, hipMemcpyDeviceToHost));
+        if (base) for (size_t j = 0; j < m; ++j) out[hdr + j] = std::max(out[hdr + j], base[j]);
+        return LASH_OK;
+    };
+    struct Event { uint64_t cut; uint32_t j; uint8_t neu, old; std::vector<uint8_t> before; };
+    std::vector<Event> events;
+    std::vector<std::pair<uint32_t, uint8_t>> todo;                 // (bucket, value above the grid) whose k-mer is to be found
+    for (size_t j = 0; j < m; ++j)
+        if (fin[hdr + j] > 53 - p && (!base || fin[hdr + j] != base[j])) todo.push_back({(uint32_t)j, fin[hdr + j]});
+    std::vector<uint8_t> probe;
+    while (!todo.empty()) {
+        const auto [j, val] = todo.back();
+        todo.pop_back();
+        uint64_t lo = rec.front(), hi = rec.back();                // prefix(lo) lacks the value, prefix(hi) has it
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if ((rc = prefix(mid, probe))) return rc;
+            if (probe[hdr + j] >= val) hi = mid; else lo = mid;
+        }
+        Event e;
+        e.cut = hi; e.j = j; e.neu = val;
+        if ((rc = prefix(hi - 1, e.before))) return rc;
+        e.old = e.before[hdr + j];
+        // an earlier k-mer OF THESE RECORDS had already put this bucket above the grid (one of an earlier chunk is `base`'s: no event here)
+        if (e.old > 53 - p && (!base || e.old != base[j])) todo.push_back({j, e.old});
+        events.push_back(std::move(e));
+    }
+    if (events.empty()) {                                           // nothing of these records touches the corner
+        if (carry) { S += grid_sum(fin + hdr, m, p) - G; }
+        else memcpy(&S, fin + hll_sum_field_offset(ctx->layout), 8);
+        G = grid_sum(fin + hdr, m, p);
+        return LASH_OK;
+    }
+    std::sort(events.begin(), events.end(), [](const Event &a, const Event &b) { return a.cut < b.cut; });
+    // up to the first such k-mer every step was exact: the sum is that of the registers (on their grid), or the carried value plus
+    // the exact net change since it was taken
+    if (carry) S += grid_sum(events[0].before.data() + hdr, m, p) - G;
+    else S = grid_sum(events[0].before.data() + hdr, m, p);
+    double grid_after = 0.0;
+    for (size_t i = 0; i < events.size(); ++i) {
+        const Event &e = events[i];
+        if (i) S += grid_sum(e.before.data() + hdr, m, p) - grid_after;      // exact steps in between: their net change
+        // the k-mer's own update, rounded as the crate's is: ONE operation, sum -= 2^-old - 2^-new (the difference is exact unless
+        // new - old > 53; ADVICE r4: the two-step form differs when the bucket's old value lies above 53 - p as well)
+        S -= ldexp(1.0, -(int)e.old) - ldexp(1.0, -(int)e.neu);
+        std::vector<uint8_t> after(e.before.begin() + hdr, e.before.end());
+        after[e.j] = e.neu;
+        grid_after = grid_sum(after.data(), m, p);
+    }
+    G = grid_sum(fin + hdr, m, p);
+    S += G - grid_after;
+    carry = true;
+    return LASH_OK;
+}
+
 static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t *d_seq, const uint64_t *d_rec_off, const uint64_t *h_rec_off,
                            const uint64_t *genome_rec_off, uint8_t *d_images, uint8_t *h_images, const std::vector<uint32_t> &flagged,
                            std::vector<uint32_t> &left)
@@ -1080,24 +1177,10 @@ static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t
     const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p, ib = hdr + m;
     if (sum_at < 0 || (prm0->flags & (LASH_F_ACCUMULATE | LASH_F_AMINO))) { left = flagged; return LASH_OK; }
     lash_params prm = *prm0;
-    // the probes are ordinary sketch calls: whatever they leave behind in the context — timing switch and sums, the list of packed
-    // batches the user's call consumed, the direct pass's dirt feedback — is put back on EVERY way out
-    struct Restore {
-        lash_ctx *c;
-        lash_timing last; bool timing; std::vector<const lash_packed *> packed; float dirty_frac; uint32_t direct_skipped; bool sole_only;
-        explicit Restore(lash_ctx *x) : c(x), last(x->last), timing(x->timing), packed(x->last_packed), dirty_frac(x->dirty_frac),
-                                        direct_skipped(x->direct_skipped), sole_only(x->last_sole_only) {}
-        ~Restore()
-        {
-            c->last = last; c->timing = timing; c->last_packed = packed; c->dirty_frac = dirty_frac; c->direct_skipped = direct_skipped;
-            c->last_sole_only = sole_only;
-            c->probe_pending = false;                                 // (a probe's feedback is not the user's batch's)
-        }
-    } restore(ctx);
+    ReplayRestore restore(ctx);
     ctx->timing = false;
     int rc = LASH_OK;
-    if ((rc = reserve(ctx, ctx->replay_img, ib + 64))) return rc;
-    std::vector<uint8_t> fin(ib), before(ib), probe(ib);
+    std::vector<uint8_t> fin(ib);
     for (uint32_t g : flagged) {
         const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], nr = r1 - r0;
         std::vector<uint64_t> rec(nr + 1);
@@ -1105,61 +1188,9 @@ static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t
         else HIPCHK(ctx, hipMemcpy(rec.data(), d_rec_off + r0, (nr + 1) * 8, hipMemcpyDeviceToHost));
         if (h_images) memcpy(fin.data(), h_images + (size_t)g * ib, ib);
         else HIPCHK(ctx, hipMemcpy(fin.data(), d_images + (size_t)g * ib, ib, hipMemcpyDeviceToHost));
-        if ((rc = reserve(ctx, ctx->replay_rec, (nr + 2) * 8))) break;
-        // the sketch of the genome's records cut at byte `cut` (absolute offset into d_seq) -> out
-        auto prefix = [&](uint64_t cut, std::vector<uint8_t> &out) -> int {
-            size_t i = (size_t)(std::upper_bound(rec.begin(), rec.end(), cut) - rec.begin());   // records [0, i-1) lie wholly before the cut
-            if (i == 0) i = 1;
-            std::vector<uint64_t> pr(rec.begin(), rec.begin() + i);
-            if (pr.back() < cut) pr.push_back(cut);                                             // the record the cut falls into, truncated
-            const uint64_t n = pr.size() - 1, goff[2] = {0, n}, gbo[2] = {pr.front(), pr.back()};
-            HIPCHK(ctx, hipMemcpy(ctx->replay_rec.ptr, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
-            int r = lash_sketch_batch_device(ctx, &prm, d_seq, static_cast<const uint64_t *>(ctx->replay_rec.ptr), n, goff, gbo, 1,
-                                             static_cast<uint8_t *>(ctx->replay_img.ptr));
-            if (r) return r;
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            HIPCHK(ctx, hipMemcpy(out.data(), ctx->replay_img.ptr, ib, hipMemcpyDeviceToHost));
-            return LASH_OK;
-        };
-        struct Event { uint64_t cut; uint32_t j; uint8_t neu, old; std::vector<uint8_t> before; };
-        std::vector<Event> events;
-        std::vector<std::pair<uint32_t, uint8_t>> todo;             // (bucket, value above the grid) whose k-mer is to be found
-        for (size_t j = 0; j < m; ++j)
-            if (fin[hdr + j] > 53 - p) todo.push_back({(uint32_t)j, fin[hdr + j]});
-        bool ok = true;
-        while (!todo.empty() && ok) {
-            const auto [j, val] = todo.back();
-            todo.pop_back();
-            uint64_t lo = rec.front(), hi = rec.back();            // prefix(lo) lacks the value, prefix(hi) has it
-            while (hi - lo > 1 && ok) {
-                const uint64_t mid = lo + (hi - lo) / 2;
-                if ((rc = prefix(mid, probe))) { ok = false; break; }
-                if (probe[hdr + j] >= val) hi = mid; else lo = mid;
-            }
-            if (!ok) break;
-            Event e;
-            e.cut = hi; e.j = j; e.neu = val; e.before.resize(ib);
-            if ((rc = prefix(hi - 1, e.before))) { ok = false; break; }
-            e.old = e.before[hdr + j];
-            if (e.old > 53 - p) todo.push_back({j, e.old});         // an earlier k-mer had already put this bucket above the grid
-            events.push_back(std::move(e));
-        }
-        if (!ok) break;
-        std::sort(events.begin(), events.end(), [](const Event &a, const Event &b) { return a.cut < b.cut; });
-        double S;
-        memcpy(&S, events[0].before.data() + sum_at, 8);            // exact up to the first such k-mer
-        double grid_after = 0.0;
-        for (size_t i = 0; i < events.size(); ++i) {
-            const Event &e = events[i];
-            if (i) S += grid_sum(e.before.data() + hdr, m, p) - grid_after;      // exact steps in between: their net change
-            // the k-mer's own update, rounded as the crate's is: ONE operation, sum -= 2^-old - 2^-new (the difference is exact unless
-            // new - old > 53; ADVICE r4: the two-step form differs when the bucket's old value lies above 53 - p as well)
-            S -= ldexp(1.0, -(int)e.old) - ldexp(1.0, -(int)e.neu);
-            std::vector<uint8_t> after(e.before.begin() + hdr, e.before.end());
-            after[e.j] = e.neu;
-            grid_after = grid_sum(after.data(), m, p);
-        }
-        S += grid_sum(fin.data() + hdr, m, p) - grid_after;
+        double S = 0.0, G = 0.0;
+        bool carry = false;
+        if ((rc = hll_replay_one(ctx, &prm, d_seq, rec, fin.data(), nullptr, S, G, carry))) break;
         if (h_images) memcpy(h_images + (size_t)g * ib + sum_at, &S, 8);
         if (d_images) HIPCHK(ctx, hipMemcpy(d_images + (size_t)g * ib + sum_at, &S, 8, hipMemcpyHostToDevice));
     }
@@ -1951,6 +1982,59 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
     if (prm->flags & LASH_F_ACCUMULATE)
         for (uint32_t g : corner)
             if (std::find(bad.begin(), bad.end(), g) == bad.end()) ctx->hll_left.push_back(g);
+    return LASH_OK;
+}
+
+int lash_hll_replay_streamed_chunk(lash_ctx *ctx, const lash_params *prm, const uint8_t *raw, uint64_t n_bytes, int fmt, const uint8_t *image_before,
+                                   uint8_t *image_after, double *carry, int *have_carry)
+{
+    if (!ctx || !prm || !image_before || !image_after || !carry || !have_carry || (n_bytes && !raw)) return LASH_EINVAL;
+    int rc = lash_params_check(prm);
+    if (rc) return rc;
+    if (prm->algo != LASH_HLL || (prm->flags & LASH_F_AMINO) || (fmt != LASH_FMT_FASTA && fmt != LASH_FMT_FASTQ)) return LASH_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    const int p = prm->p, sum_at = hll_sum_field_offset(ctx->layout);
+    if (sum_at < 0) return LASH_OK;                                  // (a layout without the field: nothing to keep)
+    const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p;
+    bool event = false;                                              // did THIS chunk lift a register above 53 - p (or one that was there, further)?
+    for (size_t j = 0; j < m && !event; ++j) event = image_after[hdr + j] > 53 - p && image_after[hdr + j] != image_before[hdr + j];
+    double S = carry[0], G = carry[1];
+    bool have = *have_carry != 0;
+    if (!event) {
+        if (!have) return LASH_OK;                                   // still on the grid: the header's sum is exact
+        const double g = grid_sum(image_after + hdr, m, p);          // every step of this chunk was exact: its net change
+        S += g - G;
+        G = g;
+    } else {
+        // the chunk's records as needletail yields them (the library's own host parse), resident for the prefix sketches
+        std::vector<uint8_t> seq;
+        std::vector<uint64_t> rec(1, 0);
+        if (fmt == LASH_FMT_FASTA && n_bytes && raw[0] != '>') {
+            // a later chunk of a record that outgrew its chunk begins with sequence lines (the carried bases first): the device parse
+            // takes them as a record's lines; the host parse wants the header line it would have had
+            std::vector<uint8_t> with_hdr;
+            with_hdr.reserve((size_t)n_bytes + 3);
+            with_hdr.push_back('>'); with_hdr.push_back('c'); with_hdr.push_back('\n');
+            with_hdr.insert(with_hdr.end(), raw, raw + n_bytes);
+            parse_fastx_strict(with_hdr.data(), with_hdr.size(), &seq, &rec, ctx->layout.fastq_skip_bad != 0);
+        } else {
+            parse_fastx_strict(raw, (size_t)n_bytes, &seq, &rec, ctx->layout.fastq_skip_bad != 0);
+        }
+        if (rec.back() == rec.front()) { ctx->err = "hll replay: the chunk holds an event but no base"; return LASH_EINVAL; }
+        if ((rc = reserve(ctx, ctx->st_seq, seq.size() + 64))) return rc;
+        if (!seq.empty()) HIPCHK(ctx, hipMemcpy(ctx->st_seq.ptr, seq.data(), seq.size(), hipMemcpyHostToDevice));
+        ReplayRestore restore(ctx);
+        ctx->timing = false;
+        lash_params pr = *prm;
+        pr.flags &= ~(uint32_t)LASH_F_ACCUMULATE;                    // (a prefix is sketched by itself; the registers before it are `image_before`'s)
+        if ((rc = hll_replay_one(ctx, &pr, static_cast<const uint8_t *>(ctx->st_seq.ptr), rec, image_after, image_before + hdr, S, G, have))) return rc;
+    }
+    memcpy(image_after + sum_at, &S, 8);
+    carry[0] = S; carry[1] = G;
+    *have_carry = have ? 1 : 0;
+    ctx->hll_flags_n = 0;                                            // (the caller's image carries the incremental value now)
+    ctx->hll_flags_on_host = true;
+    ctx->hll_left.clear();
     return LASH_OK;
 }
 

@@ -163,8 +163,29 @@ def test_cli_replays_whole_files_and_notes_streamed_ones(tmp_path):
         notes = [ln for ln in r.stderr.splitlines() if ln.startswith("note:")]
         imgs = np.frombuffer(H.zstd_read(str(tmp_path / "h_sketches.bin")), np.uint8).reshape(2, -1)
         assert np.array_equal(imgs[0], _oracle(14, O.synth_genome(6, 100_000)))
-        if not extra:                                  # files sketched whole: the corner file's sum is replayed, nothing to note
-            assert notes == [] and np.array_equal(imgs[1], _oracle(14, g)), r.stderr
-        else:                                          # c.fa streamed in 1 MiB chunks with on-device accumulation: detected, reported, not replayed
-            assert len(notes) == 1 and "c.fa" in notes[0] and "53 - p" in notes[0], r.stderr
-            assert np.array_equal(imgs[1, 24:], _oracle(14, g)[24:])
+        # files sketched whole: the corner file's sum is replayed (round 4).  c.fa streamed in 1 MiB chunks with on-device accumulation
+        # (round 5, lash_hll_replay_streamed_chunk): the chunk that lifts the register above 53 - p is replayed on top of the image
+        # before it, the later chunks' exact net changes are carried — byte equality with the oracle's incremental sum, nothing to note
+        assert notes == [] and np.array_equal(imgs[1], _oracle(14, g)), r.stderr
+
+
+def test_streamed_file_with_corner_kmers_in_later_chunks(tmp_path):
+    """Round 5: `lash sketch --stream-mb 1` on one file whose corner k-mers sit in DIFFERENT chunks — the 2nd and the
+    4th of five — with clean chunks before, between and after: the chunk that lifts a register above 53 - p is replayed on top of the image
+    before it (prefix sketches united with the earlier chunks' registers), every later chunk's exact net change is carried, a second
+    corner k-mer two chunks on is replayed on top of the carried value.  The header equals the oracle's incremental sum byte for byte."""
+    import subprocess
+    import host_lib as H
+    parts = [O.synth_genome(21, 1_300_000).tobytes(), b"CACCATGCTATGTGCATGACC", O.synth_genome(22, 2_000_000).tobytes(), b"CTGAGTGTGTCAGGCGTCATT",
+             O.synth_genome(23, 1_200_000).tobytes()]
+    g = np.frombuffer(b"".join(parts), np.uint8)
+    (tmp_path / "s.fa").write_bytes(b">s\n" + b"\n".join(g.tobytes()[i:i + 70] for i in range(0, len(g), 70)) + b"\n")
+    (tmp_path / "l.txt").write_text("s.fa\n")
+    want = _oracle(14, g)
+    for extra in (["--stream-mb", "1"], []):
+        r = subprocess.run([H.CLI, "sketch", "-f", "l.txt", "-o", "h", "-a", "hll", "-p", "14", "-k", "21"] + extra, cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert [ln for ln in r.stderr.splitlines() if ln.startswith("note:")] == [], r.stderr
+        img = np.frombuffer(H.zstd_read(str(tmp_path / "h_sketches.bin")), np.uint8)
+        assert np.array_equal(img[24:], want[24:]) and np.array_equal(img[:16], want[:16])
+        assert np.array_equal(img, want), (extra, struct.unpack("<d", img[16:24].tobytes())[0], struct.unpack("<d", want[16:24].tobytes())[0])

@@ -1,4 +1,3 @@
 OUT=gpurun_out/r05a; mkdir -p $OUT
-export KERNELS="stream_sketch"
-bash tools/pmc_cmd.sh dirty_lower bench.py --steps 10 --warmup 3 --genomes 1000 --dirty lower --no-cpu-baseline --no-ubench --no-parity-check 2>&1 | tee $OUT/pmc_dirty_lower.txt
-LASH_DEFER_MIN=-1 bash tools/pmc_cmd.sh dirty_lower_nodefer bench.py --steps 10 --warmup 3 --genomes 1000 --dirty lower --no-cpu-baseline --no-ubench --no-parity-check 2>&1 | tee $OUT/pmc_dirty_lower_nodefer.txt
+timeout 1500 python3 -m pytest tests/test_gpu_hll_corner.py tests/test_gpu_cli.py tests/test_gpu_stream_gz.py -x -q -m gpu > $OUT/pytest_h.log 2>&1; tail -12 $OUT/pytest_h.log
+timeout 600 python3 tests/fuzz_gpu_stream.py 20 41 | tail -1
