@@ -226,7 +226,11 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
              ("ull", False, 12, True): "ull_p12_k16_reads"}.get((algo, bool(defer), 0 if algo == "hmh" else p, bool(reads)))
     if sole:
         audit = None
-    apath = os.path.join(ROOT, "profiles", "r04", "isa_cost", "%s.json" % audit) if audit else None
+    apath, around = None, "r05"
+    for around in ("r05", "r04"):                     # this round's audit (the HyperLogLog selector fixed: profiles/r05/floor_hll_ull.md), else round 4's
+        apath = os.path.join(ROOT, "profiles", around, "isa_cost", "%s.json" % audit) if audit else None
+        if apath and os.path.exists(apath):
+            break
     if direct and apath and os.path.exists(apath) and (algo, k) in (("hmh", 16), ("hll", 21), ("ull", 16)):
         try:
             aj = json.load(open(apath))
@@ -236,11 +240,11 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
                    "cycles_per_wave_kmer": aj["cycles_per_kmer"], "valu_per_kmer_in_listing": aj["valu_per_kmer"], "clock_ghz": ghz,
                    "clock_source": "tools/ubench_hash (s_memtime / s_memrealtime) in this job" if clock_ghz else "datasheet maximum",
                    "sections": [{"name": x["name"], "valu_per_kmer": x["valu_per_kmer"], "cycles_per_kmer": x["cycles_per_kmer"]} for x in aj["sections"]],
-                   "source": "profiles/r04/isa_cost/%s.txt (tools/isa_audit.sh: hot blocks of %s from hipcc's listing x the issue costs of "
+                   "source": "profiles/%s/isa_cost/%s.txt (tools/isa_audit.sh: hot blocks of %s from hipcc's listing x the issue costs of "
                              "profiles/r04/isa_cost/costs.json, measured by tools/ubench_isa at 4 waves per SIMD, x the mixed-stream factor %.3f of "
                              "profiles/r04/isa_cost/mix_factor.json: tools/ubench_hash's rank-half stream measured / priced the same way); per-word "
                              "and per-tile bookkeeping outside the priced blocks is not in the sum"
-                             % (audit, aj["kernel"].replace("void lash::", "").split("(")[0], aj.get("mix_factor", 1.0))}
+                             % (around, audit, aj["kernel"].replace("void lash::", "").split("(")[0], aj.get("mix_factor", 1.0))}
         except Exception:
             mix = None
     # the absolute figure beside the self-referential one: wave-instructions issued per second against the chip's issue peak

@@ -244,6 +244,8 @@ def main():
     for spec in args.section:
         name, kmers, sel = spec.split("|")
         kmers = float(kmers)
+        aside = name.startswith("~")                      # "~name": printed for comparison, not part of the kernel's sum
+        name = name.lstrip("~")
         labels = select(blocks, sel)
         total = collections.Counter()
         for l in labels:
@@ -293,6 +295,9 @@ def main():
                 print("   source lines (VALU instructions per k-mer; inlined code is charged to the line it was written on):")
                 for at, cnt in src.most_common(24):
                     print("   %22s  %-40s %9.3f" % ("", at, cnt / kmers))
+        if aside:
+            print("   (an aside: not in the sum below)")
+            continue
         grand_c += sec_c
         grand_v += sec_v
         out_sections.append({"name": name, "select": sel, "blocks": len(labels), "kmers_per_lane": kmers, "valu_per_kmer": sec_v, "cycles_per_kmer": sec_c})
