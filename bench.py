@@ -161,10 +161,10 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
         want = O.sketch_genomes(algo_id, k, p, seed, host, np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
         ok = ok and bool(np.array_equal(got, want))
     return {"value": kmers / elapsed, "unit": "k-mers/s", "cores": best, "kind": "port",
-            "sample": "%d synthetic %d-bp genomes, %s k=%d, in-memory sequences (no FASTA parse), %.1f s of CPU work; "
+            "sample": "%d synthetic %d-bp genomes, %s k=%d, in-memory sequences (no FASTA parse), %.1f s on the wall clock = %.0f core-seconds of CPU work; "
                       "oracle/lash_oracle.c (%s), one task per genome over %d threads (effective cores %d: %d logical, affinity %d, "
                       "cgroup %s%s)"
-                      % (done, L, algo, k, elapsed, flags, best, eff, prov["logical_cpus"], prov["affinity"], prov["cgroup"],
+                      % (done, L, algo, k, elapsed, elapsed * best, flags, best, eff, prov["logical_cpus"], prov["affinity"], prov["cgroup"],
                          ("; scan over %s threads" % sorted(scan)) if scan else ""),
             "parse_inclusive_value": parse_rate,
             "parse_inclusive_sample": "%d passes over %d of those genomes as 80-column FASTA text in memory (%.1f s): needletail-like parse + "
@@ -238,6 +238,9 @@ def valu_roofline(kmers_per_launch, sketch_ms, direct, algo, k, run_ubench=True,
             ceil_rate = 256 * 4 * ghz * 1e9 / aj["cycles_per_kmer"] * 64.0
             mix = {"value": ceil_rate, "unit": "k-mers/s", "frac": rate / ceil_rate if ceil_rate else None,
                    "cycles_per_wave_kmer": aj["cycles_per_kmer"], "valu_per_kmer_in_listing": aj["valu_per_kmer"], "clock_ghz": ghz,
+                   # the same with the instructions the kernel issues OUTSIDE the priced blocks (measured SQ_INSTS_VALU - listed) at the blocks' mean cost
+                   "cycles_per_wave_kmer_with_unlisted": aj.get("cycles_per_kmer_with_unlisted"),
+                   "frac_with_unlisted": (rate / (256 * 4 * ghz * 1e9 / aj["cycles_per_kmer_with_unlisted"] * 64.0)) if aj.get("cycles_per_kmer_with_unlisted") else None,
                    "clock_source": "tools/ubench_hash (s_memtime / s_memrealtime) in this job" if clock_ghz else "datasheet maximum",
                    "sections": [{"name": x["name"], "valu_per_kmer": x["valu_per_kmer"], "cycles_per_kmer": x["cycles_per_kmer"]} for x in aj["sections"]],
                    "source": "profiles/%s/isa_cost/%s.txt (tools/isa_audit.sh: hot blocks of %s from hipcc's listing x the issue costs of "
