@@ -541,6 +541,36 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             x0 = load16_any(src); x1 = load16_any(src + 16);
         };
         uint4 n0, n1;
+        // past the wave's part, inside a long run of deleted bytes (a gap, a masked block): 8 KiB per round trip to the first chunk
+        // that may hold a survivor or a record start — the workgroup's slot waits for this wave.  (pos: the chunk that held nothing)
+        auto gap_skip = [&](uint64_t &pos) {
+            if (pos >= we && !stop) {
+                uint64_t np = pos + STREAM_CHUNK;
+                for (;;) {
+                    if (np + 4 * STREAM_CHUNK + 32 > L) break;              // near the genome's end: chunk by chunk
+                    uint4 y[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        y[2 * j] = load16_any(gseq + np + (uint64_t)j * STREAM_CHUNK + 32ull * lane);
+                        y[2 * j + 1] = load16_any(gseq + np + (uint64_t)j * STREAM_CHUNK + 32ull * lane + 16);
+                    }
+                    uint32_t first = 4;
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        bool hit = (hopeless_bits(y[2 * j]) & hopeless_bits(y[2 * j + 1]) & 0x20202020u) != 0x20202020u;
+                        if (breaks) {
+                            const uint64_t aj = np + (uint64_t)j * STREAM_CHUNK + 32ull * lane;
+                            hit = hit || (RL ? uniform_breaks((uint32_t)aj, RL, 32u).b0 != 0u : bk[aj >> 5] != 0u);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) first = (uint32_t)j;
+                    }
+                    np += (uint64_t)first * STREAM_CHUNK;
+                    if (first < 4u) break;
+                }
+                if (np != pos + STREAM_CHUNK) { pos = np - STREAM_CHUNK; chunk_load(np, n0, n1); }
+            }
+        };
+        bool was_gap = false;                                              // the last chunk held no survivor
         chunk_load(ws, n0, n1);
         for (uint64_t pos = ws; pos < L && !stop; pos += STREAM_CHUNK) {
             if (pos >= we && (own_left == 0u || la_have >= want)) break;    // nothing owned waits for more bases
@@ -555,120 +585,112 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             }
             // ---- classification in three steps: is anything deleted at all? (most chunks of most genomes: no) — is anything left?
             //      (the inside of a masked block: no) — else which bytes ----
-            uint32_t bad = 0;
-            const uint32_t cw0 = ascii16_to_word(q0, bad, ct), cw1 = ascii16_to_word(q1, bad, ct);
-            // record starts among the lane's 32 positions (multi-record genomes: contigs, reads)
-            uint32_t rb = 0;
-            if (breaks && at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
-            // nothing deleted in an owned chunk (and no record start waiting for a survivor): every base goes to the ring as it is,
-            // and a record start stays on its own base
-            const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we && !pend;
-            uint32_t T, own_t;
-            if (chunk_clean) {
-                // 2 048 survivors, all owned: lane i's 32 bases go to ring position have + 32 i, one shift for all
-                const uint32_t rel = have + 32u * lane, sh = 2u * (rel & 15u);
-                uint32_t w = head_w + (rel >> 4); w = w >= RING_W ? w - RING_W : w;
-                const uint32_t w1 = w + 1u == RING_W ? 0u : w + 1u, w2 = w1 + 1u == RING_W ? 0u : w1 + 1u;
-                if (sh) {
-                    lds_or(stage_b + 4u * w, cw0 >> sh);
-                    lds_or(stage_b + 4u * w1, (cw0 << (32u - sh)) | (cw1 >> sh));
-                    lds_or(stage_b + 4u * w2, cw1 << (32u - sh));
-                } else {
-                    lds_or(stage_b + 4u * w, cw0);
-                    lds_or(stage_b + 4u * w1, cw1);
-                }
-                if (breaks && __builtin_amdgcn_ballot_w64(rb != 0u) != 0ull && rb) {   // (reads: a dozen record starts per chunk)
-                    uint32_t bw = (head_w >> 1) + (rel >> 5); bw = bw >= RING_BW ? bw - RING_BW : bw;
-                    const uint32_t bwn = bw + 1u == RING_BW ? 0u : bw + 1u, bs = rel & 31u;
-                    lds_or(brk_b + 4u * bw, rb << bs);
-                    if (bs) lds_or(brk_b + 4u * bwn, rb >> (32u - bs));
-                }
-                T = STREAM_CHUNK; own_t = STREAM_CHUNK;
-            } else {
-            uint32_t v;
-            if (__builtin_amdgcn_ballot_w64((hopeless_bits(q0) & hopeless_bits(q1) & 0x20202020u) != 0x20202020u) == 0ull) v = 0u;
-            else v = ~(inv16(q0) | (inv16(q1) << 16));                         // bit j: byte j survives (bytes past L are 'N')
-            const uint32_t own_n = at >= we ? 0u : (we - at >= 32 ? 32u : (uint32_t)(we - at));
-            const uint32_t ownmask = own_n >= 32u ? 0xFFFFFFFFu : ((1u << own_n) - 1u);
-            // ---- record starts land on the first survivor at or after them (cf. dense_tile); one that lands BEYOND the part ends it ----
-            uint32_t recv = 0;
-            if (breaks) {
-                const uint32_t fill = ~v, rbd = rb & fill;
-                const bool gen = fill + rbd < rbd;
-                const uint64_t G = __builtin_amdgcn_ballot_w64(gen), Z = __builtin_amdgcn_ballot_w64(v == 0u);
-                const uint64_t below = (1ull << lane) - 1ull, nz = ~Z & below;
-                const uint64_t from = nz ? ~((1ull << (63 - __builtin_clzll(nz))) - 1ull) : ~0ull;
-                const bool pend_in = (G & below & from) != 0ull || (nz == 0ull && pend);
-                recv = ((fill + rbd + (pend_in ? 1u : 0u)) | rb) & v;
-                const uint64_t nzall = ~Z;
-                pend = nzall ? (G >> (63 - __builtin_clzll(nzall))) != 0ull : (pend || G != 0ull);
-                const uint32_t cut = recv & ~ownmask;                             // the next record opens here, past this wave's part
-                const uint64_t Cm = __builtin_amdgcn_ballot_w64(cut != 0u);
-                if (Cm) {
-                    const uint32_t fl = (uint32_t)__builtin_ctzll(Cm);
-                    if (lane > fl) v &= ownmask;
-                    else if (lane == fl) v &= ownmask | ((1u << __builtin_ctz(cut)) - 1u);
-                    stop = true;
-                }
+            // Inside a masked block the next chunk is most likely masked too: ask THAT first and save the conversion (54 instructions
+            // against 26; genomes with record starts keep the order: a start inside the run has to be carried, below)
+            bool hop_known = false, gap = false;
+            if (was_gap && !breaks) {
+                hop_known = true;
+                gap = __builtin_amdgcn_ballot_w64((hopeless_bits(q0) & hopeless_bits(q1) & 0x20202020u) != 0x20202020u) == 0ull;
             }
-            const uint32_t n_all = (uint32_t)__builtin_popcount(v);
-            const uint32_t off = wave_excl_scan(n_all, T);
-            if (T == 0u) {                                                     // nothing survives in this chunk
-                if (pos >= we && !stop) {
-                    // past the wave's part, inside a long run of deleted bytes (a gap, a masked block): 8 KiB per round trip to
-                    // the first chunk that may hold a survivor or a record start — the workgroup's slot waits for this wave
-                    uint64_t np = pos + STREAM_CHUNK;
-                    for (;;) {
-                        if (np + 4 * STREAM_CHUNK + 32 > L) break;              // near the genome's end: chunk by chunk
-                        uint4 y[8];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            y[2 * j] = load16_any(gseq + np + (uint64_t)j * STREAM_CHUNK + 32ull * lane);
-                            y[2 * j + 1] = load16_any(gseq + np + (uint64_t)j * STREAM_CHUNK + 32ull * lane + 16);
-                        }
-                        uint32_t first = 4;
-#pragma unroll
-                        for (int j = 3; j >= 0; --j) {
-                            bool hit = (hopeless_bits(y[2 * j]) & hopeless_bits(y[2 * j + 1]) & 0x20202020u) != 0x20202020u;
-                            if (breaks) {
-                                const uint64_t aj = np + (uint64_t)j * STREAM_CHUNK + 32ull * lane;
-                                hit = hit || (RL ? uniform_breaks((uint32_t)aj, RL, 32u).b0 != 0u : bk[aj >> 5] != 0u);
-                            }
-                            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) first = (uint32_t)j;
-                        }
-                        np += (uint64_t)first * STREAM_CHUNK;
-                        if (first < 4u) break;
+            uint32_t T = 0, own_t = 0;
+            // the chunk's survivors into the ring; true: there are none
+            auto chunk_body = [&]() -> bool {
+                uint32_t bad = 0;
+                const uint32_t cw0 = ascii16_to_word(q0, bad, ct), cw1 = ascii16_to_word(q1, bad, ct);
+                // record starts among the lane's 32 positions (multi-record genomes: contigs, reads)
+                uint32_t rb = 0;
+                if (breaks && at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
+                // nothing deleted in an owned chunk (and no record start waiting for a survivor): every base goes to the ring as it is,
+                // and a record start stays on its own base
+                const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we && !pend;
+                if (chunk_clean) {
+                    // 2 048 survivors, all owned: lane i's 32 bases go to ring position have + 32 i, one shift for all
+                    const uint32_t rel = have + 32u * lane, sh = 2u * (rel & 15u);
+                    uint32_t w = head_w + (rel >> 4); w = w >= RING_W ? w - RING_W : w;
+                    const uint32_t w1 = w + 1u == RING_W ? 0u : w + 1u, w2 = w1 + 1u == RING_W ? 0u : w1 + 1u;
+                    if (sh) {
+                        lds_or(stage_b + 4u * w, cw0 >> sh);
+                        lds_or(stage_b + 4u * w1, (cw0 << (32u - sh)) | (cw1 >> sh));
+                        lds_or(stage_b + 4u * w2, cw1 << (32u - sh));
+                    } else {
+                        lds_or(stage_b + 4u * w, cw0);
+                        lds_or(stage_b + 4u * w1, cw1);
                     }
-                    if (np != pos + STREAM_CHUNK) { pos = np - STREAM_CHUNK; chunk_load(np, n0, n1); }
+                    if (breaks && __builtin_amdgcn_ballot_w64(rb != 0u) != 0ull && rb) {   // (reads: a dozen record starts per chunk)
+                        uint32_t bw = (head_w >> 1) + (rel >> 5); bw = bw >= RING_BW ? bw - RING_BW : bw;
+                        const uint32_t bwn = bw + 1u == RING_BW ? 0u : bw + 1u, bs = rel & 31u;
+                        lds_or(brk_b + 4u * bw, rb << bs);
+                        if (bs) lds_or(brk_b + 4u * bwn, rb >> (32u - bs));
+                    }
+                    T = STREAM_CHUNK; own_t = STREAM_CHUNK;
+                } else {
+                uint32_t v;
+                if (!hop_known && __builtin_amdgcn_ballot_w64((hopeless_bits(q0) & hopeless_bits(q1) & 0x20202020u) != 0x20202020u) == 0ull) v = 0u;
+                else v = ~(inv16(q0) | (inv16(q1) << 16));                         // bit j: byte j survives (bytes past L are 'N')
+                const uint32_t own_n = at >= we ? 0u : (we - at >= 32 ? 32u : (uint32_t)(we - at));
+                const uint32_t ownmask = own_n >= 32u ? 0xFFFFFFFFu : ((1u << own_n) - 1u);
+                // ---- record starts land on the first survivor at or after them (cf. dense_tile); one that lands BEYOND the part ends it ----
+                uint32_t recv = 0;
+                if (breaks) {
+                    const uint32_t fill = ~v, rbd = rb & fill;
+                    const bool gen = fill + rbd < rbd;
+                    const uint64_t G = __builtin_amdgcn_ballot_w64(gen), Z = __builtin_amdgcn_ballot_w64(v == 0u);
+                    const uint64_t below = (1ull << lane) - 1ull, nz = ~Z & below;
+                    const uint64_t from = nz ? ~((1ull << (63 - __builtin_clzll(nz))) - 1ull) : ~0ull;
+                    const bool pend_in = (G & below & from) != 0ull || (nz == 0ull && pend);
+                    recv = ((fill + rbd + (pend_in ? 1u : 0u)) | rb) & v;
+                    const uint64_t nzall = ~Z;
+                    pend = nzall ? (G >> (63 - __builtin_clzll(nzall))) != 0ull : (pend || G != 0ull);
+                    const uint32_t cut = recv & ~ownmask;                             // the next record opens here, past this wave's part
+                    const uint64_t Cm = __builtin_amdgcn_ballot_w64(cut != 0u);
+                    if (Cm) {
+                        const uint32_t fl = (uint32_t)__builtin_ctzll(Cm);
+                        if (lane > fl) v &= ownmask;
+                        else if (lane == fl) v &= ownmask | ((1u << __builtin_ctz(cut)) - 1u);
+                        stop = true;
+                    }
                 }
+                const uint32_t n_all = (uint32_t)__builtin_popcount(v);
+                const uint32_t off = wave_excl_scan(n_all, T);
+                if (T == 0u) return true;                                          // nothing survives in this chunk
+                own_t = pos + STREAM_CHUNK <= we ? T : (pos >= we ? 0u : wave_sum((uint32_t)__builtin_popcount(v & ownmask)));
+                // ---- append: two 16-byte groups per lane at ring position have + off ----
+                {
+                    uint32_t rel = have + off;
+                    // every lane's survivors one run of neighbours per group (soft-masked blocks, gap edges)?  Then compaction is a shift
+                    const bool runs = __builtin_amdgcn_ballot_w64(!(is_run16(v & 0xFFFFu) && is_run16(v >> 16))) == 0ull;
+    #pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const uint32_t m = (v >> (16 * c)) & 0xFFFFu;
+                        uint32_t cb;
+                        const uint32_t bits = runs ? compact16_run(c ? cw1 : cw0, m, (recv >> (16 * c)) & 0xFFFFu, cb)
+                                                   : compact16(c ? cw1 : cw0, m, (recv >> (16 * c)) & 0xFFFFu, cb);
+                        const uint32_t n = (uint32_t)__builtin_popcount(m);
+                        if (n) {
+                            uint32_t w = head_w + (rel >> 4); w = w >= RING_W ? w - RING_W : w;
+                            const uint32_t wn = w + 1u == RING_W ? 0u : w + 1u, sh = 2u * (rel & 15u);
+                            lds_or(stage_b + 4u * w, bits >> sh);
+                            if (sh && (rel & 15u) + n > 16u) lds_or(stage_b + 4u * wn, bits << (32u - sh));
+                            if (breaks && cb) {
+                                uint32_t bw = (head_w >> 1) + (rel >> 5); bw = bw >= RING_BW ? bw - RING_BW : bw;
+                                const uint32_t bwn = bw + 1u == RING_BW ? 0u : bw + 1u, bs = rel & 31u;
+                                lds_or(brk_b + 4u * bw, cb << bs);
+                                if (bs && bs + n > 32u) lds_or(brk_b + 4u * bwn, cb >> (32u - bs));
+                            }
+                        }
+                        rel += n;
+                    }
+                }
+                }
+                return false;
+            };
+            if (!gap) gap = chunk_body();
+            if (gap) {
+                was_gap = true;
+                gap_skip(pos);
                 continue;
             }
-            own_t = pos + STREAM_CHUNK <= we ? T : (pos >= we ? 0u : wave_sum((uint32_t)__builtin_popcount(v & ownmask)));
-            // ---- append: two 16-byte groups per lane at ring position have + off ----
-            {
-                uint32_t rel = have + off;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const uint32_t m = (v >> (16 * c)) & 0xFFFFu;
-                    uint32_t cb;
-                    const uint32_t bits = compact16(c ? cw1 : cw0, m, (recv >> (16 * c)) & 0xFFFFu, cb);
-                    const uint32_t n = (uint32_t)__builtin_popcount(m);
-                    if (n) {
-                        uint32_t w = head_w + (rel >> 4); w = w >= RING_W ? w - RING_W : w;
-                        const uint32_t wn = w + 1u == RING_W ? 0u : w + 1u, sh = 2u * (rel & 15u);
-                        lds_or(stage_b + 4u * w, bits >> sh);
-                        if (sh && (rel & 15u) + n > 16u) lds_or(stage_b + 4u * wn, bits << (32u - sh));
-                        if (breaks && cb) {
-                            uint32_t bw = (head_w >> 1) + (rel >> 5); bw = bw >= RING_BW ? bw - RING_BW : bw;
-                            const uint32_t bwn = bw + 1u == RING_BW ? 0u : bw + 1u, bs = rel & 31u;
-                            lds_or(brk_b + 4u * bw, cb << bs);
-                            if (bs && bs + n > 32u) lds_or(brk_b + 4u * bwn, cb >> (32u - bs));
-                        }
-                    }
-                    rel += n;
-                }
-            }
-            }
+            was_gap = false;
             have += T; own_left += own_t; own_seen += own_t; la_have += T - own_t;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             while (have >= STREAM_BATCH + want && own_left > 0u) {

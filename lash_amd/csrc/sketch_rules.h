@@ -1181,6 +1181,22 @@ __device__ __forceinline__ uint32_t compact16(uint32_t codes, uint32_t m, uint32
     return bits;
 }
 
+// The same when the survivors of the 16 bytes are ONE RUN of neighbours (m = 0..01..10..0 — the edge of a soft-masked block, of a
+// gap, of the wave's part; m = 0 counts): the compaction is a shift.  compact16's loop runs once per survivor for the whole wave as
+// soon as one lane has a partial mask — 120 instructions for the one lane that holds a block's edge (round 5).
+__device__ __forceinline__ bool is_run16(uint32_t m)
+{
+    const uint32_t t = m | (m - 1u);                                       // everything below the lowest survivor filled in
+    return (t & (t + 1u)) == 0u;                                           // 0..01..1 (m = 0: all ones)
+}
+__device__ __forceinline__ uint32_t compact16_run(uint32_t codes, uint32_t m, uint32_t recv, uint32_t &cb)
+{
+    const uint32_t n = (uint32_t)__builtin_popcount(m);
+    const uint32_t a = m ? (uint32_t)__builtin_ctz(m) : 0u;
+    cb = recv >> a;                                                         // (recv holds survivors only: nothing beyond the run)
+    return n ? (codes << (2u * a)) & (0xFFFFFFFFu << (32u - 2u * n)) : 0u;
+}
+
 // `n` compacted bases (`bits`, first in 31:30) and their break bits to stream position s of the wave's staging area (LDS byte address)
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ void lds_or(uint32_t byte_addr, uint32_t v) { asm volatile("ds_or_b32 %0, %1" ::"v"(byte_addr), "v"(v) : "memory"); }

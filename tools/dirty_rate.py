@@ -27,12 +27,26 @@ def main():
     d_img = torch.zeros(G * lash_amd.image_bytes("hmh"), dtype=torch.uint8, device=dev)
     cases = [("clean", 0, 0)] + [("B=%d lower %d%%" % (B, int(100 * lo / (2 * B))), B, lo)
                                   for B, lo in ((500, 500), (2_500, 2_500), (10_000, 10_000), (100_000, 100_000), (2_500_000, 2_500_000),
-                                                (10_000, 2_000), (10_000, 18_000), (500, 100))] + [("all lower", -1, 0)]
+                                                (10_000, 2_000), (10_000, 18_000), (500, 100),
+                                                # block edges at arbitrary byte positions (the ones above all fall on multiples of 4 or 16 bytes)
+                                                (10_007, 10_007), (2_503, 2_503), (509, 509))] + \
+            [("random blocks 30..30000 B", -2, 0), ("all lower", -1, 0)]
     for name, B, lo in cases:
         d_seq.copy_(clean)
         v = d_seq.view(G, L)
         if B == -1:
             d_seq |= 0x20
+        elif B == -2:
+            # a RepeatMasker-like mask: alternating upper / lower runs of log-uniform length, the same for every genome
+            rng = np.random.default_rng(5)
+            edges = np.cumsum(np.exp(rng.uniform(np.log(30), np.log(30000), size=4 * L // 3000)).astype(np.int64))
+            edges = edges[edges < L]
+            lower = np.zeros(L + 1, np.int8)
+            lower[edges[0::2]] += 1
+            lower[edges[1::2]] -= 1
+            mask = torch.from_numpy(np.cumsum(lower[:L]).astype(np.bool_)).to(dev)
+            v[:, mask] |= 0x20
+            del mask
         elif B:
             per = 2 * B
             pos = torch.arange(L, device=dev) % per
