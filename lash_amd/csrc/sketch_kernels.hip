@@ -575,6 +575,12 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
         for (uint64_t pos = ws; pos < L && !stop; pos += STREAM_CHUNK) {
             if (pos >= we && (own_left == 0u || la_have >= want)) break;    // nothing owned waits for more bases
             const uint64_t at = pos + 32ull * lane;
+            // record starts among the lane's 32 positions (multi-record genomes: contigs, reads).  The bitmap word is asked for BEFORE the
+            // next chunk's bytes: outstanding loads retire in order, so whoever waits for a load waits for every load issued before it —
+            // with this one behind the prefetch, hipcc's wait for its register sat at the top of the hash loop as vmcnt(0) (also for
+            // genomes without record starts: the register is overwritten there) and the prefetch never overlapped the hashing
+            uint32_t rb = 0;
+            if (breaks && at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
             uint4 q0 = n0, q1 = n1;
             chunk_load(pos + STREAM_CHUNK, n0, n1);
             if (at + 32 > L) {
@@ -597,9 +603,6 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
             auto chunk_body = [&]() -> bool {
                 uint32_t bad = 0;
                 const uint32_t cw0 = ascii16_to_word(q0, bad, ct), cw1 = ascii16_to_word(q1, bad, ct);
-                // record starts among the lane's 32 positions (multi-record genomes: contigs, reads)
-                uint32_t rb = 0;
-                if (breaks && at < L) rb = RL ? uniform_breaks((uint32_t)at, RL, 32u).b0 : bk[at >> 5];
                 // nothing deleted in an owned chunk (and no record start waiting for a survivor): every base goes to the ring as it is,
                 // and a record start stays on its own base
                 const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we && !pend;
