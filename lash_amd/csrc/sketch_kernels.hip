@@ -605,7 +605,8 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
                 const uint32_t cw0 = ascii16_to_word(q0, bad, ct), cw1 = ascii16_to_word(q1, bad, ct);
                 // nothing deleted in an owned chunk (and no record start waiting for a survivor): every base goes to the ring as it is,
                 // and a record start stays on its own base
-                const bool chunk_clean = __builtin_amdgcn_ballot_w64(bad != 0u) == 0ull && pos + STREAM_CHUNK <= we && !pend;
+                const uint64_t badm = __builtin_amdgcn_ballot_w64(bad != 0u);      // lanes that hold a deleted byte
+                const bool chunk_clean = badm == 0ull && pos + STREAM_CHUNK <= we && !pend;
                 if (chunk_clean) {
                     // 2 048 survivors, all owned: lane i's 32 bases go to ring position have + 32 i, one shift for all
                     const uint32_t rel = have + 32u * lane, sh = 2u * (rel & 15u);
@@ -628,8 +629,9 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
                     T = STREAM_CHUNK; own_t = STREAM_CHUNK;
                 } else {
                 uint32_t v;
-                if (!hop_known && __builtin_amdgcn_ballot_w64((hopeless_bits(q0) & hopeless_bits(q1) & 0x20202020u) != 0x20202020u) == 0ull) v = 0u;
-                else v = ~(inv16(q0) | (inv16(q1) << 16));                         // bit j: byte j survives (bytes past L are 'N')
+                // (a lane without a deleted byte answers the question for the chunk: only when every lane has one is it worth asking)
+                if (!hop_known && badm == ~0ull && __builtin_amdgcn_ballot_w64((hopeless_bits(q0) & hopeless_bits(q1) & 0x20202020u) != 0x20202020u) == 0ull) v = 0u;
+                else v = ~(inv16s(q0) | (inv16s(q1) << 16));                       // bit j: byte j survives (bytes past L are 'N')
                 const uint32_t own_n = at >= we ? 0u : (we - at >= 32 ? 32u : (uint32_t)(we - at));
                 const uint32_t ownmask = own_n >= 32u ? 0xFFFFFFFFu : ((1u << own_n) - 1u);
                 // ---- record starts land on the first survivor at or after them (cf. dense_tile); one that lands BEYOND the part ends it ----

@@ -367,7 +367,7 @@ enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_BINS = 2, REGS_BYTES = 3 };
 // ------------------------------------------------------------------------------------------------------------
 template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs, bool HLL_HIGH = false, bool VSH = false>
 __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, uint32_t c_hi, uint32_t vm,
-                                             BitFlip bitflip, int p, uint32_t ull_sh28 = 0, uint32_t ull_sh29 = 0)
+                                             BitFlip bitflip, int p, uint32_t ull_sh28 = 0)
 {
     if constexpr (ALGO == 0) {
         // utils.rs:395-398: Sketch::add_bytes_with_seed(&(masked as u32).to_le_bytes(), seed)
@@ -460,7 +460,8 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             // same bits of g >> 28, i.e. of the high word shifted right by 28 - p (p <= 26); the index sits above the xorshift's reach
             const uint64_t g = xxh3_64_8b_pre(c_lo, c_hi, bitflip);
             hh = (uint32_t)(g >> 32); hl = (uint32_t)g;
-            th = alignbit(hh, hl, 32 - p) ^ (hh >> (VSH ? ull_sh28 : (uint32_t)(28 - p)));   // (VSH: the amounts sit in vector registers, KParams)
+            const uint32_t t28 = hh >> (VSH ? ull_sh28 : (uint32_t)(28 - p));   // (VSH: the amount sits in a vector register, KParams)
+            th = alignbit(hh, hl, 32 - p) ^ t28;
             // th != 0 -> nlz = v_ffbh(th) < 32: always the pair's first word; th == 0 -> push nothing (re-run by the caller)
             if constexpr (Regs::BINS || Regs::BYTES) {
                 uint32_t nlz = ffbh_u32(th);                                     // th == 0 -> all ones -> 63 = nothing
@@ -472,7 +473,9 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             uint32_t one;
             if constexpr (MASKED) asm("v_min3_u32 %0, %1, 1, %2" : "=v"(one) : "v"(th), "v"(vm));   // th == 0 or an invalid k-mer: nothing
             else one = th < 1u ? th : 1u;
-            if constexpr (VSH && std::is_same<Regs, LdsRegs>::value) regs.bor_b((hh >> ull_sh29) & ~7u, one << (ffbh_u32(th) & 31u));
+            // the register's byte address (hh >> (29 - p)) & ~7 from the same shifted word: ONE amount lives in a vector register (two
+            // cost the reads kernel a register it did not have: 9 -> 13 scratch instructions, one reload per tile)
+            if constexpr (VSH && std::is_same<Regs, LdsRegs>::value) regs.bor_b((t28 >> 1) & ~7u, one << (ffbh_u32(th) & 31u));
             else regs.bor_first(hh, p, one << (ffbh_u32(th) & 31u));
             return th;
         } else {
@@ -569,8 +572,8 @@ struct KParams {
     uint32_t mask_lt;      // KM_LT16: low 2k bits          with a scalar source issues in 4.4 cycles, with two vector sources in 2.6-2.9)
     uint32_t mask_hi;      // KM_GT16: bits 63:32 of mask_gt (its low word is all ones: 2k > 32)
     uint32_t sh_gt;        // KM_GT16: 64 - 2k
-    uint32_t ull_sh28 = 0, ull_sh29 = 0;   // UltraLogLog fast form: 28 - p and 29 - p as VECTOR registers (round 5: `v_lshrrev_b32 v, s, v` issues in
-                           // 4.42 cycles, `v, v, v` in 2.75 — two of them per k-mer; 0 = not set, the rule takes p as it comes)
+    uint32_t ull_sh28 = 0; // UltraLogLog fast form: 28 - p as a VECTOR register (round 5: `v_lshrrev_b32 v, s, v` issues in 4.42 cycles,
+                           // `v, v, v` in 2.75; the second shift of the rule, by 29 - p, is taken from the first's result)
     int p;
     // per-kernel constants of VOP2 instructions as vector registers (see BitFlip, lash_device.h)
     __device__ __forceinline__ void to_vector_registers()
@@ -582,9 +585,8 @@ struct KParams {
         asm volatile("v_mov_b32 %0, %1" : "=v"(mask_lt) : "s"(mask_lt));
         asm volatile("v_mov_b32 %0, %1" : "=v"(mask_hi) : "s"(mask_hi));
         if (p <= 26) {
-            ull_sh28 = 28u - (uint32_t)p; ull_sh29 = 29u - (uint32_t)p;
+            ull_sh28 = 28u - (uint32_t)p;
             asm volatile("v_mov_b32 %0, %1" : "=v"(ull_sh28) : "s"(ull_sh28));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(ull_sh29) : "s"(ull_sh29));
         }
     }
 };
@@ -649,7 +651,7 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
             if constexpr (ALT) { fwd ^= (uint32_t)kp.lsb_xor; rc ^= (uint32_t)kp.lsb_xor; }   // min() is symmetric: no swap needed
             can_lo = fwd < rc ? fwd : rc;                                        // utils.rs:470,482
         }
-        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, HLL_HIGH, !ALT>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28, kp.ull_sh29);
+        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, HLL_HIGH, !ALT>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28);
         zacc = zacc < t ? zacc : t;
         if constexpr (Regs::QUEUED) { if ((r & 3) == 3) regs.check(); }        // (LdsByteQRegs: is some lane's stack full?)
     }
@@ -678,7 +680,7 @@ __device__ __forceinline__ uint32_t process_quarter(const Regs &regs, const KPar
             if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
             can_lo = fwd < rc ? fwd : rc;
         }
-        const uint32_t t = add_kmer<ALGO, XLOW, true, FAST, Regs, false, true>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28, kp.ull_sh29);
+        const uint32_t t = add_kmer<ALGO, XLOW, true, FAST, Regs, false, true>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28);
         zacc = zacc < t ? zacc : t;
     }
     return zacc;
@@ -1014,6 +1016,16 @@ __device__ __forceinline__ uint32_t inv4(uint32_t x)            // bit j: byte j
     return ((((nz >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
 }
 __device__ __forceinline__ uint32_t inv16(const uint4 q) { return inv4(q.x) | (inv4(q.y) << 4) | (inv4(q.z) << 8) | (inv4(q.w) << 12); }
+// The same in 8 instructions per word instead of 11 (stream_sketch_kernel, round 5; the kernels above keep the form their register
+// allocation was tuned with — tests/test_kernel_budget.py): bit 7 of every byte says "that byte of z is not zero", and ONE multiply
+// gathers the four flags (7+21, 15+14, 23+7, 31+0 = bits 28..31; every other partial product lands on a bit of its own below them)
+__device__ __forceinline__ uint32_t inv4s(uint32_t x)
+{
+    const uint32_t z = x ^ __builtin_amdgcn_perm(0x47FFFF54u, 0x43FF41FFu, x & 0x07070707u);
+    const uint32_t nz = __builtin_amdgcn_bitop3_b32((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu, z, 0x80808080u, 0xA8);   // (a | b) & c
+    return (nz * 0x00204081u) >> 28;
+}
+__device__ __forceinline__ uint32_t inv16s(const uint4 q) { return inv4s(q.x) | (inv4s(q.y) << 4) | (inv4s(q.z) << 8) | (inv4s(q.w) << 12); }
 
 struct InvMask { uint64_t lo; uint32_t hi; };                  // deleted bytes among the lane's 96: own 64 + look-ahead 32
 // re-reads the lane's bytes (L1 / L2 hits: they were loaded a moment ago) so that the fast path keeps no raw bytes alive
