@@ -429,7 +429,8 @@ def cli_bench(args):
             names.append(os.path.join(d, "g%d.fa" % g))
         open(os.path.join(d, "list.txt"), "w").write("\n".join(names) + "\n")
         text_bytes = G * (L + L // 80 + len(">g0\n"))
-        threads = min(64, max(4, (os.cpu_count() or 8)))
+        from lash_amd.shard import effective_cores            # (the cgroup's CPU quota, not the host's 256 logical CPUs: 64 reader threads on a
+        threads = min(64, max(4, 2 * effective_cores()))      #  16-CPU quota cost a collection of small files a third of its rate)
         cmd = [exe, "sketch", "-f", os.path.join(d, "list.txt"), "-o", os.path.join(d, "out"), "-k", str(k), "-a", algo, "-t", str(threads)]
         if algo != "hmh":
             cmd += ["-p", str(p)]

@@ -546,15 +546,34 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             }
         };
         const uint64_t stream_bytes = std::min<uint64_t>(std::max<uint64_t>(opt.stream_bytes, 1u << 16), 0xF0000000ull);
-        for (size_t i = 0; i < n_files && err.empty(); ++i) {
-            std::string e;
-            uint64_t sz = 0;
-            const bool comp = peek_compressed(files[i], sz, e);
-            if (!e.empty()) { err = e; break; }
-            slots[i].compressed = comp;
-            slots[i].big = comp ? sz > stream_bytes / 3 : sz > stream_bytes;
-            if (slots[i].big) { slots[i].compressed = false; slots[i].size = 0; slots[i].sized = true; }   // handled by the planner itself
-            else if (!comp) { slots[i].size = sz; slots[i].sized = true; }
+        {
+            // size and kind of every file, on the pool's threads in ranges of 512 (a collection of 100 000 viral genomes spent 0.25 s
+            // in this loop on one thread — as long as the GPU needs for all of them a hundred times over); the first error in FILE
+            // order is the one reported, as the sequential loop did
+            const size_t R = 512, n_ranges = (n_files + R - 1) / R;
+            std::vector<std::string> range_err(n_ranges);
+            std::mutex pmu;
+            std::condition_variable pcv;
+            size_t pending = n_ranges;
+            for (size_t r = 0; r < n_ranges; ++r) {
+                pool.submit([&, r]() {
+                    for (size_t i = r * R; i < std::min(n_files, (r + 1) * R); ++i) {
+                        std::string e;
+                        uint64_t sz = 0;
+                        const bool comp = peek_compressed(files[i], sz, e);
+                        if (!e.empty()) { range_err[r] = e; break; }
+                        slots[i].compressed = comp;
+                        slots[i].big = comp ? sz > stream_bytes / 3 : sz > stream_bytes;
+                        if (slots[i].big) { slots[i].compressed = false; slots[i].size = 0; slots[i].sized = true; }   // handled by the planner itself
+                        else if (!comp) { slots[i].size = sz; slots[i].sized = true; }
+                    }
+                    std::lock_guard<std::mutex> lk(pmu);
+                    if (--pending == 0) pcv.notify_all();
+                });
+            }
+            std::unique_lock<std::mutex> lk(pmu);
+            pcv.wait(lk, [&] { return pending == 0; });
+            for (size_t r = 0; r < n_ranges && err.empty(); ++r) err = range_err[r];
         }
         lash_ctx *stream_ctx = nullptr;
         PinnedBuf stream_buf, stream_buf2;          // the streamer's two chunk buffers, kept across files (pinning costs 0.2 s per GiB)
@@ -575,8 +594,14 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
             cur->fmt.assign(cur->f1 - cur->f0, 0);
             cur->remaining = cur->f1 - cur->f0;
             std::shared_ptr<Batch> b = cur;
-            for (size_t i = b->f0; i < b->f1; ++i) {
-                pool.submit([&, b, i]() {
+            // one task per run of files of about 1 MiB (at most 256 files): a task per 10 kB file is 2 us of work behind a queue that
+            // sixteen threads share — 6 250 files of a batch took 32 ms to read, 80 us per file and thread
+            for (size_t g0 = b->f0; g0 < b->f1;) {
+                size_t g1 = g0 + 1;
+                uint64_t run = slots[g0].size;
+                while (g1 < b->f1 && g1 - g0 < 256 && run + slots[g1].size <= (1u << 20)) run += slots[g1++].size;
+                pool.submit([&, b, g0, g1]() {
+                  for (size_t i = g0; i < g1; ++i) {
                     FileSlot &s = slots[i];
                     uint8_t *dst = b->buf->p ? b->buf->p + b->file_off[i - b->f0] : nullptr;
                     std::string e = s.err;
@@ -605,7 +630,9 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
                         todo.push_back(b);
                         cv_todo.notify_one();
                     }
+                  }
                 });
+                g0 = g1;
             }
             cur.reset();
         };

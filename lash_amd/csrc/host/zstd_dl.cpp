@@ -2,8 +2,11 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 namespace lashhost {
 namespace {
@@ -19,6 +22,8 @@ struct Api {
     size_t (*compressStream)(void *, OutBuf *, InBuf *) = nullptr;
     size_t (*endStream)(void *, OutBuf *) = nullptr;
     size_t (*CCtx_setParameter)(void *, int, int) = nullptr;
+    size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
+    size_t (*compressBound)(size_t) = nullptr;
     void *(*createDStream)() = nullptr;
     size_t (*freeDStream)(void *) = nullptr;
     size_t (*initDStream)(void *) = nullptr;
@@ -46,6 +51,8 @@ Api &api()
         a.compressStream = (size_t(*)(void *, OutBuf *, InBuf *))sym("ZSTD_compressStream");
         a.endStream = (size_t(*)(void *, OutBuf *))sym("ZSTD_endStream");
         a.CCtx_setParameter = (size_t(*)(void *, int, int))sym("ZSTD_CCtx_setParameter");
+        a.compress = (size_t(*)(void *, size_t, const void *, size_t, int))sym("ZSTD_compress");
+        a.compressBound = (size_t(*)(size_t))sym("ZSTD_compressBound");
         a.createDStream = (void *(*)())sym("ZSTD_createDStream");
         a.freeDStream = (size_t(*)(void *))sym("ZSTD_freeDStream");
         a.initDStream = (size_t(*)(void *))sym("ZSTD_initDStream");
@@ -93,15 +100,70 @@ std::string ZstdWriter::open(const std::string &path, int level, int workers)
     if (!cstream_) return "ZSTD_createCStream failed";
     size_t rc = a.initCStream(cstream_, level);
     if (a.isError(rc)) return zerr(rc);
-    // ZSTD_c_nbWorkers = 400; fails harmlessly when the library was built without multithreading
-    if (workers > 1 && a.CCtx_setParameter) (void)a.CCtx_setParameter(cstream_, 400, workers);
+    // ZSTD_c_nbWorkers = 400; an error when the library was built without multithreading: then frames from our own threads
+    level_ = level;
+    workers_ = std::max(1, std::min(workers, 16));          // (a round of the threads is workers x 4 MiB of images: 64 MiB at most)
+    bool mt = false;
+    if (workers > 1 && a.CCtx_setParameter) mt = !a.isError(a.CCtx_setParameter(cstream_, 400, workers));
+    if (getenv("LASH_ZSTD_ONE_THREAD")) { mt = true; workers_ = 1; }    // (A/B and tests: the plain single-frame path)
+    frames_ = !mt && workers_ > 1 && a.compress && a.compressBound;
     out_.resize(1 << 20);
+    return "";
+}
+
+// p[0 .. (n_chunks - 1) * kChunk + last_bytes) as n_chunks frames, compressed by up to workers_ threads, written in order
+std::string ZstdWriter::frames(const uint8_t *p, size_t n_chunks, size_t last_bytes)
+{
+    Api &a = api();
+    std::vector<std::vector<uint8_t>> outs(n_chunks);
+    std::vector<size_t> sizes(n_chunks, 0);
+    std::string err;
+    std::mutex em;
+    const size_t T = std::min<size_t>((size_t)workers_, n_chunks);
+    auto work = [&](size_t t) {
+        for (size_t i = t; i < n_chunks; i += T) {
+            const size_t n = i + 1 == n_chunks ? last_bytes : kChunk;
+            outs[i].resize(a.compressBound(n));
+            const size_t rc = a.compress(outs[i].data(), outs[i].size(), p + i * kChunk, n, level_);
+            if (a.isError(rc)) { std::lock_guard<std::mutex> g(em); if (err.empty()) err = zerr(rc); return; }
+            sizes[i] = rc;
+        }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (!err.empty()) return err;
+    for (size_t i = 0; i < n_chunks; ++i)
+        if (fwrite(outs[i].data(), 1, sizes[i], f_) != sizes[i]) return "short write";
+    wrote_frame_ = wrote_frame_ || n_chunks > 0;
     return "";
 }
 
 std::string ZstdWriter::write(const void *data, size_t n)
 {
     Api &a = api();
+    if (frames_) {
+        const uint8_t *p = static_cast<const uint8_t *>(data);
+        const size_t round = (size_t)workers_ * kChunk;                 // one round of the threads
+        if (!pend_.empty() || n < round) {
+            // small writes (a batch of a dozen 5 Mbp genomes is 400 KB of images) gather until every thread has a piece
+            const size_t take = std::min(n, round - std::min(round, pend_.size()));
+            pend_.insert(pend_.end(), p, p + take);
+            p += take; n -= take;
+            if (pend_.size() < round) return "";
+            std::string e = frames(pend_.data(), pend_.size() / kChunk, kChunk);
+            pend_.clear();
+            if (!e.empty()) return e;
+        }
+        const size_t full = n / kChunk;                                 // large writes straight from the caller's buffer
+        if (full) {
+            std::string e = frames(p, full, kChunk);
+            if (!e.empty()) return e;
+        }
+        pend_.insert(pend_.end(), p + full * kChunk, p + n);
+        return "";
+    }
     InBuf in{data, n, 0};
     while (in.pos < in.size) {
         OutBuf ob{out_.data(), out_.size(), 0};
@@ -115,6 +177,21 @@ std::string ZstdWriter::write(const void *data, size_t n)
 std::string ZstdWriter::finish()
 {
     Api &a = api();
+    if (frames_) {
+        // what is left — and for an empty stream ONE empty frame: the file must be a zstd stream
+        if (!pend_.empty() || !wrote_frame_) {
+            const size_t nc = std::max<size_t>(1, (pend_.size() + kChunk - 1) / kChunk);
+            const size_t last = pend_.size() - (nc - 1) * kChunk;
+            std::string e = frames(pend_.data(), nc, last);
+            pend_.clear();
+            if (!e.empty()) return e;
+        }
+        a.freeCStream(cstream_);
+        cstream_ = nullptr;
+        int e = fclose(f_);
+        f_ = nullptr;
+        return e ? "close failed" : "";
+    }
     for (;;) {
         OutBuf ob{out_.data(), out_.size(), 0};
         size_t rc = a.endStream(cstream_, &ob);

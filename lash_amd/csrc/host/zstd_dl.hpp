@@ -11,7 +11,11 @@ namespace lashhost {
 
 bool zstd_available(std::string *why = nullptr);
 
-// Streaming compressor writing to a FILE*: one zstd frame, level `level`, `workers` zstdmt workers if supported.
+// Streaming compressor writing to a FILE*, level `level`.  With a libzstd built for multithreading: ONE frame, `workers` zstdmt workers
+// (what the reference's `encoder.multithread(threads)` does, utils.rs:568-569).  With one that is not (this image's 1.4.8 refuses
+// ZSTD_c_nbWorkers): the stream is cut into 4 MiB pieces which `workers` threads compress as independent FRAMES, written in order — a
+// concatenation of frames is a valid zstd stream (RFC 8878 section 3; the `zstd` crate's Decoder reads on into the next frame unless
+// `single_frame()` is asked for), the decompressed bytes are the same.  100 000 HyperMinHash images (3.3 GB) took 14 s on one thread.
 class ZstdWriter {
 public:
     ZstdWriter();
@@ -20,9 +24,15 @@ public:
     std::string write(const void *data, size_t n);
     std::string finish();                       // ends the frame and closes the file
 private:
+    std::string frames(const uint8_t *p, size_t n_chunks, size_t last_bytes);   // chunks of kChunk bytes (the last: last_bytes) -> frames
+    static constexpr size_t kChunk = 4u << 20;
     void *cstream_ = nullptr;
     FILE *f_ = nullptr;
     std::vector<uint8_t> out_;
+    bool frames_ = false;                       // independent frames from `workers_` threads
+    int workers_ = 1, level_ = 3;
+    bool wrote_frame_ = false;
+    std::vector<uint8_t> pend_;                 // frames_: bytes not yet compressed (< workers_ * kChunk)
 };
 
 // incremental decoder over a FILE* (for ByteStream)

@@ -113,6 +113,28 @@ def test_zstd_stream_roundtrip_and_interop(tmp_path):
     assert pa.decompress(raw, decompressed_size=len(data), codec="zstd").to_pybytes() == data
 
 
+def test_zstd_frames_from_several_threads(tmp_path):
+    """A libzstd without multithreading (this image's): the writer cuts the stream into 4 MiB pieces that its threads compress as
+    independent frames (zstd_dl.hpp).  The file is a concatenation of frames — what any zstd decoder reads as one stream; the bytes that
+    come out are the bytes that went in, for streams of no, one and a few bytes, of exactly one piece, of exactly one round of the threads, and beyond."""
+    rng = np.random.default_rng(4)
+    big = (rng.integers(0, 16, size=37_000_001, dtype=np.uint8)).tobytes()
+    for data in (b"", b"x", big[:(4 << 20)], big[:(16 << 20)], big[:(16 << 20) + 1], big):
+        p = str(tmp_path / "y.bin")
+        H.zstd_write(p, data, level=3, workers=4)
+        assert H.zstd_read(p) == data
+        raw = open(p, "rb").read()
+        assert raw[:4] == b"\x28\xb5\x2f\xfd"
+        if len(data) > (16 << 20):
+            assert raw.count(b"\x28\xb5\x2f\xfd") >= 4           # several frames
+        try:
+            import pyarrow as pa
+        except Exception:
+            continue
+        if data:
+            assert pa.decompress(raw, decompressed_size=len(data), codec="zstd").to_pybytes() == data
+
+
 def test_cli_without_gpu_fails_loudly(tmp_path):
     import lash_amd
     if lash_amd.load().lash_device_count() > 0:
