@@ -167,3 +167,48 @@ def test_cli_stops_at_malformed_fastq_records_like_needletail(tmp_path):
         want = O.sketch_files(O.HMH, 16, 0, 42, [files["no_plus.fq"], files["ok.fq"], files["blank_line.fq"]], layout=O.make_layout(fastq_err="skip"))
         assert np.array_equal(got, want)
         assert ctx.format_errors() == [0, 2]
+
+
+def test_many_small_files_and_a_multi_frame_sketch_file(tmp_path):
+    """A collection of small genomes (one file each): the persistent small-genome kernel behind the raw-file entry, read tasks that cover runs
+    of files, and — with this image's libzstd, which has no multithreading — a sketches.bin made of several zstd frames.  The decompressed
+    bytes equal the oracle's images in list order and the single-thread writer's bytes; `lash dist` reads the multi-frame file."""
+    import random
+    rng = random.Random(9)
+    paths, want = [], []
+    for i in range(420):                                        # 420 x 32 KiB of images: four 4 MiB pieces
+        L = rng.choice([0, 9, 40, 700, 3000, 12000, 30000])
+        seq = O.synth_genome(1000 + i, max(L, 1)).tobytes()[:L]
+        if L > 100 and i % 5 == 0:
+            seq = seq[:L // 2] + b"NNNnnacgtN" + seq[L // 2:]
+        pth = tmp_path / ("s%d.fa" % i)
+        if i % 3 == 0 and L > 200:                             # two records
+            pth.write_bytes(b">a\n" + seq[:L // 3] + b"\n>b\n" + seq[L // 3:] + b"\n")
+            recs = [seq[:L // 3], seq[L // 3:]]
+        else:
+            pth.write_bytes(b">a desc\n" + b"\n".join(seq[j:j + 60] for j in range(0, len(seq), 60)) + b"\n")
+            recs = [seq]
+        paths.append(str(pth))
+        arr = np.frombuffer(b"".join(recs), np.uint8)
+        off = np.cumsum([0] + [len(x) for x in recs]).astype(np.uint64)
+        want.append(O.sketch_genomes(O.HMH, 16, 0, 42, arr, off, np.array([0, len(recs)], np.uint64))[0].tobytes())
+    lst = tmp_path / "l.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    outs = {}
+    for tag, env in (("frames", {}), ("one", {"LASH_ZSTD_ONE_THREAD": "1"})):
+        out = str(tmp_path / tag)
+        r = subprocess.run([H.CLI, "sketch", "-f", str(lst), "-o", out, "-a", "hmh", "-k", "16", "-s", "42", "-t", "4"], capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        outs[tag] = H.zstd_read(out + "_sketches.bin")
+    assert outs["frames"] == outs["one"] == b"".join(want)
+    raw = open(str(tmp_path / "frames") + "_sketches.bin", "rb").read()
+    if raw.count(b"\x28\xb5\x2f\xfd") < 2:
+        pytest.skip("this libzstd compresses with its own threads: one frame")
+    # `lash dist` on the multi-frame file against the single-frame one: the same table
+    tabs = []
+    for tag in ("frames", "one"):
+        r = subprocess.run([H.CLI, "dist", "-q", tag, "-r", tag, "-o", tag + ".tsv", "-t", "2"], capture_output=True, text=True, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr
+        tabs.append(open(str(tmp_path / (tag + ".tsv"))).read())
+    assert tabs[0] == tabs[1] and tabs[0].count("\n") > 420
