@@ -386,7 +386,11 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
     // out to running workgroups, one that started late would only hold its first chunk back
     uint32_t per_cu = sp.wg_per_cu;
     HIPCHK(ctx, sole_resident_per_cu(sp, prm->algo, prm->k, x_low, packed, &per_cu));
-    const uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)ctx->cu_count * per_cu, n_genomes);
+    uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)ctx->cu_count * per_cu, n_genomes);
+    // (tests and the randomized runners: FEW workgroups, so that a test batch of a hundred genomes walks the paths of a collection of a
+    //  million — several genomes per chunk, one after the other on the same rings and table, the next one's bytes in flight.  Without
+    //  this every genome of a small batch has a workgroup of its own; a stale ring pointer survived round 5's suite that way.)
+    if (const char *e = getenv("LASH_SOLE_WGS")) n_wg = (uint32_t)std::max(1, std::min<int>((int)n_wg, atoi(e)));
     // chunks: a couple of dozen per workgroup, so that the tail of the launch is a few percent of a workgroup's share — but none
     // smaller than ~100 us of a workgroup's time (a chunk starts with a few dependent loads: 3..5 us)
     std::vector<uint32_t> chunk_begin;

@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                     uint32_t N = 0, H = 0, rel = 0;                                         // bases appended; ring words hashed; bytes staged
                     bool whole = false;                                                     // the genome is in the ring to its last base
                     uint32_t limit = 0, nk = 0xFFFFFFFFu;                                   // ring words that may be hashed; k-mer starts (known at the end)
-                    zero_n = 0; bzero = 0;
+                    zero_w = 0; zero_n = 0; bzero = 0;                      // (zero_w too: a stale one made the first pass wipe this genome's early record starts)
                     for (;;) {
                         if (rel < Lb) {
                             // ---- stage one round: 16 bytes per lane -> survivors -> ring ----
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                 const uint32_t *__restrict__ bk = a.brk + gd.brk_off;
                 const uint32_t n_words = (L + 15u) >> 4;
                 uint32_t N = 0, H = 0;
-                zero_n = 0; bzero = 0;
+                zero_w = 0; zero_n = 0; bzero = 0;                      // (zero_w too: a stale one made the first pass wipe this genome's early record starts)
                 for (uint32_t w0 = 0; w0 < n_words; w0 += T) {
                     // the pack stage's stream is what the ring would hold: copy T words (and their break bits) in
                     const uint32_t wi = w0 + tid;

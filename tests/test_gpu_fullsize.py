@@ -320,3 +320,56 @@ def test_config3_full_100k_genomes_all_vs_all(env, tmp_path):
           "cardinalities + operands %.2f, pair blocks incl. copy back %.2f, host rows (lash_dist_rows + text, %d threads) %.2f; %.3e printed pairs"
           % (N, t_sketch, sketch_ms, t_all, stats["gather_s"], stats["prepare_s"], stats["pair_blocks_s"], stats["threads"], stats["host_rows_s"],
              stats["printed_pairs"]))
+
+
+@pytest.mark.sole
+@pytest.mark.parametrize("algo,k,p", [("hmh", 16, 0), ("hll", 21, 10)])
+def test_a_viral_collection_at_full_size(env, algo, k, p, monkeypatch):
+    """Round 5's shape at the size it was measured on (tools/viral_rate.py): 200 000 genomes of 3..300 kbp (log-uniform), 1..4 records each,
+    12.9 GB of ASCII resident — whole through the persistent small-genome kernel (sole_kernels.hip).  Size-independent checks: the k-mer
+    census equals the sum over records of max(0, len - k + 1); the SLICED kernels (LASH_F_NO_SOLE: round 4's route, a different kernel,
+    different planning) give the same bytes for every genome; 240 genomes spread over the collection — among them the smallest, the
+    largest, the first and the last — equal the oracle bit for bit."""
+    ctx, torch, lash_amd = env
+    monkeypatch.setenv("LASH_SOLE_MAX", "393216")
+    G = 200_000 if FULL else 20_000
+    rng = np.random.default_rng(13)
+    lens = np.exp(rng.uniform(np.log(3e3), np.log(3e5), size=G)).astype(np.int64)
+    gbo = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(gbo[-1])
+    nrec = rng.integers(1, 5, size=G)
+    dev = torch.device("cuda", 0)
+    d_seq = torch.empty(total, dtype=torch.uint8, device=dev)
+    ctx.synth_genomes_device(0, 1, total, d_seq)                      # one long synthetic sequence, cut into the genomes
+    # record starts: sorted cut points inside every genome
+    starts = [gbo[:-1].astype(np.int64)]
+    cuts = (rng.random(size=(G, 3)) * (lens[:, None] - 1)).astype(np.int64) + 1 + gbo[:-1, None].astype(np.int64)
+    keep = np.arange(3)[None, :] < (nrec[:, None] - 1)
+    rec_off = np.unique(np.concatenate([starts[0], cuts[keep], [total]])).astype(np.uint64)
+    goff = np.searchsorted(rec_off, gbo).astype(np.uint64)             # first record of every genome (its byte offset IS a record start)
+    n_rec = len(rec_off) - 1
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+    ib = lash_amd.image_bytes(algo, p)
+    d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
+    ctx.enable_timing(True)
+    ctx.sketch_batch_device(algo, k, p, 42, d_seq, d_rec, n_rec, goff, gbo, d_img)
+    ctx.synchronize()
+    t = ctx.timing()
+    ctx.enable_timing(False)
+    rl = np.diff(rec_off.astype(np.int64))
+    assert t["sole_launches"] == 1 and t["kmers"] == int(np.maximum(rl - k + 1, 0).sum()) and t["bases_last"] == total
+    # the other route, every genome
+    d_img2 = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
+    ctx.sketch_batch_device(algo, k, p, 42, d_seq, d_rec, n_rec, goff, gbo, d_img2, flags=lash_amd.F_NO_SOLE)
+    ctx.synchronize()
+    assert torch.equal(d_img, d_img2)
+    del d_img2
+    # the oracle on a spread of genomes
+    pick = sorted(set([0, G - 1, int(np.argmin(lens)), int(np.argmax(lens))] + [int(x) for x in rng.integers(0, G, size=236)]))
+    img = d_img.view(G, ib)
+    algo_id = lash_amd.ALGOS[algo]
+    for g in pick:
+        host = d_seq[int(gbo[g]):int(gbo[g + 1])].cpu().numpy()
+        ro = rec_off[int(goff[g]):int(goff[g + 1]) + 1] - gbo[g]
+        want = O.sketch_genomes(algo_id, k, p, 42, host, ro.astype(np.uint64), np.array([0, len(ro) - 1], np.uint64))[0]
+        assert np.array_equal(img[g].cpu().numpy(), want), (algo, g, int(lens[g]))

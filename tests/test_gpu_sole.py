@@ -17,6 +17,20 @@ from test_gpu_parity import ALGO, messy_genomes
 pytestmark = [pytest.mark.gpu, pytest.mark.sole]
 
 
+@pytest.fixture(autouse=True, params=[None, "1", "3"], ids=["wgs=default", "wgs=1", "wgs=3"])
+def _few_workgroups(request, monkeypatch):
+    """Every test three times: with the launch the library plans (a test batch of a hundred genomes then has a workgroup per genome), and
+    with ONE and THREE workgroups (LASH_SOLE_WGS), so that many genomes follow each other on the same rings and table with the next
+    one's bytes in flight — what a collection of a million looks like to a workgroup.  (Round 5: the first hash pass of a genome wiped
+    its early record starts when the genome before it on the same workgroup had needed more than one pass — `zero_w` kept its last
+    value; nothing in the suite put two such genomes on one workgroup, tests/test_gpu_fullsize.py::test_a_viral_collection_at_full_size found it.)"""
+    if request.param is None:
+        monkeypatch.delenv("LASH_SOLE_WGS", raising=False)
+    else:
+        monkeypatch.setenv("LASH_SOLE_WGS", request.param)
+    yield
+
+
 @pytest.fixture(scope="module")
 def ctx():
     import lash_amd
