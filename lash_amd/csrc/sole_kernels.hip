@@ -116,9 +116,14 @@ __device__ __forceinline__ void sole_flush(const SoleArgs &a, uint32_t g, uint32
             if (tid == 0 && a.hll_corner) a.hll_corner[g] = 0u;            // (set again below if a register lies above 53 - p: same lane)
             write_hll_header_wave(img, a.lay.hdr_tpl, hist, a.alpha_bits, p, a.hll_corner ? a.hll_corner + g : nullptr);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            hist[tid] = 0u;                                   // (for the next genome: its tallies come a barrier later)
+            hist[tid] = 0u;                                   // (for the next genome)
             if (tid < 16u) hist[64u + tid] = 0u;
         }
+        // ... whose tallies may come at once: two flushes follow each other without a hash pass between them when a genome has no k-mer
+        // at all (an empty file, the empty half of an accumulating call) — the other waves' atomics then raced the first wave's zeros and
+        // the second header's sum lost counts (registers right, 3 bytes of `sum` off; found by the randomized runner once LASH_SOLE_WGS
+        // put several genomes on one workgroup)
+        wg_barrier(T >> 6);
     } else {
         // table = 64-bit bitmaps of the nlz values seen -> hash4j's prefix (<< p - 1) -> pack(): 4 * (index of the leading one) + the
         // two bits below it

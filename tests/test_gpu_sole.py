@@ -283,3 +283,34 @@ def test_device_entry_and_raw_files(ctx):
         ctx.enable_timing(False)
         assert tm["sole_launches"] >= 1
         same(got, O.sketch_files(ALGO[an], k, p, 42, files, threads=8), "raw files")
+
+
+@pytest.mark.parametrize("an,k,p", [("hll", 16, 13), ("hll", 21, 14), ("hmh", 16, 0), ("ull", 16, 12)])
+def test_genomes_without_a_kmer_between_others(ctx, an, k, p):
+    """Two image flushes follow each other with no hash pass between them when a genome has no k-mer at all (an empty file, a file of
+    records shorter than k, the empty half of an accumulating call).  Round 5: the HyperLogLog flush zeroed its histogram on the first
+    wave while the other waves were already tallying the next genome's registers — `sum` lost counts (registers right, three header
+    bytes off), only with several genomes on one workgroup (the fixture's wgs=1 / wgs=3) and a table large enough for several waves."""
+    rng = random.Random(5)
+    base = O.synth_genome(77, 60000).tobytes()
+    gs = []
+    for i in range(60):
+        r = i % 6
+        if r == 0: gs.append([base[rng.randint(0, 1000):][:rng.randint(2000, 40000)]])
+        elif r == 1: gs.append([b""])
+        elif r == 2: gs.append([base[:k - 1], base[5:5 + k - 1]])                      # records shorter than k
+        elif r == 3: gs.append([b"N" * 50])
+        elif r == 4: gs.append([base[100:100 + k]])                                    # exactly one k-mer
+        else: gs.append([b"", base[300:300 + rng.randint(k, 3000)], b"acgtn"])
+    got, (seq, off, goff), _ = run(ctx, an, k, p, gs)
+    want = oracle_images(an, k, p, 42, seq, off, goff)
+    same(got, want, "genomes without k-mers")
+    # the same as the second half of an accumulating call: every genome's image holds its first record already
+    import lash_amd
+    first = [[g[0]] for g in gs]
+    rest = [g[1:] if len(g) > 1 else [b""] for g in gs]
+    s1, o1, g1 = lash_amd.records_to_arrays(first)
+    s2, o2, g2 = lash_amd.records_to_arrays(rest)
+    img = ctx.sketch_batch(an, k, p, 42, s1, o1, g1)
+    img = ctx.sketch_batch(an, k, p, 42, s2, o2, g2, flags=lash_amd.F_ACCUMULATE, out=img)
+    same(img, want, "accumulate over genomes without k-mers")
