@@ -373,3 +373,52 @@ def test_a_viral_collection_at_full_size(env, algo, k, p, monkeypatch):
         ro = rec_off[int(goff[g]):int(goff[g + 1]) + 1] - gbo[g]
         want = O.sketch_genomes(algo_id, k, p, 42, host, ro.astype(np.uint64), np.array([0, len(ro) - 1], np.uint64))[0]
         assert np.array_equal(img[g].cpu().numpy(), want), (algo, g, int(lens[g]))
+
+
+@pytest.mark.sole
+@pytest.mark.parametrize("algo,k,p", [("hll", 21, 10), ("hmh", 16, 0), ("ull", 16, 10)])
+def test_a_million_tiny_genomes(env, algo, k, p, monkeypatch):
+    """10^6 genomes of 150..2 500 bytes (amplicons, short contigs), every fourth one with a run of N and lower case, 1.3 GB resident: the
+    persistent kernel with 250+ genomes per workgroup.  Census, the sliced route on every genome, 300 genomes against the oracle."""
+    ctx, torch, lash_amd = env
+    monkeypatch.setenv("LASH_SOLE_MAX", "393216")
+    G = 1_000_000 if FULL else 100_000
+    rng = np.random.default_rng(17)
+    lens = rng.integers(150, 2501, size=G).astype(np.int64)
+    gbo = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    total = int(gbo[-1])
+    dev = torch.device("cuda", 0)
+    d_seq = torch.empty(total, dtype=torch.uint8, device=dev)
+    ctx.synth_genomes_device(0, 1, total, d_seq)
+    # deleted bytes: in every fourth genome bytes [40, 40 + 12) become N and [90, 90 + 25) lower case
+    dirty = torch.from_numpy(gbo[:-1:4].astype(np.int64)).to(dev)
+    for o, n, orv in ((40, 12, None), (90, 25, 0x20)):
+        idx = (dirty[:, None] + torch.arange(o, o + n, device=dev)[None, :]).reshape(-1)
+        if orv is None:
+            d_seq[idx] = 0x4E
+        else:
+            d_seq[idx] |= orv
+    d_rec = torch.from_numpy(gbo.astype(np.int64)).to(dev)
+    goff = np.arange(G + 1, dtype=np.uint64)
+    ib = lash_amd.image_bytes(algo, p)
+    d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
+    ctx.enable_timing(True)
+    ctx.sketch_batch_device(algo, k, p, 42, d_seq, d_rec, G, goff, gbo, d_img)
+    ctx.synchronize()
+    t = ctx.timing()
+    ctx.enable_timing(False)
+    n_dirty = len(gbo[:-1:4])
+    surv = lens.copy()
+    surv[::4] -= 37
+    assert t["sole_launches"] == 1 and t["bases_last"] == total - 37 * n_dirty and t["kmers"] == int(np.maximum(surv - k + 1, 0).sum())
+    d_img2 = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
+    ctx.sketch_batch_device(algo, k, p, 42, d_seq, d_rec, G, goff, gbo, d_img2, flags=lash_amd.F_NO_SOLE)
+    ctx.synchronize()
+    assert torch.equal(d_img, d_img2)
+    del d_img2
+    img = d_img.view(G, ib)
+    algo_id = lash_amd.ALGOS[algo]
+    for g in sorted(set([0, 1, 2, 3, 4, G - 1, G - 2] + [int(x) for x in rng.integers(0, G, size=293)])):
+        host = d_seq[int(gbo[g]):int(gbo[g + 1])].cpu().numpy()
+        want = O.sketch_genomes(algo_id, k, p, 42, host, np.array([0, len(host)], np.uint64), np.array([0, 1], np.uint64))[0]
+        assert np.array_equal(img[g].cpu().numpy(), want), (algo, g, int(lens[g]))
