@@ -422,3 +422,52 @@ def test_a_million_tiny_genomes(env, algo, k, p, monkeypatch):
         host = d_seq[int(gbo[g]):int(gbo[g + 1])].cpu().numpy()
         want = O.sketch_genomes(algo_id, k, p, 42, host, np.array([0, len(host)], np.uint64), np.array([0, 1], np.uint64))[0]
         assert np.array_equal(img[g].cpu().numpy(), want), (algo, g, int(lens[g]))
+
+
+@pytest.mark.parametrize("algo,k,p", [("hmh", 16, 0), ("hll", 21, 14), ("ull", 16, 12)])
+def test_soft_masked_assemblies_at_full_size(env, algo, k, p, monkeypatch):
+    """300 genomes of 5 Mbp under a RepeatMasker-like mask — alternating upper / lower-case runs of 30..30 000 bytes at arbitrary byte
+    positions, a different phase per genome, plus a run of N per genome — 1.5 GB resident.  Three routes must give the same bytes for
+    every genome: the optimistic direct pass with its hand-over to stream_sketch_kernel (what a fresh context does), every genome straight
+    through stream_sketch_kernel (LASH_F_STREAM_ONLY: what a context does after a few soft-masked batches; HyperMinHash: the deferring
+    variant), and the pack stage first (LASH_F_NO_DIRECT); the census and the surviving-base count are exact; three genomes equal the oracle."""
+    ctx, torch, lash_amd = env
+    G = 300 if FULL else 30
+    dev = torch.device("cuda", 0)
+    d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
+    ctx.synth_genomes_device(0, G, L, d_seq)
+    rng = np.random.default_rng(23)
+    edges = np.cumsum(np.exp(rng.uniform(np.log(30), np.log(30000), size=4 * (2 * L) // 3000)).astype(np.int64))
+    edges = edges[edges < 2 * L]
+    lower = np.zeros(2 * L + 1, np.int8)
+    lower[edges[0::2]] += 1
+    lower[edges[1::2]] -= 1
+    mask2 = torch.from_numpy(np.cumsum(lower[:2 * L]).astype(np.bool_)).to(dev)          # twice a genome long: every genome takes its own window
+    v = d_seq.view(G, L)
+    phase = rng.integers(0, L, size=G)
+    for g in range(G):
+        v[g, mask2[int(phase[g]):int(phase[g]) + L]] |= 0x20
+        a = int(rng.integers(0, L - 5000))
+        v[g, a:a + int(rng.integers(1, 4000))] = 0x4E
+    surviving = ((v == 0x41) | (v == 0x43) | (v == 0x47) | (v == 0x54)).sum(dim=1).cpu().numpy().astype(np.int64)
+    rec_off = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)
+    goff = np.arange(G + 1, dtype=np.uint64)
+    d_rec = torch.from_numpy(rec_off.astype(np.int64)).to(dev)
+    ib = lash_amd.image_bytes(algo, p)
+    imgs = {}
+    for name, flags in (("direct + hand-over", 0), ("stream only", lash_amd.F_STREAM_ONLY), ("pack first", lash_amd.F_NO_DIRECT)):
+        d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
+        ctx.enable_timing(True)
+        ctx.sketch_batch_device(algo, k, p, 42, d_seq, d_rec, G, goff, rec_off, d_img, flags=flags)
+        ctx.synchronize()
+        t = ctx.timing()
+        ctx.enable_timing(False)
+        assert t["kmers"] == int(np.maximum(surviving - k + 1, 0).sum()) and t["bases_last"] == int(surviving.sum()), (name, t)
+        imgs[name] = d_img
+    assert torch.equal(imgs["direct + hand-over"], imgs["pack first"]) and torch.equal(imgs["stream only"], imgs["pack first"])
+    img = imgs["stream only"].view(G, ib)
+    algo_id = lash_amd.ALGOS[algo]
+    for g in (0, G // 2, G - 1):
+        host = v[g].cpu().numpy()
+        want = O.sketch_genomes(algo_id, k, p, 42, host, np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
+        assert np.array_equal(img[g].cpu().numpy(), want), (algo, g)
