@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""tools/debug_viral.py G — the viral-collection shape at G genomes through both routes (persistent kernel / sliced kernels): census and the first 200
+genomes against the oracle; for a genome that differs, which record starts the images behave as if they had lost (how round 5's stale ring pointer was
+narrowed down: DESIGN 4.6 "Two bugs").  GPU box."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
