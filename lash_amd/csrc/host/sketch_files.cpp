@@ -488,7 +488,7 @@ std::string sketch_files(const SketchOptions &opt, const std::vector<std::string
     std::vector<std::thread> workers;
     for (int d : devices) workers.emplace_back(gpu_worker, d);
 
-    // ---- writer: images in batch (== file) order into one zstd frame (utils.rs:567-574) ----
+    // ---- writer: images in batch (== file) order into one zstd stream (utils.rs:567-574; frames: zstd_dl.hpp) ----
     std::string werr;
     uint64_t n_batches_total = 0;
     bool batches_known = false;
