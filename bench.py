@@ -697,13 +697,15 @@ def main():
         # the dominant kernel: the direct (ASCII-reading) sketch kernel when the batch took that route (all of this
         # synthetic workload does), else the packed-input sketch kernel; both timed by HIP events on the ctx stream
         direct = tm["direct_launches"] > 0
+        # (round 5) whole small genomes through the persistent kernel: ASCII in as well — L + S bytes per genome — and a name of its own
+        sole = tm.get("sole_launches", 0) > 0 and not direct
         defer = tm["defer_launches"] > 0                 # HyperMinHash, long work items: signatures deferred
         stage_sketch_ms = tm["sketch_ms"] / max(tm["calls"], 1)
         # the dominant kernel's own time: the direct kernel's event bracket on clean input; on dirty input the genomes may be handed to
         # stream_sketch_kernel (and the optimistic pass skipped), so the figure is the whole sketch stage (direct + stream launches)
         dirty_in = args.dirty != "none"
         sketch_ms = tm["direct_ms"] / max(tm["calls"], 1) if direct and not dirty_in else stage_sketch_ms
-        alg_bytes = G * algorithmic_bytes_per_genome(L, ib, ascii_input=direct)
+        alg_bytes = G * algorithmic_bytes_per_genome(L, ib, ascii_input=direct or sole)
         achieved = alg_bytes / (sketch_ms * 1e-3) / 1e9 if sketch_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per sketch launch, if collected
@@ -727,11 +729,11 @@ def main():
                                    % (algo, k, "" if algo == "hmh" else " -p %d" % p, seed),
                        "genomes_per_gpu": G, "genome_length": L, "records_per_gpu": n_rec, "dirty": args.dirty,
                        "algo": algo, "k": k, "p": p, "sharding": "genomes across ranks"},
-            "roofline": {"bound": "hbm", "kernel": ("sketch_kernel<DIRECT> + stream_sketch_kernel (sketch stage)" if dirty_in else ("sketch_kernel<DIRECT, DEFER>" if defer else "sketch_kernel<DIRECT>")) if direct or dirty_in else "sketch_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("sketch_kernel<DIRECT> + stream_sketch_kernel (sketch stage)" if dirty_in else ("sketch_kernel<DIRECT, DEFER>" if defer else "sketch_kernel<DIRECT>")) if direct or dirty_in else ("sole_sketch_kernel (whole genomes on persistent workgroups, ASCII in)" if sole else "sketch_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed (not collected in this run)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": sketch_ms,
-                         "input": "ASCII records (1 B/base)" if direct else "packed 2-bit words (0.25 B/base)",
+                         "input": "ASCII records (1 B/base)" if direct or sole else "packed 2-bit words (0.25 B/base)",
                          # the OTHER accounting of SURVEY 8(d) / BASELINE.md (0.2566 B per k-mer at hmh k=16): the same genomes resident as the
                          # 2-bit stream, sketched by the packed-input kernel in this run — ceil(L/4) + S bytes per genome over that kernel's time
                          "frac_packed_accounting": (G * algorithmic_bytes_per_genome(L, ib, ascii_input=False) / (tm_pk["sketch_ms"] / max(tm_pk["calls"], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS)
