@@ -169,11 +169,15 @@ def test_cli_stops_at_malformed_fastq_records_like_needletail(tmp_path):
         assert ctx.format_errors() == [0, 2]
 
 
-def test_many_small_files_and_a_multi_frame_sketch_file(tmp_path):
+@pytest.mark.sole
+@pytest.mark.parametrize("wgs", [None, "2"])
+def test_many_small_files_and_a_multi_frame_sketch_file(tmp_path, wgs, monkeypatch):
     """A collection of small genomes (one file each): the persistent small-genome kernel behind the raw-file entry, read tasks that cover runs
     of files, and — with this image's libzstd, which has no multithreading — a sketches.bin made of several zstd frames.  The decompressed
     bytes equal the oracle's images in list order and the single-thread writer's bytes; `lash dist` reads the multi-frame file."""
     import random
+    if wgs:
+        monkeypatch.setenv("LASH_SOLE_WGS", wgs)              # (the child processes inherit it: many genomes per workgroup)
     rng = random.Random(9)
     paths, want = [], []
     for i in range(420):                                        # 420 x 32 KiB of images: four 4 MiB pieces

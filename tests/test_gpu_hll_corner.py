@@ -22,6 +22,21 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["sliced kernels", "persistent kernel", "persistent kernel, one workgroup"])
+def _route(request, monkeypatch, _sole_mode):
+    """Every test on both kernel families: the sliced kernels (tests/conftest.py pins LASH_SOLE_MAX=0 for tests not marked `sole`) and — the
+    test genomes are small: what the library does with them by default — the persistent small-genome kernel, whose flush sets the corner flag
+    itself and whose launches the replay's prefix probes are (p = 14: its table is the largest that kernel takes; p = 16 stays sliced).
+    (Runs after conftest's `_sole_mode`, which it names as an argument.)"""
+    import os
+    if request.param != "sliced kernels":
+        monkeypatch.delenv("LASH_SOLE_MAX", raising=False)
+        if request.param.endswith("one workgroup"):
+            monkeypatch.setenv("LASH_SOLE_WGS", "1")
+    yield
+
+
 CORNER = {  # k-mer -> rank (= leading zeros of the hash above the bucket bits + 1), the same for p = 14 and p = 16
     "CTGAGTGTGTCAGGCGTCATT": 40,
     "CGCTCAGTTGGAACGGTGCTT": 39,
