@@ -521,7 +521,7 @@ def main():
     ap.add_argument("-k", type=int, default=16)
     ap.add_argument("-p", type=int, default=14)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--workload", choices=["genomes", "reads", "allpairs", "cli"], default="genomes",
+    ap.add_argument("--workload", choices=["genomes", "reads", "allpairs", "cli", "viral"], default="genomes",
                     help="genomes: --genomes x --length bp, one record each (configs[1]/[2]); reads: ONE sketch of --reads "
                          "150-bp records (configs[4] shape; use with --algo ull -p 12); allpairs: configs[3] shape — every rank "
                          "sketches --genomes genomes, the images are all-gathered (RCCL), every rank computes its block of "
@@ -592,6 +592,28 @@ def main():
         goff = np.array([0, n_rec], dtype=np.uint64)
         d_rec = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * RL
         kmers_per_genome = n_rec * (RL - k + 1)
+    elif args.workload == "viral":
+        # round 5's shape (tools/viral_rate.py): a collection of SMALL genomes of unequal size — 3..300 kbp, log-uniform, 1..4 records each —,
+        # one sketch per genome (utils.rs:450-509): whole through the persistent small-genome kernel.  --genomes of them per GPU
+        # (200 000 = 12.9 GB is the size the round's numbers are quoted on); --length is ignored
+        vrng = np.random.default_rng(13 + rank)
+        v_lens = np.exp(vrng.uniform(np.log(3e3), np.log(3e5), size=G)).astype(np.int64)
+        v_gbo = np.concatenate([[0], np.cumsum(v_lens)]).astype(np.uint64)
+        v_total = int(v_gbo[-1])
+        v_nrec = vrng.integers(1, 5, size=G)
+        cuts = (vrng.random(size=(G, 3)) * (v_lens[:, None] - 1)).astype(np.int64) + 1 + v_gbo[:-1, None].astype(np.int64)
+        keep = np.arange(3)[None, :] < (v_nrec[:, None] - 1)
+        v_rec = np.unique(np.concatenate([v_gbo[:-1].astype(np.int64), cuts[keep], [v_total]])).astype(np.uint64)
+        first = 700_000 + rank
+        d_seq = torch.empty(v_total, dtype=torch.uint8, device=dev)
+        ctx.synth_genomes_device(first, 1, v_total, d_seq)               # one long synthetic sequence, cut into the genomes
+        n_rec = len(v_rec) - 1
+        rec_off = v_gbo                                                   # (the host array the entry takes: every genome's first byte)
+        goff = np.searchsorted(v_rec, v_gbo).astype(np.uint64)
+        d_rec = torch.from_numpy(v_rec.astype(np.int64)).to(dev)
+        L = v_total // G                                                  # (the mean: labels only)
+        kmers_per_genome = None
+        viral_kmers = int(np.maximum(np.diff(v_rec.astype(np.int64)) - k + 1, 0).sum())
     else:
         n_rec = G
         d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
@@ -622,6 +644,13 @@ def main():
         torch.cuda.synchronize()
     d_img = torch.zeros(G * ib, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+    viral = args.workload == "viral"
+
+    def alg_bytes_of(ascii_input):
+        """SURVEY 8(d) for the whole batch of this rank: sum over genomes of (L or ceil(L / 4)) + S"""
+        if viral:
+            return int(v_total if ascii_input else ((v_lens + 3) // 4).sum()) + G * ib
+        return G * algorithmic_bytes_per_genome(L, ib, ascii_input=ascii_input)
 
     if args.workload == "allpairs":
         allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L, G, d_seq, d_rec, goff, rec_off, d_img, ib)
@@ -687,7 +716,7 @@ def main():
     del d_img2
     assert routes_agree, "direct and pack-first routes disagree"
 
-    kmers_step_rank = G * kmers_per_genome
+    kmers_step_rank = viral_kmers if viral else G * kmers_per_genome
     assert tm["kmers"] == kmers_step_rank * args.steps, "device k-mer census disagrees with the workload"
     total_kmers = kmers_step_rank * world * args.steps
     value = total_kmers / elapsed
@@ -705,7 +734,7 @@ def main():
         # stream_sketch_kernel (and the optimistic pass skipped), so the figure is the whole sketch stage (direct + stream launches)
         dirty_in = args.dirty != "none"
         sketch_ms = tm["direct_ms"] / max(tm["calls"], 1) if direct and not dirty_in else stage_sketch_ms
-        alg_bytes = G * algorithmic_bytes_per_genome(L, ib, ascii_input=direct or sole)
+        alg_bytes = alg_bytes_of(direct or sole)
         achieved = alg_bytes / (sketch_ms * 1e-3) / 1e9 if sketch_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")     # PMC-derived HBM bytes per sketch launch, if collected
@@ -722,6 +751,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
             "data": "synthetic" if not dist or dist.get_backend() == "nccl" else "synthetic (LAUNCH DRY RUN: ranks share GPUs over gloo, not a scaling measurement)",
             "config": {"workload": ("ONE sketch of %d synthetic 150-bp records (%d bp) per GPU" % (n_rec, L) if reads else
+                                    ("%d synthetic genomes of 3..300 kbp (log-uniform, mean %d bp, %.2f GB), 1..4 records each, per GPU%s" % (G, L, v_total / 1e9, "")) if viral else
                                     "%d synthetic %d-bp genomes per GPU%s" % (G, L, {"none": "", "nrun": ", one 100-byte N run in each",
                                                                                      "lower": ", every other 10 kb block lower-case"}[args.dirty]))
                                    + ", -a %s -k %d%s, seed %d, ASCII records resident in HBM -> sketch images in HBM "
@@ -736,9 +766,9 @@ def main():
                          "input": "ASCII records (1 B/base)" if direct or sole else "packed 2-bit words (0.25 B/base)",
                          # the OTHER accounting of SURVEY 8(d) / BASELINE.md (0.2566 B per k-mer at hmh k=16): the same genomes resident as the
                          # 2-bit stream, sketched by the packed-input kernel in this run — ceil(L/4) + S bytes per genome over that kernel's time
-                         "frac_packed_accounting": (G * algorithmic_bytes_per_genome(L, ib, ascii_input=False) / (tm_pk["sketch_ms"] / max(tm_pk["calls"], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                         "frac_packed_accounting": (alg_bytes_of(False) / (tm_pk["sketch_ms"] / max(tm_pk["calls"], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                                    if tm_pk["sketch_ms"] > 0 else None,
-                         "packed_accounting": {"algorithmic_bytes_per_launch": G * algorithmic_bytes_per_genome(L, ib, ascii_input=False),
+                         "packed_accounting": {"algorithmic_bytes_per_launch": alg_bytes_of(False),
                                                "avg_launch_ms": tm_pk["sketch_ms"] / max(tm_pk["calls"], 1), "kernel": "sketch_kernel (packed 2-bit input, lash_sketch_packed_device)"},
                          "note": "integer-ALU/LDS-atomic bound kernel: see DESIGN.md 'Roofline'.  frac is on the bytes the dominant kernel really reads (ASCII, 1 B per base); "
                                  "frac_packed_accounting is the north-star's packed-2-bit accounting measured on the packed-input kernel"},
@@ -754,13 +784,31 @@ def main():
                 "stage_ms_per_step": {"pack": tm_pf["pack_ms"] / 3, "sketch": tm_pf["sketch_ms"] / 3, "finalize": tm_pf["finalize_ms"] / 3},
                 "pack_roofline": {"bound": "hbm", "kernel": "pack_lookback_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                   "achieved": G * (L + (L + 3) // 4) / (tm_pf["pack_ms"] / 3 * 1e-3) / 1e9,
-                                  "frac": G * (L + (L + 3) // 4) / (tm_pf["pack_ms"] / 3 * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                                  "frac": (alg_bytes_of(True) + alg_bytes_of(False) - 2 * G * ib) / (tm_pf["pack_ms"] / 3 * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
 
     # ---- the CPU leg (rank 0, N = 1 only, outside the timed region): the oracle timed as the baseline and used as the
     #      checker of three of the images this run produced ----
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not reads and args.dirty == "none":
+        if world == 1 and viral and not args.no_cpu_baseline:
+            # parity: three genomes with their own records against the oracle; baseline: the oracle on equal-length stand-ins of the mean size
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            img = d_img.view(G, ib)
+            ok = True
+            if not args.no_parity_check:
+                for g in sorted({0, G // 2, G - 1}):
+                    host = d_seq[int(v_gbo[g]):int(v_gbo[g + 1])].cpu().numpy()
+                    ro = (v_rec[int(goff[g]):int(goff[g + 1]) + 1] - v_gbo[g]).astype(np.uint64)
+                    want = O.sketch_genomes(lash_amd.ALGOS[algo], k, p, seed, host, ro, np.array([0, len(ro) - 1], np.uint64))[0]
+                    ok = ok and bool(np.array_equal(img[g].cpu().numpy(), want))
+                out["parity_vs_oracle"] = "bit-identical (3 genomes with their records spot-checked)" if ok else "MISMATCH"
+            out["cpu_baseline"], _ = cpu_baseline(algo, k, p, seed, int(L), args.cpu_seconds, first, {})
+            out["cpu_baseline"]["sample"] = "equal-length stand-ins of the collection's mean genome size (one record each): " + out["cpu_baseline"]["sample"]
+            if not ok:
+                print(json.dumps(out))
+                raise SystemExit("parity check failed")
+        elif world == 1 and not args.no_cpu_baseline and not reads and args.dirty == "none":
             img = d_img.view(G, ib)
             check = {g: img[g].cpu().numpy() for g in sorted({0, G // 2, G - 1})} if not args.no_parity_check else {}
             out["cpu_baseline"], ok = cpu_baseline(algo, k, p, seed, L, args.cpu_seconds, first, check)

@@ -98,3 +98,18 @@ def test_the_cli_workload_prints_the_same_contract():
     j = _one_line(r)
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["unit"] == "k-mers/s" and "END TO END" in j["config"]["workload"]
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 / (60 * (400000 - 16 + 1)) - 1) < 1e-6 and j["text_gb_per_s"] > 0
+
+
+def test_the_viral_workload_prints_the_same_contract():
+    """`bench.py --workload viral`: round 5's shape — small genomes of unequal size, 1..4 records each, whole through the persistent kernel —
+    with the usual line: byte accounting over the real lengths, the kernel named, three genomes with their records against the oracle."""
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LASH_BENCH_BACKEND", "LASH_SOLE_MAX"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "viral", "--genomes", "3000", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1"],
+                       cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+    j = _one_line(r)
+    assert j["n_gpus"] == 1 and j["unit"] == "k-mers/s" and "3..300 kbp" in j["config"]["workload"]
+    assert j["roofline"]["kernel"].startswith("sole_sketch_kernel") and j["roofline"]["input"].startswith("ASCII")
+    assert j["parity_vs_oracle"].startswith("bit-identical") and j["cpu_baseline"]["value"] > 0
+    assert j["roofline"]["algorithmic_bytes_per_launch"] > 3000 * 32768 and 0 < j["roofline"]["frac"] < 1
