@@ -525,7 +525,9 @@ def main():
                     help="genomes: --genomes x --length bp, one record each (configs[1]/[2]); reads: ONE sketch of --reads "
                          "150-bp records (configs[4] shape; use with --algo ull -p 12); allpairs: configs[3] shape — every rank "
                          "sketches --genomes genomes, the images are all-gathered (RCCL), every rank computes its block of "
-                         "reference rows of the all-vs-all distance matrix")
+                         "reference rows of the all-vs-all distance matrix; cli: `lash sketch` end to end from FASTA files on tmpfs; "
+                         "viral: --genomes small genomes of unequal size (3..300 kbp, 1..4 records each), one sketch per genome — a virus / "
+                         "plasmid / contig collection, whole through the persistent small-genome kernel (--length is ignored)")
     ap.add_argument("--reads", type=int, default=20_000_000, help="--workload reads: 150-bp records per step and GPU")
     ap.add_argument("--dirty", choices=["none", "nrun", "lower"], default="none",
                     help="nrun: one 100-byte run of N per genome; lower: every other 10 kb block lower-case (soft-masked "
