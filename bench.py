@@ -598,7 +598,7 @@ def main():
         # round 5's shape (tools/viral_rate.py): a collection of SMALL genomes of unequal size — 3..300 kbp, log-uniform, 1..4 records each —,
         # one sketch per genome (utils.rs:450-509): whole through the persistent small-genome kernel.  --genomes of them per GPU
         # (200 000 = 12.9 GB is the size the round's numbers are quoted on); --length is ignored
-        vrng = np.random.default_rng(13 + rank)
+        vrng = np.random.default_rng(13)                                # (the same lengths and cuts on every rank — the job's k-mer count is rank 0's times the ranks —, other bases)
         v_lens = np.exp(vrng.uniform(np.log(3e3), np.log(3e5), size=G)).astype(np.int64)
         v_gbo = np.concatenate([[0], np.cumsum(v_lens)]).astype(np.uint64)
         v_total = int(v_gbo[-1])
