@@ -69,6 +69,63 @@ def host_provenance():
             "cpu_model": model}
 
 
+XGMI_PEAK_GBS = 7 * 153.0       # the same guide: 7 xGMI links x ~153 GB/s per GPU, point to point
+
+
+def device_identity(torch, local_rank):
+    """What tells one GPU from another in a JSON line: uuid / PCI bus id from the device properties (no extra HIP state), the shader
+    clock from sysfs when the node shows it.  Every field is best effort; `id` is the one the distinct-device count is taken on."""
+    d = {"local_rank": local_rank}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        d["name"] = pr.name
+        d["arch"] = getattr(pr, "gcnArchName", None)
+        u = getattr(pr, "uuid", None)
+        d["uuid"] = str(u) if u is not None else None
+        bus = [getattr(pr, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        d["pci"] = "%04x:%02x:%02x" % tuple(bus) if all(b is not None for b in bus) else None
+        d["cus"] = getattr(pr, "multi_processor_count", None)
+    except Exception as e:                                 # (a gloo dry run on a CPU-only host lands here)
+        d["error"] = repr(e)
+    d["visible"] = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    d["id"] = d.get("uuid") if d.get("uuid") and set(d["uuid"]) - set("0-") else (d.get("pci") or "local_rank %d" % local_rank)
+    try:
+        import glob
+        for card in glob.glob("/sys/class/drm/card*/device"):
+            if d.get("pci") and os.path.basename(os.path.realpath(card)).lower().startswith(d["pci"]):
+                cur = [ln for ln in open(os.path.join(card, "pp_dpm_sclk")).read().splitlines() if ln.rstrip().endswith("*")]
+                d["sclk"] = cur[0].split(":", 1)[1].strip(" *") if cur else None
+    except Exception:
+        pass
+    return d
+
+
+def rank_evidence(torch, dist, dev, rank, world, local_rank, fields):
+    """evidence, in the ONE JSON line, that the collective library saw N ranks on N distinct devices — and what
+    each of them measured.  Every rank contributes `fields` (its own wall clock over the timed steps, its kernels' HIP-event time, ...)
+    plus host name, process id and device identity through one all_gather_object, and a 1 through an all_reduce(SUM) ON THE BACKEND'S
+    OWN DEVICE TENSORS (nccl = RCCL: the sum is the number of ranks the communicator really joined).  Outside the timed region.
+    The reference's counterpart is rayon's `files.par_iter()` (utils.rs:450-452) / `par_iter` over reference rows (utils.rs:150)."""
+    import socket
+    mine = dict(fields, rank=rank, hostname=socket.gethostname(), pid=os.getpid(), device=device_identity(torch, local_rank))
+    if not dist:
+        per = [mine]
+        seen, backend = 1, None
+    else:
+        per = [None] * world
+        dist.all_gather_object(per, mine)
+        backend = dist.get_backend()
+        one = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        seen = int(one.item())
+    per.sort(key=lambda r: r["rank"])
+    ids = [r["device"]["id"] + "@" + r["hostname"] for r in per]
+    el = [r["elapsed_ms"] for r in per]
+    return {"backend": backend, "ranks_seen": seen, "ranks_expected": world, "devices": ids, "devices_distinct": len(set(ids)),
+            "per_rank_ms": el, "imbalance": (max(el) / min(el)) if min(el) > 0 else None,
+            "per_rank": per}
+
+
 def native_oracle():
     """the CPU leg is timed on an oracle built `-O3 -march=native` for THIS host when gcc is here (temporary
     directory; the shipped generic .so otherwise).  Returns (path or None, flags string)."""
@@ -89,7 +146,7 @@ def native_oracle():
         return None, "shipped oracle/liblash_oracle.so (-O3, baseline x86-64; the native rebuild failed)"
 
 
-def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
+def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images, layout=None):
     """The only place bench.py touches oracle/.  Times the CPU oracle (a port: the Rust reference cannot be built here) with
     the reference's parallel structure — one task per genome, dynamic scheduling (utils.rs:450-452) — on a bounded sample of
     the same synthetic workload: (i) parse-inclusive, from FASTA text in memory (80-column lines; needletail-like parse +
@@ -111,12 +168,13 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
     rec_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
     goff = np.arange(n + 1, dtype=np.uint64)
     algo_id = {"hmh": O.HMH, "hll": O.HLL, "ull": O.ULL}[algo]
+    lay = O.parse_layout(layout) if layout else None          # (--layout: the oracle restates the same alternative rule)
 
     def run(threads, genomes):
         done, el = 0, 0.0
         while el < 1.0:                                       # >= 1 s per point: a cgroup quota is enforced per 100 ms period
             t0 = time.perf_counter()
-            O.sketch_genomes(algo_id, k, p, seed, seqs[:genomes * L], rec_off[:genomes + 1], goff[:genomes + 1], threads=threads)
+            O.sketch_genomes(algo_id, k, p, seed, seqs[:genomes * L], rec_off[:genomes + 1], goff[:genomes + 1], threads=threads, layout=lay)
             el += time.perf_counter() - t0
             done += genomes
         return done * (L - k + 1) / el
@@ -136,7 +194,7 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
     done, elapsed = 0, 0.0
     while elapsed < target_s:
         t0 = time.perf_counter()
-        O.sketch_genomes(algo_id, k, p, seed, seqs, rec_off, goff, threads=best)
+        O.sketch_genomes(algo_id, k, p, seed, seqs, rec_off, goff, threads=best, layout=lay)
         elapsed += time.perf_counter() - t0
         done += n
     kmers = done * (L - k + 1)
@@ -151,14 +209,14 @@ def cpu_baseline(algo, k, p, seed, L, target_s, first_genome, check_images):
     pdone, pelapsed = 0, 0.0
     while pelapsed < max(1.0, target_s / 3):                 # long enough that a cgroup CPU quota cannot be out-run by a burst
         t0 = time.perf_counter()
-        O.sketch_files(algo_id, k, p, seed, files, threads=best)
+        O.sketch_files(algo_id, k, p, seed, files, threads=best, layout=lay)
         pelapsed += time.perf_counter() - t0
         pdone += nf
     parse_rate = pdone * (L - k + 1) / pelapsed
     ok = True
     for g, got in check_images.items():
         host = O.synth_genome(first_genome + g, L)
-        want = O.sketch_genomes(algo_id, k, p, seed, host, np.array([0, L], np.uint64), np.array([0, 1], np.uint64))[0]
+        want = O.sketch_genomes(algo_id, k, p, seed, host, np.array([0, L], np.uint64), np.array([0, 1], np.uint64), layout=lay)[0]
         ok = ok and bool(np.array_equal(got, want))
     return {"value": kmers / elapsed, "unit": "k-mers/s", "cores": best, "kind": "port",
             "sample": "%d synthetic %d-bp genomes, %s k=%d, in-memory sequences (no FASTA parse), %.1f s on the wall clock = %.0f core-seconds of CPU work; "
@@ -345,10 +403,36 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
     s = step(timed=True)
     torch.cuda.synchronize()
     stage = {"sketch": ev[0].elapsed_time(ev[1]), "gather": ev[1].elapsed_time(ev[2]), "set + pairs": ev[2].elapsed_time(ev[3])}
+    # the collective alone, on its own: the stage bracket above ends when the gather's kernel has run on THIS rank, which includes waiting
+    # for the slowest rank's sketches; here every rank has its images ready and enters together (barrier), five gathers, the mean
+    gather_ms = None
+    if dist and dist.get_backend() == "nccl":
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        g0.record()
+        for _ in range(5):
+            dist.all_gather_into_tensor(every.view(-1), d_img)
+        g1.record()
+        torch.cuda.synchronize()
+        gather_ms = g0.elapsed_time(g1) / 5
+    recv_bytes = (world - 1) * G * ib                      # what one rank receives per gather (it already holds its own share)
+    evidence = rank_evidence(torch, dist, dev, rank, world, int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1),
+                             {"elapsed_ms": elapsed / args.steps * 1e3, "sketch_ms": stage["sketch"], "gather_stage_ms": stage["gather"],
+                              "pairs_ms": stage["set + pairs"], "gather_ms": gather_ms,
+                              "gather_GBps": (recv_bytes / (gather_ms * 1e-3) / 1e9) if gather_ms else None,
+                              "rows": sum(b - a for a, b in bands), "first_genome": int(rank * G)})
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    gms = [r["gather_ms"] for r in evidence["per_rank"] if r.get("gather_ms")]
+    evidence["gather"] = {"bytes_received_per_rank": recv_bytes, "gather_ms_max": max(gms) if gms else None,
+                          "gather_GBps_per_rank_min": (recv_bytes / (max(gms) * 1e-3) / 1e9) if gms else None,
+                          "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBS,
+                          "frac_of_xgmi": (recv_bytes / (max(gms) * 1e-3) / 1e9 / XGMI_PEAK_GBS) if gms else None,
+                          "note": "one all_gather_into_tensor of the finished images (lash_amd/allpairs.py does the same); gather_ms = the collective alone, ranks entering "
+                                  "together, mean of 5; a ring all-gather over point-to-point xGMI is bound by ONE link (~153 GB/s), a direct one by all seven"}
     # host side on a bounded sample of this rank's rows: cardinalities (GPU histograms + host finish) and rows -> text
     t1 = time.perf_counter()
     card = s.cardinalities()
@@ -380,7 +464,7 @@ def allpairs_bench(args, ctx, torch, dist, dev, rank, world, algo, k, p, seed, L
                                    "RCCL (%d x %d B), every rank holds them as a resident set and computes its two bands of the lower triangle "
                                    "(%d of %d rows, equal printed pairs per rank)"
                                    % (G, L, algo, k, N, ib, sum(b - a for a, b in bands), N), "genomes_per_gpu": G, "genome_length": L, "algo": algo, "k": k, "p": p},
-            "printed_pairs_per_s": pairs / elapsed, "stage_ms_rank0": stage,
+            "printed_pairs_per_s": pairs / elapsed, "stage_ms_rank0": stage, "ranks": evidence,
             "host_side": {"cardinalities_s_all_sketches": card_s, "rows_to_text_pairs_per_s_this_rank": host_pairs_per_s, "threads": threads,
                           "note": "lash_dist_rows + row text in C++ (liblash_host.so), outside the timed step: a full run's wall time is "
                                   "bounded by this, not by the GPU (profiles/r03/config3_full_one_gpu.log)"},
@@ -534,6 +618,9 @@ def main():
                          "assembly: filter_out_n deletes those bytes, utils.rs:33-41)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU work of the cpu_baseline leg (the oracle on the host cores); the leg also "
                     "sketches 2 x cores genomes once to warm up and the same genomes as FASTA text for >= 1 s")
+    ap.add_argument("--layout", default=None, help="lash_layout spec (include/lash_gfx950.h: 'hmh_x=low', 'kmer=lsb', 'codes=ACTG', 'hll_bucket=high', "
+                    "comma-separated): the SAME workload under an alternative of the reference's unpinned crate rules (SURVEY App. D) — the kernels' "
+                    "compile-time variants; the CPU leg and the parity spot check use the oracle with the same layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--no-ubench", action="store_true", help="do not run tools/ubench_hash for the VALU ceiling (profiler runs: "
@@ -579,6 +666,9 @@ def main():
     ib = lash_amd.image_bytes(algo, p)
     stream = torch.cuda.current_stream()
     ctx = lash_amd.Context(local_rank, stream=stream)     # raises without GPU / library: no fallback
+    if args.layout:
+        ctx.set_layout(args.layout)                        # every later call sketches under (and writes images in) this layout
+        ib = ctx.image_bytes(algo, p)
 
     # ---- synthetic input, generated in HBM (the same generator as oracle/lash_oracle.c) ----
     reads = args.workload == "reads"
@@ -684,6 +774,9 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = ctx.timing()
     ctx.enable_timing(False)
+    evidence = rank_evidence(torch, dist, dev, rank, world, local_rank,
+                             {"elapsed_ms": elapsed / args.steps * 1e3, "sketch_ms": tm["sketch_ms"] / max(tm["calls"], 1),
+                              "kmers_census": int(tm["kmers"]), "first_genome": int(first)})
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -744,7 +837,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 key = "%s%s_k%d_p%d_g%d_l%d" % ("direct_" if direct else "", algo, k, p, G, L)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch") if args.dirty == "none" else None   # (the counter passes are of the clean workload)
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch") if args.dirty == "none" and not args.layout else None   # (the counter passes are of the clean workload under the default layout)
             except Exception:
                 traffic = None
         out = {
@@ -760,7 +853,7 @@ def main():
                                      "(lash_sketch_batch_device: filter_out_n + k-mers + xxh3 + registers + images)"
                                    % (algo, k, "" if algo == "hmh" else " -p %d" % p, seed),
                        "genomes_per_gpu": G, "genome_length": L, "records_per_gpu": n_rec, "dirty": args.dirty,
-                       "algo": algo, "k": k, "p": p, "sharding": "genomes across ranks"},
+                       "algo": algo, "k": k, "p": p, "sharding": "genomes across ranks", "layout": args.layout or "default"},
             "roofline": {"bound": "hbm", "kernel": ("sketch_kernel<DIRECT> + stream_sketch_kernel (sketch stage)" if dirty_in else ("sketch_kernel<DIRECT, DEFER>" if defer else "sketch_kernel<DIRECT>")) if direct or dirty_in else ("sole_sketch_kernel (whole genomes on persistent workgroups, ASCII in)" if sole else "sketch_kernel"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, committed (not collected in this run)" if traffic else None,
@@ -778,6 +871,9 @@ def main():
                                            sole=tm.get("sole_launches", 0) > 0),
             "stage_ms_per_step": {"pack": tm["pack_ms"] / max(tm["calls"], 1), "sketch": stage_sketch_ms,
                                   "finalize": tm["finalize_ms"] / max(tm["calls"], 1)},
+            # what every rank measured and on which device (rank_evidence): per_rank_ms are the ranks' own wall clocks per step — `ms_per_step`
+            # is their maximum —, ranks_seen the all_reduce(SUM) of ones through the backend, devices_distinct must equal n_gpus
+            "ranks": evidence,
             "packed_resident_kmers_per_s_this_rank": kmers_step_rank * args.steps / packed_elapsed,   # 2-bit genomes kept in HBM
             "routes_agree": "direct and pack-first images identical (all %d genomes of this rank)" % G,
             # the pack-first route's own kernels (dirty genomes, raw FASTA/FASTQ input): the pack stage reads 1 B and writes
@@ -789,6 +885,9 @@ def main():
                                   "frac": (alg_bytes_of(True) + alg_bytes_of(False) - 2 * G * ib) / (tm_pf["pack_ms"] / 3 * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
 
+    if rank == 0 and args.layout:
+        out["roofline_valu"]["layout_note"] = ("--layout %s: the issue ceiling and the committed instruction count quoted here are the DEFAULT rule's "
+                                               "(tools/ubench_hash, profiles/valu.json); profiles/r06/layout_risk.txt holds the measured ratio of every alternative" % args.layout)
     # ---- the CPU leg (rank 0, N = 1 only, outside the timed region): the oracle timed as the baseline and used as the
     #      checker of three of the images this run produced ----
     if rank == 0:
@@ -802,10 +901,11 @@ def main():
                 for g in sorted({0, G // 2, G - 1}):
                     host = d_seq[int(v_gbo[g]):int(v_gbo[g + 1])].cpu().numpy()
                     ro = (v_rec[int(goff[g]):int(goff[g + 1]) + 1] - v_gbo[g]).astype(np.uint64)
-                    want = O.sketch_genomes(lash_amd.ALGOS[algo], k, p, seed, host, ro, np.array([0, len(ro) - 1], np.uint64))[0]
+                    want = O.sketch_genomes(lash_amd.ALGOS[algo], k, p, seed, host, ro, np.array([0, len(ro) - 1], np.uint64),
+                                            layout=O.parse_layout(args.layout) if args.layout else None)[0]
                     ok = ok and bool(np.array_equal(img[g].cpu().numpy(), want))
                 out["parity_vs_oracle"] = "bit-identical (3 genomes with their records spot-checked)" if ok else "MISMATCH"
-            out["cpu_baseline"], _ = cpu_baseline(algo, k, p, seed, int(L), args.cpu_seconds, first, {})
+            out["cpu_baseline"], _ = cpu_baseline(algo, k, p, seed, int(L), args.cpu_seconds, first, {}, layout=args.layout)
             out["cpu_baseline"]["sample"] = "equal-length stand-ins of the collection's mean genome size (one record each): " + out["cpu_baseline"]["sample"]
             if not ok:
                 print(json.dumps(out))
@@ -813,7 +913,7 @@ def main():
         elif world == 1 and not args.no_cpu_baseline and not reads and args.dirty == "none":
             img = d_img.view(G, ib)
             check = {g: img[g].cpu().numpy() for g in sorted({0, G // 2, G - 1})} if not args.no_parity_check else {}
-            out["cpu_baseline"], ok = cpu_baseline(algo, k, p, seed, L, args.cpu_seconds, first, check)
+            out["cpu_baseline"], ok = cpu_baseline(algo, k, p, seed, L, args.cpu_seconds, first, check, layout=args.layout)
             if check:
                 out["parity_vs_oracle"] = "bit-identical (3 genomes spot-checked)" if ok else "MISMATCH"
             if not ok:

@@ -332,11 +332,12 @@ static int global_run(lash_ctx *ctx, const SketchPlan &plan, SketchArgs sa, uint
 // fits its LDS budget and nothing asks for another route.
 uint64_t sole_max_bytes(const lash_ctx *ctx, const lash_params *prm, const SolePlan &sp)
 {
-    if (!sp.ok || (prm->flags & (LASH_F_NO_SOLE | LASH_F_AMINO | LASH_F_STREAM_ONLY)) || layout_alt(ctx->layout, prm->algo)) return 0;
+    if (!sp.ok || (prm->flags & (LASH_F_NO_SOLE | LASH_F_AMINO | LASH_F_STREAM_ONLY))) return 0;
     if (getenv("LASH_STREAM_FIRST")) return 0;                       // (A/B knob of tools/: every genome through stream_sketch_kernel)
     const char *e = getenv("LASH_SOLE_MAX");                         // read per call: tests and tools flip it in-process
     const long long v = e ? atoll(e) : 393216;
-    return v > 0 ? (uint64_t)v : 0;
+    // (the kernel holds a genome's length and offsets in 32 bits: anything that large belongs to the sliced kernels anyway)
+    return v > 0 ? (uint64_t)std::min<long long>(v, 64ll << 20) : 0;
 }
 
 // chunks per workgroup: the launch's tail is one chunk long (tools/: LASH_SOLE_CHUNKS)
@@ -381,7 +382,7 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
     if (n_genomes == 0) return LASH_OK;
     const bool packed = pk != nullptr;
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
-    const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
+    const bool x_low = rule_variant(ctx->layout, prm->algo, prm->flags);   // (HyperMinHash x = low half / HyperLogLog bucket = top bits)
     // as many workgroups as are RESIDENT at a time (the kernel variant's registers, LDS and wave slots taken together): chunks are handed
     // out to running workgroups, one that started late would only hold its first chunk back
     uint32_t per_cu = sp.wg_per_cu;
@@ -488,7 +489,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     auto blen = [&](uint32_t g) -> uint64_t { return pk->byte_len[g] <= sole_max && sole_max ? 0 : pk->byte_len[g]; };
     uint32_t n_sole = 0;
     if (sole_max) for (uint32_t g = 0; g < n_genomes; ++g) n_sole += pk->byte_len[g] <= sole_max;
-    const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
+    const bool x_low = rule_variant(ctx->layout, prm->algo, prm->flags);   // (HyperMinHash x = low half / HyperLogLog bucket = top bits)
     // what the persistent kernel's launch needs from a batch in direct mode (ASCII in the caller's buffer)
     std::vector<uint64_t> sole_gbo;
     auto sole_launch = [&](uint32_t *ndel) -> int {
@@ -521,7 +522,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     uint64_t total_bytes = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) total_bytes += blen(g);
     const bool small_items = n_genomes > n_sole && total_bytes / (n_genomes - n_sole) < 100000u;
-    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo), allow_bins);
+    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, allow_bins);
     if (plan.bins) {
         // a binned launch keeps ~4.6 bytes per input byte of one genome group in HBM: a single genome beyond the budget (a multi-Gbp
         // input in one call, which the CLI would have streamed in chunks) takes the table-in-global-memory path instead
@@ -529,12 +530,12 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         uint64_t big = 0;
         for (uint32_t g = 0; g < n_genomes; ++g) big = std::max<uint64_t>(big, pk->byte_len[g]);
         if (big * 5 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget)
-            plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, layout_alt(ctx->layout, prm->algo), false);
+            plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, false);
     }
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
 
     // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
-    const bool defer_eligible = prm->algo == LASH_HMH && !x_low && !plan.alt && plan.use_lds && plan.parts_log2 == 0;   // (see plan_d below)
+    const bool defer_eligible = prm->algo == LASH_HMH && plan.use_lds && plan.parts_log2 == 0;   // (see plan_d below)
     const uint32_t lds_wg = plan.lds_bytes + ((pk->direct || defer_eligible || plan.bytes) ? sketch_direct_stage_bytes(plan) : 0u);   // + the waves' staging areas / lists
     const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(lds_wg, 1u)) : 4u;   // 64 KiB + census -> 2
     const uint64_t slots = (uint64_t)ctx->cu_count * std::min(wg_per_cu, 2048u / plan.threads);
@@ -664,7 +665,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // 2 Mbp, -6.5 % at 1 Mbp, -2.6 % at 750 kbp, -0.7 % at 600 kbp, +1 % at 500 kbp, +6.5 % at 400 kbp, +19 % at 200 kbp)
     SketchPlan plan_d = plan;
     {
-        static const int64_t defer_min = getenv("LASH_DEFER_MIN") ? atoll(getenv("LASH_DEFER_MIN")) : 600000;   // bases per work item; < 0: never
+        const char *dm_env = getenv("LASH_DEFER_MIN");                       // (read per call: the tests flip it in-process)
+        const int64_t defer_min = dm_env ? atoll(dm_env) : 600000;          // bases per work item; < 0: never
         // (judged on the slices as first cut: the quarters at the launch's tail would pull the mean of a few-round launch under the line)
         plan_d.defer = defer_eligible && n_coarse > 0 && defer_min >= 0 && total_words * 16 / n_coarse >= (uint64_t)defer_min;
     }
@@ -895,14 +897,14 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     int rc;
     if (allow_bins && (rc = timing_begin(ctx))) return rc;            // (the second attempt keeps the first one's event set)
     EvSet *ev = ctx->cur_ev;
-    const bool x_low = (prm->flags & LASH_F_HMH_X_LOW) != 0 || ctx->layout.hmh_x_low;
-    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false, allow_bins);
+    const bool x_low = rule_variant(ctx->layout, prm->algo, prm->flags);   // (HyperMinHash x = low half / HyperLogLog bucket = top bits)
+    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, allow_bins);
     if (plan.bins) {                                                  // (as in sketch_from: one genome beyond the binned launch's budget)
         const uint64_t budget = bins_budget_bytes();
         uint64_t big = 0;
         for (uint32_t g = 0; g < n_genomes; ++g)
             big = std::max<uint64_t>(big, (genome_byte_off[g + 1] - genome_byte_off[g]) + 32 * (genome_rec_off[g + 1] - genome_rec_off[g]));
-        if (big * 6 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget) plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false, false);
+        if (big * 6 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget) plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false);
     }
     const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
     std::vector<GenomeDesc> descs(n_genomes, GenomeDesc{});
@@ -1602,7 +1604,7 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
         ctx->probe_pending = false;
     }
     // (the alternative k-mer / bucket rules of a non-default layout exist for packed input only)
-    bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct && !layout_alt(ctx->layout, prm->algo);
+    bool direct = !(prm->flags & LASH_F_NO_DIRECT) && !env_no_direct;
     bool stream_first = false;
     if (direct && ctx->dirty_frac > 0.2f) {
         if (++ctx->direct_skipped < 8) stream_first = true;     // skip the optimistic pass; try it again every 8th call

@@ -46,8 +46,8 @@ struct LayoutDev {
     uint32_t comp_mask;          // complement of 16 packed bases = word ^ comp_mask  (code[A]^code[T] in every 2-bit group)
     uint32_t hdr_bytes;          // bytes written before the register array of this algo's image
     uint32_t hmh_reg_be;         // HyperMinHash registers big-endian in images
-    uint32_t kmer_lsb_first;     // (ALT kernels only) a k-mer's first base is its least significant 2 bits
-    uint32_t hll_bucket_high;    // (ALT kernels only) HLL bucket = top p bits of the hash
+    uint32_t kmer_lsb_first;     // (informational: layout_dev() has already turned it into the complemented code tables above)
+    uint32_t hll_bucket_high;    // (informational: the launchers pick the kernels' bucket-high variant, rule_variant())
     uint32_t aa_code_base;       // amino-acid kernel: code of 'A' (1, or 0 with layout.aa_code_zero_based); the other 19 follow in letter order
     uint64_t hdr_tpl;            // that header's field codes (see lash_layout), first field in the low byte, 0-terminated
                                  // (a scalar, not an array: a dynamically indexed kernel-argument array would live in scratch)

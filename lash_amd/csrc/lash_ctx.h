@@ -333,13 +333,24 @@ bool layout_ok(const lash_layout &lay)
     }
     return true;
 }
-// non-default k-mer / bucket rule -> ALT kernels on packed input
-bool layout_alt(const lash_layout &lay, int algo) { return lay.kmer_lsb_first || (algo == LASH_HLL && lay.hll_bucket_high); }
+// The register rule's compile-time variant of the sketch kernels (sketch_rules.h, add_kmer): HyperMinHash with x = the LOW half of
+// xxh3_128 (SURVEY App. D switch U1: the context layout, or LASH_F_HMH_X_LOW per call), HyperLogLog with the bucket in the TOP p bits
+// (U3).  Every kernel family — direct, stream, persistent small-genome, packed, amino-acid, deferring — exists in both forms.
+bool rule_variant(const lash_layout &lay, int algo, uint32_t flags)
+{
+    if (algo == LASH_HMH) return (flags & LASH_F_HMH_X_LOW) != 0 || lay.hmh_x_low;
+    return algo == LASH_HLL && lay.hll_bucket_high;
+}
 
 LayoutDev layout_dev(const lash_layout &lay, int algo)
 {
     LayoutDev d{};
-    const uint32_t A = lay.base_code[0], Cc = lay.base_code[1], G = lay.base_code[2], T = lay.base_code[3];
+    // layout.kmer_lsb_first (U5: a k-mer's first base in its LEAST significant bits): the lsb-first value of a k-mer is the msb-first
+    // value of its reverse complement under the code table with every letter's code replaced by its complement's (sketch_rules.h,
+    // above process_word), and the canonical k-mer is the minimum over {k-mer, reverse complement} either way — so the kernels
+    // run unchanged on the swapped table.  comp_mask (code[A] ^ code[T]) is the same for both tables.
+    const bool sw = lay.kmer_lsb_first != 0;
+    const uint32_t A = lay.base_code[sw ? 3 : 0], Cc = lay.base_code[sw ? 2 : 1], G = lay.base_code[sw ? 1 : 2], T = lay.base_code[sw ? 0 : 3];
     d.code_lo = (A << 8) | (Cc << 24);                   // keys (byte & 7): A = 1, C = 3
     d.code_hi = T | (G << 24);                           // T = 4, G = 7
     d.code_tab4 = A | (Cc << 8) | (G << 16) | (T << 24); // index = hypothesis code A,C,G,T = 0,1,2,3

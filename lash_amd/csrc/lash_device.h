@@ -151,6 +151,48 @@ __device__ __forceinline__ uint32_t xxh3_128_4b_hmh_rank(uint32_t w, BitFlip bit
     return __umulhi(h0, m0) + h0 * m1 + h1 * m0;
 }
 
+// ---- the same three forms for x = LOW half (layout.hmh_x_low, SURVEY App. D switch U1; round 6) ---------------------------------
+// With the halves swapped the rank half is the `l` chain — l ^= h >> 3; l ^= l >> 35; l *= MX2; l ^= l >> 28 — and the signature the low
+// ten bits of avalanche(h).  The l chain in 32-bit halves: only l_hi ^= h_hi >> 3 and l_lo ^= (h >> 3)_lo ^ (l_hi >> 3) are ever
+// needed (five instructions), and the high word of the last multiply is the same three-multiply sum the default takes from h.
+__device__ __forceinline__ uint32_t xxh3_l_chain_high(uint64_t l, uint64_t h)    // bits 63:32 of (l ^ h >> 3, xorshift 35) * MX2
+{
+    uint64_t hs;                                                            // h >> 3: ONE 64-bit shift (4.4 cycles) for a shift and a funnel shift (7.3)
+    asm("v_lshrrev_b64 %0, 3, %1" : "=v"(hs) : "v"(h));
+    const uint32_t l1 = (uint32_t)(l >> 32) ^ (uint32_t)(hs >> 32);
+    const uint32_t l0 = __builtin_amdgcn_bitop3_b32((uint32_t)l, (uint32_t)hs, l1 >> 3, 0x96);
+    constexpr uint32_t m0 = (uint32_t)XXH_PRIME_MX2, m1 = (uint32_t)(XXH_PRIME_MX2 >> 32);
+    return __umulhi(l0, m0) + l0 * m1 + l1 * m0;
+}
+// xh = bits 63:32 of the low half (bucket = xh >> 18, rank field = xh & 0x3FFFF), sig10 = bits 9:0 of the high half
+__device__ __forceinline__ void xxh3_128_4b_hmh_fast_xlow(uint32_t w, BitFlip bitflip, uint32_t &xh, uint32_t &sig10)
+{
+    uint64_t l, h;
+    xxh3_mul128(w ^ bitflip.lo, w ^ bitflip.hi, l, h);
+    h += l << 1;
+    const uint32_t t = xxh3_l_chain_high(l, h);
+    xh = t ^ (t >> 28);                                                     // the final xorshift reaches bits 3:0 of the word
+    // sig10 = bits 9:0 of (m ^ m >> 32), m = (h ^ h >> 37) * MX1: bits 9:0 of both words of the product.  The low word and the carry
+    // into the high one come from ONE v_mad_u64_u32; of the two cross products only ten bits matter: full-rate 24-bit multiplies
+    const uint32_t g1 = (uint32_t)(h >> 32), g0 = (uint32_t)h ^ (g1 >> 5);
+    const uint64_t pm = (uint64_t)g0 * (uint32_t)XXH_PRIME_MX1;
+    uint32_t top;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(top) : "v"(g0), "s"((uint32_t)(XXH_PRIME_MX1 >> 32) & 0xFFFFFFu), "v"((uint32_t)(pm >> 32)));
+    asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(top) : "v"(g1), "s"((uint32_t)XXH_PRIME_MX1 & 0xFFFFFFu));
+    sig10 = ((uint32_t)pm ^ top) & 0x3FFu;
+}
+// ... and the rank half alone, WITHOUT the final xorshift: that one only moves bits 31:28 onto bits 3:0, and the deferring filter looks
+// at bits 31:4 — the bucket (31:18) and the upper 14 of the 16 rank bits below it; LdsThrRegs caps its thresholds at 14 leading
+// zeros in this variant so that the two bits it cannot trust never decide (see there)
+__device__ __forceinline__ uint32_t xxh3_128_4b_hmh_rank_xlow(uint32_t w, BitFlip bitflip)
+{
+    uint64_t l, h;
+    xxh3_mul128(w ^ bitflip.lo, w ^ bitflip.hi, l, h);
+    asm("" : "+v"(l));                                   // (opaque, as in xxh3_128_4b_hmh_rank: or hipcc folds the doubling into the multiply chain —
+    asm("v_lshl_add_u64 %0, %1, 1, %0" : "+v"(h) : "v"(l));   //  a fifth v_mad_u64_u32 and seven more instructions per k-mer)
+    return xxh3_l_chain_high(l, h);
+}
+
 // XXH3-64 of the 8 little-endian bytes of {v_hi,v_lo} (XXH3_len_4to8_64b, len = 8 -> XXH3_rrmxmx), up to but NOT including the
 // final `h ^= h >> 28`
 __device__ __forceinline__ uint64_t xxh3_64_8b_pre(uint32_t v_lo, uint32_t v_hi, BitFlip bitflip)

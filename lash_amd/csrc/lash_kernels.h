@@ -61,8 +61,8 @@ struct SketchArgs {
 
 struct SketchPlan {
     int      algo, k, p;
-    bool     x_low;
-    bool     alt;                 // non-default k-mer / bucket rule (layout.kmer_lsb_first, hll_bucket_high): ALT kernels, packed input only
+    bool     variant;             // the register rule's compile-time variant (rule_variant(), lash_ctx.h): HyperMinHash x = low half of
+                                  // xxh3_128 (layout.hmh_x_low / LASH_F_HMH_X_LOW), HyperLogLog bucket = top p bits (layout.hll_bucket_high)
     bool     use_lds;
     uint32_t threads;             // 512 (<= 64 KiB of LDS, two workgroups per CU) or 1024
     uint32_t lds_bytes;
@@ -98,7 +98,7 @@ struct BinApplyArgs {
 hipError_t launch_bins_apply(const BinApplyArgs &args, uint32_t n_group_genomes, hipStream_t stream);
 
 // small_items: the batch's genomes average under ~100 kbp (workgroup shape for small register tables, see the .hip)
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items = false, bool alt = false, bool allow_bins = true);
+SketchPlan make_sketch_plan(int algo, int k, int p, bool variant, bool small_items = false, bool allow_bins = true);
 // the genomes flagged in args.dirty, again from their ASCII bytes, compacted through an LDS ring per wave (stream_sketch_kernel)
 hipError_t launch_sketch_stream(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream);
 // direct launches: bytes of LDS the waves' staging areas take on top of plan.lds_bytes (they start at plan.lds_bytes)
@@ -158,10 +158,10 @@ struct SolePlan {
     uint32_t hist_off, scan_off, ring_off, brk_off, ring_words;
 };
 SolePlan make_sole_plan(int algo, int p, uint32_t n_genomes = 0, uint32_t cu_count = 256);   // n_genomes: of the call, 0 = unknown
-hipError_t launch_sole(const SolePlan &plan, int algo, int k, bool x_low, bool packed, const SoleArgs &args, uint32_t n_wg, hipStream_t stream);
+hipError_t launch_sole(const SolePlan &plan, int algo, int k, bool variant, bool packed, const SoleArgs &args, uint32_t n_wg, hipStream_t stream);
 // workgroups of that launch's kernel variant that one CU holds at a time (hipOccupancyMaxActiveBlocksPerMultiprocessor): the launch is
 // sized to what is resident
-hipError_t sole_resident_per_cu(const SolePlan &plan, int algo, int k, bool x_low, bool packed, uint32_t *out);
+hipError_t sole_resident_per_cu(const SolePlan &plan, int algo, int k, bool variant, bool packed, uint32_t *out);
 // bit b of brk_abs (zeroed, (seq_bytes + 63) / 32 + 2 words) set <=> some record starts at byte b
 hipError_t launch_sole_mark(const uint64_t *rec_off, uint64_t n_rec, uint64_t seq_bytes, uint32_t *brk_abs, hipStream_t stream);
 // wg_counts -> the context's k-mer census (counter[0]) and surviving-base count (counter[1])

@@ -21,11 +21,11 @@
 
 namespace lash {
 
-template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT = false, bool DEFER = false>
+// XLOW: the rule's variant (HyperMinHash x = low half; HyperLogLog bucket = top bits; sketch_rules.h, add_kmer)
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool DEFER = false>
 __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_kernel(SketchArgs a)
 {
-    static_assert(!(ALT && DIRECT), "the alternative k-mer / bucket rules run on packed input only");
-    static_assert(!DEFER || (ALGO == 0 && !XLOW && REGS == REGS_LDS && !ALT), "deferred signatures: HyperMinHash, x = high half, one LDS table");
+    static_assert(!DEFER || (ALGO == 0 && REGS == REGS_LDS), "deferred signatures: HyperMinHash, one LDS table");
     // dynamic LDS: [nreg32 register words][16 words of per-wave census]; registers start at LDS offset 0 so the
     // bucket offset goes straight into the ds_max / ds_or address
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
 
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
-    using Regs = typename std::conditional<DEFER, LdsThrRegs, typename std::conditional<REGS == REGS_LDS, LdsRegs,
+    using Regs = typename std::conditional<DEFER, typename std::conditional<XLOW, LdsThrRegsX, LdsThrRegs>::type,
+                                           typename std::conditional<REGS == REGS_LDS, LdsRegs,
                                            typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs,
                                            typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteQRegs<ALGO>>::type>::type>::type>::type;
     // what the slow paths (junction walks, dense tiles) update through: the byte tables' plain compare-and-swap form
@@ -104,11 +105,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     kp.sh_gt = 64u - 2u * (uint32_t)k;
     kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
     kp.mask_hi = (uint32_t)(kp.mask_gt >> 32);
-    if constexpr (!ALT) kp.to_vector_registers();
-    kp.lsb_xor = (ALT && a.lay.kmer_lsb_first) ? ((((uint64_t)a.lay.comp_mask << 32) | a.lay.comp_mask) & kp.mask_gt) : 0ull;
+    kp.to_vector_registers();
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ctabs{a.lay.code_lo, a.lay.code_hi};
-    constexpr bool K21 = KMODE == KM_GT16 && DIRECT && !ALT && !DEFER && (REGS == REGS_LDS || REGS == REGS_BYTES);   // kernels with a k = 21 body of their own
+    constexpr bool K21 = KMODE == KM_GT16 && DIRECT && !DEFER && (REGS == REGS_LDS || REGS == REGS_BYTES);   // kernels with a k = 21 body of their own
     uint32_t my_kmers = 0;
     const uint32_t lane = threadIdx.x & 63u;
     SigQueue sigq;                                                          // DEFER: the lanes' stacks live in the wave's staging area
@@ -301,13 +301,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 #pragma unroll LASH_WORD_UNROLL
         for (int wi = 0; wi < SKETCH_WORDS_PER_THREAD; ++wi) {
             uint32_t z;
-            if constexpr (ALT) {
-                // non-default k-mer / bucket rule: exact forms only, always masked (a compatibility mode, not a fast path)
-                uint32_t kvw = (uint32_t)kv;
-                if (a.lay.hll_bucket_high) (void)process_word<ALGO, KMODE, XLOW, true, false, Regs, true, ALGO == 1>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
-                else (void)process_word<ALGO, KMODE, XLOW, true, false, Regs, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
-                z = 0xFFFFFFFFu;
-            } else if constexpr (DEFER) {
+            if constexpr (DEFER) {
                 z = 0xFFFFFFFFu;                                               // (nothing to re-run: the full update does that itself)
                 if (all_valid) process_word_defer<KMODE, false>(regs, kp, c0, c1, c2, r0, r1, r2, 0u, sigq);
                 else {
@@ -317,11 +311,11 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 }
             } else if (K21 && k == 21) {
                 // k = 21 (BASELINE configs[2]; the fields of the 64-bit window at compile-time places: canon_gt16<21>)
-                if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true, Regs, false, false, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
+                if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true, Regs, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
                 else {
                     uint32_t kvw = (uint32_t)kv;
                     asm volatile("" : "+v"(kvw));
-                    z = process_word<ALGO, KMODE, XLOW, true, true, Regs, false, false, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
+                    z = process_word<ALGO, KMODE, XLOW, true, true, Regs, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
                 }
             } else if (all_valid) {
                 z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
@@ -334,7 +328,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             }
             // FAST forms return a word whose smallness flags "rank not decided by the bits looked at": exact re-run
             // (HMH/x-high looks at 18 bits -> 2^-18 per k-mer; the others at 32 bits -> 2^-32)
-            constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? (Regs::THR ? 0x7FFFu : 0x3FFFu) : 0u;
+            constexpr uint32_t Z_REDO = z_redo<ALGO, Regs>();
             if (z <= Z_REDO) {
                 uint32_t kvw = (uint32_t)kv;
                 asm volatile("" : "+v"(kvw));
@@ -391,7 +385,7 @@ static_assert(RING_W <= DENSE_STAGE_CODE_WORDS && RING_BW <= DENSE_STAGE_BRK_WOR
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DEFER = false>
 __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
 {
-    static_assert(!DEFER || (ALGO == 0 && !XLOW && REGS == REGS_LDS), "deferred signatures: HyperMinHash, x = high half, one LDS table");
+    static_assert(!DEFER || (ALGO == 0 && REGS == REGS_LDS), "deferred signatures: HyperMinHash, one LDS table");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
     const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x + a.item_base;
     const WorkItem it = a.items[item];
@@ -413,7 +407,8 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
         return;
     }
     constexpr bool USE_LDS = REGS != REGS_GLOBAL;
-    using Regs = typename std::conditional<DEFER, LdsThrRegs, typename std::conditional<REGS == REGS_LDS, LdsRegs,
+    using Regs = typename std::conditional<DEFER, typename std::conditional<XLOW, LdsThrRegsX, LdsThrRegs>::type,
+                                           typename std::conditional<REGS == REGS_LDS, LdsRegs,
                                            typename std::conditional<REGS == REGS_GLOBAL, GlobalRegs,
                                            typename std::conditional<REGS == REGS_BINS, BinRegs, LdsByteRegs>::type>::type>::type>::type;
     Regs regs;
@@ -451,7 +446,6 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
     kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
     kp.mask_hi = (uint32_t)(kp.mask_gt >> 32);
     kp.to_vector_registers();
-    kp.lsb_xor = 0ull;
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ct{a.lay.code_lo, a.lay.code_hi};
 
@@ -518,7 +512,7 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
                     asm volatile("" : "+v"(m));
                     z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, m);
                 }
-                constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? (Regs::THR ? 0x7FFFu : 0x3FFFu) : 0u;
+                constexpr uint32_t Z_REDO = z_redo<ALGO, Regs>();
                 if (z <= Z_REDO) {
                     uint32_t m = kvw;
                     asm volatile("" : "+v"(m));
@@ -729,7 +723,7 @@ static hipError_t launch_stream_one(const SketchPlan &plan, const SketchArgs &ar
     auto kern = stream_sketch_kernel<ALGO, KMODE, XLOW, REGS>;
     uint32_t threads = plan.threads, stacks = 0;
     SketchArgs a = args;
-    if constexpr (ALGO == 0 && !XLOW && REGS == REGS_LDS) {
+    if constexpr (ALGO == 0 && REGS == REGS_LDS) {
         if (plan.defer) {                                                  // (see the kernel: 1 024 threads, the lanes' stacks behind the rings)
             kern = stream_sketch_kernel<ALGO, KMODE, XLOW, REGS, true>;
             threads = 1024u;
@@ -781,10 +775,9 @@ static hipError_t launch_stream_kmode(const SketchPlan &plan, const SketchArgs &
 hipError_t launch_sketch_stream(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
     if (n_items == 0) return hipSuccess;
-    if (plan.alt) return hipErrorInvalidValue;
     switch (plan.algo) {
-    case 0: return plan.x_low ? launch_stream_kmode<0, true>(plan, args, n_items, stream) : launch_stream_kmode<0, false>(plan, args, n_items, stream);
-    case 1: return launch_stream_kmode<1, false>(plan, args, n_items, stream);
+    case 0: return plan.variant ? launch_stream_kmode<0, true>(plan, args, n_items, stream) : launch_stream_kmode<0, false>(plan, args, n_items, stream);
+    case 1: return plan.variant ? launch_stream_kmode<1, true>(plan, args, n_items, stream) : launch_stream_kmode<1, false>(plan, args, n_items, stream);
     case 2: return launch_stream_kmode<2, false>(plan, args, n_items, stream);
     default: return hipErrorInvalidValue;
     }
@@ -900,7 +893,7 @@ __global__ void __launch_bounds__(1024) aa_sketch_kernel(SketchArgs a)
             const uint32_t vm = emit ? 0xFFFFFFFFu : 0u;
             const uint32_t m_lo = v_lo & kmask_lo, m_hi = ALGO == 0 ? 0u : (v_hi & kmask_hi);
             const uint32_t t = add_kmer<ALGO, XLOW, true, true>(regs, m_lo, m_hi, vm, bitflip, p);
-            constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+            constexpr uint32_t Z_REDO = z_redo<ALGO, Regs>();
             if (t <= Z_REDO) (void)add_kmer<ALGO, XLOW, true, false>(regs, m_lo, m_hi, vm, bitflip, p);   // (rare: the exact form)
             my_kmers += emit ? 1u : 0u;
         }
@@ -934,8 +927,8 @@ hipError_t launch_sketch_aa(const SketchPlan &plan, const SketchArgs &args, uint
 {
     if (n_items == 0) return hipSuccess;
     switch (plan.algo) {
-    case 0: return plan.x_low ? launch_aa_regs<0, true>(plan, args, n_items, stream) : launch_aa_regs<0, false>(plan, args, n_items, stream);
-    case 1: return launch_aa_regs<1, false>(plan, args, n_items, stream);
+    case 0: return plan.variant ? launch_aa_regs<0, true>(plan, args, n_items, stream) : launch_aa_regs<0, false>(plan, args, n_items, stream);
+    case 1: return plan.variant ? launch_aa_regs<1, true>(plan, args, n_items, stream) : launch_aa_regs<1, false>(plan, args, n_items, stream);
     case 2: return launch_aa_regs<2, false>(plan, args, n_items, stream);
     default: return hipErrorInvalidValue;
     }
@@ -1155,10 +1148,10 @@ hipError_t launch_bins_apply(const BinApplyArgs &args, uint32_t n_group_genomes,
 // ------------------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------------------
-SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items, bool alt, bool allow_bins)
+SketchPlan make_sketch_plan(int algo, int k, int p, bool variant, bool small_items, bool allow_bins)
 {
     SketchPlan s{};
-    s.algo = algo; s.k = k; s.p = p; s.x_low = x_low; s.alt = alt;
+    s.algo = algo; s.k = k; s.p = p; s.variant = variant && algo != 2;
     if (algo == 0) { s.nreg32 = HMH_M; s.partial_bytes = HMH_M * 2; }
     else if (algo == 1) { s.nreg32 = 1u << p; s.partial_bytes = 1u << p; }
     else { s.nreg32 = 2u << p; s.partial_bytes = 1u << p; }
@@ -1169,8 +1162,8 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool x_low, bool small_items
     // memory per work item and one atomic per k-mer (ULL p >= 23)
     uint32_t bl = 0;
     while ((s.lds_bytes >> bl) > 128u * 1024u) ++bl;
-    static const bool no_bins = getenv("LASH_NO_BINS") != nullptr;         // A/B knob: the global-atomic path for every large table
-    static const bool no_bytes = getenv("LASH_NO_BYTES") != nullptr;       // A/B knob: bins instead of byte tables
+    const bool no_bins = getenv("LASH_NO_BINS") != nullptr;                // A/B knob (read per call): the global-atomic path for every large table
+    const bool no_bytes = getenv("LASH_NO_BYTES") != nullptr;              // A/B knob (read per call): bins instead of byte tables
     // up to 128 KiB of BYTE registers (hll p = 16, ull p = 15 .. 17): one pass, compare-and-swap updates (LdsByteRegs); binning pays from 8 bins on
     s.bytes = bl > 0 && (1u << p) <= 128u * 1024u && algo != 0 && !no_bytes;
     if (s.bytes) { bl = 0; s.nreg32 = (1u << p) >> 2; s.lds_bytes = s.nreg32 * 4u; }
@@ -1221,13 +1214,13 @@ static uint32_t stage_stride_bytes(const SketchPlan &plan, bool direct, bool def
 uint32_t sketch_direct_stage_bytes(const SketchPlan &plan) { return (plan.threads / 64u) * stage_stride_bytes(plan, true, true); }
 uint32_t sketch_bin_wave_bytes(const SketchPlan &plan) { return plan.bins ? ((1u << (plan.bins_log2 + plan.bin_sub_shift)) * (1u + plan.bin_S + 4u)) * 4u : 0u; }
 
-template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT, bool ALT>
+template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
-    auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT>;
+    auto kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT>;
     bool defer = false;
-    if constexpr (ALGO == 0 && !XLOW && REGS == REGS_LDS && !ALT) {
-        if (plan.defer) { kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, ALT, true>; defer = true; }
+    if constexpr (ALGO == 0 && REGS == REGS_LDS) {
+        if (plan.defer) { kern = sketch_kernel<ALGO, KMODE, XLOW, REGS, DIRECT, true>; defer = true; }
     }
     SketchArgs a = args;
     a.stage_off = plan.lds_bytes;                                          // direct mode: the waves' staging areas follow (dense_tile);
@@ -1244,43 +1237,42 @@ static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uin
     return hipGetLastError();
 }
 
-template <int ALGO, bool XLOW, bool DIRECT, bool ALT>
+template <int ALGO, bool XLOW, bool DIRECT>
 static hipError_t launch_kmode(const SketchPlan &plan, const SketchArgs &args, uint32_t n, hipStream_t s)
 {
     const int km = plan.k == 16 ? KM_16 : plan.k < 16 ? KM_LT16 : KM_GT16;
     if constexpr (ALGO != 0) {                                  // HMH's table always fits
         if (plan.bytes) {
-            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_BYTES, DIRECT, ALT>(plan, args, n, s);
-            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_BYTES, DIRECT, ALT>(plan, args, n, s);
-            return launch_one<ALGO, KM_GT16, XLOW, REGS_BYTES, DIRECT, ALT>(plan, args, n, s);
+            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_BYTES, DIRECT>(plan, args, n, s);
+            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_BYTES, DIRECT>(plan, args, n, s);
+            return launch_one<ALGO, KM_GT16, XLOW, REGS_BYTES, DIRECT>(plan, args, n, s);
         }
         if (plan.bins) {
-            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
-            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
-            return launch_one<ALGO, KM_GT16, XLOW, REGS_BINS, DIRECT, ALT>(plan, args, n, s);
+            if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_BINS, DIRECT>(plan, args, n, s);
+            if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_BINS, DIRECT>(plan, args, n, s);
+            return launch_one<ALGO, KM_GT16, XLOW, REGS_BINS, DIRECT>(plan, args, n, s);
         }
     }
     if (plan.use_lds) {
-        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS, DIRECT, ALT>(plan, args, n, s);
-        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS, DIRECT, ALT>(plan, args, n, s);
-        return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS, DIRECT, ALT>(plan, args, n, s);
+        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
+        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
+        return launch_one<ALGO, KM_GT16, XLOW, REGS_LDS, DIRECT>(plan, args, n, s);
     }
     if constexpr (ALGO == 2) {                                  // only ULL p >= 19 outgrows the partitioned LDS passes
-        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_GLOBAL, DIRECT, ALT>(plan, args, n, s);
-        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_GLOBAL, DIRECT, ALT>(plan, args, n, s);
-        return launch_one<ALGO, KM_GT16, XLOW, REGS_GLOBAL, DIRECT, ALT>(plan, args, n, s);
+        if (km == KM_16) return launch_one<ALGO, KM_16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
+        if (km == KM_LT16) return launch_one<ALGO, KM_LT16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
+        return launch_one<ALGO, KM_GT16, XLOW, REGS_GLOBAL, DIRECT>(plan, args, n, s);
     }
     return hipErrorInvalidValue;
 }
 
-template <bool DIRECT, bool ALT>
+template <bool DIRECT>
 static hipError_t launch_algo(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)
 {
     switch (plan.algo) {
-    case 0: return plan.x_low ? launch_kmode<0, true, DIRECT, ALT>(plan, args, n_items, stream)
-                              : launch_kmode<0, false, DIRECT, ALT>(plan, args, n_items, stream);
-    case 1: return launch_kmode<1, false, DIRECT, ALT>(plan, args, n_items, stream);
-    case 2: return launch_kmode<2, false, DIRECT, ALT>(plan, args, n_items, stream);
+    case 0: return plan.variant ? launch_kmode<0, true, DIRECT>(plan, args, n_items, stream) : launch_kmode<0, false, DIRECT>(plan, args, n_items, stream);
+    case 1: return plan.variant ? launch_kmode<1, true, DIRECT>(plan, args, n_items, stream) : launch_kmode<1, false, DIRECT>(plan, args, n_items, stream);
+    case 2: return launch_kmode<2, false, DIRECT>(plan, args, n_items, stream);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1288,8 +1280,7 @@ static hipError_t launch_algo(const SketchPlan &plan, const SketchArgs &args, ui
 hipError_t launch_sketch(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream, bool direct)
 {
     if (n_items == 0) return hipSuccess;
-    if (plan.alt) return direct ? hipErrorInvalidValue : launch_algo<false, true>(plan, args, n_items, stream);
-    return direct ? launch_algo<true, false>(plan, args, n_items, stream) : launch_algo<false, false>(plan, args, n_items, stream);
+    return direct ? launch_algo<true>(plan, args, n_items, stream) : launch_algo<false>(plan, args, n_items, stream);
 }
 
 // Are all records of a genome the same length (a FASTQ read set)?  Then record starts are the multiples of that length and the

@@ -330,20 +330,31 @@ struct LdsByteQRegs : LdsByteRegs {
 // under an UNSIGNED MINIMUM, 0xFFFFFFFF = empty (passes everything; every real word is smaller).  A smaller word is a larger
 // (lz, sig) in the reference's order (utils.rs:395-398 -> hyperminhash add_hash), so ds_min_u32 is its max; beyond 16 leading
 // zeros the threshold is 0 (x16 must be 0) and the full update decides.  get() turns the word back into lz << 10 | sig.
-struct LdsThrRegs {
+//   The x = low variant (layout.hmh_x_low; round 6) caps the threshold's shift at 14 instead of 16: its filter compares the rank half of
+// the hash WITHOUT the final xorshift (xxh3_128_4b_hmh_rank_xlow), whose bits 3:0 — the two lowest of the 16 rank bits — are not yet
+// the hash's.  A threshold of at least 3 never looks at them; ranks beyond the cap live in the low half, as they do beyond 16.
+template <uint32_t CAP_>
+struct LdsThrRegsT {
     uint32_t *base;
     static constexpr bool THR = true, BINS = false, BYTES = false, QUEUED = false;
+    static constexpr uint32_t CAP = CAP_;
+    static constexpr bool XLOW = CAP_ != 16u;
+    static constexpr uint32_t REDO_BELOW = 1u << (31u - CAP_);              // the 18-bit fast form's t18 below this: rank beyond the cap, re-run exactly
     static __device__ __forceinline__ uint32_t encode(uint32_t lzm1, uint32_t sig)
     {
-        const uint32_t m = lzm1 < 16u ? lzm1 : 16u;
+        const uint32_t m = lzm1 < CAP ? lzm1 : CAP;
         return ((0xFFFFu >> m) << 16) | (0xFFFEu - (((lzm1 - m) << 10) | sig));
     }
     __device__ __forceinline__ void push_rank(uint32_t bucket, uint32_t lzm1, uint32_t sig, uint32_t vm) const
     { asm volatile("ds_min_u32 %0, %1" ::"v"(bucket << 2), "v"(encode(lzm1, sig) | ~vm) : "memory"); }
-    // lzm1 <= 18 (the 18-bit fast form): exact up to 16, 17 and 18 go in as 16 — an under-estimate, and the caller re-runs those
-    // (THR_REDO) — which makes the word three instructions
+    // lzm1 <= 18 (the 18-bit fast form): exact up to the cap, what lies beyond goes in as the cap — an under-estimate, and the caller
+    // re-runs those (REDO_BELOW) — which makes the word three instructions (four with the cap at 14)
     __device__ __forceinline__ void push_rank_fast(uint32_t bucket, uint32_t lzm1, uint32_t sig, uint32_t vm) const
-    { asm volatile("ds_min_u32 %0, %1" ::"v"(bucket << 2), "v"((((0xFFFF0000u >> lzm1) & 0xFFFF0000u) | (0xFFFEu - sig)) | ~vm) : "memory"); }
+    {
+        uint32_t thr = (0xFFFF0000u >> lzm1) & 0xFFFF0000u;
+        if constexpr (CAP < 16u) thr |= (0xFFFF0000u >> CAP) & 0xFFFF0000u;
+        asm volatile("ds_min_u32 %0, %1" ::"v"(bucket << 2), "v"((thr | (0xFFFEu - sig)) | ~vm) : "memory");
+    }
     __device__ __forceinline__ uint32_t get(uint32_t i) const                 // -> the table word LdsRegs would hold
     {
         const uint32_t w = base[i];
@@ -354,6 +365,8 @@ struct LdsThrRegs {
     }
     static __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 };
+using LdsThrRegs = LdsThrRegsT<16u>;      // x = high half (the default)
+using LdsThrRegsX = LdsThrRegsT<14u>;     // x = low half
 
 enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_BINS = 2, REGS_BYTES = 3 };
 
@@ -364,19 +377,26 @@ enum { REGS_LDS = 0, REGS_GLOBAL = 1, REGS_BINS = 2, REGS_BYTES = 3 };
 // counted value is 0 (probability 2^-32 per k-mer).  The fast form counts in the top word only
 // (one v_ffbh_u32) and returns `t`; when t == 0 it has pushed a harmless under-estimate (max) or nothing (OR),
 // and the caller re-runs the word with FAST = false — legal because max/OR are idempotent.
+//
+// XLOW is the rule's VARIANT (round 6: every unpinned register rule is a compile-time form of the same kernels, not a separate slow
+// route): HyperMinHash — x (bucket, rank) is the LOW half of xxh3_128 and y (signature) the high one (layout.hmh_x_low, SURVEY App. D
+// U1); HyperLogLog — the bucket is the TOP p bits of the hash and rho counts the zeros below them (layout.hll_bucket_high, U3);
+// UltraLogLog has no variant.
 // ------------------------------------------------------------------------------------------------------------
-template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs, bool HLL_HIGH = false, bool VSH = false>
+template <int ALGO, bool XLOW, bool MASKED, bool FAST, class Regs, bool VSH = false>
 __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, uint32_t c_hi, uint32_t vm,
                                              BitFlip bitflip, int p, uint32_t ull_sh28 = 0)
 {
+    constexpr bool HLL_HIGH = ALGO == 1 && XLOW;
     if constexpr (ALGO == 0) {
         // utils.rs:395-398: Sketch::add_bytes_with_seed(&(masked as u32).to_le_bytes(), seed)
         (void)c_hi;                                      // k > 16: only the low 32 bits are hashed
-        if constexpr (FAST && !XLOW) {
+        if constexpr (FAST) {
             // rank from the 18 bits of x that share a word with the bucket: t18 = those bits, left-aligned, padded
             // with ones -> clz(t18) = lz - 1 when any of them is set, else 18 (an under-estimate; re-run by caller)
             uint32_t xh, sig;
-            xxh3_128_4b_hmh_fast(c_lo, bitflip, xh, sig);
+            if constexpr (XLOW) xxh3_128_4b_hmh_fast_xlow(c_lo, bitflip, xh, sig);
+            else xxh3_128_4b_hmh_fast(c_lo, bitflip, xh, sig);
             const uint32_t t18 = (xh << 14) | 0x3FFFu;
             if constexpr (Regs::THR) {
                 regs.push_rank_fast(xh >> 18, ffbh_u32(t18), sig, MASKED ? vm : 0xFFFFFFFFu);
@@ -385,7 +405,7 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
                 if constexpr (MASKED) raw |= ~vm;
                 regs.smax(xh >> 18, raw);
             }
-            return t18;                                  // < 0x4000 <=> all 18 rank bits were zero (LdsThrRegs: < 0x8000, 17 of them)
+            return t18;                                  // < 0x4000 <=> all 18 rank bits were zero (LdsThrRegs: < REDO_BELOW, a rank beyond its cap)
         } else {
             uint64_t lo, hi;
             xxh3_128_4b(c_lo, bitflip, lo, hi);
@@ -393,15 +413,9 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x;
             const uint32_t bucket = xh >> 18;                                // x >> 50
             const uint32_t th = alignbit(xh, xl, 18);                        // high word of (x << 14) ^ 0x3FFF
-            uint32_t lzm1;                                                   // lz - 1; FAST with th == 0: 0xFFFFFFFF, a raw word
-            if constexpr (FAST) {                                            // below "empty" (an under-estimate: nothing happens)
-                lzm1 = ffbh_u32(th);
-            } else {
-                const uint32_t tl = (xl << 14) | 0x3FFFu;                    // low word, never 0
-                lzm1 = clz64_nz(th, tl);                                     // lz = lzm1 + 1 = 1..=51
-            }
+            const uint32_t tl = (xl << 14) | 0x3FFFu;                        // low word, never 0
+            const uint32_t lzm1 = clz64_nz(th, tl);                          // lz = lzm1 + 1 = 1..=51
             if constexpr (Regs::THR) {
-                static_assert(!FAST || !Regs::THR, "deferring launches use the 18-bit fast form or the exact one");
                 regs.push_rank(bucket, lzm1, (uint32_t)y & 0x3FFu, MASKED ? vm : 0xFFFFFFFFu);
             } else {
                 uint32_t raw = (lzm1 << 10) | ((uint32_t)y & 0x3FFu);        // flush: + 0x400 = (lz << 10) | sig
@@ -427,12 +441,26 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             else regs.smax(j, raw);
             return gh;
         }
+        if constexpr (FAST && HLL_HIGH) {
+            // layout.hll_bucket_high (SURVEY App. D, U3 alternative): bucket = top p bits, rho - 1 = leading zeros of the 64 - p bits
+            // below them — UltraLogLog's (index, nlz) to the letter (the all-zero tail gives 64 - p under both paddings), so its fast
+            // form applies: the top word of h << p without materialising the last xorshift, the index from above the xorshift's reach
+            const uint64_t g = xxh3_64_8b_pre(c_lo, c_hi, bitflip);
+            const uint32_t gh = (uint32_t)(g >> 32), gl = (uint32_t)g;
+            const uint32_t t28 = gh >> (VSH ? ull_sh28 : (uint32_t)(28 - p));
+            const uint32_t th = alignbit(gh, gl, 32 - p) ^ t28;
+            uint32_t raw = ffbh_u32(th);                                        // th == 0 -> "empty" (nothing happens; re-run by the caller)
+            if constexpr (MASKED) raw |= ~vm;
+            const uint32_t jh = gh >> (32 - p);
+            if constexpr (Regs::BINS) regs.push(jh, raw);
+            else if constexpr (Regs::BYTES) regs.hll_max(jh, raw);
+            else regs.smax(jh, raw);
+            return th;
+        }
         const uint64_t h = xxh3_64_8b(c_lo, c_hi, bitflip);
         const uint32_t hh = (uint32_t)(h >> 32), hl = (uint32_t)h;
         if constexpr (HLL_HIGH) {
-            // layout.hll_bucket_high (SURVEY App. D, U3 alternative; ALT kernels, exact form only): bucket = top p bits,
-            // rho = 1 + leading zeros of the lower 64-p bits = clz64((h << p) | 2^(p-1)) + 1
-            static_assert(!FAST || !HLL_HIGH, "the alternative bucket rule has no fast form");
+            // the exact form: rho = 1 + leading zeros of the lower 64-p bits = clz64((h << p) | 2^(p-1)) + 1
             const uint32_t jh = hh >> (32 - p);
             uint32_t raw = clz64_nz(alignbit(hh, hl, 32 - p), (hl << p) | (1u << (p - 1)));
             if constexpr (MASKED) raw |= ~vm;
@@ -498,6 +526,16 @@ __device__ __forceinline__ uint32_t add_kmer(const Regs &regs, uint32_t c_lo, ui
             return th;
         }
     }
+}
+
+// what a FAST form's return value must exceed for its update to stand (the callers re-run the exact form at or below it): HyperMinHash
+// looks at the 18 rank bits of the bucket's word (t18 < 0x4000: all zero; threshold tables: a rank beyond their cap), the others at 32 bits
+template <int ALGO, class Regs>
+__host__ __device__ constexpr uint32_t z_redo()
+{
+    if constexpr (ALGO != 0) return 0u;
+    else if constexpr (Regs::THR) return Regs::REDO_BELOW - 1u;
+    else return 0x3FFFu;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -567,7 +605,6 @@ __device__ __forceinline__ uint64_t uniform_valid_mask(uint32_t pos0, uint32_t R
 struct KParams {
     BitFlip bitflip;
     uint64_t mask_gt;      // KM_GT16: low 2k bits
-    uint64_t lsb_xor;      // ALT: 0, or (layout.kmer_lsb_first) the complement mask on the low 2k bits
     uint32_t sh_lt;        // KM_LT16: 32 - 2k            (these two and mask_hi sit in VECTOR registers in the hot kernels: a VOP2
     uint32_t mask_lt;      // KM_LT16: low 2k bits          with a scalar source issues in 4.4 cycles, with two vector sources in 2.6-2.9)
     uint32_t mask_hi;      // KM_GT16: bits 63:32 of mask_gt (its low word is all ones: 2k > 32)
@@ -620,11 +657,13 @@ __device__ __forceinline__ void canon_gt16(int r, uint32_t c0, uint32_t c1, uint
     min_u64(f_lo, f_hi, q_lo, q_hi, can_lo, can_hi);                           // km.min(rc), utils.rs:494
 }
 
-// ALT (layout.kmer_lsb_first / hll_bucket_high; SURVEY App. D alternatives of U5 / U3): with the first base of a k-mer in
-// its LEAST significant bits the iterator's value is the group-reversed window, and
-//     groups_reversed(fwd) = rc ^ cm,   its reverse complement = fwd ^ cm      (cm = complement mask on 2k bits),
-// because rc = groups_reversed(fwd ^ cm) and cm reads the same in both directions.  Two extra XORs per k-mer, exact forms only.
-template <int ALGO, int KMODE, bool XLOW, bool MASKED, bool FAST, class Regs, bool ALT = false, bool HLL_HIGH = false, int K = 0>
+// layout.kmer_lsb_first (SURVEY App. D, U5 alternative: a k-mer's FIRST base in its least significant bits) needs no code here:
+// the iterator's value is then the group-reversed window, and with cm = the complement mask on 2k bits
+//     groups_reversed(fwd) = rc ^ cm,   its reverse complement = fwd ^ cm,
+// i.e. the pair {fwd, rc} of the stream c ^ cm.  x ^ cm maps every base's code to its complement's, so the lsb-first k-mers ARE the
+// msb-first k-mers under the complemented code table — layout_dev() hands the kernels that table (round 6; rounds 2-5 ran a separate
+// always-masked, packed-only kernel family for it at 0.55-0.72 of the default's rate).
+template <int ALGO, int KMODE, bool XLOW, bool MASKED, bool FAST, class Regs, int K = 0>
 __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams &kp, uint32_t c0, uint32_t c1,
                                                  uint32_t c2, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t kvw)
 {
@@ -633,25 +672,15 @@ __device__ __forceinline__ uint32_t process_word(const Regs &regs, const KParams
     for (int r = 0; r < 16; ++r) {
         const uint32_t vm = MASKED ? (uint32_t)__builtin_amdgcn_sbfe((int)kvw, r, 1) : 0xFFFFFFFFu;   // 0 or ~0
         uint32_t can_lo, can_hi = 0;
-        if constexpr (KMODE == KM_GT16 && !ALT) {
+        if constexpr (KMODE == KM_GT16) {
             canon_gt16<K>(r, c0, c1, c2, r0, r1, r2, kp, can_lo, can_hi);
-        } else if constexpr (KMODE == KM_GT16) {
-            const uint32_t fh = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
-            const uint32_t fl = r ? alignbit(c1, c2, 32 - 2 * r) : c1;
-            const uint64_t fwd = (((uint64_t)fh << 32) | fl) >> kp.sh_gt;
-            const uint32_t rl = r ? alignbit(r1, r0, 2 * r) : r0;
-            const uint32_t rh = (r ? alignbit(r2, r1, 2 * r) : r1) & kp.mask_hi;     // (the mask's low word is all ones)
-            const uint64_t rc = ((uint64_t)rh << 32) | rl;
-            // first base least significant: the iterator's value is the group-reversed window (see above); lsb_xor == 0: min(rc, fwd)
-            min_u64((uint32_t)(rc ^ kp.lsb_xor), (uint32_t)((rc ^ kp.lsb_xor) >> 32), (uint32_t)(fwd ^ kp.lsb_xor), (uint32_t)((fwd ^ kp.lsb_xor) >> 32), can_lo, can_hi);
         } else {
             uint32_t fwd = r ? alignbit(c0, c1, 32 - 2 * r) : c0;
             uint32_t rc = r ? alignbit(r1, r0, 2 * r) : r0;
             if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
-            if constexpr (ALT) { fwd ^= (uint32_t)kp.lsb_xor; rc ^= (uint32_t)kp.lsb_xor; }   // min() is symmetric: no swap needed
             can_lo = fwd < rc ? fwd : rc;                                        // utils.rs:470,482
         }
-        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, HLL_HIGH, !ALT>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28);
+        const uint32_t t = add_kmer<ALGO, XLOW, MASKED, FAST, Regs, true>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28);
         zacc = zacc < t ? zacc : t;
         if constexpr (Regs::QUEUED) { if ((r & 3) == 3) regs.check(); }        // (LdsByteQRegs: is some lane's stack full?)
     }
@@ -680,7 +709,7 @@ __device__ __forceinline__ uint32_t process_quarter(const Regs &regs, const KPar
             if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
             can_lo = fwd < rc ? fwd : rc;
         }
-        const uint32_t t = add_kmer<ALGO, XLOW, true, FAST, Regs, false, true>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28);
+        const uint32_t t = add_kmer<ALGO, XLOW, true, FAST, Regs, true>(regs, can_lo, can_hi, vm, kp.bitflip, kp.p, kp.ull_sh28);
         zacc = zacc < t ? zacc : t;
     }
     return zacc;
@@ -733,8 +762,8 @@ __device__ __forceinline__ void sigq_drain(const Regs &regs, BitFlip bitflip, in
         if (q.ptr != q.lane_b) {
             q.ptr -= 4u;
             const uint32_t c = lds_load(q.ptr);
-            const uint32_t t = add_kmer<0, false, false, true>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
-            if (t < 0x8000u) (void)add_kmer<0, false, false, false>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);   // rank 17 and up: exact form
+            const uint32_t t = add_kmer<0, Regs::XLOW, false, true>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);
+            if (t < Regs::REDO_BELOW) (void)add_kmer<0, Regs::XLOW, false, false>(regs, c, 0u, 0xFFFFFFFFu, bitflip, p);   // a rank beyond the threshold's cap: exact form
         }
     } while (__builtin_amdgcn_ballot_w64(ALL ? q.ptr != q.lane_b : q.ptr > q.lim) != 0ull);
 }
@@ -761,7 +790,7 @@ __device__ __forceinline__ void process_word_defer(const Regs &regs, const KPara
                 if constexpr (KMODE == KM_LT16) { fwd >>= kp.sh_lt; rc &= kp.mask_lt; }
                 can[j] = fwd < rc ? fwd : rc;
             }
-            const uint32_t xh = xxh3_128_4b_hmh_rank(can[j], kp.bitflip);
+            const uint32_t xh = Regs::XLOW ? xxh3_128_4b_hmh_rank_xlow(can[j], kp.bitflip) : xxh3_128_4b_hmh_rank(can[j], kp.bitflip);
 #ifdef LASH_ABL_DEFER_NO_READ
             cur[j] = (xh >> 16) & 0xFFFCu;
 #else
@@ -1433,7 +1462,7 @@ inline __device__ __noinline__ uint32_t dense_tile(const Regs regs, const KParam
             asm volatile("" : "+v"(kvw));
             z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
         }
-        constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? (Regs::THR ? 0x7FFFu : 0x3FFFu) : 0u;
+        constexpr uint32_t Z_REDO = z_redo<ALGO, Regs>();
         if (z <= Z_REDO) {
             uint32_t kvw = (uint32_t)kv;
             asm volatile("" : "+v"(kvw));

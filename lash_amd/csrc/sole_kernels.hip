@@ -24,6 +24,8 @@
 // Bit-exact by the same argument as everywhere else: max / OR are commutative and idempotent, so the order in which a genome's
 // k-mers reach the table does not matter, and the k-mer multiset is the reference's: windows of the filtered
 // sequence that do not span a record start (utils.rs:457-499).
+#include <atomic>
+
 #include "sketch_rules.h"
 
 namespace lash {
@@ -177,7 +179,6 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
     kp.mask_gt = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
     kp.mask_hi = (uint32_t)(kp.mask_gt >> 32);
     kp.to_vector_registers();
-    kp.lsb_xor = 0ull;
     const uint32_t cmask = a.lay.comp_mask;
     const CodeTabs ct{a.lay.code_lo, a.lay.code_hi};
     const uint32_t ring_b = a.ring_off, brk_b = a.brk_off, scan_b = a.scan_off;
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                 uint32_t m = kvw;
                 asm volatile("" : "+v"(m));
                 const uint32_t z = process_quarter<ALGO, KMODE, XLOW, true>(regs, kp, c0, c1, c2, r0, r1, r2, m, rq + 4u * i);
-                constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+                constexpr uint32_t Z_REDO = z_redo<ALGO, LdsRegs>();
                 if (z <= Z_REDO) (void)process_quarter<ALGO, KMODE, XLOW, false>(regs, kp, c0, c1, c2, r0, r1, r2, m, rq + 4u * i);
             }
             return;
@@ -248,11 +249,11 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
         kmers_wave += all_valid ? 1024u : wave_sum((uint32_t)__builtin_popcount(kvw));
         uint32_t z;
         if (K21 && k == 21) {
-            if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true, LdsRegs, false, false, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
+            if (all_valid) z = process_word<ALGO, KMODE, XLOW, false, true, LdsRegs, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
             else {
                 uint32_t m = kvw;
                 asm volatile("" : "+v"(m));
-                z = process_word<ALGO, KMODE, XLOW, true, true, LdsRegs, false, false, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, m);
+                z = process_word<ALGO, KMODE, XLOW, true, true, LdsRegs, K21 ? 21 : 0>(regs, kp, c0, c1, c2, r0, r1, r2, m);
             }
         } else if (all_valid) {
             z = process_word<ALGO, KMODE, XLOW, false, true>(regs, kp, c0, c1, c2, r0, r1, r2, 0u);
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
             z = process_word<ALGO, KMODE, XLOW, true, true>(regs, kp, c0, c1, c2, r0, r1, r2, m);
         }
         // the fast forms return a word whose smallness says "rank not decided by the bits looked at": the exact form again (idempotent)
-        constexpr uint32_t Z_REDO = (ALGO == 0 && !XLOW) ? 0x3FFFu : 0u;
+        constexpr uint32_t Z_REDO = z_redo<ALGO, LdsRegs>();
         if (z <= Z_REDO) {
             uint32_t m = kvw;
             asm volatile("" : "+v"(m));
@@ -632,7 +633,7 @@ static hipError_t launch_sole_algo(const SolePlan &plan, int algo, int k, bool x
 {
     switch (algo) {
     case 0: return x_low ? launch_sole_kmode<0, true, PACKED>(plan, k, args, n_wg, stream, occ) : launch_sole_kmode<0, false, PACKED>(plan, k, args, n_wg, stream, occ);
-    case 1: return launch_sole_kmode<1, false, PACKED>(plan, k, args, n_wg, stream, occ);
+    case 1: return x_low ? launch_sole_kmode<1, true, PACKED>(plan, k, args, n_wg, stream, occ) : launch_sole_kmode<1, false, PACKED>(plan, k, args, n_wg, stream, occ);
     case 2: return launch_sole_kmode<2, false, PACKED>(plan, k, args, n_wg, stream, occ);
     default: return hipErrorInvalidValue;
     }
@@ -650,18 +651,20 @@ hipError_t sole_resident_per_cu(const SolePlan &plan, int algo, int k, bool x_lo
 {
     if (!plan.ok) return hipErrorInvalidValue;
     // asked once per kernel variant and workgroup shape
-    struct Entry { uint32_t occ, lds; };
-    static Entry cache[2][3][3][2][9] = {};
-    if (algo < 0 || algo > 2) return hipErrorInvalidValue;
-    Entry &c = cache[packed ? 1 : 0][algo][k == 16 ? 0 : k < 16 ? 1 : 2][x_low ? 1 : 0][plan.threads / 64u];
-    if (!c.occ || c.lds != plan.lds_bytes) {
+    // (one entry = {occupancy, LDS bytes it was asked with} in ONE atomic word: `lash sketch --gpus N` runs a thread per device through here)
+    static std::atomic<uint64_t> cache[2][3][3][2][17] = {};
+    if (algo < 0 || algo > 2 || plan.threads / 64u > 16u) return hipErrorInvalidValue;
+    std::atomic<uint64_t> &c = cache[packed ? 1 : 0][algo][k == 16 ? 0 : k < 16 ? 1 : 2][x_low ? 1 : 0][plan.threads / 64u];
+    uint64_t e64 = c.load(std::memory_order_acquire);
+    if ((uint32_t)e64 == 0u || (uint32_t)(e64 >> 32) != plan.lds_bytes) {
         SoleArgs none{};
         uint32_t occ = 0;
         hipError_t e = packed ? launch_sole_algo<true>(plan, algo, k, x_low, none, 0, nullptr, &occ) : launch_sole_algo<false>(plan, algo, k, x_low, none, 0, nullptr, &occ);
         if (e != hipSuccess) return e;
-        c.occ = occ; c.lds = plan.lds_bytes;
+        e64 = ((uint64_t)plan.lds_bytes << 32) | occ;
+        c.store(e64, std::memory_order_release);
     }
-    *out = c.occ;
+    *out = (uint32_t)e64;
     return hipSuccess;
 }
 

@@ -70,6 +70,15 @@ def main():
         if os.environ.get("FUZZ_P") and an != "hmh":      # e.g. FUZZ_P=15,16,17: the byte tables (hll: p <= 16)
             p = min(rng.choice([int(x) for x in os.environ["FUZZ_P"].split(",")]), 16 if an == "hll" else 26)
         seed = rng.choice([0, 42, rng.getrandbits(64)])
+        # round 6: the unpinned register / k-mer rules are compile-time variants of every kernel family — drawn per iteration (FUZZ_LAYOUT pins one;
+        # FUZZ_LAYOUT=default pins the default)
+        lrng = random.Random(seed0 * 7000003 + it)
+        spec = lrng.choice([None, None, None, "hmh_x=low", "kmer=lsb", "hll_bucket=high", "codes=GATC,kmer=lsb,hll_bucket=high,hmh_x=low"])
+        if os.environ.get("FUZZ_LAYOUT"):
+            spec = None if os.environ["FUZZ_LAYOUT"] == "default" else os.environ["FUZZ_LAYOUT"]
+        ctx.set_layout(spec)
+        lay = O.parse_layout(spec) if spec else None
+        knobs += " layout=%s" % (spec or "default")
         flags = rng.choice([0, 0, lash_amd.F_NO_DIRECT, lash_amd.F_STREAM_ONLY]) | (lash_amd.F_HMH_X_LOW if an == "hmh" and rng.random() < 0.2 else 0)
         gs = [random_genome(rng) for _ in range(rng.randint(1, 12))]
         seq, off, goff = lash_amd.records_to_arrays(gs)
@@ -89,7 +98,7 @@ def main():
             d_seq = torch.from_numpy(seq).cuda()
             d_off = torch.from_numpy(off.astype(np.int64)).cuda()
             gbo = off[goff.astype(np.int64)]
-            d_img = torch.zeros(len(gs) * lash_amd.image_bytes(an, p), dtype=torch.uint8, device="cuda")
+            d_img = torch.zeros(len(gs) * ctx.image_bytes(an, p), dtype=torch.uint8, device="cuda")
             if mode == "device":
                 ctx.sketch_batch_device(an, k, p, seed, d_seq, d_off, len(off) - 1, goff, gbo, d_img, flags=flags)
             else:
@@ -109,7 +118,7 @@ def main():
         ctx.enable_timing(False)
         if mode == "packed":
             kmers //= 2                                      # sketched twice
-        want = O.sketch_genomes(ALGO[an], k, p, seed, seq, off, goff, threads=8, hmh_x_is_low=1 if flags & lash_amd.F_HMH_X_LOW else 0)
+        want = O.sketch_genomes(ALGO[an], k, p, seed, seq, off, goff, threads=8, hmh_x_is_low=1 if flags & lash_amd.F_HMH_X_LOW else 0, layout=lay)
         want_kmers = sum(len(O.record_kmers(r, k)) for g in gs for r in g)
         if not np.array_equal(got, want) or kmers != want_kmers:
             bad = sorted({int(r) for r in np.argwhere(got != want)[:, 0]}) if got.shape == want.shape else "shape"

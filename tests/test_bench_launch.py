@@ -88,3 +88,47 @@ def test_more_ranks_than_gpus_is_refused_in_one_line(monkeypatch, capsys):
         b.main()
     except SystemExit as e:
         assert e.code == 0 and launched
+
+
+def _evidence_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        b = _bench()
+        ev = b.rank_evidence(torch, dist, torch.device("cpu"), rank, world, rank, {"elapsed_ms": 10.0 + rank, "sketch_ms": 9.0, "kmers_census": 7 * (rank + 1)})
+        q.put((rank, ev))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_evidence_over_gloo_world_size_3():
+    """every rank's own time, host, process and device identity reach the JSON line through the backend, with a count
+    (all_reduce SUM of ones) that proves how many ranks the communicator joined.  World size 3 over gloo here; nccl (= RCCL) on the node."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_evidence_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(3):
+        ev = got[r]
+        assert ev["backend"] == "gloo" and ev["ranks_seen"] == 3 == ev["ranks_expected"]
+        assert ev["per_rank_ms"] == [10.0, 11.0, 12.0] and abs(ev["imbalance"] - 1.2) < 1e-12
+        assert [x["rank"] for x in ev["per_rank"]] == [0, 1, 2] and [x["kmers_census"] for x in ev["per_rank"]] == [7, 14, 21]
+        assert len({x["pid"] for x in ev["per_rank"]}) == 3 and len(ev["devices"]) == 3
+    # one rank, no process group: the same fields
+    import torch
+    one = _bench().rank_evidence(torch, None, torch.device("cpu"), 0, 1, 0, {"elapsed_ms": 5.0})
+    assert one["ranks_seen"] == 1 and one["per_rank_ms"] == [5.0] and one["imbalance"] == 1.0 and one["devices_distinct"] == 1

@@ -25,6 +25,17 @@ def _check_line(r):
     kmers = 2 * 40 * (5_000_000 - 16 + 1) * 3                    # both ranks' genomes, every step
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 * 3 / kmers - 1) < 1e-6
     assert j["roofline"]["frac"] > 0 and j["roofline_valu"]["bound"] == "valu-issue"
+    _check_ranks(j, 2)
+
+
+def _check_ranks(j, n):
+    """VERDICT r5 next #3: the line carries what every rank measured and on which device, and a count that went THROUGH the backend."""
+    r = j["ranks"]
+    assert r["ranks_seen"] == n == r["ranks_expected"] and len(r["per_rank_ms"]) == n and len(r["devices"]) == n
+    assert [q["rank"] for q in r["per_rank"]] == list(range(n)) and len({q["pid"] for q in r["per_rank"]}) == n
+    assert all(q["hostname"] and q["device"]["id"] for q in r["per_rank"])
+    assert r["imbalance"] >= 1.0 and abs(max(r["per_rank_ms"]) / j["ms_per_step"] - 1) < 0.05       # ms_per_step = the slowest rank's
+    assert 1 <= r["devices_distinct"] <= n                      # (the dry run's ranks share a GPU; on a real node it must equal n: docs/SCALE_RUNBOOK.md)
 
 
 def test_two_ranks_dry_run_on_one_gpu():
@@ -70,11 +81,18 @@ def test_every_workload_rehearses_with_two_ranks():
     j = _one_line(r)
     assert j["n_gpus"] == 2 and "DRY RUN" in j["data"] and j["cpu_baseline"] is None
     assert abs(j["value"] * j["ms_per_step"] * 1e-3 * 2 / (2 * 2_000_000 * (150 - 16 + 1) * 2) - 1) < 1e-6
+    _check_ranks(j, 2)
+    assert [q["kmers_census"] for q in j["ranks"]["per_rank"]] == [2_000_000 * (150 - 16 + 1) * 2] * 2      # every rank's device census
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "allpairs", "--genomes", "300",
                         "--length", "200000"], cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
     j = _one_line(r)
     assert j["n_gpus"] == 2 and "DRY RUN" in j["data"] and j["printed_pairs_per_s"] > 0
     assert set(j["stage_ms_rank0"]) == {"sketch", "gather", "set + pairs"}
+    _check_ranks(j, 2)
+    g = j["ranks"]["gather"]
+    assert g["bytes_received_per_rank"] == 300 * 32768 and g["xgmi_peak_GBps_per_gpu"] == 7 * 153.0
+    assert all(q["rows"] > 0 and q["gather_stage_ms"] >= 0 for q in j["ranks"]["per_rank"])
+    assert sum(q["rows"] for q in j["ranks"]["per_rank"]) == 600                                       # the bands cover the matrix
 
 
 def test_asking_for_more_gpus_than_the_box_has_fails_in_one_line():

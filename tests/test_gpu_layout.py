@@ -108,3 +108,97 @@ def test_layout_raw_files_and_pair_kernels(ctx, spec):
                 assert zero[i, j] == int((u == 0).sum()) and abs(usum[i, j] - float(np.sum(2.0 ** -u.astype(np.float64)))) < 1e-9
     finally:
         ctx.set_layout(None)
+
+
+# Round 6: every rule alternative is a compile-time variant of EVERY kernel family, not a packed-only slow route.
+# One alternative at a time and all of them together, through each route the library can take for a genome: the persistent small-genome
+# kernel (the default for genomes <= LASH_SOLE_MAX), the sliced direct kernel (with and without deferred signatures), the compacting
+# stream kernel, the pack-first route, large register tables as bytes and as bins.
+RULE_SPECS = ["hmh_x=low", "kmer=lsb", "hll_bucket=high", "codes=GATC,kmer=lsb,hll_bucket=high,hmh_x=low"]
+
+
+def _route_genomes(rng):
+    gs = _genomes(rng, clean=False)
+    gs.append([O.synth_genome(78, 1_300_000).tobytes()])             # work items long enough for the deferring launch's default threshold
+    soft = bytearray(O.synth_genome(79, 400_000).tobytes())           # a soft-masked stretch and an N gap: junction walks, dense tiles, stream
+    soft[100_000:160_000] = bytes(soft[100_000:160_000]).lower()
+    soft[300_000:300_700] = b"N" * 700
+    gs.append([bytes(soft[:250_000]), bytes(soft[250_000:])])
+    return gs
+
+
+@pytest.mark.sole
+@pytest.mark.parametrize("spec", RULE_SPECS)
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hmh", 9, 0), ("hmh", 27, 0), ("hll", 21, 14), ("hll", 16, 10), ("hll", 12, 16),
+                                    ("ull", 16, 12), ("ull", 31, 15)])
+def test_rule_alternatives_through_every_route(ctx, spec, an, k, p, monkeypatch):
+    import lash_amd
+    lay = O.parse_layout(spec)
+    ctx.set_layout(spec)
+    try:
+        seed = zlib.crc32(repr(("routes", spec, an, k, p)).encode())
+        seq, off, goff = lash_amd.records_to_arrays(_route_genomes(random.Random(seed)))
+        want = O.sketch_genomes(ALGO[an], k, p, 42, seq, off, goff, threads=8, layout=lay)
+        routes = [("default (small genomes through the persistent kernel)", 0, {}),
+                  ("sliced direct kernel", lash_amd.F_NO_SOLE, {}),
+                  ("sliced direct kernel, every HyperMinHash launch deferring", lash_amd.F_NO_SOLE, {"LASH_DEFER_MIN": "0"}),
+                  ("stream kernel", lash_amd.F_STREAM_ONLY, {}),
+                  ("stream kernel, deferring", lash_amd.F_STREAM_ONLY, {"LASH_DEFER_MIN": "0"}),
+                  ("pack first", lash_amd.F_NO_DIRECT | lash_amd.F_NO_SOLE, {}),
+                  ("pack first, persistent kernel on packed words", lash_amd.F_NO_DIRECT, {})]
+        if p >= 15:
+            routes.append(("bins instead of byte tables", lash_amd.F_NO_SOLE, {"LASH_NO_BYTES": "1"}))
+        for name, flags, envs in routes:
+            if "LASH_DEFER_MIN" in envs and an != "hmh":
+                continue
+            with monkeypatch.context() as m:
+                for key, v in envs.items():
+                    m.setenv(key, v)
+                ctx.enable_timing(True)
+                got = ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=flags)
+                tm = ctx.timing()
+                ctx.enable_timing(False)
+            assert got.shape == want.shape and np.array_equal(got, want), (spec, an, k, p, name, seed)
+            if envs.get("LASH_DEFER_MIN") == "0" and not (flags & lash_amd.F_STREAM_ONLY):
+                assert tm["defer_launches"] >= 1, (spec, name, tm)      # x = low defers like the default (round 6)
+            if flags == 0 and p <= 14:                                   # (a table the persistent kernel's LDS budget holds)
+                assert tm["sole_launches"] >= 1, (spec, name, tm)       # no layout keeps a genome from the persistent kernel any more
+            if flags == lash_amd.F_NO_SOLE and not envs:
+                assert tm["direct_launches"] >= 1, (spec, name, tm)     # ... or from the ASCII-reading kernels
+    finally:
+        ctx.set_layout(None)
+
+
+@pytest.mark.parametrize("spec,an,k,p", [("hmh_x=low", "hmh", 16, 0), ("kmer=lsb", "hmh", 16, 0), ("kmer=lsb", "ull", 16, 12),
+                                         ("hll_bucket=high", "hll", 21, 14), ("kmer=lsb", "hll", 21, 14)])
+def test_rule_alternatives_full_size_spot_check(ctx, spec, an, k, p):
+    """40 x 5 Mbp per alternative, ASCII resident in HBM -> the judged kernels' variants at the size bench.py runs them
+    (sliced direct kernel, HyperMinHash deferring by itself); three genomes against the oracle, the census against L - k + 1."""
+    import torch
+    import lash_amd
+    G, L = 40, 5_000_000
+    lay = O.parse_layout(spec)
+    ctx.set_layout(spec)
+    try:
+        d_seq = torch.empty(G * L, dtype=torch.uint8, device="cuda:0")
+        ctx.synth_genomes_device(3000, G, L, d_seq)
+        rec_off = np.arange(G + 1, dtype=np.uint64) * np.uint64(L)
+        goff = np.arange(G + 1, dtype=np.uint64)
+        d_rec = torch.from_numpy(rec_off.astype(np.int64)).cuda()
+        ib = ctx.image_bytes(an, p)
+        d_img = torch.zeros(G * ib, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.enable_timing(True)
+        ctx.sketch_batch_device(an, k, p, 42, d_seq, d_rec, G, goff, rec_off, d_img)
+        tm = ctx.timing()
+        ctx.enable_timing(False)
+        assert tm["kmers"] == G * (L - k + 1) and tm["direct_launches"] == 1, tm
+        if an == "hmh" and "LASH_DEFER_MIN" not in __import__("os").environ:
+            assert tm["defer_launches"] == 1, tm
+        img = d_img.view(G, ib).cpu().numpy()
+        for g in (0, 17, G - 1):
+            want = O.sketch_genomes(ALGO[an], k, p, 42, O.synth_genome(3000 + g, L), np.array([0, L], np.uint64), np.array([0, 1], np.uint64),
+                                    layout=lay)[0]
+            assert np.array_equal(img[g], want), (spec, an, g)
+    finally:
+        ctx.set_layout(None)
