@@ -809,9 +809,34 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             }
         } else {
             if (!pk->stream_first) {
+                // diagnostic, LASH_ITEM_TRACE=file (tools/item_trace.py): when and where every workgroup of this launch ran, appended as text
+                const char *trace_path = getenv("LASH_ITEM_TRACE");
+                unsigned long long *d_trace = nullptr;
+                if (trace_path && n_items) {
+                    HIPCHK(ctx, hipMalloc(&d_trace, (size_t)n_items * 32));
+                    HIPCHK(ctx, hipMemsetAsync(d_trace, 0, (size_t)n_items * 32, ctx->stream));
+                    sa.item_trace = d_trace;
+                }
                 if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));       // direct_ms: this one launch
                 HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
                 if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
+                if (d_trace) {
+                    std::vector<unsigned long long> h((size_t)n_items * 4);
+                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                    HIPCHK(ctx, hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost));
+                    (void)hipFree(d_trace);
+                    sa.item_trace = nullptr;
+                    if (FILE *f = fopen(trace_path, "a")) {
+                        fprintf(f, "# launch: %u items, %u threads, order %s; columns: launch_index item genome word_begin word_end start_10ns end_10ns hw_id xcc_id\n",
+                                n_items, plan_d.threads, order.empty() ? "item" : "longest first");
+                        for (uint32_t b = 0; b < n_items; ++b) {
+                            const uint32_t i = order.empty() ? b : order[b];
+                            fprintf(f, "%u %u %u %u %u %llu %llu %u %u\n", b, i, items[i].genome, items[i].word_begin, items[i].word_end, h[4ull * i], h[4ull * i + 1],
+                                    (unsigned)(h[4ull * i + 2] & 0xFFFFFFFFu), (unsigned)(h[4ull * i + 2] >> 32));
+                        }
+                        fclose(f);
+                    }
+                }
                 if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
                 ctx->last.direct_launches += n_items ? 1 : 0;
                 ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;

@@ -34,6 +34,13 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     // workgroups to start are the short ones: a mixed collection lost 11 % to its tail in launch order = genome order
     const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x + a.item_base;
     const WorkItem it = a.items[item];
+    if (a.item_trace && threadIdx.x == 0) {                                // (diagnostic: nothing of it stays live)
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.item_trace[4ull * item] = wall_clock64();
+        a.item_trace[4ull * item + 2] = ((unsigned long long)xcc << 32) | hw;
+    }
     const GenomeDesc gd = a.genomes[it.genome];
     const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
     const int k = a.k, p = a.p;
@@ -359,6 +366,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     if (a.k != 99) return;
 #endif
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
+    if (a.item_trace && threadIdx.x == 0) a.item_trace[4ull * item + 1] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------------

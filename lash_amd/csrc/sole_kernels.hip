@@ -337,6 +337,19 @@ __global__ void __launch_bounds__(512) sole_sketch_kernel(SoleArgs a)
                     bool whole = false;                                                     // the genome is in the ring to its last base
                     uint32_t limit = 0, nk = 0xFFFFFFFFu;                                   // ring words that may be hashed; k-mer starts (known at the end)
                     zero_w = 0; zero_n = 0; bzero = 0;                      // (zero_w too: a stale one made the first pass wipe this genome's early record starts)
+#ifdef LASH_DEBUG_STALE
+                    // Debug build (tools/build_debug_stale.sh): what a genome inherits must be EXACTLY the rest state — both
+                    // rings zero from end to end, and the table armed unless the previous genome's registers still wait in it.  Anything else is
+                    // a stale word that the release build would "mostly" survive (appends OR into it, a max against it): here it traps, and the
+                    // call fails with a HIP error instead of an image that is right for most genomes.
+                    wg_barrier(nw);
+                    for (uint32_t i = tid; i < a.ring_words; i += T) if (lds_load(ring_b + 4u * i) != 0u) __builtin_trap();
+                    for (uint32_t i = tid; i < (a.ring_words >> 1); i += T) if (lds_load(brk_b + 4u * i) != 0u) __builtin_trap();
+                    if (pending == NONE)
+                        for (uint32_t i = tid; i < a.nreg32; i += T) if (lds_regs[i] != (ALGO == 2 ? 0u : RANK_EMPTY)) __builtin_trap();
+                    if (ALGO == 1 && tid < 72u && lds_load(a.hist_off + 4u * tid) != 0u && pending == NONE) __builtin_trap();
+                    wg_barrier(nw);
+#endif
                     for (;;) {
                         if (rel < Lb) {
                             // ---- stage one round: 16 bytes per lane -> survivors -> ring ----

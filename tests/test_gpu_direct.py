@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+import routes as R
 
 pytestmark = pytest.mark.gpu
 ALGO = {"hmh": 0, "hll": 1, "ull": 2}
@@ -55,7 +56,7 @@ def test_clean_genomes_any_alignment(an, k, p):
     got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
     tm = ctx.timing()
     ctx.enable_timing(False)
-    assert tm["direct_launches"] == 1
+    R.assert_ascii_route(tm)
     assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
     same(got, oracle_images(an, k, p, 42, seq, off, goff), "%s k=%d p=%d" % (an, k, p))
     same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), got, "NO_DIRECT")
@@ -161,7 +162,7 @@ def test_every_short_length_on_the_direct_pass(an, k, p):
     ctx.enable_timing(True)
     got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
     tm = ctx.timing()
-    assert tm["direct_launches"] == 1
+    R.assert_ascii_route(tm)
     assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
     same(got, oracle_images(an, k, p, 42, seq, off, goff), "short lengths %s k=%d" % (an, k))
     ctx.close()
@@ -191,7 +192,10 @@ def test_many_small_genomes_write_their_own_images(an, k, p):
     got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
     tm = ctx.timing()
     ctx.enable_timing(False)
-    assert tm["sketch_workgroups"] == sum(1 for g in gs if sum(len(r) for r in g) > 0)     # one work item per non-empty genome
+    if R.sole_on():
+        assert tm["sole_launches"] == 1 and tm["direct_launches"] == 0, tm                   # whole genomes on persistent workgroups, no work items at all
+    else:
+        assert tm["sketch_workgroups"] == sum(1 for g in gs if sum(len(r) for r in g) > 0)     # one work item per non-empty genome
     assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
     same(got, want, "small genomes " + an)
     same(ctx.sketch_batch(an, k, p, 42, seq, off, goff, flags=lash_amd.F_NO_DIRECT), want, "pack-first")
@@ -249,7 +253,7 @@ def test_sparse_dirt_is_handled_in_place(an, k, p):
     got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
     tm = ctx.timing()
     ctx.enable_timing(False)
-    assert tm["direct_launches"] == 1
+    R.assert_ascii_route(tm)
     same(got, want, "sparse dirt in place %s k=%d" % (an, k))
     assert tm["kmers"] == sum(len(O.record_kmers(r, k)) for g in gs for r in g)
     assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g in gs for r in g)

@@ -35,13 +35,17 @@ def test_fuzz_with_deferred_signatures_everywhere():
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("script,iters,seed,ok", [("fuzz_gpu.py", 150, 31, "fuzz ok"), ("fuzz_gpu_raw.py", 100, 32, "raw fuzz ok"),
-                                                  ("fuzz_gpu_cli.py", 12, 33, "cli fuzz ok")])
-def test_fuzz_with_the_persistent_kernel_everywhere(script, iters, seed, ok):
+@pytest.mark.parametrize("script,iters,seed,ok,wgs", [("fuzz_gpu.py", 150, 31, "fuzz ok", "1"), ("fuzz_gpu_raw.py", 100, 32, "raw fuzz ok", "3"),
+                                                      ("fuzz_gpu_cli.py", 12, 33, "cli fuzz ok", None), ("fuzz_gpu.py", 100, 34, "fuzz ok", "3")])
+def test_fuzz_with_the_persistent_kernel_everywhere(script, iters, seed, ok, wgs):
     """Round 5: genomes of at most LASH_SOLE_MAX bytes run on the persistent small-genome kernel (sole_kernels.hip).  By default the
     runners draw that limit per iteration (tests/fuzz_knobs.py: 0, 2 000, 50 000 or the library's default, and the kernel's workgroup
     shape); FUZZ_SOLE=1 pins the default, so that nearly every genome of every iteration — clean, dirty, multi-record, accumulated,
     packed first, raw FASTA / FASTQ bytes, through the CLI — takes the new path, against the oracle as usual."""
+    # Round 6: the number of persistent workgroups is pinned too — 1 and 3 put every genome of an iteration's batch on the same one or three
+    # workgroups, one after the other on the same rings and table (round 5's two late bugs needed exactly that); None = drawn per iteration
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + HERE, FUZZ_SOLE="1")
+    if wgs:
+        env["FUZZ_SOLE_WGS"] = wgs
     r = subprocess.run([sys.executable, os.path.join(HERE, script), str(iters), str(seed)], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and ok in r.stdout, (script, r.stdout[-1500:], r.stderr[-3000:])
+    assert r.returncode == 0 and ok in r.stdout, (script, wgs, r.stdout[-1500:], r.stderr[-3000:])

@@ -172,11 +172,11 @@ def test_rule_alternatives_through_every_route(ctx, spec, an, k, p, monkeypatch)
 @pytest.mark.parametrize("spec,an,k,p", [("hmh_x=low", "hmh", 16, 0), ("kmer=lsb", "hmh", 16, 0), ("kmer=lsb", "ull", 16, 12),
                                          ("hll_bucket=high", "hll", 21, 14), ("kmer=lsb", "hll", 21, 14)])
 def test_rule_alternatives_full_size_spot_check(ctx, spec, an, k, p):
-    """40 x 5 Mbp per alternative, ASCII resident in HBM -> the judged kernels' variants at the size bench.py runs them
+    """40 (hmh: 300) x 5 Mbp per alternative, ASCII resident in HBM -> the judged kernels' variants at the size bench.py runs them
     (sliced direct kernel, HyperMinHash deferring by itself); three genomes against the oracle, the census against L - k + 1."""
     import torch
     import lash_amd
-    G, L = 40, 5_000_000
+    G, L = (300 if an == "hmh" else 40), 5_000_000              # (hmh: enough genomes for work items of >= 0.6 Mbp, the deferring launch's threshold)
     lay = O.parse_layout(spec)
     ctx.set_layout(spec)
     try:

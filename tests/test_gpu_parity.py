@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+import routes as R
 from fastx import read_fastx
 
 pytestmark = pytest.mark.gpu
@@ -284,7 +285,7 @@ def test_device_entries_and_synth_generator(ctx):
     want = oracle_images(0, 16, 0, 42, host, rec_off, goff)
     assert_same(d_out.cpu().numpy().reshape(n_g, ib), want, "device entry")
     assert t["kmers"] == n_g * (L - 15) and t["bases_last"] == n_g * L and t["calls"] == 1
-    assert t["sketch_ms"] > 0 and t["pack_ms"] > 0
+    assert t["sketch_ms"] > 0 and (t["pack_ms"] > 0 or R.sole_on())     # (six 100 kbp genomes: the persistent kernel takes them all, nothing is uploaded for slices)
     # two-stage form: pack once, sketch with several parameter sets
     pk = ctx.pack_device(d_seq, d_rec, n_g, goff, rec_off)
     for an, k, p in (("hll", 21, 14), ("ull", 16, 12), ("hmh", 24, 0)):
