@@ -23,6 +23,17 @@
 using namespace lashhost;
 
 namespace {
+
+// The test-only environment knobs of the host side are read HERE — in the library the tests load — and nowhere in the product objects
+// (VERDICT r5 next #8): LASH_TEST_FAST_INFLATE_FAIL_AFTER=<bytes>, LASH_TEST_FAST_INFLATE_FLIP_AT=<output byte>
+struct TestSeamsFromEnv {
+    TestSeamsFromEnv()
+    {
+        if (const char *e = getenv("LASH_TEST_FAST_INFLATE_FAIL_AFTER")) lashhost::test_seams::inflate_fail_after = atol(e);
+        if (const char *e = getenv("LASH_TEST_FAST_INFLATE_FLIP_AT")) lashhost::test_seams::inflate_flip_at = atol(e);
+    }
+} test_seams_from_env;
+
 char *dup_str(const std::string &s)
 {
     char *p = (char *)malloc(s.size() + 1);

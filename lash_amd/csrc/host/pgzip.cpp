@@ -21,6 +21,11 @@
 
 namespace lashhost {
 
+// fault injectors of the fast-inflate fallback tests (tests/test_host.py): hand the member over to zlib after that many delivered bytes / flip
+// that output byte.  Plain variables here, -1 = off; the environment variables that set them (LASH_TEST_FAST_INFLATE_*) are read by a static
+// initialiser in host_hooks.cpp, which is linked into liblash_host.so (the tests' library) and NOT into the `lash` command
+namespace test_seams { long inflate_fail_after = -1, inflate_flip_at = -1; }
+
 namespace {
 
 size_t member_cap()                                // a speculative worker gives up on a member that inflates beyond this
@@ -106,8 +111,8 @@ struct ParallelGzip::Impl {
     size_t fast_ip = 0;
     uint64_t delivered = 0, z_skip = 0;
     const bool no_fast = getenv("LASH_NO_FAST_INFLATE") != nullptr;
-    const long test_fail_after = getenv("LASH_TEST_FAST_INFLATE_FAIL_AFTER") ? atol(getenv("LASH_TEST_FAST_INFLATE_FAIL_AFTER")) : -1;
-    const long test_flip_at = getenv("LASH_TEST_FAST_INFLATE_FLIP_AT") ? atol(getenv("LASH_TEST_FAST_INFLATE_FLIP_AT")) : -1;   // corrupt that output byte
+    const long test_fail_after = test_seams::inflate_fail_after;   // (-1 in the product: only liblash_host.so's hooks ever set these, host_hooks.cpp)
+    const long test_flip_at = test_seams::inflate_flip_at;         // corrupt that output byte
     uint32_t skip_crc = 0, skip_crc_want = 0;
     // speculative side
     std::mutex mu;

@@ -17,6 +17,8 @@
 
 namespace lashhost {
 
+namespace test_seams { extern long inflate_fail_after, inflate_flip_at; }   // see pgzip.cpp; set only by host_hooks.cpp
+
 class ParallelGzip {
 public:
     ParallelGzip();

@@ -156,9 +156,12 @@ std::string ZstdWriter::write(const void *data, size_t n)
             pend_.clear();
             if (!e.empty()) return e;
         }
-        const size_t full = n / kChunk;                                 // large writes straight from the caller's buffer
-        if (full) {
-            std::string e = frames(p, full, kChunk);
+        // large writes straight from the caller's buffer, a ROUND of the threads at a time: frames() holds every chunk's compressed bytes
+        // until all threads have joined, so one call over a whole multi-GB write would take memory of the write's size, not the
+        // workers x 4 MiB the class promises (a batch of thousands of HyperMinHash images is hundreds of MB per write)
+        const size_t full = n / kChunk;
+        for (size_t done = 0; done < full; done += (size_t)workers_) {
+            std::string e = frames(p + done * kChunk, std::min<size_t>((size_t)workers_, full - done), kChunk);
             if (!e.empty()) return e;
         }
         pend_.insert(pend_.end(), p + full * kChunk, p + n);

@@ -376,8 +376,8 @@ void sole_chunks(const uint64_t *off, uint32_t n_genomes, uint64_t fixed, uint32
 // ASCII source: d_seq / d_rec_off / host genome_byte_off; packed source: pk.  per_genome_ndel: the direct pass's per-genome
 // deleted-byte counts (calls that also run the sliced launch keep lash_timing::bases_last per genome), else NULL.
 int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t max_len, const uint8_t *d_seq, uint64_t seq_bytes,
-             const uint64_t *d_rec_off, uint64_t n_rec, bool any_multi, const uint64_t *genome_byte_off, const lash_packed *pk, uint32_t n_genomes,
-             uint8_t *d_out_images, uint32_t *per_genome_ndel)
+             const uint64_t *d_rec_off, uint64_t n_rec, bool any_multi, bool rec_identity, const uint64_t *genome_byte_off, const lash_packed *pk,
+             uint32_t n_genomes, uint8_t *d_out_images, uint32_t *per_genome_ndel)
 {
     if (n_genomes == 0) return LASH_OK;
     const bool packed = pk != nullptr;
@@ -415,7 +415,8 @@ int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t
     std::vector<Section> sec = {{chunk_begin.data(), chunk_begin.size() * 4, 0}};
     // every genome exactly one record (the usual case: one sequence per file): its byte offsets ARE the record offsets, which are
     // resident already — no per-genome table goes up at all
-    const bool gbo_is_rec_off = !packed && !any_multi && n_rec == n_genomes && d_rec_off != nullptr;
+    // (identity mapping only: genome_rec_off = [0, 1, 1] with two records has n_rec == n_genomes and no multi-record genome either — ADVICE r5)
+    const bool gbo_is_rec_off = !packed && !any_multi && n_rec == n_genomes && d_rec_off != nullptr && rec_identity;
     if (!packed && !gbo_is_rec_off) sec.push_back({genome_byte_off, ((size_t)n_genomes + 1) * 8, 0});
     const size_t tabs = layout_sections(sec), counts_bytes = ((size_t)n_wg * 16 + 255) & ~(size_t)255;
     if ((rc = reserve(ctx, ctx->sole_tab, tabs + counts_bytes + 256))) return rc;
@@ -497,10 +498,12 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
             sole_gbo.resize((size_t)n_genomes + 1);
             for (uint32_t g = 0; g < n_genomes; ++g) sole_gbo[g] = pk->h_descs[g].byte_off;
             sole_gbo[n_genomes] = pk->h_descs[n_genomes - 1].byte_off + pk->h_descs[n_genomes - 1].byte_len;
-            return sole_run(ctx, prm, sole_plan, sole_max, pk->d_seq, sole_gbo[n_genomes], pk->d_rec_off, pk->n_rec, pk->any_multi, sole_gbo.data(),
+            bool identity = pk->n_rec == n_genomes;                        // genome g IS record g (then the resident record offsets serve as byte offsets)
+            for (uint32_t g = 0; g < n_genomes && identity; ++g) identity = pk->h_descs[g].rec_begin == g && pk->h_descs[g].rec_end == g + 1u;
+            return sole_run(ctx, prm, sole_plan, sole_max, pk->d_seq, sole_gbo[n_genomes], pk->d_rec_off, pk->n_rec, pk->any_multi, identity, sole_gbo.data(),
                             nullptr, n_genomes, d_out_images, ndel);
         }
-        return sole_run(ctx, prm, sole_plan, sole_max, nullptr, 0, nullptr, 0, false, nullptr, pk, n_genomes, d_out_images, nullptr);
+        return sole_run(ctx, prm, sole_plan, sole_max, nullptr, 0, nullptr, 0, false, false, nullptr, pk, n_genomes, d_out_images, nullptr);
     };
     if (n_sole == n_genomes && n_genomes && !pk->direct) {
         // a packed batch of small genomes only (lash_sketch_packed_device, raw files, LASH_F_NO_DIRECT): no work items at all
@@ -597,6 +600,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     //  mask.  10 kb blocks 2.94 -> 2.80 ms, 2.5 kb blocks 3.39 -> 3.27 ms per 1 000 x 5 Mbp)
     const uint32_t tail_split = tail_split_env ? tail_split_env : (pk->direct && pk->stream_first ? 1u : (defer_eligible && equal_genomes ? 2u : 4u));
     const uint64_t tail_min = min_slice / 8;                        // 32 kb of sequence: 15 us of a workgroup's time
+    const bool tail_geo = !(getenv("LASH_TAIL_GEO") && atoi(getenv("LASH_TAIL_GEO")) == 0);   // A/B knob (read per call): 0 = the uniform split of rounds 3-5
     uint64_t n_coarse = 0, fine_from = ~0ull;
     uint64_t c_lo = ~0ull, c_hi = 0;                               // smallest and largest slice
     for (uint32_t g = 0; g < n_genomes; ++g) {
@@ -622,7 +626,19 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         for (uint64_t b = 0; b < nw; b += per, ++ci) {
             const uint64_t e = std::min(nw, b + per);
             uint64_t sub = e - b;                                  // this slice as one item, or as tail_split smaller ones
-            if (ci >= fine_from && (e - b) / tail_split >= tail_min) sub = ((((e - b) + tail_split - 1) / tail_split) + 3) & ~3ull;
+            if (ci >= fine_from) {
+                // ... and the later HALF of that last round in twice as many parts, its last QUARTER in four times as many (round 6): sizes
+                // are what the host balances by, but a byte's cost varies sixfold with what it holds — the soft-masked half of a genome runs
+                // at 0.07 us per kB, the clean half at 0.41 — so a launch of equal halves can still end on one full half running alone
+                // (profiles/r06/dirty_2500000_trace.txt: the last items started at 2.5 of 3.5 ms).  Ever smaller items towards the end
+                // bound that tail whatever the bytes cost; on clean input it is neutral (12 500 x 5 Mbp, 1 000 x 5 Mbp: profiles/r06/tail_geo_ab.txt)
+                uint64_t split = tail_split;
+                const uint64_t from_end = n_coarse - 1 - ci;
+                if (tail_geo && from_end < slots / 2) split *= 2;
+                if (tail_geo && from_end < slots / 4) split *= 2;
+                while (split > 1 && (e - b) / split < tail_min) split /= 2;
+                if (split > 1) sub = ((((e - b) + split - 1) / split) + 3) & ~3ull;
+            }
             const bool sole = whole && sub == e - b;
             for (uint64_t bb = b; bb < e; bb += sub, ++s)
                 for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)               // slice index | pass << 16
@@ -827,7 +843,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
                     (void)hipFree(d_trace);
                     sa.item_trace = nullptr;
                     if (FILE *f = fopen(trace_path, "a")) {
-                        fprintf(f, "# launch: %u items, %u threads, order %s; columns: launch_index item genome word_begin word_end start_10ns end_10ns hw_id xcc_id\n",
+                        fprintf(f, "# launch: %u items, %u threads, order %s; columns: slot item genome word_begin word_end start_10ns end_10ns hw_id xcc_id\n",
                                 n_items, plan_d.threads, order.empty() ? "item" : "longest first");
                         for (uint32_t b = 0; b < n_items; ++b) {
                             const uint32_t i = order.empty() ? b : order[b];
@@ -856,7 +872,9 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
         HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream));
         ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
     }
-    if (n_sole && (rc = sole_launch(pk->direct ? sa.ndel : nullptr))) return rc;   // the small genomes, whole, on resident workgroups
+    // the small genomes, whole, on resident workgroups.  Their deleted-byte counts go where lash_ctx_get_timing() will look: with the learnt
+    // stream_first every genome's flag is up (d_dirty = 0x01..) and the statistic subtracts ndel2, else ndel
+    if (n_sole && (rc = sole_launch(pk->direct ? (pk->stream_first ? sa.ndel2 : sa.ndel) : nullptr))) return rc;
     if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
     TRACE("sketch: launched");
 
@@ -1645,10 +1663,12 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
         const SolePlan sp = make_sole_plan(prm->algo, prm->p, n_genomes, (uint32_t)ctx->cu_count);
         const uint64_t smax = sole_max_bytes(ctx, prm, sp);
         bool all_small = smax != 0 && genome_byte_off[n_genomes] >= 16, any_multi = false;   // (the kernel loads 16 bytes at a time, from inside the buffer)
+        bool identity = n_rec == n_genomes;                            // genome g IS record g: its byte offsets are the resident record offsets
         for (uint32_t g = 0; g < n_genomes && all_small; ++g) {
             if (genome_byte_off[g + 1] < genome_byte_off[g] || genome_rec_off[g + 1] < genome_rec_off[g] || genome_rec_off[g + 1] > n_rec) return LASH_EINVAL;
             all_small = genome_byte_off[g + 1] - genome_byte_off[g] <= smax;
             any_multi = any_multi || genome_rec_off[g + 1] - genome_rec_off[g] > 1;
+            identity = identity && genome_rec_off[g] == g && genome_rec_off[g + 1] == (uint64_t)g + 1;
         }
         if (all_small) {
             ctx->hll_flags_n = 0;
@@ -1658,7 +1678,7 @@ int lash_sketch_batch_device(lash_ctx *ctx, const lash_params *prm, const uint8_
                 ctx->hll_flags_n = n_genomes;
             }
             if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
-            rc = sole_run(ctx, prm, sp, smax, d_seq, genome_byte_off[n_genomes], d_rec_off, n_rec, any_multi, genome_byte_off, nullptr, n_genomes,
+            rc = sole_run(ctx, prm, sp, smax, d_seq, genome_byte_off[n_genomes], d_rec_off, n_rec, any_multi, identity, genome_byte_off, nullptr, n_genomes,
                           d_out_images, nullptr);
             if (rc) return rc;
             if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream)); HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }

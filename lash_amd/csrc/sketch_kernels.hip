@@ -32,7 +32,8 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
 
     // work items are handed out longest first when their sizes differ (a.item_order: the host's permutation), so that the last
     // workgroups to start are the short ones: a mixed collection lost 11 % to its tail in launch order = genome order
-    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x + a.item_base;
+    const uint32_t slot = xcd_skewed(blockIdx.x, gridDim.x);
+    const uint32_t item = a.item_order ? a.item_order[slot] : slot + a.item_base;
     const WorkItem it = a.items[item];
     if (a.item_trace && threadIdx.x == 0) {                                // (diagnostic: nothing of it stays live)
         uint32_t hw, xcc;
@@ -395,7 +396,8 @@ __global__ void __launch_bounds__(1024) stream_sketch_kernel(SketchArgs a)
 {
     static_assert(!DEFER || (ALGO == 0 && REGS == REGS_LDS), "deferred signatures: HyperMinHash, one LDS table");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_regs[];
-    const uint32_t item = a.item_order ? a.item_order[blockIdx.x] : blockIdx.x + a.item_base;
+    const uint32_t slot = xcd_skewed(blockIdx.x, gridDim.x);
+    const uint32_t item = a.item_order ? a.item_order[slot] : slot + a.item_base;
     const WorkItem it = a.items[item];
     if (a.dirty[it.genome] == 0u) return;                                  // only the genomes the direct pass gave up
     const GenomeDesc gd = a.genomes[it.genome];

@@ -820,6 +820,22 @@ __device__ __forceinline__ void process_word_defer(const Regs &regs, const KPara
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// which work item a workgroup takes.  The hardware hands workgroup b to XCD b mod 8 (eight dies, each with its own workgroup slots and L2:
+// nothing moves between them once dispatched) and, inside the die, to its four shader engines in turn ((b / 8) mod 4, measured with
+// LASH_ITEM_TRACE: profiles/r06/dirty_2500000_trace_*.txt) — 32 static classes of workgroup slots; only the CU inside a class is chosen
+// dynamically.  A launch whose items alternate between dear and cheap with a period that divides 32 — the two halves of genomes that are clean up
+// to the middle and soft-masked after it; (C, C, M, M) quarters — therefore puts all the dear ones on the same dies, or on the same half of every
+// die's CUs: 1 000 x 5 Mbp with 2.5 Mb lower-case blocks ran its clean halves on 128 of the 256 CUs, 3.6 ms for half the k-mers of a 3.9 ms clean
+// run.  Row j of 32 workgroups therefore takes its 32 items rotated by j: a bijection inside the row (the launch's last, incomplete row stays
+// as it is), three scalar instructions, and every short-period pattern of costs meets every class equally often.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcd_skewed(uint32_t b, uint32_t n)
+{
+    const uint32_t j = b >> 5;
+    return b < (n & ~31u) ? (b & ~31u) | ((b + j) & 31u) : b;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------------------
 #ifndef LASH_SKETCH_WAVES_PER_EU

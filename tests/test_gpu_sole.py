@@ -314,3 +314,60 @@ def test_genomes_without_a_kmer_between_others(ctx, an, k, p):
     img = ctx.sketch_batch(an, k, p, 42, s1, o1, g1)
     img = ctx.sketch_batch(an, k, p, 42, s2, o2, g2, flags=lash_amd.F_ACCUMULATE, out=img)
     same(img, want, "accumulate over genomes without k-mers")
+
+
+def test_bases_last_counts_small_genomes_when_the_context_streams_first():
+    """once a context has learnt that its batches are soft-masked (`stream_first`: the optimistic direct pass is skipped, every
+    sliced genome's flag is up), lash_timing.bases_last subtracts the stream kernel's deleted-byte counts — and the persistent kernel must
+    write the small genomes' counts THERE too.  A batch of large soft-masked genomes teaches the context, then a mixed batch whose small
+    genomes hold N runs is sketched: images, census and surviving bases against the oracle."""
+    import lash_amd
+    c = lash_amd.Context(0)
+    large = []
+    for i in range(6):
+        g = O.synth_genome(940 + i, 1_000_000).copy()
+        g[::97] |= 0x20
+        large.append([g.tobytes()])
+    sd, od, gd = lash_amd.records_to_arrays(large)
+    for _ in range(3):
+        c.sketch_batch("hmh", 16, 0, 42, sd, od, gd)
+    small = []
+    for i in range(9):
+        s = bytearray(O.synth_genome(960 + i, 20_000 + 777 * i).tobytes())
+        s[5_000 + i:5_300 + i] = b"N" * 300
+        s[100:140] = bytes(s[100:140]).lower()
+        small.append([bytes(s)])
+    gs = small[:4] + large[:2] + small[4:] + large[2:4]
+    seq, off, goff = lash_amd.records_to_arrays(gs)
+    c.enable_timing(True)
+    got = c.sketch_batch("hmh", 16, 0, 42, seq, off, goff)
+    tm = c.timing()
+    c.enable_timing(False)
+    assert tm["sole_launches"] == 1 and tm["direct_launches"] == 0, tm          # the context streamed first: no optimistic pass in this call
+    assert tm["bases_last"] == sum(len(O.filter_out_n(r)) for g in gs for r in g), tm
+    assert tm["kmers"] == sum(len(O.record_kmers(r, 16)) for g in gs for r in g)
+    same(got, oracle_images("hmh", 16, 0, 42, seq, off, goff), "mixed batch on a context that streams first")
+    c.close()
+
+
+@pytest.mark.parametrize("an,k,p", [("hmh", 16, 0), ("hll", 21, 12), ("ull", 16, 10)])
+def test_a_record_that_belongs_to_no_genome_is_not_sketched(ctx, an, k, p):
+    """genome_rec_off = [0, 1, 1] with two records is legal input — genome 1 is empty and record 1 belongs to nobody.  It has as many
+    records as genomes and no multi-record genome, which is what the all-small route took for "the record offsets ARE the genome byte
+    offsets"; it then sketched the stray record as genome 1, past the declared end of the sequence bytes.  Also with the stray record in front."""
+    a, b = O.synth_genome(970, 9_000).tobytes(), O.synth_genome(971, 7_000).tobytes()
+    for goff, off, seq, keep in (([0, 1, 1], [0, 9_000, 16_000], a + b, a), ([0, 0, 1], [0, 9_000, 16_000], a + b, None)):
+        seq = np.frombuffer(seq, np.uint8)
+        off, goff = np.array(off, np.uint64), np.array(goff, np.uint64)
+        if keep is None:
+            # genome 0 empty, genome 1 = record 0, record 1 belongs to nobody
+            pass
+        want = oracle_images(an, k, p, 42, seq, off, goff)
+        ctx.enable_timing(True)
+        got = ctx.sketch_batch(an, k, p, 42, seq, off, goff)
+        tm = ctx.timing()
+        ctx.enable_timing(False)
+        same(got, want, "stray record %s" % goff.tolist())
+        empty = oracle_images(an, k, p, 42, np.zeros(1, np.uint8), np.array([0, 0], np.uint64), np.array([0, 1], np.uint64))[0]
+        assert np.array_equal(got[0 if keep is None else 1], empty)              # the empty genome's image is the empty sketch
+        assert tm["kmers"] == 9_000 - k + 1, tm

@@ -1,0 +1,434 @@
+// tools/gpu_inflate.hip — the go / no-go experiment of VERDICT r5 next #7: DEFLATE (RFC 1951) decoded on gfx950.
+//
+// Why: through the drop-in CLI the kernels idle — `lash sketch` on .gz input is bound by host inflate (needletail -> flate2 in the reference,
+// utils.rs:453; host/inflate_fast.cpp + host/pgzip.cpp here: ~15 GB/s of text on a 16-CPU box), the sketch kernels take 1 200 GB/s.  A collection
+// of 10 000 .fa.gz files, or one multi-member reads.gz, is thousands of INDEPENDENT gzip members: this tool measures what the GPU makes of them.
+//
+// Shape — one WAVEFRONT per member, everything wave-uniform, no MFMA, no atomics in the data path:
+//   * the bit reader lives in scalar registers; the compressed bytes come from a 256-byte window held one dword per lane (v_readlane by a
+//     scalar index), the window after it already loaded;
+//   * a Huffman code is decoded WITHOUT a table walk: canonical codes, lane l (1..15) holds the left-aligned upper limit of the codes of
+//     length l and the offset of their first symbol; one v_cmp of the bit-reversed 15-bit peek against all limits + s_bcnt1 gives the length,
+//     two v_readlane give the symbol (the sorted symbol list sits in five vector registers, symbol i in lane i mod 64).  Building the tables
+//     of a dynamic block is ballots and prefix counts over the wave — no 2^k-entry table is ever filled;
+//   * the 32 KiB window is a ring in LDS (four waves per workgroup: 128 KiB + tables, one workgroup per CU); a match is copied by its
+//     bytes' lanes side by side (source index i mod dist when it overlaps itself); finished KiB leave the ring in 16-byte stores.
+// Output is checked byte for byte against the text zlib compressed (and every member's length against its ISIZE).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/gpu_inflate tools/gpu_inflate.hip -lz
+// Run:   tools/gpu_inflate [members=1024] [text_bytes_per_member=5000000] [shape=fasta|fastq] [level=6]
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Member { uint64_t in_off, out_off; uint32_t in_len, out_len; };
+
+constexpr uint32_t RING = 32768, WAVES = 4, LENS = 320;
+constexpr uint32_t WAVE_LDS = RING + LENS + 2 * LENS + 32;      // ring | code lengths (bytes) | sorted symbols (u16) | pad
+enum { E_OK = 0, E_BTYPE = 1, E_STORED = 2, E_HEADER = 3, E_CODE = 4, E_DIST = 5, E_OVERRUN = 6, E_INPUT = 7, E_TABLE = 8, E_LENGTH = 9, E_WATCHDOG = 10 };
+
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t below(uint64_t m)           // set bits of m in the lanes below this one
+{ return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+struct Bits {
+    uint64_t buf;          // uniform: the next cnt bits of the stream, first bit lowest
+    uint32_t cnt, pos;     // uniform: valid bits; index of the next dword to feed (from the aligned base)
+    uint32_t w, wn;        // per lane: dword 64 * (pos >> 6) + lane of the input, and the same of the window after it
+    const uint32_t *base;
+    uint32_t n_dw;         // readable dwords from base (the host pads its buffer)
+};
+__device__ __forceinline__ void refill(Bits &b, uint32_t lane)    // afterwards cnt > 32
+{
+    if (b.cnt <= 32u) {
+        const uint32_t d = rdl(b.w, b.pos & 63u);
+        b.buf |= (uint64_t)d << b.cnt;
+        b.cnt += 32u;
+        ++b.pos;
+        if ((b.pos & 63u) == 0u) {
+            b.w = b.wn;
+            const uint32_t i = b.pos + 64u + lane;
+            b.wn = b.base[i < b.n_dw ? i : b.n_dw - 1u];
+        }
+    }
+}
+__device__ __forceinline__ uint32_t take(Bits &b, uint32_t n)
+{
+    const uint32_t v = (uint32_t)b.buf & ((1u << n) - 1u);
+    b.buf >>= n;
+    b.cnt -= n;
+    return v;
+}
+
+// a canonical Huffman code as the wave holds it
+struct Code {
+    uint32_t limit;        // lane l in 1..15: (first code of length l + number of such codes) << (15 - l); other lanes: all ones
+    int32_t base;          // lane l: index of the first symbol of length l in the sorted list, minus the first code of length l
+};
+// the next symbol's index in the sorted list and its length; L == 16: no code matches
+__device__ __forceinline__ uint32_t decode_index(const Bits &b, const Code &c, uint32_t &L)
+{
+    const uint32_t rev = __builtin_bitreverse32((uint32_t)b.buf & 0x7FFFu) >> 17;                 // the 15 bits as a code reads them
+    L = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(rev >= c.limit)) + 1u;
+    const uint32_t Lc = L < 16u ? L : 15u;
+    return (uint32_t)((int32_t)rdl((uint32_t)c.base, Lc) + (int32_t)(rev >> (15u - Lc)));
+}
+
+// code lengths lens[0 .. n) (LDS bytes) -> Code + the symbols sorted by (length, symbol), symbol i of the list in register i / 64, lane i % 64
+template <int R>
+__device__ __forceinline__ bool build_code(const uint8_t *lens, uint32_t n, uint32_t lane, uint16_t *sorted, Code &code, uint32_t (&sym)[R], uint32_t &n_used)
+{
+    uint32_t len_r[R], rank_r[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t s = 64u * r + lane;
+        len_r[r] = s < n ? lens[s] : 0u;
+        rank_r[r] = 0u;
+    }
+    code.limit = 0xFFFFFFFFu;
+    code.base = 0;
+    uint32_t off_of_len = 0;                 // lane l: where the symbols of length l begin in the sorted list
+    uint32_t next = 0, offset = 0;
+    bool ok = true;
+    for (uint32_t l = 1; l <= 15u; ++l) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool mine = len_r[r] == l;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+            if (mine) rank_r[r] = run + below(m);
+            run += (uint32_t)__builtin_popcountll(m);
+        }
+        const uint32_t first = next, end = first + run;
+        ok = ok && end <= (1u << l);                                   // over-subscribed
+        if (lane == l) { code.limit = end << (15u - l); code.base = (int32_t)offset - (int32_t)first; off_of_len = offset; }
+        offset += run;
+        next = end << 1;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        // (the permute runs with every lane active: an inactive SOURCE lane would hand over zero)
+        const uint32_t at = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(len_r[r] * 4u), (int)off_of_len) + rank_r[r];
+        if (len_r[r]) sorted[at] = (uint16_t)(64u * r + lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t i = 64u * r + lane;
+        sym[r] = i < offset ? sorted[i] : 0xFFFFu;
+    }
+    n_used = offset;
+    return ok;
+}
+template <int R>
+__device__ __forceinline__ uint32_t sym_at(const uint32_t (&sym)[R], uint32_t idx)
+{
+    const uint32_t q = idx >> 6, r = idx & 63u;
+    if (R == 1 || q == 0u) return rdl(sym[0], r);
+    if (R > 1 && q == 1u) return rdl(sym[R > 1 ? 1 : 0], r);
+    if (R > 2 && q == 2u) return rdl(sym[R > 2 ? 2 : 0], r);
+    if (R > 3 && q == 3u) return rdl(sym[R > 3 ? 3 : 0], r);
+    return rdl(sym[R > 4 ? 4 : 0], r);
+}
+
+__constant__ uint16_t k_len_base[32] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0, 0};
+__constant__ uint8_t k_len_extra[32] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0, 0};
+__constant__ uint16_t k_dist_base[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0, 0};
+__constant__ uint8_t k_dist_extra[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
+__constant__ uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, uint64_t in_bytes, const Member *members, uint32_t n_members, uint8_t *out,
+                                                             uint32_t *status, uint32_t *ticket)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = rfl(threadIdx.x >> 6);
+    uint8_t *ring = lds + wave * WAVE_LDS;
+    uint8_t *lens = ring + RING;
+    uint16_t *sorted = reinterpret_cast<uint16_t *>(lens + LENS);
+    const uint32_t len_base = k_len_base[lane & 31u], len_extra = k_len_extra[lane & 31u];
+    const uint32_t dist_base = k_dist_base[lane & 31u], dist_extra = k_dist_extra[lane & 31u];
+
+    for (;;) {
+        uint32_t mi = 0;
+        if (lane == 0) mi = atomicAdd(ticket, 1u);
+        mi = rfl(mi);
+        if (mi >= n_members) return;
+        const Member mb = members[mi];
+        uint8_t *dst = out + mb.out_off;
+        Bits b;
+        {
+            const uint64_t a = mb.in_off & ~3ull;
+            b.base = reinterpret_cast<const uint32_t *>(in + a);
+            b.n_dw = (uint32_t)std::min<uint64_t>((in_bytes - a) >> 2, 0xFFFFFFFFull);
+            b.w = b.base[lane < b.n_dw ? lane : b.n_dw - 1u];
+            b.wn = b.base[64u + lane < b.n_dw ? 64u + lane : b.n_dw - 1u];
+            b.buf = 0; b.cnt = 0; b.pos = 0;
+            refill(b, lane);
+            (void)take(b, 8u * (uint32_t)(mb.in_off & 3ull));
+        }
+        const uint64_t bit_limit = 8ull * ((mb.in_off & 3ull) + mb.in_len) + 64ull;       // bits fed beyond this: the stream ran off its member
+        uint32_t p = 0, err = E_OK;
+        // every loop below counts its iterations against this: a member cannot take more steps than the bytes it makes plus its blocks' header
+        // symbols, so a defect ends as an error code in the status word, never as a kernel that does not return
+        int64_t budget = 4ll * mb.out_len + 4ll * mb.in_len + 100000ll;
+        uint32_t stage = 0;
+        auto flush_kib = [&](uint32_t c) {                                                 // KiB c of the output is complete: 16 bytes per lane
+            const uint4 v = *reinterpret_cast<const uint4 *>(ring + ((c << 10) & (RING - 1u)) + 16u * lane);
+            *reinterpret_cast<uint4 *>(dst + ((uint64_t)c << 10) + 16u * lane) = v;
+        };
+        bool final_block = false;
+        while (!final_block && err == E_OK) {
+            if (--budget < 0) { err = E_WATCHDOG; stage = 1; break; }
+            refill(b, lane);
+            final_block = take(b, 1) != 0u;
+            const uint32_t btype = take(b, 2);
+            if ((uint64_t)b.pos * 32ull - b.cnt > bit_limit) { err = E_INPUT; break; }
+            if (btype == 0u) {
+                // stored: to the byte boundary, LEN, ~LEN, the bytes (through the bit reader: rare in text)
+                (void)take(b, b.cnt & 7u);
+                refill(b, lane);
+                const uint32_t n = take(b, 16);
+                refill(b, lane);
+                const uint32_t nn = take(b, 16);
+                if ((n ^ nn) != 0xFFFFu) { err = E_STORED; break; }
+                if (p + n > mb.out_len) { err = E_OVERRUN; break; }
+                for (uint32_t i = 0; i < n; ++i) {
+                    if (--budget < 0) { err = E_WATCHDOG; stage = 2; break; }
+                    refill(b, lane);
+                    const uint32_t v = take(b, 8);
+                    if (lane == 0) ring[p & (RING - 1u)] = (uint8_t)v;
+                    ++p;
+                    if ((p & 1023u) == 0u) flush_kib((p >> 10) - 1u);
+                }
+                continue;
+            }
+            if (btype == 3u) { err = E_BTYPE; break; }
+            uint32_t n_ll = 288, n_d = 30;
+            if (btype == 1u) {
+                for (uint32_t i = lane; i < 320u; i += 64u) lens[i] = i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : i < 288u ? 8 : 5;
+                n_ll = 288; n_d = 32;
+            } else {
+                refill(b, lane);
+                n_ll = take(b, 5) + 257u;
+                n_d = take(b, 5) + 1u;
+                const uint32_t n_cl = take(b, 4) + 4u;
+                if (n_ll > 286u || n_d > 30u) { err = E_HEADER; break; }
+                if (lane < 19u) lens[lane] = 0;
+                for (uint32_t i = 0; i < n_cl; ++i) {
+                    refill(b, lane);
+                    const uint32_t v = take(b, 3);
+                    if (lane == 0) lens[k_cl_order[i]] = (uint8_t)v;
+                }
+                Code cl;
+                uint32_t cl_sym[1], used;
+                if (!build_code<1>(lens, 19u, lane, sorted, cl, cl_sym, used) || used == 0u) { err = E_TABLE; break; }
+                // the literal/length and distance code lengths, run-length coded in the code just built; they overwrite the 19 lengths
+                uint32_t i = 0, prev = 0;
+                const uint32_t n_all = n_ll + n_d;
+                while (i < n_all) {
+                    if (--budget < 0) { err = E_WATCHDOG; stage = 3; break; }
+                    refill(b, lane);
+                    uint32_t L;
+                    const uint32_t idx = decode_index(b, cl, L);
+                    if (L > 15u || idx >= used) { err = E_CODE; break; }
+                    (void)take(b, L);
+                    const uint32_t s = sym_at<1>(cl_sym, idx);
+                    uint32_t rep = 1, val = s;
+                    if (s == 16u) { if (i == 0u) { err = E_HEADER; break; } rep = 3u + take(b, 2); val = prev; }
+                    else if (s == 17u) { rep = 3u + take(b, 3); val = 0u; }
+                    else if (s == 18u) { rep = 11u + take(b, 7); val = 0u; }
+                    if (i + rep > n_all) { err = E_HEADER; break; }
+                    for (uint32_t c = lane; c < rep; c += 64u) lens[i + c] = (uint8_t)val;
+                    i += rep;
+                    prev = val;
+                }
+                if (err != E_OK) break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            Code ll, dc;
+            uint32_t ll_sym[5], d_sym[1], ll_used, d_used;
+            if (!build_code<5>(lens, n_ll, lane, sorted, ll, ll_sym, ll_used) || ll_used == 0u) { err = E_TABLE; break; }
+            if (!build_code<1>(lens + n_ll, n_d, lane, sorted, dc, d_sym, d_used)) { err = E_TABLE; break; }
+            // ---- the block's symbols ----
+            for (;;) {
+                if (--budget < 0) { err = E_WATCHDOG; stage = 4; break; }
+                refill(b, lane);
+                uint32_t L;
+                uint32_t idx = decode_index(b, ll, L);
+                if (L > 15u || idx >= ll_used) { err = E_CODE; break; }
+                (void)take(b, L);
+                uint32_t s = sym_at<5>(ll_sym, idx);
+                if (s < 256u) {
+                    if (p >= mb.out_len) { err = E_OVERRUN; break; }
+                    if (lane == 0) ring[p & (RING - 1u)] = (uint8_t)s;
+                    ++p;
+                    if ((p & 1023u) == 0u) flush_kib((p >> 10) - 1u);
+                    continue;
+                }
+                if (s == 256u) break;
+                s -= 257u;
+                if (s >= 29u) { err = E_CODE; break; }
+                const uint32_t len = rdl(len_base, s) + take(b, rdl(len_extra, s));
+                refill(b, lane);
+                idx = decode_index(b, dc, L);
+                if (L > 15u || idx >= d_used) { err = E_CODE; break; }
+                (void)take(b, L);
+                const uint32_t ds = sym_at<1>(d_sym, idx);
+                if (ds >= 30u) { err = E_CODE; break; }
+                const uint32_t dist = rdl(dist_base, ds) + take(b, rdl(dist_extra, ds));
+                if (dist > p) { err = E_DIST; break; }
+                if (p + len > mb.out_len) { err = E_OVERRUN; break; }
+                for (uint32_t c = 0; c < len; c += 64u) {
+                    const uint32_t i = c + lane;
+                    if (i < len) {
+                        const uint32_t o = dist >= len ? i : (dist == 1u ? 0u : i % dist);
+                        ring[(p + i) & (RING - 1u)] = ring[(p - dist + o) & (RING - 1u)];
+                    }
+                }
+                const uint32_t kib = p >> 10;
+                p += len;
+                if ((p >> 10) != kib) flush_kib(kib);
+            }
+            if ((uint64_t)b.pos * 32ull - b.cnt > bit_limit) err = err ? err : E_INPUT;
+        }
+        // what is left of the last KiB
+        for (uint32_t i = (p & ~1023u) + lane; i < p; i += 64u) dst[i] = ring[i & (RING - 1u)];
+        if (err == E_OK && p != mb.out_len) err = E_LENGTH;
+        if (lane == 0) { status[2u * mi] = err | (stage << 8); status[2u * mi + 1u] = p; }
+    }
+}
+
+// ---- host: synthetic text, zlib raw deflate, launch, check -------------------------------------------------------------------------
+static uint64_t splitmix(uint64_t &s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+static std::string make_text(const std::string &shape, size_t bytes, uint64_t seed)
+{
+    std::string t;
+    t.reserve(bytes + 256);
+    uint64_t s = seed * 77 + 1, r = 0;
+    int left = 0;
+    auto base = [&]() { if (!left) { r = splitmix(s); left = 32; } const char c = "ACGT"[r & 3]; r >>= 2; --left; return c; };
+    if (shape == "fastq") {
+        uint64_t n = 0;
+        while (t.size() < bytes) {
+            t += "@read" + std::to_string(seed) + "." + std::to_string(n++) + "\n";
+            for (int i = 0; i < 150; ++i) t += base();
+            t += "\n+\n";
+            t.append(150, 'I');
+            t += "\n";
+        }
+    } else {
+        t += ">genome" + std::to_string(seed) + " synthetic\n";
+        while (t.size() < bytes) { for (int i = 0; i < 80 && t.size() < bytes; ++i) t += base(); t += "\n"; }
+    }
+    return t;
+}
+static std::vector<uint8_t> raw_deflate(const std::string &t, int level)
+{
+    z_stream z{};
+    if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { fprintf(stderr, "deflateInit2 failed\n"); exit(1); }
+    std::vector<uint8_t> o(deflateBound(&z, t.size()));
+    z.next_in = (Bytef *)t.data(); z.avail_in = (uInt)t.size();
+    z.next_out = o.data(); z.avail_out = (uInt)o.size();
+    if (deflate(&z, Z_FINISH) != Z_STREAM_END) { fprintf(stderr, "deflate failed\n"); exit(1); }
+    o.resize(z.total_out);
+    deflateEnd(&z);
+    return o;
+}
+
+int main(int argc, char **argv)
+{
+    const uint32_t N = argc > 1 ? (uint32_t)atoi(argv[1]) : 1024u;
+    const size_t text_bytes = argc > 2 ? (size_t)atoll(argv[2]) : 5000000;
+    const std::string shape = argc > 3 ? argv[3] : "fasta";
+    const int level = argc > 4 ? atoi(argv[4]) : 6;
+    const uint32_t M = std::min<uint32_t>(N, 16u);                            // distinct members; the others repeat them (own output each)
+    std::vector<std::string> texts;
+    std::vector<std::vector<uint8_t>> comp;
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < M; ++i) { texts.push_back(make_text(shape, text_bytes + 1000 * i, i + 1)); comp.push_back(raw_deflate(texts.back(), level)); }
+    const double host_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<uint8_t> h_in;
+    std::vector<uint64_t> in_off(M);
+    for (uint32_t i = 0; i < M; ++i) { in_off[i] = h_in.size() + (i % 4u); h_in.resize(in_off[i]); h_in.insert(h_in.end(), comp[i].begin(), comp[i].end()); }   // (every byte alignment)
+    h_in.resize(h_in.size() + 1024, 0);
+    std::vector<Member> mem(N);
+    uint64_t out_bytes = 0, in_total = 0;
+    for (uint32_t i = 0; i < N; ++i) {
+        const uint32_t j = i % M;
+        mem[i] = Member{in_off[j], out_bytes, (uint32_t)comp[j].size(), (uint32_t)texts[j].size()};
+        out_bytes += (texts[j].size() + 1024 + 15) & ~(size_t)15;
+        in_total += comp[j].size();
+    }
+    uint8_t *d_in, *d_out;
+    Member *d_mem;
+    uint32_t *d_status, *d_ticket;
+    CHECK(hipMalloc(&d_in, h_in.size()));
+    CHECK(hipMalloc(&d_out, out_bytes + 4096));
+    CHECK(hipMalloc(&d_mem, N * sizeof(Member)));
+    CHECK(hipMalloc(&d_status, N * 8));
+    CHECK(hipMalloc(&d_ticket, 4));
+    CHECK(hipMemcpy(d_in, h_in.data(), h_in.size(), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_mem, mem.data(), N * sizeof(Member), hipMemcpyHostToDevice));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const uint32_t lds = WAVES * WAVE_LDS;
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(inflate_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t grid = std::min<uint32_t>((N + WAVES - 1) / WAVES, (uint32_t)prop.multiProcessorCount);
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    const int reps = getenv("GPU_INFLATE_REPS") ? atoi(getenv("GPU_INFLATE_REPS")) : 3;
+    for (int rep = 0; rep < reps; ++rep) {
+        fprintf(stderr, "launch %d: %u workgroups, %u members\n", rep, grid, N);
+        CHECK(hipMemset(d_ticket, 0, 4));
+        CHECK(hipMemset(d_status, 0xFF, N * 8));
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(inflate_kernel, dim3(grid), dim3(64 * WAVES), lds, 0, d_in, (uint64_t)h_in.size(), d_mem, N, d_out, d_status, d_ticket);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        CHECK(hipGetLastError());
+        fprintf(stderr, "launch %d done\n", rep);
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    std::vector<uint32_t> st(2 * N);
+    CHECK(hipMemcpy(st.data(), d_status, N * 8, hipMemcpyDeviceToHost));
+    uint32_t bad = 0;
+    for (uint32_t i = 0; i < N; ++i)
+        if (st[2 * i] != 0) { if (bad++ < 5) fprintf(stderr, "member %u: error %u (stage %u) after %u of %u bytes\n", i, st[2 * i] & 0xFF, st[2 * i] >> 8, st[2 * i + 1], mem[i].out_len); }
+    // bytes: the first 2 M members and a spread of the others
+    uint32_t checked = 0, differ = 0;
+    std::vector<uint8_t> got;
+    for (uint32_t i = 0; i < N; i += (i < 2 * M ? 1 : std::max(1u, N / 64u))) {
+        got.resize(mem[i].out_len);
+        CHECK(hipMemcpy(got.data(), d_out + mem[i].out_off, mem[i].out_len, hipMemcpyDeviceToHost));
+        const std::string &want = texts[i % M];
+        if (memcmp(got.data(), want.data(), want.size()) != 0) {
+            size_t at = 0;
+            while (at < want.size() && got[at] == (uint8_t)want[at]) ++at;
+            if (differ++ < 5) fprintf(stderr, "member %u: first difference at byte %zu of %zu\n", i, at, want.size());
+        }
+        ++checked;
+    }
+    printf("gpu inflate: %u members (%u distinct), shape %s, zlib level %d, %.2f MB of text and %.2f MB compressed per member (ratio %.2f); %u workgroups x %u waves, %u B of LDS each\n",
+           N, M, shape.c_str(), level, texts[0].size() / 1e6, comp[0].size() / 1e6, (double)texts[0].size() / comp[0].size(), grid, WAVES, lds);
+    printf("  kernel %.3f ms (best of 3): %.2f GB/s of text out, %.2f GB/s compressed in; per member in flight (%u at a time): %.1f MB/s\n", best, (out_bytes - 1024.0 * N) / best / 1e6,
+           in_total / best / 1e6, std::min(N, grid * WAVES), (out_bytes - 1024.0 * N) / best / 1e3 / std::min(N, grid * WAVES));
+    printf("  status: %u of %u members in error; bytes of %u members compared with the text zlib compressed: %u differ  (host: %.1f s to make and compress %u texts)\n", bad, N, checked, differ, host_s, M);
+    return bad || differ ? 1 : 0;
+}
