@@ -39,6 +39,7 @@ enum { E_OK = 0, E_BTYPE = 1, E_STORED = 2, E_HEADER = 3, E_CODE = 4, E_DIST = 5
 
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t rfl64(uint64_t v) { return ((uint64_t)rfl((uint32_t)(v >> 32)) << 32) | rfl((uint32_t)v); }
 __device__ __forceinline__ uint32_t below(uint64_t m)           // set bits of m in the lanes below this one
 { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
@@ -51,6 +52,10 @@ struct Bits {
 };
 __device__ __forceinline__ void refill(Bits &b, uint32_t lane)    // afterwards cnt > 32
 {
+    // (every wave-uniform value is pinned to scalar registers where control flow merges — rfl() of a scalar is a move: hipcc's uniformity
+    //  analysis gives up on values that came through vector memory, and a bit reader in VECTOR registers under exec masks was the first
+    //  version of this kernel: 2 600 cycles per match, profiles/r06/gpu_inflate/first_version.txt)
+    b.cnt = rfl(b.cnt); b.pos = rfl(b.pos);
     if (b.cnt <= 32u) {
         const uint32_t d = rdl(b.w, b.pos & 63u);
         b.buf |= (uint64_t)d << b.cnt;
@@ -62,6 +67,7 @@ __device__ __forceinline__ void refill(Bits &b, uint32_t lane)    // afterwards 
             b.wn = b.base[i < b.n_dw ? i : b.n_dw - 1u];
         }
     }
+    b.buf = rfl64(b.buf); b.cnt = rfl(b.cnt); b.pos = rfl(b.pos);
 }
 __device__ __forceinline__ uint32_t take(Bits &b, uint32_t n)
 {
@@ -150,7 +156,7 @@ __constant__ uint8_t k_dist_extra[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 
 __constant__ uint8_t k_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 __global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, uint64_t in_bytes, const Member *members, uint32_t n_members, uint8_t *out,
-                                                             uint32_t *status, uint32_t *ticket)
+                                                             uint32_t *status, uint32_t *ticket, uint32_t stop_at)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = rfl(threadIdx.x >> 6);
@@ -165,7 +171,9 @@ __global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, 
         if (lane == 0) mi = atomicAdd(ticket, 1u);
         mi = rfl(mi);
         if (mi >= n_members) return;
-        const Member mb = members[mi];
+        if (stop_at == 1u) { if (lane == 0) { status[2u * mi] = 101u; status[2u * mi + 1u] = 0u; } continue; }      // (bisecting a defect: GPU_INFLATE_STOP)
+        Member mb = members[mi];
+        mb.in_off = rfl64(mb.in_off); mb.out_off = rfl64(mb.out_off); mb.in_len = rfl(mb.in_len); mb.out_len = rfl(mb.out_len);
         uint8_t *dst = out + mb.out_off;
         Bits b;
         {
@@ -178,11 +186,12 @@ __global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, 
             refill(b, lane);
             (void)take(b, 8u * (uint32_t)(mb.in_off & 3ull));
         }
+        if (stop_at == 2u) { if (lane == 0) { status[2u * mi] = 102u; status[2u * mi + 1u] = (uint32_t)b.buf; } continue; }
         const uint64_t bit_limit = 8ull * ((mb.in_off & 3ull) + mb.in_len) + 64ull;       // bits fed beyond this: the stream ran off its member
         uint32_t p = 0, err = E_OK;
         // every loop below counts its iterations against this: a member cannot take more steps than the bytes it makes plus its blocks' header
         // symbols, so a defect ends as an error code in the status word, never as a kernel that does not return
-        int64_t budget = 4ll * mb.out_len + 4ll * mb.in_len + 100000ll;
+        int64_t budget = (int64_t)rfl64((uint64_t)(4ll * mb.out_len + 4ll * mb.in_len + 100000ll));
         uint32_t stage = 0;
         auto flush_kib = [&](uint32_t c) {                                                 // KiB c of the output is complete: 16 bytes per lane
             const uint4 v = *reinterpret_cast<const uint4 *>(ring + ((c << 10) & (RING - 1u)) + 16u * lane);
@@ -215,6 +224,7 @@ __global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, 
                 continue;
             }
             if (btype == 3u) { err = E_BTYPE; break; }
+            if (stop_at == 3u) { err = 103u; p = btype; break; }
             uint32_t n_ll = 288, n_d = 30;
             if (btype == 1u) {
                 for (uint32_t i = lane; i < 320u; i += 64u) lens[i] = i < 144u ? 8 : i < 256u ? 9 : i < 280u ? 7 : i < 288u ? 8 : 5;
@@ -258,13 +268,16 @@ __global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (stop_at == 4u) { err = 104u; p = n_ll * 1000u + n_d; break; }
             Code ll, dc;
             uint32_t ll_sym[5], d_sym[1], ll_used, d_used;
             if (!build_code<5>(lens, n_ll, lane, sorted, ll, ll_sym, ll_used) || ll_used == 0u) { err = E_TABLE; break; }
             if (!build_code<1>(lens + n_ll, n_d, lane, sorted, dc, d_sym, d_used)) { err = E_TABLE; break; }
+            if (stop_at == 5u) { err = 105u; p = ll_used * 1000u + d_used; break; }
             // ---- the block's symbols ----
             for (;;) {
                 if (--budget < 0) { err = E_WATCHDOG; stage = 4; break; }
+                p = rfl(p);
                 refill(b, lane);
                 uint32_t L;
                 uint32_t idx = decode_index(b, ll, L);
@@ -397,7 +410,7 @@ int main(int argc, char **argv)
         CHECK(hipMemset(d_ticket, 0, 4));
         CHECK(hipMemset(d_status, 0xFF, N * 8));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(inflate_kernel, dim3(grid), dim3(64 * WAVES), lds, 0, d_in, (uint64_t)h_in.size(), d_mem, N, d_out, d_status, d_ticket);
+        hipLaunchKernelGGL(inflate_kernel, dim3(grid), dim3(64 * WAVES), lds, 0, d_in, (uint64_t)h_in.size(), d_mem, N, d_out, d_status, d_ticket, getenv("GPU_INFLATE_STOP") ? (uint32_t)atoi(getenv("GPU_INFLATE_STOP")) : 0u);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         CHECK(hipGetLastError());
