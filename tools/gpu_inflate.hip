@@ -275,8 +275,7 @@ __global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, 
             if (!build_code<1>(lens + n_ll, n_d, lane, sorted, dc, d_sym, d_used)) { err = E_TABLE; break; }
             if (stop_at == 5u) { err = 105u; p = ll_used * 1000u + d_used; break; }
             // ---- the block's symbols ----
-            for (;;) {
-                if (--budget < 0) { err = E_WATCHDOG; stage = 4; break; }
+            for (;;) {                                                  // (no watchdog here: every turn ends the block, fails, or makes p grow towards out_len)
                 p = rfl(p);
                 refill(b, lane);
                 uint32_t L;
@@ -304,11 +303,17 @@ __global__ void __launch_bounds__(64 * WAVES) inflate_kernel(const uint8_t *in, 
                 const uint32_t dist = rdl(dist_base, ds) + take(b, rdl(dist_extra, ds));
                 if (dist > p) { err = E_DIST; break; }
                 if (p + len > mb.out_len) { err = E_OVERRUN; break; }
-                for (uint32_t c = 0; c < len; c += 64u) {
-                    const uint32_t i = c + lane;
-                    if (i < len) {
-                        const uint32_t o = dist >= len ? i : (dist == 1u ? 0u : i % dist);
-                        ring[(p + i) & (RING - 1u)] = ring[(p - dist + o) & (RING - 1u)];
+                // three shapes of a copy, chosen by scalar branches (the general one's division was 20 vector instructions in EVERY match's path):
+                // the usual one — up to 64 bytes, no overlap —, a run (distance 1: a FASTQ quality line), and everything else
+                if (len <= 64u && dist >= len) {
+                    if (lane < len) ring[(p + lane) & (RING - 1u)] = ring[(p - dist + lane) & (RING - 1u)];
+                } else if (dist == 1u) {
+                    const uint8_t v = ring[(p - 1u) & (RING - 1u)];
+                    for (uint32_t c = lane; c < len; c += 64u) ring[(p + c) & (RING - 1u)] = v;
+                } else {
+                    for (uint32_t c = 0; c < len; c += 64u) {
+                        const uint32_t i = c + lane;
+                        if (i < len) ring[(p + i) & (RING - 1u)] = ring[(p - dist + (dist >= len ? i : i % dist)) & (RING - 1u)];
                     }
                 }
                 const uint32_t kib = p >> 10;
