@@ -8,8 +8,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "liblash_gfx950.so")
-SOURCES = ["lash_api.hip", "sketch_set.hip", "sketch_kernels.hip", "sole_kernels.hip", "pack_kernels.hip", "fastq_check.hip", "dist_kernels.hip", "pair_planes.hip", "dist_estimators.hip"]
-HEADERS = ["lash_common.h", "lash_ctx.h", "lash_kernels.h", "lash_device.h", "sketch_rules.h", "ull_estimators.h", os.path.join(ROOT, "include", "lash_gfx950.h")]
+SOURCES = ["lash_api.hip", "lash_plan.hip", "lash_hll_replay.hip", "lash_dist_api.hip", "sketch_set.hip", "sketch_kernels.hip", "sole_kernels.hip", "pack_kernels.hip", "fastq_check.hip", "dist_kernels.hip", "pair_planes.hip", "dist_estimators.hip"]
+HEADERS = ["lash_common.h", "lash_ctx.h", "lash_internal.h", "lash_kernels.h", "lash_device.h", "sketch_rules.h", "ull_estimators.h", os.path.join(ROOT, "include", "lash_gfx950.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

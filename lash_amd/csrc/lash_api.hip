@@ -1,1257 +1,86 @@
-// lash_api.hip — the extern "C" boundary of liblash_gfx950.so (include/lash_gfx950.h): contexts, HBM workspace,
-// work-item planning and the three stages pack -> sketch -> finalize on one HIP stream.
+// lash_api.hip — the extern "C" boundary of liblash_gfx950.so (include/lash_gfx950.h): library / context / layout entries and the sketch
+// entries (record batches, packed genomes, raw files).  Round 6 moved the planning behind them to lash_plan.hip, the HyperLogLog `sum`
+// replay to lash_hll_replay.hip and the merge / dist-side entries to lash_dist_api.hip (lash_internal.h declares what they share).
 //
 // Reference side of the boundary: the per-file closure of sketch_files
 // (/root/reference/src/utils.rs:452-508) and KmerSketch::{new,add_kmer,save} (utils.rs:377-434).
 // There is no CPU fallback here: every compute entry needs a HIP device.
 #include "lash_ctx.h"
+#include "lash_internal.h"
 
-namespace {
-
-
-// Packs genomes [0, n_genomes) described by genome_rec_off / genome_byte_off (absolute record indices / byte offsets
-// into d_seq) on `stream`.  `ev`, when set, gets its pack-start / pack-end events recorded on that stream.
-int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, const uint8_t *d_seq, const uint8_t *d_seq_end,
-              const uint64_t *d_rec_off, uint64_t n_rec, const uint64_t *genome_rec_off, const uint64_t *genome_byte_off,
-              uint32_t n_genomes, const uint8_t *formats = nullptr, bool direct = false)
-{
-    // formats == nullptr: record sequences + rec_off table; else per genome LASH_FMT_FASTA / LASH_FMT_FASTQ raw file bytes
-    if (n_genomes && (!genome_byte_off || (!formats && !genome_rec_off))) return LASH_EINVAL;
-    pk->error_flag = nullptr;
-    pk->direct = direct && !formats && n_genomes;
-    direct = pk->direct;
-    pk->d_seq = d_seq;
-    std::vector<GenomeDesc> &descs = pk->h_descs;
-    descs.assign(n_genomes, GenomeDesc{});
-    pk->byte_len.assign(n_genomes, 0);
-    uint64_t wo = 0, bo = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g) {
-        if (genome_byte_off[g + 1] < genome_byte_off[g]) return LASH_EINVAL;
-        if (!formats && (genome_rec_off[g + 1] < genome_rec_off[g] || genome_rec_off[g + 1] > n_rec)) return LASH_EINVAL;
-        if (formats && formats[g] != LASH_FMT_FASTA && formats[g] != LASH_FMT_FASTQ) return LASH_EINVAL;
-        GenomeDesc &d = descs[g];
-        d.byte_off = genome_byte_off[g];
-        d.byte_len = genome_byte_off[g + 1] - genome_byte_off[g];
-        if (d.byte_len > 0xFFFFFFFFull - 64) return LASH_ELIMIT;
-        d.rec_begin = formats ? 0 : genome_rec_off[g];
-        d.rec_end = formats ? 0 : genome_rec_off[g + 1];
-        d.format = formats ? formats[g] : 0u;
-        d.handover = 1;
-        d.word_off = wo;
-        d.brk_off = bo;
-        pk->byte_len[g] = d.byte_len;
-        uint64_t nw = (d.byte_len + 15) / 16 + 2 * PAD_WORDS;
-        wo += (nw + 3) & ~3ull;                                   // keep every genome 16-byte aligned
-        bo += (d.byte_len + 1 + 31) / 32 + 4;                     // +3 words of look-ahead in kmer_valid_mask
-    }
-    pk->n_genomes = n_genomes;
-    pk->total_words = wo + 2 * PAD_WORDS;
-    pk->total_brk = bo + 4;
-    // tiles of the single-pass pack: genomes are cut at 16-byte-aligned addresses, tiles never straddle genomes
-    const uint64_t tile_bytes = pack_v2_tile_bytes();
-    std::vector<uint32_t> &tile_begin = pk->h_tile_begin;
-    tile_begin.assign(n_genomes + 1, 0);
-    uint64_t n_tiles = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g) {
-        tile_begin[g] = (uint32_t)n_tiles;
-        if (descs[g].byte_len) {
-            const uint64_t lead = (reinterpret_cast<uintptr_t>(d_seq) + descs[g].byte_off) & 15u;
-            n_tiles += (lead + descs[g].byte_len + tile_bytes - 1) / tile_bytes;
-        }
-        if (n_tiles > 0x7FFFFFFFull) return LASH_ELIMIT;
-    }
-    tile_begin[n_genomes] = (uint32_t)n_tiles;
-    TRACE("pack: tables built");
-    int rc;
-    // direct mode packs nothing (round 3: the genomes the direct pass gives up are redone from their ASCII bytes by
-    // stream_sketch_kernel), so there is no 2-bit stream, no tile table and no look-back state to make room for
-    if (!direct) {
-        if ((rc = reserve(ctx, pk->words, pk->total_words * 4))) return rc;
-        if ((rc = reserve(ctx, pk->brk, pk->total_brk * 4))) return rc;
-        if ((rc = reserve(ctx, pk->tiles, (size_t)(n_tiles + 1) * sizeof(TileInfo)))) return rc;
-    }
-    const size_t lb_bytes = direct ? 0 : (((size_t)(n_tiles + 2) * 12 + PACK_TICKET_SHARDS * 128 + 512) + 15) & ~(size_t)15;
-    if ((rc = reserve(ctx, pk->lookback, lb_bytes + (size_t)(5 * (size_t)n_genomes + 2) * 4))) return rc;
-    pk->d_dirty = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(pk->lookback.ptr) + lb_bytes);
-    if (direct && (rc = reserve(ctx, pk->tile_begin_c, (size_t)(n_genomes + 2) * 4))) return rc;
-    if (n_genomes == 0) return LASH_OK;
-    TRACE("pack: reserved");
-    bool any_multi = false;                                   // single-record genomes never consult the bitmap
-    for (uint32_t g = 0; g < n_genomes && !any_multi; ++g)
-        any_multi = descs[g].format != 0u || descs[g].rec_end - descs[g].rec_begin > 1;
-    pk->any_multi = any_multi;
-    pk->d_rec_off = d_rec_off;
-    pk->n_rec = n_rec;
-    // surviving bases per genome: written by the pack kernel; direct mode starts from "nothing deleted" (= bytes) and
-    // the deferred pack overwrites the genomes that turn out dirty
-    pk->h_nvalid.assign(n_genomes + 1, 0);
-    if (direct) std::copy(pk->byte_len.begin(), pk->byte_len.end(), pk->h_nvalid.begin());
-    if (ev) { ev->pack = true; HIPCHK(ctx, hipEventRecord(ev->e[0], stream)); }
-    if (!direct) {
-        std::vector<Section> sec = {{descs.data(), descs.size() * sizeof(GenomeDesc), 0},
-                                    {tile_begin.data(), tile_begin.size() * 4, 0},
-                                    {pk->h_nvalid.data(), pk->h_nvalid.size() * 8, 0}};
-        const size_t total = layout_sections(sec);
-        if ((rc = reserve(ctx, pk->tables, total))) return rc;
-        if ((rc = upload_sections(ctx, pk->tables.ptr, sec, total, stream))) return rc;
-        uint8_t *tb = static_cast<uint8_t *>(pk->tables.ptr);
-        pk->d_descs = reinterpret_cast<GenomeDesc *>(tb + sec[0].off);
-        pk->d_tile_begin = reinterpret_cast<uint32_t *>(tb + sec[1].off);
-        pk->d_nvalid = reinterpret_cast<uint64_t *>(tb + sec[2].off);
-        TRACE("pack: tables uploaded");
-        if (any_multi) HIPCHK(ctx, hipMemsetAsync(pk->brk.ptr, 0, pk->total_brk * 4, stream));
-        HIPCHK(ctx, hipMemsetAsync(pk->lookback.ptr, 0, lb_bytes + (formats ? (size_t)(5 * (size_t)n_genomes + 2) * 4 : 0), stream));
-        TRACE("pack: memsets queued");
-    } else {
-        // direct mode: tables go up together with the work items (sketch_from), the pack launch follows the direct pass
-        pk->d_descs = nullptr; pk->d_tile_begin = nullptr; pk->d_nvalid = nullptr;
-        if (any_multi && (rc = reserve(ctx, pk->brk_bytes, pk->total_brk * 4))) return rc;
-    }
-    PackArgs pa{};
-    pa.seq = d_seq;
-    pa.seq_end = d_seq_end;
-    pa.rec_off = d_rec_off;
-    pa.genomes = pk->d_descs;                                 // direct mode: filled in by direct_begin()
-    pa.words = static_cast<uint32_t *>(pk->words.ptr);
-    pa.brk = static_cast<uint32_t *>(pk->brk.ptr);
-    pa.nvalid = pk->d_nvalid;
-    pa.code_tab4 = layout_dev(ctx->layout, LASH_HMH).code_tab4;
-    pa.file_err = formats ? pk->d_dirty + 3 * (size_t)n_genomes + 1 : nullptr;      // raw files: FASTQ structure flags
-    uint64_t *lb = static_cast<uint64_t *>(pk->lookback.ptr);
-    PackV2Args v2{};
-    v2.tiles = static_cast<const TileInfo *>(pk->tiles.ptr);
-    v2.desc = lb;
-    v2.error_flag = reinterpret_cast<uint32_t *>(lb + n_tiles);
-    v2.desc2 = reinterpret_cast<uint32_t *>(lb + n_tiles + 1);
-    v2.ticket = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(v2.desc2 + n_tiles + 1) + 127) & ~(uintptr_t)127);
-    v2.n_tiles = (uint32_t)n_tiles;
-    PackMapArgs pm{};
-    pm.seq = d_seq;
-    pm.rec_off = d_rec_off;
-    pm.genomes = pa.genomes;
-    pm.tile_begin = pk->d_tile_begin;
-    pm.tiles = static_cast<TileInfo *>(pk->tiles.ptr);
-    pm.n_tiles = (uint32_t)n_tiles;
-    pm.n_genomes = n_genomes;
-    pk->error_flag = direct ? nullptr : v2.error_flag;        // (direct mode launches no pack kernel)
-    if (!direct) {
-        HIPCHK(ctx, launch_pack_v2(pa, v2, pm, (uint32_t)ctx->cu_count, formats != nullptr, stream));
-        if (formats) {
-            // FASTQ files: quality-line lengths and how the file ends, into the same flags (fastq_check.hip)
-            std::vector<FqFile> fq;
-            uint64_t blocks = 0;
-            const uint64_t bb = fastq_check_block_bytes();
-            for (uint32_t g = 0; g < n_genomes; ++g) {
-                if (formats[g] != LASH_FMT_FASTQ || descs[g].byte_len == 0) continue;
-                const uint64_t nb = (descs[g].byte_len + bb - 1) / bb;
-                fq.push_back(FqFile{descs[g].byte_off, descs[g].byte_len, (uint32_t)blocks, (uint32_t)nb, g, 0u});
-                blocks += nb;
-            }
-            if (blocks > 0x7FFFFFFFull) return LASH_ELIMIT;
-            if (!fq.empty()) {
-                std::vector<Section> sec = {{fq.data(), fq.size() * sizeof(FqFile), 0}};
-                const size_t total = layout_sections(sec), tab = total;
-                if ((rc = reserve(ctx, pk->fq, tab + fastq_check_scratch_words((uint32_t)fq.size(), (uint32_t)blocks) * 4))) return rc;
-                if ((rc = upload_sections(ctx, pk->fq.ptr, sec, total, stream))) return rc;
-                uint8_t *fb = static_cast<uint8_t *>(pk->fq.ptr);
-                HIPCHK(ctx, launch_fastq_check(d_seq, reinterpret_cast<const FqFile *>(fb + sec[0].off), (uint32_t)fq.size(), (uint32_t)blocks,
-                                               reinterpret_cast<uint32_t *>(fb + tab), pa.file_err, stream));
-            }
-        }
-    }
-    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[1], stream));
-    TRACE("pack: done");
-    return LASH_OK;
-}
-
-// direct mode, feedback: how much of the batch (in 16 KiB tiles) lies in genomes the direct pass gave up — counted on the device,
-// copied to a pinned word without waiting; lash_sketch_batch_device looks at it before its next call (dirty_frac).
-int probe_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
-{
-    uint32_t *tbc = static_cast<uint32_t *>(pk->tile_begin_c.ptr);
-    HIPCHK(ctx, launch_dirty_tile_scan(pk->d_tile_begin, pk->d_dirty, pk->n_genomes, tbc, tbc + pk->n_genomes + 1, stream));
-    if (!ctx->probe_host) {
-        HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->probe_host), 64, hipHostMallocDefault));
-        ctx->probe_host[0] = 0;
-        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->probe_ev, hipEventDisableTiming));
-    }
-    if (!ctx->probe_pending) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->probe_host, tbc + pk->n_genomes + 1, 4, hipMemcpyDeviceToHost, stream));
-        HIPCHK(ctx, hipEventRecord(ctx->probe_ev, stream));
-        ctx->probe_pending = true;
-        ctx->probe_tiles = pk->h_tile_begin.empty() ? 0 : pk->h_tile_begin.back();
-    }
-    return LASH_OK;
-}
-
-// ---- binned launches (SketchPlan::bins; sketch_kernels.hip "BinRegs") ---------------------------------------------------------
-// Register tables beyond 128 KiB of LDS: the sketch kernels hash every k-mer once and append a 4-byte entry to the list of its bin,
-// bins_apply_kernel builds each bin's registers in LDS and leaves ONE partial per genome ("virtual item" n_items + g) for the
-// ordinary finalize stage.  Lists, counters and fallback tables are sized per genome GROUP (a few GiB at a time; the stream orders
-// the groups, so the buffers are reused), from an upper bound of the entries each genome's work items push.
-// HBM one group of a binned launch (or one chunk of per-item global tables) may take: LASH_BINS_MB, default 6 GiB; read per call
-uint64_t bins_budget_bytes()
-{
-    const char *e = getenv("LASH_BINS_MB");
-    return (e ? (uint64_t)std::max(64, atoi(e)) : 6144ull) << 20;
-}
-
-struct BinsRun {
-    std::vector<uint32_t> group_end;                  // genome index at which each group ends
-    std::vector<BinGenome> table;                     // per genome: list offset inside its group's buffer, list capacity
-    const BinGenome *d_table = nullptr;
-    uint32_t *d_cnt = nullptr, *d_spill = nullptr;    // [max group][bins], [max group]
-    WorkItem *d_vitems = nullptr;                     // one virtual item per genome
-    uint32_t *d_vbegin = nullptr;                     // 0, 1, ..., n_genomes
-    uint32_t slab_words = 0, max_group = 0;
-    bool fits = true;
-};
-static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector<uint64_t> &entries_of_genome, uint32_t n_genomes, BinsRun &br)
-{
-    const uint32_t B = 1u << plan.bins_log2;
-    br.slab_words = plan.nreg32;                                     // HLL: 2^p words, ULL: 2 * 2^p
-    const uint64_t budget = bins_budget_bytes();
-    br.table.resize(n_genomes);
-    uint64_t bytes = 0, off = 0, group_max_bytes = 0;
-    uint32_t in_group = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g) {
-        // a row's entries leave padded to a multiple of four: (m + 1.5) / m on average for rows of m entries per flush
-        const uint64_t m_row = std::max<uint64_t>(1, 1024u >> (plan.bins_log2 + plan.bin_sub_shift));
-        uint64_t mean = entries_of_genome[g] / B * (2 * m_row + 4) / (2 * m_row);
-        uint64_t sq = 1; while (sq * sq < mean) ++sq;
-        const uint64_t cap = (mean + mean / 8 + 8 * sq + 1024 + 63) & ~63ull;
-        if (cap > 0xFFFFFFFFull) { br.fits = false; return LASH_OK; }
-        const uint64_t mine = B * cap * 4 + (uint64_t)br.slab_words * 4;
-        if (mine > budget) { br.fits = false; return LASH_OK; }     // one genome beyond the budget: the caller takes the global-table path
-        if (in_group && (bytes + mine > budget || in_group == 65535u)) {
-            br.group_end.push_back(g);
-            br.max_group = std::max(br.max_group, in_group);
-            bytes = 0; off = 0; in_group = 0;
-        }
-        br.table[g] = BinGenome{off, (uint32_t)cap, 0u};
-        off += B * cap;
-        bytes += mine;
-        group_max_bytes = std::max(group_max_bytes, off * 4);
-        ++in_group;
-    }
-    br.group_end.push_back(n_genomes);
-    br.max_group = std::max(br.max_group, in_group);
-    int rc;
-    if ((rc = reserve(ctx, ctx->bins_lists, group_max_bytes + 256))) return rc;
-    {
-        void *before = ctx->bins_slab.ptr;
-        if ((rc = reserve(ctx, ctx->bins_slab, (size_t)br.max_group * br.slab_words * 4 + 256))) return rc;
-        if (ctx->bins_slab.ptr != before) ctx->bins_slab_fill = -1;     // new memory: contents unknown
-    }
-    std::vector<WorkItem> vitems(n_genomes);
-    std::vector<uint32_t> vbegin(n_genomes + 1);
-    for (uint32_t g = 0; g < n_genomes; ++g) { vitems[g] = WorkItem{g, 0u, 4u, 0u}; vbegin[g] = g; }
-    vbegin[n_genomes] = n_genomes;
-    std::vector<Section> sec = {{br.table.data(), br.table.size() * sizeof(BinGenome), 0}, {vitems.data(), vitems.size() * sizeof(WorkItem), 0},
-                                {vbegin.data(), vbegin.size() * 4, 0}};
-    const size_t tabs = layout_sections(sec), cnt_bytes = ((size_t)br.max_group * B * 4 + 255) & ~(size_t)255, spill_bytes = cnt_bytes;   // (one flag per bin)
-    if ((rc = reserve(ctx, ctx->bins_meta, tabs + cnt_bytes + spill_bytes + 256))) return rc;
-    if ((rc = upload_sections(ctx, ctx->bins_meta.ptr, sec, tabs, ctx->stream))) return rc;
-    uint8_t *mb = static_cast<uint8_t *>(ctx->bins_meta.ptr);
-    br.d_table = reinterpret_cast<const BinGenome *>(mb + sec[0].off);
-    br.d_vitems = reinterpret_cast<WorkItem *>(mb + sec[1].off);
-    br.d_vbegin = reinterpret_cast<uint32_t *>(mb + sec[2].off);
-    br.d_cnt = reinterpret_cast<uint32_t *>(mb + tabs);
-    br.d_spill = reinterpret_cast<uint32_t *>(mb + tabs + cnt_bytes);
-    return LASH_OK;
-}
-// the launches of one call, group by group: launch(sa, first item, items) queues the sketch kernels of an item range
-template <class Launch>
-static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *prm, SketchArgs sa, const BinsRun &br, const std::vector<uint32_t> &item_begin,
-                    uint32_t n_items, const uint32_t *d_item_begin, Launch launch)
-{
-    const uint32_t B = 1u << plan.bins_log2;
-    sa.bin_lists = static_cast<uint32_t *>(ctx->bins_lists.ptr);
-    sa.bin_cnt = br.d_cnt;
-    sa.bin_slab = static_cast<uint32_t *>(ctx->bins_slab.ptr);
-    sa.bin_spill = br.d_spill;
-    sa.bins = B; sa.bin_shift = plan.bin_shift; sa.bin_S = plan.bin_S; sa.bin_sub_shift = plan.bin_sub_shift; sa.bin_slab_words = br.slab_words;
-    sa.item_order = nullptr;
-    // the fallback tables: empty at rest (bins_apply_kernel wipes what it folds in); wiped here only when new, or last left by the other sketch type
-    {
-        const int fill = prm->algo == LASH_ULL ? 0x00 : 0xFF;
-        const size_t need = (size_t)br.max_group * br.slab_words * 4;
-        if (ctx->bins_slab_fill != fill || ctx->bins_slab_clean < need) {
-            HIPCHK(ctx, hipMemsetAsync(ctx->bins_slab.ptr, fill, need, ctx->stream));
-            ctx->bins_slab_clean = need;
-        }
-        ctx->bins_slab_fill = -1;                                      // (until this call's last bins_apply_kernel is queued)
-    }
-    uint32_t g0 = 0;
-    for (uint32_t g1 : br.group_end) {
-        const uint32_t ng = g1 - g0;
-        HIPCHK(ctx, hipMemsetAsync(br.d_cnt, 0, (size_t)ng * B * 4, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(br.d_spill, 0, (size_t)ng * B * 4, ctx->stream));
-        sa.bin_genomes = br.d_table + g0;
-        sa.bin_genome0 = g0;
-        sa.item_base = item_begin[g0];
-        int rc = launch(sa, item_begin[g0], item_begin[g1] - item_begin[g0]);
-        if (rc) return rc;
-        BinApplyArgs ba{};
-        ba.lists = sa.bin_lists; ba.cnt = br.d_cnt; ba.slab = sa.bin_slab; ba.spill = br.d_spill; ba.genomes = sa.bin_genomes;
-        ba.partials = sa.partials; ba.item_kmers = sa.item_kmers; ba.genome_item_begin = d_item_begin;
-        ba.items = sa.items; ba.nvalid = sa.nvalid; ba.k = prm->k;
-        ba.partial_stride = sa.partial_stride; ba.virt0 = n_items + g0; ba.genome0 = g0;
-        ba.bins = B; ba.bin_shift = plan.bin_shift; ba.slab_words = br.slab_words; ba.algo = prm->algo; ba.p = prm->p;
-        HIPCHK(ctx, launch_bins_apply(ba, ng, ctx->stream));
-        g0 = g1;
-    }
-    ctx->bins_slab_fill = prm->algo == LASH_ULL ? 0x00 : 0xFF;
-    return LASH_OK;
-}
-
-// UltraLogLog p >= 23: every work item updates a table of its own in global memory (2^p x 8 bytes: 64 MiB at p = 23, 512 MiB at
-// p = 26).  The items of a call run a chunk at a time so that the tables of one chunk fit a budget (round 4; a table per item of
-// the whole call was 256 GB for 200 genomes at p = 23); launch(sa, items) queues the sketch kernels of an item range.
-template <class Launch>
-static int global_run(lash_ctx *ctx, const SketchPlan &plan, SketchArgs sa, uint32_t n_items, Launch launch)
-{
-    const uint64_t budget = bins_budget_bytes();
-    const uint64_t table = (uint64_t)plan.nreg32 * 4;
-    const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_items ? n_items : 1, budget / table));
-    int rc;
-    if ((rc = reserve(ctx, ctx->gregs, (size_t)per * table + 256))) return rc;
-    sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
-    sa.item_order = nullptr;
-    for (uint32_t i0 = 0; i0 < n_items; i0 += per) {
-        const uint32_t n = std::min(per, n_items - i0);
-        HIPCHK(ctx, hipMemsetAsync(ctx->gregs.ptr, 0, (size_t)n * table, ctx->stream));
-        sa.item_base = i0;
-        if ((rc = launch(sa, n))) return rc;
-    }
-    return LASH_OK;
-}
-
-// ---- whole small genomes on persistent workgroups (sole_kernels.hip, round 5) --------------------------------------------------
-// Which genomes of a call the persistent kernel takes: those of at most LASH_SOLE_MAX bytes (0 = none), when the sketch's table
-// fits its LDS budget and nothing asks for another route.
-uint64_t sole_max_bytes(const lash_ctx *ctx, const lash_params *prm, const SolePlan &sp)
-{
-    if (!sp.ok || (prm->flags & (LASH_F_NO_SOLE | LASH_F_AMINO | LASH_F_STREAM_ONLY))) return 0;
-    if (getenv("LASH_STREAM_FIRST")) return 0;                       // (A/B knob of tools/: every genome through stream_sketch_kernel)
-    const char *e = getenv("LASH_SOLE_MAX");                         // read per call: tests and tools flip it in-process
-    const long long v = e ? atoll(e) : 393216;
-    // (the kernel holds a genome's length and offsets in 32 bits: anything that large belongs to the sliced kernels anyway)
-    return v > 0 ? (uint64_t)std::min<long long>(v, 64ll << 20) : 0;
-}
-
-// chunks per workgroup: the launch's tail is one chunk long (tools/: LASH_SOLE_CHUNKS)
-uint32_t sole_chunks_per_wg()
-{
-    const char *e = getenv("LASH_SOLE_CHUNKS");
-    const int v = e ? atoi(e) : 24;
-    return (uint32_t)std::max(1, std::min(v, 4096));
-}
-
-// Chunks of consecutive genomes of about equal cost, planned from the genome byte offsets alone: cost = bytes + a fixed part per
-// genome (its flush).  off[g] = first byte (or any monotone position) of genome g, off[n] = the end.
-void sole_chunks(const uint64_t *off, uint32_t n_genomes, uint64_t fixed, uint32_t want, std::vector<uint32_t> &chunk_begin)
-{
-    const uint32_t n_chunks = std::max(1u, std::min(want, n_genomes));
-    chunk_begin.resize(n_chunks + 1);
-    const long double total = (long double)(off[n_genomes] - off[0]) + (long double)fixed * n_genomes;
-    uint32_t g = 0;
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-        chunk_begin[c] = g;
-        const long double goal = total * (c + 1) / n_chunks;
-        // first genome whose PREFIX cost reaches the goal: binary search (cost is monotone in g)
-        uint32_t lo = g, hi = n_genomes;
-        while (lo < hi) {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            const long double cost = (long double)(off[mid + 1] - off[0]) + (long double)fixed * (mid + 1);
-            if (cost < goal) lo = mid + 1; else hi = mid;
-        }
-        g = std::min(n_genomes, std::max(lo + 1, g + 1));            // at least one genome per chunk
-        if (n_genomes - g < n_chunks - 1 - c) g = n_genomes - (n_chunks - 1 - c);   // ... and one left for each chunk to come
-    }
-    chunk_begin[n_chunks] = n_genomes;
-}
-
-// Queues the persistent kernel over every genome of at most `max_len` bytes (+ the record-start marks it reads, + its census).
-// ASCII source: d_seq / d_rec_off / host genome_byte_off; packed source: pk.  per_genome_ndel: the direct pass's per-genome
-// deleted-byte counts (calls that also run the sliced launch keep lash_timing::bases_last per genome), else NULL.
-int sole_run(lash_ctx *ctx, const lash_params *prm, const SolePlan &sp, uint64_t max_len, const uint8_t *d_seq, uint64_t seq_bytes,
-             const uint64_t *d_rec_off, uint64_t n_rec, bool any_multi, bool rec_identity, const uint64_t *genome_byte_off, const lash_packed *pk,
-             uint32_t n_genomes, uint8_t *d_out_images, uint32_t *per_genome_ndel)
-{
-    if (n_genomes == 0) return LASH_OK;
-    const bool packed = pk != nullptr;
-    const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
-    const bool x_low = rule_variant(ctx->layout, prm->algo, prm->flags);   // (HyperMinHash x = low half / HyperLogLog bucket = top bits)
-    // as many workgroups as are RESIDENT at a time (the kernel variant's registers, LDS and wave slots taken together): chunks are handed
-    // out to running workgroups, one that started late would only hold its first chunk back
-    uint32_t per_cu = sp.wg_per_cu;
-    HIPCHK(ctx, sole_resident_per_cu(sp, prm->algo, prm->k, x_low, packed, &per_cu));
-    uint32_t n_wg = (uint32_t)std::min<uint64_t>((uint64_t)ctx->cu_count * per_cu, n_genomes);
-    // (tests and the randomized runners: FEW workgroups, so that a test batch of a hundred genomes walks the paths of a collection of a
-    //  million — several genomes per chunk, one after the other on the same rings and table, the next one's bytes in flight.  Without
-    //  this every genome of a small batch has a workgroup of its own; a stale ring pointer survived round 5's suite that way.)
-    if (const char *e = getenv("LASH_SOLE_WGS")) n_wg = (uint32_t)std::max(1, std::min<int>((int)n_wg, atoi(e)));
-    // chunks: a couple of dozen per workgroup, so that the tail of the launch is a few percent of a workgroup's share — but none
-    // smaller than ~100 us of a workgroup's time (a chunk starts with a few dependent loads: 3..5 us)
-    std::vector<uint32_t> chunk_begin;
-    std::vector<uint64_t> off_tmp;
-    const uint64_t *off = genome_byte_off;
-    if (packed) {
-        off_tmp.resize((size_t)n_genomes + 1);
-        off_tmp[0] = 0;
-        for (uint32_t g = 0; g < n_genomes; ++g) off_tmp[g + 1] = off_tmp[g] + pk->byte_len[g];
-        off = off_tmp.data();
-    }
-    {
-        const uint64_t fixed = image_bytes / 4 + 256;
-        const uint64_t total = off[n_genomes] - off[0] + fixed * n_genomes;
-        const uint64_t min_cost = 512ull * sp.threads;                     // 256 KiB for eight waves, 32 KiB for one
-        const uint64_t by_cost = std::max<uint64_t>(n_wg, total / min_cost);
-        sole_chunks(off, n_genomes, fixed, (uint32_t)std::min<uint64_t>((uint64_t)n_wg * sole_chunks_per_wg(), by_cost), chunk_begin);
-    }
-    const uint32_t n_chunks = (uint32_t)chunk_begin.size() - 1;
-    int rc;
-    std::vector<Section> sec = {{chunk_begin.data(), chunk_begin.size() * 4, 0}};
-    // every genome exactly one record (the usual case: one sequence per file): its byte offsets ARE the record offsets, which are
-    // resident already — no per-genome table goes up at all
-    // (identity mapping only: genome_rec_off = [0, 1, 1] with two records has n_rec == n_genomes and no multi-record genome either — ADVICE r5)
-    const bool gbo_is_rec_off = !packed && !any_multi && n_rec == n_genomes && d_rec_off != nullptr && rec_identity;
-    if (!packed && !gbo_is_rec_off) sec.push_back({genome_byte_off, ((size_t)n_genomes + 1) * 8, 0});
-    const size_t tabs = layout_sections(sec), counts_bytes = ((size_t)n_wg * 16 + 255) & ~(size_t)255;
-    if ((rc = reserve(ctx, ctx->sole_tab, tabs + counts_bytes + 256))) return rc;
-    if ((rc = upload_sections(ctx, ctx->sole_tab.ptr, sec, tabs, ctx->stream))) return rc;
-    uint8_t *tb = static_cast<uint8_t *>(ctx->sole_tab.ptr);
-    if (!ctx->sole_state.ptr) {
-        // the chunk ticket: zero at rest (sole_census_kernel, which follows every launch on the stream, puts it back)
-        if ((rc = reserve(ctx, ctx->sole_state, 256))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->sole_state.ptr, 0, 256, ctx->stream));
-    }
-    if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
-    if (!ctx->counter_zeroed) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));
-        ctx->counter_zeroed = true;
-    }
-    SoleArgs sa{};
-    sa.chunk_begin = reinterpret_cast<const uint32_t *>(tb + sec[0].off);
-    sa.n_chunks = n_chunks;
-    sa.ticket = static_cast<uint32_t *>(ctx->sole_state.ptr);
-    sa.wg_counts = reinterpret_cast<unsigned long long *>(tb + tabs);
-    sa.max_len = max_len;
-    sa.safe = static_cast<const uint8_t *>(ctx->counter.ptr) + 128;
-    if (!packed) {
-        sa.seq = d_seq;
-        sa.seq_bytes = seq_bytes;
-        sa.genome_byte_off = gbo_is_rec_off ? d_rec_off : reinterpret_cast<const uint64_t *>(tb + sec[1].off);
-        sa.ndel = per_genome_ndel;
-        if (any_multi) {
-            // some genome has more than one record: record starts as bits at absolute byte positions (16 spare bytes: a lane reads
-            // its 16 bits with one 4-byte load at any alignment)
-            const size_t bm_bytes = ((seq_bytes + 63) / 32 + 2) * 4 + 2048;    // (+ a round of the widest workgroup: the prefetch past the last genome)
-            if ((rc = reserve(ctx, ctx->sole_brk, bm_bytes))) return rc;
-            HIPCHK(ctx, hipMemsetAsync(ctx->sole_brk.ptr, 0, bm_bytes, ctx->stream));
-            HIPCHK(ctx, launch_sole_mark(d_rec_off, n_rec, seq_bytes, static_cast<uint32_t *>(ctx->sole_brk.ptr), ctx->stream));
-            sa.brk_abs = static_cast<const uint32_t *>(ctx->sole_brk.ptr);
-        }
-    } else {
-        sa.words = static_cast<const uint32_t *>(pk->words.ptr);
-        sa.brk = static_cast<const uint32_t *>(pk->brk.ptr);
-        sa.genomes = pk->d_descs;
-        sa.nvalid = pk->d_nvalid;
-    }
-    sa.images = d_out_images;
-    sa.image_bytes = image_bytes;
-    {
-        const double alpha0 = hll_alpha(prm->p);
-        memcpy(&sa.alpha_bits, &alpha0, 8);
-    }
-    sa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
-    sa.hll_corner = prm->algo == LASH_HLL ? static_cast<uint32_t *>(ctx->hll_flags.ptr) : nullptr;
-    sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
-    sa.lay = layout_dev(ctx->layout, prm->algo);
-    sa.nreg32 = prm->algo == LASH_HMH ? HMH_M : prm->algo == LASH_HLL ? (1u << prm->p) : (2u << prm->p);
-    sa.k = prm->k;
-    sa.p = prm->p;
-    HIPCHK(ctx, launch_sole(sp, prm->algo, prm->k, x_low, packed, sa, n_wg, ctx->stream));
-    unsigned long long *ctr = static_cast<unsigned long long *>(ctx->counter.ptr);
-    HIPCHK(ctx, launch_sole_census(sa.wg_counts, n_wg, ctr, ctr + 1, sa.ticket, ctx->stream));
-    ctx->last.sole_launches += 1;
-    return LASH_OK;
-}
-
-int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, uint8_t *d_out_images, EvSet *ev, bool allow_bins = true)
-{
-    const uint32_t n_genomes = pk->n_genomes;
-    // Genomes of at most sole_max bytes go to the persistent kernel (sole_kernels.hip), the others are cut into work items as ever;
-    // blen() is a genome's length as the planning below sees it (0 = not this launch's)
-    const SolePlan sole_plan = make_sole_plan(prm->algo, prm->p, n_genomes, (uint32_t)ctx->cu_count);
-    uint64_t sole_max = sole_max_bytes(ctx, prm, sole_plan);
-    if (pk->direct && n_genomes && pk->h_descs[n_genomes - 1].byte_off + pk->h_descs[n_genomes - 1].byte_len < 16) sole_max = 0;   // (the kernel loads 16 bytes at a time, from inside the buffer)
-    auto blen = [&](uint32_t g) -> uint64_t { return pk->byte_len[g] <= sole_max && sole_max ? 0 : pk->byte_len[g]; };
-    uint32_t n_sole = 0;
-    if (sole_max) for (uint32_t g = 0; g < n_genomes; ++g) n_sole += pk->byte_len[g] <= sole_max;
-    const bool x_low = rule_variant(ctx->layout, prm->algo, prm->flags);   // (HyperMinHash x = low half / HyperLogLog bucket = top bits)
-    // what the persistent kernel's launch needs from a batch in direct mode (ASCII in the caller's buffer)
-    std::vector<uint64_t> sole_gbo;
-    auto sole_launch = [&](uint32_t *ndel) -> int {
-        if (pk->direct) {
-            sole_gbo.resize((size_t)n_genomes + 1);
-            for (uint32_t g = 0; g < n_genomes; ++g) sole_gbo[g] = pk->h_descs[g].byte_off;
-            sole_gbo[n_genomes] = pk->h_descs[n_genomes - 1].byte_off + pk->h_descs[n_genomes - 1].byte_len;
-            bool identity = pk->n_rec == n_genomes;                        // genome g IS record g (then the resident record offsets serve as byte offsets)
-            for (uint32_t g = 0; g < n_genomes && identity; ++g) identity = pk->h_descs[g].rec_begin == g && pk->h_descs[g].rec_end == g + 1u;
-            return sole_run(ctx, prm, sole_plan, sole_max, pk->d_seq, sole_gbo[n_genomes], pk->d_rec_off, pk->n_rec, pk->any_multi, identity, sole_gbo.data(),
-                            nullptr, n_genomes, d_out_images, ndel);
-        }
-        return sole_run(ctx, prm, sole_plan, sole_max, nullptr, 0, nullptr, 0, false, false, nullptr, pk, n_genomes, d_out_images, nullptr);
-    };
-    if (n_sole == n_genomes && n_genomes && !pk->direct) {
-        // a packed batch of small genomes only (lash_sketch_packed_device, raw files, LASH_F_NO_DIRECT): no work items at all
-        int rc;
-        ctx->hll_flags_n = 0;
-        ctx->hll_flags_on_host = false;
-        if (prm->algo == LASH_HLL) {                                    // (every genome's flag is written by the kernel: nothing to clear)
-            if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
-            ctx->hll_flags_n = n_genomes;
-        }
-        if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
-        if ((rc = sole_launch(nullptr))) return rc;
-        if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream)); HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
-        ctx->last_packed.push_back(pk);
-        ctx->last.sketch_launches += 1;
-        ctx->last.sketch_workgroups = (uint32_t)std::min<uint64_t>((uint64_t)ctx->cu_count * sole_plan.wg_per_cu, n_genomes);
-        return LASH_OK;
-    }
-    uint64_t total_bytes = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g) total_bytes += blen(g);
-    const bool small_items = n_genomes > n_sole && total_bytes / (n_genomes - n_sole) < 100000u;
-    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, allow_bins);
-    if (plan.bins) {
-        // a binned launch keeps ~4.6 bytes per input byte of one genome group in HBM: a single genome beyond the budget (a multi-Gbp
-        // input in one call, which the CLI would have streamed in chunks) takes the table-in-global-memory path instead
-        const uint64_t budget = bins_budget_bytes();
-        uint64_t big = 0;
-        for (uint32_t g = 0; g < n_genomes; ++g) big = std::max<uint64_t>(big, pk->byte_len[g]);
-        if (big * 5 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget)
-            plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, small_items, false);
-    }
-    const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
-
-    // ---- plan work items: slices of genomes, enough of them to keep every CU's workgroup slots busy ----
-    const bool defer_eligible = prm->algo == LASH_HMH && plan.use_lds && plan.parts_log2 == 0;   // (see plan_d below)
-    const uint32_t lds_wg = plan.lds_bytes + ((pk->direct || defer_eligible || plan.bytes) ? sketch_direct_stage_bytes(plan) : 0u);   // + the waves' staging areas / lists
-    const uint32_t wg_per_cu = plan.use_lds ? std::max(1u, (160u * 1024u) / std::max(lds_wg, 1u)) : 4u;   // 64 KiB + census -> 2
-    const uint64_t slots = (uint64_t)ctx->cu_count * std::min(wg_per_cu, 2048u / plan.threads);
-    uint64_t total_words = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g) total_words += (blen(g) + 15) / 16;
-    const uint64_t step = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
-    const uint64_t min_slice = step * 8;                           // amortise the LDS clear + flush
-    static const uint64_t slice_factor_env = getenv("LASH_SLICE_FACTOR") ? std::max(1, atoi(getenv("LASH_SLICE_FACTOR"))) : 0;
-    uint64_t len_lo = ~0ull, len_hi = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g) { len_lo = std::min<uint64_t>(len_lo, blen(g)); len_hi = std::max<uint64_t>(len_hi, blen(g)); }
-    const bool equal_genomes = n_genomes > 0 && len_hi <= len_lo + len_lo / 4;
-    // HyperMinHash launches that may defer their signatures (below) like long items — a slice starts with an empty table, and the share
-    // of k-mers that pass the filter is 2.8 % over a whole 5 Mbp genome, 7.7 % over a third of one — and the split tail (below) has
-    // taken over what the many small slices were for: 2x the slots there (1 000 x 5 Mbp: 4.39 -> 4.33 ms, round 3), and for batches of
-    // EQUAL genomes 1x: BASELINE configs[1], 1 000 x 5 Mbp, runs whole genomes in two rounds instead of thirds in six (4.12 -> 3.95 ms,
-    // profiles/r04/cfg1_slicing.txt; a collection of unequal genomes loses a third with that: it needs the item cap below)
-    const uint64_t slice_factor = slice_factor_env ? slice_factor_env : (defer_eligible ? (equal_genomes ? 1 : 2) : 4);   // tuning knob: the
-    // sketch time is flat from 2x to 24x the slots (4.87-4.91 ms on the default bench), the finalize time grows with it
-    uint64_t target = total_words / (slots * slice_factor) + 1;
-    // a table in global memory per work item (UltraLogLog p >= 23: 64 .. 512 MiB each, zeroed before and read back after): few, long items
-    if (!plan.use_lds) target = total_words / std::max<uint64_t>(1, slots / 4) + 1;
-    target = std::max(target, min_slice);
-    {
-        // When some genome is cut anyway (so partials and the finalize pass exist whatever the slicing), items of at most 1 MiB: a
-        // large batch would otherwise get multi-megabyte items, and the few genomes handed to stream_sketch_kernel — one or two
-        // items each — would run on a fraction of the chip (2 000 mixed genomes: that launch 1.6 ms -> 0.5 ms).
-        // (2 MiB where the launch may defer signatures: that kernel wants long items — the same collection 7.83 -> 7.50 ms, while the
-        // HyperLogLog kernel loses with the larger items, 8.09 -> 8.49 ms)
-        static const uint64_t cap_env = getenv("LASH_ITEM_CAP_WORDS") ? std::max(1024, atoi(getenv("LASH_ITEM_CAP_WORDS"))) : 0;
-        const uint64_t cap = cap_env ? cap_env : (defer_eligible ? 131072 : 65536);
-        // (only for batches of unequal genomes: a batch of equal ones keeps its few large items — when those are soft-masked they all
-        // are, every item is busy in both launches, and smaller items only add ramp-up: -3 % on bench.py --dirty lower)
-        bool any_cut = false;
-        uint64_t lo = ~0ull, hi = 0;
-        for (uint32_t g = 0; g < n_genomes; ++g) {
-            any_cut = any_cut || (((blen(g) + 15) / 16 + 3) & ~3ull) > target;
-            lo = std::min<uint64_t>(lo, blen(g)); hi = std::max<uint64_t>(hi, blen(g));
-        }
-        if (any_cut && hi > lo + lo / 4) target = std::max(min_slice, std::min(target, cap));
-    }
-    std::vector<WorkItem> items;
-    uint32_t max_slices = 0;                                       // most slices any genome is cut into
-    bool all_sole = plan.parts_log2 == 0 && plan.use_lds && !plan.bins && n_genomes > 0;   // every genome has exactly one work item
-    std::vector<uint32_t> item_begin(n_genomes + 1, 0);
-    items.reserve(n_genomes * 2);
-    auto slicing = [&](uint32_t g, uint64_t &nw, uint64_t &ns, uint64_t &per) {
-        nw = ((blen(g) + 15) / 16 + 3) & ~3ull;
-        ns = nw ? (nw + target - 1) / target : 0;
-        per = nw ? (((nw + ns - 1) / ns) + 3) & ~3ull : 0;
-    };
-    // The tail of a launch: equal items run in lockstep rounds of `slots`, and the last round is as long as a full one however
-    // few items it holds (600 x 5 Mbp in 2 400 items = 4.7 rounds took the time of 5; 12 500 whole genomes 24.4 -> 25).  The last
-    // round's worth of slices is therefore cut into quarters: the launch ends on a quarter-round boundary instead.  Index order is
-    // launch order, so the small items are the ones handed out last.
-    static const uint32_t tail_split_env = getenv("LASH_TAIL_SPLIT") ? (uint32_t)std::max(1, atoi(getenv("LASH_TAIL_SPLIT"))) : 0u;
-    // (halves where whole genomes may defer signatures: a quarter of a genome fills its table four times over)
-    // (none where every genome goes straight to stream_sketch_kernel — recent batches were soft-masked: a wave of that kernel walks a
-    //  contiguous sixteenth of its item and pays per part: its ring's warm-up, the look-ahead past its part, a last batch under a
-    //  mask.  10 kb blocks 2.94 -> 2.80 ms, 2.5 kb blocks 3.39 -> 3.27 ms per 1 000 x 5 Mbp)
-    const uint32_t tail_split = tail_split_env ? tail_split_env : (pk->direct && pk->stream_first ? 1u : (defer_eligible && equal_genomes ? 2u : 4u));
-    const uint64_t tail_min = min_slice / 8;                        // 32 kb of sequence: 15 us of a workgroup's time
-    const bool tail_geo = !(getenv("LASH_TAIL_GEO") && atoi(getenv("LASH_TAIL_GEO")) == 0);   // A/B knob (read per call): 0 = the uniform split of rounds 3-5
-    uint64_t n_coarse = 0, fine_from = ~0ull;
-    uint64_t c_lo = ~0ull, c_hi = 0;                               // smallest and largest slice
-    for (uint32_t g = 0; g < n_genomes; ++g) {
-        uint64_t nw, ns, per;
-        slicing(g, nw, ns, per);
-        if (!nw) continue;
-        const uint64_t cnt = (nw + per - 1) / per, last = nw - (cnt - 1) * per;
-        n_coarse += cnt;
-        c_lo = std::min(c_lo, last); c_hi = std::max(c_hi, cnt > 1 ? per : last);
-    }
-    const bool unequal = c_hi > c_lo + c_lo / 4;                   // then the launch goes longest first (below) and ends on its small items anyway
-    // (two or three rounds' worth in quarters, or halves / eighths: the same within noise)
-    if (plan.use_lds && tail_split > 1 && n_coarse > slots && !unequal) fine_from = n_coarse - slots;
-    uint64_t ci = 0;                                               // coarse slice counter over the batch
-    for (uint32_t g = 0; g < n_genomes; ++g) {
-        item_begin[g] = (uint32_t)items.size();
-        uint64_t nw, ns, per;
-        slicing(g, nw, ns, per);
-        if (nw == 0) { all_sole = false; continue; }               // no work item at all: finalize writes the empty image (or it is the
-                                                                   // persistent kernel's: FinalizeArgs::skip_max_len)
-        uint32_t s = 0;
-        const bool whole = ns == 1 && plan.parts_log2 == 0 && plan.use_lds && !plan.bins;
-        for (uint64_t b = 0; b < nw; b += per, ++ci) {
-            const uint64_t e = std::min(nw, b + per);
-            uint64_t sub = e - b;                                  // this slice as one item, or as tail_split smaller ones
-            if (ci >= fine_from) {
-                // ... and the later HALF of that last round in twice as many parts, its last QUARTER in four times as many (round 6): sizes
-                // are what the host balances by, but a byte's cost varies sixfold with what it holds — the soft-masked half of a genome runs
-                // at 0.07 us per kB, the clean half at 0.41 — so a launch of equal halves can still end on one full half running alone
-                // (profiles/r06/dirty_2500000_trace.txt: the last items started at 2.5 of 3.5 ms).  Ever smaller items towards the end
-                // bound that tail whatever the bytes cost; on clean input it is neutral (12 500 x 5 Mbp, 1 000 x 5 Mbp: profiles/r06/tail_geo_ab.txt)
-                uint64_t split = tail_split;
-                const uint64_t from_end = n_coarse - 1 - ci;
-                if (tail_geo && from_end < slots / 2) split *= 2;
-                if (tail_geo && from_end < slots / 4) split *= 2;
-                while (split > 1 && (e - b) / split < tail_min) split /= 2;
-                if (split > 1) sub = ((((e - b) + split - 1) / split) + 3) & ~3ull;
-            }
-            const bool sole = whole && sub == e - b;
-            for (uint64_t bb = b; bb < e; bb += sub, ++s)
-                for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)               // slice index | pass << 16
-                    items.push_back(WorkItem{g, (uint32_t)bb, (uint32_t)std::min(e, bb + sub), (s & 0x7FFFu) | (part << 16) | (sole ? ITEM_SOLE : 0u)});
-        }
-        max_slices = std::max<uint32_t>(max_slices, s);
-        if (s != 1) all_sole = false;
-    }
-    item_begin[n_genomes] = (uint32_t)items.size();
-    const uint32_t n_items = (uint32_t)items.size();
-    if (pk->direct) {
-        // how many waves must judge a genome too dirty before it is handed over: one for a genome of a few items, 1 in 32 for a 3 Gbp
-        // read set cut into thousands (where SOME wave always meets four reads with an N among its first tiles)
-        lash_packed *mpk = const_cast<lash_packed *>(pk);
-        for (uint32_t g = 0; g < n_genomes; ++g)
-            mpk->h_descs[g].handover = std::max<uint32_t>(1u, (item_begin[g + 1] - item_begin[g]) * (plan.threads / 64u) / 32u);
-    }
-    // Launch order: longest items first when their sizes differ (a collection of 0.6 .. 12 Mbp genomes lost 11 % to the tail of a
-    // launch in genome order: the hardware hands workgroups out in index order, and a 3.6 MB item that starts last runs alone).
-    // A bucket sort on the size's leading bits: O(items), stable inside a bucket (neighbouring items still share cache lines).
-    std::vector<uint32_t> order;
-    {
-        if (n_items > slots && unequal && !plan.bins && plan.use_lds) { // (binned / global-table launches run their items range by range, in order)
-            auto bucket = [&](uint32_t n) {                             // 8 buckets per octave, larger sizes first
-                const uint32_t e = 31u - (uint32_t)__builtin_clz(n | 1u);
-                const uint32_t m = e >= 3 ? (n >> (e - 3)) & 7u : 0u;
-                return 255u - (e * 8u + m);
-            };
-            uint32_t count[257] = {0};
-            for (const WorkItem &w : items) ++count[bucket(w.word_end - w.word_begin) + 1];
-            for (int b = 0; b < 256; ++b) count[b + 1] += count[b];
-            order.resize(n_items);
-            for (uint32_t i = 0; i < n_items; ++i) order[count[bucket(items[i].word_end - items[i].word_begin)]++] = i;
-        }
-    }
-    // HyperMinHash with deferred signatures (process_word_defer) pays off when a work item's table fills up early in the item, i.e.
-    // when items are long: the share of k-mers that can still change their bucket is 2.8 % at 5 Mbp per item, 10 % at 1 Mbp
-    // (profiles/r03/defer/ab.txt: -12 % of the kernel's time at 5 Mbp per item, -5.5 % at 1 Mbp, -3 % at 1.25 Mbp slices, +3 % at
-    // 0.73 Mbp, +17 % at 0.26 Mbp; with round 4's threshold words and per-lane stacks, profiles/r04/defer/items.txt: -13.8 % at
-    // 2 Mbp, -6.5 % at 1 Mbp, -2.6 % at 750 kbp, -0.7 % at 600 kbp, +1 % at 500 kbp, +6.5 % at 400 kbp, +19 % at 200 kbp)
-    SketchPlan plan_d = plan;
-    {
-        const char *dm_env = getenv("LASH_DEFER_MIN");                       // (read per call: the tests flip it in-process)
-        const int64_t defer_min = dm_env ? atoll(dm_env) : 600000;          // bases per work item; < 0: never
-        // (judged on the slices as first cut: the quarters at the launch's tail would pull the mean of a few-round launch under the line)
-        plan_d.defer = defer_eligible && n_coarse > 0 && defer_min >= 0 && total_words * 16 / n_coarse >= (uint64_t)defer_min;
-    }
-    TRACE("sketch: planned");
-
-    int rc;
-    const size_t n_virtual = plan.bins ? n_genomes : 0;               // binned launches: one partial per genome behind the items'
-    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + n_virtual + 1) * plan.partial_stride))) return rc;
-    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + n_virtual + 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
-    BinsRun bins_run_state;
-    if (plan.bins) {
-        // entries a genome's work items push: 16 per lane and word for every tile a wave takes part in (masked positions and the
-        // idle lanes of a busy wave included); what dirt adds on top (junction walks, a second pass by the compacting kernel) goes to
-        // the genome's fallback table if its lists run full
-        std::vector<uint64_t> entries(n_genomes, 0);
-        const uint64_t tile_words = (uint64_t)plan.threads * SKETCH_WORDS_PER_THREAD;
-        for (const WorkItem &w : items) entries[w.genome] += ((w.word_end - w.word_begin + tile_words - 1) / tile_words) * tile_words * 16;
-        if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
-        // a genome whose lists outgrow the budget after all (the estimate above is coarser than bins_prepare's sizing: ADVICE r4): the
-        // call is planned again without bins — a table in global memory per work item, as the comment above promises.  Nothing has
-        // been queued yet.
-        if (!bins_run_state.fits) return sketch_from(ctx, prm, pk, d_out_images, ev, false);
-    }
-    const WorkItem *d_items;
-    const uint32_t *d_item_begin, *d_item_order = nullptr;
-    {
-        std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0},
-                                    {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0}};
-        lash_packed *mpk = const_cast<lash_packed *>(pk);
-        if (pk->direct) {                                          // everything this call needs in ONE copy
-            sec.push_back({pk->h_descs.data(), pk->h_descs.size() * sizeof(GenomeDesc), 0});
-            sec.push_back({pk->h_tile_begin.data(), pk->h_tile_begin.size() * 4, 0});
-            sec.push_back({pk->h_nvalid.data(), pk->h_nvalid.size() * 8, 0});
-        }
-        const size_t order_sec = sec.size();
-        if (!order.empty()) sec.push_back({order.data(), order.size() * 4, 0});
-        const size_t total = layout_sections(sec);
-        DevBuf &dst = pk->direct ? mpk->tables : ctx->items;
-        if ((rc = reserve(ctx, dst, total + 256))) return rc;
-        if ((rc = upload_sections(ctx, dst.ptr, sec, total, ctx->stream))) return rc;
-        if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));            // the sketch stage: record-start bitmaps included
-        uint8_t *tb = static_cast<uint8_t *>(dst.ptr);
-        d_items = reinterpret_cast<const WorkItem *>(tb + sec[0].off);
-        d_item_begin = reinterpret_cast<const uint32_t *>(tb + sec[1].off);
-        d_item_order = order.empty() ? nullptr : reinterpret_cast<const uint32_t *>(tb + sec[order_sec].off);
-        if (pk->direct) {
-            mpk->d_descs = reinterpret_cast<GenomeDesc *>(tb + sec[2].off);
-            mpk->d_tile_begin = reinterpret_cast<uint32_t *>(tb + sec[3].off);
-            mpk->d_nvalid = reinterpret_cast<uint64_t *>(tb + sec[4].off);
-            // flags and counters of the direct pass: dirty [n+1] | nslow [n] | ndel [n] | nonuniform [n] +1 | ndel2 [n]
-            HIPCHK(ctx, hipMemsetAsync(pk->d_dirty, 0, (size_t)(5 * (size_t)n_genomes + 2) * 4, ctx->stream));
-            if (pk->any_multi) {
-                // record starts in BYTE positions: genomes whose records are all equally long (read sets) get theirs computed in
-                // the sketch kernel, the others a bitmap every word of which brk_bytes_kernel writes (no memset).  The
-                // packed-position bitmap of the fallback is cleared only for the genomes that take it (pack_dirty)
-                uint32_t *nonuni = pk->d_dirty + 3 * (size_t)n_genomes + 1;
-                HIPCHK(ctx, launch_rec_uniform(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, ctx->stream));
-                HIPCHK(ctx, launch_brk_bytes(pk->d_descs, pk->d_rec_off, n_genomes, pk->n_rec, nonuni, static_cast<uint32_t *>(pk->brk_bytes.ptr),
-                                             ctx->stream));
-            }
-        }
-    }
-    if (!ctx->counter_zeroed) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));     // [0,8) k-mer census, [16,64) zero words,
-                                                                                 // [128,256) direct mode's safe load target
-        ctx->counter_zeroed = true;
-    }
-    TRACE("sketch: items uploaded");
-
-    SketchArgs sa{};
-    sa.words = static_cast<const uint32_t *>(pk->words.ptr);
-    sa.brk = static_cast<const uint32_t *>(pk->brk.ptr);
-    sa.zero_words = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(ctx->counter.ptr) + 16);   // zeroed once, never written
-    sa.genomes = pk->d_descs;
-    sa.nvalid = pk->d_nvalid;
-    sa.items = d_items;
-    sa.item_order = d_item_order;
-    sa.partials = static_cast<uint8_t *>(ctx->partials.ptr);
-    sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
-    sa.item_kmers = static_cast<uint32_t *>(ctx->item_kmers.ptr);
-    sa.safe = static_cast<const uint8_t *>(ctx->counter.ptr) + 128;
-    sa.images = d_out_images;
-    sa.image_bytes = image_bytes;
-    {
-        const double alpha0 = hll_alpha(prm->p);
-        memcpy(&sa.alpha_bits, &alpha0, 8);
-    }
-    sa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
-    sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
-    sa.lay = layout_dev(ctx->layout, prm->algo);
-    sa.partial_stride = plan.partial_stride;
-    sa.nreg32 = plan.nreg32 >> plan.parts_log2;                 // register words of one pass
-    sa.k = prm->k;
-    sa.p = prm->p;
-    ctx->hll_flags_n = 0;
-    ctx->hll_flags_on_host = false;
-    if (prm->algo == LASH_HLL) {                                // which genomes end with a register above 53 - p (write_hll_header)
-        if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
-        sa.hll_corner = static_cast<uint32_t *>(ctx->hll_flags.ptr);
-        ctx->hll_flags_n = n_genomes;
-    }
-    if (pk->direct) {
-        sa.seq = pk->d_seq;
-        sa.brk_bytes = static_cast<const uint32_t *>(pk->brk_bytes.ptr);
-        sa.dirty = pk->d_dirty;
-        sa.rec_off = pk->d_rec_off;
-        sa.nonuniform = pk->d_dirty + 3 * (size_t)n_genomes + 1;
-        sa.nslow = pk->d_dirty + n_genomes + 1;
-        sa.ndel = sa.nslow + n_genomes;
-        sa.ndel2 = pk->d_dirty + 4 * (size_t)n_genomes + 2;
-        if (pk->stream_first)   // recent batches were full of finely fragmented dirt: every genome goes straight to the compacting kernel
-            HIPCHK(ctx, hipMemsetAsync(pk->d_dirty, 0x01, (size_t)n_genomes * 4, ctx->stream));
-        if (!plan.use_lds) {
-            if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));
-            rc = global_run(ctx, plan, sa, n_items, [&](const SketchArgs &a, uint32_t cnt) -> int {
-                if (!pk->stream_first) HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream, true));
-                HIPCHK(ctx, launch_sketch_stream(plan, a, cnt, ctx->stream));
-                return LASH_OK;
-            });
-            if (rc) return rc;
-            if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
-            if (!pk->stream_first) {
-                if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
-                ctx->last.direct_launches += n_items ? 1 : 0;
-            }
-        } else if (plan.bins) {
-            if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));
-            rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, d_item_begin, [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int {
-                if (!pk->stream_first) HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream, true));
-                HIPCHK(ctx, launch_sketch_stream(plan, a, cnt, ctx->stream));
-                return LASH_OK;
-            });
-            if (rc) return rc;
-            if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
-            if (!pk->stream_first) {
-                if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
-                ctx->last.direct_launches += n_items ? 1 : 0;
-            }
-        } else {
-            if (!pk->stream_first) {
-                // diagnostic, LASH_ITEM_TRACE=file (tools/item_trace.py): when and where every workgroup of this launch ran, appended as text
-                const char *trace_path = getenv("LASH_ITEM_TRACE");
-                unsigned long long *d_trace = nullptr;
-                if (trace_path && n_items) {
-                    HIPCHK(ctx, hipMalloc(&d_trace, (size_t)n_items * 32));
-                    HIPCHK(ctx, hipMemsetAsync(d_trace, 0, (size_t)n_items * 32, ctx->stream));
-                    sa.item_trace = d_trace;
-                }
-                if (ev) HIPCHK(ctx, hipEventRecord(ev->e[6], ctx->stream));       // direct_ms: this one launch
-                HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream, true)); // ASCII in; sparse and coarse dirt handled in place
-                if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[5], ctx->stream)); ev->direct = true; }
-                if (d_trace) {
-                    std::vector<unsigned long long> h((size_t)n_items * 4);
-                    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-                    HIPCHK(ctx, hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost));
-                    (void)hipFree(d_trace);
-                    sa.item_trace = nullptr;
-                    if (FILE *f = fopen(trace_path, "a")) {
-                        fprintf(f, "# launch: %u items, %u threads, order %s; columns: slot item genome word_begin word_end start_10ns end_10ns hw_id xcc_id\n",
-                                n_items, plan_d.threads, order.empty() ? "item" : "longest first");
-                        for (uint32_t b = 0; b < n_items; ++b) {
-                            const uint32_t i = order.empty() ? b : order[b];
-                            fprintf(f, "%u %u %u %u %u %llu %llu %u %u\n", b, i, items[i].genome, items[i].word_begin, items[i].word_end, h[4ull * i], h[4ull * i + 1],
-                                    (unsigned)(h[4ull * i + 2] & 0xFFFFFFFFu), (unsigned)(h[4ull * i + 2] >> 32));
-                        }
-                        fclose(f);
-                    }
-                }
-                if ((rc = probe_dirty(ctx, const_cast<lash_packed *>(pk), ctx->stream))) return rc;
-                ctx->last.direct_launches += n_items ? 1 : 0;
-                ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
-            }
-            HIPCHK(ctx, launch_sketch_stream(plan_d, sa, n_items, ctx->stream));    // the flagged genomes, compacted on the fly
-        }
-    } else if (plan.bins) {
-        rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, d_item_begin, [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int {
-            HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream));
-            return LASH_OK;
-        });
-        if (rc) return rc;
-    } else if (!plan.use_lds) {
-        rc = global_run(ctx, plan, sa, n_items, [&](const SketchArgs &a, uint32_t cnt) -> int { HIPCHK(ctx, launch_sketch(plan_d, a, cnt, ctx->stream)); return LASH_OK; });
-        if (rc) return rc;
-    } else {
-        HIPCHK(ctx, launch_sketch(plan_d, sa, n_items, ctx->stream));
-        ctx->last.defer_launches += (n_items && plan_d.defer) ? 1 : 0;
-    }
-    // the small genomes, whole, on resident workgroups.  Their deleted-byte counts go where lash_ctx_get_timing() will look: with the learnt
-    // stream_first every genome's flag is up (d_dirty = 0x01..) and the statistic subtracts ndel2, else ndel
-    if (n_sole && (rc = sole_launch(pk->direct ? (pk->stream_first ? sa.ndel2 : sa.ndel) : nullptr))) return rc;
-    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
-    TRACE("sketch: launched");
-
-    FinalizeArgs fa{};
-    fa.partials = static_cast<const uint8_t *>(ctx->partials.ptr);
-    fa.items = d_items;
-    fa.genome_item_begin = d_item_begin;
-    fa.nvalid = pk->d_nvalid;
-    fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
-    if (plan.bins) {                                               // one partial per genome, written by bins_apply_kernel behind the items'
-        fa.partials += (size_t)n_items * plan.partial_stride;
-        fa.item_kmers += n_items;
-        fa.items = bins_run_state.d_vitems;
-        fa.genome_item_begin = bins_run_state.d_vbegin;
-        max_slices = 1;
-    }
-    fa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
-    fa.images = d_out_images;
-    fa.partial_stride = plan.partial_stride;
-    fa.partial_base_off = 0;
-    fa.image_bytes = image_bytes;
-    const double alpha = hll_alpha(prm->p);
-    memcpy(&fa.alpha_bits, &alpha, 8);
-    fa.algo = prm->algo;
-    fa.p = prm->p;
-    fa.k = prm->k;
-    fa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
-    fa.parts_log2 = plan.parts_log2;
-    fa.lay = sa.lay;
-    fa.src_images = 0;
-    fa.hll_corner = sa.hll_corner;
-    fa.descs = n_sole ? pk->d_descs : nullptr;
-    fa.skip_max_len = n_sole ? sole_max : 0;
-    // one finalize workgroup walks all of a genome's partials: fine for a handful of slices, 20 ms for the 4 096 slices of
-    // a metagenome-sized input (BASELINE configs[4]) -> fold groups of 32 slices first (until <= 16 heads remain)
-    fa.group = 0;
-    // (from 9 slices on: finalize_kernel's walk is serial — a dependent load per slice and word — and the tail quarters give a
-    // genome up to 16: 300 x 5 Mbp, finalize stage 0.27 -> 0.15 ms)
-    // (the fold's grid spans every genome of the batch: with many thousands of genomes and ONE long one, wait for the 33rd slice as before)
-    if (max_slices > (n_genomes <= 4096u ? 8u : 32u) && n_genomes <= 65535u)
-        for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
-    if (all_sole) {
-        HIPCHK(ctx, launch_census(fa, n_genomes, ctx->stream));            // every image was written by its one work item
-    } else {
-        HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
-        HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
-    }
-    if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
-    TRACE("finalize: launched");
-    ctx->last_packed.push_back(pk);
-    ctx->last.sketch_launches += n_items ? 1 : 0;
-    ctx->last.sketch_workgroups = n_items;
-    for (uint32_t g = 0; g < n_genomes; ++g)
-        ctx->last.packed_bytes += (pk->byte_len[g] + 15) / 16 * 4 + (pk->byte_len[g] + 31) / 32 * 4;
-    return LASH_OK;
-}
-
-// The amino-acid branch (LASH_F_AMINO; utils.rs:511-563): no pack stage — a lane of aa_sketch_kernel reads a record's bytes itself.
-// Work items are ranges of a genome's records; partials and finalize as for nucleotides.
-int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
-              const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes, uint8_t *d_out_images, bool allow_bins = true)
-{
-    int rc;
-    if (allow_bins && (rc = timing_begin(ctx))) return rc;            // (the second attempt keeps the first one's event set)
-    EvSet *ev = ctx->cur_ev;
-    const bool x_low = rule_variant(ctx->layout, prm->algo, prm->flags);   // (HyperMinHash x = low half / HyperLogLog bucket = top bits)
-    SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, allow_bins);
-    if (plan.bins) {                                                  // (as in sketch_from: one genome beyond the binned launch's budget)
-        const uint64_t budget = bins_budget_bytes();
-        uint64_t big = 0;
-        for (uint32_t g = 0; g < n_genomes; ++g)
-            big = std::max<uint64_t>(big, (genome_byte_off[g + 1] - genome_byte_off[g]) + 32 * (genome_rec_off[g + 1] - genome_rec_off[g]));
-        if (big * 6 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget) plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, false);
-    }
-    const uint64_t image_bytes = ::image_bytes(ctx->layout, prm->algo, prm->p);
-    std::vector<GenomeDesc> descs(n_genomes, GenomeDesc{});
-    std::vector<WorkItem> items;
-    std::vector<uint32_t> item_begin(n_genomes + 1, 0);
-    uint32_t max_slices = 0;
-    for (uint32_t g = 0; g < n_genomes; ++g) {
-        if (genome_rec_off[g + 1] < genome_rec_off[g] || genome_rec_off[g + 1] > n_rec) return LASH_EINVAL;
-        GenomeDesc &d = descs[g];
-        d.byte_off = genome_byte_off[g];
-        d.byte_len = genome_byte_off[g + 1] - genome_byte_off[g];
-        d.rec_begin = genome_rec_off[g];
-        d.rec_end = genome_rec_off[g + 1];
-        item_begin[g] = (uint32_t)items.size();
-        const uint64_t nr = d.rec_end - d.rec_begin;
-        if (nr > 0xFFFFFFFFull) return LASH_ELIMIT;
-        uint32_t s = 0;
-        for (uint64_t r0 = 0; r0 < nr; r0 += AA_RECORDS_PER_ITEM, ++s)
-            for (uint32_t part = 0; part < (1u << plan.parts_log2); ++part)
-                items.push_back(WorkItem{g, (uint32_t)r0, (uint32_t)std::min<uint64_t>(nr, r0 + AA_RECORDS_PER_ITEM), (s & 0x7FFFu) | (part << 16)});
-        max_slices = std::max(max_slices, s);
-    }
-    item_begin[n_genomes] = (uint32_t)items.size();
-    const uint32_t n_items = (uint32_t)items.size();
-    const size_t n_virtual = plan.bins ? n_genomes : 0;
-    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + n_virtual + 1) * plan.partial_stride))) return rc;
-    if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + n_virtual + 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
-    BinsRun bins_run_state;
-    if (plan.bins) {
-        // a lane pushes 16 entries per trip of its loop — 16 residues of a record, or the fetch of the next one — and the idle lanes of a
-        // busy wave push along: residues + 32 per record, and a quarter on top
-        std::vector<uint64_t> entries(n_genomes);
-        for (uint32_t g = 0; g < n_genomes; ++g) {
-            const uint64_t e = descs[g].byte_len + 32 * (descs[g].rec_end - descs[g].rec_begin);
-            entries[g] = e + e / 4 + (uint64_t)plan.threads * 256;
-        }
-        if ((rc = bins_prepare(ctx, plan, entries, n_genomes, bins_run_state))) return rc;
-        if (!bins_run_state.fits)                                    // (as in sketch_from: planned again without bins; nothing has been queued yet)
-            return sketch_aa(ctx, prm, d_seq, d_rec_off, n_rec, genome_rec_off, genome_byte_off, n_genomes, d_out_images, false);
-    }
-    std::vector<Section> sec = {{items.data(), (size_t)n_items * sizeof(WorkItem), 0}, {item_begin.data(), (size_t)(n_genomes + 1) * 4, 0},
-                                {descs.data(), descs.size() * sizeof(GenomeDesc), 0}};
-    const size_t total = layout_sections(sec);
-    if ((rc = reserve(ctx, ctx->items, total + 256))) return rc;
-    if ((rc = upload_sections(ctx, ctx->items.ptr, sec, total, ctx->stream))) return rc;
-    uint8_t *tb = static_cast<uint8_t *>(ctx->items.ptr);
-    if (!ctx->counter_zeroed) {
-        HIPCHK(ctx, hipMemsetAsync(ctx->counter.ptr, 0, 256, ctx->stream));
-        ctx->counter_zeroed = true;
-    }
-    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[2], ctx->stream));
-    SketchArgs sa{};
-    sa.seq = d_seq;
-    sa.rec_off = d_rec_off;
-    sa.genomes = reinterpret_cast<const GenomeDesc *>(tb + sec[2].off);
-    sa.items = reinterpret_cast<const WorkItem *>(tb + sec[0].off);
-    sa.partials = static_cast<uint8_t *>(ctx->partials.ptr);
-    sa.gregs = static_cast<uint32_t *>(ctx->gregs.ptr);
-    sa.item_kmers = static_cast<uint32_t *>(ctx->item_kmers.ptr);
-    sa.images = d_out_images;
-    sa.image_bytes = image_bytes;
-    const double alpha = hll_alpha(prm->p);
-    memcpy(&sa.alpha_bits, &alpha, 8);
-    sa.accumulate = (prm->flags & LASH_F_ACCUMULATE) ? 1 : 0;
-    sa.bitflip = prm->algo == LASH_HMH ? xxh3_bitflip128(prm->seed) : xxh3_bitflip64(prm->seed);
-    sa.lay = layout_dev(ctx->layout, prm->algo);
-    sa.partial_stride = plan.partial_stride;
-    sa.nreg32 = plan.nreg32 >> plan.parts_log2;
-    sa.k = prm->k;
-    sa.p = prm->p;
-    ctx->hll_flags_n = 0;
-    ctx->hll_flags_on_host = false;
-    if (prm->algo == LASH_HLL) {
-        if ((rc = reserve(ctx, ctx->hll_flags, (size_t)n_genomes * 4))) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->hll_flags.ptr, 0, (size_t)n_genomes * 4, ctx->stream));
-        sa.hll_corner = static_cast<uint32_t *>(ctx->hll_flags.ptr);
-        ctx->hll_flags_n = n_genomes;
-    }
-    if (plan.bins) {
-        rc = bins_run(ctx, plan, prm, sa, bins_run_state, item_begin, n_items, reinterpret_cast<const uint32_t *>(tb + sec[1].off),
-                      [&](const SketchArgs &a, uint32_t, uint32_t cnt) -> int { HIPCHK(ctx, launch_sketch_aa(plan, a, cnt, ctx->stream)); return LASH_OK; });
-        if (rc) return rc;
-    } else if (!plan.use_lds) {
-        rc = global_run(ctx, plan, sa, n_items, [&](const SketchArgs &a, uint32_t cnt) -> int { HIPCHK(ctx, launch_sketch_aa(plan, a, cnt, ctx->stream)); return LASH_OK; });
-        if (rc) return rc;
-    } else {
-        HIPCHK(ctx, launch_sketch_aa(plan, sa, n_items, ctx->stream));
-    }
-    if (ev) HIPCHK(ctx, hipEventRecord(ev->e[3], ctx->stream));
-    FinalizeArgs fa{};
-    fa.partials = static_cast<const uint8_t *>(ctx->partials.ptr);
-    fa.items = sa.items;
-    fa.genome_item_begin = reinterpret_cast<const uint32_t *>(tb + sec[1].off);
-    fa.nvalid = nullptr;                                           // every item is live
-    fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
-    if (plan.bins) {
-        fa.partials += (size_t)n_items * plan.partial_stride;
-        fa.item_kmers += n_items;
-        fa.items = bins_run_state.d_vitems;
-        fa.genome_item_begin = bins_run_state.d_vbegin;
-        max_slices = 1;
-    }
-    fa.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
-    fa.images = d_out_images;
-    fa.partial_stride = plan.partial_stride;
-    fa.partial_base_off = 0;
-    fa.image_bytes = image_bytes;
-    memcpy(&fa.alpha_bits, &alpha, 8);
-    fa.algo = prm->algo;
-    fa.p = prm->p;
-    fa.k = prm->k;
-    fa.accumulate = sa.accumulate;
-    fa.parts_log2 = plan.parts_log2;
-    fa.lay = sa.lay;
-    fa.src_images = 0;
-    fa.hll_corner = sa.hll_corner;
-    fa.group = 0;
-    // (from 9 slices on: finalize_kernel's walk is serial — a dependent load per slice and word — and the tail quarters give a
-    // genome up to 16: 300 x 5 Mbp, finalize stage 0.27 -> 0.15 ms)
-    if (max_slices > 8u && n_genomes <= 65535u)
-        for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
-    HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
-    HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
-    if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
-    ctx->cur_ev = nullptr;
-    ctx->last.sketch_launches += n_items ? 1 : 0;
-    ctx->last.sketch_workgroups = n_items;
-    return LASH_OK;
-}
-
-}  // namespace
 
 // ===============================================================================================================
 
-// ---- HyperLogLog: the incremental `sum` of genomes in the > 53 - p corner, replayed -------------------------------------------
-// streaming_algorithms keeps `sum` per k-mer: sum -= 2^-old; sum += 2^-new (utils.rs:411-413 -> push_hash64).
-// Every such pair is exact in f64 — the terms are multiples of 2^(p-53) and the sum only falls — except where a term BELOW that
-// grid is involved: the k-mer that lifts a register above 53 - p (one in 2^(52-p)), or one that later overwrites such a register.
-// There the result depends on the value `sum` had at that moment, i.e. on the registers of the genome's PREFIX.  So:
-//   * the registers of the final image name the buckets above 53 - p;
-//   * a bucket's value in the sketch of a prefix is monotone in the prefix length: a binary search over cut positions — each probe
-//     one ordinary sketch call on the records cut at that byte — finds the k-mer that did it (prefixes are cut by BYTES, so
-//     deleted bytes, records and k-mer order need no special care: a k-mer belongs to a prefix iff its last base does);
-//   * the sketch of the prefix just before it carries the incremental sum up to there (no sub-grid term yet: its header IS
-//     exact) and the register's old value; the two f64 operations of that k-mer are then done here, on the host, in IEEE double;
-//   * from there to the genome's end (or the next such k-mer) every step is exact, so the net change is the difference of the
-//     on-grid parts of the two register states — one more exact addition.
-// Returns the number of genomes redone; `left` lists those it had to leave (accumulating calls hold registers the replay cannot
-// see).  Synchronous; runs ~25 small sketch calls per flagged genome (one genome in ~10^4 at p = 14).
-static double grid_sum(const uint8_t *regs, size_t m, int p)
+namespace lashi {
+
+// needletail's record rules for uncompressed input as lash uses it (utils.rs:453-459; SURVEY App. A.5), on the host: the exact
+// path for the rare file the device parse flags.  FASTA: '>' header line, sequence lines up to the next line that starts with
+// '>', line ends stripped.  FASTQ: '@' header, sequence line, '+' line, quality line of the same length; iteration STOPS at
+// the first record that breaks this (the records before it stand).  Returns the offset at which the iteration stopped
+// (n when the whole buffer parsed); seq / rec_off may be NULL (validation only).
+// `bad` (FASTQ, may be NULL): the byte ranges [first, second) that are not part of any record the iteration yields.
+size_t parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> *seq, std::vector<uint64_t> *rec_off, bool skip_bad,
+                                 std::vector<std::pair<size_t, size_t>> *bad)
 {
-    uint32_t hist[72] = {0};
-    for (size_t i = 0; i < m; ++i) ++hist[regs[i] < 71 ? regs[i] : 71];
-    double s = 0.0;                                                // multiples of 2^(p-53) below 2^p: exact in any order
-    for (int r = 0; r <= 53 - p; ++r) s += (double)hist[r] * ldexp(1.0, -r);
-    return s;
-}
-static int hll_sum_field_offset(const lash_layout &lay)
-{
-    const char *t = header_tpl(lay, LASH_HLL);
-    int at = 0;
-    for (int i = 0; i < 8 && t[i]; ++i) {
-        switch (t[i]) {
-        case 's': return at;
-        case 'a': case 'z': case 'Q': case 'l': at += 8; break;
-        case 'Z': case 'P': case 'L': at += 4; break;
-        case 'p': at += 1; break;
-        default: break;
+    auto line_end = [&](size_t p) { const void *q = memchr(d + p, '\n', n - p); return q ? (size_t)((const uint8_t *)q - d) : n; };
+    size_t i = 0;
+    if (n && d[0] == '>') {
+        while (i < n) {
+            i = line_end(i);
+            if (i < n) ++i;
+            while (i < n && d[i] != '>') {
+                size_t e = line_end(i), stop = e;
+                while (stop > i && d[stop - 1] == '\r') --stop;
+                if (seq) seq->insert(seq->end(), d + i, d + stop);
+                i = e < n ? e + 1 : n;
+            }
+            if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
         }
+        return n;
     }
-    return -1;
-}
-
-// the replay's probes are ordinary sketch calls: whatever they leave behind in the context — timing switch and sums, the list of
-// packed batches the user's call consumed, the direct pass's dirt feedback — is put back on EVERY way out
-struct ReplayRestore {
-    lash_ctx *c;
-    lash_timing last; bool timing; std::vector<const lash_packed *> packed; float dirty_frac; uint32_t direct_skipped; bool sole_only;
-    explicit ReplayRestore(lash_ctx *x) : c(x), last(x->last), timing(x->timing), packed(x->last_packed), dirty_frac(x->dirty_frac),
-                                          direct_skipped(x->direct_skipped), sole_only(x->last_sole_only) {}
-    ~ReplayRestore()
-    {
-        c->last = last; c->timing = timing; c->last_packed = packed; c->dirty_frac = dirty_frac; c->direct_skipped = direct_skipped;
-        c->last_sole_only = sole_only;
-        c->probe_pending = false;                                     // (a probe's feedback is not the user's batch's)
-    }
-};
-
-// One genome (or one streamed chunk of a file) of the replay.  `rec`: its records' absolute offsets into d_seq; `fin`: its image
-// AFTER (header + registers, on the host); `base`: NULL, or the registers the sketch held BEFORE these records (a streamed file's
-// earlier chunks: every prefix sketch is united with them before it is looked at).  (S, G, carry): the incremental sum and the on-grid
-// sum of the registers at the moment S was last brought up to date — carried from chunk to chunk of a streamed file; in: carry == false
-// means "no register has been above 53 - p so far" (S is then the exact sum, taken from the registers).  Out: S is the reference's
-// incremental value after these records, G the on-grid sum of `fin`'s registers, carry = true.
-static int hll_replay_one(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const std::vector<uint64_t> &rec, const uint8_t *fin,
-                          const uint8_t *base, double &S, double &G, bool &carry)
-{
-    const int p = prm->p;
-    const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p, ib = hdr + m;
-    int rc;
-    if ((rc = reserve(ctx, ctx->replay_img, ib + 64))) return rc;
-    if ((rc = reserve(ctx, ctx->replay_rec, (rec.size() + 1) * 8))) return rc;
-    // the registers after the genome's records cut at byte `cut` (absolute offset into d_seq), united with `base` -> out
-    auto prefix = [&](uint64_t cut, std::vector<uint8_t> &out) -> int {
-        size_t i = (size_t)(std::upper_bound(rec.begin(), rec.end(), cut) - rec.begin());   // records [0, i-1) lie wholly before the cut
-        if (i == 0) i = 1;
-        std::vector<uint64_t> pr(rec.begin(), rec.begin() + i);
-        if (pr.back() < cut) pr.push_back(cut);                                             // the record the cut falls into, truncated
-        const uint64_t n = pr.size() - 1, goff[2] = {0, n}, gbo[2] = {pr.front(), pr.back()};
-        HIPCHK(ctx, hipMemcpy(ctx->replay_rec.ptr, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
-        int r = lash_sketch_batch_device(ctx, prm, d_seq, static_cast<const uint64_t *>(ctx->replay_rec.ptr), n, goff, gbo, 1,
-                                         static_cast<uint8_t *>(ctx->replay_img.ptr));
-        if (r) return r;
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        out.resize(ib);
-        HIPCHK(ctx, hipMemcpy(out.data(), ctx->replay_img.ptr, ib, hipMemcpyDeviceToHost));
-        if (base) for (size_t j = 0; j < m; ++j) out[hdr + j] = std::max(out[hdr + j], base[j]);
-        return LASH_OK;
-    };
-    struct Event { uint64_t cut; uint32_t j; uint8_t neu, old; std::vector<uint8_t> before; };
-    std::vector<Event> events;
-    std::vector<std::pair<uint32_t, uint8_t>> todo;                 // (bucket, value above the grid) whose k-mer is to be found
-    for (size_t j = 0; j < m; ++j)
-        if (fin[hdr + j] > 53 - p && (!base || fin[hdr + j] != base[j])) todo.push_back({(uint32_t)j, fin[hdr + j]});
-    std::vector<uint8_t> probe;
-    while (!todo.empty()) {
-        const auto [j, val] = todo.back();
-        todo.pop_back();
-        uint64_t lo = rec.front(), hi = rec.back();                // prefix(lo) lacks the value, prefix(hi) has it
-        while (hi - lo > 1) {
-            const uint64_t mid = lo + (hi - lo) / 2;
-            if ((rc = prefix(mid, probe))) return rc;
-            if (probe[hdr + j] >= val) hi = mid; else lo = mid;
+    while (i < n) {
+        const size_t rec = i;
+        bool ok = false;
+        do {
+            if (d[i] != '@') break;
+            const size_t e = line_end(i);
+            if (e >= n) break;
+            const size_t s = e + 1, se = line_end(s);
+            if (se >= n) break;
+            const size_t pl = se + 1;
+            if (pl >= n || d[pl] != '+') break;
+            const size_t pe = line_end(pl);
+            if (pe >= n) break;
+            const size_t ql = pe + 1, qe = line_end(ql);
+            size_t sl = se - s, qn = qe - ql;
+            while (sl && d[s + sl - 1] == '\r') --sl;
+            while (qn && d[ql + qn - 1] == '\r') --qn;
+            if (sl != qn) break;
+            if (seq) seq->insert(seq->end(), d + s, d + s + sl);
+            if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
+            i = qe < n ? qe + 1 : n;
+            ok = true;
+        } while (false);
+        if (ok) continue;
+        if (!skip_bad) { if (bad) bad->emplace_back(rec, n); return rec; }      // the iterator is finished by the error
+        // layout.fastq_skip_bad: resume at the next plausible record start after `rec`
+        size_t c = line_end(rec), resume = n;
+        while (c < n) {
+            const size_t ls = c + 1;
+            if (ls >= n) break;
+            if (d[ls] == '@') {
+                const size_t l1 = line_end(ls), l2 = l1 < n ? line_end(l1 + 1) : n;
+                if (l2 < n && l2 + 1 < n && d[l2 + 1] == '+') { resume = ls; break; }
+            }
+            c = line_end(ls);
         }
-        Event e;
-        e.cut = hi; e.j = j; e.neu = val;
-        if ((rc = prefix(hi - 1, e.before))) return rc;
-        e.old = e.before[hdr + j];
-        // an earlier k-mer OF THESE RECORDS had already put this bucket above the grid (one of an earlier chunk is `base`'s: no event here)
-        if (e.old > 53 - p && (!base || e.old != base[j])) todo.push_back({j, e.old});
-        events.push_back(std::move(e));
+        if (bad) bad->emplace_back(rec, resume);
+        i = resume;
     }
-    if (events.empty()) {                                           // nothing of these records touches the corner
-        if (carry) { S += grid_sum(fin + hdr, m, p) - G; }
-        else memcpy(&S, fin + hll_sum_field_offset(ctx->layout), 8);
-        G = grid_sum(fin + hdr, m, p);
-        return LASH_OK;
-    }
-    std::sort(events.begin(), events.end(), [](const Event &a, const Event &b) { return a.cut < b.cut; });
-    // up to the first such k-mer every step was exact: the sum is that of the registers (on their grid), or the carried value plus
-    // the exact net change since it was taken
-    if (carry) S += grid_sum(events[0].before.data() + hdr, m, p) - G;
-    else S = grid_sum(events[0].before.data() + hdr, m, p);
-    double grid_after = 0.0;
-    for (size_t i = 0; i < events.size(); ++i) {
-        const Event &e = events[i];
-        if (i) S += grid_sum(e.before.data() + hdr, m, p) - grid_after;      // exact steps in between: their net change
-        // the k-mer's own update, rounded as the crate's is: ONE operation, sum -= 2^-old - 2^-new (the difference is exact unless
-        // new - old > 53; ADVICE r4: the two-step form differs when the bucket's old value lies above 53 - p as well)
-        S -= ldexp(1.0, -(int)e.old) - ldexp(1.0, -(int)e.neu);
-        std::vector<uint8_t> after(e.before.begin() + hdr, e.before.end());
-        after[e.j] = e.neu;
-        grid_after = grid_sum(after.data(), m, p);
-    }
-    G = grid_sum(fin + hdr, m, p);
-    S += G - grid_after;
-    carry = true;
-    return LASH_OK;
+    return n;
 }
 
-static int hll_replay_sums(lash_ctx *ctx, const lash_params *prm0, const uint8_t *d_seq, const uint64_t *d_rec_off, const uint64_t *h_rec_off,
-                           const uint64_t *genome_rec_off, uint8_t *d_images, uint8_t *h_images, const std::vector<uint32_t> &flagged,
-                           std::vector<uint32_t> &left)
-{
-    left.clear();
-    if (flagged.empty()) return LASH_OK;
-    const int p = prm0->p, sum_at = hll_sum_field_offset(ctx->layout);
-    const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p, ib = hdr + m;
-    if (sum_at < 0 || (prm0->flags & (LASH_F_ACCUMULATE | LASH_F_AMINO))) { left = flagged; return LASH_OK; }
-    lash_params prm = *prm0;
-    ReplayRestore restore(ctx);
-    ctx->timing = false;
-    int rc = LASH_OK;
-    std::vector<uint8_t> fin(ib);
-    for (uint32_t g : flagged) {
-        const uint64_t r0 = genome_rec_off[g], r1 = genome_rec_off[g + 1], nr = r1 - r0;
-        std::vector<uint64_t> rec(nr + 1);
-        if (h_rec_off) memcpy(rec.data(), h_rec_off + r0, (nr + 1) * 8);
-        else HIPCHK(ctx, hipMemcpy(rec.data(), d_rec_off + r0, (nr + 1) * 8, hipMemcpyDeviceToHost));
-        if (h_images) memcpy(fin.data(), h_images + (size_t)g * ib, ib);
-        else HIPCHK(ctx, hipMemcpy(fin.data(), d_images + (size_t)g * ib, ib, hipMemcpyDeviceToHost));
-        double S = 0.0, G = 0.0;
-        bool carry = false;
-        if ((rc = hll_replay_one(ctx, &prm, d_seq, rec, fin.data(), nullptr, S, G, carry))) break;
-        if (h_images) memcpy(h_images + (size_t)g * ib + sum_at, &S, 8);
-        if (d_images) HIPCHK(ctx, hipMemcpy(d_images + (size_t)g * ib + sum_at, &S, 8, hipMemcpyHostToDevice));
-    }
-    if (rc) return rc;
-    ctx->hll_flags_n = 0;
-    ctx->hll_flags_on_host = true;
-    ctx->hll_left = left;
-    return LASH_OK;
-}
+}  // namespace lashi
 
 extern "C" {
 
@@ -1750,13 +579,6 @@ int lash_sketch_batch_async(lash_ctx *ctx, const lash_params *prm, const uint8_t
     return LASH_OK;
 }
 
-static std::vector<uint32_t> hll_flagged(lash_ctx *ctx)
-{
-    std::vector<uint32_t> idx(lash_ctx_hll_inexact_sums(ctx, nullptr, 0));
-    if (!idx.empty()) lash_ctx_hll_inexact_sums(ctx, idx.data(), (uint32_t)idx.size());
-    return idx;
-}
-
 int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq, const uint64_t *rec_off, uint64_t n_rec,
                       const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *out_images)
 {
@@ -1774,21 +596,6 @@ int lash_sketch_batch(lash_ctx *ctx, const lash_params *prm, const uint8_t *seq,
         }
     }
     return rc;
-}
-
-int lash_hll_replay_sums_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
-                                const uint64_t *genome_rec_off, uint32_t n_genomes, uint8_t *d_images)
-{
-    (void)n_rec;
-    if (!ctx || !prm || !genome_rec_off || (n_genomes && !d_images)) return LASH_EINVAL;
-    if (prm->algo != LASH_HLL) return LASH_OK;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->hll_flags_on_host) return LASH_OK;                     // already done for this call
-    if (ctx->hll_flags_n != n_genomes) return LASH_EINVAL;          // not the arguments of the last HyperLogLog call
-    const std::vector<uint32_t> flagged = hll_flagged(ctx);          // (synchronizes the stream)
-    std::vector<uint32_t> left;
-    if (flagged.empty()) { ctx->hll_flags_on_host = true; ctx->hll_left.clear(); return LASH_OK; }
-    return hll_replay_sums(ctx, prm, d_seq, d_rec_off, nullptr, genome_rec_off, d_images, nullptr, flagged, left);
 }
 
 int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_raw, const uint64_t *file_off,
@@ -1820,98 +627,11 @@ int lash_sketch_files_raw_device(lash_ctx *ctx, const lash_params *prm, const ui
     return rc;
 }
 
-uint32_t lash_ctx_hll_inexact_sums(lash_ctx *ctx, uint32_t *genome_index, uint32_t cap)
-{
-    if (ctx && ctx->hll_flags_on_host) {                          // a replay has run: what it could not redo
-        for (uint32_t i = 0; i < ctx->hll_left.size() && i < cap && genome_index; ++i) genome_index[i] = ctx->hll_left[i];
-        return (uint32_t)ctx->hll_left.size();
-    }
-    if (!ctx || !ctx->hll_flags_n || !ctx->hll_flags.ptr) return 0;
-    (void)hipSetDevice(ctx->device);
-    std::vector<uint32_t> fl(ctx->hll_flags_n);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
-        hipMemcpy(fl.data(), ctx->hll_flags.ptr, fl.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
-        ctx->err = "lash_ctx_hll_inexact_sums: reading the flags failed";
-        return 0;
-    }
-    uint32_t n = 0;
-    for (uint32_t g = 0; g < fl.size(); ++g)
-        if (fl[g]) { if (genome_index && n < cap) genome_index[n] = g; ++n; }
-    return n;
-}
-
 uint32_t lash_ctx_format_errors(lash_ctx *ctx, uint32_t *file_index, uint32_t cap)
 {
     if (!ctx) return 0;
     const uint32_t n = (uint32_t)ctx->bad_files.size();
     for (uint32_t i = 0; i < n && i < cap && file_index; ++i) file_index[i] = ctx->bad_files[i];
-    return n;
-}
-
-// needletail's record rules for uncompressed input as lash uses it (utils.rs:453-459; SURVEY App. A.5), on the host: the exact
-// path for the rare file the device parse flags.  FASTA: '>' header line, sequence lines up to the next line that starts with
-// '>', line ends stripped.  FASTQ: '@' header, sequence line, '+' line, quality line of the same length; iteration STOPS at
-// the first record that breaks this (the records before it stand).  Returns the offset at which the iteration stopped
-// (n when the whole buffer parsed); seq / rec_off may be NULL (validation only).
-// `bad` (FASTQ, may be NULL): the byte ranges [first, second) that are not part of any record the iteration yields.
-static size_t parse_fastx_strict(const uint8_t *d, size_t n, std::vector<uint8_t> *seq, std::vector<uint64_t> *rec_off, bool skip_bad = false,
-                                 std::vector<std::pair<size_t, size_t>> *bad = nullptr)
-{
-    auto line_end = [&](size_t p) { const void *q = memchr(d + p, '\n', n - p); return q ? (size_t)((const uint8_t *)q - d) : n; };
-    size_t i = 0;
-    if (n && d[0] == '>') {
-        while (i < n) {
-            i = line_end(i);
-            if (i < n) ++i;
-            while (i < n && d[i] != '>') {
-                size_t e = line_end(i), stop = e;
-                while (stop > i && d[stop - 1] == '\r') --stop;
-                if (seq) seq->insert(seq->end(), d + i, d + stop);
-                i = e < n ? e + 1 : n;
-            }
-            if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
-        }
-        return n;
-    }
-    while (i < n) {
-        const size_t rec = i;
-        bool ok = false;
-        do {
-            if (d[i] != '@') break;
-            const size_t e = line_end(i);
-            if (e >= n) break;
-            const size_t s = e + 1, se = line_end(s);
-            if (se >= n) break;
-            const size_t pl = se + 1;
-            if (pl >= n || d[pl] != '+') break;
-            const size_t pe = line_end(pl);
-            if (pe >= n) break;
-            const size_t ql = pe + 1, qe = line_end(ql);
-            size_t sl = se - s, qn = qe - ql;
-            while (sl && d[s + sl - 1] == '\r') --sl;
-            while (qn && d[ql + qn - 1] == '\r') --qn;
-            if (sl != qn) break;
-            if (seq) seq->insert(seq->end(), d + s, d + s + sl);
-            if (rec_off) rec_off->push_back(seq ? seq->size() : 0);
-            i = qe < n ? qe + 1 : n;
-            ok = true;
-        } while (false);
-        if (ok) continue;
-        if (!skip_bad) { if (bad) bad->emplace_back(rec, n); return rec; }      // the iterator is finished by the error
-        // layout.fastq_skip_bad: resume at the next plausible record start after `rec`
-        size_t c = line_end(rec), resume = n;
-        while (c < n) {
-            const size_t ls = c + 1;
-            if (ls >= n) break;
-            if (d[ls] == '@') {
-                const size_t l1 = line_end(ls), l2 = l1 < n ? line_end(l1 + 1) : n;
-                if (l2 < n && l2 + 1 < n && d[l2 + 1] == '+') { resume = ls; break; }
-            }
-            c = line_end(ls);
-        }
-        if (bad) bad->emplace_back(rec, resume);
-        i = resume;
-    }
     return n;
 }
 
@@ -2037,337 +757,6 @@ int lash_sketch_files_raw(lash_ctx *ctx, const lash_params *prm, const uint8_t *
         for (uint32_t g : corner)
             if (std::find(bad.begin(), bad.end(), g) == bad.end()) ctx->hll_left.push_back(g);
     return LASH_OK;
-}
-
-int lash_hll_replay_streamed_chunk(lash_ctx *ctx, const lash_params *prm, const uint8_t *raw, uint64_t n_bytes, int fmt, const uint8_t *image_before,
-                                   uint8_t *image_after, double *carry, int *have_carry)
-{
-    if (!ctx || !prm || !image_before || !image_after || !carry || !have_carry || (n_bytes && !raw)) return LASH_EINVAL;
-    int rc = lash_params_check(prm);
-    if (rc) return rc;
-    if (prm->algo != LASH_HLL || (prm->flags & LASH_F_AMINO) || (fmt != LASH_FMT_FASTA && fmt != LASH_FMT_FASTQ)) return LASH_EINVAL;
-    (void)hipSetDevice(ctx->device);
-    const int p = prm->p, sum_at = hll_sum_field_offset(ctx->layout);
-    if (sum_at < 0) return LASH_OK;                                  // (a layout without the field: nothing to keep)
-    const size_t hdr = header_bytes(ctx->layout, LASH_HLL), m = (size_t)1 << p;
-    bool event = false;                                              // did THIS chunk lift a register above 53 - p (or one that was there, further)?
-    for (size_t j = 0; j < m && !event; ++j) event = image_after[hdr + j] > 53 - p && image_after[hdr + j] != image_before[hdr + j];
-    double S = carry[0], G = carry[1];
-    bool have = *have_carry != 0;
-    if (!event) {
-        if (!have) return LASH_OK;                                   // still on the grid: the header's sum is exact
-        const double g = grid_sum(image_after + hdr, m, p);          // every step of this chunk was exact: its net change
-        S += g - G;
-        G = g;
-    } else {
-        // the chunk's records as needletail yields them (the library's own host parse), resident for the prefix sketches
-        std::vector<uint8_t> seq;
-        std::vector<uint64_t> rec(1, 0);
-        if (fmt == LASH_FMT_FASTA && n_bytes && raw[0] != '>') {
-            // a later chunk of a record that outgrew its chunk begins with sequence lines (the carried bases first): the device parse
-            // takes them as a record's lines; the host parse wants the header line it would have had
-            std::vector<uint8_t> with_hdr;
-            with_hdr.reserve((size_t)n_bytes + 3);
-            with_hdr.push_back('>'); with_hdr.push_back('c'); with_hdr.push_back('\n');
-            with_hdr.insert(with_hdr.end(), raw, raw + n_bytes);
-            parse_fastx_strict(with_hdr.data(), with_hdr.size(), &seq, &rec, ctx->layout.fastq_skip_bad != 0);
-        } else {
-            parse_fastx_strict(raw, (size_t)n_bytes, &seq, &rec, ctx->layout.fastq_skip_bad != 0);
-        }
-        if (rec.back() == rec.front()) { ctx->err = "hll replay: the chunk holds an event but no base"; return LASH_EINVAL; }
-        if ((rc = reserve(ctx, ctx->st_seq, seq.size() + 64))) return rc;
-        if (!seq.empty()) HIPCHK(ctx, hipMemcpy(ctx->st_seq.ptr, seq.data(), seq.size(), hipMemcpyHostToDevice));
-        ReplayRestore restore(ctx);
-        ctx->timing = false;
-        lash_params pr = *prm;
-        pr.flags &= ~(uint32_t)LASH_F_ACCUMULATE;                    // (a prefix is sketched by itself; the registers before it are `image_before`'s)
-        if ((rc = hll_replay_one(ctx, &pr, static_cast<const uint8_t *>(ctx->st_seq.ptr), rec, image_after, image_before + hdr, S, G, have))) return rc;
-    }
-    memcpy(image_after + sum_at, &S, 8);
-    carry[0] = S; carry[1] = G;
-    *have_carry = have ? 1 : 0;
-    ctx->hll_flags_n = 0;                                            // (the caller's image carries the incremental value now)
-    ctx->hll_flags_on_host = true;
-    ctx->hll_left.clear();
-    return LASH_OK;
-}
-
-int lash_merge_images_device(lash_ctx *ctx, int algo, int p, uint8_t *d_dst, const uint8_t *d_src, uint64_t n_images)
-{
-    if (!ctx || (n_images && (!d_dst || !d_src)) || n_images > 0x7FFFFFFFull) return LASH_EINVAL;
-    lash_params prm{algo, 16, p, 0, 0};
-    int rc = lash_params_check(&prm);
-    if (rc) return rc;
-    if (n_images == 0) return LASH_OK;
-    (void)hipSetDevice(ctx->device);
-    // one pseudo work item per image: "partials" are the source images themselves (registers after the header)
-    std::vector<WorkItem> items((size_t)n_images);
-    std::vector<uint32_t> begin((size_t)n_images + 1);
-    for (uint64_t i = 0; i < n_images; ++i) { items[i] = WorkItem{(uint32_t)i, 0, 0, 0}; begin[i] = (uint32_t)i; }
-    begin[n_images] = (uint32_t)n_images;
-    if ((rc = reserve(ctx, ctx->items, (size_t)(n_images + 1) * sizeof(WorkItem)))) return rc;
-    if ((rc = reserve(ctx, ctx->item_begin, (size_t)(n_images + 1) * 4))) return rc;
-    if ((rc = upload(ctx, ctx->items.ptr, items.data(), items.size() * sizeof(WorkItem)))) return rc;
-    if ((rc = upload(ctx, ctx->item_begin.ptr, begin.data(), begin.size() * 4))) return rc;
-    FinalizeArgs fa{};
-    fa.partials = d_src;
-    fa.items = static_cast<const WorkItem *>(ctx->items.ptr);
-    fa.genome_item_begin = static_cast<const uint32_t *>(ctx->item_begin.ptr);
-    fa.nvalid = nullptr;
-    fa.images = d_dst;
-    fa.image_bytes = image_bytes(ctx->layout, algo, p);
-    fa.partial_stride = fa.image_bytes;
-    fa.partial_base_off = header_bytes(ctx->layout, algo);
-    fa.lay = layout_dev(ctx->layout, algo);
-    fa.src_images = 1;
-    const double alpha = hll_alpha(p);
-    memcpy(&fa.alpha_bits, &alpha, 8);
-    fa.algo = algo;
-    fa.p = p;
-    fa.k = 16;
-    fa.accumulate = 1;
-    HIPCHK(ctx, launch_finalize(fa, (uint32_t)n_images, ctx->stream));
-    return LASH_OK;
-}
-
-int lash_merge_images(lash_ctx *ctx, int algo, int p, uint8_t *dst, const uint8_t *src, uint64_t n_images)
-{
-    if (!ctx || (n_images && (!dst || !src))) return LASH_EINVAL;
-    const size_t ib = image_bytes(ctx->layout, algo, p);
-    if (!ib) return LASH_EINVAL;
-    (void)hipSetDevice(ctx->device);
-    const size_t bytes = ib * (size_t)n_images;
-    int rc;
-    if ((rc = reserve(ctx, ctx->st_img, bytes + 64))) return rc;
-    if ((rc = reserve(ctx, ctx->st_seq, bytes + 64))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->st_img.ptr, dst, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->st_seq.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    rc = lash_merge_images_device(ctx, algo, p, static_cast<uint8_t *>(ctx->st_img.ptr),
-                                  static_cast<const uint8_t *>(ctx->st_seq.ptr), n_images);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(dst, ctx->st_img.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return LASH_OK;
-}
-
-int lash_hmh_pair_counts_device(lash_ctx *ctx, const uint8_t *d_ref_images, uint32_t n_ref, const uint8_t *d_qry_images,
-                                uint32_t n_qry, uint32_t *d_out_c, uint32_t *d_out_n)
-{
-    if (!ctx || ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_c || !d_out_n))) return LASH_EINVAL;
-    (void)hipSetDevice(ctx->device);
-    if (n_ref == 0 || n_qry == 0) return LASH_OK;
-    const uint32_t hdr = (uint32_t)header_bytes(ctx->layout, LASH_HMH);
-    const uint64_t stride = image_bytes(ctx->layout, LASH_HMH, 0);
-    static const bool words_kernel = getenv("LASH_HMH_PAIRS_WORDS") != nullptr;      // A/B knob: the u16-pair kernel on the images
-    if (words_kernel) {
-        HIPCHK(ctx, launch_hmh_pairs(d_ref_images, n_ref, d_qry_images, n_qry, hdr, stride, d_out_c, d_out_n, ctx->stream));
-        return LASH_OK;
-    }
-    // register bit planes of the call's images (pair_planes.hip; one read-back of the non-zero counts: synchronizes once)
-    const bool same = d_ref_images == d_qry_images && n_ref == n_qry;
-    lash_sketch_set *sets[2] = {&ctx->pl_ref, same ? &ctx->pl_ref : &ctx->pl_qry};
-    for (int i = 0; i < (same ? 1 : 2); ++i) {
-        lash_sketch_set *s = sets[i];
-        s->device = ctx->device; s->algo = LASH_HMH; s->p = 0; s->hdr = hdr; s->stride = stride;
-        s->n = i ? n_qry : n_ref;
-        s->d_images = i ? d_qry_images : d_ref_images;
-        s->have_S = s->have_T = false;                               // (the buffers are kept, their contents are this call's)
-    }
-    int rc;
-    if ((rc = lash_set_build_planes(ctx, sets[0], true))) return rc;                 // (row and column layout in one pass when the sets coincide)
-    if ((rc = lash_set_build_planes(ctx, sets[1], false))) return rc;
-    HIPCHK(ctx, launch_hmh_pairs_planes(static_cast<const uint32_t *>(sets[0]->T.ptr), sets[0]->ldT, 0, n_ref, static_cast<const uint32_t *>(sets[1]->S.ptr),
-                                        sets[1]->n_pad, n_qry, sets[0]->full && sets[1]->full, false, d_out_c, d_out_n, n_qry, ctx->stream));
-    return LASH_OK;
-}
-
-int lash_hmh_pair_counts(lash_ctx *ctx, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
-                         uint32_t n_qry, uint32_t *out_c, uint32_t *out_n)
-{
-    if (!ctx || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_c || !out_n))) return LASH_EINVAL;
-    if (n_ref == 0 || n_qry == 0) return LASH_OK;
-    (void)hipSetDevice(ctx->device);
-    const size_t ib = image_bytes(ctx->layout, LASH_HMH, 0), rb = ib * n_ref, qb = ib * n_qry, pb = (size_t)n_ref * n_qry * 4;
-    int rc;
-    if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
-    if ((rc = reserve(ctx, ctx->st_img, 2 * pb + 64))) return rc;
-    uint8_t *d_r = static_cast<uint8_t *>(ctx->st_seq.ptr), *d_q = d_r + rb;
-    uint32_t *d_c = static_cast<uint32_t *>(ctx->st_img.ptr), *d_n = d_c + (size_t)n_ref * n_qry;
-    HIPCHK(ctx, hipMemcpyAsync(d_r, ref_images, rb, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_q, qry_images, qb, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = lash_hmh_pair_counts_device(ctx, d_r, n_ref, d_q, n_qry, d_c, d_n))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(out_c, d_c, pb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(out_n, d_n, pb, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return LASH_OK;
-}
-
-int lash_hmh_pair_expected_collisions(lash_ctx *ctx, const double *ref_card, uint32_t n_ref, const double *qry_card, uint32_t n_qry,
-                                      double *out_ec)
-{
-    if (!ctx || ((n_ref && n_qry) && (!ref_card || !qry_card || !out_ec))) return LASH_EINVAL;
-    if (n_ref == 0 || n_qry == 0) return LASH_OK;
-    (void)hipSetDevice(ctx->device);
-    // O(1) regimes on the host; what is left needs the cell sum: pairs whose LARGER sketch is at or below 2^(p+5), i.e. both are
-    std::vector<uint32_t> rs, qs;
-    std::vector<uint8_t> rsmall(n_ref), qsmall(n_qry);
-    double dummy;
-    for (uint32_t i = 0; i < n_ref; ++i) rsmall[i] = !hmh_ec_closed_form(ref_card[i], ref_card[i], &dummy);
-    for (uint32_t j = 0; j < n_qry; ++j) qsmall[j] = !hmh_ec_closed_form(qry_card[j], qry_card[j], &dummy);
-    for (uint32_t j = 0; j < n_qry; ++j) if (qsmall[j]) qs.push_back(j);
-    if (!qs.empty()) for (uint32_t i = 0; i < n_ref; ++i) if (rsmall[i]) rs.push_back(i);
-    for (uint32_t i = 0; i < n_ref; ++i) {
-        double *row = out_ec + (size_t)i * n_qry;
-        for (uint32_t j = 0; j < n_qry; ++j)
-            if (!(rsmall[i] && qsmall[j])) (void)hmh_ec_closed_form(qry_card[j], ref_card[i], &row[j]);
-    }
-    if (rs.empty()) return LASH_OK;
-    constexpr size_t VEC = 65536 * sizeof(double);
-    constexpr size_t Q_CHUNK = (24ull << 30) / VEC, R_CHUNK = (4ull << 30) / VEC;      // <= 24 + 4 GiB of vectors at a time
-    int rc;
-    std::vector<double> cards, x;
-    for (size_t q0 = 0; q0 < qs.size(); q0 += Q_CHUNK) {
-        const uint32_t nq = (uint32_t)std::min(Q_CHUNK, qs.size() - q0);
-        cards.resize(nq);
-        for (uint32_t j = 0; j < nq; ++j) cards[j] = qry_card[qs[q0 + j]];
-        if ((rc = reserve(ctx, ctx->ec_card, (size_t)(nq + R_CHUNK) * 8))) return rc;
-        double *d_card = static_cast<double *>(ctx->ec_card.ptr);
-        const bool cached = qs.size() <= Q_CHUNK && ctx->ec_qry.ptr && cards == ctx->ec_qry_cards;
-        if (!cached) {
-            ctx->ec_qry_cards.clear();
-            if ((rc = reserve(ctx, ctx->ec_qry, (size_t)nq * VEC))) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(d_card, cards.data(), (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, launch_collision_vectors(d_card, nq, static_cast<double *>(ctx->ec_qry.ptr), ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));    // (`cards` is reused below)
-            if (qs.size() <= Q_CHUNK) ctx->ec_qry_cards = cards;
-        }
-        for (size_t r0 = 0; r0 < rs.size(); r0 += R_CHUNK) {
-            const uint32_t nr = (uint32_t)std::min(R_CHUNK, rs.size() - r0);
-            std::vector<double> rcards(nr);
-            for (uint32_t i = 0; i < nr; ++i) rcards[i] = ref_card[rs[r0 + i]];
-            if ((rc = reserve(ctx, ctx->ec_ref, (size_t)nr * VEC))) return rc;
-            if ((rc = reserve(ctx, ctx->ec_x, (size_t)nr * nq * 8))) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(d_card + nq, rcards.data(), (size_t)nr * 8, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, launch_collision_vectors(d_card + nq, nr, static_cast<double *>(ctx->ec_ref.ptr), ctx->stream));
-            HIPCHK(ctx, launch_collision_gemm(static_cast<const double *>(ctx->ec_ref.ptr), nr, static_cast<const double *>(ctx->ec_qry.ptr), nq,
-                                              static_cast<double *>(ctx->ec_x.ptr), ctx->stream));
-            x.resize((size_t)nr * nq);
-            HIPCHK(ctx, hipMemcpyAsync(x.data(), ctx->ec_x.ptr, x.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            for (uint32_t i = 0; i < nr; ++i) {
-                const uint32_t ri = rs[r0 + i];
-                for (uint32_t j = 0; j < nq; ++j) {
-                    const uint32_t qj = qs[q0 + j];
-                    out_ec[(size_t)ri * n_qry + qj] = hmh_ec_from_cell_sum(x[(size_t)i * nq + j]);
-                }
-            }
-        }
-    }
-    return LASH_OK;
-}
-
-int lash_hll_pair_union_stats_device(lash_ctx *ctx, int p, const uint8_t *d_ref_images, uint32_t n_ref,
-                                     const uint8_t *d_qry_images, uint32_t n_qry, uint32_t *d_out_zero, double *d_out_sum)
-{
-    if (!ctx || p < 4 || p > 16 || ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_zero || !d_out_sum)))
-        return LASH_EINVAL;
-    (void)hipSetDevice(ctx->device);
-    const uint32_t hdr = (uint32_t)header_bytes(ctx->layout, LASH_HLL);
-    static const bool byte_kernel_only = getenv("LASH_HLL_PAIRS_BYTEWISE") != nullptr;
-    if (p >= 10 && n_ref && n_qry && !byte_kernel_only) {
-        // threshold-bitmap form (dist_kernels.hip): needs the range of register values first — one 8-byte read-back
-        int rc;
-        if ((rc = reserve(ctx, ctx->hll_lohi, 8))) return rc;
-        uint32_t *d_lohi = static_cast<uint32_t *>(ctx->hll_lohi.ptr);
-        HIPCHK(ctx, hipMemsetAsync(d_lohi, 0xFF, 4, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_lohi + 1, 0, 4, ctx->stream));
-        HIPCHK(ctx, launch_hll_minmax(d_ref_images, n_ref, p, hdr, d_lohi, ctx->stream));
-        const bool same = d_ref_images == d_qry_images && n_ref == n_qry;
-        if (!same) HIPCHK(ctx, launch_hll_minmax(d_qry_images, n_qry, p, hdr, d_lohi, ctx->stream));
-        uint32_t lohi[2] = {0, 0};
-        HIPCHK(ctx, hipMemcpyAsync(lohi, d_lohi, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        const uint32_t lo = lohi[0], hi = lohi[1];
-        if (hi > lo && hi <= 64u) {                              // (all registers equal, or values no sketch can hold: the byte-wise kernel)
-            const uint32_t band = hi - lo;
-            const size_t per = (size_t)band * ((size_t)1 << p) / 8;
-            if ((rc = reserve(ctx, ctx->hll_bm_qry, (size_t)n_qry * per))) return rc;
-            uint32_t *bq = static_cast<uint32_t *>(ctx->hll_bm_qry.ptr), *br = bq;
-            HIPCHK(ctx, launch_hll_bitmaps(d_qry_images, n_qry, p, hdr, lo, band, bq, ctx->stream));
-            if (!same) {
-                if ((rc = reserve(ctx, ctx->hll_bm_ref, (size_t)n_ref * per))) return rc;
-                br = static_cast<uint32_t *>(ctx->hll_bm_ref.ptr);
-                HIPCHK(ctx, launch_hll_bitmaps(d_ref_images, n_ref, p, hdr, lo, band, br, ctx->stream));
-            }
-            HIPCHK(ctx, launch_hll_pairs_bitmap(br, n_ref, bq, n_qry, p, lo, band, d_out_zero, d_out_sum, ctx->stream));
-            return LASH_OK;
-        }
-    }
-    HIPCHK(ctx, launch_hll_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, hdr, d_out_zero, d_out_sum, ctx->stream));
-    return LASH_OK;
-}
-
-int lash_hll_pair_union_stats(lash_ctx *ctx, int p, const uint8_t *ref_images, uint32_t n_ref, const uint8_t *qry_images,
-                              uint32_t n_qry, uint32_t *out_zero, double *out_sum)
-{
-    if (!ctx || p < 4 || p > 16 || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_zero || !out_sum))) return LASH_EINVAL;
-    if (n_ref == 0 || n_qry == 0) return LASH_OK;
-    (void)hipSetDevice(ctx->device);
-    const size_t ib = image_bytes(ctx->layout, LASH_HLL, p), rb = ib * n_ref, qb = ib * n_qry, np = (size_t)n_ref * n_qry;
-    int rc;
-    if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
-    if ((rc = reserve(ctx, ctx->st_img, np * 12 + 64))) return rc;
-    uint8_t *d_r = static_cast<uint8_t *>(ctx->st_seq.ptr), *d_q = d_r + rb;
-    double *d_s = static_cast<double *>(ctx->st_img.ptr);
-    uint32_t *d_z = reinterpret_cast<uint32_t *>(d_s + np);
-    HIPCHK(ctx, hipMemcpyAsync(d_r, ref_images, rb, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_q, qry_images, qb, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = lash_hll_pair_union_stats_device(ctx, p, d_r, n_ref, d_q, n_qry, d_z, d_s))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(out_zero, d_z, np * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(out_sum, d_s, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return LASH_OK;
-}
-
-int lash_ull_pair_union_estimates_device(lash_ctx *ctx, int p, int estimator, const uint8_t *d_ref_images, uint32_t n_ref,
-                                         const uint8_t *d_qry_images, uint32_t n_qry, double *d_out_est)
-{
-    if (!ctx || p < 3 || p > 26 || (estimator != LASH_ULL_FGRA && estimator != LASH_ULL_ML) ||
-        ((n_ref && n_qry) && (!d_ref_images || !d_qry_images || !d_out_est)))
-        return LASH_EINVAL;
-    (void)hipSetDevice(ctx->device);
-    HIPCHK(ctx, launch_ull_pairs(d_ref_images, n_ref, d_qry_images, n_qry, p, (uint32_t)header_bytes(ctx->layout, LASH_ULL), estimator,
-                                 d_out_est, ctx->stream));
-    return LASH_OK;
-}
-
-int lash_ull_pair_union_estimates(lash_ctx *ctx, int p, int estimator, const uint8_t *ref_images, uint32_t n_ref,
-                                  const uint8_t *qry_images, uint32_t n_qry, double *out_est)
-{
-    if (!ctx || p < 3 || p > 26 || ((n_ref && n_qry) && (!ref_images || !qry_images || !out_est))) return LASH_EINVAL;
-    if (n_ref == 0 || n_qry == 0) return LASH_OK;
-    (void)hipSetDevice(ctx->device);
-    const size_t ib = image_bytes(ctx->layout, LASH_ULL, p), rb = ib * n_ref, qb = ib * n_qry, np = (size_t)n_ref * n_qry;
-    int rc;
-    if ((rc = reserve(ctx, ctx->st_seq, rb + qb + 64))) return rc;
-    if ((rc = reserve(ctx, ctx->st_img, np * 8 + 64))) return rc;
-    uint8_t *d_r = static_cast<uint8_t *>(ctx->st_seq.ptr), *d_q = d_r + rb;
-    double *d_e = static_cast<double *>(ctx->st_img.ptr);
-    HIPCHK(ctx, hipMemcpyAsync(d_r, ref_images, rb, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_q, qry_images, qb, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = lash_ull_pair_union_estimates_device(ctx, p, estimator, d_r, n_ref, d_q, n_qry, d_e))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(out_est, d_e, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return LASH_OK;
-}
-
-double lash_ull_estimate(const uint8_t *registers, int p, int estimator)
-{
-    if (!registers || p < 3 || p > 26) return -1.0;
-    uint32_t hist[256] = {0};
-    for (size_t i = 0, m = (size_t)1 << p; i < m; ++i) hist[registers[i]]++;
-    auto h = [&](uint32_t r) { return hist[r]; };
-    return estimator == LASH_ULL_ML ? lash::ull::ml(h, p) : lash::ull::fgra(h, p);
 }
 
 int lash_synth_genomes_device(lash_ctx *ctx, uint64_t first_genome, uint32_t n_genomes, uint64_t n_bases, uint8_t *d_out)

@@ -11,7 +11,7 @@ python3 -m lash_amd.build > /dev/null
 mkdir -p build/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -DLASH_DEBUG_STALE -Iinclude -c -o build/variants/stale.sole_kernels.o lash_amd/csrc/sole_kernels.hip
 OBJS=""
-for s in lash_api sketch_set sketch_kernels pack_kernels fastq_check dist_kernels pair_planes dist_estimators; do OBJS="$OBJS build/obj/$s.hip.o"; done
+for s in lash_api lash_plan lash_hll_replay lash_dist_api sketch_set sketch_kernels pack_kernels fastq_check dist_kernels pair_planes dist_estimators; do OBJS="$OBJS build/obj/$s.hip.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/liblash_stale.so $OBJS build/variants/stale.sole_kernels.o
 rm -f build/variants/stale.sole_kernels.o
 ls -la build/variants/liblash_stale.so
