@@ -48,7 +48,8 @@ struct SketchArgs {
     int               p;
     uint32_t          item_base;  // launches over a range of the items: workgroup b takes item item_base + b (item_order == NULL)
     unsigned long long *item_trace;  // diagnostic (LASH_ITEM_TRACE=file, tools/item_trace.py): NULL, or [n_items][4] — the workgroup's first and
-                                     // last instruction on the 100 MHz wall clock, its XCC / CU / SIMD ids, 0.  Two scalar branches per workgroup
+                                     // last instruction on the 100 MHz wall clock, its XCC / CU / SIMD ids, 0.  Read by the kernels only in a library
+                                     // built with -DLASH_ITEM_TRACE_BUILD (tools/build_trace_lib.sh); the shipped kernels ignore it
     // binned launches (SketchPlan::bins; sketch_kernels.hip "BinRegs"): the sketch kernels append entries, bins_apply_kernel builds registers
     uint32_t         *bin_lists;  // every (genome of the group, bin) list, BinGenome::list_off apart
     uint32_t         *bin_cnt;    // [genomes of the group][bins] fill counters, zeroed

@@ -35,13 +35,15 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     const uint32_t slot = xcd_skewed(blockIdx.x, gridDim.x);
     const uint32_t item = a.item_order ? a.item_order[slot] : slot + a.item_base;
     const WorkItem it = a.items[item];
-    if (a.item_trace && threadIdx.x == 0) {                                // (diagnostic: nothing of it stays live)
+#ifdef LASH_ITEM_TRACE_BUILD   // diagnostic build only (tools/build_trace_lib.sh): in the shipped kernels the two branches cost scalar registers the tile loop is short of
+    if (a.item_trace && threadIdx.x == 0) {
         uint32_t hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         a.item_trace[4ull * item] = wall_clock64();
         a.item_trace[4ull * item + 2] = ((unsigned long long)xcc << 32) | hw;
     }
+#endif
     const GenomeDesc gd = a.genomes[it.genome];
     const uint64_t L = DIRECT ? gd.byte_len : a.nvalid[it.genome];
     const int k = a.k, p = a.p;
@@ -367,7 +369,9 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     if (a.k != 99) return;
 #endif
     finish_item<ALGO, REGS, Regs>(a, it, regs, census, part, my_kmers, p, item);
+#ifdef LASH_ITEM_TRACE_BUILD
     if (a.item_trace && threadIdx.x == 0) a.item_trace[4ull * item + 1] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -17,7 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 BUDGET = {  # kernel (demangled prefix) -> most scratch instructions it may hold
     "void lash::sketch_kernel<0, 0, false, 0, true, true>": 20,    # hmh k=16, direct, deferring (the default bench): 18
     "void lash::sketch_kernel<1, 2, false, 0, true, false>": 17,   # hll k>16 (configs[2]): 15
-    "void lash::sketch_kernel<2, 0, false, 0, true, false>": 11,   # ull k=16 (the reads shape): 9
+    "void lash::sketch_kernel<2, 0, false, 0, true, false>": 11,   # ull k=16 (the reads shape): 9 (round 6, with the XCD skew of the item index: 11)
+    # round 6: the rule variants are the same kernels with another hash half / bucket side — and must stay inside the same budget
+    "void lash::sketch_kernel<0, 0, true, 0, true, true>": 20,     # hmh x = low half, direct, deferring: 18
+    "void lash::sketch_kernel<1, 2, true, 0, true, false>": 17,    # hll bucket = top bits, k>16: 15
 }
 
 

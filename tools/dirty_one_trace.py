@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/dirty_one_trace.py B [genomes] — ONE soft-masked shape of tools/dirty_rate.py (every other block of B bytes lower-case; B = 0: clean), timed,
+"""tools/dirty_one_trace.py B [genomes]  (the trace needs LASH_GFX950_LIB=build/variants/liblash_trace.so: tools/build_trace_lib.sh)
+ — ONE soft-masked shape of tools/dirty_rate.py (every other block of B bytes lower-case; B = 0: clean), timed,
 and its last launch traced per workgroup (LASH_ITEM_TRACE -> gpurun_out/item_trace_B.txt, read by tools/item_trace.py)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
