@@ -260,7 +260,8 @@ void     lash_fastq_neutralise_tail(uint8_t *tail, uint64_t n);
 uint64_t lash_fastq_sanitize(uint8_t *buf, uint64_t n, int skip_bad);
 
 /* Two-stage form for callers that keep genomes resident in HBM as 2-bit (0.28 B/base incl. break bitmap):
- * pack once, sketch many times (other k / algo / seed).  The pack stage performs filter_out_n + KSeq::new
+ * pack once, sketch many times (other k / algo / seed; a packed batch belongs to the base codes / k-mer bit order of the layout it was packed
+ * under: after lash_ctx_set_layout changes those, lash_sketch_packed_device returns LASH_EINVAL).  The pack stage performs filter_out_n + KSeq::new
  * (utils.rs:459,464) and records where records begin so that no k-mer spans two records (utils.rs:457-464). */
 int  lash_pack_device(lash_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_rec_off, uint64_t n_rec,
                       const uint64_t *genome_rec_off, const uint64_t *genome_byte_off, uint32_t n_genomes,

@@ -439,6 +439,12 @@ int lash_sketch_packed_device(lash_ctx *ctx, const lash_params *prm, const lash_
     int rc = lash_params_check(prm);
     if (rc) return rc;
     if (prm->flags & LASH_F_AMINO) return LASH_EINVAL;                   // packed genomes are 2-bit nucleotides
+    // the words carry the code table of the layout they were packed under (base codes, and their swap for kmer_lsb_first): another layout's
+    // reverse complement and canonical order would read them wrongly — refuse instead of sketching something else
+    if (pk->code_tab4 != layout_dev(ctx->layout, prm->algo).code_tab4) {
+        ctx->err = "lash_sketch_packed_device: the context's layout changed its base codes / k-mer bit order since lash_pack_device";
+        return LASH_EINVAL;
+    }
     (void)hipSetDevice(ctx->device);
     if ((rc = timing_begin(ctx))) return rc;
     ctx->last_packed.clear();

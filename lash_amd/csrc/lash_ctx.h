@@ -88,6 +88,8 @@ struct lash_packed {
     const uint64_t *d_rec_off = nullptr;
     uint64_t n_rec = 0;
     bool owned_by_ctx = false;           // the scratch instance reused by lash_sketch_batch_device
+    uint32_t code_tab4 = 0;              // the 2-bit code table the words were packed under (layout.base_code, swapped for kmer_lsb_first): a
+                                         // packed batch belongs to that table; lash_sketch_packed_device refuses another (round 6)
 };
 
 struct lash_ctx;

@@ -115,6 +115,7 @@ int pack_into(lash_ctx *ctx, lash_packed *pk, hipStream_t stream, EvSet *ev, con
     pa.brk = static_cast<uint32_t *>(pk->brk.ptr);
     pa.nvalid = pk->d_nvalid;
     pa.code_tab4 = layout_dev(ctx->layout, LASH_HMH).code_tab4;
+    pk->code_tab4 = pa.code_tab4;
     pa.file_err = formats ? pk->d_dirty + 3 * (size_t)n_genomes + 1 : nullptr;      // raw files: FASTQ structure flags
     uint64_t *lb = static_cast<uint64_t *>(pk->lookback.ptr);
     PackV2Args v2{};
@@ -214,9 +215,10 @@ static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector
     uint64_t bytes = 0, off = 0, group_max_bytes = 0;
     uint32_t in_group = 0;
     for (uint32_t g = 0; g < n_genomes; ++g) {
-        // a row's entries leave padded to a multiple of four: (m + 1.5) / m on average for rows of m entries per flush
+        // a row's entries leave padded to a multiple of SIX, six to a 16-byte chunk (round 6): (m + 2.5) / m on average for rows of m entries per
+        // flush, two thirds of a 32-bit word each; `cap` and the lists' counters are in words
         const uint64_t m_row = std::max<uint64_t>(1, 1024u >> (plan.bins_log2 + plan.bin_sub_shift));
-        uint64_t mean = entries_of_genome[g] / B * (2 * m_row + 4) / (2 * m_row);
+        uint64_t mean = entries_of_genome[g] / B * (2 * m_row + 6) / (2 * m_row) * 2 / 3 + 4;
         uint64_t sq = 1; while (sq * sq < mean) ++sq;
         const uint64_t cap = (mean + mean / 8 + 8 * sq + 1024 + 63) & ~63ull;
         if (cap > 0xFFFFFFFFull) { br.fits = false; return LASH_OK; }

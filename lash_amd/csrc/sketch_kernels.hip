@@ -1080,13 +1080,20 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
     // 16 x LASH_BINS_APPLY_LOADS bytes per lane and round, all loads issued before the first update, no branch ("nothing" ORs a zero / offers
     // -1): one entry per round with a `continue` in it ran one global load latency per entry — 76 in a row per lane at p = 20,
     // 129 us per workgroup, half of a binned launch's time
-    auto apply = [&](uint32_t e) {
+    // a list entry (round 6): index inside the bin << 6 | value in bin_shift + 6 bits, six of them in a 16-byte chunk (BinRegs::flush)
+    auto apply = [&](uint32_t f) {
         // ("nothing" — a row's padding, a round's idle lanes — goes to a register of the lane's own: the lanes' zeros on ONE word serialise)
-        const uint32_t v = e & 63u, r = (v == 63u ? threadIdx.x : (e >> 6)) & (regs_per_bin - 1u);
+        const uint32_t v = f & 63u, r = (v == 63u ? threadIdx.x : (f >> 6)) & (regs_per_bin - 1u);
         if constexpr (ALGO == 2) atomicOr(&tab[2u * r + ((v >> 5) & 1u)], v == 63u ? 0u : 1u << (v & 31u));
         else atomicMax(reinterpret_cast<int *>(tab) + r, v == 63u ? -1 : (int)v);
     };
-    const uint4 *l4 = reinterpret_cast<const uint4 *>(list);          // (lists start and reservations are whole 16-byte groups)
+    const uint32_t F = a.bin_shift + 6u, fmask = (1u << F) - 1u;
+    auto apply_chunk = [&](const uint4 q) {
+        const uint64_t lo = ((uint64_t)q.y << 32) | q.x, hi = ((uint64_t)q.w << 32) | q.z;
+        apply((uint32_t)lo & fmask); apply((uint32_t)(lo >> F) & fmask); apply((uint32_t)(lo >> (2u * F)) & fmask);
+        apply((uint32_t)hi & fmask); apply((uint32_t)(hi >> F) & fmask); apply((uint32_t)(hi >> (2u * F)) & fmask);
+    };
+    const uint4 *l4 = reinterpret_cast<const uint4 *>(list);          // (lists start and reservations are whole 16-byte chunks)
     const uint32_t n4 = n >> 2;
     constexpr uint32_t Q = LASH_BINS_APPLY_LOADS;
     for (uint32_t i = threadIdx.x; i < n4; i += Q * blockDim.x) {
@@ -1094,12 +1101,11 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
 #pragma unroll
         for (uint32_t b = 0; b < Q; ++b) {
             const uint32_t at = i + b * blockDim.x;
-            q[b] = at < n4 ? l4[at] : make_uint4(~0u, ~0u, ~0u, ~0u);
+            q[b] = at < n4 ? l4[at] : make_uint4(~0u, ~0u, ~0u, ~0u);      // (all ones: six times "nothing")
         }
 #pragma unroll
-        for (uint32_t b = 0; b < Q; ++b) { apply(q[b].x); apply(q[b].y); apply(q[b].z); apply(q[b].w); }
+        for (uint32_t b = 0; b < Q; ++b) apply_chunk(q[b]);
     }
-    for (uint32_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) apply(list[i]);
     __syncthreads();
     if (a.spill[(uint64_t)gi * a.bins + bin]) {                           // entries of this bin that found a row or a list full
         // fold this bin's part of the fallback table in and leave it empty again: the table is wiped once, when it is allocated, not 8 MiB
@@ -1189,7 +1195,7 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool variant, bool small_ite
         s.bin_sub_shift = bl < 5u ? 5u - bl : 0u;                           // at least 32 staging rows per wave (see BinRegs)
         const uint32_t mean = 1024u >> (bl + s.bin_sub_shift);              // staged entries per row and word of 16 k-mers per lane
         uint32_t sq = 1; while (sq * sq < mean) ++sq;
-        s.bin_S = (mean + 4u * sq + 4u + 3u) & ~3u;                         // room for the mean + 4 sigma (rows of 16-byte chunks); more goes to the fallback table
+        s.bin_S = ((mean + 4u * sq + 4u + 11u) / 12u) * 12u;                // room for the mean + 4 sigma, a multiple of 12 (six entries per chunk, rows 16-byte aligned); more goes to the fallback table
         s.lds_bytes = 0;                                                    // no table in the sketch kernels
     }
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU

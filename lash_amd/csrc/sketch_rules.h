@@ -139,14 +139,18 @@ struct BinRegs {
         return o;
     }
     // staged entries -> the bins' lists: a lane owns a row, reserves room for its entries in the bin's list and copies them out 16 bytes
-    // at a time (rows are padded to four entries with 0xFFFFFFFF = "nothing", so every reservation and every store is 16-byte
-    // aligned: scattered 4-byte stores were what bound the first version).  The rows of one bin sit in neighbouring lanes and share
-    // ONE returning global atomic (a prefix sum over the wave; 32 lanes adding to the same two counters was the other thing that did).
+    // at a time (scattered 4-byte stores were what bound the first version).  Round 6: inside a bin the high bits of the register index are the
+    // bin's own, so a list entry needs bin_shift + 6 = 20 (UltraLogLog) or 21 (HyperLogLog) bits: SIX entries leave in one 16-byte chunk (two
+    // 64-bit words of three fields each; rows are padded to six entries with "nothing" = 63), a third less list traffic in both passes wherever
+    // a row holds more than a handful of entries per flush (profiles/r06/floor_bins.md).  The rows of one bin sit in neighbouring lanes and share
+    // ONE returning global atomic (a prefix sum over the wave; 32 lanes adding to the same two counters was the other thing that bound it).
     // (Reserving chunks ahead — one atomic per ~8 flushes — was tried and lost: more atomics on fewer counters where bins are few,
-    // and the filling of unused tails.)  Every lane of the wave must call it.
+    // and the filling of unused tails.)  The lists' counters count 32-bit WORDS (four per chunk).  Every lane of the wave must call it.
     __device__ __forceinline__ void flush(uint32_t lane) const
     {
         auto lds = [](uint32_t b) { return (__attribute__((address_space(3))) uint32_t *)(uintptr_t)b; };
+        const uint32_t F = bin_shift + 6u;                                 // bits of a list entry: index inside the bin << 6 | value
+        const uint32_t fmask = (1u << F) - 1u;
         // 64 rows and more (64 bins and more, a row per lane): up to four groups of 64 rows; ALL their reservations are issued before the
         // first copy waits for one (p = 22, 256 rows: four returning atomics one after the other per word of 16 k-mers were most of its pass)
         uint32_t n_[4], base_[4];
@@ -161,7 +165,7 @@ struct BinRegs {
                 if (n) *lds(cnt_b + row * 4u) = 0u;
                 n = n < S ? n : S;                                         // (what went beyond the row has been spilled / redone)
             }
-            const uint32_t n4 = (n + 3u) & ~3u, bin = row >> sub_shift;
+            const uint32_t n4 = ((n + 5u) / 6u) * 4u, bin = row >> sub_shift;   // words: four per chunk of six entries
             uint32_t base;
 #ifdef LASH_ABL_BINS_NO_ATOMIC  // timing-only diagnostic build: every row lands at the start of its list
             if (true) { base = 0u; (void)bin; } else
@@ -177,7 +181,7 @@ struct BinRegs {
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);
                 incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);
                 const uint32_t sub = (1u << sub_shift) - 1u, gs = lane & ~sub, ge = gs | sub;
-                const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs * 4u), (int)(incl - n4));     // entries of the bins before this one
+                const uint32_t before = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs * 4u), (int)(incl - n4));     // words of the bins before this one
                 const uint32_t total = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ge * 4u), (int)incl) - before;
                 uint32_t bin_base = 0;
                 if (lane == gs && total) bin_base = __hip_atomic_fetch_add(cnt + bin, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -190,24 +194,29 @@ struct BinRegs {
         for (uint32_t g = 0; g < 4u; ++g) {
             if (g * 64u >= V) continue;
             const uint32_t row = g * 64u + lane, n = n_[g], base = base_[g];
-            const uint32_t n4 = (n + 3u) & ~3u, bin = row >> sub_shift;
+            const uint32_t bin = row >> sub_shift;
             uint32_t *dst = lists + (uint64_t)bin * cap;
             const uint32_t src = stage_b + row * (S + 4u) * 4u;
-            for (uint32_t i = 0; i < n4; i += 4u) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 raw = *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)(src + i * 4u);    // ds_read_b128
-                uint4 q = make_uint4(raw.x, raw.y, raw.z, raw.w);
-                if (i + 4u > n) {                                          // the padding (the row holds older entries there)
-                    if (i + 1u >= n) q.y = 0xFFFFFFFFu;
-                    if (i + 2u >= n) q.z = 0xFFFFFFFFu;
-                    q.w = 0xFFFFFFFFu;
-                }
-                const uint32_t at = base + i;
+            for (uint32_t i = 0, at = base; i < n; i += 6u, at += 4u) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                // six staged entries (rows are multiples of six slots long and 8-byte aligned at every sixth: three ds_read_b64)
+                const u32x2 r0 = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(src + i * 4u);
+                const u32x2 r1 = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(src + i * 4u + 8u);
+                const u32x2 r2 = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(src + i * 4u + 16u);
+                uint32_t e[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+#pragma unroll
+                for (uint32_t j = 1; j < 6u; ++j) e[j] = i + j < n ? e[j] : 0xFFFFFFFFu;       // the padding (the row holds older entries there)
 #ifdef LASH_ABL_BINS_NO_STORE   // timing-only diagnostic build (tools/build_variant.sh): results are wrong by construction
-                asm volatile("" ::"v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w), "v"(at));
+                asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(at));
 #else
-                if (at + 4u <= cap) *reinterpret_cast<uint4 *>(dst + at) = q;
-                else { spill_entry(q.x); spill_entry(q.y); spill_entry(q.z); spill_entry(q.w); }
+                if (at + 4u <= cap) {
+                    const uint64_t lo = (uint64_t)(e[0] & fmask) | ((uint64_t)(e[1] & fmask) << F) | ((uint64_t)(e[2] & fmask) << (2u * F));
+                    const uint64_t hi = (uint64_t)(e[3] & fmask) | ((uint64_t)(e[4] & fmask) << F) | ((uint64_t)(e[5] & fmask) << (2u * F));
+                    *reinterpret_cast<uint4 *>(dst + at) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 6u; ++j) spill_entry(e[j]);                        // (the list is full: the full entries, to the fallback table)
+                }
 #endif
             }
         }

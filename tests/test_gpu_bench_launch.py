@@ -131,3 +131,19 @@ def test_the_viral_workload_prints_the_same_contract():
     assert j["roofline"]["kernel"].startswith("sole_sketch_kernel") and j["roofline"]["input"].startswith("ASCII")
     assert j["parity_vs_oracle"].startswith("bit-identical") and j["cpu_baseline"]["value"] > 0
     assert j["roofline"]["algorithmic_bytes_per_launch"] > 3000 * 32768 and 0 < j["roofline"]["frac"] < 1
+
+
+def test_the_layout_flag_reproduces_the_line_on_an_alternative_rule():
+    """`bench.py --layout SPEC` runs the same workload under an alternative of the reference's unpinned crate rules — the kernels'
+    compile-time variants — and its parity spot check and CPU leg use the oracle with the same layout."""
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LASH_BENCH_BACKEND"):
+        env.pop(v, None)
+    for spec in ("hmh_x=low", "kmer=lsb"):
+        r = subprocess.run([sys.executable, "bench.py", "--genomes", "300", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--layout", spec],
+                           cwd=ROOT, capture_output=True, text=True, env=env, timeout=900)
+        j = _one_line(r)
+        assert j["config"]["layout"] == spec and j["parity_vs_oracle"].startswith("bit-identical"), j.get("parity_vs_oracle")
+        assert j["roofline"]["kernel"] == "sketch_kernel<DIRECT, DEFER>" and j["roofline"]["traffic"] is None      # x = low defers like the default
+        assert j["ranks"]["ranks_seen"] == 1 and j["ranks"]["devices_distinct"] == 1 and "layout_note" in j["roofline_valu"]
+        assert abs(j["value"] * j["ms_per_step"] * 1e-3 / (300 * (5_000_000 - 16 + 1)) - 1) < 1e-6

@@ -202,3 +202,33 @@ def test_rule_alternatives_full_size_spot_check(ctx, spec, an, k, p):
             assert np.array_equal(img[g], want), (spec, an, g)
     finally:
         ctx.set_layout(None)
+
+
+def test_a_packed_batch_belongs_to_the_code_table_it_was_packed_under(ctx):
+    """Round 6: kmer_lsb_first is the complemented code table, so packed 2-bit words depend on it (as they always did on `codes=`).  Sketching a batch
+    packed under another table would silently give another sketch: LASH_EINVAL instead.  Header templates and the hash half may change freely."""
+    import torch
+    import lash_amd
+    seq, off, goff = lash_amd.records_to_arrays([[O.synth_genome(5, 50_000).tobytes()], [O.synth_genome(6, 30_000).tobytes()]])
+    d_seq = torch.from_numpy(seq).cuda()
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    gbo = off[goff.astype(np.int64)]
+    try:
+        ctx.set_layout(None)
+        pk = ctx.pack_device(d_seq, d_off, len(off) - 1, goff, gbo)
+        d_img = torch.zeros(2 * lash_amd.image_bytes("hmh"), dtype=torch.uint8, device="cuda")
+        ctx.sketch_packed_device("hmh", 16, 0, 42, pk, d_img)
+        ctx.set_layout("hmh_x=low,hmh_hdr=l")                              # same k-mers: allowed
+        d_img2 = torch.zeros(2 * ctx.image_bytes("hmh"), dtype=torch.uint8, device="cuda")
+        ctx.sketch_packed_device("hmh", 16, 0, 42, pk, d_img2)
+        ctx.synchronize()
+        want = O.sketch_genomes(O.HMH, 16, 0, 42, seq, off, goff, layout=O.parse_layout("hmh_x=low,hmh_hdr=l"))
+        assert np.array_equal(d_img2.cpu().numpy().reshape(2, -1), want)
+        for spec in ("kmer=lsb", "codes=ACTG"):
+            ctx.set_layout(spec)
+            with pytest.raises(lash_amd.LashError) as e:
+                ctx.sketch_packed_device("hmh", 16, 0, 42, pk, d_img)
+            assert e.value.code == lash_amd.EINVAL
+        pk.free()
+    finally:
+        ctx.set_layout(None)
