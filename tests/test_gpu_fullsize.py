@@ -390,6 +390,8 @@ def test_a_million_tiny_genomes(env, algo, k, p, monkeypatch):
     dev = torch.device("cuda", 0)
     d_seq = torch.empty(total, dtype=torch.uint8, device=dev)
     ctx.synth_genomes_device(0, 1, total, d_seq)
+    ctx.synchronize()                    # (the generator runs on the context's stream, the edits below on torch's: without this some of them were
+                                         #  overwritten by the generator once in a while — bases_last 0.02 % high, round 6)
     # deleted bytes: in every fourth genome bytes [40, 40 + 12) become N and [90, 90 + 25) lower case
     dirty = torch.from_numpy(gbo[:-1:4].astype(np.int64)).to(dev)
     for o, n, orv in ((40, 12, None), (90, 25, 0x20)):
@@ -436,6 +438,7 @@ def test_soft_masked_assemblies_at_full_size(env, algo, k, p, monkeypatch):
     dev = torch.device("cuda", 0)
     d_seq = torch.empty(G * L, dtype=torch.uint8, device=dev)
     ctx.synth_genomes_device(0, G, L, d_seq)
+    ctx.synchronize()                    # (the edits below run on torch's stream)
     rng = np.random.default_rng(23)
     edges = np.cumsum(np.exp(rng.uniform(np.log(30), np.log(30000), size=4 * (2 * L) // 3000)).astype(np.int64))
     edges = edges[edges < 2 * L]

@@ -91,14 +91,15 @@ def main():
         elif cfg.get("dirty") == "lower":
             kmers = cfg["genomes_per_gpu"] * (cfg["genome_length"] // 2 - cfg["k"] + 1)
         key = "%s%s_k%d_p%d_g%d_l%d" % ("direct_" if direct else "", cfg["algo"], cfg["k"], cfg["p"], cfg["genomes_per_gpu"], cfg["genome_length"])
-        if hbm is not None and cfg.get("dirty", "none") == "none":
+        default_layout = cfg.get("layout", "default") == "default"      # (bench.py --layout runs are listed, but the committed figures bench.py quotes are the default rule's)
+        if hbm is not None and cfg.get("dirty", "none") == "none" and default_layout:
             traffic[key] = {"hbm_bytes_per_launch": hbm, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
                             "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1; calibrated in the same session (%s/hbm_calibration.txt)" % dst,
                             "source": "%s/%s/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes)" % (dst, name),
                             "kernel": short, "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "round": rnd}
         defer = "DEFER" in roof["kernel"]               # HyperMinHash with deferred signatures: a stream, a count and a ceiling of its own
         vkey = "%s%s_k%d%s" % ("direct_" if direct else "", cfg["algo"], cfg["k"], "_defer" if defer else "")
-        if insts is not None and cfg.get("dirty", "none") == "none":
+        if insts is not None and cfg.get("dirty", "none") == "none" and default_layout:
             # one entry per kernel: the deferring kernel's from the default workload (whole genomes: what bench.py runs by default), the
             # others' from the 1 000-genome / read-set runs unless only a large run exists
             if (cfg["genomes_per_gpu"] == 12500 or vkey not in valu) if defer else \
