@@ -163,16 +163,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         t.b = load16_any(reinterpret_cast<const uint8_t *>(bk + bi));
     };
     TileRegs nxt;
-#ifdef LASH_TILE_ROTATE
-    // (experiment, round 6: every other work item walks its tiles from the MIDDLE — the k-mer multiset is the same, max / OR do not care about order —
-    // so that a launch of identically laid-out genomes (all clean up to a point and soft-masked after it) does not enter its memory-bound phase on
-    // every CU at once; tools/build_variant_lib.sh rotate "-DLASH_TILE_ROTATE", profiles/r06/tile_rotate_ab.txt)
-    const uint32_t n_tiles = (it.word_end - it.word_begin + step - 1u) / step;
-    const uint32_t first_tile = it.word_begin + ((item & 1u) ? (n_tiles >> 1) * step : 0u);
-    tile_load(first_tile, nxt);
-#else
     tile_load(it.word_begin, nxt);
-#endif
     // the table is cleared while the first tile's loads are in flight; a raw barrier, because __syncthreads() would also
     // drain vmcnt and with it those loads
     if constexpr (USE_LDS && REGS != REGS_BINS) {
@@ -181,20 +172,10 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifdef LASH_ABL_PROLOGUE_ONLY   // timing-only diagnostic builds (tools/build_variant.sh): results are wrong by construction
+#ifdef LASH_ABL_PROLOGUE_ONLY   // timing-only diagnostic builds (tools/build_variant_lib.sh): results are wrong by construction
     if (a.k != 99) return;
 #endif
-#ifdef LASH_TILE_ROTATE
-    uint32_t tile = first_tile;
-    for (uint32_t ti = 0; ti < n_tiles; ++ti, tile = (tile + step < it.word_end ? tile + step : it.word_begin)) {
-        const uint32_t tile_next = ti + 1u < n_tiles ? (tile + step < it.word_end ? tile + step : it.word_begin) : tile + step;   // (past the last: the clamped dummy load)
-#define LASH_NEXT_TILE tile_next
-#define LASH_TILES_DONE (ti + 1u)
-#else
-#define LASH_NEXT_TILE (tile + step)
-#define LASH_TILES_DONE ((tile - it.word_begin) / step + 1u)
     for (uint32_t tile = it.word_begin; tile < it.word_end; tile += step) {
-#endif
         const uint32_t w0 = tile + threadIdx.x * SKETCH_WORDS_PER_THREAD;
         const uint64_t pos0 = (uint64_t)w0 * 16;
         const bool active = tile_active(tile);
@@ -208,7 +189,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
         // A wave with no lane inside the slice has nothing to hash (a 10 kbp genome fills 2.5 of a workgroup's 8 waves).
         // Letting it run the masked body is worse than wasted issue slots: its lanes would all hash the same all-zero
         // words and hit ONE LDS address with 64-way serialized atomics (46 us per small genome instead of ~10).
-        if (__builtin_amdgcn_ballot_w64(active) == 0ull) { tile_load(LASH_NEXT_TILE, nxt); continue; }
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) { tile_load(tile + step, nxt); continue; }
 
         // inactive lanes of an active wave: distinct garbage words (their updates are masked to no-ops), for the same reason
         const uint32_t junk = (threadIdx.x + 1u) * 0x9E3779B1u;
@@ -246,7 +227,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     if (__builtin_amdgcn_ballot_w64(gone) == act) {
                         // (raw_ok lanes own exactly their 64 bytes: the genome's tail is at least 32 bytes away)
                         if ((threadIdx.x & 63) == 0 && part == 0u) atomicAdd(a.ndel + it.genome, 64u * (uint32_t)__builtin_popcountll(act));
-                        tile_load(LASH_NEXT_TILE, nxt);
+                        tile_load(tile + step, nxt);
                         continue;
                     }
                 }
@@ -257,7 +238,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                 // counter in memory held a budget of walked tiles: one returning atomic per dirty tile on ONE address, which for a
                 // single 3 Gbp read set with 20 000 Ns serialised in the L2 and cost more than the walks — 2.9 -> 4.4 ms.)
                 tiles_dense = (uint32_t)__builtin_amdgcn_readfirstlane((int)tiles_dense) + 1u;
-                if (tiles_dense >= 4u && tiles_dense * 8u > LASH_TILES_DONE && !judged) {
+                if (tiles_dense >= 4u && tiles_dense * 8u > (tile - it.word_begin) / step + 1u && !judged) {
                     // this wave's verdict, once; the genome goes when enough of its waves agree (GenomeDesc::handover: one for a
                     // genome of a few items, 1 in 32 for a read set of thousands — there SOME wave always meets four dirty tiles early)
                     judged = true;
@@ -303,7 +284,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     my_kmers += wave_sum(dense_tile<ALGO, KMODE, XLOW, SlowRegs>(regs, kp, gseq, L, P0, E, use_bitmap ? bk : nullptr, RL, k, cmask, ctabs,
                                                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)stage_b), dirty,
                                                                             part == 0u ? a.ndel + it.genome : nullptr, raw_ok, cur.q, cur.a1, cur.a2, cur.a3));
-                    tile_load(LASH_NEXT_TILE, nxt);
+                    tile_load(tile + step, nxt);
                     continue;
                 }
                 if (wave_nd && part == 0u && (threadIdx.x & 63) == 0) atomicAdd(a.ndel + it.genome, wave_nd);   // (one per wave; the passes of a partitioned table see the same bytes)
@@ -317,7 +298,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
             c0 = cur.q.x; c1 = cur.q.y; c2 = cur.q.z; c3 = cur.q.w; c4 = cur.c4; c5 = cur.c5;
             kv = kmer_valid_mask(cur.b.x, cur.b.y, cur.b.z, (uint32_t)pos0, (uint32_t)nk, k);
         }
-        tile_load(LASH_NEXT_TILE, nxt);                                    // (see the top of the loop)
+        tile_load(tile + step, nxt);                                    // (see the top of the loop)
         // wave-uniform: every lane of this wave has 64 real k-mers -> no per-k-mer masking at all
         const bool all_valid = __builtin_amdgcn_ballot_w64(kv != ~0ull) == 0ull;
         // the k-mer census is kept per WAVE in a scalar register (a vector register less across the hashing: the k > 16 kernels sit

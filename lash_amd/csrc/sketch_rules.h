@@ -206,7 +206,7 @@ struct BinRegs {
                 uint32_t e[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
 #pragma unroll
                 for (uint32_t j = 1; j < 6u; ++j) e[j] = i + j < n ? e[j] : 0xFFFFFFFFu;       // the padding (the row holds older entries there)
-#ifdef LASH_ABL_BINS_NO_STORE   // timing-only diagnostic build (tools/build_variant.sh): results are wrong by construction
+#ifdef LASH_ABL_BINS_NO_STORE   // timing-only diagnostic build (tools/build_variant_lib.sh): results are wrong by construction
                 asm volatile("" ::"v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(at));
 #else
                 if (at + 4u <= cap) {

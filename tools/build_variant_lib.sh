@@ -2,7 +2,6 @@
 # tools/build_variant_lib.sh NAME "-DFLAG ..." — liblash_gfx950.so with sketch_kernels.hip compiled under extra flags, as build/variants/liblash_NAME.so
 # (LASH_GFX950_LIB=$PWD/build/variants/liblash_NAME.so for A/B runs on one box; build/ is git-ignored but travels with gpurun).  Known variants:
 #     trace   -DLASH_ITEM_TRACE_BUILD   per-workgroup trace of direct sketch launches (LASH_ITEM_TRACE=<file>, tools/item_trace.py)
-#     rotate  -DLASH_TILE_ROTATE        every other work item walks its tiles from the middle (profiles/r06/tile_rotate_ab.txt)
 set -e
 cd "$(dirname "$0")/.."
 python3 -m lash_amd.build > /dev/null
