@@ -137,6 +137,7 @@ struct lash_ctx {
     unsigned ring_next = 0;
     std::vector<const lash_packed *> last_packed;   // what the last sketch call consumed (for bases_last / error flags)
     DevBuf items, item_begin, item_kmers, partials, gregs, counter;   // items: [work items | item_begin] of a sketch call
+    uint64_t bins_budget = 0;     // bytes one group of a binned launch may take (0: not asked yet; lash_plan.hip bins_budget_bytes)
     int bins_slab_fill = -1; size_t bins_slab_clean = 0;   // the fallback tables rest EMPTY between launches: with which byte (0x00 ull / 0xFF hll; -1: unknown), how far
     DevBuf bins_lists, bins_meta, bins_slab;   // binned launches (SketchPlan::bins): entry lists, tables + counters, fallback tables of one genome group
     bool counter_zeroed = false;

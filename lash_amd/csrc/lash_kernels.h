@@ -84,8 +84,9 @@ struct SketchPlan {
 // per wave: bytes of LDS a binned launch needs for its bin counters and staging rows
 uint32_t sketch_bin_wave_bytes(const SketchPlan &plan);
 struct BinApplyArgs {
-    const uint32_t *lists, *cnt, *spill;
-    uint32_t *slab;                 // (a bin's part is folded in and wiped when its flag is up)
+    const uint32_t *lists, *cnt;
+    uint32_t *spill;                // one flag per (genome, bin): its part of the fallback table holds something
+    uint32_t *slab;                 // (a bin's part is read beside the LDS table and wiped when its flag is up)
     const BinGenome *genomes;
     uint8_t  *partials;           // the group's genomes' "virtual" partials: genome gi of the group at partials + (virt0 + gi) * partial_stride
     uint32_t *item_kmers;         // ... and its k-mer count at item_kmers[virt0 + gi] = the sum over its real items
@@ -97,6 +98,13 @@ struct BinApplyArgs {
     uint32_t  virt0, genome0;
     uint32_t  bins, bin_shift, slab_words;
     int       algo, p;
+    // UltraLogLog, not accumulating (round 6): the registers leave straight into the caller's images — header by the genome's first bin, k-mer census
+    // into kmer_counter — and no finalize launch follows (at p = 22 it read and wrote 4 MiB per genome only to move them: 4.1 of 33 ms)
+    uint8_t  *images;             // NULL: into the partials, finalize_kernel does the rest
+    uint64_t  image_bytes;
+    uint64_t  hdr_tpl;
+    uint32_t  hdr_bytes;
+    unsigned long long *kmer_counter;
 };
 hipError_t launch_bins_apply(const BinApplyArgs &args, uint32_t n_group_genomes, hipStream_t stream);
 

@@ -189,11 +189,22 @@ int probe_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 // bins_apply_kernel builds each bin's registers in LDS and leaves ONE partial per genome ("virtual item" n_items + g) for the
 // ordinary finalize stage.  Lists, counters and fallback tables are sized per genome GROUP (a few GiB at a time; the stream orders
 // the groups, so the buffers are reused), from an upper bound of the entries each genome's work items push.
-// HBM one group of a binned launch (or one chunk of per-item global tables) may take: LASH_BINS_MB, default 6 GiB; read per call
-uint64_t bins_budget_bytes()
+// HBM one group of a binned launch (or one chunk of per-item global tables) may take.  LASH_BINS_MB (read per call), else a twelfth of the
+// device's memory but no more than 24 GiB nor a third of what was free when the context first asked (round 6; 6 GiB before: 1 000 x 5 Mbp at
+// p = 22 ran in ten groups of ~100 genomes — 300 work items for 256 workgroup slots, a tail per group — and each genome's 32 MiB fallback
+// table is most of what the budget pays for; 24 GiB: -7 .. -9 %, more buys nothing, profiles/r06/bins_ab.txt)
+uint64_t bins_budget_bytes(lash_ctx *ctx)
 {
-    const char *e = getenv("LASH_BINS_MB");
-    return (e ? (uint64_t)std::max(64, atoi(e)) : 6144ull) << 20;
+    if (const char *e = getenv("LASH_BINS_MB")) return (uint64_t)std::max(64, atoi(e)) << 20;
+    if (!ctx->bins_budget) {
+        size_t free_b = 0, total_b = 0;
+        uint64_t b = 6144ull << 20;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b)
+            b = std::max<uint64_t>(1ull << 30, std::min<uint64_t>({24ull << 30, (uint64_t)total_b / 12, (uint64_t)free_b / 3}));
+        else (void)hipGetLastError();
+        ctx->bins_budget = b;
+    }
+    return ctx->bins_budget;
 }
 
 struct BinsRun {
@@ -210,7 +221,7 @@ static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector
 {
     const uint32_t B = 1u << plan.bins_log2;
     br.slab_words = plan.nreg32;                                     // HLL: 2^p words, ULL: 2 * 2^p
-    const uint64_t budget = bins_budget_bytes();
+    const uint64_t budget = bins_budget_bytes(ctx);
     br.table.resize(n_genomes);
     uint64_t bytes = 0, off = 0, group_max_bytes = 0;
     uint32_t in_group = 0;
@@ -261,11 +272,14 @@ static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector
     br.d_spill = reinterpret_cast<uint32_t *>(mb + tabs + cnt_bytes);
     return LASH_OK;
 }
+// UltraLogLog, not accumulating: bins_apply_kernel writes the images itself and the call queues no finalize launch (BinApplyArgs::images)
+static bool bins_write_images(const lash_params *prm) { return prm->algo == LASH_ULL && !(prm->flags & LASH_F_ACCUMULATE); }
 // the launches of one call, group by group: launch(sa, first item, items) queues the sketch kernels of an item range
 template <class Launch>
 static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *prm, SketchArgs sa, const BinsRun &br, const std::vector<uint32_t> &item_begin,
                     uint32_t n_items, const uint32_t *d_item_begin, Launch launch)
 {
+    const bool to_images = bins_write_images(prm);
     const uint32_t B = 1u << plan.bins_log2;
     sa.bin_lists = static_cast<uint32_t *>(ctx->bins_lists.ptr);
     sa.bin_cnt = br.d_cnt;
@@ -299,6 +313,10 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
         ba.items = sa.items; ba.nvalid = sa.nvalid; ba.k = prm->k;
         ba.partial_stride = sa.partial_stride; ba.virt0 = n_items + g0; ba.genome0 = g0;
         ba.bins = B; ba.bin_shift = plan.bin_shift; ba.slab_words = br.slab_words; ba.algo = prm->algo; ba.p = prm->p;
+        if (to_images) {
+            ba.images = sa.images; ba.image_bytes = sa.image_bytes; ba.hdr_tpl = sa.lay.hdr_tpl; ba.hdr_bytes = sa.lay.hdr_bytes;
+            ba.kmer_counter = static_cast<unsigned long long *>(ctx->counter.ptr);
+        }
         HIPCHK(ctx, launch_bins_apply(ba, ng, ctx->stream));
         g0 = g1;
     }
@@ -312,7 +330,7 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
 template <class Launch>
 static int global_run(lash_ctx *ctx, const SketchPlan &plan, SketchArgs sa, uint32_t n_items, Launch launch)
 {
-    const uint64_t budget = bins_budget_bytes();
+    const uint64_t budget = bins_budget_bytes(ctx);
     const uint64_t table = (uint64_t)plan.nreg32 * 4;
     const uint32_t per = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_items ? n_items : 1, budget / table));
     int rc;
@@ -530,7 +548,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     if (plan.bins) {
         // a binned launch keeps ~4.6 bytes per input byte of one genome group in HBM: a single genome beyond the budget (a multi-Gbp
         // input in one call, which the CLI would have streamed in chunks) takes the table-in-global-memory path instead
-        const uint64_t budget = bins_budget_bytes();
+        const uint64_t budget = bins_budget_bytes(ctx);
         uint64_t big = 0;
         for (uint32_t g = 0; g < n_genomes; ++g) big = std::max<uint64_t>(big, pk->byte_len[g]);
         if (big * 5 + (uint64_t)plan.nreg32 * 4 + (64u << 20) > budget)
@@ -917,7 +935,9 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     // (the fold's grid spans every genome of the batch: with many thousands of genomes and ONE long one, wait for the 33rd slice as before)
     if (max_slices > (n_genomes <= 4096u ? 8u : 32u) && n_genomes <= 65535u)
         for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
-    if (all_sole) {
+    if (plan.bins && bins_write_images(prm)) {
+        // bins_apply_kernel wrote the images, headers and census itself
+    } else if (all_sole) {
         HIPCHK(ctx, launch_census(fa, n_genomes, ctx->stream));            // every image was written by its one work item
     } else {
         HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
@@ -944,7 +964,7 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     const bool x_low = rule_variant(ctx->layout, prm->algo, prm->flags);   // (HyperMinHash x = low half / HyperLogLog bucket = top bits)
     SketchPlan plan = make_sketch_plan(prm->algo, prm->k, prm->p, x_low, false, allow_bins);
     if (plan.bins) {                                                  // (as in sketch_from: one genome beyond the binned launch's budget)
-        const uint64_t budget = bins_budget_bytes();
+        const uint64_t budget = bins_budget_bytes(ctx);
         uint64_t big = 0;
         for (uint32_t g = 0; g < n_genomes; ++g)
             big = std::max<uint64_t>(big, (genome_byte_off[g + 1] - genome_byte_off[g]) + 32 * (genome_rec_off[g + 1] - genome_rec_off[g]));
@@ -1071,8 +1091,10 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     // genome up to 16: 300 x 5 Mbp, finalize stage 0.27 -> 0.15 ms)
     if (max_slices > 8u && n_genomes <= 65535u)
         for (fa.group = 32u; (max_slices + fa.group - 1) / fa.group > 16u; fa.group *= 32u) {}
-    HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
-    HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
+    if (!(plan.bins && bins_write_images(prm))) {                      // (else bins_apply_kernel wrote the images, headers and census itself)
+        HIPCHK(ctx, launch_reduce_groups(fa, n_genomes, max_slices, ctx->stream));
+        HIPCHK(ctx, launch_finalize(fa, n_genomes, ctx->stream));
+    }
     if (ev) { HIPCHK(ctx, hipEventRecord(ev->e[4], ctx->stream)); ev->done = true; }
     ctx->cur_ev = nullptr;
     ctx->last.sketch_launches += n_items ? 1 : 0;

@@ -1070,28 +1070,56 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
     const uint32_t bin = blockIdx.x, gi = blockIdx.y;
-    const uint32_t regs_per_bin = 1u << a.bin_shift, words = ALGO == 2 ? 2u * regs_per_bin : regs_per_bin;
-    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) tab[i] = ALGO == 2 ? 0u : RANK_EMPTY;
+    // ONE 32-bit word per register.  HyperLogLog: rho - 1 under max.  UltraLogLog: the nlz bitmap's low word — an entry with 32 or more leading
+    // zeros (2^-32 of the k-mers) waits in a short list beside the table and is merged when the registers are written out
+    // (round 6: the 64-bit bitmaps took 128 KiB for a bin of 2^14 registers = ONE workgroup per CU, whose clear / load / update / write-out phases
+    // nothing overlapped; at 64 KiB two workgroups share a CU)
+    const uint32_t regs_per_bin = 1u << a.bin_shift, words = regs_per_bin, slab_words_bin = ALGO == 2 ? 2u * regs_per_bin : regs_per_bin;
+    uint32_t *const rare = tab + words;                                   // [0]: how many, [1 ..]: the entries (BINS_APPLY_RARE of them)
+    {
+        const uint32_t fill = ALGO == 2 ? 0u : RANK_EMPTY;
+        uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t i = threadIdx.x; i < (words >> 2); i += blockDim.x) t4[i] = make_uint4(fill, fill, fill, fill);
+        if (threadIdx.x == 0u) rare[0] = 0u;
+    }
     __syncthreads();
     const BinGenome bg = a.genomes[gi];
     const uint32_t *list = a.lists + bg.list_off + (uint64_t)bin * bg.cap;
     uint32_t n = a.cnt[(uint64_t)gi * a.bins + bin];
     n = n < bg.cap ? n : bg.cap;
+    uint32_t *const sl = a.slab + (uint64_t)gi * a.slab_words + (uint64_t)bin * slab_words_bin;
+    uint32_t *const flag = a.spill + (uint64_t)gi * a.bins + bin;
     // 16 x LASH_BINS_APPLY_LOADS bytes per lane and round, all loads issued before the first update, no branch ("nothing" ORs a zero / offers
     // -1): one entry per round with a `continue` in it ran one global load latency per entry — 76 in a row per lane at p = 20,
     // 129 us per workgroup, half of a binned launch's time
     // a list entry (round 6): index inside the bin << 6 | value in bin_shift + 6 bits, six of them in a 16-byte chunk (BinRegs::flush)
+    uint32_t rare_seen = 0;
     auto apply = [&](uint32_t f) {
         // ("nothing" — a row's padding, a round's idle lanes — goes to a register of the lane's own: the lanes' zeros on ONE word serialise)
         const uint32_t v = f & 63u, r = (v == 63u ? threadIdx.x : (f >> 6)) & (regs_per_bin - 1u);
-        if constexpr (ALGO == 2) atomicOr(&tab[2u * r + ((v >> 5) & 1u)], v == 63u ? 0u : 1u << (v & 31u));
-        else atomicMax(reinterpret_cast<int *>(tab) + r, v == 63u ? -1 : (int)v);
+        if constexpr (ALGO == 2) {
+            atomicOr(&tab[r], v >= 32u ? 0u : 1u << v);
+            rare_seen |= (v + 1u) & 63u;                                   // 33 .. 63 for nlz = 32 .. 62, at most 32 otherwise
+        } else {
+            atomicMax(reinterpret_cast<int *>(tab) + r, v == 63u ? -1 : (int)v);
+        }
+    };
+    // the rare entry: into the short list; a list that is full (never, with hashed input) sends it to the genome's fallback table instead
+    auto apply_rare = [&](uint32_t f) {
+        const uint32_t v = f & 63u, r = (f >> 6) & (regs_per_bin - 1u);
+        if (((v + 1u) & 63u) <= 32u) return;
+        const uint32_t slot = atomicAdd(&rare[0], 1u);
+        if (slot < BINS_APPLY_RARE) rare[1u + slot] = (r << 6) | v;
+        else {
+            (void)__hip_atomic_fetch_or(sl + 2u * r + 1u, 1u << (v - 32u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     };
     const uint32_t F = a.bin_shift + 6u, fmask = (1u << F) - 1u;
-    auto apply_chunk = [&](const uint4 q) {
+    auto for_fields = [&](const uint4 q, auto fn) {
         const uint64_t lo = ((uint64_t)q.y << 32) | q.x, hi = ((uint64_t)q.w << 32) | q.z;
-        apply((uint32_t)lo & fmask); apply((uint32_t)(lo >> F) & fmask); apply((uint32_t)(lo >> (2u * F)) & fmask);
-        apply((uint32_t)hi & fmask); apply((uint32_t)(hi >> F) & fmask); apply((uint32_t)(hi >> (2u * F)) & fmask);
+        fn((uint32_t)lo & fmask); fn((uint32_t)(lo >> F) & fmask); fn((uint32_t)(lo >> (2u * F)) & fmask);
+        fn((uint32_t)hi & fmask); fn((uint32_t)(hi >> F) & fmask); fn((uint32_t)(hi >> (2u * F)) & fmask);
     };
     const uint4 *l4 = reinterpret_cast<const uint4 *>(list);          // (lists start and reservations are whole 16-byte chunks)
     const uint32_t n4 = n >> 2;
@@ -1103,28 +1131,56 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
             const uint32_t at = i + b * blockDim.x;
             q[b] = at < n4 ? l4[at] : make_uint4(~0u, ~0u, ~0u, ~0u);      // (all ones: six times "nothing")
         }
+        // (a wave whose 64 chunks all lie beyond the list skips them: the last round of a list is on average half empty, and its "nothing"
+        // entries are LDS atomics like any other — Q = 8 lost 10 % to them, Q = 2 won 3 %, profiles/r06/bins_ab.txt)
+        const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(i - (threadIdx.x & 63u)));
 #pragma unroll
-        for (uint32_t b = 0; b < Q; ++b) apply_chunk(q[b]);
+        for (uint32_t b = 0; b < Q; ++b)
+            if (wave_first + b * blockDim.x < n4) for_fields(q[b], apply);
+        if constexpr (ALGO == 2) {
+            if (__builtin_expect(rare_seen > 32u, 0)) {
+#pragma unroll
+                for (uint32_t b = 0; b < Q; ++b) for_fields(q[b], apply_rare);
+            }
+            rare_seen = 0;
+        }
     }
     __syncthreads();
-    if (a.spill[(uint64_t)gi * a.bins + bin]) {                           // entries of this bin that found a row or a list full
-        // fold this bin's part of the fallback table in and leave it empty again: the table is wiped once, when it is allocated, not 8 MiB
-        // per genome and call (p = 20; with ONE flag per genome every bin of nearly every genome read its part: some row overflows somewhere)
-        uint32_t *sl = a.slab + (uint64_t)gi * a.slab_words + (uint64_t)bin * words;
-        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) {
-            if constexpr (ALGO == 2) { tab[i] |= sl[i]; sl[i] = 0u; }
-            else { tab[i] = (uint32_t)max((int)tab[i], (int)sl[i]); sl[i] = RANK_EMPTY; }
+    uint32_t n_rare = 0;
+    if constexpr (ALGO == 2) {
+        n_rare = rare[0];
+        if (__builtin_expect(n_rare > BINS_APPLY_RARE, 0)) {              // (workgroup-uniform) this workgroup's own entries in the fallback table: an
+            __threadfence();                                              // agent-scope release — a whole L2 write-back on this chip, hence never
+            __syncthreads();                                              // on the common path
+            n_rare = BINS_APPLY_RARE;
         }
-        __syncthreads();
     }
+    // entries of this bin that found a row or a list full sit in this bin's part of the genome's fallback table: read beside the LDS table and
+    // left empty again — the table is wiped once, when it is allocated, not 8 MiB per genome and call (p = 20; with ONE flag per genome
+    // every bin of nearly every genome read its part: some row overflows somewhere)
+    const bool spilled = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    auto slab_take = [&](uint32_t i, uint32_t empty) {                    // (agent scope: past this CU's vector cache)
+        const uint32_t x = __hip_atomic_load(sl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x != empty) sl[i] = empty;
+        return x;
+    };
     uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)(a.virt0 + gi) * a.partial_stride) + (uint64_t)bin * (regs_per_bin >> 2);
+    uint8_t *const img = a.images ? a.images + (uint64_t)(a.genome0 + gi) * a.image_bytes : nullptr;
+    uint8_t *const img_out = img ? img + a.hdr_bytes + (uint64_t)bin * regs_per_bin : nullptr;
     for (uint32_t i = threadIdx.x; i < (regs_per_bin >> 2); i += blockDim.x) {
+        const uint4 t = reinterpret_cast<const uint4 *>(tab)[i];
+        const uint32_t tv[4] = {t.x, t.y, t.z, t.w};
         uint32_t o = 0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (uint32_t b = 0; b < 4u; ++b) {
             uint32_t r;
             if constexpr (ALGO == 2) {
-                const uint32_t lo = tab[8u * i + 2u * b], hi = tab[8u * i + 2u * b + 1u];
+                uint32_t lo = tv[b], hi = 0u;
+                if (spilled) { lo |= slab_take(8u * i + 2u * b, 0u); hi = slab_take(8u * i + 2u * b + 1u, 0u); }
+                for (uint32_t j = 0; j < n_rare; ++j) {                    // (n_rare is zero but once in 2^32 k-mers)
+                    const uint32_t e = rare[1u + j];
+                    if ((e >> 6) == 4u * i + b) hi |= 1u << ((e & 63u) - 32u);
+                }
                 r = 0;
                 if (lo | hi) {                                             // as finish_item: nlz bitmap -> hash4j prefix -> pack()
                     const uint64_t x = (((uint64_t)hi << 32) | lo) << (a.p - 1);
@@ -1133,11 +1189,14 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
                     r = (top << 2) | below;
                 }
             } else {
-                r = tab[4u * i + b] + 1u;                                  // rho - 1, -1 = empty
+                int m = (int)tv[b];
+                if (spilled) { const int s2 = (int)slab_take(4u * i + b, RANK_EMPTY); m = m > s2 ? m : s2; }
+                r = (uint32_t)m + 1u;                                      // rho - 1, -1 = empty
             }
             o |= (r & 0xFFu) << (8 * b);
         }
-        out[i] = o;
+        if (img_out) store_u32_any(img_out + 4ull * i, o);
+        else out[i] = o;
     }
     if (bin == 0u && threadIdx.x == 0u) {                                  // the genome's k-mer census: the sum over its work items
         const uint32_t g = a.genome0 + gi;
@@ -1147,13 +1206,17 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
         for (uint32_t it = a.genome_item_begin[g]; it < a.genome_item_begin[g + 1]; ++it)
             if ((uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];      // (a slice beyond the surviving bases never ran)
         a.item_kmers[a.virt0 + gi] = tot;
+        if (img) {                                                         // (what finalize_kernel would have done for this genome)
+            if (tot) atomicAdd(a.kmer_counter, (unsigned long long)tot);
+            if (a.hdr_bytes) write_header(img, a.hdr_tpl, 0ull, 1ull << a.p, 0, 0.0, a.p);
+        }
     }
 }
 
 hipError_t launch_bins_apply(const BinApplyArgs &args, uint32_t n_group_genomes, hipStream_t stream)
 {
     if (n_group_genomes == 0) return hipSuccess;
-    const uint32_t words = (args.algo == 2 ? 2u : 1u) << args.bin_shift, lds = words * 4u;
+    const uint32_t words = 1u << args.bin_shift, lds = (words + 1u + BINS_APPLY_RARE) * 4u;   // one word per register + the short list of rare entries
     auto go = [&](auto kern) {
         if (lds > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1190,12 +1253,20 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool variant, bool small_ite
     s.bins = bl > 0 && bl <= 8u && !no_bins && allow_bins;
     s.use_lds = bl == 0 || s.bins;
     if (s.bins) {
+        // registers per bin: bins_apply_kernel holds a 32-bit word per register, 2^15 of them = 128 KiB of LDS (round 6: UltraLogLog too — its bitmap's
+        // high word is the rare entries' short list —, so half as many bins as with 64-bit words: fuller staging rows per flush, fuller chunks)
+        s.bin_shift = 15u;
+        if (algo == 2) {
+            if (bl > 1u) --bl; else s.bin_shift = 14u;
+            if (const char *e = getenv("LASH_BIN_SHIFT")) {                 // A/B knob (read per call): 14 = bins of 2^14 registers as in round 5
+                if (atoi(e) == 14 && s.bin_shift == 15u && bl < 8u) { s.bin_shift = 14u; ++bl; }
+            }
+        }
         s.bins_log2 = bl;
-        s.bin_shift = (algo == 2 ? 14u : 15u);                             // registers per bin: 128 KiB of LDS table in bins_apply_kernel
-        s.bin_sub_shift = bl < 5u ? 5u - bl : 0u;                           // at least 32 staging rows per wave (see BinRegs)
+        s.bin_sub_shift = bl < 5u ? 5u - bl : 0u;                           // at least 32 staging rows per wave (see BinRegs; 64: slower at p = 18 .. 20, profiles/r06/bins_ab.txt)
         const uint32_t mean = 1024u >> (bl + s.bin_sub_shift);              // staged entries per row and word of 16 k-mers per lane
         uint32_t sq = 1; while (sq * sq < mean) ++sq;
-        s.bin_S = ((mean + 4u * sq + 4u + 11u) / 12u) * 12u;                // room for the mean + 4 sigma, a multiple of 12 (six entries per chunk, rows 16-byte aligned); more goes to the fallback table
+        s.bin_S = ((mean + 4u * sq + 4u + 5u) / 6u) * 6u;                  // room for the mean + 4 sigma, a multiple of six (six entries per chunk; rows stay 8-byte aligned for the flush's ds_read_b64); more goes to the fallback table
         s.lds_bytes = 0;                                                    // no table in the sketch kernels
     }
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU
@@ -1232,7 +1303,7 @@ static uint32_t stage_stride_bytes(const SketchPlan &plan, bool direct, bool def
     return std::max(stage, stacks);
 }
 uint32_t sketch_direct_stage_bytes(const SketchPlan &plan) { return (plan.threads / 64u) * stage_stride_bytes(plan, true, true); }
-uint32_t sketch_bin_wave_bytes(const SketchPlan &plan) { return plan.bins ? ((1u << (plan.bins_log2 + plan.bin_sub_shift)) * (1u + plan.bin_S + 4u)) * 4u : 0u; }
+uint32_t sketch_bin_wave_bytes(const SketchPlan &plan) { return plan.bins ? ((1u << (plan.bins_log2 + plan.bin_sub_shift)) * (1u + bin_row_stride(plan.bin_S))) * 4u : 0u; }
 
 template <int ALGO, int KMODE, bool XLOW, int REGS, bool DIRECT>
 static hipError_t launch_one(const SketchPlan &plan, const SketchArgs &args, uint32_t n_items, hipStream_t stream)

@@ -14,6 +14,7 @@
 
 
 // how far the four-word loop of a tile is unrolled (1: one body, the window rotates through register copies)
+constexpr uint32_t BINS_APPLY_RARE = 62;   // bins_apply_kernel: room for the UltraLogLog entries with 32 and more leading zeros of one (genome, bin)
 #ifndef LASH_BINS_APPLY_LOADS
 #define LASH_BINS_APPLY_LOADS 4         // 16-byte loads a lane of bins_apply_kernel has in flight (8, 16: the same or slower)
 #endif
@@ -87,10 +88,14 @@ struct GlobalRegs {                                            // (UltraLogLog p
 // their staging row or their list full go straight into the genome's full-size table in global memory (the rounds 1-3 path: exact,
 // slow, and only met by genomes whose k-mers pile into few buckets — a satellite repeat); bins_apply_kernel folds that table in
 // when the genome's flag is up.
+// words from one staging row to the next: the row's S slots + the spare one (BinRegs::push, mode 1), made ODD — lane l of a flush reads row l, the
+// pushes of a word land at about the same rank in every row: with the round-5 stride S + 4 (64 words at p = 18) all of that met in ONE bank
+// (SQ_LDS_BANK_CONFLICT: 83 % of the LDS pipe's active cycles, profiles/r06/bins_pmc_p18.txt)
+__host__ __device__ constexpr uint32_t bin_row_stride(uint32_t S) { return (S + 1u) | 1u; }
 struct BinRegs {
     static constexpr bool THR = false, BINS = true, BYTES = false, QUEUED = false;
     uint32_t cnt_b, stage_b;      // LDS byte addresses of this wave's row counters [V] and staging rows [V][S]
-    uint32_t S, V, sub_shift;     // slots per row; rows: V = bins << sub_shift (few bins: each has 2^sub_shift rows, a lane uses row
+    uint32_t S, RS, V, sub_shift; // slots per row, words from one row to the next (bin_row_stride); rows: V = bins << sub_shift (few bins: each has 2^sub_shift rows, a lane uses row
     uint32_t sub_lane;            //   lane & (2^sub_shift - 1) of its bin — 64 lanes on 2 counters would be 32-way LDS atomic conflicts)
     uint32_t bin_shift;           // register index >> bin_shift = bin
     uint32_t cap;                 // entries per list
@@ -125,10 +130,10 @@ struct BinRegs {
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (mode == 1u) {
             ovf = ovf > rank ? ovf : rank;
-            *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(stage_b + (row * (S + 4u) + (rank < S ? rank : S)) * 4u) = e;
+            *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(stage_b + (row * RS + (rank < S ? rank : S)) * 4u) = e;
             return;
         }
-        if (__builtin_expect(rank < S, 1)) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(stage_b + (row * (S + 4u) + rank) * 4u) = e;
+        if (__builtin_expect(rank < S, 1)) *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(stage_b + (row * RS + rank) * 4u) = e;
         else spill_entry(e);
     }
     // after a word pushed in mode 1: did a row run full?  (wave-uniform answer; clears the mark)
@@ -196,13 +201,14 @@ struct BinRegs {
             const uint32_t row = g * 64u + lane, n = n_[g], base = base_[g];
             const uint32_t bin = row >> sub_shift;
             uint32_t *dst = lists + (uint64_t)bin * cap;
-            const uint32_t src = stage_b + row * (S + 4u) * 4u;
+            const uint32_t src = stage_b + row * RS * 4u;
             for (uint32_t i = 0, at = base; i < n; i += 6u, at += 4u) {
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                // six staged entries (rows are multiples of six slots long and 8-byte aligned at every sixth: three ds_read_b64)
-                const u32x2 r0 = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(src + i * 4u);
-                const u32x2 r1 = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(src + i * 4u + 8u);
-                const u32x2 r2 = *(__attribute__((address_space(3))) u32x2 *)(uintptr_t)(src + i * 4u + 16u);
+                // six staged entries (rows are multiples of six slots long; their stride is ODD, so only 4-byte aligned: three ds_read2_b32)
+                typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+                const u32x2 r0 = *(__attribute__((address_space(3))) u32x2_a4 *)(uintptr_t)(src + i * 4u);
+                const u32x2 r1 = *(__attribute__((address_space(3))) u32x2_a4 *)(uintptr_t)(src + i * 4u + 8u);
+                const u32x2 r2 = *(__attribute__((address_space(3))) u32x2_a4 *)(uintptr_t)(src + i * 4u + 16u);
                 uint32_t e[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
 #pragma unroll
                 for (uint32_t j = 1; j < 6u; ++j) e[j] = i + j < n ? e[j] : 0xFFFFFFFFu;       // the padding (the row holds older entries there)
@@ -1523,7 +1529,7 @@ __device__ __forceinline__ BinRegs bin_regs_of(const SketchArgs &a, uint32_t gen
     r.sub_lane = lane & ((1u << r.sub_shift) - 1u);
     r.cnt_b = a.bin_lds_off + wave * a.bin_wave_bytes;
     r.stage_b = r.cnt_b + r.V * 4u;
-    r.S = a.bin_S; r.bin_shift = a.bin_shift; r.algo = ALGO;
+    r.S = a.bin_S; r.RS = bin_row_stride(a.bin_S); r.bin_shift = a.bin_shift; r.algo = ALGO;
     r.mode = 0u; r.ovf = 0u;
 
     const uint32_t gi = genome - a.bin_genome0;

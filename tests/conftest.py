@@ -33,7 +33,8 @@ def pytest_collection_modifyitems(config, items):
 
 # GPU test modules whose genomes are (mostly) small enough for the persistent small-genome kernel: every test in them runs on BOTH routes
 # (see tests/routes.py).  The others use genomes above LASH_SOLE_MAX, the dist side, or pin their routes themselves.
-DUAL_ROUTE_MODULES = {"test_gpu_direct", "test_gpu_parity", "test_gpu_cli", "test_gpu_rawfiles", "test_gpu_hll_corner", "test_gpu_layout"}
+DUAL_ROUTE_MODULES = {"test_gpu_direct", "test_gpu_parity", "test_gpu_cli", "test_gpu_rawfiles", "test_gpu_hll_corner", "test_gpu_layout",
+                      "test_gpu_rare_hashes"}
 
 
 def pytest_generate_tests(metafunc):

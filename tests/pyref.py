@@ -37,6 +37,22 @@ def xxh3_64_8b(v, seed):
     return h ^ (h >> 28)
 
 
+def xxh3_64_8b_inverse(h, seed):
+    """The 8-byte value whose xxh3_64 under `seed` is h: every step of the len-4..8 branch is a bijection of 64-bit words (an odd multiplier,
+    an xorshift, x ^ ((x >> 35) + 8), and x ^ rotl(x, 49) ^ rotl(x, 24), whose 64th power is the identity).  Tests use it to BUILD k-mers
+    with hashes one would wait 2^32 k-mers and more for (tests/test_gpu_rare_hashes.py)."""
+    inv = pow(MX2, -1, 1 << 64)
+    h ^= (h >> 28) ^ (h >> 56)
+    h = (h * inv) & M64
+    h ^= ((h >> 35) + 8)                      # (bits 63..35 pass unchanged, and they are all the step reads)
+    h = (h * inv) & M64
+    for _ in range(63):
+        h ^= _rotl(h, 49) ^ _rotl(h, 24)
+    s = _short_seed(seed)
+    keyed = h ^ (((SEC8 ^ SEC16) - s) & M64)
+    return ((keyed >> 32) | ((keyed & 0xFFFFFFFF) << 32)) & M64
+
+
 def xxh3_128_4b(w, seed):
     s = _short_seed(seed)
     bitflip = ((SEC16 ^ SEC24) + s) & M64
