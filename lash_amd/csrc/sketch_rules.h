@@ -158,19 +158,23 @@ struct BinRegs {
         const uint32_t fmask = (1u << F) - 1u;
         // 64 rows and more (64 bins and more, a row per lane): up to four groups of 64 rows; ALL their reservations are issued before the
         // first copy waits for one (p = 22, 256 rows: four returning atomics one after the other per word of 16 k-mers were most of its pass)
+        // 32 rows (p = 18 .. 20): lanes l and l + 32 share row l and copy its even and odd chunks — with a row per lane half the wave sat out
+        // the copy loop, a quarter of the pass's vector instructions
+        const bool twin = V == 32u;
+        const uint32_t half = twin ? lane >> 5 : 0u;
         uint32_t n_[4], base_[4];
 #pragma unroll
         for (uint32_t g = 0; g < 4u; ++g) {
             n_[g] = 0u; base_[g] = 0u;
             if (g * 64u >= V) continue;
-            const uint32_t row = g * 64u + lane;
+            const uint32_t row = twin ? (lane & 31u) : g * 64u + lane;
             uint32_t n = 0;
             if (row < V) {
-                n = *lds(cnt_b + row * 4u);
-                if (n) *lds(cnt_b + row * 4u) = 0u;
+                n = *lds(cnt_b + row * 4u);                                // (both lanes of a twin read in this one instruction, before the reset)
+                if (n && half == 0u) *lds(cnt_b + row * 4u) = 0u;
                 n = n < S ? n : S;                                         // (what went beyond the row has been spilled / redone)
             }
-            const uint32_t n4 = ((n + 5u) / 6u) * 4u, bin = row >> sub_shift;   // words: four per chunk of six entries
+            const uint32_t n4 = half ? 0u : ((n + 5u) / 6u) * 4u, bin = row >> sub_shift;   // words: four per chunk of six entries (reserved by the row's first lane)
             uint32_t base;
 #ifdef LASH_ABL_BINS_NO_ATOMIC  // timing-only diagnostic build: every row lands at the start of its list
             if (true) { base = 0u; (void)bin; } else
@@ -193,16 +197,18 @@ struct BinRegs {
                 bin_base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(gs * 4u), (int)bin_base);
                 base = bin_base + (incl - n4) - before;
             }
+            if (twin) base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane & 31u) * 4u), (int)base);
             n_[g] = n; base_[g] = base;
         }
 #pragma unroll
         for (uint32_t g = 0; g < 4u; ++g) {
             if (g * 64u >= V) continue;
-            const uint32_t row = g * 64u + lane, n = n_[g], base = base_[g];
+            const uint32_t row = twin ? (lane & 31u) : g * 64u + lane, n = n_[g], base = base_[g];
             const uint32_t bin = row >> sub_shift;
             uint32_t *dst = lists + (uint64_t)bin * cap;
             const uint32_t src = stage_b + row * RS * 4u;
-            for (uint32_t i = 0, at = base; i < n; i += 6u, at += 4u) {
+            const uint32_t di = twin ? 12u : 6u, dat = twin ? 8u : 4u;
+            for (uint32_t i = 6u * half, at = base + 4u * half; i < n; i += di, at += dat) {
                 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                 // six staged entries (rows are multiples of six slots long; their stride is ODD, so only 4-byte aligned: three ds_read2_b32)
                 typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
