@@ -61,6 +61,8 @@ def main():
                 algo = os.environ["FUZZ_ALGO"]
             k = rng.choice([rng.randint(1, 32), 16, 21])
             p = rng.randint(4, 14)
+            if os.environ.get("FUZZ_P") and algo != "hmh":           # pin the precision (register tables beyond LDS: tools/bins_fuzz.sh)
+                p = min(rng.choice([int(x) for x in os.environ["FUZZ_P"].split(",")]), 16 if algo == "hll" else 26)
             extra = rng.choice([[], ["--batch-mb", "1"], ["--batch-mb", "1", "--devices", "0,0"], ["--devices", "0,0,0"], ["-t", "2"]])
             out = os.path.join(td, "o")
             r = subprocess.run([H.CLI, "sketch", "-f", lst, "-o", out, "-a", algo, "-k", str(k), "-p", str(p)] + extra, capture_output=True, text=True)

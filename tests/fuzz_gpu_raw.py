@@ -89,6 +89,8 @@ def main():
                 an = os.environ["FUZZ_ALGO"]
             k = rng.choice([rng.randint(1, 32), 16, 21])
             p = 0 if an == "hmh" else rng.randint(4, 14)
+            if os.environ.get("FUZZ_P") and an != "hmh":             # pin the precision (register tables beyond LDS: tools/bins_fuzz.sh)
+                p = min(rng.choice([int(x) for x in os.environ["FUZZ_P"].split(",")]), 16 if an == "hll" else 26)
             files = [fasta_file(rng) if rng.random() < 0.6 else fastq_file(rng) for _ in range(rng.randint(1, 6))]
             files = [f for f in files if f[:1] in (b">", b"@")] or [b">only\nACGT\n"]
             got = ctx.sketch_files_raw(an, k, p, 42, files)
