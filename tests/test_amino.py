@@ -64,7 +64,7 @@ def test_oracle_amino_equals_python_restatement(algo, p):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo,p", [("hmh", 0), ("hll", 12), ("hll", 16), ("ull", 10), ("ull", 16)])
+@pytest.mark.parametrize("algo,p", [("hmh", 0), ("hll", 12), ("hll", 16), ("ull", 10), ("ull", 16), ("ull", 18), ("ull", 21)])   # (18, 21: binned tables)
 def test_gpu_amino_equals_oracle(algo, p):
     import lash_amd
     rng = np.random.default_rng(37)
