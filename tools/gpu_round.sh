@@ -32,6 +32,8 @@ if [ -f build/variants/liblash_stale.so ]; then
         LASH_GFX950_LIB=$S FUZZ_SOLE=1 FUZZ_SOLE_WGS=$4 timeout 900 python3 tests/$1 $2 $(($3 + ${SEED_ADD:-0})) > $OUT/stale_$1_$3.log 2>&1; echo "stale-state build FUZZ_SOLE=1 FUZZ_SOLE_WGS=$4 $1 rc=$? $(tail -1 $OUT/stale_$1_$3.log)"
     done
 fi
+# round 6: the runners pinned to the binned register tables (UltraLogLog p = 18 .. 22: default planning, many genome groups, bins of 2^14 registers)
+SEED_ADD=${SEED_ADD:-0} bash tools/bins_fuzz.sh ${1:-gpu_round}/bins_fuzz
 LASH_TEST_SOLE_EVERYWHERE=1 timeout 1500 python3 -m pytest tests -q -m gpu > $OUT/sole_everywhere.log 2>&1; echo "LASH_TEST_SOLE_EVERYWHERE=1: $(grep -E 'passed|failed' $OUT/sole_everywhere.log | tail -1)"
 python3 tools/dist_rate.py > $OUT/dist_rate.txt 2>&1; cat $OUT/dist_rate.txt
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
