@@ -185,9 +185,9 @@ int probe_dirty(lash_ctx *ctx, lash_packed *pk, hipStream_t stream)
 }
 
 // ---- binned launches (SketchPlan::bins; sketch_kernels.hip "BinRegs") ---------------------------------------------------------
-// Register tables beyond 128 KiB of LDS: the sketch kernels hash every k-mer once and append a 4-byte entry to the list of its bin,
-// bins_apply_kernel builds each bin's registers in LDS and leaves ONE partial per genome ("virtual item" n_items + g) for the
-// ordinary finalize stage.  Lists, counters and fallback tables are sized per genome GROUP (a few GiB at a time; the stream orders
+// Register tables beyond 128 KiB of LDS: the sketch kernels hash every k-mer once and append an entry to the list of its bin,
+// bins_apply_kernel builds each bin's registers in LDS and writes them into the genome's image (UltraLogLog, not accumulating) or leaves
+// ONE partial per genome ("virtual item" n_items + g) for the ordinary finalize stage.  Lists, counters and fallback tables are sized per genome GROUP (a few GiB at a time; the stream orders
 // the groups, so the buffers are reused), from an upper bound of the entries each genome's work items push.
 // HBM one group of a binned launch (or one chunk of per-item global tables) may take.  LASH_BINS_MB (read per call), else a twelfth of the
 // device's memory but no more than 24 GiB nor a third of what was free when the context first asked (round 6; 6 GiB before: 1 000 x 5 Mbp at

@@ -1062,8 +1062,9 @@ __global__ void __launch_bounds__(1024) finalize_kernel(FinalizeArgs a)
 
 // ------------------------------------------------------------------------------------------------------------
 // bins_apply_kernel — one workgroup per (genome, bin) of a binned launch: the bin's registers are built in LDS from the bin's
-// list (4 bytes per k-mer, read once, coalesced), the genome's fallback table is folded in if anything was spilled there, and the
-// registers leave as image-format bytes into the genome's one partial sketch; finalize_kernel does the rest as for any genome.
+// list (six 21-bit entries per 16-byte chunk, read once, coalesced), the genome's fallback table is read beside it if anything was spilled
+// there, and the registers leave as image-format bytes — UltraLogLog, not accumulating: straight into the caller's image (header and k-mer
+// census too, no finalize launch); otherwise into the genome's one partial sketch, and finalize_kernel does the rest as for any genome.
 // ------------------------------------------------------------------------------------------------------------
 template <int ALGO>
 __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
@@ -1072,8 +1073,7 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
     const uint32_t bin = blockIdx.x, gi = blockIdx.y;
     // ONE 32-bit word per register.  HyperLogLog: rho - 1 under max.  UltraLogLog: the nlz bitmap's low word — an entry with 32 or more leading
     // zeros (2^-32 of the k-mers) waits in a short list beside the table and is merged when the registers are written out
-    // (round 6: the 64-bit bitmaps took 128 KiB for a bin of 2^14 registers = ONE workgroup per CU, whose clear / load / update / write-out phases
-    // nothing overlapped; at 64 KiB two workgroups share a CU)
+    // (round 6: with 64-bit bitmaps a bin was 2^14 registers; at a word each it is 2^15 — half as many bins for the sketch kernels to scatter over)
     const uint32_t regs_per_bin = 1u << a.bin_shift, words = regs_per_bin, slab_words_bin = ALGO == 2 ? 2u * regs_per_bin : regs_per_bin;
     uint32_t *const rare = tab + words;                                   // [0]: how many, [1 ..]: the entries (BINS_APPLY_RARE of them)
     {

@@ -78,10 +78,12 @@ struct GlobalRegs {                                            // (UltraLogLog p
 
 // A register table larger than 128 KiB of LDS (HyperLogLog p = 16; UltraLogLog p = 15 .. 22) is not updated by the sketch kernels
 // at all (round 4; rounds 1-3 hashed every k-mer once per 128 KiB part of the table, 2 .. 16 times, and from p = 19 fell back to
-// one L2 atomic per k-mer: 1.7e10 k-mers/s).  Every k-mer is hashed ONCE and leaves a 4-byte entry, register index << 6 | value
-// (HyperLogLog: rho - 1; UltraLogLog: nlz; 63 = nothing), in the list of its BIN — the genome's registers cut into bins of 2^14
-// (ULL) / 2^15 (HLL) of them, one LDS table's worth.  bins_apply_kernel then reads each list once and builds its bin's registers in
-// LDS.  HBM: 4 bytes written + 4 read per k-mer beside the 1 byte of input; no atomics in the data path.
+// one L2 atomic per k-mer: 1.7e10 k-mers/s).  Every k-mer is hashed ONCE and leaves an entry, register index << 6 | value
+// (HyperLogLog: rho - 1; UltraLogLog: nlz; 63 = nothing), in the list of its BIN — the genome's registers cut into bins of 2^15
+// of them, one LDS table's worth of 32-bit words (round 6; before: 2^14 for UltraLogLog's 64-bit bitmaps).  bins_apply_kernel then reads each
+// list once and builds its bin's registers in LDS.  In the lists only the bits an entry does not share with its bin travel: six 21-bit
+// fields per 16-byte chunk.  HBM: ~3 - 6 bytes written + as many read per k-mer beside the 1 byte of input (profiles/r06/large_tables/);
+// no atomics in the data path.
 //   The scatter is staged per WAVE: push() takes a slot in the wave's LDS area of its bin (returning ds_add on the bin's counter),
 // and after each word of 16 k-mers per lane the wave reserves room in the bins' lists (one returning global atomic per bin holding
 // entries, issued by 64 lanes at once) and copies the staged entries out, a bin at a time, lanes side by side.  Entries that find
@@ -90,7 +92,7 @@ struct GlobalRegs {                                            // (UltraLogLog p
 // when the genome's flag is up.
 // words from one staging row to the next: the row's S slots + the spare one (BinRegs::push, mode 1), made ODD — lane l of a flush reads row l, the
 // pushes of a word land at about the same rank in every row: with the round-5 stride S + 4 (64 words at p = 18) all of that met in ONE bank
-// (SQ_LDS_BANK_CONFLICT: 83 % of the LDS pipe's active cycles, profiles/r06/bins_pmc_p18.txt)
+// (SQ_LDS_BANK_CONFLICT: 83 % of the LDS pipe's active cycles, profiles/r06/bins_ab.txt section 6)
 __host__ __device__ constexpr uint32_t bin_row_stride(uint32_t S) { return (S + 1u) | 1u; }
 struct BinRegs {
     static constexpr bool THR = false, BINS = true, BYTES = false, QUEUED = false;
