@@ -88,7 +88,7 @@ struct BinApplyArgs {
     uint32_t *spill;                // one flag per (genome, bin): its part of the fallback table holds something
     uint32_t *slab;                 // (a bin's part is read beside the LDS table and wiped when its flag is up)
     const BinGenome *genomes;
-    uint8_t  *partials;           // the group's genomes' "virtual" partials: genome gi of the group at partials + (virt0 + gi) * partial_stride
+    uint8_t  *partials;           // one partial per GENOME of the call: genome gi of the group at partials + (genome0 + gi) * partial_stride
     uint32_t *item_kmers;         // ... and its k-mer count at item_kmers[virt0 + gi] = the sum over its real items
     const uint32_t *genome_item_begin;   // real items of genome g: [genome_item_begin[g], genome_item_begin[g + 1])
     const WorkItem *items;               // ... of which those that begin beyond the genome's surviving bases never ran (as in finalize_kernel)

@@ -274,6 +274,14 @@ static int bins_prepare(lash_ctx *ctx, const SketchPlan &plan, const std::vector
 }
 // UltraLogLog, not accumulating: bins_apply_kernel writes the images itself and the call queues no finalize launch (BinApplyArgs::images)
 static bool bins_write_images(const lash_params *prm) { return prm->algo == LASH_ULL && !(prm->flags & LASH_F_ACCUMULATE); }
+// partial sketches a call needs room for: one per work item — but the items of a binned launch leave entries, not partials: one per GENOME then
+// (bins_apply_kernel's, for finalize_kernel), or none when it writes the images itself (round 6: a slot per item was 4 MiB x 3 000 items at
+// p = 22 for 1 000 genomes, never touched — and out of memory at p = 23)
+static size_t bins_partials(const SketchPlan &plan, const lash_params *prm, size_t n_items, size_t n_genomes)
+{
+    if (!plan.bins) return n_items + 1;
+    return bins_write_images(prm) ? 1 : n_genomes + 1;
+}
 // the launches of one call, group by group: launch(sa, first item, items) queues the sketch kernels of an item range
 template <class Launch>
 static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *prm, SketchArgs sa, const BinsRun &br, const std::vector<uint32_t> &item_begin,
@@ -311,7 +319,7 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
         ba.lists = sa.bin_lists; ba.cnt = br.d_cnt; ba.slab = sa.bin_slab; ba.spill = br.d_spill; ba.genomes = sa.bin_genomes;
         ba.partials = sa.partials; ba.item_kmers = sa.item_kmers; ba.genome_item_begin = d_item_begin;
         ba.items = sa.items; ba.nvalid = sa.nvalid; ba.k = prm->k;
-        ba.partial_stride = sa.partial_stride; ba.virt0 = n_items + g0; ba.genome0 = g0;
+        ba.partial_stride = sa.partial_stride; ba.virt0 = n_items + g0; ba.genome0 = g0;      // (k-mer count at item_kmers[virt0 + gi], partial sketch at partials[genome0 + gi])
         ba.bins = B; ba.bin_shift = plan.bin_shift; ba.slab_words = br.slab_words; ba.algo = prm->algo; ba.p = prm->p;
         if (to_images) {
             ba.images = sa.images; ba.image_bytes = sa.image_bytes; ba.hdr_tpl = sa.lay.hdr_tpl; ba.hdr_bytes = sa.lay.hdr_bytes;
@@ -708,8 +716,8 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     TRACE("sketch: planned");
 
     int rc;
-    const size_t n_virtual = plan.bins ? n_genomes : 0;               // binned launches: one partial per genome behind the items'
-    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + n_virtual + 1) * plan.partial_stride))) return rc;
+    const size_t n_virtual = plan.bins ? n_genomes : 0;               // binned launches: one k-mer count per genome behind the items'
+    if ((rc = reserve(ctx, ctx->partials, bins_partials(plan, prm, n_items, n_genomes) * plan.partial_stride))) return rc;
     if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + n_virtual + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
     BinsRun bins_run_state;
@@ -903,8 +911,7 @@ int sketch_from(lash_ctx *ctx, const lash_params *prm, const lash_packed *pk, ui
     fa.genome_item_begin = d_item_begin;
     fa.nvalid = pk->d_nvalid;
     fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
-    if (plan.bins) {                                               // one partial per genome, written by bins_apply_kernel behind the items'
-        fa.partials += (size_t)n_items * plan.partial_stride;
+    if (plan.bins) {                                               // one partial per genome (bins_apply_kernel), its k-mer count behind the items'
         fa.item_kmers += n_items;
         fa.items = bins_run_state.d_vitems;
         fa.genome_item_begin = bins_run_state.d_vbegin;
@@ -994,7 +1001,7 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     item_begin[n_genomes] = (uint32_t)items.size();
     const uint32_t n_items = (uint32_t)items.size();
     const size_t n_virtual = plan.bins ? n_genomes : 0;
-    if ((rc = reserve(ctx, ctx->partials, (size_t)(n_items + n_virtual + 1) * plan.partial_stride))) return rc;
+    if ((rc = reserve(ctx, ctx->partials, bins_partials(plan, prm, n_items, n_genomes) * plan.partial_stride))) return rc;
     if ((rc = reserve(ctx, ctx->item_kmers, (size_t)(n_items + n_virtual + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->counter, 256))) return rc;
     BinsRun bins_run_state;
@@ -1066,7 +1073,6 @@ int sketch_aa(lash_ctx *ctx, const lash_params *prm, const uint8_t *d_seq, const
     fa.nvalid = nullptr;                                           // every item is live
     fa.item_kmers = static_cast<const uint32_t *>(ctx->item_kmers.ptr);
     if (plan.bins) {
-        fa.partials += (size_t)n_items * plan.partial_stride;
         fa.item_kmers += n_items;
         fa.items = bins_run_state.d_vitems;
         fa.genome_item_begin = bins_run_state.d_vbegin;

@@ -1164,7 +1164,7 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
         if (x != empty) sl[i] = empty;
         return x;
     };
-    uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)(a.virt0 + gi) * a.partial_stride) + (uint64_t)bin * (regs_per_bin >> 2);
+    uint32_t *out = reinterpret_cast<uint32_t *>(a.partials + (uint64_t)(a.genome0 + gi) * a.partial_stride) + (uint64_t)bin * (regs_per_bin >> 2);
     uint8_t *const img = a.images ? a.images + (uint64_t)(a.genome0 + gi) * a.image_bytes : nullptr;
     uint8_t *const img_out = img ? img + a.hdr_bytes + (uint64_t)bin * regs_per_bin : nullptr;
     for (uint32_t i = threadIdx.x; i < (regs_per_bin >> 2); i += blockDim.x) {
@@ -1241,8 +1241,8 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool variant, bool small_ite
     s.partial_stride = (s.partial_bytes + 15u) & ~15u;
     s.lds_bytes = s.nreg32 * 4u;
     s.parts_log2 = 0;
-    // tables beyond 128 KiB: binned (BinRegs; up to 256 bins of 128 KiB: HLL p = 16, ULL p = 15 .. 22), beyond that a table in global
-    // memory per work item and one atomic per k-mer (ULL p >= 23)
+    // tables beyond 128 KiB: binned (BinRegs; up to 256 bins: HLL p = 16, ULL p = 15 .. 23), beyond that a table in global
+    // memory per work item and one atomic per k-mer (ULL p >= 24)
     uint32_t bl = 0;
     while ((s.lds_bytes >> bl) > 128u * 1024u) ++bl;
     const bool no_bins = getenv("LASH_NO_BINS") != nullptr;                // A/B knob (read per call): the global-atomic path for every large table
@@ -1250,18 +1250,19 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool variant, bool small_ite
     // up to 128 KiB of BYTE registers (hll p = 16, ull p = 15 .. 17): one pass, compare-and-swap updates (LdsByteRegs); binning pays from 8 bins on
     s.bytes = bl > 0 && (1u << p) <= 128u * 1024u && algo != 0 && !no_bytes;
     if (s.bytes) { bl = 0; s.nreg32 = (1u << p) >> 2; s.lds_bytes = s.nreg32 * 4u; }
+    // bins of 2^15 registers: bins_apply_kernel holds a 32-bit word per register, 128 KiB of LDS (round 6: UltraLogLog too — its bitmap's high word is
+    // the rare entries' short list —, so half as many bins as with 64-bit words: fuller staging rows per flush, fuller chunks; and p = 23 fits 256 bins)
+    uint32_t bin_shift = 15u;
+    if (algo == 2 && bl > 0) {
+        if (bl > 1u) --bl; else bin_shift = 14u;
+        if (const char *e = getenv("LASH_BIN_SHIFT")) {                     // A/B knob (read per call): 14 = bins of 2^14 registers as in round 5
+            if (atoi(e) == 14 && bin_shift == 15u) { bin_shift = 14u; ++bl; }
+        }
+    }
     s.bins = bl > 0 && bl <= 8u && !no_bins && allow_bins;
     s.use_lds = bl == 0 || s.bins;
     if (s.bins) {
-        // registers per bin: bins_apply_kernel holds a 32-bit word per register, 2^15 of them = 128 KiB of LDS (round 6: UltraLogLog too — its bitmap's
-        // high word is the rare entries' short list —, so half as many bins as with 64-bit words: fuller staging rows per flush, fuller chunks)
-        s.bin_shift = 15u;
-        if (algo == 2) {
-            if (bl > 1u) --bl; else s.bin_shift = 14u;
-            if (const char *e = getenv("LASH_BIN_SHIFT")) {                 // A/B knob (read per call): 14 = bins of 2^14 registers as in round 5
-                if (atoi(e) == 14 && s.bin_shift == 15u && bl < 8u) { s.bin_shift = 14u; ++bl; }
-            }
-        }
+        s.bin_shift = bin_shift;
         s.bins_log2 = bl;
         s.bin_sub_shift = bl < 5u ? 5u - bl : 0u;                           // at least 32 staging rows per wave (see BinRegs; 64: slower at p = 18 .. 20, profiles/r06/bins_ab.txt)
         const uint32_t mean = 1024u >> (bl + s.bin_sub_shift);              // staged entries per row and word of 16 k-mers per lane

@@ -91,7 +91,7 @@ def _genomes(kms, rng):
 
 
 @pytest.mark.parametrize("k", [32, 31, 28])
-@pytest.mark.parametrize("p", [10, 12, 14, 16, 17, 18, 20, 22, 24])
+@pytest.mark.parametrize("p", [10, 12, 14, 16, 17, 18, 20, 22, 23, 24])
 def test_ultraloglog_kmers_with_32_and_more_leading_zeros(ctx, p, k):
     import lash_amd
     rng = random.Random(zlib.crc32(repr(("ull", p, k)).encode()))
@@ -122,7 +122,7 @@ def test_ultraloglog_kmers_with_32_and_more_leading_zeros(ctx, p, k):
     assert np.array_equal(got, want), "ull p=%d k=%d pack-first: %d bytes differ" % (p, k, int((got != want).sum()))
 
 
-@pytest.mark.parametrize("p", [18, 20, 22])
+@pytest.mark.parametrize("p", [18, 20, 22, 23])
 def test_more_rare_entries_in_one_bin_than_its_short_list_holds(ctx, p):
     """bins_apply_kernel keeps the entries with nlz >= 32 of one (genome, bin) in a list of 62 beside its table; the 63rd and later go to the
     genome's fallback table in global memory (and the workgroup then pays an agent-scope fence).  Hashed input never gets there; 150 built k-mers
