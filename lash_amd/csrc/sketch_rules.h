@@ -107,8 +107,8 @@ struct BinRegs {
     // mode (wave-uniform): 0 = careful — an entry that finds its row full is applied to the fallback table there and then (junction
     // walks, dense tiles: lanes push one at a time); 1 = the hot loops' form — no branch between the 16 pushes of a word (with one, each
     // push waits for its own returning LDS atomic: 16 round trips per word): a full row's entries land in the row's spare slot, `ovf`
-    // remembers it, and the caller runs the word again in mode 2; 2 = every entry straight to the fallback table (max / OR are
-    // idempotent: what was staged the first time does no harm)
+    // remembers it, and the caller runs the word again in mode 2; 2 = the entries of the rows that ran full straight to the fallback table
+    // (max / OR are idempotent: what was staged the first time does no harm)
     uint32_t mode;
     mutable uint32_t ovf;
     // exact, slow: one global atomic.  (Static, everything by value: a member function that is not inlined takes `this`, the struct
@@ -127,7 +127,14 @@ struct BinRegs {
     __device__ __forceinline__ void push(uint32_t idx, uint32_t v) const
     {
         const uint32_t row = ((idx >> bin_shift) << sub_shift) | sub_lane, e = (idx << 6) | (v & 63u);
-        if (mode == 2u) { spill_entry(e); return; }
+        if (mode == 2u) {
+            // the word's second run: only the rows that ran full the first time (their counters still say so: flush has not reset them) lost
+            // entries — and only THEIR bins get the "look in the fallback table" flag.  (Round 6: every entry of the word went there, 1 024
+            // global atomics and a flag on EVERY bin of the genome for one full row — at p = 22 about half of all bins were flagged, and
+            // bins_apply_kernel read and wiped 256 KiB of fallback table for each: profiles/r06/bins_ab.txt section 8)
+            if (*(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(cnt_b + row * 4u) > S) spill_entry(e);
+            return;
+        }
         const uint32_t rank = __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(uintptr_t)(cnt_b + row * 4u), 1u,
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (mode == 1u) {
