@@ -57,6 +57,7 @@ struct SketchArgs {
     uint32_t         *bin_spill;  // [genomes of the group][bins] set when that bin's part of the genome's fallback table holds something
     const BinGenome  *bin_genomes;   // [genomes of the group]
     uint32_t          bins, bin_shift, bin_S, bin_sub_shift;
+    uint32_t          bin_flush_words;              // the word loop empties the staging rows after every 1 / 2 / 4 words of 16 k-mers per lane
     uint32_t          bin_lds_off, bin_wave_bytes;   // LDS: the waves' counter + staging areas
     uint32_t          bin_slab_words;
     uint32_t          bin_genome0;                  // first genome of the group
@@ -79,7 +80,7 @@ struct SketchPlan {
     // one LDS pass per bin (BinRegs / bins_apply_kernel).  use_lds stays true (no per-item global table), lds_bytes holds no table.
     bool     bins = false;
     bool     bytes = false;       // byte registers in LDS with compare-and-swap updates (LdsByteRegs): hll p = 16, ull p = 15 .. 17
-    uint32_t bins_log2 = 0, bin_shift = 0, bin_S = 0, bin_sub_shift = 0;
+    uint32_t bins_log2 = 0, bin_shift = 0, bin_S = 0, bin_sub_shift = 0, bin_flush_words = 1;
 };
 // per wave: bytes of LDS a binned launch needs for its bin counters and staging rows
 uint32_t sketch_bin_wave_bytes(const SketchPlan &plan);

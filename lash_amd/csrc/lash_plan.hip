@@ -293,7 +293,7 @@ static int bins_run(lash_ctx *ctx, const SketchPlan &plan, const lash_params *pr
     sa.bin_cnt = br.d_cnt;
     sa.bin_slab = static_cast<uint32_t *>(ctx->bins_slab.ptr);
     sa.bin_spill = br.d_spill;
-    sa.bins = B; sa.bin_shift = plan.bin_shift; sa.bin_S = plan.bin_S; sa.bin_sub_shift = plan.bin_sub_shift; sa.bin_slab_words = br.slab_words;
+    sa.bins = B; sa.bin_shift = plan.bin_shift; sa.bin_S = plan.bin_S; sa.bin_sub_shift = plan.bin_sub_shift; sa.bin_flush_words = plan.bin_flush_words; sa.bin_slab_words = br.slab_words;
     sa.item_order = nullptr;
     // the fallback tables: empty at rest (bins_apply_kernel wipes what it folds in); wiped here only when new, or last left by the other sketch type
     {

@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(1024) LASH_SKETCH_WAVES_PER_EU_ATTR sketch_ker
                     (void)process_word<ALGO, KMODE, XLOW, true, false>(regs, kp, c0, c1, c2, r0, r1, r2, kvw);
                     regs.mode = 1u;
                 }
-                regs.flush(lane);                                              // this word's 1 024 entries leave the wave's staging rows
+                if ((((uint32_t)wi + 1u) & (a.bin_flush_words - 1u)) == 0u) regs.flush(lane);   // the staged entries leave the wave's rows (every word, or every 2nd / 4th)
             }
             // rotate the window by one word
             c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5; c5 = 0;
@@ -1265,9 +1265,18 @@ SketchPlan make_sketch_plan(int algo, int k, int p, bool variant, bool small_ite
         s.bin_shift = bin_shift;
         s.bins_log2 = bl;
         s.bin_sub_shift = bl < 5u ? 5u - bl : 0u;                           // at least 32 staging rows per wave (see BinRegs; 64: slower at p = 18 .. 20, profiles/r06/bins_ab.txt)
-        const uint32_t mean = 1024u >> (bl + s.bin_sub_shift);              // staged entries per row and word of 16 k-mers per lane
-        uint32_t sq = 1; while (sq * sq < mean) ++sq;
-        s.bin_S = ((mean + 4u * sq + 4u + 5u) / 6u) * 6u;                  // room for the mean + 4 sigma, a multiple of six (six entries per chunk; rows stay 8-byte aligned for the flush's ds_read_b64); more goes to the fallback table
+        // 64 bins (p = 21) and 256 (p = 23): a row collects TWO words' entries before it leaves — fuller chunks, half as many list reservations and
+        // partial cache lines: -5 % and -19 % (profiles/r06/bins_ab.txt section 10).  Not at 128 bins: the rows of p = 22 would then take a CU's LDS with
+        // eight waves instead of twelve (+12 %); not below 64 bins: rows are full enough (+9 % at p = 20).  (A/B knob LASH_BIN_FLUSH = 1 / 2 / 4)
+        s.bin_flush_words = (bl == 6u || bl == 8u) ? 2u : 1u;
+        if (const char *e = getenv("LASH_BIN_FLUSH")) { const int f = atoi(e); if (f == 1 || f == 2 || f == 4) s.bin_flush_words = (uint32_t)f; }
+        for (;; s.bin_flush_words >>= 1) {
+            const uint32_t mean = (1024u * s.bin_flush_words) >> (bl + s.bin_sub_shift);   // staged entries per row between two flushes (a word = 16 k-mers per lane)
+            uint32_t sq = 1; while (sq * sq < mean) ++sq;
+            s.bin_S = ((mean + 4u * sq + 4u + 5u) / 6u) * 6u;              // room for the mean + 4 sigma, a multiple of six (six entries per chunk); more goes to the fallback table
+            const uint32_t wave_bytes = ((1u << (bl + s.bin_sub_shift)) * (1u + bin_row_stride(s.bin_S))) * 4u;
+            if (s.bin_flush_words == 1u || wave_bytes <= (bl >= 6u ? 39u : 19u) * 1024u) break;   // (a workgroup's four / eight waves of rows must fit a CU's LDS)
+        }
         s.lds_bytes = 0;                                                    // no table in the sketch kernels
     }
     s.threads = (s.use_lds && s.lds_bytes > 64u * 1024u) ? 1024u : 512u;  // <=64 KiB: two workgroups per CU
