@@ -1202,12 +1202,12 @@ __global__ void __launch_bounds__(1024) bins_apply_kernel(BinApplyArgs a)
         const uint32_t g = a.genome0 + gi;
         uint64_t nk = ~0ull;
         if (a.nvalid) { const uint64_t L = a.nvalid[g]; nk = L >= (uint64_t)a.k ? L - (uint64_t)a.k + 1 : 0; }
-        uint32_t tot = 0;
+        unsigned long long tot = 0;                                        // (a genome beyond 2^32 k-mers: only this statistic would notice)
         for (uint32_t it = a.genome_item_begin[g]; it < a.genome_item_begin[g + 1]; ++it)
             if ((uint64_t)a.items[it].word_begin * 16 < nk) tot += a.item_kmers[it];      // (a slice beyond the surviving bases never ran)
-        a.item_kmers[a.virt0 + gi] = tot;
+        a.item_kmers[a.virt0 + gi] = (uint32_t)tot;
         if (img) {                                                         // (what finalize_kernel would have done for this genome)
-            if (tot) atomicAdd(a.kmer_counter, (unsigned long long)tot);
+            if (tot) atomicAdd(a.kmer_counter, tot);
             if (a.hdr_bytes) write_header(img, a.hdr_tpl, 0ull, 1ull << a.p, 0, 0.0, a.p);
         }
     }
