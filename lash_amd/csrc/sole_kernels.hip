@@ -74,26 +74,32 @@ __device__ __forceinline__ void sole_flush(const SoleArgs &a, uint32_t g, uint32
     uint8_t *regs_out = img + HDR;
     uint32_t *hist = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)hist_b;
     HllTally tally;
+    // HyperMinHash registers in image byte order (layout.hmh_reg_be): ONE byte permute per word with a selector from the layout — the
+    // shift / shift / permute / select form cost 16 of the flush loop's 69 instructions for a switch that is off by default
+    const uint32_t order_sel = (ALGO == 0 && a.lay.hmh_reg_be) ? 0x02030001u : 0x03020100u;
+    auto img_order = [&](uint32_t v) { return ALGO == 0 ? __builtin_amdgcn_perm(v, v, order_sel) : v; };
     auto emit = [&](uint32_t i16, uint4 v) {                 // 16 image bytes at regs_out + 16 * i16
         uint8_t *dst = regs_out + 16ull * i16;
         if (a.accumulate) {
             const uint4 old = load16_any(dst);
-            const uint32_t be = ALGO == 0 ? a.lay.hmh_reg_be : 0u;
-            v.x = merge_word<ALGO>(hmh_img_order(old.x, be), v.x); v.y = merge_word<ALGO>(hmh_img_order(old.y, be), v.y);
-            v.z = merge_word<ALGO>(hmh_img_order(old.z, be), v.z); v.w = merge_word<ALGO>(hmh_img_order(old.w, be), v.w);
+            v.x = merge_word<ALGO>(img_order(old.x), v.x); v.y = merge_word<ALGO>(img_order(old.y), v.y);
+            v.z = merge_word<ALGO>(img_order(old.z), v.z); v.w = merge_word<ALGO>(img_order(old.w), v.w);
         }
         if constexpr (ALGO == 1) { tally.add(hist, v.x); tally.add(hist, v.y); tally.add(hist, v.z); tally.add(hist, v.w); }
-        if constexpr (ALGO == 0) {
-            const uint32_t be = a.lay.hmh_reg_be;
-            v.x = hmh_img_order(v.x, be); v.y = hmh_img_order(v.y, be); v.z = hmh_img_order(v.z, be); v.w = hmh_img_order(v.w, be);
-        }
+        if constexpr (ALGO == 0) { v.x = img_order(v.x); v.y = img_order(v.y); v.z = img_order(v.z); v.w = img_order(v.w); }
         store16_any(dst, v);
     };
     if constexpr (ALGO == 0) {
-        // table word = (lz - 1) << 10 | sig under a signed maximum, -1 = empty  ->  register lz << 10 | sig, 0
+        // table word = (lz - 1) << 10 | sig under a signed maximum, -1 = empty  ->  register lz << 10 | sig, 0.  Two registers at a time in packed
+        // 16-bit arithmetic (round 6: a 10 kbp genome spends a quarter of its instructions in this loop): the words' low halves side by side
+        // (empty = 0xFFFF, real ones <= 50 << 10 | 0x3FF), t = w + 1 (empty -> 0), then t + 0x3FF * min(t, 1) = w + 0x400, or 0
         auto reg2 = [](uint32_t lo, uint32_t hi) {
-            const uint32_t l = (int32_t)lo < 0 ? 0u : lo + 0x400u, h = (int32_t)hi < 0 ? 0u : hi + 0x400u;
-            return l | (h << 16);
+            uint32_t w = __builtin_amdgcn_perm(hi, lo, 0x05040100u), t, u, r;
+            const uint32_t one = 0x00010001u, k3ff = 0x03FF03FFu;
+            asm("v_pk_add_u16 %0, %1, %2" : "=v"(t) : "v"(w), "s"(one));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(u) : "v"(t), "s"(one));
+            asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(u), "s"(k3ff), "v"(t));
+            return r;
         };
         for (uint32_t i = tid; i < HMH_M / 8u; i += T) {
             const uint4 t0 = lds_load4(32u * i), t1 = lds_load4(32u * i + 16u);
