@@ -890,8 +890,9 @@ template <int ALGO>
 __device__ __forceinline__ uint32_t merge_word(uint32_t a, uint32_t b)
 {
     if constexpr (ALGO == 0) {
-        const uint32_t al = a & 0xFFFFu, ah = a >> 16, bl = b & 0xFFFFu, bh = b >> 16;
-        return (al > bl ? al : bl) | ((ah > bh ? ah : bh) << 16);
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));   // two u16 registers per word: one packed maximum (v_pk_max_u16; the
+        const u16x2 m = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));   // mask / compare form: two SDWA maxima and a shift-or)
+        return __builtin_bit_cast(uint32_t, m);
     } else {
         uint32_t o = 0;
 #pragma unroll
