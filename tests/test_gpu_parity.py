@@ -157,7 +157,7 @@ def test_short_reads_fastq_like(ctx):
                                     ("ull", 21, 18), ("ull", 9, 19), ("ull", 16, 20), ("ull", 30, 21), ("ull", 16, 22), ("ull", 16, 23), ("ull", 21, 24)])
 def test_register_tables_larger_than_lds(ctx, an, k, p):
     """2^p registers beyond 128 KiB of LDS as 32-bit words.  Round 4: hll p=16 and ull p=15..17 keep them as BYTES (one pass, updates
-    behind a filter: LdsByteQRegs); ull p=18..23 are BINNED — every k-mer hashed once, a 4-byte entry appended to the list of its bin
+    behind a filter: LdsByteQRegs); ull p=18..23 are BINNED — every k-mer hashed once, an entry appended to the list of its bin
     (2^15 registers), one LDS pass per bin (bins_apply_kernel); ull p >= 24 keeps its table in HBM/L2 and takes one global atomic per k-mer.  Multi-record, multi-slice, dirty and empty genomes, through the direct route and the
     pack-first route."""
     import lash_amd
@@ -203,7 +203,7 @@ def test_byte_tables_behind_their_filter_on_reads(ctx, an, k, p):
 def test_large_tables_on_repeats_take_the_fallback_paths(ctx, an, k, p):
     """Binned tables (ull p >= 18) stage entries in per-bin rows and append them to per-bin lists sized for hashed — i.e. spread — k-mers.
     A satellite-like genome puts millions of identical k-mers into a handful of buckets: rows overflow (the word is re-run straight into
-    the fallback table) and lists overflow (the rest is spilled there, bins_apply_kernel folds it in).  Byte tables (hll p = 16, ull
+    the fallback table) and lists overflow (the rest is spilled there, bins_apply_kernel reads it beside its table).  Byte tables (hll p = 16, ull
     p = 16) see the same input as compare-and-swap contention on few words.  All of it must still be the oracle's image."""
     import lash_amd
     rnd = O.synth_genome(77, 400_000).tobytes()

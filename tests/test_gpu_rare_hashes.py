@@ -126,14 +126,14 @@ def test_ultraloglog_kmers_with_32_and_more_leading_zeros(ctx, p, k):
 def test_more_rare_entries_in_one_bin_than_its_short_list_holds(ctx, p):
     """bins_apply_kernel keeps the entries with nlz >= 32 of one (genome, bin) in a list of 62 beside its table; the 63rd and later go to the
     genome's fallback table in global memory (and the workgroup then pays an agent-scope fence).  Hashed input never gets there; 150 built k-mers
-    in one bin of 2^14 registers do — some sharing a register with each other and with the list's entries."""
+    in one quarter of the table's first 2^16 registers (one bin, whichever size bins have) do — some sharing a register with each other and with the list's entries."""
     import lash_amd
     k = 32
     rng = random.Random(p)
     q = 64 - p
     kms, held = [], {}
     for i in range(150):
-        idx = (3 << 14) | rng.choice((rng.randrange(1 << 14), 7, 8, (1 << 14) - 1))       # bin 3
+        idx = (3 << 14) | rng.choice((rng.randrange(1 << 14), 7, 8, (1 << 14) - 1))       # bin 3 of 2^14 registers = the upper half of bin 1 of 2^15
         nlz = rng.choice((31, 32, 33, 34, 35))
         km, h = _kmer_with_hash(_ull_hash(p, idx, nlz, k), k, rng)
         assert h >> q == idx
